@@ -1,0 +1,33 @@
+"""pytest configuration: the ``gpu`` marker and shared fixture helpers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def rel_err(a, b):
+    """The parity metric of BASELINE.md section 3: max|a-b| / max|b| per array."""
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    den = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
