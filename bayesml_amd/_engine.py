@@ -1,0 +1,225 @@
+"""ctypes binding of ``libgmmvb.so`` (C ABI in ``include/gmmvb.h``) over PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every N-sized computation
+is done by the hand-written gfx950 kernels behind the C ABI.  There is NO CPU fallback: if the
+shared library or a GPU is missing, construction raises ``EngineUnavailableError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgmmvb.so")
+
+GMMVB_F32, GMMVB_F64 = 0, 1
+_STATUS = {0: "GMMVB_OK", 1: "GMMVB_EINVAL", 2: "GMMVB_EUNSUPPORTED", 3: "GMMVB_EHIP", 4: "GMMVB_ENOMEM",
+           5: "GMMVB_ESTATE"}
+
+# every symbol include/gmmvb.h declares: name -> (restype, argtypes)
+_vp, _i64, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+SYMBOLS = {
+    "gmmvb_abi_version": (_int, []),
+    "gmmvb_last_error": (ctypes.c_char_p, []),
+    "gmmvb_stats_len": (_i64, [_int, _int]),
+    "gmmvb_workspace_create": (_int, [_int, _int, _int, _i64, ctypes.POINTER(_vp)]),
+    "gmmvb_workspace_destroy": (_int, [_vp]),
+    "gmmvb_workspace_bytes": (_i64, [_vp]),
+    "gmmvb_set_pivot": (_int, [_vp, _vp, _vp]),
+    "gmmvb_set_params": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "gmmvb_estep": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "gmmvb_load_responsibilities": (_int, [_vp, _vp, _i64, _vp]),
+    "gmmvb_mstep": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "gmmvb_estep_mstep": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "gmmvb_responsibilities": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "gmmvb_ln_rho": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "gmmvb_argmax": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "gmmvb_last_launch_info": (ctypes.c_char_p, [_vp]),
+    "gmmvb_profile_enable": (_int, [_vp, _int]),
+    "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+}
+
+
+class EngineUnavailableError(RuntimeError):
+    """The HIP extension or the GPU is missing; the product path has no fallback."""
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the in-tree library and declare every prototype (works without a GPU)."""
+    global _lib
+    if _lib is not None and path == LIB_PATH:
+        return _lib
+    if not os.path.exists(path):
+        raise EngineUnavailableError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C bayesml_amd/csrc`). bayesml_amd has no CPU fallback for the data pass.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.gmmvb_last_error()
+        raise EngineError(f"{what}: {_STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+
+def _f64(t: torch.Tensor, shape, device) -> torch.Tensor:
+    t = torch.as_tensor(t, dtype=torch.float64, device=device).contiguous()
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+class DataPass:
+    """One workspace = one (K, D, x dtype, max rows) problem on one GPU.
+
+    ``estep``/``mstep`` enqueue on the current torch stream of ``device`` and return device
+    tensors; nothing here synchronises with the host.
+    """
+
+    def __init__(self, K: int, D: int, x_dtype: torch.dtype, max_rows: int, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineUnavailableError("no ROCm GPU visible to PyTorch; the GMM-VB data pass runs on MI355X only")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if x_dtype not in (torch.float32, torch.float64):
+            raise ValueError("x dtype must be float32 or float64")
+        self.K, self.D, self.x_dtype, self.max_rows = int(K), int(D), x_dtype, int(max_rows)
+        self.stats_len = int(self.lib.gmmvb_stats_len(self.K, self.D))
+        handle = _vp()
+        with torch.cuda.device(self.device):
+            rc = self.lib.gmmvb_workspace_create(self.K, self.D, GMMVB_F64 if x_dtype == torch.float64 else GMMVB_F32,
+                                                 self.max_rows, ctypes.byref(handle))
+        _check(self.lib, rc, "gmmvb_workspace_create")
+        self._ws = handle
+        self._keep = []      # tensors whose memory an enqueued kernel may still read
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_ws", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.gmmvb_workspace_destroy(self._ws)
+            self._ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    # -- helpers
+    def _stream(self):
+        return _vp(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _x(self, x: torch.Tensor):
+        if x.device != self.device or x.dtype != self.x_dtype or x.dim() != 2 or x.shape[1] != self.D:
+            raise ValueError(f"x must be a [{'*'}, {self.D}] {self.x_dtype} tensor on {self.device}")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        return x, int(x.stride(0)) if x.shape[0] > 1 else self.D
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.gmmvb_workspace_bytes(self._ws))
+
+    @property
+    def launch_info(self) -> str:
+        s = self.lib.gmmvb_last_launch_info(self._ws)
+        return s.decode() if s else ""
+
+    def profile(self, on: bool = True):
+        _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")
+
+    def last_kernel_ms(self):
+        """(estep_mfma_f64 ms, mstep_mfma_f64 ms) of the last launches, from HIP events on the launch stream."""
+        e, m = ctypes.c_float(), ctypes.c_float()
+        _check(self.lib, self.lib.gmmvb_profile_last_ms(self._ws, ctypes.byref(e), ctypes.byref(m)),
+               "gmmvb_profile_last_ms")
+        return float(e.value), float(m.value)
+
+    # -- C ABI
+    def set_pivot(self, pivot):
+        p = _f64(pivot, (self.D,), self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_set_pivot(self._ws, p.data_ptr(), self._stream()), "gmmvb_set_pivot")
+        self.pivot = p
+
+    def set_params(self, c, m, u):
+        c = _f64(c, (self.K,), self.device)
+        m = _f64(m, (self.K, self.D), self.device)
+        u = _f64(u, (self.K, self.D, self.D), self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_set_params(self._ws, c.data_ptr(), m.data_ptr(), u.data_ptr(),
+                                                       self._stream()), "gmmvb_set_params")
+        self._keep = [c, m, u]
+
+    def estep(self, x: torch.Tensor):
+        x, ldx = self._x(x)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_estep(self._ws, x.data_ptr(), ldx, x.shape[0], self._stream()),
+                   "gmmvb_estep")
+        self.rows = x.shape[0]
+
+    def load_responsibilities(self, r: torch.Tensor):
+        r = torch.as_tensor(r, dtype=torch.float64, device=self.device).contiguous()
+        if r.dim() != 2 or r.shape[1] != self.K:
+            raise ValueError("r must be [n, K]")
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_load_responsibilities(self._ws, r.data_ptr(), r.shape[0], self._stream()),
+                   "gmmvb_load_responsibilities")
+        self.rows = r.shape[0]
+        self._keep.append(r)
+
+    def mstep(self, x: torch.Tensor) -> torch.Tensor:
+        x, ldx = self._x(x)
+        stats = torch.empty(self.stats_len, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_mstep(self._ws, x.data_ptr(), ldx, x.shape[0], stats.data_ptr(),
+                                                  self._stream()), "gmmvb_mstep")
+        return stats
+
+    def estep_mstep(self, x: torch.Tensor) -> torch.Tensor:
+        x, ldx = self._x(x)
+        stats = torch.empty(self.stats_len, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_estep_mstep(self._ws, x.data_ptr(), ldx, x.shape[0], stats.data_ptr(),
+                                                        self._stream()), "gmmvb_estep_mstep")
+        self.rows = x.shape[0]
+        return stats
+
+    def split_stats(self, stats: torch.Tensor):
+        """[ns | h | a | B] views of a statistics block."""
+        K, D = self.K, self.D
+        return (stats[:K], stats[K:2 * K], stats[2 * K:2 * K + K * D].view(K, D),
+                stats[2 * K + K * D:].view(K, D, D))
+
+    def _readout(self, fn, name, row0, n, dtype=torch.float64, cols=None):
+        n = self.rows - row0 if n is None else n
+        out = torch.empty((n, self.K) if cols is None else (n,), dtype=dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, fn(self._ws, row0, n, out.data_ptr(), self._stream()), name)
+        return out
+
+    def responsibilities(self, row0=0, n=None) -> torch.Tensor:
+        return self._readout(self.lib.gmmvb_responsibilities, "gmmvb_responsibilities", row0, n)
+
+    def ln_rho(self, row0=0, n=None) -> torch.Tensor:
+        return self._readout(self.lib.gmmvb_ln_rho, "gmmvb_ln_rho", row0, n)
+
+    def argmax(self, row0=0, n=None) -> torch.Tensor:
+        return self._readout(self.lib.gmmvb_argmax, "gmmvb_argmax", row0, n, dtype=torch.int32, cols=1)

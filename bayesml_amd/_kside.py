@@ -1,0 +1,177 @@
+"""K-sized closed-form updates of the Dirichlet x Normal-Wishart posterior, in fp64 torch.
+
+Device-agnostic (runs where its input tensors live: the GPU inside ``update_posterior``, the CPU
+in the unit tests).  These are the K-sized steps of the reference that bracket the data pass:
+
+  moments_from_stats      _calc_n_x_bar_s's per-component finishing   _gaussianmixture.py:729-732
+  update_q                _update_q_mu_lambda + _update_q_pi          _gaussianmixture.py:758-770, 741-743
+  features                _calc_q_pi_features, _calc_q_lambda_features  :738-739, :745-756
+  lower_bound             _calc_vl                                    :671-723
+  subsample_moments_init  _init_subsampling                           :786-796
+
+Unlike the reference, ``W = inv(W^-1)`` is obtained from ONE Cholesky factorisation
+W^-1 = G G^T per component, which also yields ln det W^-1 = 2 sum ln diag G and the whitening
+factor U = sqrt(nu) G^-1 (U^T U = nu W = E[Lambda]) that the E-step kernel consumes.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+LN_2PI = math.log(2.0 * math.pi)
+LN_2 = math.log(2.0)
+LN_PI = math.log(math.pi)
+
+
+@dataclass
+class PriorT:
+    alpha: torch.Tensor     # [K]
+    m: torch.Tensor         # [K, D]
+    kappa: torch.Tensor     # [K]
+    nu: torch.Tensor        # [K]
+    w_inv: torch.Tensor     # [K, D, D]
+    ln_c_alpha: float       # _gaussianmixture.py:662
+    ln_b_w_nu: torch.Tensor  # [K]  :663-669
+
+
+@dataclass
+class PostT:
+    alpha: torch.Tensor
+    m: torch.Tensor
+    kappa: torch.Tensor
+    nu: torch.Tensor
+    w_inv: torch.Tensor
+    # derived (features())
+    w: torch.Tensor = None
+    u: torch.Tensor = None               # [K, D, D] lower triangular, u^T u = nu * w
+    e_ln_pi: torch.Tensor = None
+    e_ln_lambda_det: torch.Tensor = None
+    ln_b_w_nu: torch.Tensor = None
+    c: torch.Tensor = None               # E-step constant per component
+
+    def clone(self) -> "PostT":
+        return PostT(*(None if t is None else t.clone() for t in (
+            self.alpha, self.m, self.kappa, self.nu, self.w_inv, self.w, self.u, self.e_ln_pi,
+            self.e_ln_lambda_det, self.ln_b_w_nu, self.c)))
+
+
+def _half_lgamma_sum(nu: torch.Tensor, D: int) -> torch.Tensor:
+    d = torch.arange(D, dtype=nu.dtype, device=nu.device)
+    return torch.lgamma((nu[:, None] - d) / 2.0).sum(dim=1)
+
+
+def _half_digamma_sum(nu: torch.Tensor, D: int) -> torch.Tensor:
+    d = torch.arange(D, dtype=nu.dtype, device=nu.device)
+    return torch.digamma((nu[:, None] - d) / 2.0).sum(dim=1)
+
+
+def ln_wishart_b(logdet_w_inv: torch.Tensor, nu: torch.Tensor, D: int) -> torch.Tensor:
+    """ln B(W, nu) from ln det W^-1 (_gaussianmixture.py:750-756; the prior form :663-669 is the
+    same expression with ln det W = -ln det W^-1)."""
+    return (nu * logdet_w_inv - nu * D * LN_2 - D * (D - 1) / 2.0 * LN_PI - 2.0 * _half_lgamma_sum(nu, D)) / 2.0
+
+
+def features(q: PostT) -> PostT:
+    """Refresh every derived quantity of ``q`` from (alpha, m, kappa, nu, w_inv)."""
+    K, D = q.m.shape
+    q.e_ln_pi = torch.digamma(q.alpha) - torch.digamma(q.alpha.sum())
+    g, _info = torch.linalg.cholesky_ex(q.w_inv)          # NaNs propagate instead of raising, like inv()
+    eye = torch.eye(D, dtype=q.w_inv.dtype, device=q.w_inv.device).expand(K, D, D)
+    g_inv = torch.linalg.solve_triangular(g, eye, upper=False)
+    q.w = g_inv.transpose(1, 2) @ g_inv
+    q.w = 0.5 * (q.w + q.w.transpose(1, 2))
+    q.u = torch.sqrt(q.nu)[:, None, None] * g_inv
+    logdet = 2.0 * torch.log(torch.diagonal(g, dim1=1, dim2=2)).sum(dim=1)
+    q.e_ln_lambda_det = _half_digamma_sum(q.nu, D) + D * LN_2 - logdet
+    q.ln_b_w_nu = ln_wishart_b(logdet, q.nu, D)
+    q.c = q.e_ln_pi + (q.e_ln_lambda_det - D * LN_2PI - D / q.kappa) / 2.0
+    return q
+
+
+def prior_from_numpy(alpha, m, kappa, nu, w, device) -> PriorT:
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=device).clone()   # noqa: E731
+    alpha, m, kappa, nu, w = t(alpha), t(m), t(kappa), t(nu), t(w)
+    D = m.shape[1]
+    w_inv = torch.linalg.inv(w)
+    w_inv = 0.5 * (w_inv + w_inv.transpose(1, 2))
+    ln_c = float(torch.lgamma(alpha.sum()) - torch.lgamma(alpha).sum())
+    logdet_w_inv = -torch.linalg.slogdet(w)[1]
+    return PriorT(alpha, m, kappa, nu, w_inv, ln_c, ln_wishart_b(logdet_w_inv, nu, D))
+
+
+def post_from_prior(p: PriorT) -> PostT:
+    """reset_hn_params (reference base.py:260-267)."""
+    return features(PostT(p.alpha.clone(), p.m.clone(), p.kappa.clone(), p.nu.clone(), p.w_inv.clone()))
+
+
+def moments_from_stats(ns, a, B, pivot, s_prev):
+    """Engine statistics (about ``pivot``) -> the reference's (x_bar_vecs, s_mats).
+
+    For ns[k] == 0 the reference leaves x_bar_vecs[k] as the raw zero sum and does not touch
+    s_mats[k] (_gaussianmixture.py:729); ``s_prev`` carries that previous value (zeros initially)."""
+    pos = ns > 0
+    safe = torch.where(pos, ns, torch.ones_like(ns))
+    abar = a / safe[:, None]
+    x_bar = torch.where(pos[:, None], pivot[None, :] + abar, torch.zeros_like(abar))
+    s = B / safe[:, None, None] - abar[:, :, None] * abar[:, None, :]
+    s = torch.where(pos[:, None, None], s, s_prev)
+    return x_bar, s
+
+
+def update_q(p: PriorT, ns, x_bar, s) -> PostT:
+    """_update_q_mu_lambda (:758-770) + _update_q_pi (:741-743), then features()."""
+    kappa = p.kappa + ns
+    m = (p.kappa[:, None] * p.m + ns[:, None] * x_bar) / kappa[:, None]
+    nu = p.nu + ns
+    dev = x_bar - p.m
+    w_inv = (p.w_inv + ns[:, None, None] * s
+             + (p.kappa * ns / kappa)[:, None, None] * (dev[:, :, None] * dev[:, None, :]))
+    return features(PostT(p.alpha + ns, m, kappa, nu, w_inv))
+
+
+def dirichlet_entropy(alpha: torch.Tensor) -> torch.Tensor:
+    """Differential entropy of Dirichlet(alpha) — what scipy.stats.dirichlet.entropy returns
+    (used at _gaussianmixture.py:707)."""
+    a0 = alpha.sum()
+    K = alpha.numel()
+    ln_b = torch.lgamma(alpha).sum() - torch.lgamma(a0)
+    return ln_b + (a0 - K) * torch.digamma(a0) - ((alpha - 1.0) * torch.digamma(alpha)).sum()
+
+
+def lower_bound(p: PriorT, q: PostT, ns, x_bar, s, sum_r_ln_r) -> dict:
+    """_calc_vl (_gaussianmixture.py:671-723).  ``sum_r_ln_r`` = sum_nk r ln r from the M-step kernel.
+    Returns 0-dim tensors (no host sync here)."""
+    K, D = q.m.shape
+    e_lambda = q.nu[:, None, None] * q.w
+
+    def quad(v):
+        return torch.einsum("ki,kij,kj->k", v, e_lambda, v)
+
+    p_x = (ns * (q.e_ln_lambda_det - D / q.kappa - (s * e_lambda).sum(dim=(1, 2)) - quad(x_bar - q.m)
+                 - D * LN_2PI)).sum() / 2.0
+    p_z = (ns * q.e_ln_pi).sum()
+    p_pi = p.ln_c_alpha + ((p.alpha - 1.0) * q.e_ln_pi).sum()
+    p_mu_lambda = (D * (torch.log(p.kappa) - LN_2PI - p.kappa / q.kappa) - p.kappa * quad(q.m - p.m)
+                   + 2.0 * p.ln_b_w_nu + (p.nu - D) * q.e_ln_lambda_det
+                   - (p.w_inv * e_lambda).sum(dim=(1, 2))).sum() / 2.0
+    q_z = -sum_r_ln_r
+    q_pi = dirichlet_entropy(q.alpha)
+    q_mu_lambda = (D * (1.0 + LN_2PI - torch.log(q.kappa)) - 2.0 * q.ln_b_w_nu
+                   - (q.nu - D) * q.e_ln_lambda_det + q.nu * D).sum() / 2.0
+    terms = dict(p_x=p_x, p_z=p_z, p_pi=p_pi, p_mu_lambda=p_mu_lambda, q_z=q_z, q_pi=q_pi, q_mu_lambda=q_mu_lambda)
+    terms["vl"] = p_x + p_z + p_pi + p_mu_lambda + q_z + q_pi + q_mu_lambda
+    return terms
+
+
+def subsample_moments_init(q: PostT, cnt, a, B, pivot) -> PostT:
+    """_init_subsampling (_gaussianmixture.py:786-796) from per-component raw moments of the drawn
+    rows about ``pivot``: cnt (scalar subsample size), a [K, D] = sum (x - pivot), B [K, D, D]."""
+    D = q.m.shape[1]
+    abar = a / cnt
+    q.m = pivot[None, :] + abar
+    cov = B / cnt - abar[:, :, None] * abar[:, None, :]
+    eye = torch.eye(D, dtype=cov.dtype, device=cov.device)
+    q.w_inv = cov * q.nu[:, None, None] + eye * 1.0e-5
+    return features(q)

@@ -1,0 +1,124 @@
+// K-sized packing, row log-normaliser, slab reduction and read-out kernels (all f64, bandwidth-trivial).
+#pragma once
+#include "common.h"
+
+namespace gmmvb {
+
+// u [K][D][D] lower triangular (y = u d)  ->  upack [K][P][16][16] (zero padded), bpack = -(u m).
+__global__ void pack_params_kernel(const double* __restrict__ u, const double* __restrict__ m, int K, int D,
+                                   int T, double* __restrict__ upack, double* __restrict__ bpack) {
+    const int k = blockIdx.x;
+    const int P = tri_pairs(T);
+    const double* uk = u + (int64_t)k * D * D;
+    double* up = upack + (int64_t)k * P * 256;
+    for (int e = threadIdx.x; e < P * 256; e += blockDim.x) {
+        const int p = e >> 8, row = (e >> 4) & 15, col = e & 15;
+        int jt = 0;
+        while (tri_pairs(jt + 1) <= p) ++jt;
+        const int b = p - tri_pairs(jt);
+        const int jj = 16 * jt + row, ii = 16 * b + col;
+        up[e] = (jj < D && ii < D && ii <= jj) ? uk[(int64_t)jj * D + ii] : 0.0;
+    }
+    const double* mk = m + (int64_t)k * D;
+    for (int jj = threadIdx.x; jj < 16 * T; jj += blockDim.x) {
+        double s = 0.0;
+        if (jj < D)
+            for (int ii = 0; ii <= jj; ++ii) s = fma(uk[(int64_t)jj * D + ii], mk[ii], s);
+        const int jt = jj >> 4, w = jj & 15, g = w & 3, r = w >> 2;   // row = g + 4 r
+        bpack[(((int64_t)k * T + jt) * 4 + g) * 4 + r] = -s;
+    }
+}
+
+// lse[n] = ln sum_k exp(lnrho[k][n]) (single pass, running max); optional argmax.
+__global__ void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows, int K,
+                               double* __restrict__ lse) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_rows) return;
+    double mx = lnrho[n], s = 1.0;
+    for (int k = 1; k < K; ++k) {
+        const double v = lnrho[(int64_t)k * npad + n];
+        if (v > mx) {
+            s = fma(s, exp(mx - v), 1.0);
+            mx = v;
+        } else {
+            s += exp(v - mx);
+        }
+    }
+    lse[n] = mx + log(s);
+}
+
+// r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0
+__global__ void load_r_kernel(const double* __restrict__ r, int64_t n_rows, int K, double* __restrict__ buf,
+                              int64_t npad, double* __restrict__ lse) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_rows) return;
+    for (int k = 0; k < K; ++k) buf[(int64_t)k * npad + n] = r[n * K + k];
+    lse[n] = 0.0;
+}
+
+// mode 0: ln rho; mode 1: r = exp(ln rho - lse) (or the stored r in direct mode)
+__global__ void readout_kernel(const double* __restrict__ buf, const double* __restrict__ lse, int64_t npad,
+                               int64_t row0, int64_t n_rows, int K, int mode, int direct_r,
+                               double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * K) return;
+    const int64_t n = e / K;
+    const int k = (int)(e - n * K);
+    const double v = buf[(int64_t)k * npad + row0 + n];
+    out[e] = (mode == 0 || direct_r) ? v : exp(v - lse[row0 + n]);
+}
+
+// first maximiser over k, like numpy.argmax on the reference's r_vecs (_gaussianmixture.py:1191)
+__global__ void argmax_kernel(const double* __restrict__ buf, int64_t npad, int64_t row0, int64_t n_rows, int K,
+                              int32_t* __restrict__ z) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_rows) return;
+    double best = buf[row0 + n];
+    int arg = 0;
+    for (int k = 1; k < K; ++k) {
+        const double v = buf[(int64_t)k * npad + row0 + n];
+        if (v > best) {
+            best = v;
+            arg = k;
+        }
+    }
+    z[n] = arg;
+}
+
+// Sum slabs over row splits (fixed order => run-to-run identical) and scatter to
+// stats = [ ns[K] | h[K] | a[K][D] | B[K][D][D] ].
+__global__ void reduce_stats_kernel(const double* __restrict__ slabs, int S, int K, int D, int T,
+                                    double* __restrict__ stats) {
+    const int k = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = tri_pairs(T);
+    const int L = slab_len(T);
+    if (e >= P * 256 + 16 * T + 2) return;
+    double v = 0.0;
+    for (int s = 0; s < S; ++s) v += slabs[((int64_t)s * K + k) * L + e];
+    double* ns = stats;
+    double* h = stats + K;
+    double* a = stats + 2 * (int64_t)K;
+    double* B = a + (int64_t)K * D;
+    if (e < P * 256) {
+        const int p = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+        int t2 = 0;
+        while (tri_pairs(t2 + 1) <= p) ++t2;
+        const int t1 = p - tri_pairs(t2);
+        const int col = lane & 15, row = (lane >> 4) + 4 * r;     // f64 MFMA C/D map
+        const int f1 = T * row + t1, f2 = T * col + t2;
+        if (f1 >= D || f2 >= D) return;
+        if (t1 == t2 && row > col) return;   // diagonal tiles: keep one triangle, mirror it (exact symmetry)
+        B[((int64_t)k * D + f1) * D + f2] = v;
+        B[((int64_t)k * D + f2) * D + f1] = v;
+    } else if (e < P * 256 + 16 * T) {
+        const int f = e - P * 256;
+        if (f < D) a[(int64_t)k * D + f] = v;
+    } else if (e == P * 256 + 16 * T) {
+        ns[k] = v;
+    } else {
+        h[k] = v;
+    }
+}
+
+}  // namespace gmmvb

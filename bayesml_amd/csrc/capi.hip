@@ -1,0 +1,310 @@
+// C ABI of the GMM-VB data-pass engine (see include/gmmvb.h for the contract and the reference
+// call sites each entry point replaces).
+#include "../../include/gmmvb.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "aux_kernels.h"
+#include "launch.h"
+
+using namespace gmmvb;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    g_err = what;
+    if (e != hipSuccess) {
+        g_err += ": ";
+        g_err += hipGetErrorString(e);
+    }
+    return code;
+}
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct gmmvb_workspace {
+    int K = 0, D = 0, T = 0, x_dtype = 0;
+    int64_t max_rows = 0, npad = 0;
+    int num_cu = 0, KG = 0, S_cap = 0;
+    double* lnrho = nullptr;   // [K][npad]
+    double* lse = nullptr;     // [npad]
+    double* upack = nullptr;   // [K][P][256]
+    double* bpack = nullptr;   // [K][T][16]
+    double* cvec = nullptr;    // [K]
+    double* pivot = nullptr;   // [D]
+    double* slabs = nullptr;   // [S_cap][K][slab_len]
+    int64_t bytes = 0;
+    bool have_params = false;
+    int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly
+    int64_t e_rows = 0;
+    char info[512] = {0};
+    bool prof = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // E begin/end, M begin/end
+    bool ev_e = false, ev_m = false;
+};
+
+extern "C" {
+
+int gmmvb_abi_version(void) { return GMMVB_ABI_VERSION; }
+const char* gmmvb_last_error(void) { return g_err.c_str(); }
+
+int64_t gmmvb_stats_len(int K, int D) {
+    if (K < 1 || D < 1) return -1;
+    return (int64_t)K * (2 + (int64_t)D + (int64_t)D * D);
+}
+
+int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace** out) {
+    if (!out) return fail(GMMVB_EINVAL, "out is null");
+    *out = nullptr;
+    if (K < 1 || D < 1 || max_rows < 1) return fail(GMMVB_EINVAL, "K, D and max_rows must be positive");
+    if (x_dtype != GMMVB_F32 && x_dtype != GMMVB_F64) return fail(GMMVB_EINVAL, "x_dtype must be GMMVB_F32 or GMMVB_F64");
+    if (D > 16 * kMaxTiles) return fail(GMMVB_EUNSUPPORTED, "D > 128 is not supported by this version");
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "hipGetDevice", e);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "hipGetDeviceProperties", e);
+
+    gmmvb_workspace* ws = new (std::nothrow) gmmvb_workspace();
+    if (!ws) return fail(GMMVB_ENOMEM, "host allocation failed");
+    ws->K = K;
+    ws->D = D;
+    ws->T = (D + 15) / 16;
+    ws->x_dtype = x_dtype;
+    ws->max_rows = max_rows;
+    ws->npad = round_up(max_rows, 64);
+    ws->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        const int kpw = mstep_components_per_wg(ws->T);
+        ws->KG = (K + kpw - 1) / kpw;
+    }
+    ws->S_cap = (int)round_up(((int64_t)4 * ws->num_cu + ws->KG - 1) / ws->KG, 8);
+    if (ws->S_cap < 8) ws->S_cap = 8;
+    const int P = tri_pairs(ws->T);
+    struct { double** p; int64_t n; } bufs[] = {
+        {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},
+        {&ws->upack, (int64_t)K * P * 256},  {&ws->bpack, (int64_t)K * ws->T * 16},
+        {&ws->cvec, K},                      {&ws->pivot, D},
+        {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)}};
+    for (auto& b : bufs) {
+        e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
+        if (e != hipSuccess) {
+            gmmvb_workspace_destroy(ws);
+            return fail(GMMVB_ENOMEM, "hipMalloc (workspace)", e);
+        }
+        ws->bytes += b.n * (int64_t)sizeof(double);
+    }
+    e = hipMemset(ws->pivot, 0, (size_t)D * sizeof(double));
+    if (e != hipSuccess) {
+        gmmvb_workspace_destroy(ws);
+        return fail(GMMVB_EHIP, "hipMemset(pivot)", e);
+    }
+    *out = ws;
+    return GMMVB_OK;
+}
+
+int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
+    if (!ws) return GMMVB_OK;
+    double* bufs[] = {ws->lnrho, ws->lse, ws->upack, ws->bpack, ws->cvec, ws->pivot, ws->slabs};
+    for (double* p : bufs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : ws->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete ws;
+    return GMMVB_OK;
+}
+
+int64_t gmmvb_workspace_bytes(const gmmvb_workspace* ws) { return ws ? ws->bytes : -1; }
+
+const char* gmmvb_last_launch_info(const gmmvb_workspace* ws) { return ws ? ws->info : ""; }
+
+int gmmvb_profile_enable(gmmvb_workspace* ws, int on) {
+    if (!ws) return fail(GMMVB_EINVAL, "null argument");
+    if (on && !ws->ev[0]) {
+        for (auto& e : ws->ev) {
+            hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) return fail(GMMVB_EHIP, "hipEventCreate", rc);
+        }
+    }
+    ws->prof = on != 0;
+    return GMMVB_OK;
+}
+
+int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms) {
+    if (!ws || !estep_ms || !mstep_ms) return fail(GMMVB_EINVAL, "null argument");
+    *estep_ms = *mstep_ms = -1.0f;
+    if (ws->ev_e) {
+        hipError_t rc = hipEventSynchronize(ws->ev[1]);
+        if (rc == hipSuccess) rc = hipEventElapsedTime(estep_ms, ws->ev[0], ws->ev[1]);
+        if (rc != hipSuccess) return fail(GMMVB_EHIP, "event timing (estep)", rc);
+    }
+    if (ws->ev_m) {
+        hipError_t rc = hipEventSynchronize(ws->ev[3]);
+        if (rc == hipSuccess) rc = hipEventElapsedTime(mstep_ms, ws->ev[2], ws->ev[3]);
+        if (rc != hipSuccess) return fail(GMMVB_EHIP, "event timing (mstep)", rc);
+    }
+    return GMMVB_OK;
+}
+
+int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) {
+    if (!ws || !pivot_dev) return fail(GMMVB_EINVAL, "null argument");
+    hipError_t e = hipMemcpyAsync(ws->pivot, pivot_dev, (size_t)ws->D * sizeof(double), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(pivot)", e);
+    return GMMVB_OK;
+}
+
+int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_dev, const double* u_dev,
+                     void* stream) {
+    if (!ws || !c_dev || !m_dev || !u_dev) return fail(GMMVB_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(ws->cvec, c_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(c)", e);
+    hipLaunchKernelGGL(pack_params_kernel, dim3(ws->K), dim3(256), 0, st, u_dev, m_dev, ws->K, ws->D, ws->T,
+                       ws->upack, ws->bpack);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_kernel", e);
+    ws->have_params = true;
+    return GMMVB_OK;
+}
+
+static int check_x(const gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, bool* vec) {
+    if (!ws || !x_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (n_rows < 1 || n_rows > ws->max_rows) return fail(GMMVB_EINVAL, "n_rows must be in [1, max_rows]");
+    if (ldx < ws->D) return fail(GMMVB_EINVAL, "ldx must be >= D");
+    const int64_t esz = ws->x_dtype == GMMVB_F64 ? 8 : 4;
+    // vector loads: whole 16-feature blocks, 4-element (E) and T-element (M) vectors naturally aligned
+    const int64_t valign = esz * (ws->T > 4 ? ws->T : 4);
+    *vec = (ws->D % 16 == 0) && ((uintptr_t)x_dev % valign == 0) && ((ldx * esz) % valign == 0);
+    return GMMVB_OK;
+}
+
+int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream) {
+    bool vec = false;
+    int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
+    if (rc) return rc;
+    if (!ws->have_params) return fail(GMMVB_ESTATE, "gmmvb_set_params has not been called");
+    hipStream_t st = (hipStream_t)stream;
+    const int is64 = ws->x_dtype == GMMVB_F64;
+    const int rpw = estep_rows_per_wave(ws->T, is64);
+    const int64_t tiles = (n_rows + rpw - 1) / rpw;
+    int64_t grid = (tiles + 3) / 4;
+    if (grid > (1 << 20)) grid = 1 << 20;
+    EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->upack, ws->bpack, ws->cvec, ws->K, ws->lnrho, ws->npad};
+    const char* name = "";
+    if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
+    hipError_t e = launch_estep(ws->T, is64, vec, (int)grid, st, a, &name);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
+    if (ws->prof) {
+        (void)hipEventRecord(ws->ev[1], st);
+        ws->ev_e = true;
+    }
+    const int tb = 256;
+    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)((n_rows + tb - 1) / tb)), dim3(tb), 0, st, ws->lnrho,
+                       ws->npad, n_rows, ws->K, ws->lse);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
+    ws->e_state = 1;
+    ws->e_rows = n_rows;
+    std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx256 rows/wave=%d", name, (long long)grid, rpw);
+    return GMMVB_OK;
+}
+
+int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_t n_rows, void* stream) {
+    if (!ws || !r_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (n_rows < 1 || n_rows > ws->max_rows) return fail(GMMVB_EINVAL, "n_rows must be in [1, max_rows]");
+    const int tb = 256;
+    hipLaunchKernelGGL(load_r_kernel, dim3((unsigned)((n_rows + tb - 1) / tb)), dim3(tb), 0, (hipStream_t)stream,
+                       r_dev, n_rows, ws->K, ws->lnrho, ws->npad, ws->lse);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "load_r launch", e);
+    ws->e_state = 2;
+    ws->e_rows = n_rows;
+    return GMMVB_OK;
+}
+
+int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, double* stats_dev,
+                void* stream) {
+    bool vec = false;
+    int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
+    if (rc) return rc;
+    if (!stats_dev) return fail(GMMVB_EINVAL, "stats_dev is null");
+    if (ws->e_state == 0 || ws->e_rows != n_rows)
+        return fail(GMMVB_ESTATE, "no responsibilities for these rows: call gmmvb_estep or gmmvb_load_responsibilities first");
+    hipStream_t st = (hipStream_t)stream;
+    // row splits: ~4 workgroups per CU in total, whole 64-row groups per split, S a multiple of 8 where possible
+    int64_t S = ws->S_cap;
+    const int64_t groups = (n_rows + 63) / 64;
+    if (S > groups) S = groups;
+    const int64_t rows_per_split = round_up((n_rows + S - 1) / S, 64);
+    S = (n_rows + rows_per_split - 1) / rows_per_split;
+    const int64_t grid = 8 * ((S + 7) / 8) * ws->KG;
+    MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, ws->npad, ws->K, ws->KG, (int)S,
+                rows_per_split, ws->e_state == 2 ? 1 : 0, ws->slabs};
+    const char* name = "";
+    if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
+    hipError_t e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, (int)grid, st, a, &name);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);
+    if (ws->prof) {
+        (void)hipEventRecord(ws->ev[3], st);
+        ws->ev_m = true;
+    }
+    const int elems = tri_pairs(ws->T) * 256 + 16 * ws->T + 2;
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3((elems + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, (int)S,
+                       ws->K, ws->D, ws->T, stats_dev);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "reduce_stats launch", e);
+    const size_t used = std::strlen(ws->info);
+    std::snprintf(ws->info + used, sizeof(ws->info) - used, " | %s grid=%lldx256 splits=%lld rows/split=%lld", name,
+                  (long long)grid, (long long)S, (long long)rows_per_split);
+    return GMMVB_OK;
+}
+
+int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, double* stats_dev,
+                      void* stream) {
+    int rc = gmmvb_estep(ws, x_dev, ldx, n_rows, stream);
+    if (rc) return rc;
+    return gmmvb_mstep(ws, x_dev, ldx, n_rows, stats_dev, stream);
+}
+
+static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out, void* stream, int mode) {
+    if (!ws || !out) return fail(GMMVB_EINVAL, "null argument");
+    if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
+    if (mode == 0 && ws->e_state == 2) return fail(GMMVB_ESTATE, "ln rho is undefined after gmmvb_load_responsibilities");
+    const int64_t total = n_rows * ws->K;
+    hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ws->lnrho, ws->lse, ws->npad, row0, n_rows, ws->K, mode, ws->e_state == 2 ? 1 : 0, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "readout launch", e);
+    return GMMVB_OK;
+}
+
+int gmmvb_responsibilities(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* r_dev, void* stream) {
+    return readout(ws, row0, n_rows, r_dev, stream, 1);
+}
+
+int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_dev, void* stream) {
+    return readout(ws, row0, n_rows, out_dev, stream, 0);
+}
+
+int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_dev, void* stream) {
+    if (!ws || !z_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ws->lnrho, ws->npad, row0, n_rows, ws->K, z_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax launch", e);
+    return GMMVB_OK;
+}
+
+}  // extern "C"

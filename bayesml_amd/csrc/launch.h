@@ -1,0 +1,27 @@
+// Host-side launch entry points implemented in the per-kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmmvb {
+
+struct EstepArgs {
+    const void* x; int64_t ldx; int64_t n_rows; int D;
+    const double* upack; const double* bpack; const double* cvec; int K;
+    double* lnrho; int64_t npad;
+};
+struct MstepArgs {
+    const void* x; int64_t ldx; int64_t n_rows; int D;
+    const double* pivot; const double* lnrho; const double* lse; int64_t npad;
+    int K; int KG; int S; int64_t rows_per_split; int direct_r; double* slabs;
+};
+
+// rows of x handled by one E-step wave for (T, dtype)
+int estep_rows_per_wave(int T, int x_is_f64);
+// components handled by one M-step workgroup for T feature tiles (4 waves / waves-per-component)
+int mstep_components_per_wg(int T);
+// returns hipSuccess or the launch error; `name` receives a static description of the instantiation
+hipError_t launch_estep(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a, const char** name);
+hipError_t launch_mstep(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const MstepArgs& a, const char** name);
+
+}  // namespace gmmvb

@@ -1,0 +1,171 @@
+// M-step kernel: per-component weighted sufficient statistics on f64 MFMA.
+//
+// Replaces the reference's _calc_n_x_bar_s (bayesml/gaussianmixture/_gaussianmixture.py:725-732:
+// ns = r.sum(0); x_bar = r.T @ x; S_k = ((r_k * diff.T) @ diff) / ns_k, two passes over x and one
+// [N, D] temporary pair per component) and the N-sized lower-bound term -sum xlogy(r, r) (:704)
+// with one pass that accumulates, about a fixed pivot p,
+//   ns_k = sum_n r_nk,  a_k = sum_n r_nk (x_n - p),  B_k = sum_n r_nk (x_n - p)(x_n - p)^T,
+//   h_k = sum_n r_nk ln r_nk,
+// which are linear in the rows (row shards and GPUs add).  r_nk = exp(ln rho_nk - lse_n) is
+// recomputed from the E-step's output; the [N, K] responsibility matrix is never materialised.
+//
+// Mapping: WS waves share ONE component k and a contiguous row range (WS = 1 up to T = 7; WS = 2 at
+// T = 8, where the 36 accumulator tiles = 288 registers exceed the 256 AGPRs and would otherwise
+// bounce through v_accvgpr copies every step); the 4/WS component slots of a workgroup take
+// consecutive k over the SAME rows (their x loads hit L1).  The sample index is the MFMA contraction
+// index: D[i][j] += A[i][n] B[n][j] with A = r_n x'_n (feature tile t1), B = x'_n (feature tile t2),
+// t1 <= t2 only (B_k is symmetric).  Lane l = (i = l & 15, g = l >> 4) handles sample n0 + g and
+// features T*i .. T*i + T-1 (contiguous in memory: one vector load per sample), i.e. feature f
+// lives in tile f % T at row f / T.  A wave's accumulator tiles (pairs p with p % WS == sub) stay in
+// registers for the whole row range (f64 accumulation, no flush needed) and are written once as a
+// slab in register order; reduce_stats sums slabs over row splits in a fixed order.
+#pragma once
+#include "common.h"
+
+namespace gmmvb {
+
+__host__ __device__ constexpr int mstep_ws(int t) { return t >= 8 ? 2 : 1; }
+
+template <int T, int WS, int SUB, typename XT, bool VEC>
+__device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                           const double* __restrict__ pivot, const double* __restrict__ lr,
+                                           const double* __restrict__ lse, int64_t lo, int64_t hi, int direct_r,
+                                           double* __restrict__ out) {
+    constexpr int P = tri_pairs(T);
+    constexpr int NP = (P - SUB + WS - 1) / WS;   // tile pairs owned by this wave
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15;
+    const int g = lane >> 4;
+
+    double pv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) pv[t] = (T * i + t < D) ? pivot[T * i + t] : 0.0;
+    d4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = d4{0.0, 0.0, 0.0, 0.0};
+    double asum[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) asum[t] = 0.0;
+    double nsum = 0.0, hsum = 0.0;
+
+    struct RawRow { XT v[T]; };
+    auto load_row = [&](int64_t row) {
+        if (row >= n_rows) row = n_rows - 1;               // r is 0 there
+        const XT* xp = x + row * ldx + T * i;
+        RawRow o;
+        if constexpr (VEC) {
+            typedef XT vt __attribute__((ext_vector_type(T)));
+            const vt v = *reinterpret_cast<const vt*>(xp);
+#pragma unroll
+            for (int t = 0; t < T; ++t) o.v[t] = v[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) o.v[t] = (T * i + t < D) ? xp[t] : XT(0);
+        }
+        return o;
+    };
+
+    RawRow nxt = load_row(lo + g);
+    for (int64_t c0 = lo; c0 < hi; c0 += 64) {
+        // responsibilities of 64 samples, one per lane
+        const int64_t nl = c0 + lane;
+        double r_l = 0.0;
+        if (nl < hi) {
+            const double v = lr[nl];
+            if (direct_r) {
+                r_l = v;
+                if (v > 0.0) hsum = fma(v, log(v), hsum);
+            } else {
+                const double t = v - lse[nl];
+                r_l = exp(t);
+                hsum = fma(r_l, t, hsum);        // r ln r, with ln r = ln rho - lse exactly
+            }
+            nsum += r_l;
+        }
+#pragma unroll 2
+        for (int st = 0; st < 16; ++st) {
+            const RawRow cur = nxt;
+            nxt = load_row(c0 + 4 * (st + 1) + g);    // software prefetch of the next 4 samples
+            double xq[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) xq[t] = (T * i + t < D) ? (double)cur.v[t] - pv[t] : 0.0;
+            const double rr = __shfl(r_l, 4 * st + g);
+            double ra[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                ra[t] = rr * xq[t];
+                if (SUB == 0) asum[t] += ra[t];
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < T; ++t2) {
+#pragma unroll
+                for (int t1 = 0; t1 <= t2; ++t1) {
+                    const int p = pair_index(t2, t1);
+                    if (p % WS == SUB) acc[p / WS] = mfma_f64(ra[t1], xq[t2], acc[p / WS]);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (p % WS == SUB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(p * 4 + r) * 64 + lane] = acc[p / WS][r];
+        }
+    }
+    if (SUB == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const double v = sum_groups(asum[t]);
+            if (g == 0) out[P * 256 + T * i + t] = v;
+        }
+        nsum = sum_wave(nsum);
+        hsum = sum_wave(hsum);
+        if (lane == 0) {
+            out[P * 256 + 16 * T + 0] = nsum;
+            out[P * 256 + 16 * T + 1] = hsum;
+        }
+    }
+}
+
+template <int T, typename XT, bool VEC>
+__global__ __launch_bounds__(256) void mstep_mfma_f64(
+    const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+    const double* __restrict__ pivot,      // [D]
+    const double* __restrict__ lnrho,      // [K][npad]  (ln rho, or r itself when direct_r)
+    const double* __restrict__ lse,        // [npad]
+    int64_t npad, int K, int KG, int S, int64_t rows_per_split, int direct_r,
+    double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
+    constexpr int WS = mstep_ws(T);
+    constexpr int KPW = 4 / WS;            // components per workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // XCD-aware decode: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD
+    // whole row splits: all KG component groups of a split stream the same rows through one L2.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int j = bid >> 3;
+    const int kg = j % KG;
+    const int split = (j / KG) * 8 + xcd;
+    if (split >= S) return;
+    const int k = kg * KPW + wave / WS;
+    if (k >= K) return;
+    const int sub = wave % WS;
+
+    const int64_t lo = (int64_t)split * rows_per_split;
+    int64_t hi = lo + rows_per_split;
+    if (hi > n_rows) hi = n_rows;
+    const double* lr = lnrho + (int64_t)k * npad;
+    double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
+    if constexpr (WS == 1) {
+        mstep_body<T, 1, 0, XT, VEC>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+    } else {
+        if (sub == 0)
+            mstep_body<T, 2, 0, XT, VEC>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+        else
+            mstep_body<T, 2, 1, XT, VEC>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+    }
+}
+
+}  // namespace gmmvb

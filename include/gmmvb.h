@@ -1,0 +1,113 @@
+/*
+ * gmmvb.h — C ABI of the MI355X (gfx950) GMM variational-Bayes data-pass engine.
+ *
+ * The reference (bayesml/BayesML v0.3.1) is pure Python and has no FFI; its boundary for this
+ * path is the Python class contract of gaussianmixture.LearnModel.  These entry points are what
+ * a binding for that class calls in place of the two NumPy methods that touch the N-sized data:
+ *
+ *   _update_q_z(x)        bayesml/gaussianmixture/_gaussianmixture.py:772-784   (E-step)
+ *   _calc_n_x_bar_s(x)    bayesml/gaussianmixture/_gaussianmixture.py:725-732   (M-step statistics)
+ *   -sum xlogy(r, r)      bayesml/gaussianmixture/_gaussianmixture.py:704       (N-sized VL term)
+ *   estimate_latent_vars  bayesml/gaussianmixture/_gaussianmixture.py:1186-1193 (r / argmax read-out)
+ *
+ * Conventions
+ *   - every pointer argument named *_dev is a DEVICE pointer owned by the caller; `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work; they never
+ *     synchronise, never allocate (only gmmvb_workspace_create/destroy touch the allocator) and never throw.
+ *   - return value: GMMVB_OK or an error code; gmmvb_last_error() gives a thread-local message.
+ *   - all K-sized quantities and all outputs are IEEE binary64.  The sample matrix x stays in its
+ *     storage dtype (f32 or f64) in HBM and is widened on load; all arithmetic is f64
+ *     (v_mfma_f64_16x16x4_f64), because f32 arithmetic misses the 1e-5 parity target.
+ *   - supported shapes in this version: 1 <= D <= 128, K >= 1, n_rows <= max_rows.
+ */
+#ifndef GMMVB_H
+#define GMMVB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMMVB_ABI_VERSION 1
+
+enum gmmvb_status {
+    GMMVB_OK = 0,
+    GMMVB_EINVAL = 1,       /* bad argument (null pointer, bad shape, n_rows > max_rows, misaligned x) */
+    GMMVB_EUNSUPPORTED = 2, /* shape outside this version's range (D > 128)                            */
+    GMMVB_EHIP = 3,         /* a HIP runtime call failed (see gmmvb_last_error)                       */
+    GMMVB_ENOMEM = 4,       /* device allocation failed                                               */
+    GMMVB_ESTATE = 5        /* call order violated (e.g. mstep before estep / load_responsibilities)  */
+};
+
+enum gmmvb_dtype { GMMVB_F32 = 0, GMMVB_F64 = 1 };
+
+typedef struct gmmvb_workspace gmmvb_workspace;
+
+int gmmvb_abi_version(void);
+const char* gmmvb_last_error(void);
+
+/* Number of doubles in the statistics block written by gmmvb_mstep:
+ *   [ ns[K] | h[K] | a[K][D] | B[K][D][D] ]   (len = K*(2 + D + D*D))
+ * ns[k] = sum_n r_nk; h[k] = sum_n r_nk ln r_nk; a[k] = sum_n r_nk (x_n - pivot);
+ * B[k] = sum_n r_nk (x_n - pivot)(x_n - pivot)^T (exactly symmetric).
+ * The sums are linear in the rows, so row shards are combined by adding their blocks
+ * (one all-reduce per VB iteration).  The caller turns them into the reference's
+ * ns / x_bar_vecs / s_mats: x_bar = pivot + a/ns, S = B/ns - (a/ns)(a/ns)^T. */
+int64_t gmmvb_stats_len(int K, int D);
+
+/* Workspace on the CURRENT HIP device for up to max_rows rows of a [*, D] matrix of dtype x_dtype. */
+int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace** out);
+int gmmvb_workspace_destroy(gmmvb_workspace* ws);
+int64_t gmmvb_workspace_bytes(const gmmvb_workspace* ws);
+
+/* Expansion point for the second moments (default: zeros).  Any fixed vector near the data keeps
+ * B/ns - (a/ns)(a/ns)^T free of cancellation; results do not depend on it beyond rounding. */
+int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev /*[D]*/, void* stream);
+
+/* Posterior expectations consumed by the E-step, replacing the reads of _e_ln_pi_vec,
+ * _e_ln_lambda_dets, hn_kappas, hn_m_vecs and _e_lambda_mats at _gaussianmixture.py:773-781:
+ *   c[k]  = E[ln pi_k] + (E[ln det Lambda_k] - D ln 2pi - D/kappa_k)/2
+ *   m[k]  = hn_m_vecs[k]
+ *   u[k]  = lower-triangular D x D (row-major) with u^T u = E[Lambda_k] = nu_k W_k, so that
+ *           (x-m)^T E[Lambda_k] (x-m) = || u (x-m) ||^2.
+ * Packs them into the kernel layout (MFMA tiles + bias -u m). */
+int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev /*[K]*/, const double* m_dev /*[K][D]*/,
+                     const double* u_dev /*[K][D][D]*/, void* stream);
+
+/* E-step over rows [0, n_rows) of x (row stride ldx elements): ln rho_nk and the row log-normaliser
+ * ln sum_k exp(ln rho_nk) are left in the workspace (replaces _gaussianmixture.py:773-783). */
+int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream);
+
+/* Initialise from given responsibilities instead of an E-step (r row-major [n_rows][K]);
+ * used by the 'random_responsibility' restart (_gaussianmixture.py:734-736). */
+int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_t n_rows, void* stream);
+
+/* M-step statistics for the responsibilities currently in the workspace (replaces
+ * _gaussianmixture.py:725-732 and the N-sized term of :704).  stats_dev: gmmvb_stats_len doubles. */
+int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, double* stats_dev,
+                void* stream);
+
+/* gmmvb_estep followed by gmmvb_mstep (one VB data pass). */
+int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows,
+                      double* stats_dev, void* stream);
+
+/* Read-outs for rows [row0, row0 + n_rows) of the last E-step, row-major [n_rows][K]. */
+int gmmvb_responsibilities(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* r_dev, void* stream);
+int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
+int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_dev, void* stream);
+
+/* Optional in-library timing of the two dominant kernels with HIP events recorded on the launch
+ * stream immediately before/after the estep_mfma_f64 / mstep_mfma_f64 launches (bench.py's
+ * roofline leg).  gmmvb_profile_last_ms waits for the events of the last estep / mstep. */
+int gmmvb_profile_enable(gmmvb_workspace* ws, int on);
+int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms);
+
+/* Kernel names and launch geometry of the last estep/mstep (for profiling reports); returns a
+ * static string such as "estep_mfma_f64<8,2,f32,vec> grid=1024x256". */
+const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMMVB_H */
