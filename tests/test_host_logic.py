@@ -1,0 +1,270 @@
+"""Host-side logic of the drop-in on CPU: validators/exceptions, K-side math, restart driver, RNG
+consumption order and stdout protocol.  The N-sized data pass is supplied by tests/fake_engine.py
+(a CPU stand-in injected through the private test seam) so these run without a GPU; the HIP path
+itself is covered by tests/test_gpu_parity.py (-m gpu)."""
+import io
+import json
+import os
+import pickle
+import warnings
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_err
+from fake_engine import cpu_factory
+from oracle import gmm_vb_oracle as orc
+
+import bayesml_amd
+from bayesml_amd import _kside
+from bayesml_amd import gaussianmixture as gm
+
+
+def cpu_model(*a, **k):
+    m = gm.LearnModel(*a, **k)
+    m._data_pass_factory = cpu_factory
+    return m
+
+
+def quiet(fn, *a, **k):
+    with redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return fn(*a, **k)
+
+
+# ------------------------------------------------------------------ F5: boundary errors
+def _error_cases():
+    rng = np.random.default_rng(0)
+    return {
+        "ctor_float_degree": lambda: gm.LearnModel(3, 2.0),
+        "ctor_zero_classes": lambda: gm.LearnModel(0, 2),
+        "ctor_bool_like_negative": lambda: gm.LearnModel(3, -1),
+        "h0_m_vecs_wrong_dim": lambda: gm.LearnModel(3, 2, h0_m_vecs=np.zeros((3, 3))),
+        "h0_w_mats_not_pd": lambda: gm.LearnModel(3, 2, h0_w_mats=np.array([[1.0, 2.0], [2.0, 1.0]])),
+        "h0_w_mats_not_sym": lambda: gm.LearnModel(3, 2, h0_w_mats=np.array([[1.0, 0.5], [0.0, 1.0]])),
+        "h0_nus_too_small": lambda: gm.LearnModel(3, 2, h0_nus=1.0),
+        "h0_alpha_nonpos": lambda: gm.LearnModel(3, 2, h0_alpha_vec=np.array([1.0, 0.0, 1.0])),
+        "h0_kappas_negative": lambda: gm.LearnModel(3, 2, h0_kappas=-1.0),
+        "x_wrong_last_dim": lambda: quiet(cpu_model(3, 2).update_posterior, np.zeros((10, 3))),
+        "x_not_ndarray": lambda: quiet(cpu_model(3, 2).update_posterior, [[0.0, 1.0]]),
+        "x_complex": lambda: quiet(cpu_model(3, 2).update_posterior, np.zeros((4, 2), dtype=complex)),
+        "bad_init_type": lambda: quiet(cpu_model(3, 2, seed=0).update_posterior, rng.standard_normal((50, 2)),
+                                       init_type="kmeans"),
+        "bad_loss_estimate_params": lambda: gm.LearnModel(3, 2).estimate_params("L1"),
+        "bad_loss_make_prediction": lambda: gm.LearnModel(3, 2).make_prediction("KL"),
+        "bad_loss_latent": lambda: cpu_model(3, 2).estimate_latent_vars(np.zeros((4, 2)), "L1"),
+        "pred_and_update_wrong_shape": lambda: quiet(cpu_model(3, 2).pred_and_update, np.zeros((1, 2))),
+        "gen_pi_not_sum1": lambda: gm.GenModel(3, 2, pi_vec=np.array([0.5, 0.4, 0.2])),
+        "gen_sample_size_float": lambda: gm.GenModel(3, 2).gen_sample(10.0),
+        "visualize_d3": lambda: quiet(gm.LearnModel(2, 3).visualize_posterior),
+        "ctor_numpy_int": lambda: gm.LearnModel(np.int64(3), np.int32(2)),
+        "h0_scalar_broadcast": lambda: gm.LearnModel(3, 2, h0_kappas=2.0, h0_nus=3, h0_w_mats=np.eye(2) * 2),
+        "x_int_dtype": lambda: quiet(cpu_model(2, 2, seed=0).update_posterior,
+                                     np.random.default_rng(0).integers(-5, 5, (40, 2)), num_init=1, max_itr=2),
+        "x_3d_reshaped": lambda: quiet(cpu_model(2, 2, seed=0).update_posterior,
+                                       np.random.default_rng(0).standard_normal((5, 8, 2)), num_init=1, max_itr=2),
+    }
+
+
+def test_boundary_errors_match_reference_classes():
+    with open(os.path.join(GOLDEN, "gmm_errors.json")) as f:
+        expected = json.load(f)
+    cases = _error_cases()
+    assert set(cases) == set(expected)
+    for name, fn in cases.items():
+        try:
+            fn()
+            got = None
+        except Exception as e:      # noqa: BLE001
+            got = type(e).__name__
+        assert got == expected[name], (name, got, expected[name])
+
+
+def test_exception_classes_and_str():
+    e = bayesml_amd.ParameterFormatError("bad")
+    assert str(e) == "'bad'" and e.value == "bad"
+    assert issubclass(bayesml_amd.ResultWarning, UserWarning)
+
+
+# ------------------------------------------------------------------ API surface
+def test_constructor_defaults_and_dict_key_order():
+    m = gm.LearnModel(4, 3)
+    assert list(m.get_h0_params()) == ["h0_alpha_vec", "h0_m_vecs", "h0_kappas", "h0_nus", "h0_w_mats"]
+    assert list(m.get_hn_params()) == ["hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"]
+    assert list(m.get_p_params()) == ["p_mu_vecs", "p_nus", "p_lambda_mats"]
+    assert m.get_constants() == {"c_num_classes": 4, "c_degree": 3}
+    assert np.all(m.h0_alpha_vec == 0.5) and np.all(m.h0_nus == 3) and np.all(m.h0_kappas == 1)
+    assert np.array_equal(m.h0_w_mats, np.tile(np.eye(3), (4, 1, 1)))
+    assert m.get_hn_params()["hn_m_vecs"] is m.hn_m_vecs          # getters return live arrays
+    assert m.r_vecs is None
+    g = gm.GenModel(4, 3)
+    assert list(g.get_h_params()) == ["h_alpha_vec", "h_m_vecs", "h_kappas", "h_nus", "h_w_mats"]
+    assert list(g.get_params()) == ["pi_vec", "mu_vecs", "lambda_mats"]
+
+
+def test_pickle_roundtrips_are_positional(tmp_path):
+    m = gm.LearnModel(3, 2, h0_kappas=2.0, h0_nus=np.array([3.0, 4.0, 5.0]))
+    f = str(tmp_path / "h0.pkl")
+    m.save_h0_params(f)
+    m2 = gm.LearnModel(3, 2).load_h0_params(f)
+    assert np.array_equal(m2.h0_nus, [3.0, 4.0, 5.0]) and np.all(m2.h0_kappas == 2.0)
+    m2.load_hn_params(f)                   # an h0 dict loads into hn positionally (reference base.py:251)
+    assert np.array_equal(m2.hn_nus, [3.0, 4.0, 5.0])
+    with open(f, "wb") as fh:
+        pickle.dump([1, 2], fh)
+    with pytest.raises(bayesml_amd.ParameterFormatError):
+        m2.load_h0_params(f)
+    g = gm.GenModel(3, 2, seed=1)
+    g.gen_params()
+    fp = str(tmp_path / "p.pkl")
+    g.save_params(fp)
+    g2 = gm.GenModel(3, 2).load_params(fp)
+    assert np.array_equal(g2.mu_vecs, g.mu_vecs)
+
+
+def test_gen_sample_reproduces_reference_stream():
+    """Same seed, same per-row call order => the fixture the reference's GenModel generated."""
+    gen = gm.GenModel(3, 2, pi_vec=np.array([0.3, 0.3, 0.4]),
+                      mu_vecs=np.array([[-4.0, 0.0], [4.0, 0.0], [0.0, 5.0]]),
+                      lambda_mats=np.array([[[1.0, 0.3], [0.3, 2.0]], [[2.0, 0.0], [0.0, 0.5]], [[1.0, -0.4], [-0.4, 1.0]]]),
+                      seed=123)
+    x, z = gen.gen_sample(1000)
+    ref = load_golden("gmm_c1_sample.npz")
+    assert np.array_equal(z, ref["z"])
+    assert np.allclose(x, ref["x"], rtol=1e-13, atol=1e-13)
+
+
+def test_subsample_index_draw_consumes_stream_like_row_draw():
+    """rng.choice(x, n, replace=False, axis=0, shuffle=False) == x[rng.choice(N, n, replace=False, shuffle=False)]."""
+    x = np.random.default_rng(3).standard_normal((1000, 4))
+    a, b = np.random.default_rng(7), np.random.default_rng(7)
+    for _ in range(5):
+        rows = a.choice(x, size=31, replace=False, axis=0, shuffle=False)
+        idx = b.choice(1000, size=31, replace=False, shuffle=False)
+        assert np.array_equal(rows, x[idx])
+    assert a.random() == b.random()
+
+
+# ------------------------------------------------------------------ F2: K-side math on CPU tensors
+F1 = ["gmm_f1_c1_k3_d2_n1000.npz", "gmm_f1_k16_d32_n2048.npz", "gmm_f1_k4_d128_n32768_f32.npz"]
+
+
+@pytest.mark.parametrize("name", F1)
+def test_k_side_update_matches_reference(name):
+    g = load_golden(name)
+    K, D = int(g["K"]), int(g["D"])
+    m = gm.LearnModel(K, D)
+    p = m._prior_tensors("cpu")
+    assert abs(p.ln_c_alpha - float(orc.Prior.default(K, D).ln_c_alpha)) < 1e-12
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)   # noqa: E731
+    q = _kside.update_q(p, t(g["ns"]), t(g["x_bar_vecs"]), t(g["s_mats"]))
+    for mine, key, tol in ((q.alpha, "hn_alpha_vec", 1e-14), (q.m, "hn_m_vecs", 1e-13), (q.kappa, "hn_kappas", 1e-14),
+                           (q.nu, "hn_nus", 1e-14), (q.w_inv, "hn_w_mats_inv", 1e-13), (q.w, "hn_w_mats", 1e-9),
+                           (q.e_ln_pi, "e_ln_pi_vec", 1e-12), (q.e_ln_lambda_det, "e_ln_lambda_dets", 1e-11),
+                           (q.nu[:, None, None] * q.w, "e_lambda_mats", 1e-9), (q.ln_b_w_nu, "ln_b_hn_w_nus", 1e-11)):
+        assert rel_err(mine.numpy(), g["out_" + key]) < tol, key
+    # whitening factor: u^T u = E[Lambda]
+    assert rel_err((q.u.transpose(1, 2) @ q.u).numpy(), g["out_e_lambda_mats"]) < 1e-9
+    assert float(torch.triu(q.u, diagonal=1).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", F1[:2])
+def test_lower_bound_matches_reference(name):
+    g = load_golden(name)
+    K, D = int(g["K"]), int(g["D"])
+    m = gm.LearnModel(K, D)
+    p = m._prior_tensors("cpu")
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)   # noqa: E731
+    q = _kside.features(_kside.PostT(t(g["in_hn_alpha_vec"]), t(g["in_hn_m_vecs"]), t(g["in_hn_kappas"]),
+                                     t(g["in_hn_nus"]), t(g["in_hn_w_mats_inv"])))
+    terms = _kside.lower_bound(p, q, t(g["ns"]), t(g["x_bar_vecs"]), t(g["s_mats"]), -t(g["vl_q_z"]))
+    for key in ("p_x", "p_z", "p_pi", "p_mu_lambda", "q_z", "q_pi", "q_mu_lambda", "vl"):
+        ref = float(g["vl" if key == "vl" else "vl_" + key])
+        assert abs(float(terms[key]) - ref) <= 1e-10 * max(1.0, abs(ref)), key
+
+
+def test_moments_guard_for_empty_components():
+    ns = torch.tensor([2.0, 0.0], dtype=torch.float64)
+    a = torch.tensor([[2.0, 4.0], [0.0, 0.0]], dtype=torch.float64)
+    B = torch.stack([torch.eye(2, dtype=torch.float64) * 10, torch.zeros(2, 2, dtype=torch.float64)])
+    prev = torch.full((2, 2, 2), 7.0, dtype=torch.float64)
+    x_bar, s = _kside.moments_from_stats(ns, a, B, torch.tensor([1.0, 1.0], dtype=torch.float64), prev)
+    assert torch.equal(x_bar[0], torch.tensor([2.0, 3.0], dtype=torch.float64))
+    assert torch.equal(x_bar[1], torch.zeros(2, dtype=torch.float64))        # raw zero sum (ref:727,729)
+    assert torch.equal(s[1], prev[1])                                         # untouched (ref:729)
+    assert torch.allclose(s[0], torch.tensor([[4.0, -2.0], [-2.0, 1.0]], dtype=torch.float64))
+
+
+# ------------------------------------------------------------------ F3: the restart driver on the CPU stand-in
+DRIVER = ["gmm_f3_c1_subsampling.npz", "gmm_f3_c1_random_resp.npz", "gmm_f3_c1_noconv.npz", "gmm_f3_n1.npz"]
+
+
+@pytest.mark.parametrize("name", DRIVER)
+def test_driver_protocol_and_rng_order(name):
+    g = load_golden(name)
+    x = g["x"] if "x" in g else load_golden("gmm_c1_sample.npz")["x"]
+    K, D = int(g["K"]), int(g["D"])
+    kw = json.loads(str(g["kw"]))
+    m = cpu_model(K, D, seed=int(g["seed"]))
+    buf = io.StringIO()
+    with warnings.catch_warnings(record=True) as w, redirect_stdout(buf):
+        warnings.simplefilter("always")
+        ret = m.update_posterior(x, **kw)
+    assert ret is m
+    assert any(issubclass(i.category, bayesml_amd.ResultWarning) for i in w) == bool(g["result_warning"])
+    lines = [ln for ln in buf.getvalue().split("\n") if ln.strip()]
+    tr = g["vl_trace"]
+    assert len(lines) == tr.shape[0]
+    assert max(i for i, ln in enumerate(lines) if ln.endswith("*")) == int(g["winner"])
+    conv = ["(converged)" in ln for ln in lines]
+    assert conv == [bool(c) for c in g["converged"]]
+    for i, ln in enumerate(lines):
+        segs = [s for s in ln.split("\r") if s]
+        assert segs[0].startswith(f"{i}. VL: ")
+        ref = tr[i][~np.isnan(tr[i])]
+        assert len(segs) == len(ref)
+        for j, s in enumerate(segs[1:]):
+            assert f" t={j} " in s
+        vals = [float(s.split("VL: ")[1].split(" ")[0].rstrip("*")) for s in segs]
+        assert np.allclose(vals, ref, rtol=1e-8)
+    for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+        assert rel_err(m.get_hn_params()[key], g[key]) < 1e-7, key
+    assert rel_err(m.ns, g["ns"]) < 1e-7
+    assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+    if "est_sq_pi" in g:
+        for key in ("p_mu_vecs", "p_nus", "p_lambda_mats"):      # stale until calc_pred_dist, like the reference
+            assert np.allclose(m.get_p_params()[key], g["stale_" + key], rtol=1e-12, atol=1e-300), key
+        assert np.allclose(m.make_prediction("squared"), g["stale_pred_squared"], atol=1e-12)
+        m.calc_pred_dist()
+        assert rel_err(m.make_prediction("squared"), g["pred_squared"]) < 1e-7
+        pi01, _, lam01 = quiet(m.estimate_params, "0-1")
+        assert np.allclose(pi01, g["est_01_pi"], rtol=1e-7, equal_nan=True)
+        assert np.allclose(lam01, g["est_01_lambda"], rtol=1e-6, equal_nan=True)
+        kl = m.estimate_params("KL")
+        assert len(kl[1]) == K and len(kl[2]) == K
+
+
+def test_num_init_zero_keeps_posterior_and_warns():
+    x = load_golden("gmm_c1_sample.npz")["x"]
+    m = cpu_model(3, 2, seed=0)
+    before = {k: v.copy() for k, v in m.get_hn_params().items()}
+    with pytest.warns(bayesml_amd.ResultWarning):
+        quiet_out = io.StringIO()
+        with redirect_stdout(quiet_out):
+            m.update_posterior(x, num_init=0)
+    for k, v in before.items():
+        assert np.array_equal(m.get_hn_params()[k], v)
+    assert m.r_vecs.shape == (1000, 3) and abs(m.ns.sum() - 1000) < 1e-9
+
+
+def test_pred_and_update_and_latent_update_paths():
+    x = load_golden("gmm_c1_sample.npz")["x"]
+    m = cpu_model(3, 2, seed=0)
+    quiet(m.update_posterior, x[:200], num_init=2, max_itr=20)
+    pred = quiet(m.pred_and_update, x[200], num_init=1, max_itr=5)
+    assert pred.shape == (2,)
+    assert np.allclose(m.h0_m_vecs, m.h0_m_vecs) and m.hn_kappas.sum() > m.h0_kappas.sum() - 1e-9
+    z = quiet(m.estimate_latent_vars_and_update, x[201:260], num_init=1, max_itr=5)
+    assert z.shape == (59, 3) and np.all(z.sum(axis=1) == 1)

@@ -1,0 +1,86 @@
+"""world_size = 2 (gloo, CPU): row-sharded update_posterior equals the single-process run.
+
+Covers the N > 1 host path of bench.py / LearnModel(comm=RowShard()): per-rank row blocks, global
+subsample indices, ONE all-reduce of the statistics block per VB iteration.  The data pass is the CPU
+stand-in of tests/fake_engine.py (the HIP kernels are covered by -m gpu tests; their linearity over
+row shards by test_gpu_parity.py::test_linearity_over_row_shards_full_width)."""
+import io
+import os
+import socket
+import warnings
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden, rel_err
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, cuts, kw, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_engine import cpu_factory
+    from bayesml_amd import RowShard
+    from bayesml_amd import gaussianmixture as gm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = load_golden("gmm_c1_sample.npz")["x"]
+    m = gm.LearnModel(3, 2, seed=0, comm=RowShard())
+    m._data_pass_factory = cpu_factory
+    with redirect_stdout(io.StringIO()) as buf, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.update_posterior(x[cuts[rank]:cuts[rank + 1]], **kw)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), vl=m.vl, ns=m.ns, stdout=buf.getvalue(),
+             r_rows=m.r_vecs.shape[0], **m.get_hn_params())
+    dist.destroy_process_group()
+
+
+def _run(kw, tmp_path):
+    cuts = [0, 437, 1000]                       # deliberately uneven
+    mp.spawn(_worker, args=(2, _free_port(), cuts, kw, str(tmp_path)), nprocs=2, join=True)
+    return [dict(np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))) for r in range(2)], cuts
+
+
+def _single(kw):
+    from fake_engine import cpu_factory
+    from bayesml_amd import gaussianmixture as gm
+    m = gm.LearnModel(3, 2, seed=0)
+    m._data_pass_factory = cpu_factory
+    with redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.update_posterior(load_golden("gmm_c1_sample.npz")["x"], **kw)
+    return m
+
+
+def test_two_rank_subsampling_equals_single_process(tmp_path):
+    kw = dict(num_init=3, max_itr=30)
+    ranks, cuts = _run(kw, tmp_path)
+    one = _single(kw)
+    for r, res in enumerate(ranks):
+        for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+            assert rel_err(res[key], one.get_hn_params()[key]) < 1e-9, (r, key)
+        assert abs(float(res["vl"]) - one.vl) < 1e-8 * abs(one.vl)
+        assert rel_err(res["ns"], one.ns) < 1e-9                 # statistics are the all-reduced, global ones
+        assert int(res["r_rows"]) == cuts[r + 1] - cuts[r]       # responsibilities stay local to the shard
+    assert str(ranks[0]["stdout"]).count("\n") == 3 and str(ranks[1]["stdout"]) == ""   # only rank 0 prints
+    # and the sharded run still matches the reference fixture
+    g = load_golden("gmm_f3_c1_subsampling.npz")
+    assert rel_err(_single(dict()).hn_m_vecs, g["hn_m_vecs"]) < 1e-7
+
+
+def test_two_rank_random_responsibility(tmp_path):
+    kw = dict(num_init=2, max_itr=15, init_type="random_responsibility")
+    ranks, _ = _run(kw, tmp_path)
+    one = _single(kw)
+    for res in ranks:
+        assert rel_err(res["hn_w_mats"], one.hn_w_mats) < 1e-9
+        assert rel_err(res["hn_m_vecs"], one.hn_m_vecs) < 1e-9
