@@ -96,7 +96,8 @@ def test_full_driver(name, xsrc):
     kw = json.loads(str(g["kw"]))
     p = orc.Prior.default(K, D)
     q0 = orc.Posterior.from_prior(p)
-    res = orc.update_posterior(x, p, q0, np.random.default_rng(int(g["seed"])), **kw)
+    # the fixture was made by feeding the reference x.astype(float64) (see make_golden.full_driver)
+    res = orc.update_posterior(x.astype(np.float64), p, q0, np.random.default_rng(int(g["seed"])), **kw)
     assert res.winner == int(g["winner"])
     assert (not res.converged_any) == bool(g["result_warning"])
     tr = g["vl_trace"]
