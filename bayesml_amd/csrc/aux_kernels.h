@@ -4,29 +4,31 @@
 
 namespace gmmvb {
 
-// u [K][D][D] lower triangular (y = u d)  ->  upack [K][P][16][16] (zero padded), bpack = -(u m).
+// u [K][D][D] lower triangular (y = u d)  ->  per-component parameter image (layout: estep.h)
+//   [P][half][lane][2] tiles of u (zero padded to 16T) | [T][g][r] bias = -(u m) | zero pad to 1 KB
 __global__ void pack_params_kernel(const double* __restrict__ u, const double* __restrict__ m, int K, int D,
-                                   int T, double* __restrict__ upack, double* __restrict__ bpack) {
+                                   int T, int img_len, double* __restrict__ img) {
     const int k = blockIdx.x;
     const int P = tri_pairs(T);
     const double* uk = u + (int64_t)k * D * D;
-    double* up = upack + (int64_t)k * P * 256;
+    double* im = img + (int64_t)k * img_len;
     for (int e = threadIdx.x; e < P * 256; e += blockDim.x) {
-        const int p = e >> 8, row = (e >> 4) & 15, col = e & 15;
+        const int p = e >> 8, h = (e >> 7) & 1, lane = (e >> 1) & 63, ee = e & 1;
         int jt = 0;
         while (tri_pairs(jt + 1) <= p) ++jt;
         const int b = p - tri_pairs(jt);
-        const int jj = 16 * jt + row, ii = 16 * b + col;
-        up[e] = (jj < D && ii < D && ii <= jj) ? uk[(int64_t)jj * D + ii] : 0.0;
+        const int jj = 16 * jt + (lane & 15), ii = 16 * b + 4 * (lane >> 4) + 2 * h + ee;
+        im[e] = (jj < D && ii < D && ii <= jj) ? uk[(int64_t)jj * D + ii] : 0.0;
     }
     const double* mk = m + (int64_t)k * D;
     for (int jj = threadIdx.x; jj < 16 * T; jj += blockDim.x) {
         double s = 0.0;
         if (jj < D)
             for (int ii = 0; ii <= jj; ++ii) s = fma(uk[(int64_t)jj * D + ii], mk[ii], s);
-        const int jt = jj >> 4, w = jj & 15, g = w & 3, r = w >> 2;   // row = g + 4 r
-        bpack[(((int64_t)k * T + jt) * 4 + g) * 4 + r] = -s;
+        const int jt = jj >> 4, w = jj & 15, g = w & 3, r = w >> 2;   // accumulator row = g + 4 r
+        im[P * 256 + (jt * 4 + g) * 4 + r] = -s;
     }
+    for (int e = P * 256 + 16 * T + threadIdx.x; e < img_len; e += blockDim.x) im[e] = 0.0;
 }
 
 // lse[n] = ln sum_k exp(lnrho[k][n]) (single pass, running max); optional argmax.

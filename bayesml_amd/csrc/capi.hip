@@ -3,6 +3,7 @@
 #include "../../include/gmmvb.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -35,8 +36,9 @@ struct gmmvb_workspace {
     int num_cu = 0, KG = 0, S_cap = 0;
     double* lnrho = nullptr;   // [K][npad]
     double* lse = nullptr;     // [npad]
-    double* upack = nullptr;   // [K][P][256]
-    double* bpack = nullptr;   // [K][T][16]
+    double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
+    int img_len = 0;
+    int estep_variant = 0;     // kEstepLds (default) or kEstepDirect (env GMMVB_ESTEP_VARIANT=direct)
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* slabs = nullptr;   // [S_cap][K][slab_len]
@@ -88,10 +90,14 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     }
     ws->S_cap = (int)round_up(((int64_t)4 * ws->num_cu + ws->KG - 1) / ws->KG, 8);
     if (ws->S_cap < 8) ws->S_cap = 8;
-    const int P = tri_pairs(ws->T);
+    ws->img_len = estep_image_doubles(ws->T);
+    {
+        const char* v = std::getenv("GMMVB_ESTEP_VARIANT");
+        ws->estep_variant = (v && std::strcmp(v, "direct") == 0) ? kEstepDirect : kEstepLds;
+    }
     struct { double** p; int64_t n; } bufs[] = {
         {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},
-        {&ws->upack, (int64_t)K * P * 256},  {&ws->bpack, (int64_t)K * ws->T * 16},
+        {&ws->img, (int64_t)K * ws->img_len},
         {&ws->cvec, K},                      {&ws->pivot, D},
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)}};
     for (auto& b : bufs) {
@@ -113,7 +119,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
-    double* bufs[] = {ws->lnrho, ws->lse, ws->upack, ws->bpack, ws->cvec, ws->pivot, ws->slabs};
+    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws->ev)
@@ -169,7 +175,7 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
     hipError_t e = hipMemcpyAsync(ws->cvec, c_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(c)", e);
     hipLaunchKernelGGL(pack_params_kernel, dim3(ws->K), dim3(256), 0, st, u_dev, m_dev, ws->K, ws->D, ws->T,
-                       ws->upack, ws->bpack);
+                       ws->img_len, ws->img);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_kernel", e);
     ws->have_params = true;
@@ -198,10 +204,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const int64_t tiles = (n_rows + rpw - 1) / rpw;
     int64_t grid = (tiles + 3) / 4;
     if (grid > (1 << 20)) grid = 1 << 20;
-    EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->upack, ws->bpack, ws->cvec, ws->K, ws->lnrho, ws->npad};
+    EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
     const char* name = "";
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
-    hipError_t e = launch_estep(ws->T, is64, vec, (int)grid, st, a, &name);
+    hipError_t e = launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
     if (ws->prof) {
         (void)hipEventRecord(ws->ev[1], st);

@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256) void estep_lds_f64(const XT* __restrict__ x, i
         const int pieces = kcount * (IMG / 128);
         const double* src = img + (int64_t)k0 * IMG + lane * 2;
         for (int piece = wave; piece < pieces; piece += 4)
-            __builtin_amdgcn_global_load_lds(
-                reinterpret_cast<const __attribute__((address_space(1))) void*>(src + piece * 128),
-                reinterpret_cast<__attribute__((address_space(3))) void*>(&smem[buf][piece * 128]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 128),
+                                             (__attribute__((address_space(3))) void*)(&smem[buf][piece * 128]), 16, 0,
+                                             0);
     };
 
     for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {

@@ -1,32 +1,37 @@
-// Instantiations of the E-step kernel for T = ceil(D/16) in 1..8, x in {f32, f64}.
+// Instantiations of the E-step kernels for T = ceil(D/16) in 1..8, x in {f32, f64}.
 #include "estep.h"
 #include "launch.h"
 
 namespace gmmvb {
 
 template <int T, typename XT, bool VEC>
-static hipError_t go(int grid, hipStream_t st, const EstepArgs& a) {
-    hipLaunchKernelGGL((estep_mfma_f64<T, XT, VEC>), dim3(grid), dim3(256), 0, st,
-                       static_cast<const XT*>(a.x), a.ldx, a.n_rows, a.D, a.upack, a.bpack, a.cvec, a.K, a.lnrho,
-                       a.npad);
+static hipError_t go(int variant, int grid, hipStream_t st, const EstepArgs& a) {
+    if (variant == kEstepDirect)
+        hipLaunchKernelGGL((estep_mfma_f64<T, XT, VEC>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx,
+                           a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
+    else
+        hipLaunchKernelGGL((estep_lds_f64<T, XT, VEC>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx,
+                           a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
     return hipGetLastError();
 }
 
 int estep_rows_per_wave(int T, int x_is_f64) {
     return 16 * (x_is_f64 ? estep_nb<double>(T) : estep_nb<float>(T));
 }
+int estep_image_doubles(int T) { return img_doubles(T); }
 
-#define CASE(TT)                                                                                  \
-    case TT:                                                                                      \
-        if (x_is_f64) {                                                                           \
-            *name = vec ? "estep_mfma_f64<T=" #TT ",x=f64,vec>" : "estep_mfma_f64<T=" #TT ",x=f64,masked>"; \
-            return vec ? go<TT, double, true>(grid, st, a) : go<TT, double, false>(grid, st, a);  \
-        } else {                                                                                  \
-            *name = vec ? "estep_mfma_f64<T=" #TT ",x=f32,vec>" : "estep_mfma_f64<T=" #TT ",x=f32,masked>"; \
-            return vec ? go<TT, float, true>(grid, st, a) : go<TT, float, false>(grid, st, a);    \
+#define NAME(V, TT, X, M) (V == kEstepDirect ? "estep_mfma_f64<T=" #TT ",x=" X "," M ">" : "estep_lds_f64<T=" #TT ",x=" X "," M ">")
+#define CASE(TT)                                                                                         \
+    case TT:                                                                                             \
+        if (x_is_f64) {                                                                                  \
+            *name = vec ? NAME(variant, TT, "f64", "vec") : NAME(variant, TT, "f64", "masked");          \
+            return vec ? go<TT, double, true>(variant, grid, st, a) : go<TT, double, false>(variant, grid, st, a); \
+        } else {                                                                                         \
+            *name = vec ? NAME(variant, TT, "f32", "vec") : NAME(variant, TT, "f32", "masked");          \
+            return vec ? go<TT, float, true>(variant, grid, st, a) : go<TT, float, false>(variant, grid, st, a);   \
         }
 
-hipError_t launch_estep(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
+hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
                         const char** name) {
     switch (T) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)

@@ -7,7 +7,7 @@ namespace gmmvb {
 
 struct EstepArgs {
     const void* x; int64_t ldx; int64_t n_rows; int D;
-    const double* upack; const double* bpack; const double* cvec; int K;
+    const double* img; const double* cvec; int K;
     double* lnrho; int64_t npad;
 };
 struct MstepArgs {
@@ -16,12 +16,15 @@ struct MstepArgs {
     int K; int KG; int S; int64_t rows_per_split; int direct_r; double* slabs;
 };
 
-// rows of x handled by one E-step wave for (T, dtype)
+// rows of x handled by one E-step wave for (T, dtype); doubles per component parameter image
 int estep_rows_per_wave(int T, int x_is_f64);
+int estep_image_doubles(int T);
+enum EstepVariant { kEstepLds = 0, kEstepDirect = 1 };
 // components handled by one M-step workgroup for T feature tiles (4 waves / waves-per-component)
 int mstep_components_per_wg(int T);
 // returns hipSuccess or the launch error; `name` receives a static description of the instantiation
-hipError_t launch_estep(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a, const char** name);
+hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
+                        const char** name);
 hipError_t launch_mstep(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const MstepArgs& a, const char** name);
 
 }  // namespace gmmvb
