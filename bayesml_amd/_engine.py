@@ -29,6 +29,7 @@ SYMBOLS = {
     "gmmvb_workspace_bytes": (_i64, [_vp]),
     "gmmvb_set_pivot": (_int, [_vp, _vp, _vp]),
     "gmmvb_set_params": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "gmmvb_prepare_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_estep": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_load_responsibilities": (_int, [_vp, _vp, _i64, _vp]),
     "gmmvb_mstep": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
@@ -158,6 +159,13 @@ class DataPass:
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.gmmvb_set_pivot(self._ws, p.data_ptr(), self._stream()), "gmmvb_set_pivot")
         self.pivot = p
+
+    def prepare_rows(self, x: torch.Tensor):
+        """Build the centred f64 copy the M-step streams (once per sample matrix, after set_pivot)."""
+        x, ldx = self._x(x)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_prepare_rows(self._ws, x.data_ptr(), ldx, x.shape[0], self._stream()),
+                   "gmmvb_prepare_rows")
 
     def set_params(self, c, m, u):
         c = _f64(c, (self.K,), self.device)

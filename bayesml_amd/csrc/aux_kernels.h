@@ -31,6 +31,18 @@ __global__ void pack_params_kernel(const double* __restrict__ u, const double* _
     for (int e = P * 256 + 16 * T + threadIdx.x; e < img_len; e += blockDim.x) im[e] = 0.0;
 }
 
+// xc[n][f] = (double)x[n][f] - pivot[f] for f < D, 0 for D <= f < Dp (Dp = 16T): the M-step's operand,
+// made once per sample matrix so its inner loop carries no convert / subtract / mask work.
+template <typename XT>
+__global__ void center_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D, int Dp,
+                                   const double* __restrict__ pivot, double* __restrict__ xc) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * Dp) return;
+    const int64_t n = e / Dp;
+    const int f = (int)(e - n * Dp);
+    xc[e] = f < D ? (double)x[n * ldx + f] - pivot[f] : 0.0;
+}
+
 // lse[n] = ln sum_k exp(lnrho[k][n]) (single pass, running max); optional argmax.
 __global__ void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows, int K,
                                double* __restrict__ lse) {

@@ -38,10 +38,13 @@ struct gmmvb_workspace {
     double* lse = nullptr;     // [npad]
     double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
     int img_len = 0;
-    int estep_variant = 0;     // kEstepLds (default) or kEstepDirect (env GMMVB_ESTEP_VARIANT=direct)
+    int estep_variant = 0;     // kEstepLds (default); env GMMVB_ESTEP_VARIANT=direct|lds8 selects the others
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* slabs = nullptr;   // [S_cap][K][slab_len]
+    double* xc = nullptr;      // [npad][16T] centred f64 copy of the sample matrix (M-step operand), optional
+    const void* xc_src = nullptr;   // the x it was made from (null = not prepared)
+    int64_t xc_rows = 0, xc_ldx = 0;
     int64_t bytes = 0;
     bool have_params = false;
     int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly
@@ -93,14 +96,22 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     ws->img_len = estep_image_doubles(ws->T);
     {
         const char* v = std::getenv("GMMVB_ESTEP_VARIANT");
-        ws->estep_variant = (v && std::strcmp(v, "direct") == 0) ? kEstepDirect : kEstepLds;
+        ws->estep_variant = kEstepLds;
+        if (v && std::strcmp(v, "direct") == 0) ws->estep_variant = kEstepDirect;
+        if (v && std::strcmp(v, "lds8") == 0) ws->estep_variant = kEstepLds8;
     }
     struct { double** p; int64_t n; } bufs[] = {
         {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},
         {&ws->img, (int64_t)K * ws->img_len},
         {&ws->cvec, K},                      {&ws->pivot, D},
-        {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)}};
+        {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
+        {&ws->xc, 0}};
+    {
+        const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
+        if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = ws->npad * 16 * (int64_t)ws->T;
+    }
     for (auto& b : bufs) {
+        if (b.n == 0) continue;
         e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
         if (e != hipSuccess) {
             gmmvb_workspace_destroy(ws);
@@ -119,7 +130,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
-    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs};
+    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws->ev)
@@ -165,6 +176,7 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
     hipError_t e = hipMemcpyAsync(ws->pivot, pivot_dev, (size_t)ws->D * sizeof(double), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(pivot)", e);
+    ws->xc_src = nullptr;      // the centred copy (if any) is stale now
     return GMMVB_OK;
 }
 
@@ -193,6 +205,29 @@ static int check_x(const gmmvb_workspace* ws, const void* x_dev, int64_t ldx, in
     return GMMVB_OK;
 }
 
+int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream) {
+    bool vec = false;
+    int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
+    if (rc) return rc;
+    if (!ws->xc) return GMMVB_OK;      // disabled: the M-step reads x directly
+    const int Dp = 16 * ws->T;
+    const int64_t total = n_rows * Dp;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (ws->x_dtype == GMMVB_F64)
+        hipLaunchKernelGGL(center_rows_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)x_dev, ldx, n_rows,
+                           ws->D, Dp, ws->pivot, ws->xc);
+    else
+        hipLaunchKernelGGL(center_rows_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x_dev, ldx, n_rows,
+                           ws->D, Dp, ws->pivot, ws->xc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
+    ws->xc_src = x_dev;
+    ws->xc_rows = n_rows;
+    ws->xc_ldx = ldx;
+    return GMMVB_OK;
+}
+
 int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream) {
     bool vec = false;
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
@@ -200,9 +235,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (!ws->have_params) return fail(GMMVB_ESTATE, "gmmvb_set_params has not been called");
     hipStream_t st = (hipStream_t)stream;
     const int is64 = ws->x_dtype == GMMVB_F64;
-    const int rpw = estep_rows_per_wave(ws->T, is64);
-    const int64_t tiles = (n_rows + rpw - 1) / rpw;
-    int64_t grid = (tiles + 3) / 4;
+    const int rpw = estep_rows_per_wg(ws->estep_variant, ws->T, is64);
+    int64_t grid = (n_rows + rpw - 1) / rpw;
     if (grid > (1 << 20)) grid = 1 << 20;
     EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
     const char* name = "";
@@ -220,7 +254,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
     ws->e_state = 1;
     ws->e_rows = n_rows;
-    std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx256 rows/wave=%d", name, (long long)grid, rpw);
+    std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
+                  estep_threads(ws->estep_variant), rpw);
     return GMMVB_OK;
 }
 
@@ -253,11 +288,17 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const int64_t rows_per_split = round_up((n_rows + S - 1) / S, 64);
     S = (n_rows + rows_per_split - 1) / rows_per_split;
     const int64_t grid = 8 * ((S + 7) / 8) * ws->KG;
+    const bool pre = ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, ws->npad, ws->K, ws->KG, (int)S,
                 rows_per_split, ws->e_state == 2 ? 1 : 0, ws->slabs};
+    if (pre) {
+        a.x = ws->xc;
+        a.ldx = 16 * ws->T;
+        a.D = 16 * ws->T;
+    }
     const char* name = "";
     if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
-    hipError_t e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, (int)grid, st, a, &name);
+    hipError_t e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);
     if (ws->prof) {
         (void)hipEventRecord(ws->ev[3], st);

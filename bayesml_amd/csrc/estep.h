@@ -136,19 +136,27 @@ __global__ __launch_bounds__(256) void estep_mfma_f64(const XT* __restrict__ x, 
 }
 
 // ---- LDS-staged variant ----------------------------------------------------------------------
-template <int T, typename XT, bool VEC>
-__global__ __launch_bounds__(256) void estep_lds_f64(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
-                                                     const double* __restrict__ img /*[K][IMG]*/,
-                                                     const double* __restrict__ cvec, int K,
-                                                     double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
-    constexpr int NB = estep_nb<XT>(T);
+// NW = 4: one wave per SIMD, 16*NB samples per wave.  NW = 8: two waves per SIMD with half the samples
+// each (same samples per workgroup and per LDS fill), so one wave's epilogue / LDS waits / barrier
+// arrival overlap the other wave's MFMAs.
+template <typename XT>
+__host__ __device__ constexpr int estep_nb_w(int t, int nw) {
+    return nw == 8 ? (estep_nb<XT>(t) > 1 ? estep_nb<XT>(t) / 2 : 1) : estep_nb<XT>(t);
+}
+
+template <int T, typename XT, bool VEC, int NW>
+__global__ __launch_bounds__(64 * NW) void estep_lds_f64(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                                         const double* __restrict__ img /*[K][IMG]*/,
+                                                         const double* __restrict__ cvec, int K,
+                                                         double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
+    constexpr int NB = estep_nb_w<XT>(T, NW);
     constexpr int IMG = img_doubles(T);
     constexpr int KB = estep_kb(T);
     __shared__ __attribute__((aligned(16))) double smem[2][KB * IMG];   // the ONLY LDS object of the kernel
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
-    const int64_t rows_per_wg = 4 * 16 * NB;
+    const int64_t rows_per_wg = NW * 16 * NB;
     const int64_t n_wg_tiles = (n_rows + rows_per_wg - 1) / rows_per_wg;
     const int n_blocks = (K + KB - 1) / KB;
 
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256) void estep_lds_f64(const XT* __restrict__ x, i
         const int kcount = (K - k0 < KB) ? (K - k0) : KB;
         const int pieces = kcount * (IMG / 128);
         const double* src = img + (int64_t)k0 * IMG + lane * 2;
-        for (int piece = wave; piece < pieces; piece += 4)
+        for (int piece = wave; piece < pieces; piece += NW)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 128),
                                              (__attribute__((address_space(3))) void*)(&smem[buf][piece * 128]), 16, 0,
                                              0);

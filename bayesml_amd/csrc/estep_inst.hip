@@ -9,18 +9,27 @@ static hipError_t go(int variant, int grid, hipStream_t st, const EstepArgs& a) 
     if (variant == kEstepDirect)
         hipLaunchKernelGGL((estep_mfma_f64<T, XT, VEC>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx,
                            a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
+    else if (variant == kEstepLds8)
+        hipLaunchKernelGGL((estep_lds_f64<T, XT, VEC, 8>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x),
+                           a.ldx, a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
     else
-        hipLaunchKernelGGL((estep_lds_f64<T, XT, VEC>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx,
-                           a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
+        hipLaunchKernelGGL((estep_lds_f64<T, XT, VEC, 4>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x),
+                           a.ldx, a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
     return hipGetLastError();
 }
 
-int estep_rows_per_wave(int T, int x_is_f64) {
-    return 16 * (x_is_f64 ? estep_nb<double>(T) : estep_nb<float>(T));
+int estep_threads(int variant) { return variant == kEstepLds8 ? 512 : 256; }
+int estep_rows_per_wg(int variant, int T, int x_is_f64) {
+    const int nw = variant == kEstepLds8 ? 8 : 4;
+    const int nb = variant == kEstepDirect ? (x_is_f64 ? estep_nb<double>(T) : estep_nb<float>(T))
+                                           : (x_is_f64 ? estep_nb_w<double>(T, nw) : estep_nb_w<float>(T, nw));
+    return nw * 16 * nb;
 }
 int estep_image_doubles(int T) { return img_doubles(T); }
 
-#define NAME(V, TT, X, M) (V == kEstepDirect ? "estep_mfma_f64<T=" #TT ",x=" X "," M ">" : "estep_lds_f64<T=" #TT ",x=" X "," M ">")
+#define NAME(V, TT, X, M)                                              \
+    (V == kEstepDirect ? "estep_mfma_f64<T=" #TT ",x=" X "," M ">"     \
+                       : (V == kEstepLds8 ? "estep_lds_f64<T=" #TT ",x=" X "," M ",8 waves>" : "estep_lds_f64<T=" #TT ",x=" X "," M ",4 waves>"))
 #define CASE(TT)                                                                                         \
     case TT:                                                                                             \
         if (x_is_f64) {                                                                                  \

@@ -16,15 +16,18 @@ struct MstepArgs {
     int K; int KG; int S; int64_t rows_per_split; int direct_r; double* slabs;
 };
 
-// rows of x handled by one E-step wave for (T, dtype); doubles per component parameter image
-int estep_rows_per_wave(int T, int x_is_f64);
+// rows of x handled by one E-step workgroup for (variant, T, dtype); doubles per component parameter image
+enum EstepVariant { kEstepLds = 0, kEstepDirect = 1, kEstepLds8 = 2 };
+int estep_rows_per_wg(int variant, int T, int x_is_f64);
+int estep_threads(int variant);
 int estep_image_doubles(int T);
-enum EstepVariant { kEstepLds = 0, kEstepDirect = 1 };
 // components handled by one M-step workgroup for T feature tiles (4 waves / waves-per-component)
 int mstep_components_per_wg(int T);
 // returns hipSuccess or the launch error; `name` receives a static description of the instantiation
 hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
                         const char** name);
-hipError_t launch_mstep(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const MstepArgs& a, const char** name);
+// pre = true: a.x is the workspace's centred f64 copy [n_rows][16T] (see center_rows_kernel)
+hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipStream_t st, const MstepArgs& a,
+                        const char** name);
 
 }  // namespace gmmvb

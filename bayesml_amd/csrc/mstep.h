@@ -26,20 +26,46 @@ namespace gmmvb {
 
 __host__ __device__ constexpr int mstep_ws(int t) { return t >= 8 ? 2 : 1; }
 
-template <int T, int WS, int SUB, typename XT, bool VEC>
+// Which of the WS waves of a component owns A-operand tile t1 (and every pair (t2, t1) with it).
+// WS = 2 (T = 8): t1 in {0,3,4,7} -> wave 0, {1,2,5,6} -> wave 1: 18 tile pairs each, and each wave
+// only forms r * x' for its own four t1 (f64 VALU work competes with the f64 MFMA pipe on gfx950).
+__host__ __device__ constexpr int mstep_owner(int ws, int t1) {
+    return ws == 1 ? 0 : (((t1 & 3) == 0 || (t1 & 3) == 3) ? 0 : 1);
+}
+// rank of pair (t2, t1) among the pairs owned by the same wave (its accumulator slot)
+__host__ __device__ constexpr int mstep_slot(int ws, int t2, int t1) {
+    int n = 0;
+    for (int b = 0; b <= t2; ++b)
+        for (int a = 0; a <= b; ++a) {
+            if (b == t2 && a == t1) return n;
+            if (mstep_owner(ws, a) == mstep_owner(ws, t1)) ++n;
+        }
+    return n;
+}
+__host__ __device__ constexpr int mstep_owned(int ws, int sub, int t) {
+    int n = 0;
+    for (int b = 0; b < t; ++b)
+        for (int a = 0; a <= b; ++a)
+            if (mstep_owner(ws, a) == sub) ++n;
+    return n;
+}
+
+// PRE = true: rows come from the workspace's centred f64 copy xc[n][16T] = (double)x - pivot (zero padded),
+// made once per sample matrix by center_rows_kernel, so the loop has no convert/subtract/mask work.
+template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE>
 __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                            const double* __restrict__ pivot, const double* __restrict__ lr,
                                            const double* __restrict__ lse, int64_t lo, int64_t hi, int direct_r,
                                            double* __restrict__ out) {
     constexpr int P = tri_pairs(T);
-    constexpr int NP = (P - SUB + WS - 1) / WS;   // tile pairs owned by this wave
+    constexpr int NP = mstep_owned(WS, SUB, T);   // tile pairs owned by this wave
     const int lane = threadIdx.x & 63;
     const int i = lane & 15;
     const int g = lane >> 4;
 
     double pv[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) pv[t] = (T * i + t < D) ? pivot[T * i + t] : 0.0;
+    for (int t = 0; t < T; ++t) pv[t] = (!PRE && T * i + t < D) ? pivot[T * i + t] : 0.0;
     d4 acc[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[p] = d4{0.0, 0.0, 0.0, 0.0};
@@ -53,7 +79,19 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
         if (row >= n_rows) row = n_rows - 1;               // r is 0 there
         const XT* xp = x + row * ldx + T * i;
         RawRow o;
-        if constexpr (VEC) {
+        if constexpr (PRE) {
+            typedef XT v2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int t = 0; t < T; t += 2) {
+                if (t + 1 < T) {
+                    const v2 v = *reinterpret_cast<const v2*>(xp + t);
+                    o.v[t] = v[0];
+                    o.v[t + 1] = v[1];
+                } else {
+                    o.v[t] = xp[t];
+                }
+            }
+        } else if constexpr (VEC) {
             typedef XT vt __attribute__((ext_vector_type(T)));
             const vt v = *reinterpret_cast<const vt*>(xp);
 #pragma unroll
@@ -88,38 +126,51 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
             nxt = load_row(c0 + 4 * (st + 1) + g);    // software prefetch of the next 4 samples
             double xq[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) xq[t] = (T * i + t < D) ? (double)cur.v[t] - pv[t] : 0.0;
+            for (int t = 0; t < T; ++t) {
+                if constexpr (PRE) xq[t] = (double)cur.v[t];
+                else xq[t] = (T * i + t < D) ? (double)cur.v[t] - pv[t] : 0.0;
+            }
             const double rr = __shfl(r_l, 4 * st + g);
             double ra[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                ra[t] = rr * xq[t];
-                if (SUB == 0) asum[t] += ra[t];
+                if (mstep_owner(WS, t) == SUB) {
+                    ra[t] = rr * xq[t];
+                    asum[t] += ra[t];
+                } else {
+                    ra[t] = 0.0;
+                }
             }
 #pragma unroll
             for (int t2 = 0; t2 < T; ++t2) {
 #pragma unroll
                 for (int t1 = 0; t1 <= t2; ++t1) {
-                    const int p = pair_index(t2, t1);
-                    if (p % WS == SUB) acc[p / WS] = mfma_f64(ra[t1], xq[t2], acc[p / WS]);
+                    if (mstep_owner(WS, t1) == SUB)
+                        acc[mstep_slot(WS, t2, t1)] = mfma_f64(ra[t1], xq[t2], acc[mstep_slot(WS, t2, t1)]);
                 }
             }
         }
     }
 
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (p % WS == SUB) {
+    for (int t2 = 0; t2 < T; ++t2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(p * 4 + r) * 64 + lane] = acc[p / WS][r];
+        for (int t1 = 0; t1 <= t2; ++t1) {
+            if (mstep_owner(WS, t1) == SUB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(pair_index(t2, t1) * 4 + r) * 64 + lane] = acc[mstep_slot(WS, t2, t1)][r];
+            }
         }
     }
-    if (SUB == 0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < T; ++t) {
+        if (mstep_owner(WS, t) == SUB) {
             const double v = sum_groups(asum[t]);
             if (g == 0) out[P * 256 + T * i + t] = v;
         }
+    }
+    if (SUB == 0) {
         nsum = sum_wave(nsum);
         hsum = sum_wave(hsum);
         if (lane == 0) {
@@ -129,7 +180,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     }
 }
 
-template <int T, typename XT, bool VEC>
+template <int T, typename XT, bool VEC, bool PRE>
 __global__ __launch_bounds__(256) void mstep_mfma_f64(
     const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
     const double* __restrict__ pivot,      // [D]
@@ -159,12 +210,12 @@ __global__ __launch_bounds__(256) void mstep_mfma_f64(
     const double* lr = lnrho + (int64_t)k * npad;
     double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
     if constexpr (WS == 1) {
-        mstep_body<T, 1, 0, XT, VEC>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+        mstep_body<T, 1, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
     } else {
         if (sub == 0)
-            mstep_body<T, 2, 0, XT, VEC>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+            mstep_body<T, 2, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
         else
-            mstep_body<T, 2, 1, XT, VEC>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+            mstep_body<T, 2, 1, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
     }
 }
 

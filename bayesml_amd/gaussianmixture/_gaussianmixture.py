@@ -325,6 +325,7 @@ class LearnModel(base.Posterior, base.PredictiveMixin):
         acc = torch.cat([head.sum(dim=0), cnt])
         self._comm.all_reduce_(acc)
         eng.set_pivot(acc[:-1] / acc[-1])
+        eng.prepare_rows(xd)
         return eng, xd
 
     def _pass(self, eng, xd, q, s_prev, estep=True):

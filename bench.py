@@ -189,8 +189,14 @@ def main():
         # algorithmic flops per sample: E = K(2D^2+3D) + 6K, M = K(2D^2+2D) + 2KD
         fl_e = K * (2 * D * D + 3 * D) + 6 * K
         fl_m = K * (2 * D * D + 2 * D) + 2 * K * D
-        kern = {"estep_mfma_f64": dict(ms=e_ms, algorithmic_tflops=fl_e * n_local / (e_ms * 1e-3) / 1e12),
-                "mstep_mfma_f64": dict(ms=m_ms, algorithmic_tflops=fl_m * n_local / (m_ms * 1e-3) / 1e12)}
+        names = [part.strip().split("<")[0] for part in eng.launch_info.split("|")]      # kernels actually launched
+        # executed MFMA flops: T(T+1)/2 tile pairs of 16x16, x4 (E: per 16 samples) or x1 (M: per 4 samples) MFMAs of 2048 flops
+        tiles = (D + 15) // 16
+        fl_exec = K * 512 * tiles * (tiles + 1) // 2
+        kern = {names[0]: dict(ms=e_ms, algorithmic_tflops=fl_e * n_local / (e_ms * 1e-3) / 1e12,
+                               executed_mfma_tflops=fl_exec * n_local / (e_ms * 1e-3) / 1e12),
+                names[1]: dict(ms=m_ms, algorithmic_tflops=fl_m * n_local / (m_ms * 1e-3) / 1e12,
+                               executed_mfma_tflops=fl_exec * n_local / (m_ms * 1e-3) / 1e12)}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         ach = kern[dom]["algorithmic_tflops"]
         bytes_per_sample = D * x.element_size()

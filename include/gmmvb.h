@@ -65,6 +65,13 @@ int64_t gmmvb_workspace_bytes(const gmmvb_workspace* ws);
  * B/ns - (a/ns)(a/ns)^T free of cancellation; results do not depend on it beyond rounding. */
 int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev /*[D]*/, void* stream);
 
+/* Optional, once per sample matrix (after gmmvb_set_pivot): build the workspace's centred f64 copy
+ * xc = (double)x - pivot that gmmvb_mstep then streams instead of x whenever it is called with the same
+ * (x_dev, ldx, n_rows).  Results are identical; the M-step loop loses its convert/subtract work, which on
+ * gfx950 competes with the f64 MFMA pipe.  Costs 8 * 16*ceil(D/16) bytes per row of workspace; disabled
+ * (a no-op) when the workspace was created under GMMVB_MSTEP_PRECENTER=0. */
+int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream);
+
 /* Posterior expectations consumed by the E-step, replacing the reads of _e_ln_pi_vec,
  * _e_ln_lambda_dets, hn_kappas, hn_m_vecs and _e_lambda_mats at _gaussianmixture.py:773-781:
  *   c[k]  = E[ln pi_k] + (E[ln det Lambda_k] - D ln 2pi - D/kappa_k)/2

@@ -27,6 +27,9 @@ class CpuDataPass:
     def set_pivot(self, p):
         self.pivot = torch.as_tensor(p, dtype=torch.float64).clone()
 
+    def prepare_rows(self, x):
+        pass
+
     def set_params(self, c, m, u):
         self.c, self.m, self.u = c.clone(), m.clone(), u.clone()
 

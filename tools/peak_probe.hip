@@ -25,10 +25,13 @@ __global__ __launch_bounds__(256) void mfma_loop(double* out, unsigned long long
 #pragma unroll
     for (int j = 0; j < (NFMA > 0 ? NFMA : 1); ++j) v[j] = 1.0 + j;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters / 16; ++it) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc[i], 0, 0, 0);
+        for (int ui = 0; ui < 16 * NACC; ++ui) {
+            const int i = ui % NACC;
+            // inline asm pins the accumulator in AGPRs: the builtin form made hipcc shuttle every
+            // accumulator VGPR<->AGPR on each loop iteration (128 v_accvgpr per 8 MFMAs)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[i]), "v"(b[i]));
 #pragma unroll
             for (int j = 0; j < NFMA; ++j) v[j] = fma(v[j], 0.9999999, 1e-9);
         }

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of rocprofv3 --pmc counters for the gmmvb kernels (largest grid of each kernel only).
+
+usage: summarize_pmc.py <dir> [<dir> ...]     (each dir = one --pmc pass, *_counter_collection.csv inside)
+FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section); on gfx950 FETCH_SIZE reports half of
+the bytes of wide coalesced streaming reads, so both the raw and the x2 figure are printed.
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    rows = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> values (largest grid only)
+    grid = {}
+    dur = defaultdict(list)
+    for d in sys.argv[1:]:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    name = r["Kernel_Name"].replace("void ", "").split("(")[0]
+                    if not name.startswith("gmmvb::"):
+                        continue
+                    g = int(r["Grid_Size"])
+                    if g > grid.get(name, 0):
+                        grid[name] = g
+                        rows[name].clear()
+                        dur[name].clear()
+                    if g == grid[name]:
+                        rows[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                        dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    for name in sorted(rows, key=lambda n: -sum(dur[n])):
+        print(f"## {name}  (grid {grid[name]} threads, profiled launch {sum(dur[name])/len(dur[name]):.2f} ms avg)")
+        for c, v in sorted(rows[name].items()):
+            avg = sum(v) / len(v)
+            extra = ""
+            if c == "FETCH_SIZE":
+                extra = f"  = {avg*1024/1e9:.3f} GB raw, {2*avg*1024/1e9:.3f} GB with the gfx950 x2 correction"
+            if c == "WRITE_SIZE":
+                extra = f"  = {avg*1024/1e9:.3f} GB"
+            print(f"  {c:32s} {avg:18.1f}   (n={len(v)}){extra}")
+        c = {k: sum(v) / len(v) for k, v in rows[name].items()}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
+            util = (c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (c["GRBM_GUI_ACTIVE"] / 8.0)
+            print(f"  => MFMA pipe utilisation = busy cycles per SIMD / kernel cycles = {100*util:.1f} %")
+            if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c:
+                print(f"  => executed f64 MFMA flops = MOPS x 512 = {c['SQ_INSTS_VALU_MFMA_MOPS_F64']*512/1e12:.3f} TFLOP per launch")
+            if "SQ_INSTS_VALU" in c:
+                n_mfma = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0
+                print(f"  => non-MFMA vector instructions per MFMA = {(c['SQ_INSTS_VALU'] - n_mfma) / n_mfma:.2f}")
+        print()
+
+
+if __name__ == "__main__":
+    main()
