@@ -38,7 +38,7 @@ struct gmmvb_workspace {
     double* lse = nullptr;     // [npad]
     double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
     int img_len = 0;
-    int estep_variant = 0;     // kEstepLds (default); env GMMVB_ESTEP_VARIANT=direct|lds8 selects the others
+    int estep_variant = 0;     // kEstepLds8 (default); env GMMVB_ESTEP_VARIANT=direct|lds4 selects the others
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* slabs = nullptr;   // [S_cap][K][slab_len]
@@ -96,9 +96,9 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     ws->img_len = estep_image_doubles(ws->T);
     {
         const char* v = std::getenv("GMMVB_ESTEP_VARIANT");
-        ws->estep_variant = kEstepLds;
+        ws->estep_variant = kEstepLds8;      // measured fastest (two waves per SIMD share one LDS image)
         if (v && std::strcmp(v, "direct") == 0) ws->estep_variant = kEstepDirect;
-        if (v && std::strcmp(v, "lds8") == 0) ws->estep_variant = kEstepLds8;
+        if (v && std::strcmp(v, "lds4") == 0) ws->estep_variant = kEstepLds;
     }
     struct { double** p; int64_t n; } bufs[] = {
         {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},

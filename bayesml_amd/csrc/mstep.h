@@ -103,6 +103,10 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
         return o;
     };
 
+    // Software pipeline, one step = 4 samples: the row loads and the responsibility broadcast of step
+    // s+1 are issued before the MFMAs of step s and consumed after them.  The sched_barriers keep hipcc
+    // from hoisting those loads above the VALU block, where a register it then reuses forces a
+    // vmcnt(0) right behind the issue (measured: -7 % on the whole kernel).
     RawRow nxt = load_row(lo + g);
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         // responsibilities of 64 samples, one per lane
@@ -120,17 +124,17 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
             }
             nsum += r_l;
         }
+        double rr_n = __shfl(r_l, g);
 #pragma unroll 2
         for (int st = 0; st < 16; ++st) {
             const RawRow cur = nxt;
-            nxt = load_row(c0 + 4 * (st + 1) + g);    // software prefetch of the next 4 samples
+            const double rr = rr_n;
             double xq[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 if constexpr (PRE) xq[t] = (double)cur.v[t];
                 else xq[t] = (T * i + t < D) ? (double)cur.v[t] - pv[t] : 0.0;
             }
-            const double rr = __shfl(r_l, 4 * st + g);
             double ra[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -141,6 +145,10 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
                     ra[t] = 0.0;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            nxt = load_row(c0 + 4 * (st + 1) + g);
+            rr_n = __shfl(r_l, (4 * (st + 1) + g) & 63);      // st = 15: unused (next batch recomputes)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t2 = 0; t2 < T; ++t2) {
 #pragma unroll
@@ -149,6 +157,10 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
                         acc[mstep_slot(WS, t2, t1)] = mfma_f64(ra[t1], xq[t2], acc[mstep_slot(WS, t2, t1)]);
                 }
             }
+            // keep every loaded element live to here: a dead half of a 16-byte load (tile 0 is never a B
+            // operand of wave 1) otherwise gets its register reused while the load is in flight -> vmcnt(0)
+#pragma unroll
+            for (int t = 0; t < T; ++t) asm volatile("" ::"v"(xq[t]));
         }
     }
 

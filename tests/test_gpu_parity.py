@@ -84,11 +84,13 @@ def test_single_data_pass_matches_reference(name):
     # run-to-run determinism: fixed reduction order, no atomics
     stats2 = eng.estep_mstep(xd)
     assert torch.equal(stats, stats2)
-    # the centred-f64-copy form of the M-step (what LearnModel uses) is the same arithmetic in the same order
+    # the centred-f64-copy form of the M-step (what LearnModel uses) is the same arithmetic in the same
+    # order up to the compiler's fma contraction of the first-moment sum
     eng.prepare_rows(xd)
     stats3 = eng.estep_mstep(xd)
     assert "centred-f64" in eng.launch_info
-    assert torch.equal(stats, stats3)
+    assert rel_err(stats3.cpu().numpy(), stats.cpu().numpy()) < 1e-13
+    assert torch.equal(stats3, eng.estep_mstep(xd))
     eng.close()
 
 
