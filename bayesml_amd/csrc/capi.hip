@@ -88,7 +88,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     ws->npad = round_up(max_rows, 64);
     ws->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {
-        const int kpw = mstep_components_per_wg(ws->T);
+        const int kpw = mstep_components_per_wg(ws->T, false);     // the smaller of the two forms: sizes the slabs
         ws->KG = (K + kpw - 1) / kpw;
     }
     ws->S_cap = (int)round_up(((int64_t)4 * ws->num_cu + ws->KG - 1) / ws->KG, 8);
@@ -287,9 +287,11 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (S > groups) S = groups;
     const int64_t rows_per_split = round_up((n_rows + S - 1) / S, 64);
     S = (n_rows + rows_per_split - 1) / rows_per_split;
-    const int64_t grid = 8 * ((S + 7) / 8) * ws->KG;
     const bool pre = ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx;
-    MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, ws->npad, ws->K, ws->KG, (int)S,
+    const int kpw = mstep_components_per_wg(ws->T, pre);
+    const int KG = (ws->K + kpw - 1) / kpw;
+    const int64_t grid = 8 * ((S + 7) / 8) * KG;
+    MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, ws->npad, ws->K, KG, (int)S,
                 rows_per_split, ws->e_state == 2 ? 1 : 0, ws->slabs};
     if (pre) {
         a.x = ws->xc;
@@ -310,8 +312,8 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "reduce_stats launch", e);
     const size_t used = std::strlen(ws->info);
-    std::snprintf(ws->info + used, sizeof(ws->info) - used, " | %s grid=%lldx256 splits=%lld rows/split=%lld", name,
-                  (long long)grid, (long long)S, (long long)rows_per_split);
+    std::snprintf(ws->info + used, sizeof(ws->info) - used, " | %s grid=%lldx%d splits=%lld rows/split=%lld", name,
+                  (long long)grid, mstep_threads(ws->T, pre), (long long)S, (long long)rows_per_split);
     return GMMVB_OK;
 }
 

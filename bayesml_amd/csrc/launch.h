@@ -22,7 +22,8 @@ int estep_rows_per_wg(int variant, int T, int x_is_f64);
 int estep_threads(int variant);
 int estep_image_doubles(int T);
 // components handled by one M-step workgroup for T feature tiles (4 waves / waves-per-component)
-int mstep_components_per_wg(int T);
+int mstep_components_per_wg(int T, bool pre);
+int mstep_threads(int T, bool pre);
 // returns hipSuccess or the launch error; `name` receives a static description of the instantiation
 hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
                         const char** name);

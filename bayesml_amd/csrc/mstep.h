@@ -25,6 +25,10 @@
 namespace gmmvb {
 
 __host__ __device__ constexpr int mstep_ws(int t) { return t >= 8 ? 2 : 1; }
+// waves per workgroup.  8-wave workgroups (4 components per row stream at T = 8) were measured: L2-side
+// fetch traffic drops 3x (96 -> 33 GB per launch at C3) but the kernel is 12 % slower (the 256-register cap
+// of a 512-thread workgroup costs more than the traffic, which is nowhere near a bandwidth limit) -> 4.
+__host__ __device__ constexpr int mstep_waves(int t, bool pre) { return 4; }
 
 // Which of the WS waves of a component owns A-operand tile t1 (and every pair (t2, t1) with it).
 // WS = 2 (T = 8): t1 in {0,3,4,7} -> wave 0, {1,2,5,6} -> wave 1: 18 tile pairs each, and each wave
@@ -193,7 +197,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
 }
 
 template <int T, typename XT, bool VEC, bool PRE>
-__global__ __launch_bounds__(256) void mstep_mfma_f64(
+__global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
     const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
     const double* __restrict__ pivot,      // [D]
     const double* __restrict__ lnrho,      // [K][npad]  (ln rho, or r itself when direct_r)
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void mstep_mfma_f64(
     int64_t npad, int K, int KG, int S, int64_t rows_per_split, int direct_r,
     double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
     constexpr int WS = mstep_ws(T);
-    constexpr int KPW = 4 / WS;            // components per workgroup
+    constexpr int KPW = mstep_waves(T, PRE) / WS;   // components per workgroup
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     // XCD-aware decode: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD

@@ -9,13 +9,14 @@ namespace gmmvb {
 
 template <int T, typename XT, bool VEC, bool PRE>
 static hipError_t go(int grid, hipStream_t st, const MstepArgs& a) {
-    hipLaunchKernelGGL((mstep_mfma_f64<T, XT, VEC, PRE>), dim3(grid), dim3(256), 0, st,
+    hipLaunchKernelGGL((mstep_mfma_f64<T, XT, VEC, PRE>), dim3(grid), dim3(64 * mstep_waves(T, PRE)), 0, st,
                        static_cast<const XT*>(a.x), a.ldx, a.n_rows, a.D, a.pivot, a.lnrho, a.lse, a.npad, a.K, a.KG,
                        a.S, a.rows_per_split, a.direct_r, a.slabs);
     return hipGetLastError();
 }
 
-int mstep_components_per_wg(int T) { return 4 / mstep_ws(T); }
+int mstep_components_per_wg(int T, bool pre) { return mstep_waves(T, pre) / mstep_ws(T); }
+int mstep_threads(int T, bool pre) { return 64 * mstep_waves(T, pre); }
 
 template <int T, bool HAS_VEC>
 static hipError_t dispatch(int x_is_f64, bool vec, bool pre, int grid, hipStream_t st, const MstepArgs& a) {
