@@ -1,13 +1,13 @@
 """bayesml_amd — MI355X-native engine for the variational-Bayes GMM posterior update of BayesML.
 
 Only the path named by BASELINE.json's ``north_star`` lives here: ``gaussianmixture.GenModel`` /
-``gaussianmixture.LearnModel`` with the reference's API, backed by hand-written gfx950 HIP kernels
+``gaussianmixture.LearnModel`` (and ``hiddenmarkovnormal`` for config 5) with the reference's API, backed by hand-written gfx950 HIP kernels
 (``csrc/``) behind the C ABI of ``include/gmmvb.h``.  The rest of BayesML is out of scope.
 """
-from . import gaussianmixture
+from . import gaussianmixture, hiddenmarkovnormal
 from ._dist import RowShard
 from ._exceptions import (CriteriaError, DataFormatError, ParameterFormatError, ParameterFormatWarning,
                           ResultWarning)
 
-__all__ = ["gaussianmixture", "RowShard", "ParameterFormatError", "DataFormatError", "CriteriaError",
+__all__ = ["gaussianmixture", "hiddenmarkovnormal", "RowShard", "ParameterFormatError", "DataFormatError", "CriteriaError",
            "ResultWarning", "ParameterFormatWarning"]

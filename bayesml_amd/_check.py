@@ -35,6 +35,16 @@ def pos_int(val, name, exc):
     raise exc(name + " must be int. Its value must be positive (not including 0).")
 
 
+def floats(val, name, exc):
+    """_check.py:163-173 — real scalar or real ndarray (ints are cast); no sign condition."""
+    if _is_real(val):
+        return float(val) if _is_int(val) else val
+    kind = _arr_kind(val)
+    if kind is not None:
+        return val.astype(float) if kind == "i" else val
+    raise exc(name + " must be float or a numpy.ndarray.")
+
+
 def pos_floats(val, name, exc):
     """_check.py:175-185 — positive real scalar or positive real ndarray (ints are cast)."""
     if _is_real(val) and val > 0.0:

@@ -38,6 +38,11 @@ SYMBOLS = {
     "gmmvb_ln_rho": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gmmvb_argmax": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gmmvb_last_launch_info": (ctypes.c_char_p, [_vp]),
+    "hmmvb_out_len": (_i64, [_int]),
+    "hmmvb_enable": (_int, [_vp]),
+    "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "hmmvb_debug_readout": (_int, [_vp, _int, _i64, _i64, _vp, _vp]),
+    "hmmvb_viterbi": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "gmmvb_profile_enable": (_int, [_vp, _int]),
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
 }
@@ -209,6 +214,48 @@ class DataPass:
                                                         self._stream()), "gmmvb_estep_mstep")
         self.rows = x.shape[0]
         return stats
+
+    # -- HMM
+    def enable_hmm(self):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.hmmvb_enable(self._ws), "hmmvb_enable")
+
+    def forward_backward(self, pi_tilde, a_tilde):
+        """(ms [K, K], gamma_0 [K], gamma_last [K], sum ln c) of the pass over the rows of the last estep;
+        leaves gamma as the workspace's responsibilities (mstep / responsibilities / argmax use it)."""
+        K = self.K
+        pi = _f64(pi_tilde, (K,), self.device)
+        a = _f64(a_tilde, (K, K), self.device)
+        out = torch.empty(int(self.lib.hmmvb_out_len(K)), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.hmmvb_forward_backward(self._ws, self.rows, pi.data_ptr(), a.data_ptr(),
+                                                             out.data_ptr(), self._stream()), "hmmvb_forward_backward")
+        self._keep = self._keep[-3:] + [pi, a]
+        return out[:K * K].view(K, K), out[K * K:K * K + K], out[K * K + K:K * K + 2 * K], out[K * K + 2 * K]
+
+    def viterbi(self, ln_pi_tilde, ln_a_tilde) -> torch.Tensor:
+        """Most probable state path (int32 [rows]) for the emission ln rho of the last estep."""
+        K = self.K
+        pi = _f64(ln_pi_tilde, (K,), self.device)
+        a = _f64(ln_a_tilde, (K, K), self.device)
+        z = torch.empty(self.rows, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.hmmvb_viterbi(self._ws, self.rows, pi.data_ptr(), a.data_ptr(), z.data_ptr(),
+                                                    self._stream()), "hmmvb_viterbi")
+        torch.cuda.current_stream(self.device).synchronize()     # pi / a must outlive the kernels
+        return z
+
+    def hmm_debug(self, what, row0=0, n=None):
+        n = self.rows - row0 if n is None else n
+        Kp = 16 * ((self.K + 15) // 16)
+        out = torch.empty((n, Kp) if what == 0 else (n,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.hmmvb_debug_readout(self._ws, what, row0, n, out.data_ptr(), self._stream()),
+                   "hmmvb_debug_readout")
+        if what == 0:          # lane order -> natural state order
+            pos = [(s & ~15) + 4 * ((s & 15) & 3) + ((s & 15) >> 2) for s in range(self.K)]
+            out = out[:, pos]
+        return out
 
     def split_stats(self, stats: torch.Tensor):
         """[ns | h | a | B] views of a statistics block."""

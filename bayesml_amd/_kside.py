@@ -75,8 +75,17 @@ def ln_wishart_b(logdet_w_inv: torch.Tensor, nu: torch.Tensor, D: int) -> torch.
 
 def features(q: PostT) -> PostT:
     """Refresh every derived quantity of ``q`` from (alpha, m, kappa, nu, w_inv)."""
-    K, D = q.m.shape
     q.e_ln_pi = torch.digamma(q.alpha) - torch.digamma(q.alpha.sum())
+    niw_features(q)
+    q.c = q.e_ln_pi + q.c
+    return q
+
+
+def niw_features(q):
+    """Normal-Wishart part shared by the GMM and the HMM: w, u, E[ln det Lambda], ln B, and the emission
+    constant c = (E[ln det Lambda] - D ln 2pi - D/kappa)/2 (the HMM's _calc_rho constant,
+    _hiddenmarkovnormal.py:989-993; the GMM adds E[ln pi] to it)."""
+    K, D = q.m.shape
     g, _info = torch.linalg.cholesky_ex(q.w_inv)          # NaNs propagate instead of raising, like inv()
     eye = torch.eye(D, dtype=q.w_inv.dtype, device=q.w_inv.device).expand(K, D, D)
     g_inv = torch.linalg.solve_triangular(g, eye, upper=False)
@@ -86,7 +95,7 @@ def features(q: PostT) -> PostT:
     logdet = 2.0 * torch.log(torch.diagonal(g, dim1=1, dim2=2)).sum(dim=1)
     q.e_ln_lambda_det = _half_digamma_sum(q.nu, D) + D * LN_2 - logdet
     q.ln_b_w_nu = ln_wishart_b(logdet, q.nu, D)
-    q.c = q.e_ln_pi + (q.e_ln_lambda_det - D * LN_2PI - D / q.kappa) / 2.0
+    q.c = (q.e_ln_lambda_det - D * LN_2PI - D / q.kappa) / 2.0
     return q
 
 
@@ -165,7 +174,7 @@ def lower_bound(p: PriorT, q: PostT, ns, x_bar, s, sum_r_ln_r) -> dict:
     return terms
 
 
-def subsample_moments_init(q: PostT, cnt, a, B, pivot) -> PostT:
+def subsample_moments_init(q, cnt, a, B, pivot, refresh=None):
     """_init_subsampling (_gaussianmixture.py:786-796) from per-component raw moments of the drawn
     rows about ``pivot``: cnt (scalar subsample size), a [K, D] = sum (x - pivot), B [K, D, D]."""
     D = q.m.shape[1]
@@ -174,4 +183,109 @@ def subsample_moments_init(q: PostT, cnt, a, B, pivot) -> PostT:
     cov = B / cnt - abar[:, :, None] * abar[:, None, :]
     eye = torch.eye(D, dtype=cov.dtype, device=cov.device)
     q.w_inv = cov * q.nu[:, None, None] + eye * 1.0e-5
-    return features(q)
+    return (refresh or features)(q)
+
+
+# ----------------------------------------------------------------------------------------------- HMM
+@dataclass
+class HmmPriorT:
+    eta: torch.Tensor        # [K]
+    zeta: torch.Tensor       # [K, K]
+    m: torch.Tensor
+    kappa: torch.Tensor
+    nu: torch.Tensor
+    w_inv: torch.Tensor
+    ln_c_eta: float          # _hiddenmarkovnormal.py:851
+    ln_c_zeta_sum: float     # :852
+    ln_b_w_nu: torch.Tensor  # :853-859
+
+
+@dataclass
+class HmmPostT:
+    eta: torch.Tensor
+    zeta: torch.Tensor
+    m: torch.Tensor
+    kappa: torch.Tensor
+    nu: torch.Tensor
+    w_inv: torch.Tensor
+    w: torch.Tensor = None
+    u: torch.Tensor = None
+    e_ln_lambda_det: torch.Tensor = None
+    ln_b_w_nu: torch.Tensor = None
+    c: torch.Tensor = None              # emission constant
+    ln_pi_tilde: torch.Tensor = None    # :862
+    pi_tilde: torch.Tensor = None       # :863
+    ln_a_tilde: torch.Tensor = None     # :866
+    a_tilde: torch.Tensor = None        # :867  (ONE global max)
+    ln_c_zeta_sum: torch.Tensor = None  # :868
+
+    def clone(self) -> "HmmPostT":
+        return hmm_features(HmmPostT(*(t.clone() for t in (self.eta, self.zeta, self.m, self.kappa, self.nu, self.w_inv))))
+
+
+def _ln_c_rows(z: torch.Tensor) -> torch.Tensor:
+    return (torch.lgamma(z.sum(dim=-1)) - torch.lgamma(z).sum(dim=-1)).sum()
+
+
+def hmm_features(q: HmmPostT) -> HmmPostT:
+    """_calc_q_pi_features :861-863, _calc_q_a_features :865-868, _calc_q_lambda_features :870-881."""
+    q.ln_pi_tilde = torch.digamma(q.eta) - torch.digamma(q.eta.sum())
+    q.pi_tilde = torch.exp(q.ln_pi_tilde - q.ln_pi_tilde.max())
+    q.ln_a_tilde = torch.digamma(q.zeta) - torch.digamma(q.zeta.sum(dim=1, keepdim=True))
+    q.a_tilde = torch.exp(q.ln_a_tilde - q.ln_a_tilde.max())
+    q.ln_c_zeta_sum = _ln_c_rows(q.zeta)
+    return niw_features(q)
+
+
+def hmm_prior_from_numpy(eta, zeta, m, kappa, nu, w, device) -> HmmPriorT:
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=device).clone()   # noqa: E731
+    eta, zeta, m, kappa, nu, w = t(eta), t(zeta), t(m), t(kappa), t(nu), t(w)
+    D = m.shape[1]
+    w_inv = torch.linalg.inv(w)
+    w_inv = 0.5 * (w_inv + w_inv.transpose(1, 2))
+    return HmmPriorT(eta, zeta, m, kappa, nu, w_inv, float(torch.lgamma(eta.sum()) - torch.lgamma(eta).sum()),
+                     float(_ln_c_rows(zeta)), ln_wishart_b(-torch.linalg.slogdet(w)[1], nu, D))
+
+
+def hmm_post_from_prior(p: HmmPriorT) -> HmmPostT:
+    return hmm_features(HmmPostT(p.eta.clone(), p.zeta.clone(), p.m.clone(), p.kappa.clone(), p.nu.clone(),
+                                 p.w_inv.clone()))
+
+
+def hmm_update_q(p: HmmPriorT, ns, ms, x_bar, s) -> HmmPostT:
+    """_update_q_mu_lambda :966-978, _update_q_pi :980-982 (eta += ns: the code, not the docstring's
+    gamma_1), _update_q_a :984-986."""
+    kappa = p.kappa + ns
+    m = (p.kappa[:, None] * p.m + ns[:, None] * x_bar) / kappa[:, None]
+    dev = x_bar - p.m
+    w_inv = (p.w_inv + ns[:, None, None] * s
+             + (p.kappa * ns / kappa)[:, None, None] * (dev[:, :, None] * dev[:, None, :]))
+    return hmm_features(HmmPostT(p.eta + ns, p.zeta + ms, m, kappa, p.nu + ns, w_inv))
+
+
+def hmm_lower_bound(p: HmmPriorT, q: HmmPostT, ns, ms, x_bar, s, gamma0, sum_gamma_ln_rho, sum_ln_c) -> dict:
+    """_calc_vl, _hiddenmarkovnormal.py:883-943 (nine terms)."""
+    K, D = q.m.shape
+    e_lambda = q.nu[:, None, None] * q.w
+
+    def quad(v):
+        return torch.einsum("ki,kij,kj->k", v, e_lambda, v)
+
+    p_x = (ns * (q.e_ln_lambda_det - D / q.kappa - (s * e_lambda).sum(dim=(1, 2)) - quad(x_bar - q.m)
+                 - D * LN_2PI)).sum() / 2.0
+    p_z = (gamma0 * q.ln_pi_tilde).sum() + (ms * q.ln_a_tilde).sum()
+    p_pi = p.ln_c_eta + ((p.eta - 1.0) * q.ln_pi_tilde).sum()
+    p_a = p.ln_c_zeta_sum + ((p.zeta - 1.0) * q.ln_a_tilde).sum()
+    p_mu_lambda = (D * (torch.log(p.kappa) - LN_2PI - p.kappa / q.kappa) - p.kappa * quad(q.m - p.m)
+                   + 2.0 * p.ln_b_w_nu + (p.nu - D) * q.e_ln_lambda_det
+                   - (p.w_inv * e_lambda).sum(dim=(1, 2))).sum() / 2.0
+    q_z = (-sum_gamma_ln_rho - (ms * (q.ln_a_tilde - q.ln_a_tilde.max())).sum()
+           - (gamma0 * (q.ln_pi_tilde - q.ln_pi_tilde.max())).sum() + sum_ln_c)
+    q_pi = dirichlet_entropy(q.eta)
+    q_a = -q.ln_c_zeta_sum - ((q.zeta - 1.0) * q.ln_a_tilde).sum()
+    q_mu_lambda = (D * (1.0 + LN_2PI - torch.log(q.kappa)) - 2.0 * q.ln_b_w_nu
+                   - (q.nu - D) * q.e_ln_lambda_det + q.nu * D).sum() / 2.0
+    t = dict(p_x=p_x, p_z=p_z, p_pi=p_pi, p_a=p_a, p_mu_lambda=p_mu_lambda, q_z=q_z, q_pi=q_pi, q_a=q_a,
+             q_mu_lambda=q_mu_lambda)
+    t["vl"] = p_x + p_z + p_pi + p_a + p_mu_lambda + q_z + q_pi + q_a + q_mu_lambda
+    return t

@@ -1,6 +1,6 @@
 // C ABI of the GMM-VB data-pass engine (see include/gmmvb.h for the contract and the reference
 // call sites each entry point replaces).
-#include "../../include/gmmvb.h"
+#include "workspace.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -14,10 +14,11 @@
 using namespace gmmvb;
 
 namespace {
-
 thread_local std::string g_err;
+}  // namespace
 
-int fail(int code, const char* what, hipError_t e = hipSuccess) {
+namespace gmmvb {
+int fail(int code, const char* what, hipError_t e) {
     g_err = what;
     if (e != hipSuccess) {
         g_err += ": ";
@@ -25,35 +26,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     }
     return code;
 }
-
-inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-
-}  // namespace
-
-struct gmmvb_workspace {
-    int K = 0, D = 0, T = 0, x_dtype = 0;
-    int64_t max_rows = 0, npad = 0;
-    int num_cu = 0, KG = 0, S_cap = 0;
-    double* lnrho = nullptr;   // [K][npad]
-    double* lse = nullptr;     // [npad]
-    double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
-    int img_len = 0;
-    int estep_variant = 0;     // kEstepLds8 (default); env GMMVB_ESTEP_VARIANT=direct|lds4 selects the others
-    double* cvec = nullptr;    // [K]
-    double* pivot = nullptr;   // [D]
-    double* slabs = nullptr;   // [S_cap][K][slab_len]
-    double* xc = nullptr;      // [npad][16T] centred f64 copy of the sample matrix (M-step operand), optional
-    const void* xc_src = nullptr;   // the x it was made from (null = not prepared)
-    int64_t xc_rows = 0, xc_ldx = 0;
-    int64_t bytes = 0;
-    bool have_params = false;
-    int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly
-    int64_t e_rows = 0;
-    char info[512] = {0};
-    bool prof = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // E begin/end, M begin/end
-    bool ev_e = false, ev_m = false;
-};
+}  // namespace gmmvb
 
 extern "C" {
 
@@ -135,6 +108,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws->ev)
         if (e) (void)hipEventDestroy(e);
+    if (ws->hmm) hmm_state_destroy(ws->hmm);
     delete ws;
     return GMMVB_OK;
 }
@@ -291,8 +265,13 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const int kpw = mstep_components_per_wg(ws->T, pre);
     const int KG = (ws->K + kpw - 1) / kpw;
     const int64_t grid = 8 * ((S + 7) / 8) * KG;
-    MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, ws->npad, ws->K, KG, (int)S,
+    MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, nullptr, ws->npad, ws->K, KG, (int)S,
                 rows_per_split, ws->e_state == 2 ? 1 : 0, ws->slabs};
+    if (ws->e_state == 3) {          // HMM: responsibilities = gamma from the forward-backward pass, h = sum gamma ln rho
+        a.lnrho = hmm_gamma_cm(ws->hmm);
+        a.aux = ws->lnrho;
+        a.direct_r = 2;
+    }
     if (pre) {
         a.x = ws->xc;
         a.ldx = 16 * ws->T;
@@ -330,8 +309,10 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
     if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
     if (mode == 0 && ws->e_state == 2) return fail(GMMVB_ESTATE, "ln rho is undefined after gmmvb_load_responsibilities");
     const int64_t total = n_rows * ws->K;
+    const bool hmm_gamma = ws->e_state == 3 && mode == 1;      // responsibilities of an HMM pass = gamma
     hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       ws->lnrho, ws->lse, ws->npad, row0, n_rows, ws->K, mode, ws->e_state == 2 ? 1 : 0, out);
+                       hmm_gamma ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->lse, ws->npad, row0, n_rows, ws->K, mode,
+                       (ws->e_state == 2 || hmm_gamma) ? 1 : 0, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "readout launch", e);
     return GMMVB_OK;
@@ -350,7 +331,7 @@ int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_d
     if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
     hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       ws->lnrho, ws->npad, row0, n_rows, ws->K, z_dev);
+                       ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->npad, row0, n_rows, ws->K, z_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax launch", e);
     return GMMVB_OK;

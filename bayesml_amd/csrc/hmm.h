@@ -1,0 +1,531 @@
+// Scaled forward-backward for the Gaussian-emission HMM on f64 MFMA, chunk-parallel over time.
+//
+// Replaces the reference's Python loops over T (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py:
+// _forward :999-1006, _backward :1008-1011), _update_gamma :1013-1014, _update_xi :1016-1018 (a
+// materialised [T, K, K] array, 82 GB at config 5) and the ms/ns part of _calc_n_m_x_bar_s :837-845.
+//
+// With rho'_t = exp(ln rho_t - max_k ln rho_tk) (the reference exponentiates unshifted, :997, and
+// underflows) the recursions are
+//   alpha_t  = rho'_t o (alpha_{t-1} A~) / c'_t,   c'_t = sum(...)          ln c_t = ln c'_t + max_t
+//   beta~_i  ~ A~ (rho'_{i+1} o beta~_{i+1})        (any per-step scale: gamma and xi renormalise)
+//   gamma_t  = alpha_t o beta~_t / (alpha_t . beta~_t)
+//   ms       = A~ o sum_{t>=1} alpha_{t-1}^T w_t,   w_t = rho'_t o beta~_t / (c'_t (alpha_t . beta~_t))
+// Both directions are linear maps per step, M_t = A~ diag(rho'_t), so time is cut into chunks of L
+// steps (chunk c = steps 1 + cL .. (c+1)L; t = 0 is the start vector) and
+//   H2  chunk_products : P_c = prod_{t in c} M_t, one wave per chunk, K^3 per step on MFMA (both
+//                        directions use the same P_c: forward as row-vector x P_c, backward as P_c x column)
+//   H3  boundary_scan  : the short sequential pass over chunks (start vector of every chunk)
+//   H4  forward_replay : 16 chunks per wave as the 16 MFMA columns, K^2 per step; writes alpha, c'
+//   H5  backward_replay: same shape, descending; writes gamma (time-major) and w
+//   H6  xi_sum         : the [K x T] x [T x K] product over time on MFMA, slabs per wave
+// State vectors live in the MFMA C/D layout (state on register/lane-group, chunk on lane & 15) and the
+// contraction index of step s is taken as {16 kt + g + 4 s}, which makes the accumulator of one time
+// step directly the B operand of the next: no cross-lane movement, no LDS, in the whole recursion.
+// Time-major arrays store state 16 it + (g + 4 r) at position 16 it + 4 g + r ("lane order"), so each
+// lane reads/writes 4 contiguous doubles per 16-state block.
+#pragma once
+#include "common.h"
+
+namespace gmmvb {
+
+__host__ __device__ constexpr int hmm_pos(int state) {          // natural state -> lane-order position
+    const int w = state & 15;
+    return (state & ~15) + 4 * (w & 3) + (w >> 2);
+}
+__host__ __device__ constexpr int hmm_state(int pos) {          // inverse
+    const int w = pos & 15;
+    return (pos & ~15) + (w >> 2) + 4 * (w & 3);
+}
+
+// H1: ln rho [K][npad] (component-major) -> rho' [T][Kp] lane order, mx[T].  Thread per time step.
+__global__ void hmm_prep_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t T, int K, int Kp,
+                                double* __restrict__ rho_tm, double* __restrict__ mx) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double m = lnrho[t];
+    for (int k = 1; k < K; ++k) m = fmax(m, lnrho[(int64_t)k * npad + t]);
+    mx[t] = m;
+    double* out = rho_tm + t * Kp;
+    for (int p = 0; p < Kp; ++p) {
+        const int k = hmm_state(p);
+        out[p] = k < K ? exp(lnrho[(int64_t)k * npad + t] - m) : 0.0;
+    }
+}
+
+// A operand registers of a constant Kp x Kp matrix M for D' = M . (state-major operand):
+//   aop[it][kt][s] = M[16 it + i][16 kt + g + 4 s]      lane = (i = l & 15, g = l >> 4)
+template <int KT>
+__device__ __forceinline__ void load_aop(const double* __restrict__ m, int ld, bool transpose, int K,
+                                         double (&aop)[KT][KT][4]) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int r = 16 * it + i, c = 16 * kt + g + 4 * s;
+                double v = 0.0;
+                if (r < K && c < K) v = transpose ? m[c * ld + r] : m[r * ld + c];
+                aop[it][kt][s] = v;
+            }
+}
+
+// out[it] = M . in  for one 16-column block (in/out in C/D layout: reg r of tile it = state 16 it + g + 4 r)
+template <int KT>
+__device__ __forceinline__ void apply(const double (&aop)[KT][KT][4], const d4 (&in)[KT], d4 (&out)[KT]) {
+#pragma unroll
+    for (int it = 0; it < KT; ++it) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_f64(aop[it][kt][s], in[kt][s], acc);
+        out[it] = acc;
+    }
+}
+
+__device__ __forceinline__ double max_wave(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// H2: P_c = prod_{t = 1 + cL}^{min((c+1)L, T-1)} A~ diag(rho'_t).  One wave per chunk; P^T is kept as KT
+// column blocks in C/D layout: P^T <- diag(rho'_t) A~^T P^T.  Rescaled (any positive factor) every 4 steps.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_chunk_products_kernel(const double* __restrict__ rho_tm,
+                                                                 const double* __restrict__ a_tilde, int K, int64_t T,
+                                                                 int64_t L, int64_t n_chunks,
+                                                                 double* __restrict__ prod /*[n_chunks][Kp][Kp] (P, natural order)*/) {
+    constexpr int Kp = 16 * KT;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    double aop[KT][KT][4];
+    load_aop<KT>(a_tilde, K, /*transpose=*/true, K, aop);
+    d4 pt[KT][KT];   // [column block jt][row tile it] of P^T
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[jt][it][r] = (it == jt && (g + 4 * r) == j) ? 1.0 : 0.0;
+    const int64_t t0 = 1 + c * L;
+    int64_t t1 = t0 + L;
+    if (t1 > T) t1 = T;
+    for (int64_t t = t0; t < t1; ++t) {
+        d4 rho[KT];
+#pragma unroll
+        for (int it = 0; it < KT; ++it) rho[it] = *reinterpret_cast<const d4*>(rho_tm + t * Kp + 16 * it + 4 * g);
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt) {
+            d4 nw[KT];
+            apply<KT>(aop, pt[jt], nw);
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[jt][it][r] = nw[it][r] * rho[it][r];
+        }
+        if (((t - t0) & 3) == 3) {
+            double m = 0.0;
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int it = 0; it < KT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmax(m, pt[jt][it][r]);
+            m = max_wave(m);
+            const double sc = m > 0.0 ? 1.0 / m : 1.0;
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int it = 0; it < KT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[jt][it][r] *= sc;
+        }
+    }
+    // P[row = column index of P^T][col = row index of P^T]
+    double* out = prod + c * Kp * Kp;
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * jt + j) * Kp + 16 * it + g + 4 * r] = pt[jt][it][r];
+}
+
+// H3: sequential pass over chunk boundaries; wave 0 forward, wave 1 backward (natural state order, lane =
+// state, the running vector lives in one register per lane and is broadcast with shuffles: no LDS, no barrier).
+//   fstart[c] = alpha at t = c L (normalised), fstart[0] = alpha_0;  cprime[0] = c'_0
+//   bend[c]   = beta~ at the last step of chunk c (normalised to sum 1), bend[last] = uniform
+//   T == 1 (no chunks): gamma_0 = alpha_0, w_0 = 0 are written here.
+__global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __restrict__ rho_tm,
+                                                                const double* __restrict__ pi_tilde,
+                                                                const double* __restrict__ prod, int K, int Kp,
+                                                                int64_t n_chunks, double* __restrict__ fstart,
+                                                                double* __restrict__ bend, double* __restrict__ cprime,
+                                                                double* __restrict__ alpha_tm, double* __restrict__ gamma_tm,
+                                                                double* __restrict__ w_tm) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        double v = lane < K ? rho_tm[hmm_pos(lane)] * pi_tilde[lane] : 0.0;
+        const double s = sum_wave(v);
+        if (lane == 0) cprime[0] = s;
+        v = s > 0.0 ? v / s : 0.0;
+        if (lane < Kp) {
+            fstart[lane] = v;
+            if (n_chunks == 0) {
+                alpha_tm[hmm_pos(lane)] = v;
+                gamma_tm[hmm_pos(lane)] = v;
+                w_tm[hmm_pos(lane)] = 0.0;
+            }
+        }
+        for (int64_t c = 0; c + 1 < n_chunks; ++c) {
+            const double* P = prod + c * Kp * Kp;
+            double acc = 0.0;
+            for (int i = 0; i < Kp; ++i) {
+                const double vi = __shfl(v, i);
+                if (lane < Kp) acc = fma(vi, P[i * Kp + lane], acc);
+            }
+            const double tot = sum_wave(acc);
+            v = tot > 0.0 ? acc / tot : 0.0;
+            if (lane < Kp) fstart[(c + 1) * Kp + lane] = v;
+        }
+    } else {
+        double v = lane < K ? 1.0 / K : 0.0;
+        if (lane < Kp && n_chunks > 0) bend[(n_chunks - 1) * Kp + lane] = v;
+        for (int64_t c = n_chunks - 1; c >= 1; --c) {
+            const double* P = prod + c * Kp * Kp;
+            double acc = 0.0;
+            for (int jj = 0; jj < Kp; ++jj) {
+                const double vj = __shfl(v, jj);
+                if (lane < Kp) acc = fma(P[lane * Kp + jj], vj, acc);
+            }
+            const double tot = sum_wave(acc);
+            v = tot > 0.0 ? acc / tot : 0.0;
+            if (lane < Kp) bend[(c - 1) * Kp + lane] = v;
+        }
+    }
+}
+
+// H4: forward replay.  One wave = 16 chunks (MFMA columns).  alpha_tm / rho_tm in lane order.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* __restrict__ rho_tm,
+                                                                 const double* __restrict__ a_tilde, int K, int64_t T,
+                                                                 int64_t L, int64_t n_chunks,
+                                                                 const double* __restrict__ fstart,
+                                                                 double* __restrict__ alpha_tm, double* __restrict__ cprime) {
+    constexpr int Kp = 16 * KT;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + j;
+    const bool live = c < n_chunks;
+    double aop[KT][KT][4];
+    load_aop<KT>(a_tilde, K, /*transpose=*/true, K, aop);      // alpha^T_new = A~^T alpha^T_old
+    d4 al[KT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) al[it][r] = live ? fstart[c * Kp + 16 * it + g + 4 * r] : 0.0;
+    if (live && c == 0) {                                        // alpha_0 itself is part of the output
+#pragma unroll
+        for (int it = 0; it < KT; ++it) *reinterpret_cast<d4*>(alpha_tm + 16 * it + 4 * g) = al[it];
+    }
+    const int64_t t0 = 1 + c * L;
+    for (int64_t s = 0; s < L; ++s) {
+        const int64_t t = t0 + s;
+        const bool on = live && t < T;
+        d4 nw[KT];
+        apply<KT>(aop, al, nw);
+        double part = 0.0;
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            d4 rho = {0.0, 0.0, 0.0, 0.0};
+            if (on) rho = *reinterpret_cast<const d4*>(rho_tm + t * Kp + 16 * it + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nw[it][r] *= rho[r];
+                part += nw[it][r];
+            }
+        }
+        const double cp = sum_groups(part);
+        const double inv = cp > 0.0 ? 1.0 / cp : 0.0;
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) al[it][r] = nw[it][r] * inv;
+            if (on) *reinterpret_cast<d4*>(alpha_tm + t * Kp + 16 * it + 4 * g) = al[it];
+        }
+        if (on && g == 0) cprime[t] = cp;
+    }
+}
+
+// H5: backward replay, descending in time.  Writes gamma_tm (lane order) and w_tm; gamma_0 too.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* __restrict__ rho_tm,
+                                                                  const double* __restrict__ a_tilde, int K, int64_t T,
+                                                                  int64_t L, int64_t n_chunks,
+                                                                  const double* __restrict__ bend,
+                                                                  const double* __restrict__ alpha_tm,
+                                                                  const double* __restrict__ cprime,
+                                                                  double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
+    constexpr int Kp = 16 * KT;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + j;
+    const bool live = c < n_chunks;
+    double aop[KT][KT][4];
+    load_aop<KT>(a_tilde, K, /*transpose=*/false, K, aop);     // beta_{t-1} ~ A~ (rho'_t o beta_t)
+    d4 be[KT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) be[it][r] = live ? bend[c * Kp + 16 * it + g + 4 * r] : 0.0;
+    const int64_t t0 = 1 + c * L;
+    for (int64_t s = L - 1; s >= 0; --s) {
+        const int64_t t = t0 + s;
+        const bool on = live && t < T;
+        // gamma_t, w_t from beta~_t (registers), alpha_t, rho'_t, c'_t
+        d4 y[KT];
+        double dot = 0.0;
+        d4 al[KT], rho[KT];
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            al[it] = d4{0.0, 0.0, 0.0, 0.0};
+            rho[it] = d4{0.0, 0.0, 0.0, 0.0};
+            if (on) {
+                al[it] = *reinterpret_cast<const d4*>(alpha_tm + t * Kp + 16 * it + 4 * g);
+                rho[it] = *reinterpret_cast<const d4*>(rho_tm + t * Kp + 16 * it + 4 * g);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot = fma(al[it][r], be[it][r], dot);
+        }
+        dot = sum_groups(dot);
+        const double cp = on ? cprime[t] : 1.0;
+        const double ginv = dot > 0.0 ? 1.0 / dot : 0.0;
+        const double winv = (dot > 0.0 && cp > 0.0) ? 1.0 / (dot * cp) : 0.0;
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            d4 gm, ww;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y[it][r] = rho[it][r] * be[it][r];
+                gm[r] = al[it][r] * be[it][r] * ginv;
+                ww[r] = y[it][r] * winv;
+            }
+            if (on) {
+                *reinterpret_cast<d4*>(gamma_tm + t * Kp + 16 * it + 4 * g) = gm;
+                *reinterpret_cast<d4*>(w_tm + t * Kp + 16 * it + 4 * g) = ww;
+            }
+        }
+        // beta~_{t-1} ~ A~ y, renormalised to sum 1 (columns that are off keep their start vector)
+        d4 nb[KT];
+        apply<KT>(aop, y, nb);
+        double part = 0.0;
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += nb[it][r];
+        const double tot = sum_groups(part);
+        const double inv = tot > 0.0 ? 1.0 / tot : 0.0;
+        if (on) {
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) be[it][r] = nb[it][r] * inv;
+        }
+    }
+    if (live && c == 0) {                                       // gamma_0 = alpha_0 o beta~_0, normalised
+        double dot = 0.0;
+        d4 al[KT];
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            al[it] = *reinterpret_cast<const d4*>(alpha_tm + 16 * it + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot = fma(al[it][r], be[it][r], dot);
+        }
+        // only the 4 lanes with j == 0 hold chunk 0: reduce over the lane groups of THIS column
+        dot = sum_groups(dot);
+        const double ginv = dot > 0.0 ? 1.0 / dot : 0.0;
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            d4 gm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gm[r] = al[it][r] * be[it][r] * ginv;
+            *reinterpret_cast<d4*>(gamma_tm + 16 * it + 4 * g) = gm;
+            *reinterpret_cast<d4*>(w_tm + 16 * it + 4 * g) = d4{0.0, 0.0, 0.0, 0.0};      // xi_0 = 0
+        }
+    }
+}
+
+// H6: raw[pi][pj] = sum_{t=1}^{T-1} alpha_tm[t-1][pi] * w_tm[t][pj] (lane-order positions), slabs per wave.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_xi_sum_kernel(const double* __restrict__ alpha_tm,
+                                                         const double* __restrict__ w_tm, int64_t T,
+                                                         int64_t steps_per_wave, double* __restrict__ slabs) {
+    constexpr int Kp = 16 * KT;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t lo = 1 + w * steps_per_wave;
+    int64_t hi = lo + steps_per_wave;
+    if (hi > T) hi = T;
+    d4 acc[KT][KT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt) acc[it][jt] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int64_t t = lo; t < hi; t += 4) {
+        const int64_t tt = t + g;
+        double a[KT], b[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            a[kt] = tt < hi ? alpha_tm[(tt - 1) * Kp + 16 * kt + i] : 0.0;
+            b[kt] = tt < hi ? w_tm[tt * Kp + 16 * kt + i] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) acc[it][jt] = mfma_f64(a[it], b[jt], acc[it][jt]);
+    }
+    double* out = slabs + w * Kp * Kp;
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * it + g + 4 * r) * Kp + 16 * jt + i] = acc[it][jt][r];
+}
+
+// ms[i][j] = a_tilde[i][j] * sum_w slabs[w][pos(i)][pos(j)];  also sum_t (ln c'_t + mx_t), gamma_first/last
+__global__ void hmm_finish_kernel(const double* __restrict__ slabs, int64_t n_waves, const double* __restrict__ a_tilde,
+                                  int K, int Kp, const double* __restrict__ cprime, const double* __restrict__ mx,
+                                  int64_t T, const double* __restrict__ gamma_tm,
+                                  double* __restrict__ out /*[K*K | K | K | 1]*/) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < K * K; e += blockDim.x) {
+        const int i = e / K, j = e - i * K;
+        double s = 0.0;
+        for (int64_t w = 0; w < n_waves; ++w) s += slabs[w * Kp * Kp + hmm_pos(i) * Kp + hmm_pos(j)];
+        out[e] = a_tilde[e] * s;
+    }
+    for (int k = tid; k < K; k += blockDim.x) {
+        out[K * K + k] = gamma_tm[hmm_pos(k)];
+        out[K * K + K + k] = gamma_tm[(T - 1) * Kp + hmm_pos(k)];
+    }
+    // deterministic tree over a fixed partition of t
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t t = tid; t < T; t += blockDim.x) s += log(cprime[t]) + mx[t];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) out[K * K + 2 * K] = red[0];
+}
+
+// gamma_tm [T][Kp] lane order -> component-major [K][npad] (the M-step's responsibility buffer)
+__global__ void hmm_gamma_to_cm_kernel(const double* __restrict__ gamma_tm, int64_t T, int K, int Kp, int64_t npad,
+                                       double* __restrict__ gamma_cm) {
+    __shared__ double tile[64][65];
+    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const int k0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+        const int tt = e >> 6, kk = e & 63;
+        const int64_t t = t0 + tt;
+        const int k = k0 + kk;
+        tile[tt][kk] = (t < T && k < K) ? gamma_tm[t * Kp + hmm_pos(k)] : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+        const int kk = e >> 6, tt = e & 63;
+        const int64_t t = t0 + tt;
+        const int k = k0 + kk;
+        if (t < T && k < K) gamma_cm[(int64_t)k * npad + t] = tile[tt][kk];
+    }
+}
+
+// ---- Viterbi (estimate_latent_vars(loss="0-1", viterbi=True), _hiddenmarkovnormal.py:1465-1481) ----------
+// First version: the max-plus recursion is run sequentially by ONE wave (lane = state), 8 time steps of
+// ln rho prefetched per lane; the back-pointers are chased through LDS-staged blocks.  A chunked max-plus
+// scan (the same structure as the sum-product kernels above) is the planned replacement.
+template <int KT>
+__global__ __launch_bounds__(64) void hmm_viterbi_forward_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                                 const double* __restrict__ ln_pi_tilde,
+                                                                 const double* __restrict__ ln_a_tilde, int K, int64_t T,
+                                                                 unsigned char* __restrict__ phi /*[T][Kp]*/,
+                                                                 int* __restrict__ last_state) {
+    constexpr int Kp = 16 * KT;
+    const int j = threadIdx.x;
+    const double NEG = -1.0e300;
+    double col[Kp];
+#pragma unroll
+    for (int i = 0; i < Kp; ++i) col[i] = (i < K && j < K) ? ln_a_tilde[i * K + j] : NEG;
+    const double* lr = lnrho + (int64_t)(j < K ? j : 0) * npad;
+    double omega = j < K ? lr[0] + ln_pi_tilde[j] : NEG;
+    for (int64_t t0 = 1; t0 < T; t0 += 8) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = (t0 + u < T) ? lr[t0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (t0 + u < T) {
+                double best = NEG * 2.0;
+                int arg = 0;
+#pragma unroll
+                for (int i = 0; i < Kp; ++i) {
+                    const double v = __shfl(omega, i) + col[i];
+                    if (v > best) {          // strict: first maximiser, like numpy.argmax
+                        best = v;
+                        arg = i;
+                    }
+                }
+                omega = j < K ? e[u] + best : NEG;
+                if (j < Kp) phi[(t0 + u) * Kp + j] = (unsigned char)arg;
+            }
+        }
+    }
+    // first maximiser of omega_{T-1}
+    double best = omega;
+    int arg = j;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int oa = __shfl_xor(arg, o);
+        if (ob > best || (ob == best && oa < arg)) {
+            best = ob;
+            arg = oa;
+        }
+    }
+    if (j == 0) *last_state = arg;
+}
+
+__global__ __launch_bounds__(256) void hmm_viterbi_backtrack_kernel(const unsigned char* __restrict__ phi, int Kp,
+                                                                    int64_t T, const int* __restrict__ last_state,
+                                                                    int32_t* __restrict__ z) {
+    constexpr int BLK = 512;
+    __shared__ unsigned char tile[BLK * 64];
+    __shared__ int cur;
+    if (threadIdx.x == 0) {
+        cur = *last_state;
+        z[T - 1] = cur;
+    }
+    __syncthreads();
+    for (int64_t hi = T - 1; hi >= 1; hi -= BLK) {          // steps hi, hi-1, ..., lo use phi[t] to get state at t-1
+        const int64_t lo = hi - BLK + 1 > 1 ? hi - BLK + 1 : 1;
+        const int64_t n = (hi - lo + 1) * Kp;
+        for (int64_t e = threadIdx.x; e < n; e += blockDim.x) tile[e] = phi[lo * Kp + e];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k = cur;
+            for (int64_t t = hi; t >= lo; --t) {
+                k = tile[(t - lo) * Kp + k];
+                z[t - 1] = k;
+            }
+            cur = k;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace gmmvb

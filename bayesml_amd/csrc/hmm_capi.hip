@@ -1,0 +1,200 @@
+// C ABI of the HMM forward-backward pass (include/gmmvb.h, hmmvb_* entry points).
+#include "workspace.h"
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+
+#include "hmm.h"
+
+using namespace gmmvb;
+
+struct gmmvb_hmm_state {
+    int K = 0, Kp = 0, KT = 0;
+    int64_t npad = 0, max_chunks = 0, xi_waves = 0;
+    double* rho_tm = nullptr;     // [npad][Kp] lane order
+    double* alpha_tm = nullptr;   // [npad][Kp]
+    double* gamma_tm = nullptr;   // [npad][Kp]
+    double* w_tm = nullptr;       // [npad][Kp]
+    double* gamma_cm = nullptr;   // [K][npad]  (the M-step's responsibility buffer)
+    double* mx = nullptr;         // [npad]
+    double* cprime = nullptr;     // [npad]
+    double* prod = nullptr;       // [max_chunks][Kp][Kp]
+    double* fstart = nullptr;     // [max_chunks][Kp]
+    double* bend = nullptr;       // [max_chunks][Kp]
+    double* xi_slabs = nullptr;   // [xi_waves][Kp][Kp]
+    unsigned char* phi = nullptr; // [npad][Kp] Viterbi back-pointers (allocated on first use by hmmvb_enable)
+    int* last_state = nullptr;
+    int64_t bytes = 0;
+};
+
+namespace gmmvb {
+void hmm_state_destroy(gmmvb_hmm_state* h) {
+    if (!h) return;
+    double* bufs[] = {h->rho_tm, h->alpha_tm, h->gamma_tm, h->w_tm, h->gamma_cm, h->mx,
+                      h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs};
+    for (double* p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->phi) (void)hipFree(h->phi);
+    if (h->last_state) (void)hipFree(h->last_state);
+    delete h;
+}
+const double* hmm_gamma_cm(const gmmvb_hmm_state* h) { return h ? h->gamma_cm : nullptr; }
+}  // namespace gmmvb
+
+namespace {
+
+// chunk length: balances the sequential boundary scan (~T/L steps) against the replay depth (~L steps)
+int64_t chunk_len(int64_t T) {
+    int64_t L = 16;
+    while (L < 4096 && L * L < T) L *= 2;
+    return L;
+}
+
+template <int KT>
+hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
+               double* out, hipStream_t st) {
+    const int K = h->K, Kp = h->Kp;
+    const int64_t L = chunk_len(T);
+    const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
+    hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ws->lnrho, ws->npad, T, K,
+                       Kp, h->rho_tm, h->mx);
+    if (n_chunks > 0)
+        hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
+                           h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod);
+    hipLaunchKernelGGL(hmm_boundary_scan_kernel, dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K, Kp,
+                       n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+    if (n_chunks > 0) {
+        const unsigned grid = (unsigned)((n_chunks + 63) / 64);      // 16 chunks per wave, 4 waves per block
+        hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
+                           n_chunks, h->fstart, h->alpha_tm, h->cprime);
+        hipLaunchKernelGGL((hmm_backward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
+                           n_chunks, h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+    }
+    // xi sum over t = 1 .. T-1
+    int64_t n_waves = h->xi_waves;
+    int64_t steps = T > 1 ? round_up((T - 1 + n_waves - 1) / n_waves, 4) : 4;
+    n_waves = T > 1 ? (T - 1 + steps - 1) / steps : 0;
+    if (n_waves > 0)
+        hipLaunchKernelGGL((hmm_xi_sum_kernel<KT>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, h->alpha_tm,
+                           h->w_tm, T, steps, h->xi_slabs);
+    // waves of the last block beyond n_waves write slabs too (zeros): include them only if they exist
+    const int64_t n_slabs = n_waves > 0 ? ((n_waves + 3) / 4) * 4 : 0;
+    hipLaunchKernelGGL(hmm_finish_kernel, dim3(1), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp, h->cprime,
+                       h->mx, T, h->gamma_tm, out);
+    hipLaunchKernelGGL(hmm_gamma_to_cm_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0,
+                       st, h->gamma_tm, T, K, Kp, ws->npad, h->gamma_cm);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t hmmvb_out_len(int K) { return K < 1 ? -1 : (int64_t)K * K + 2 * (int64_t)K + 1; }
+
+int hmmvb_enable(gmmvb_workspace* ws) {
+    if (!ws) return fail(GMMVB_EINVAL, "null argument");
+    if (ws->hmm) return GMMVB_OK;
+    if (ws->K > 64) return fail(GMMVB_EUNSUPPORTED, "HMM forward-backward supports K <= 64 in this version");
+    gmmvb_hmm_state* h = new (std::nothrow) gmmvb_hmm_state();
+    if (!h) return fail(GMMVB_ENOMEM, "host allocation failed");
+    h->K = ws->K;
+    h->KT = (ws->K + 15) / 16;
+    h->Kp = 16 * h->KT;
+    h->npad = ws->npad;
+    h->max_chunks = ws->npad / 16 + 2;          // chunk_len >= 16
+    h->xi_waves = 4 * (int64_t)ws->num_cu;
+    const int64_t tk = h->npad * h->Kp;
+    struct { double** p; int64_t n; } bufs[] = {
+        {&h->rho_tm, tk}, {&h->alpha_tm, tk}, {&h->gamma_tm, tk}, {&h->w_tm, tk},
+        {&h->gamma_cm, (int64_t)ws->K * h->npad}, {&h->mx, h->npad}, {&h->cprime, h->npad},
+        {&h->prod, h->max_chunks * h->Kp * h->Kp}, {&h->fstart, h->max_chunks * h->Kp},
+        {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, (h->xi_waves + 4) * h->Kp * h->Kp}};
+    for (auto& b : bufs) {
+        hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
+        if (e != hipSuccess) {
+            hmm_state_destroy(h);
+            return fail(GMMVB_ENOMEM, "hipMalloc (HMM buffers)", e);
+        }
+        h->bytes += b.n * (int64_t)sizeof(double);
+    }
+    hipError_t e2 = hipMalloc((void**)&h->phi, (size_t)(h->npad * h->Kp));
+    if (e2 == hipSuccess) e2 = hipMalloc((void**)&h->last_state, sizeof(int));
+    if (e2 != hipSuccess) {
+        hmm_state_destroy(h);
+        return fail(GMMVB_ENOMEM, "hipMalloc (Viterbi buffers)", e2);
+    }
+    h->bytes += h->npad * h->Kp + 4;
+    ws->hmm = h;
+    ws->bytes += h->bytes;
+    return GMMVB_OK;
+}
+
+int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde_dev, const double* ln_a_tilde_dev,
+                  int32_t* z_dev, void* stream) {
+    if (!ws || !ln_pi_tilde_dev || !ln_a_tilde_dev || !z_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
+    if (ws->e_state != 1 || ws->e_rows != n_rows)
+        return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
+    gmmvb_hmm_state* h = ws->hmm;
+    hipStream_t st = (hipStream_t)stream;
+#define VIT(KTT)                                                                                                     \
+    hipLaunchKernelGGL((hmm_viterbi_forward_kernel<KTT>), dim3(1), dim3(64), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, \
+                       ln_a_tilde_dev, h->K, n_rows, h->phi, h->last_state)
+    switch (h->KT) {
+        case 1: VIT(1); break;
+        case 2: VIT(2); break;
+        case 3: VIT(3); break;
+        default: VIT(4); break;
+    }
+#undef VIT
+    hipLaunchKernelGGL(hmm_viterbi_backtrack_kernel, dim3(1), dim3(256), 0, st, h->phi, h->Kp, n_rows, h->last_state,
+                       z_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "viterbi launch", e);
+    return GMMVB_OK;
+}
+
+int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi_tilde_dev, const double* a_tilde_dev,
+                           double* out_dev, void* stream) {
+    if (!ws || !pi_tilde_dev || !a_tilde_dev || !out_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
+    if (ws->e_state != 1 || ws->e_rows != n_rows)
+        return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    switch (ws->hmm->KT) {
+        case 1: e = run<1>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+        case 2: e = run<2>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+        case 3: e = run<3>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+        case 4: e = run<4>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+        default: return fail(GMMVB_EUNSUPPORTED, "K > 64");
+    }
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "HMM forward-backward launch", e);
+    ws->e_state = 3;
+    return GMMVB_OK;
+}
+
+/* Read-outs of the last forward-backward pass for rows [row0, row0 + n_rows): alpha / beta~ are not kept in
+ * natural order; this returns alpha (mode 0) or c' (mode 1, [n_rows]) for tests. */
+int hmmvb_debug_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, double* out_dev, void* stream) {
+    if (!ws || !ws->hmm || !out_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (ws->e_state != 3 || row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "bad range");
+    gmmvb_hmm_state* h = ws->hmm;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (what == 1) {
+        e = hipMemcpyAsync(out_dev, h->cprime + row0, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToDevice, st);
+    } else if (what == 2) {
+        e = hipMemcpyAsync(out_dev, h->mx + row0, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToDevice, st);
+    } else {
+        // alpha in lane order, [n_rows][Kp]; the caller un-permutes (positions: hmm_pos)
+        e = hipMemcpyAsync(out_dev, h->alpha_tm + row0 * h->Kp, (size_t)n_rows * h->Kp * sizeof(double),
+                           hipMemcpyDeviceToDevice, st);
+    }
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "debug readout", e);
+    return GMMVB_OK;
+}
+
+}  // extern "C"

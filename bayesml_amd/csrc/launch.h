@@ -12,7 +12,7 @@ struct EstepArgs {
 };
 struct MstepArgs {
     const void* x; int64_t ldx; int64_t n_rows; int D;
-    const double* pivot; const double* lnrho; const double* lse; int64_t npad;
+    const double* pivot; const double* lnrho; const double* lse; const double* aux; int64_t npad;
     int K; int KG; int S; int64_t rows_per_split; int direct_r; double* slabs;
 };
 

@@ -59,8 +59,8 @@ __host__ __device__ constexpr int mstep_owned(int ws, int sub, int t) {
 template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE>
 __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                            const double* __restrict__ pivot, const double* __restrict__ lr,
-                                           const double* __restrict__ lse, int64_t lo, int64_t hi, int direct_r,
-                                           double* __restrict__ out) {
+                                           const double* __restrict__ lse, const double* __restrict__ aux_k,
+                                           int64_t lo, int64_t hi, int direct_r, double* __restrict__ out) {
     constexpr int P = tri_pairs(T);
     constexpr int NP = mstep_owned(WS, SUB, T);   // tile pairs owned by this wave
     const int lane = threadIdx.x & 63;
@@ -118,7 +118,10 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
         double r_l = 0.0;
         if (nl < hi) {
             const double v = lr[nl];
-            if (direct_r) {
+            if (direct_r == 2) {                 // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
+                r_l = v;
+                if (v > 0.0) hsum = fma(v, aux_k[nl], hsum);
+            } else if (direct_r) {
                 r_l = v;
                 if (v > 0.0) hsum = fma(v, log(v), hsum);
             } else {
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
     const double* __restrict__ pivot,      // [D]
     const double* __restrict__ lnrho,      // [K][npad]  (ln rho, or r itself when direct_r)
     const double* __restrict__ lse,        // [npad]
+    const double* __restrict__ aux,        // [K][npad] (direct_r == 2 only)
     int64_t npad, int K, int KG, int S, int64_t rows_per_split, int direct_r,
     double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
     constexpr int WS = mstep_ws(T);
@@ -224,14 +228,15 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
     int64_t hi = lo + rows_per_split;
     if (hi > n_rows) hi = n_rows;
     const double* lr = lnrho + (int64_t)k * npad;
+    const double* aux_k = aux ? aux + (int64_t)k * npad : nullptr;
     double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
     if constexpr (WS == 1) {
-        mstep_body<T, 1, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+        mstep_body<T, 1, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out);
     } else {
         if (sub == 0)
-            mstep_body<T, 2, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+            mstep_body<T, 2, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out);
         else
-            mstep_body<T, 2, 1, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, lo, hi, direct_r, out);
+            mstep_body<T, 2, 1, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out);
     }
 }
 

@@ -10,7 +10,7 @@ namespace gmmvb {
 template <int T, typename XT, bool VEC, bool PRE>
 static hipError_t go(int grid, hipStream_t st, const MstepArgs& a) {
     hipLaunchKernelGGL((mstep_mfma_f64<T, XT, VEC, PRE>), dim3(grid), dim3(64 * mstep_waves(T, PRE)), 0, st,
-                       static_cast<const XT*>(a.x), a.ldx, a.n_rows, a.D, a.pivot, a.lnrho, a.lse, a.npad, a.K, a.KG,
+                       static_cast<const XT*>(a.x), a.ldx, a.n_rows, a.D, a.pivot, a.lnrho, a.lse, a.aux, a.npad, a.K, a.KG,
                        a.S, a.rows_per_split, a.direct_r, a.slabs);
     return hipGetLastError();
 }

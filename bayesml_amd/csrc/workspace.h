@@ -1,0 +1,41 @@
+// Workspace object and error helper shared by the C-ABI translation units.
+#pragma once
+#include "../../include/gmmvb.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct gmmvb_hmm_state;      // HMM forward-backward buffers (hmm_capi.hip), allocated by hmmvb_enable
+
+struct gmmvb_workspace {
+    int K = 0, D = 0, T = 0, x_dtype = 0;
+    int64_t max_rows = 0, npad = 0;
+    int num_cu = 0, KG = 0, S_cap = 0;
+    double* lnrho = nullptr;   // [K][npad]
+    double* lse = nullptr;     // [npad]
+    double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
+    int img_len = 0;
+    int estep_variant = 0;     // kEstepLds8 (default); env GMMVB_ESTEP_VARIANT=direct|lds4 selects the others
+    double* cvec = nullptr;    // [K]
+    double* pivot = nullptr;   // [D]
+    double* slabs = nullptr;   // [S_cap][K][slab_len]
+    double* xc = nullptr;      // [npad][16T] centred f64 copy of the sample matrix (M-step operand), optional
+    const void* xc_src = nullptr;   // the x it was made from (null = not prepared)
+    int64_t xc_rows = 0, xc_ldx = 0;
+    int64_t bytes = 0;
+    bool have_params = false;
+    int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly, 3 HMM gamma
+    int64_t e_rows = 0;
+    char info[512] = {0};
+    bool prof = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // E begin/end, M begin/end
+    bool ev_e = false, ev_m = false;
+    gmmvb_hmm_state* hmm = nullptr;
+};
+
+namespace gmmvb {
+int fail(int code, const char* what, hipError_t e = hipSuccess);     // sets the thread-local message
+void hmm_state_destroy(gmmvb_hmm_state* h);
+const double* hmm_gamma_cm(const gmmvb_hmm_state* h);                 // [K][npad] responsibilities of the last pass
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+}  // namespace gmmvb

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from .. import _check, _kside, base
+from .._device import DeviceModel
 from .._dist import SingleProcess
 from .._exceptions import CriteriaError, DataFormatError, ParameterFormatError, ResultWarning
 
@@ -163,7 +164,7 @@ class GenModel(base.Generative):
         raise NotImplementedError("plotting is out of scope for bayesml_amd (SURVEY.md section 2, row 2)")
 
 
-class LearnModel(base.Posterior, base.PredictiveMixin):
+class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
     """Variational posterior and predictive distribution of the Gaussian mixture.
 
     Positional parameters are the reference's (ref:421-431): ``c_num_classes, c_degree,
@@ -282,52 +283,7 @@ class LearnModel(base.Posterior, base.PredictiveMixin):
         self._e_ln_lambda_dets[:] = _np(q.e_ln_lambda_det)
         self._ln_b_hn_w_nus[:] = _np(q.ln_b_w_nu)
 
-    # ------------------------------------------------------------------ device plumbing
-    def _open(self, x):
-        """Validate ``x`` like ref:829-834, move it to the GPU once, (re)create the workspace."""
-        D, K = self.c_degree, self.c_num_classes
-        if isinstance(x, torch.Tensor):
-            if not (x.dtype.is_floating_point and x.dim() >= 1):
-                raise DataFormatError("x must be a numpy.ndarray whose ndim >= 1.")
-        else:
-            _check.float_vecs(x, "x", DataFormatError)
-        if x.shape[-1] != D:
-            raise DataFormatError(f"x.shape[-1] must be self.c_degree: x.shape[-1]={x.shape[-1]}, self.c_degree={D}")
-        x = x.reshape(-1, D)
-        if self._data_pass_factory is not None:
-            eng = self._data_pass_factory(K, D, x)
-            xd = eng.adopt(x)
-        else:
-            from .._engine import DataPass, EngineUnavailableError
-            if not torch.cuda.is_available():
-                raise EngineUnavailableError(
-                    "bayesml_amd.gaussianmixture.LearnModel needs an MI355X: the data pass has no CPU fallback")
-            dev = torch.device("cuda", torch.cuda.current_device()) if self._device is None else torch.device(self._device)
-            if isinstance(x, torch.Tensor):
-                xd = x.to(dev)
-                if xd.dtype not in (torch.float32, torch.float64):
-                    xd = xd.to(torch.float64)
-            else:
-                xh = np.ascontiguousarray(x if x.dtype in (np.float32, np.float64) else x.astype(np.float64))
-                xd = torch.from_numpy(xh).to(dev)
-            xd = xd.contiguous()
-            eng = self._engine
-            if (eng is None or eng.K != K or eng.D != D or eng.x_dtype != xd.dtype or eng.max_rows < xd.shape[0]
-                    or eng.device != dev or getattr(eng, "_ws", None) is None):
-                if eng is not None:
-                    eng.close()
-                eng = DataPass(K, D, xd.dtype, xd.shape[0], dev)
-        self._engine, self._x_dev, self._r_cache = eng, xd, None
-        self._comm.bind_rows(xd.shape[0], xd.device)
-        # expansion point of the second moments: mean of the leading rows (any fixed point near the data works)
-        head = xd[: min(xd.shape[0], 4096)].to(torch.float64)
-        cnt = torch.tensor([float(head.shape[0])], dtype=torch.float64, device=xd.device)
-        acc = torch.cat([head.sum(dim=0), cnt])
-        self._comm.all_reduce_(acc)
-        eng.set_pivot(acc[:-1] / acc[-1])
-        eng.prepare_rows(xd)
-        return eng, xd
-
+    # ------------------------------------------------------------------ device plumbing (see _device.py)
     def _pass(self, eng, xd, q, s_prev, estep=True):
         """One data pass: statistics block -> all-reduce over row shards -> reference moments."""
         if estep:
@@ -339,10 +295,6 @@ class LearnModel(base.Posterior, base.PredictiveMixin):
         ns, h, a, B = eng.split_stats(stats)
         x_bar, s = _kside.moments_from_stats(ns, a, B, eng.pivot, s_prev)
         return ns, x_bar, s, h.sum()
-
-    def _say(self, text, end=""):
-        if self._verbose and self._comm.rank == 0:
-            print(text, end=end)
 
     # ------------------------------------------------------------------ the hot path
     def update_posterior(self, x, max_itr=100, num_init=10, tolerance=1.0E-8, init_type="subsampling"):
@@ -421,20 +373,9 @@ class LearnModel(base.Posterior, base.PredictiveMixin):
         return self
 
     def _init_subsampling(self, eng, xd, q, n_global):
-        """ref:786-796.  The host draws the row INDICES with the model's Generator —
-        ``rng.choice(x, size, replace=False, axis=0, shuffle=False)`` consumes the stream exactly like
-        ``rng.choice(N, size, replace=False, shuffle=False)`` — and the GPU gathers the rows it owns."""
-        K, D = self.c_num_classes, self.c_degree
-        size = int(np.sqrt(n_global))
-        dev = xd.device
-        ab = torch.zeros(K, D + D * D, dtype=torch.float64, device=dev)
-        for k in range(K):
-            idx = torch.from_numpy(self.rng.choice(n_global, size=size, replace=False, shuffle=False)).to(dev)
-            rows = xd.index_select(0, self._comm.local_indices(idx)).to(torch.float64) - eng.pivot
-            ab[k, :D] = rows.sum(dim=0)
-            ab[k, D:] = (rows.T @ rows).reshape(-1)
-        self._comm.all_reduce_(ab)
-        return _kside.subsample_moments_init(q, float(size), ab[:, :D], ab[:, D:].reshape(K, D, D), eng.pivot)
+        """ref:786-796 on the GPU (index draw on the host, see _device.DeviceModel._subsample_moments)."""
+        size, a, B = self._subsample_moments(eng, xd, n_global)
+        return _kside.subsample_moments_init(q, size, a, B, eng.pivot, _kside.features)
 
     # lazily fetched [N, K] arrays of the last data pass (the reference keeps them as attributes)
     @property

@@ -104,6 +104,32 @@ int gmmvb_responsibilities(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, do
 int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
 int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_dev, void* stream);
 
+/* ---- Gaussian-emission HMM (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py) -------------------------
+ * The emission term is the GMM E-step without E[ln pi]: call gmmvb_set_params with
+ *   c[k] = (E[ln det Lambda_k] - D ln 2pi - D/kappa_k)/2     (_calc_rho, :988-996)
+ * and gmmvb_estep; then hmmvb_forward_backward replaces _forward :999-1006, _backward :1008-1011,
+ * _update_gamma :1013-1014, _update_xi :1016-1018 and the ms / gamma part of _calc_n_m_x_bar_s :837-845:
+ *   pi_tilde[k]   = exp(ln pi~_k - max)          (:862-863)
+ *   a_tilde[i][j] = exp(ln a~_ij - max over all) (:866-867)
+ *   out = [ ms[K][K] = sum_{t>=1} xi_t | gamma_0[K] | gamma_{T-1}[K] | sum_t ln c_t ]   (hmmvb_out_len doubles)
+ * where c_t are the reference's scaling constants (the engine shifts ln rho per row and adds the shift back).
+ * Afterwards the workspace holds gamma as the responsibilities: gmmvb_mstep returns ns / a / B for gamma
+ * and h[k] = sum_t gamma_tk ln rho_tk (the first term of _vl_q_z, :905), gmmvb_responsibilities returns
+ * gamma and gmmvb_argmax its row-wise argmax.  hmmvb_enable allocates the forward-backward buffers
+ * (4 [T][16 ceil(K/16)] + 1 [K][T] doubles); K <= 64. */
+int64_t hmmvb_out_len(int K);
+int hmmvb_enable(gmmvb_workspace* ws);
+int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi_tilde_dev, const double* a_tilde_dev,
+                           double* out_dev, void* stream);
+/* Viterbi path (estimate_latent_vars(loss="0-1", viterbi=True), :1465-1481) from the emission ln rho of the
+ * last gmmvb_estep: z_dev[t] = state index of the most probable path (first maximiser on ties). */
+int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde_dev, const double* ln_a_tilde_dev,
+                  int32_t* z_dev, void* stream);
+
+/* test/diagnostic read-out of the last pass: what = 0 alpha ([n_rows][16 ceil(K/16)], lane order: state
+ * 16b + (g + 4r) at position 16b + 4g + r), 1 c' ([n_rows]), 2 row shift max_k ln rho ([n_rows]). */
+int hmmvb_debug_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
+
 /* Optional in-library timing of the two dominant kernels with HIP events recorded on the launch
  * stream immediately before/after the estep_mfma_f64 / mstep_mfma_f64 launches (bench.py's
  * roofline leg).  gmmvb_profile_last_ms waits for the events of the last estep / mstep. */

@@ -37,6 +37,7 @@ class CpuDataPass:
         pass
 
     def estep(self, x):
+        self._hmm_gamma = None
         x = x.to(torch.float64)
         y = torch.einsum("kji,nki->nkj", self.u, x[:, None, :] - self.m[None])     # y = u (x - m)
         self._ln_rho = self.c[None, :] - 0.5 * (y * y).sum(dim=2)
@@ -63,12 +64,67 @@ class CpuDataPass:
         src = self._direct if self._direct is not None else self._ln_rho
         return torch.argmax(src[row0:row0 + n], dim=1).to(torch.int32)
 
+    # ---- HMM (semantics of hmmvb_* in include/gmmvb.h), plain sequential recursions
+    def enable_hmm(self):
+        self._hmm_gamma = None
+
+    def forward_backward(self, pi_tilde, a_tilde):
+        ln_rho = self._ln_rho
+        T, K = ln_rho.shape
+        mx = ln_rho.max(dim=1).values
+        rho = torch.exp(ln_rho - mx[:, None])
+        alpha = torch.empty_like(rho)
+        cs = torch.empty(T, dtype=torch.float64)
+        a = rho[0] * pi_tilde
+        cs[0] = a.sum()
+        alpha[0] = a / cs[0]
+        for t in range(1, T):
+            a = rho[t] * (alpha[t - 1] @ a_tilde)
+            cs[t] = a.sum()
+            alpha[t] = a / cs[t]
+        beta = torch.ones_like(rho)
+        for t in range(T - 2, -1, -1):
+            beta[t] = a_tilde @ (rho[t + 1] * beta[t + 1]) / cs[t + 1]
+        gamma = alpha * beta
+        ms = torch.zeros(K, K, dtype=torch.float64)
+        for t in range(1, T):
+            ms += alpha[t - 1][:, None] * rho[t][None, :] * a_tilde * beta[t][None, :] / cs[t]
+        self._hmm_gamma, self._alpha = gamma, alpha
+        self._direct = gamma
+        return ms, gamma[0].clone(), gamma[-1].clone(), (torch.log(cs) + mx).sum()
+
+    def viterbi(self, ln_pi_tilde, ln_a_tilde):
+        ln_rho = self._ln_rho
+        T, K = ln_rho.shape
+        omega = ln_rho[0] + ln_pi_tilde
+        phi = torch.zeros(T, K, dtype=torch.int64)
+        for t in range(1, T):
+            cand = ln_a_tilde + omega[:, None]
+            best, arg = cand.max(dim=0)
+            phi[t] = arg
+            omega = ln_rho[t] + best
+        z = torch.zeros(T, dtype=torch.int32)
+        k = int(torch.argmax(omega))
+        z[-1] = k
+        for t in range(T - 2, -1, -1):
+            k = int(phi[t + 1, k])
+            z[t] = k
+        return z
+
+    def hmm_debug(self, what, row0=0, n=None):
+        return self._alpha
+
     def mstep(self, x):
         K, D = self.K, self.D
         r = self.responsibilities()
         xp = x.to(torch.float64) - self.pivot
         stats = torch.empty(self.stats_len, dtype=torch.float64)
         stats[:K] = r.sum(dim=0)
+        if getattr(self, "_hmm_gamma", None) is not None and self._direct is self._hmm_gamma:
+            stats[K:2 * K] = (r * self._ln_rho).sum(dim=0)          # HMM mode: h = sum gamma ln rho
+            stats[2 * K:2 * K + K * D] = (r.T @ xp).reshape(-1)
+            stats[2 * K + K * D:] = torch.einsum("nk,ni,nj->kij", r, xp, xp).reshape(-1)
+            return stats
         stats[K:2 * K] = torch.special.xlogy(r, r).sum(dim=0)
         stats[2 * K:2 * K + K * D] = (r.T @ xp).reshape(-1)
         stats[2 * K + K * D:] = torch.einsum("nk,ni,nj->kij", r, xp, xp).reshape(-1)

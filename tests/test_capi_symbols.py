@@ -10,7 +10,7 @@ from conftest import ROOT
 def header_functions():
     text = open(os.path.join(ROOT, "include", "gmmvb.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gmmvb_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:gmmvb|hmmvb)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_the_expected_entry_points():

@@ -1,0 +1,177 @@
+"""GPU parity of the HMM forward-backward kernels (through the C ABI) against the reference fixtures
+(tests/golden/hmm_f6_*.npz) and against the oracle on seeded ragged shapes.  Tolerances: the engine is f64;
+alpha/gamma are probabilities (absolute 1e-10), sums relative 1e-9 (north_star asks 1e-5 on hyper-parameters)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import hmm_vb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def fixture_x(g):
+    K, D, T = int(g["K"]), int(g["D"]), int(g["N"])
+    if D == 2:
+        return load_golden("hmm_c1_sample.npz")["x"]
+    return orc.synth_hmm({16: 32 if K == 32 else 8}[D], D, T, np.dtype(str(g["x_dtype"])))[0]
+
+
+def device_pass(x, q, dev):
+    """One HMM data pass through the C ABI for oracle posterior `q`; returns numpy results."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    K, D = q.m.shape
+    T = x.shape[0]
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
+    f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), t(q.m), t(q.kappa), t(q.nu),
+                                     t(q.w_inv)))
+    c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    eng = DataPass(K, D, xd.dtype, T, dev)
+    eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+    eng.prepare_rows(xd)
+    eng.set_params(c, f.m, f.u)
+    eng.estep(xd)
+    ln_rho = eng.ln_rho().cpu().numpy()
+    eng.enable_hmm()
+    ms, g0, gl, lnc = eng.forward_backward(t(q.pi_tilde), t(q.a_tilde))
+    ns, h, a, B = eng.split_stats(eng.mstep(xd))
+    x_bar, s = _kside.moments_from_stats(ns, a, B, eng.pivot, torch.zeros(K, D, D, dtype=torch.float64, device=dev))
+    out = dict(ln_rho=ln_rho, ms=ms.cpu().numpy(), g0=g0.cpu().numpy(), gl=gl.cpu().numpy(), lnc=float(lnc),
+               ns=ns.cpu().numpy(), h=float(h.sum()), x_bar=x_bar.cpu().numpy(), s=s.cpu().numpy(),
+               gamma=eng.responsibilities().cpu().numpy(), alpha=eng.hmm_debug(0).cpu().numpy(),
+               argmax=eng.argmax().cpu().numpy())
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["hmm_f6_k4_d2_t500.npz", "hmm_f6_k32_d16_t4096.npz"])
+def test_forward_backward_matches_reference(name):
+    g = load_golden(name)
+    x = fixture_x(g)
+    q = orc.HmmPosterior(*(g["in_" + k].copy() for k in ("hn_eta_vec", "hn_zeta_vecs", "hn_m_vecs", "hn_kappas",
+                                                         "hn_nus", "hn_w_mats", "hn_w_mats_inv"))).refresh()
+    r = device_pass(x, q, torch.device("cuda", 0))
+    n = g["ln_rho"].shape[0]
+    assert rel_err(r["ln_rho"][:n], g["ln_rho"]) < 1e-11
+    assert np.max(np.abs(r["alpha"][:n] - g["alpha_vecs"])) < 1e-10
+    assert np.max(np.abs(r["gamma"][:n] - g["gamma_vecs"])) < 1e-10
+    assert np.max(np.abs(r["gl"] - g["gamma_last"])) < 1e-10
+    assert np.max(np.abs(r["g0"] - g["gamma_vecs"][0])) < 1e-10
+    assert abs(r["lnc"] - float(g["ln_cs_sum"])) < 1e-9 * abs(float(g["ln_cs_sum"]))
+    assert rel_err(r["ms"], g["ms"]) < 1e-9
+    assert rel_err(r["ns"], g["ns"]) < 1e-9
+    assert rel_err(r["x_bar"], g["x_bar_vecs"]) < 1e-9
+    assert rel_err(r["s"], g["s_mats"]) < 1e-8
+    # h = sum gamma ln rho is the first term of _vl_q_z; rebuild that term from the fixture's pieces
+    K = int(g["K"])
+    assert abs(r["ms"].sum() - (int(g["N"]) - 1)) < 1e-7          # every xi_t sums to one
+    assert abs(r["ns"].sum() - int(g["N"])) < 1e-7
+
+
+@pytest.mark.parametrize("K,D,T,dtype", [(3, 2, 1, np.float64), (5, 3, 2, np.float64), (7, 4, 17, np.float32),
+                                         (16, 8, 1000, np.float64), (20, 5, 3001, np.float32),
+                                         (33, 6, 777, np.float64), (64, 4, 5000, np.float32), (2, 1, 40000, np.float64)])
+def test_ragged_shapes_against_oracle(K, D, T, dtype):
+    """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths; random posterior."""
+    rng = np.random.default_rng(100 * K + D)
+    x, _ = orc.synth_hmm(max(2, K // 2), D, T, dtype, seed=K + T, stay=0.8)
+    p = orc.HmmPrior.default(K, D)
+    q = orc.HmmPosterior.from_prior(p)
+    q.m = 3.0 * rng.standard_normal((K, D))
+    a = rng.standard_normal((K, D, D))
+    q.w_inv = a @ np.swapaxes(a, 1, 2) + D * np.eye(D)
+    q.w = np.linalg.inv(q.w_inv)
+    q.nu = q.nu + rng.uniform(0, 3, K)
+    q.kappa = q.kappa + rng.uniform(0, 3, K)
+    q.eta = q.eta + rng.uniform(0, 5, K)
+    q.zeta = q.zeta + rng.uniform(0, 5, (K, K)) + 4 * np.eye(K)
+    q.refresh()
+    x64 = x.astype(np.float64)
+    ln_rho = orc.emission_ln_rho(x64, q)
+    mx = ln_rho.max(axis=1, keepdims=True)
+    alpha, beta, cs = orc.forward_backward(np.exp(ln_rho - mx), q.pi_tilde, q.a_tilde)   # shifted: no underflow
+    gamma = alpha * beta
+    ms = np.zeros((K, K))
+    rho = np.exp(ln_rho - mx)
+    for t in range(1, T):
+        ms += alpha[t - 1][:, None] * rho[t][None, :] * q.a_tilde * beta[t][None, :] / cs[t]
+    r = device_pass(x, q, torch.device("cuda", 0))
+    assert np.max(np.abs(r["alpha"] - alpha)) < 1e-10
+    assert np.max(np.abs(r["gamma"] - gamma)) < 1e-10
+    assert np.max(np.abs(r["g0"] - gamma[0])) < 1e-10 and np.max(np.abs(r["gl"] - gamma[-1])) < 1e-10
+    assert abs(r["lnc"] - float((np.log(cs) + mx[:, 0]).sum())) < 1e-9 * max(1.0, abs(float((np.log(cs) + mx[:, 0]).sum())))
+    if T > 1:
+        assert rel_err(r["ms"], ms) < 1e-9
+    else:
+        assert np.all(r["ms"] == 0.0)
+    assert rel_err(r["ns"], gamma.sum(axis=0)) < 1e-9
+    assert abs(r["h"] - float((gamma * ln_rho).sum())) < 1e-9 * max(1.0, abs(float((gamma * ln_rho).sum())))
+    assert np.array_equal(r["argmax"], np.argmax(gamma, axis=1)) or np.mean(r["argmax"] == np.argmax(gamma, axis=1)) > 0.999
+
+
+DRIVER = ["hmm_f3_k4_subsampling.npz", "hmm_f3_k4_random_resp.npz", "hmm_f3_k8_d16_t8192_f32.npz", "hmm_f3_t1.npz"]
+
+
+@pytest.mark.parametrize("name", DRIVER)
+def test_full_driver_matches_reference(name):
+    import io
+    import json
+    import warnings
+    from contextlib import redirect_stdout
+    from bayesml_amd import ResultWarning
+    from bayesml_amd import hiddenmarkovnormal as hmm
+    g = load_golden(name)
+    if "x" in g:
+        x = g["x"]
+    elif int(g["D"]) == 2:
+        x = load_golden("hmm_c1_sample.npz")["x"]
+    else:
+        x = orc.synth_hmm(8, 16, int(g["N"]), np.float32)[0]
+    K, D = int(g["K"]), int(g["D"])
+    kw = json.loads(str(g["kw"]))
+    m = hmm.LearnModel(K, D, seed=int(g["seed"]))
+    buf = io.StringIO()
+    with warnings.catch_warnings(record=True) as w, redirect_stdout(buf):
+        warnings.simplefilter("always")
+        m.update_posterior(x, **kw)
+    assert any(issubclass(i.category, ResultWarning) for i in w) == bool(g["result_warning"])
+    lines = [ln for ln in buf.getvalue().split("\n") if ln.strip()]
+    tr = g["vl_trace"]
+    assert len(lines) == tr.shape[0]
+    assert max(i for i, ln in enumerate(lines) if ln.endswith("*")) == int(g["winner"])
+    for i, ln in enumerate(lines):
+        vals = [float(s.split("VL: ")[1].split(" ")[0].rstrip("*")) for s in ln.split("\r") if s]
+        ref = tr[i][~np.isnan(tr[i])]
+        assert len(vals) == len(ref) and np.allclose(vals, ref, rtol=1e-8)
+    tol = 1e-7                                   # north_star asks for 1e-5
+    for key in ("hn_eta_vec", "hn_zeta_vecs", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+        assert rel_err(m.get_hn_params()[key], g[key]) < tol, key
+    assert rel_err(m.ns, g["ns"]) < tol
+    if float(np.abs(g["ms"]).max()) > 0:
+        assert rel_err(m.ms, g["ms"]) < tol
+    assert np.max(np.abs(m.gamma_vecs[:64] - g["gamma_head"])) < 1e-7
+    assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+    m.calc_pred_dist()
+    assert rel_err(m.make_prediction("squared"), g["pred_squared"]) < 1e-6
+    if "viterbi_01" in g:
+        xs = x[:g["viterbi_01"].shape[0]]
+        with redirect_stdout(io.StringIO()):
+            assert np.array_equal(m.estimate_latent_vars(xs, "0-1", viterbi=True), g["viterbi_01"])
+            assert np.array_equal(m.estimate_latent_vars(xs, "0-1", viterbi=False), g["marginal_01"])
+            assert np.max(np.abs(m.estimate_latent_vars(xs, "squared", viterbi=False) - g["marginal_sq"])) < 1e-7
+
+
+@pytest.mark.parametrize("K,D,T", [(5, 3, 1), (12, 4, 700), (40, 2, 3000)])
+def test_viterbi_kernel_against_oracle(K, D, T):
+    from bayesml_amd import hiddenmarkovnormal as hmm
+    x, _ = orc.synth_hmm(max(2, K // 2), D, T, np.float64, seed=7 * K + T)
+    m = hmm.LearnModel(K, D, seed=1, verbose=False)
+    rng = np.random.default_rng(K)
+    m.set_hn_params(hn_eta_vec=rng.uniform(0.5, 5, K), hn_zeta_vecs=rng.uniform(0.5, 5, (K, K)) + 3 * np.eye(K),
+                    hn_m_vecs=3.0 * rng.standard_normal((K, D)))
+    q = orc.HmmPosterior(m.hn_eta_vec.copy(), m.hn_zeta_vecs.copy(), m.hn_m_vecs.copy(), m.hn_kappas.copy(),
+                         m.hn_nus.copy(), m.hn_w_mats.copy(), m.hn_w_mats_inv.copy()).refresh()
+    assert np.array_equal(m.estimate_latent_vars(x, "0-1", viterbi=True), orc.viterbi(x, q))

@@ -1,0 +1,119 @@
+"""HMM host logic on CPU (validators, K-side math, restart driver, RNG order, stdout protocol) with the
+test-only CPU stand-in for the data pass; the HIP kernels are covered by tests/test_gpu_hmm.py."""
+import io
+import json
+import os
+import warnings
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_err
+from fake_engine import cpu_factory
+
+import bayesml_amd
+from bayesml_amd import hiddenmarkovnormal as hmm
+
+
+def cpu_model(*a, **k):
+    m = hmm.LearnModel(*a, **k)
+    m._data_pass_factory = cpu_factory
+    return m
+
+
+def quiet(fn, *a, **k):
+    with redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return fn(*a, **k)
+
+
+def test_boundary_errors_match_reference_classes():
+    with open(os.path.join(GOLDEN, "hmm_errors.json")) as f:
+        expected = json.load(f)
+    cases = {
+        "ctor_positional_h0": lambda: hmm.LearnModel(3, 2, np.ones(3)),
+        "ctor_float_degree": lambda: hmm.LearnModel(3, 2.0),
+        "h0_zeta_nonpos": lambda: hmm.LearnModel(3, 2, h0_zeta_vecs=np.zeros((3, 3))),
+        "h0_nus_all_small": lambda: hmm.LearnModel(3, 2, h0_nus=np.array([1.0, 1.0, 1.0])),
+        "h0_nus_some_small": lambda: hmm.LearnModel(3, 2, h0_nus=np.array([1.0, 3.0, 3.0])),
+        "h0_w_not_pd": lambda: hmm.LearnModel(3, 2, h0_w_mats=np.array([[1.0, 2.0], [2.0, 1.0]])),
+        "h0_m_wrong_dim": lambda: hmm.LearnModel(3, 2, h0_m_vecs=np.zeros((3, 3))),
+        "x_wrong_last_dim": lambda: quiet(cpu_model(3, 2).update_posterior, np.zeros((10, 3))),
+        "x_not_ndarray": lambda: quiet(cpu_model(3, 2).update_posterior, [[0.0, 1.0]]),
+        "bad_init_type": lambda: quiet(cpu_model(3, 2, seed=0).update_posterior,
+                                       np.random.default_rng(0).standard_normal((50, 2)), init_type="kmeans"),
+        "bad_loss_estimate_params": lambda: hmm.LearnModel(3, 2).estimate_params("L1"),
+        "viterbi_bad_loss": lambda: cpu_model(3, 2).estimate_latent_vars(np.zeros((4, 2)), "squared", viterbi=True),
+        "marginal_bad_loss": lambda: cpu_model(3, 2).estimate_latent_vars(np.zeros((4, 2)), "L1", viterbi=False),
+        "gen_a_not_sum1": lambda: hmm.GenModel(2, 1, a_mat=np.array([[0.5, 0.4], [0.5, 0.5]])),
+        "gen_positional": lambda: hmm.GenModel(2, 1, np.array([0.5, 0.5])),
+        "scalar_broadcast_ok": lambda: hmm.LearnModel(3, 2, h0_eta_vec=2.0, h0_zeta_vecs=1.5, h0_kappas=2.0, h0_nus=3.0),
+    }
+    assert set(cases) == set(expected)
+    for name, fn in cases.items():
+        try:
+            fn()
+            got = None
+        except Exception as e:      # noqa: BLE001
+            got = type(e).__name__
+        assert got == expected[name], (name, got, expected[name])
+
+
+def test_key_order_and_defaults():
+    m = hmm.LearnModel(3, 2)
+    assert list(m.get_h0_params()) == ["h0_eta_vec", "h0_zeta_vecs", "h0_m_vecs", "h0_kappas", "h0_nus", "h0_w_mats"]
+    assert list(m.get_hn_params()) == ["hn_eta_vec", "hn_zeta_vecs", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"]
+    assert list(m.get_p_params()) == ["p_a_mat", "p_mu_vecs", "p_nus", "p_lambda_mats"]
+    assert np.all(m.h0_zeta_vecs == 0.5) and np.all(m.h0_eta_vec == 0.5)
+    g = hmm.GenModel(3, 2)
+    assert list(g.get_params()) == ["pi_vec", "a_mat", "mu_vecs", "lambda_mats"]
+
+
+def test_gen_sample_reproduces_reference_stream():
+    gen = hmm.GenModel(4, 2, a_mat=np.array([[0.85, 0.05, 0.05, 0.05], [0.05, 0.85, 0.05, 0.05],
+                                             [0.05, 0.05, 0.85, 0.05], [0.05, 0.05, 0.05, 0.85]]),
+                       mu_vecs=np.array([[-4.0, 0.0], [4.0, 0.0], [0.0, 5.0], [0.0, -5.0]]), seed=321)
+    x, z = gen.gen_sample(500)
+    ref = load_golden("hmm_c1_sample.npz")
+    assert np.array_equal(z, ref["z"]) and np.allclose(x, ref["x"], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["hmm_f3_k4_subsampling.npz", "hmm_f3_k4_random_resp.npz", "hmm_f3_t1.npz"])
+def test_driver_protocol_and_rng_order(name):
+    g = load_golden(name)
+    x = g["x"] if "x" in g else load_golden("hmm_c1_sample.npz")["x"]
+    K, D = int(g["K"]), int(g["D"])
+    kw = json.loads(str(g["kw"]))
+    m = cpu_model(K, D, seed=int(g["seed"]))
+    buf = io.StringIO()
+    with warnings.catch_warnings(record=True) as w, redirect_stdout(buf):
+        warnings.simplefilter("always")
+        m.update_posterior(x, **kw)
+    assert any(issubclass(i.category, bayesml_amd.ResultWarning) for i in w) == bool(g["result_warning"])
+    lines = [ln for ln in buf.getvalue().split("\n") if ln.strip()]
+    tr = g["vl_trace"]
+    assert len(lines) == tr.shape[0]
+    assert max(i for i, ln in enumerate(lines) if ln.endswith("*")) == int(g["winner"])
+    for i, ln in enumerate(lines):
+        vals = [float(s.split("VL: ")[1].split(" ")[0].rstrip("*")) for s in ln.split("\r") if s]
+        ref = tr[i][~np.isnan(tr[i])]
+        assert len(vals) == len(ref) and np.allclose(vals, ref, rtol=1e-8)
+    for key in ("hn_eta_vec", "hn_zeta_vecs", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+        assert rel_err(m.get_hn_params()[key], g[key]) < 1e-7, key
+    assert rel_err(m.ms, g["ms"]) < 1e-7 or float(np.abs(g["ms"]).max()) == 0.0
+    assert np.max(np.abs(m.gamma_vecs[:64] - g["gamma_head"])) < 1e-7
+    pi, a, mu, lam = m.estimate_params("squared")
+    assert rel_err(a, g["est_sq_a"]) < 1e-7 and rel_err(lam, g["est_sq_lambda"]) < 1e-6
+    pi01, a01, _, lam01 = quiet(m.estimate_params, "0-1")
+    assert np.allclose(a01, g["est_01_a"], rtol=1e-6, equal_nan=True)
+    for key in ("p_a_mat", "p_mu_vecs", "p_nus", "p_lambda_mats"):
+        assert np.allclose(m.get_p_params()[key], g["stale_" + key], rtol=1e-12, atol=1e-300), key
+    m.calc_pred_dist()
+    assert rel_err(m.make_prediction("squared"), g["pred_squared"]) < 1e-6
+    assert rel_err(m.make_prediction("0-1"), g["pred_01"]) < 1e-6
+    if "viterbi_01" in g:
+        xs = x[:g["viterbi_01"].shape[0]]
+        assert np.array_equal(quiet(m.estimate_latent_vars, xs, "0-1", True), g["viterbi_01"])
+        assert np.array_equal(quiet(m.estimate_latent_vars, xs, "0-1", False), g["marginal_01"])
+        assert np.max(np.abs(quiet(m.estimate_latent_vars, xs, "squared", False) - g["marginal_sq"])) < 1e-7
