@@ -157,17 +157,23 @@ __global__ __launch_bounds__(256) void hmm_chunk_products_kernel(const double* _
 
 // H3: sequential pass over chunk boundaries; wave 0 forward, wave 1 backward (natural state order, lane =
 // state, the running vector lives in one register per lane and is broadcast with shuffles: no LDS, no barrier).
+// The lane's column (forward) / row (backward) of the NEXT chunk product is loaded while the current one is
+// multiplied, so the dependent chain per chunk is Kp shuffles + FMAs, not Kp memory round trips.
 //   fstart[c] = alpha at t = c L (normalised), fstart[0] = alpha_0;  cprime[0] = c'_0
 //   bend[c]   = beta~ at the last step of chunk c (normalised to sum 1), bend[last] = uniform
 //   T == 1 (no chunks): gamma_0 = alpha_0, w_0 = 0 are written here.
+template <int KT>
 __global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __restrict__ rho_tm,
                                                                 const double* __restrict__ pi_tilde,
-                                                                const double* __restrict__ prod, int K, int Kp,
+                                                                const double* __restrict__ prod, int K,
                                                                 int64_t n_chunks, double* __restrict__ fstart,
                                                                 double* __restrict__ bend, double* __restrict__ cprime,
                                                                 double* __restrict__ alpha_tm, double* __restrict__ gamma_tm,
                                                                 double* __restrict__ w_tm) {
+    constexpr int Kp = 16 * KT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ln = lane < Kp ? lane : 0;
+    double cur[Kp], nxt[Kp];
     if (wave == 0) {
         double v = lane < K ? rho_tm[hmm_pos(lane)] * pi_tilde[lane] : 0.0;
         const double s = sum_wave(v);
@@ -181,13 +187,22 @@ __global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __
                 w_tm[hmm_pos(lane)] = 0.0;
             }
         }
+        if (n_chunks > 1) {
+#pragma unroll
+            for (int i = 0; i < Kp; ++i) nxt[i] = prod[i * Kp + ln];
+        }
         for (int64_t c = 0; c + 1 < n_chunks; ++c) {
-            const double* P = prod + c * Kp * Kp;
-            double acc = 0.0;
-            for (int i = 0; i < Kp; ++i) {
-                const double vi = __shfl(v, i);
-                if (lane < Kp) acc = fma(vi, P[i * Kp + lane], acc);
+#pragma unroll
+            for (int i = 0; i < Kp; ++i) cur[i] = nxt[i];
+            if (c + 2 < n_chunks) {
+                const double* P = prod + (c + 1) * Kp * Kp;
+#pragma unroll
+                for (int i = 0; i < Kp; ++i) nxt[i] = P[i * Kp + ln];
             }
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < Kp; ++i) acc = fma(__shfl(v, i), cur[i], acc);
+            if (lane >= Kp) acc = 0.0;
             const double tot = sum_wave(acc);
             v = tot > 0.0 ? acc / tot : 0.0;
             if (lane < Kp) fstart[(c + 1) * Kp + lane] = v;
@@ -195,13 +210,23 @@ __global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __
     } else {
         double v = lane < K ? 1.0 / K : 0.0;
         if (lane < Kp && n_chunks > 0) bend[(n_chunks - 1) * Kp + lane] = v;
+        if (n_chunks > 1) {
+            const double* P = prod + (n_chunks - 1) * Kp * Kp;
+#pragma unroll
+            for (int jj = 0; jj < Kp; ++jj) nxt[jj] = P[ln * Kp + jj];
+        }
         for (int64_t c = n_chunks - 1; c >= 1; --c) {
-            const double* P = prod + c * Kp * Kp;
-            double acc = 0.0;
-            for (int jj = 0; jj < Kp; ++jj) {
-                const double vj = __shfl(v, jj);
-                if (lane < Kp) acc = fma(P[lane * Kp + jj], vj, acc);
+#pragma unroll
+            for (int jj = 0; jj < Kp; ++jj) cur[jj] = nxt[jj];
+            if (c >= 2) {
+                const double* P = prod + (c - 1) * Kp * Kp;
+#pragma unroll
+                for (int jj = 0; jj < Kp; ++jj) nxt[jj] = P[ln * Kp + jj];
             }
+            double acc = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < Kp; ++jj) acc = fma(cur[jj], __shfl(v, jj), acc);
+            if (lane >= Kp) acc = 0.0;
             const double tot = sum_wave(acc);
             v = tot > 0.0 ? acc / tot : 0.0;
             if (lane < Kp) bend[(c - 1) * Kp + lane] = v;
@@ -395,9 +420,29 @@ __global__ __launch_bounds__(256) void hmm_xi_sum_kernel(const double* __restric
             for (int r = 0; r < 4; ++r) out[(16 * it + g + 4 * r) * Kp + 16 * jt + i] = acc[it][jt][r];
 }
 
+// partial[b] = sum over the b-th slice of t of (ln c'_t + mx_t); fixed partition and tree => deterministic
+__global__ __launch_bounds__(256) void hmm_lnc_partial_kernel(const double* __restrict__ cprime,
+                                                              const double* __restrict__ mx, int64_t T,
+                                                              double* __restrict__ partial) {
+    __shared__ double red[256];
+    const int64_t per = (T + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    int64_t hi = lo + per;
+    if (hi > T) hi = T;
+    double s = 0.0;
+    for (int64_t t = lo + threadIdx.x; t < hi; t += 256) s += log(cprime[t]) + mx[t];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // ms[i][j] = a_tilde[i][j] * sum_w slabs[w][pos(i)][pos(j)];  also sum_t (ln c'_t + mx_t), gamma_first/last
 __global__ void hmm_finish_kernel(const double* __restrict__ slabs, int64_t n_waves, const double* __restrict__ a_tilde,
-                                  int K, int Kp, const double* __restrict__ cprime, const double* __restrict__ mx,
+                                  int K, int Kp, const double* __restrict__ lnc_partial, int n_partial,
                                   int64_t T, const double* __restrict__ gamma_tm,
                                   double* __restrict__ out /*[K*K | K | K | 1]*/) {
     const int tid = threadIdx.x;
@@ -411,17 +456,11 @@ __global__ void hmm_finish_kernel(const double* __restrict__ slabs, int64_t n_wa
         out[K * K + k] = gamma_tm[hmm_pos(k)];
         out[K * K + K + k] = gamma_tm[(T - 1) * Kp + hmm_pos(k)];
     }
-    // deterministic tree over a fixed partition of t
-    __shared__ double red[256];
-    double s = 0.0;
-    for (int64_t t = tid; t < T; t += blockDim.x) s += log(cprime[t]) + mx[t];
-    red[tid] = s;
-    __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int b = 0; b < n_partial; ++b) s += lnc_partial[b];
+        out[K * K + 2 * K] = s;
     }
-    if (tid == 0) out[K * K + 2 * K] = red[0];
 }
 
 // gamma_tm [T][Kp] lane order -> component-major [K][npad] (the M-step's responsibility buffer)

@@ -23,6 +23,7 @@ struct gmmvb_hmm_state {
     double* fstart = nullptr;     // [max_chunks][Kp]
     double* bend = nullptr;       // [max_chunks][Kp]
     double* xi_slabs = nullptr;   // [xi_waves][Kp][Kp]
+    double* lnc_partial = nullptr;   // [kLncBlocks]
     unsigned char* phi = nullptr; // [npad][Kp] Viterbi back-pointers (allocated on first use by hmmvb_enable)
     int* last_state = nullptr;
     int64_t bytes = 0;
@@ -32,7 +33,7 @@ namespace gmmvb {
 void hmm_state_destroy(gmmvb_hmm_state* h) {
     if (!h) return;
     double* bufs[] = {h->rho_tm, h->alpha_tm, h->gamma_tm, h->w_tm, h->gamma_cm, h->mx,
-                      h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs};
+                      h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs, h->lnc_partial};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (h->phi) (void)hipFree(h->phi);
@@ -44,10 +45,13 @@ const double* hmm_gamma_cm(const gmmvb_hmm_state* h) { return h ? h->gamma_cm : 
 
 namespace {
 
-// chunk length: balances the sequential boundary scan (~T/L steps) against the replay depth (~L steps)
+constexpr int kLncBlocks = 1024;
+
+// chunk length: balances the sequential boundary scan (T/L steps of ~1.5 us) against the replay depth
+// (L steps of ~4 us forward+backward): L ~ sqrt(T * 1.5 / 4), a power of two in [16, 4096]
 int64_t chunk_len(int64_t T) {
     int64_t L = 16;
-    while (L < 4096 && L * L < T) L *= 2;
+    while (L < 4096 && 8 * L * L < 3 * T) L *= 2;
     return L;
 }
 
@@ -62,7 +66,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     if (n_chunks > 0)
         hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
                            h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod);
-    hipLaunchKernelGGL(hmm_boundary_scan_kernel, dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K, Kp,
+    hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K,
                        n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
     if (n_chunks > 0) {
         const unsigned grid = (unsigned)((n_chunks + 63) / 64);      // 16 chunks per wave, 4 waves per block
@@ -80,8 +84,10 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
                            h->w_tm, T, steps, h->xi_slabs);
     // waves of the last block beyond n_waves write slabs too (zeros): include them only if they exist
     const int64_t n_slabs = n_waves > 0 ? ((n_waves + 3) / 4) * 4 : 0;
-    hipLaunchKernelGGL(hmm_finish_kernel, dim3(1), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp, h->cprime,
-                       h->mx, T, h->gamma_tm, out);
+    const int n_part = (int)std::min<int64_t>(kLncBlocks, (T + 255) / 256);
+    hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
+    hipLaunchKernelGGL(hmm_finish_kernel, dim3(1), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
+                       h->lnc_partial, n_part, T, h->gamma_tm, out);
     hipLaunchKernelGGL(hmm_gamma_to_cm_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0,
                        st, h->gamma_tm, T, K, Kp, ws->npad, h->gamma_cm);
     return hipGetLastError();
@@ -110,7 +116,8 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         {&h->rho_tm, tk}, {&h->alpha_tm, tk}, {&h->gamma_tm, tk}, {&h->w_tm, tk},
         {&h->gamma_cm, (int64_t)ws->K * h->npad}, {&h->mx, h->npad}, {&h->cprime, h->npad},
         {&h->prod, h->max_chunks * h->Kp * h->Kp}, {&h->fstart, h->max_chunks * h->Kp},
-        {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, (h->xi_waves + 4) * h->Kp * h->Kp}};
+        {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, (h->xi_waves + 4) * h->Kp * h->Kp},
+        {&h->lnc_partial, kLncBlocks}};
     for (auto& b : bufs) {
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
         if (e != hipSuccess) {

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""HMM-VB time steps/sec at K=32, D=16, T=1e7 (BASELINE.json configs[4]) on one MI355X.
+
+Not the headline metric (bench.py is); this is the measurement for SURVEY.md section 8 row a11.
+A "step" = one VB iteration of hiddenmarkovnormal.LearnModel.update_posterior's inner loop
+(reference ``_hiddenmarkovnormal.py:1099-1105``): K-side update -> emission E-step -> forward-backward ->
+statistics -> lower bound.  Prints one JSON line; ``cpu_baseline`` times the oracle (NumPy restatement of
+the reference's Python loops over T) on the first ``--ref-rows`` steps and the parity of the posterior
+after 5 iterations on those steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from bayesml_amd import _kside                                   # noqa: E402
+from bayesml_amd import hiddenmarkovnormal as hmm                # noqa: E402
+
+
+def synth_device(K, D, T, dtype, dev, seed=20250711, stay=0.9, head=None):
+    """Sticky chain drawn on the device (state sequence via blocks of geometric run lengths is overkill:
+    a jump mask + cumulative 'last jump' gather gives the same process)."""
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    mu = 3.0 * torch.randn(K, D, dtype=torch.float64, device=dev, generator=gen)
+    jump = torch.rand(T, device=dev, generator=gen) >= stay
+    jump[0] = True
+    target = torch.randint(0, K, (T,), device=dev, generator=gen)
+    idx = torch.arange(T, device=dev)
+    last = torch.cummax(torch.where(jump, idx, torch.zeros_like(idx)), dim=0).values
+    z = target[last]
+    x = torch.empty((T, D), dtype=dtype, device=dev)
+    step = 1 << 20
+    for lo in range(0, T, step):
+        hi = min(T, lo + step)
+        x[lo:hi] = (mu[z[lo:hi]] + torch.randn(hi - lo, D, dtype=torch.float64, device=dev, generator=gen)).to(dtype)
+    if head is not None:
+        x[: head.shape[0]] = torch.from_numpy(head).to(dev)
+    return x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--classes", type=int, default=32)
+    ap.add_argument("--degree", type=int, default=16)
+    ap.add_argument("--ref-rows", type=int, default=20_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    K, D, T = args.classes, args.degree, args.rows
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+
+    from oracle import hmm_vb_oracle as orc
+    x_ref, _ = orc.synth_hmm(K, D, min(args.ref_rows, T), np.float32)
+    x = synth_device(K, D, T, torch.float32, dev, head=x_ref)
+
+    cpu = parity = None
+    if not args.no_cpu:
+        x64 = x_ref.astype(np.float64)
+        p = orc.HmmPrior.default(K, D)
+        q = orc.HmmPosterior.from_prior(p)
+        orc.init_subsampling(x64, q, np.random.default_rng(0))
+        st = orc.data_pass(x64, q)
+        iters = 5
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            orc.update_q(p, q, st)
+            st = orc.data_pass(x64, q, st.s)
+            orc.lower_bound(p, q, st)
+        cpu_s = time.perf_counter() - t0
+        m = hmm.LearnModel(K, D, seed=0, device=dev, verbose=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.update_posterior(x_ref, max_itr=iters, num_init=1, tolerance=0.0)
+
+        def rel(a, b):
+            return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+        errs = dict(hn_eta_vec=rel(m.hn_eta_vec, q.eta), hn_zeta_vecs=rel(m.hn_zeta_vecs, q.zeta),
+                    hn_m_vecs=rel(m.hn_m_vecs, q.m), hn_kappas=rel(m.hn_kappas, q.kappa), hn_nus=rel(m.hn_nus, q.nu),
+                    hn_w_mats=rel(m.hn_w_mats, q.w))
+        cpu = dict(value=x_ref.shape[0] * iters / cpu_s, unit="time steps/s", cores=1, kind="port",
+                   sample=f"{iters} VB iterations over the first {x_ref.shape[0]} steps (Python loop over T like the "
+                          "reference; the K x K mat-vec per step does not thread)", seconds=cpu_s)
+        parity = dict(max_rel_err=max(errs.values()), tolerance=1e-5, passed=max(errs.values()) < 1e-5, per_array=errs)
+        m._engine.close()
+
+    m = hmm.LearnModel(K, D, seed=0, device=dev, verbose=False)
+    eng, xd = m._open(x)
+    eng.enable_hmm()
+    prior = m._prior_tensors(dev)
+    q = _kside.hmm_post_from_prior(prior)
+    size, a, B = m._subsample_moments(eng, xd, T)
+    q = _kside.subsample_moments_init(q, size, a, B, eng.pivot, _kside.hmm_features)
+    st = m._pass(eng, xd, q, torch.zeros(K, D, D, dtype=torch.float64, device=dev))
+
+    def step():
+        nonlocal q, st
+        q = _kside.hmm_update_q(prior, st["ns"], st["ms"], st["x_bar"], st["s"])
+        st = m._pass(eng, xd, q, st["s"])
+        return float(m._vl(prior, q, st)["vl"])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vl = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "HMM-VB time steps/sec at K=32,D=16,T=1e7 (BASELINE.json configs[4])", "value": T * args.steps / el,
+        "unit": "time steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"HMM-VB K={K} D={D} T={T}, x stored f32, one VB iteration per step"},
+        "cpu_baseline": cpu, "parity": parity, "final_vl": vl}))
+
+
+if __name__ == "__main__":
+    main()
