@@ -3,6 +3,7 @@
 #include "workspace.h"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -66,6 +67,19 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     }
     ws->S_cap = (int)round_up(((int64_t)4 * ws->num_cu + ws->KG - 1) / ws->KG, 8);
     if (ws->S_cap < 8) ws->S_cap = 8;
+    {
+        // Cap on the rows of one M-step split: 16 MB of centred rows (16384 rows at D = 128).  All component groups
+        // of a split stream the same rows; short splits keep those workgroups within an L2's reach of each other
+        // (measured at C3: fetch 96 GB -> 16-21 GB ~ the algorithmic 15.4 GB, kernel 175.6 -> 171.5 ms) at the
+        // price of more slabs (+0.7 ms reduce).  env GMMVB_MSTEP_SPLIT_ROWS overrides; 0 disables the cap.
+        const char* v = std::getenv("GMMVB_MSTEP_SPLIT_ROWS");
+        ws->split_rows = round_up(std::max<int64_t>(64, (16 << 20) / (16 * ws->T * 8)), 64);
+        if (v) ws->split_rows = std::atoll(v) > 0 ? round_up(std::max<int64_t>(64, std::atoll(v)), 64) : 0;
+        if (ws->split_rows) {
+            const int64_t need = round_up((max_rows + ws->split_rows - 1) / ws->split_rows, 8);
+            if (need > ws->S_cap) ws->S_cap = (int)need;
+        }
+    }
     ws->img_len = estep_image_doubles(ws->T);
     {
         const char* v = std::getenv("GMMVB_ESTEP_VARIANT");
@@ -259,7 +273,8 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int64_t S = ws->S_cap;
     const int64_t groups = (n_rows + 63) / 64;
     if (S > groups) S = groups;
-    const int64_t rows_per_split = round_up((n_rows + S - 1) / S, 64);
+    int64_t rows_per_split = round_up((n_rows + S - 1) / S, 64);
+    if (ws->split_rows && rows_per_split > ws->split_rows) rows_per_split = ws->split_rows;
     S = (n_rows + rows_per_split - 1) / rows_per_split;
     const bool pre = ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     const int kpw = mstep_components_per_wg(ws->T, pre);

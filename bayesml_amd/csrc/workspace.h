@@ -11,6 +11,7 @@ struct gmmvb_workspace {
     int K = 0, D = 0, T = 0, x_dtype = 0;
     int64_t max_rows = 0, npad = 0;
     int num_cu = 0, KG = 0, S_cap = 0;
+    int64_t split_rows = 0;    // optional cap on rows per M-step split (0 = ~4 workgroups per CU)
     double* lnrho = nullptr;   // [K][npad]
     double* lse = nullptr;     // [npad]
     double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)

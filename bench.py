@@ -199,6 +199,17 @@ def main():
                                executed_mfma_tflops=fl_exec * n_local / (m_ms * 1e-3) / 1e12)}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         ach = kern[dom]["algorithmic_tflops"]
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
+        # take them from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py)
+        traffic = traffic_src = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pm = json.load(f).get(dom)
+            if pm and K == 64 and D == 128 and n_local == 10_000_000 and args.dtype == "f32":
+                traffic = pm["fetch_bytes"] + pm["write_bytes"]
+                traffic_src = "profiles/pmc_traffic.json: " + pm["note"]
+        except (OSError, ValueError, KeyError):
+            pass
         bytes_per_sample = D * x.element_size()
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
@@ -210,7 +221,8 @@ def main():
                        "classes": K, "degree": D, "rows_per_gpu": n_local, "x_storage": args.dtype,
                        "parallelism": f"rows{world}"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernels": kern,
                          "hbm_algorithmic_GBps": bytes_per_sample * n_local / ((e_ms + m_ms) * 1e-3) / 1e9,
                          "note": "achieved = algorithmic (dense) flops of SURVEY 8d / HIP-event kernel time; the kernels "

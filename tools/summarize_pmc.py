@@ -13,6 +13,11 @@ from collections import defaultdict
 
 
 def main():
+    json_out = None
+    if "--json" in sys.argv:
+        i = sys.argv.index("--json")
+        json_out = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     rows = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> values (largest grid only)
     grid = {}
     dur = defaultdict(list)
@@ -52,6 +57,18 @@ def main():
                 n_mfma = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0
                 print(f"  => non-MFMA vector instructions per MFMA = {(c['SQ_INSTS_VALU'] - n_mfma) / n_mfma:.2f}")
         print()
+    if json_out:
+        import json
+        out = {}
+        for name in rows:
+            c = {k: sum(v) / len(v) for k, v in rows[name].items()}
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                out[name.replace("gmmvb::", "").split("<")[0]] = dict(
+                    kernel=name, grid_threads=grid[name], fetch_bytes_raw=c["FETCH_SIZE"] * 1024,
+                    fetch_bytes=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024,
+                    note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, FETCH x2 (gfx950)")
+        with open(json_out, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
