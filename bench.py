@@ -38,7 +38,6 @@ from bayesml_amd import gaussianmixture as gm                 # noqa: E402
 
 SEED = 20250711
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X datasheet FP64 matrix (MI355X_MICROARCH.md lists no f64 row)
-PEAK_HBM_GBS = 8000.0
 
 
 def recipe_means(K, D):
