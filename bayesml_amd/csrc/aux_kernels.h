@@ -33,14 +33,15 @@ __global__ void pack_params_kernel(const double* __restrict__ u, const double* _
 
 // xc[n][f] = (double)x[n][f] - pivot[f] for f < D, 0 for D <= f < Dp (Dp = 16T): the M-step's operand,
 // made once per sample matrix so its inner loop carries no convert / subtract / mask work.
+// Rows n_rows .. pad_rows-1 are zero filled: the M-step prefetches a few rows past its range without a clamp.
 template <typename XT>
-__global__ void center_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D, int Dp,
-                                   const double* __restrict__ pivot, double* __restrict__ xc) {
+__global__ void center_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int64_t pad_rows, int D,
+                                   int Dp, const double* __restrict__ pivot, double* __restrict__ xc) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_rows * Dp) return;
+    if (e >= pad_rows * Dp) return;
     const int64_t n = e / Dp;
     const int f = (int)(e - n * Dp);
-    xc[e] = f < D ? (double)x[n * ldx + f] - pivot[f] : 0.0;
+    xc[e] = (n < n_rows && f < D) ? (double)x[n * ldx + f] - pivot[f] : 0.0;
 }
 
 // lse[n] = ln sum_k exp(lnrho[k][n]) (single pass, running max); optional argmax.

@@ -95,7 +95,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->xc, 0}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
-        if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = ws->npad * 16 * (int64_t)ws->T;
+        if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
     }
     for (auto& b : bufs) {
         if (b.n == 0) continue;
@@ -199,15 +199,16 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     if (rc) return rc;
     if (!ws->xc) return GMMVB_OK;      // disabled: the M-step reads x directly
     const int Dp = 16 * ws->T;
-    const int64_t total = n_rows * Dp;
+    const int64_t pad_rows = round_up(n_rows, 64) + 64;
+    const int64_t total = pad_rows * Dp;
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     if (ws->x_dtype == GMMVB_F64)
         hipLaunchKernelGGL(center_rows_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)x_dev, ldx, n_rows,
-                           ws->D, Dp, ws->pivot, ws->xc);
+                           pad_rows, ws->D, Dp, ws->pivot, ws->xc);
     else
         hipLaunchKernelGGL(center_rows_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x_dev, ldx, n_rows,
-                           ws->D, Dp, ws->pivot, ws->xc);
+                           pad_rows, ws->D, Dp, ws->pivot, ws->xc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
     ws->xc_src = x_dev;

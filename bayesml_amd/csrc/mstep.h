@@ -80,7 +80,11 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
 
     struct RawRow { XT v[T]; };
     auto load_row = [&](int64_t row) {
-        if (row >= n_rows) row = n_rows - 1;               // r is 0 there
+        // PRE: the centred copy has zero rows up to npad + 64, so no clamp (and no 64-bit compare/select/multiply
+        // per step); otherwise clamp to the last valid row (r is 0 there)
+        if constexpr (!PRE) {
+            if (row >= n_rows) row = n_rows - 1;
+        }
         const XT* xp = x + row * ldx + T * i;
         RawRow o;
         if constexpr (PRE) {
