@@ -44,22 +44,71 @@ __global__ void center_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_
     xc[e] = (n < n_rows && f < D) ? (double)x[n * ldx + f] - pivot[f] : 0.0;
 }
 
-// lse[n] = ln sum_k exp(lnrho[k][n]) (single pass, running max); optional argmax.
-__global__ void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows, int K,
-                               double* __restrict__ lse) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_rows) return;
-    double mx = lnrho[n], s = 1.0;
-    for (int k = 1; k < K; ++k) {
-        const double v = lnrho[(int64_t)k * npad + n];
-        if (v > mx) {
-            s = fma(s, exp(mx - v), 1.0);
-            mx = v;
-        } else {
-            s += exp(v - mx);
+// lse[n] = ln sum_k exp(lnrho[k][n]) (single pass, running max), and per block of kLseRows rows the largest
+// ln r_nk = lnrho[k][n] - lse[n] of every component (dpart[block][k]); thr_kernel turns those into the M-step's
+// skip thresholds.
+constexpr int kLseRows = 1024;      // rows per block (256 threads x 4)
+__global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
+                                                      int K, double* __restrict__ lse, double* __restrict__ dpart) {
+    __shared__ double wmax[4];
+    const int64_t base = (int64_t)blockIdx.x * kLseRows + threadIdx.x;
+    double l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t n = base + 256 * q;
+        l[q] = 0.0;
+        if (n >= n_rows) continue;
+        double mx = lnrho[n], s = 1.0;
+        for (int k = 1; k < K; ++k) {
+            const double v = lnrho[(int64_t)k * npad + n];
+            if (v > mx) {
+                s = fma(s, exp(mx - v), 1.0);
+                mx = v;
+            } else {
+                s += exp(v - mx);
+            }
         }
+        l[q] = mx + log(s);
+        lse[n] = l[q];
     }
-    lse[n] = mx + log(s);
+    if (!dpart) return;
+    const double ninf = -__builtin_huge_val();
+    for (int k = 0; k < K; ++k) {
+        double d = ninf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t n = base + 256 * q;
+            if (n < n_rows) {
+                const double v = lnrho[(int64_t)k * npad + n] - l[q];
+                d = (v > d || v != v) ? v : d;          // NaN wins: the threshold becomes NaN = nothing is skipped
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v = __shfl_xor(d, o);
+            d = (v > d || v != v) ? v : d;
+        }
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; ++w) d = (wmax[w] > d || wmax[w] != wmax[w]) ? wmax[w] : d;
+            dpart[(int64_t)blockIdx.x * K + k] = d;
+        }
+        __syncthreads();
+    }
+}
+
+// thr[k] = max over blocks of dpart[.][k] - 100 ln 2 (mstep.h, sparse responsibilities)
+__global__ void thr_kernel(const double* __restrict__ dpart, int blocks, int K, double* __restrict__ thr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double d = -__builtin_huge_val();
+    for (int b = 0; b < blocks; ++b) {
+        const double v = dpart[(int64_t)b * K + k];
+        d = (v > d || v != v) ? v : d;
+    }
+    thr[k] = d - 69.314718055994530942;
 }
 
 // r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0

@@ -86,16 +86,32 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         ws->estep_variant = kEstepLds8;      // measured fastest (two waves per SIMD share one LDS image)
         if (v && std::strcmp(v, "direct") == 0) ws->estep_variant = kEstepDirect;
         if (v && std::strcmp(v, "lds4") == 0) ws->estep_variant = kEstepLds;
+        if (v && std::strcmp(v, "i8") == 0) ws->estep_variant = kEstepI8;
+    }
+    if (ws->estep_variant == kEstepI8) {
+        ws->img_i8_len = estep_i8_image_bytes(D);
+        e = hipMalloc((void**)&ws->img_i8, (size_t)K * ws->img_i8_len);
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->pivot_i8, (size_t)D * sizeof(double));
+        if (e != hipSuccess) {
+            gmmvb_workspace_destroy(ws);
+            return fail(GMMVB_ENOMEM, "hipMalloc (int8 images)", e);
+        }
+        ws->bytes += (int64_t)K * ws->img_i8_len + D * (int64_t)sizeof(double);
     }
     struct { double** p; int64_t n; } bufs[] = {
         {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},
         {&ws->img, (int64_t)K * ws->img_len},
         {&ws->cvec, K},                      {&ws->pivot, D},
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
-        {&ws->xc, 0}};
+        {&ws->xc, 0},
+        {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
         if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
+    }
+    {
+        const char* v = std::getenv("GMMVB_MSTEP_SPARSE");         // "0" = always the dense M-step
+        ws->sparse = !(v && std::strcmp(v, "0") == 0);
     }
     for (auto& b : bufs) {
         if (b.n == 0) continue;
@@ -117,9 +133,11 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
-    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc};
+    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
+    if (ws->img_i8) (void)hipFree(ws->img_i8);
+    if (ws->pivot_i8) (void)hipFree(ws->pivot_i8);
     for (hipEvent_t e : ws->ev)
         if (e) (void)hipEventDestroy(e);
     if (ws->hmm) hmm_state_destroy(ws->hmm);
@@ -178,6 +196,12 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
                        ws->img_len, ws->img);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_kernel", e);
+    if (ws->estep_variant == kEstepI8) {
+        // the digits are taken about the pivot in force now; the E-step reads this copy, not ws->pivot
+        e = hipMemcpyAsync(ws->pivot_i8, ws->pivot, (size_t)ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_i8_kernel", e);
+    }
     ws->have_params = true;
     return GMMVB_OK;
 }
@@ -224,27 +248,36 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (!ws->have_params) return fail(GMMVB_ESTATE, "gmmvb_set_params has not been called");
     hipStream_t st = (hipStream_t)stream;
     const int is64 = ws->x_dtype == GMMVB_F64;
-    const int rpw = estep_rows_per_wg(ws->estep_variant, ws->T, is64);
+    const bool i8 = ws->estep_variant == kEstepI8;
+    const int rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
     int64_t grid = (n_rows + rpw - 1) / rpw;
     if (grid > (1 << 20)) grid = 1 << 20;
     EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
+    EstepI8Args a8{x_dev, ldx, n_rows, ws->D, ws->img_i8, ws->pivot_i8, ws->cvec, ws->K, ws->lnrho, ws->npad};
     const char* name = "";
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
-    hipError_t e = launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name);
+    hipError_t e = i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
+                      : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
     if (ws->prof) {
         (void)hipEventRecord(ws->ev[1], st);
         ws->ev_e = true;
     }
-    const int tb = 256;
-    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)((n_rows + tb - 1) / tb)), dim3(tb), 0, st, ws->lnrho,
-                       ws->npad, n_rows, ws->K, ws->lse);
+    const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
+    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)lse_blocks), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                       ws->lse, ws->sparse ? ws->dpart : nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
+    if (ws->sparse) {
+        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)((ws->K + 63) / 64)), dim3(64), 0, st, ws->dpart, lse_blocks, ws->K,
+                           ws->thr);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "thr_kernel launch", e);
+    }
     ws->e_state = 1;
     ws->e_rows = n_rows;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
-                  estep_threads(ws->estep_variant), rpw);
+                  i8 ? 512 : estep_threads(ws->estep_variant), rpw);
     return GMMVB_OK;
 }
 
@@ -295,7 +328,13 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     const char* name = "";
     if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
-    hipError_t e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
+    hipError_t e;
+    if (ws->sparse && pre && ws->e_state == 1) {     // E-step output: skip samples that cannot change the f64 sums
+        a.aux = ws->thr;
+        e = launch_mstep_sparse(ws->T, (int)grid, st, a, &name);
+    } else {
+        e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
+    }
     if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);
     if (ws->prof) {
         (void)hipEventRecord(ws->ev[3], st);

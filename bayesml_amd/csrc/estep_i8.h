@@ -1,0 +1,370 @@
+// E-step on the int8 matrix pipe: ln rho_nk = c_k - 0.5 * || U_k (x_n - m_k) ||^2 with both operands cut into
+// 7-bit signed digits and the products summed exactly in int32 (v_mfma_i32_32x32x32_i8, 32 cycles per
+// 32x32x32 block = 8x the f64 MFMA's multiply rate).  Same function, same outputs as estep.h; the arithmetic is
+// fixed point per row of U_k and per sample:
+//
+//   U_k[j][:]      = 2^ej * sum_a dU_a[j][:] 2^(-6-7a)      a = 0..5, dU_a in [-64, 64]  (ej: exponent of the row max)
+//   x_n - pivot    = 2^en * sum_b dX_b[n][:] 2^(-6-7b)      b = 0..5                       (en: exponent of the sample max)
+//   (U_k (x_n - pivot))_j = 2^(ej+en-12) * sum_w 2^(-7w) * [ sum_{a+b=w} dU_a[j][:] . dX_b[n][:] ]      w = 0..5
+//
+// The bracket is an exact integer (<= 24 MFMAs x 32 x 64 x 64 < 2^22); digit pairs with a + b > 5 are dropped, which
+// together with the 42-bit truncation of each operand is an error of about 20 x 2^-42 relative to
+// (row max of U) x (sample max of |x - pivot|) per term - 1e-9 absolute on ln rho at the benchmark's scale, 5e-8 on the
+// posterior after 10 VB iterations (f64 path: 1e-9), against the 1e-5 contract.  21 int8 MFMAs (672 cycles) replace
+// the 64 f64 MFMAs (4096 cycles) of a 32x32x32 block; the lower-triangular U_k skips 6 of the 16 block pairs at D = 128.
+//
+// Mapping: one wave = 32 samples (columns of the MFMA), all K components.  Lane l = (c = l & 31, h = l >> 5) holds
+// the sample's digits for features 32 it + 16 h + (0..15) in byte order for the whole k loop (6 x T32 x 4 VGPRs).
+// Output rows land on (register g, h): row = (g & 3) + 8 (g >> 2) + 4 h, so ||y||^2 is a per-lane sum plus one
+// cross-half add.
+//
+// Component image (bytes; 1-KB granules for the LDS-DMA, written by pack_params_i8_kernel):
+//   [ pair p = (jt, it <= jt) ][ digit a ][ lane ][ 16 ]   byte e of lane (r, h) = dU_a[32 jt + r][32 it + 16 h + e]
+//   [ jt ][ h ][ g ][ 2 ] doubles                         (2^ej, (U_k (m_k - pivot))_j) for row j = 32 jt + (g&3) + 8(g>>2) + 4h
+#pragma once
+#include "common.h"
+
+namespace gmmvb {
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i16v __attribute__((ext_vector_type(16)));
+
+constexpr int kDigits = 6;
+
+__host__ __device__ constexpr int i8_blocks(int D) { return (D + 31) / 32; }
+__host__ __device__ constexpr int i8_img_bytes(int t32) {
+    return (tri_pairs(t32) * kDigits * 1024 + t32 * 512 + 1023) / 1024 * 1024;
+}
+__host__ __device__ constexpr int i8_kb(int t32) {
+    const int kb = (64 * 1024) / i8_img_bytes(t32);
+    return kb < 1 ? 1 : (kb > 8 ? 8 : kb);
+}
+
+// kDigits balanced base-128 digits of t (|t| <= 64): t = d0 + d1/128 + d2/128^2 + ...; returns them as bytes
+__device__ __forceinline__ void digits_of(double t, int (&d)[kDigits]) {
+#pragma unroll
+    for (int a = 0; a < kDigits; ++a) {
+        const double r = __builtin_rint(t);
+        d[a] = (int)r;
+        t = (t - r) * 128.0;
+    }
+}
+
+// K-side: digits of u, row exponents, bias.  One block per component.
+__global__ void pack_params_i8_kernel(const double* __restrict__ u, const double* __restrict__ m,
+                                      const double* __restrict__ pivot, int K, int D, int T32, int img_bytes,
+                                      unsigned char* __restrict__ img) {
+    __shared__ double row_scale[128];   // 2^(6 - ej)  (0 for padding rows)
+    const int k = blockIdx.x;
+    const int P = tri_pairs(T32);
+    const double* uk = u + (int64_t)k * D * D;
+    const double* mk = m + (int64_t)k * D;
+    unsigned char* im = img + (int64_t)k * img_bytes;
+    double* consts = reinterpret_cast<double*>(im + P * kDigits * 1024);
+    for (int j = threadIdx.x; j < 32 * T32; j += blockDim.x) {
+        double mx = 0.0, bias = 0.0;
+        bool bad = false;
+        if (j < D) {
+            for (int i = 0; i <= j; ++i) {
+                const double v = uk[(int64_t)j * D + i];
+                bad |= !(fabs(v) <= 1.7976931348623157e308);
+                mx = fmax(mx, fabs(v));
+                bias = fma(v, mk[i] - pivot[i], bias);
+            }
+        }
+        int e = 0;
+        if (mx > 0.0) (void)frexp(mx, &e);          // mx = f 2^e, f in [0.5, 1)
+        row_scale[j] = (mx > 0.0 && !bad) ? ldexp(1.0, 6 - e) : 0.0;
+        const int jt = j >> 5, w = j & 31;
+        const int h = (w >> 2) & 1, g = (w & 3) + 4 * (w >> 3);      // w = (g & 3) + 8 (g >> 2) + 4 h
+        double* cp = consts + ((jt * 2 + h) * 16 + g) * 2;
+        cp[0] = bad ? __builtin_nan("") : (mx > 0.0 ? ldexp(1.0, e) : 0.0);
+        cp[1] = bias;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < P * 1024; e += blockDim.x) {
+        const int p = e >> 10, lane = (e >> 4) & 63, b = e & 15;
+        int jt = 0;
+        while (tri_pairs(jt + 1) <= p) ++jt;
+        const int it = p - tri_pairs(jt);
+        const int jj = 32 * jt + (lane & 31), ii = 32 * it + 16 * (lane >> 5) + b;
+        const double v = (jj < D && ii <= jj) ? uk[(int64_t)jj * D + ii] * row_scale[jj] : 0.0;
+        int d[kDigits];
+        digits_of(v, d);
+#pragma unroll
+        for (int a = 0; a < kDigits; ++a) im[((p * kDigits + a) * 64 + lane) * 16 + b] = (unsigned char)(d[a] & 0xff);
+    }
+    for (int e = P * kDigits * 1024 + T32 * 512 + threadIdx.x; e < img_bytes; e += blockDim.x) im[e] = 0;
+}
+
+// Sample digits for one wave tile.  xd[a][it] = 16 bytes = digit a of features 32 it + 16 h + (0..15); c2 = 2^(en - 47)
+// (NaN when the sample holds a non-finite value, so that its ln rho comes out NaN like the f64 path's).
+template <int T32, typename XT, bool VEC>
+__device__ __forceinline__ void load_x_digits(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                              const double* __restrict__ pivot, int64_t n0, int c, int h,
+                                              i4v (&xd)[kDigits][T32], double& c2) {
+    int64_t row = n0 + c;
+    if (row >= n_rows) row = n_rows - 1;          // clamp: padded samples are never stored
+    const XT* xp = x + row * ldx + 16 * h;
+    // 16 features of block `it` as centred doubles (zero past D); two passes over x (the second hits L1/L2) keep
+    // the conversion's live registers at one block instead of the whole row
+    auto load_block = [&](int it, double (&v)[16]) {
+        const int f0 = 32 * it + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (VEC) {
+                typedef XT v4 __attribute__((ext_vector_type(4)));
+                const bool in = f0 < D;             // D % 16 == 0 here: a 16-feature block is all in or all out
+                v4 t = {0, 0, 0, 0};
+                if (in) t = *reinterpret_cast<const v4*>(xp + 32 * it + 4 * q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[4 * q + s] = in ? (double)t[s] - pivot[f0 + 4 * q + s] : 0.0;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int f = f0 + 4 * q + s;
+                    v[4 * q + s] = f < D ? (double)xp[32 * it + 4 * q + s] - pivot[f] : 0.0;
+                }
+            }
+        }
+    };
+    double mx = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < T32; ++it) {
+        double v[16];
+        load_block(it, v);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double a = fabs(v[e]);
+            bad |= !(a <= 1.7976931348623157e308);
+            mx = fmax(mx, a);
+        }
+    }
+    mx = fmax(mx, __shfl_xor(mx, 32));
+    bad |= (bool)__shfl_xor((int)bad, 32);
+    int en = 0;
+    if (mx > 0.0) (void)frexp(mx, &en);
+    const double scale = bad ? 0.0 : ldexp(1.0, 6 - en);
+    c2 = bad ? __builtin_nan("") : ldexp(1.0, en - 47);
+#pragma unroll
+    for (int it = 0; it < T32; ++it) {
+        double v[16];
+        load_block(it, v);
+        unsigned w[kDigits][4];
+#pragma unroll
+        for (int a = 0; a < kDigits; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[a][q] = 0u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int d[kDigits];
+            digits_of(bad ? 0.0 : v[e] * scale, d);
+#pragma unroll
+            for (int a = 0; a < kDigits; ++a) w[a][e >> 2] |= (unsigned)(d[a] & 0xff) << (8 * (e & 3));
+        }
+#pragma unroll
+        for (int a = 0; a < kDigits; ++a) xd[a][it] = i4v{(int)w[a][0], (int)w[a][1], (int)w[a][2], (int)w[a][3]};
+    }
+}
+
+// LDS reads whose completion is awaited by hand.  The compiler only ever emits s_waitcnt lgkmcnt(0) in this
+// kernel, which would drain the prefetches together with the operand it needs; these reads are invisible to its
+// counter model and are fenced by lds_wait<N>() (LDS returns in order: "at most N younger reads still in flight").
+// The waited-for registers pass through the fence as in/out operands so that no consumer can be moved above it.
+template <int OFF>
+__device__ __forceinline__ void lds_read16(i4v& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(i4v& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(i4v& a, i4v& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+union pair_bits {
+    i4v v;
+    double d[2];
+};
+
+// MFMAs of step (JT, IT, A) with U digit fragment `ua`
+template <int T32, int IT, int A>
+__device__ __forceinline__ void i8_step_mfma(const i4v& ua, const i4v (&xd)[kDigits][T32], i16v (&acc)[kDigits]) {
+#pragma unroll
+    for (int b = 0; b + A < kDigits; ++b)
+        acc[A + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ua, xd[b][IT], acc[A + b], 0, 0, 0);
+}
+
+// Execution order of the steps.  Output blocks run in ascending order (REV = false) or descending order (REV = true):
+// the two waves that share a SIMD take opposite orders, so that one's epilogues (vector ALU) fall into the other's
+// long MFMA runs instead of both leaving the matrix pipe idle at the same time.  Step e (execution index) of a
+// component -> its output block, and its position in the image (layout step = 6 pair + digit).
+template <int T32, bool REV>
+struct i8_order {
+    static constexpr int block_of(int e) {
+        int o = 0, base = 0;
+        while (true) {
+            const int jt = REV ? T32 - 1 - o : o;
+            const int n = (jt + 1) * kDigits;
+            if (e < base + n) return jt;
+            base += n;
+            ++o;
+        }
+    }
+    static constexpr int first_of(int jt) {      // execution index of the block's first step
+        int base = 0;
+        for (int o = 0; o < T32; ++o) {
+            const int b = REV ? T32 - 1 - o : o;
+            if (b == jt) return base;
+            base += (b + 1) * kDigits;
+        }
+        return base;
+    }
+    static constexpr int layout_of(int e) {
+        const int jt = block_of(e);
+        return tri_pairs(jt) * kDigits + (e - first_of(jt));
+    }
+};
+
+// Steps E .. end of its output block (recursion over the compile-time execution index: offsets and wait counts are
+// immediates).  ua[e % 3] holds step e; step e + 2 is requested before step e runs.
+template <int T32, bool REV, int E>
+__device__ __forceinline__ void i8_steps(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3],
+                                         const i4v (&xd)[kDigits][T32], i16v (&acc)[kDigits], i4v (&sb)[2][2]) {
+    using ord = i8_order<T32, REV>;
+    constexpr int NS = tri_pairs(T32) * kDigits;
+    constexpr int JT = ord::block_of(E), S = ord::layout_of(E);
+    constexpr int IT = S / kDigits - tri_pairs(JT), A = S % kDigits;
+    constexpr bool last = (IT == JT && A == kDigits - 1);
+    if constexpr (E + 2 < NS) lds_read16<1024 * ord::layout_of(E + 2 < NS ? E + 2 : 0)>(ua[(E + 2) % 3], frag_addr);
+    if constexpr (last) {
+        lds_read16<JT * 512 + 0>(sb[0][0], const_addr);
+        lds_read16<JT * 512 + 16>(sb[0][1], const_addr);
+    }
+    lds_wait<(E + 1 < NS) + (E + 2 < NS) + (last ? 2 : 0)>(ua[E % 3]);
+    i8_step_mfma<T32, IT, A>(ua[E % 3], xd, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!last) i8_steps<T32, REV, E + 1>(frag_addr, const_addr, ua, xd, acc, sb);
+}
+
+// Epilogue of output block JT, rows 2 GP and 2 GP + 1 of this lane: integer digit sums -> y -> q
+template <int JT, int GP>
+__device__ __forceinline__ void i8_rows(unsigned const_addr, const i16v (&acc)[kDigits], i4v (&sb)[2][2], double c0,
+                                        double c1, double c2, double& q) {
+    if constexpr (GP + 1 < 8) {
+        lds_read16<JT * 512 + 32 * (GP + 1)>(sb[(GP + 1) & 1][0], const_addr);
+        lds_read16<JT * 512 + 32 * (GP + 1) + 16>(sb[(GP + 1) & 1][1], const_addr);
+    }
+    lds_wait<(GP + 1 < 8) ? 2 : 0>(sb[GP & 1][0], sb[GP & 1][1]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int g = 2 * GP + e;
+        const int t0 = (acc[0][g] << 7) + acc[1][g];
+        const int t1 = (acc[2][g] << 7) + acc[3][g];
+        const int t2 = (acc[4][g] << 7) + acc[5][g];
+        const double z = fma((double)t0, c0, fma((double)t1, c1, (double)t2 * c2));
+        pair_bits u;
+        u.v = sb[GP & 1][e];
+        const double y = fma(z, u.d[0], -u.d[1]);
+        q = fma(y, y, q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (GP + 1 < 8) i8_rows<JT, GP + 1>(const_addr, acc, sb, c0, c1, c2, q);
+}
+
+template <int T32, bool REV, int O>
+__device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3],
+                                               const i4v (&xd)[kDigits][T32], double c0, double c1, double c2,
+                                               double& q) {
+    constexpr int JT = REV ? T32 - 1 - O : O;
+    i16v acc[kDigits];
+#pragma unroll
+    for (int w = 0; w < kDigits; ++w) acc[w] = i16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    i4v sb[2][2];
+    i8_steps<T32, REV, i8_order<T32, REV>::first_of(JT)>(frag_addr, const_addr, ua, xd, acc, sb);
+    i8_rows<JT, 0>(const_addr, acc, sb, c0, c1, c2, q);
+    if constexpr (O + 1 < T32) i8_blocks_from<T32, REV, O + 1>(frag_addr, const_addr, ua, xd, c0, c1, c2, q);
+}
+
+// One component for one wave tile; `im_lds` is the LDS byte address of the component's image.
+// The U digits are requested two steps (one step = one digit a of one block pair = 6 - a MFMAs) ahead of their
+// use and the epilogue's row constants one pair of rows ahead, so that with only two waves per SIMD the LDS
+// latency sits behind MFMAs instead of in front of them.
+template <int T32, bool REV>
+__device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&xd)[kDigits][T32], double ck, double c0,
+                                                   double c1, double c2, int lane, int c, int h, int64_t n0,
+                                                   int64_t n_rows, double* __restrict__ lnrho_k) {
+    using ord = i8_order<T32, REV>;
+    constexpr int P = tri_pairs(T32);
+    const unsigned frag_addr = im_lds + lane * 16;                              // layout step s at + 1024 s
+    const unsigned const_addr = im_lds + P * kDigits * 1024 + h * 256;          // (jt, g) at + 512 jt + 16 g
+    double q = 0.0;
+    i4v ua[3];
+    lds_read16<1024 * ord::layout_of(0)>(ua[0], frag_addr);
+    lds_read16<1024 * ord::layout_of(1)>(ua[1], frag_addr);
+    i8_blocks_from<T32, REV, 0>(frag_addr, const_addr, ua, xd, c0, c1, c2, q);
+    q += __shfl_xor(q, 32);
+    const int64_t row = n0 + c;
+    if (h == 0 && row < n_rows) lnrho_k[row] = ck - 0.5 * q;
+}
+
+template <int T32, typename XT, bool VEC, int NW>
+__global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                                    const unsigned char* __restrict__ img /*[K][IMGB]*/,
+                                                    const double* __restrict__ pivot, const double* __restrict__ cvec,
+                                                    int K, double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
+    constexpr int IMGB = i8_img_bytes(T32);
+    constexpr int KB = i8_kb(T32);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][KB * IMGB];   // the ONLY LDS object of the kernel
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t rows_per_wg = NW * 32;
+    const int64_t n_wg_tiles = (n_rows + rows_per_wg - 1) / rows_per_wg;
+    const int n_blocks = (K + KB - 1) / KB;
+
+    auto stage = [&](int kb, int buf) {
+        const int k0 = kb * KB;
+        const int kcount = (K - k0 < KB) ? (K - k0) : KB;
+        const int pieces = kcount * (IMGB / 1024);
+        const unsigned char* src = img + (int64_t)k0 * IMGB + lane * 16;
+        for (int piece = wave; piece < pieces; piece += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void*)(&smem[buf][piece * 1024]), 16, 0,
+                                             0);
+    };
+
+    for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
+        const int64_t n0 = wt * rows_per_wg + (int64_t)wave * 32;
+        stage(0, 0);
+        i4v xd[kDigits][T32];
+        double c2;
+        load_x_digits<T32, XT, VEC>(x, ldx, n_rows, D, pivot, n0, c, h, xd, c2);
+        const double c1 = c2 * 16384.0, c0 = c2 * 268435456.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = 0; kb < n_blocks; ++kb) {
+            if (kb + 1 < n_blocks) stage(kb + 1, (kb + 1) & 1);
+            const unsigned buf = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem[kb & 1]);
+            const int k0 = kb * KB;
+#pragma unroll 1
+            for (int kk = 0; kk < KB; ++kk) {
+                const int k = k0 + kk;
+                if (k >= K) break;
+                if (T32 > 1 && wave >= NW / 2)      // the second wave of each SIMD (wave uniform: no divergence)
+                    estep_i8_component<T32, true>(buf + kk * IMGB, xd, cvec[k], c0, c1, c2, lane, c, h, n0, n_rows,
+                                                  lnrho + (int64_t)k * npad);
+                else
+                    estep_i8_component<T32, false>(buf + kk * IMGB, xd, cvec[k], c0, c1, c2, lane, c, h, n0, n_rows,
+                                                   lnrho + (int64_t)k * npad);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace gmmvb

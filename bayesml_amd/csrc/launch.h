@@ -17,10 +17,21 @@ struct MstepArgs {
 };
 
 // rows of x handled by one E-step workgroup for (variant, T, dtype); doubles per component parameter image
-enum EstepVariant { kEstepLds = 0, kEstepDirect = 1, kEstepLds8 = 2 };
+enum EstepVariant { kEstepLds = 0, kEstepDirect = 1, kEstepLds8 = 2, kEstepI8 = 3 };
 int estep_rows_per_wg(int variant, int T, int x_is_f64);
 int estep_threads(int variant);
 int estep_image_doubles(int T);
+// int8-digit E-step (estep_i8.h): own parameter image (bytes per component), 256 rows per workgroup
+struct EstepI8Args {
+    const void* x; int64_t ldx; int64_t n_rows; int D;
+    const unsigned char* img; const double* pivot; const double* cvec; int K;
+    double* lnrho; int64_t npad;
+};
+int estep_i8_image_bytes(int D);
+int estep_i8_rows_per_wg();
+hipError_t launch_pack_i8(const double* u, const double* m, const double* pivot, int K, int D, unsigned char* img,
+                          hipStream_t st);
+hipError_t launch_estep_i8(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const char** name);
 // components handled by one M-step workgroup for T feature tiles (4 waves / waves-per-component)
 int mstep_components_per_wg(int T, bool pre);
 int mstep_threads(int T, bool pre);
@@ -30,5 +41,8 @@ hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hi
 // pre = true: a.x is the workspace's centred f64 copy [n_rows][16T] (see center_rows_kernel)
 hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipStream_t st, const MstepArgs& a,
                         const char** name);
+
+// sparse-responsibility M-step over the centred copy (mstep.h); a.x = xc, a.aux = thr[K]
+hipError_t launch_mstep_sparse(int T, int grid, hipStream_t st, const MstepArgs& a, const char** name);
 
 }  // namespace gmmvb

@@ -244,4 +244,191 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
     }
 }
 
+// ---- sparse responsibilities ---------------------------------------------------------------------------------
+// After the first VB iterations most responsibilities are negligible: a sample belongs to a handful of the K
+// components.  A term with r_nk < 2^-100 max_n r_nk cannot change any of component k's f64 sums (there are fewer
+// than 2^40 terms and the sums are at least as large as their largest term), so the statistics are unchanged to the
+// last bit of rounding when such samples are skipped - and skipping them removes their row loads and MFMAs.
+// `thr` = max_n (ln rho_nk - lse_n) - 100 ln 2 (row_lse_kernel / thr_kernel).  The wave scans its rows 64 at a time,
+// ballots the active ones and feeds them to the MFMAs four at a time (a short last group of a batch is padded with
+// r = 0); batches with no active sample cost one load, one compare and one ballot.  Dense input degenerates to the
+// dense kernel's work plus a few scalar instructions per step.  Centred-copy rows only (PRE form).
+template <int T, int WS, int SUB>
+__device__ __forceinline__ void mstep_sparse_body(const double* __restrict__ xc, const double* __restrict__ lr,
+                                                  const double* __restrict__ lse, double thr, int64_t lo, int64_t hi,
+                                                  double* __restrict__ out) {
+    constexpr int P = tri_pairs(T);
+    constexpr int NP = mstep_owned(WS, SUB, T);
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15;
+    const int g = lane >> 4;
+
+    d4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = d4{0.0, 0.0, 0.0, 0.0};
+    double asum[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) asum[t] = 0.0;
+    double nsum = 0.0, hsum = 0.0;
+
+    struct RawRow { double v[T]; };
+    auto load_row = [&](int64_t row) {
+        const double* xp = xc + row * (16 * T) + T * i;
+        RawRow o;
+        typedef double v2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+            if (t + 1 < T) {
+                const v2 v = *reinterpret_cast<const v2*>(xp + t);
+                o.v[t] = v[0];
+                o.v[t + 1] = v[1];
+            } else {
+                o.v[t] = xp[t];
+            }
+        }
+        return o;
+    };
+
+    // scan state: batch [c0, c0 + 64), its not yet consumed active lanes m (wave uniform), its r per lane
+    int64_t c0 = lo - 64;
+    unsigned long long m = 0;
+    double r_l = 0.0;
+    int64_t grow = 0;      // next group: row of this lane's sample slot g, and its responsibility
+    double grr = 0.0;
+    auto advance = [&]() -> bool {
+        while (m == 0) {
+            c0 += 64;
+            if (c0 >= hi) return false;
+            const int64_t nl = c0 + lane;
+            bool act = false;
+            double t = 0.0;
+            if (nl < hi) {
+                t = lr[nl] - lse[nl];
+                act = !(t < thr);              // NaN stays active and propagates like in the dense kernel
+            }
+            r_l = act ? exp(t) : 0.0;
+            if (act) hsum = fma(r_l, t, hsum);  // r ln r, with ln r = ln rho - lse exactly
+            nsum += r_l;
+            m = __ballot(act);
+        }
+        int pos[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ok[q] = m != 0;
+            pos[q] = ok[q] ? __builtin_ctzll(m) : 0;
+            if (ok[q]) m &= m - 1;
+        }
+        const int my = g == 0 ? pos[0] : (g == 1 ? pos[1] : (g == 2 ? pos[2] : pos[3]));
+        const bool mine = g == 0 ? ok[0] : (g == 1 ? ok[1] : (g == 2 ? ok[2] : ok[3]));
+        grow = c0 + my;
+        const double rv = __shfl(r_l, my);
+        grr = mine ? rv : 0.0;
+        return true;
+    };
+
+    bool have = advance();
+    RawRow nxt;
+    double rr_n = 0.0;
+    if (have) {
+        nxt = load_row(grow);
+        rr_n = grr;
+    }
+    while (have) {
+        const RawRow cur = nxt;
+        const double rr = rr_n;
+        double xq[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xq[t] = cur.v[t];
+        double ra[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (mstep_owner(WS, t) == SUB) {
+                ra[t] = rr * xq[t];
+                asum[t] += ra[t];
+            } else {
+                ra[t] = 0.0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        have = advance();
+        if (have) {
+            nxt = load_row(grow);
+            rr_n = grr;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t2 = 0; t2 < T; ++t2) {
+#pragma unroll
+            for (int t1 = 0; t1 <= t2; ++t1) {
+                if (mstep_owner(WS, t1) == SUB)
+                    acc[mstep_slot(WS, t2, t1)] = mfma_f64(ra[t1], xq[t2], acc[mstep_slot(WS, t2, t1)]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) asm volatile("" ::"v"(xq[t]));
+    }
+
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2) {
+#pragma unroll
+        for (int t1 = 0; t1 <= t2; ++t1) {
+            if (mstep_owner(WS, t1) == SUB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(pair_index(t2, t1) * 4 + r) * 64 + lane] = acc[mstep_slot(WS, t2, t1)][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (mstep_owner(WS, t) == SUB) {
+            const double v = sum_groups(asum[t]);
+            if (g == 0) out[P * 256 + T * i + t] = v;
+        }
+    }
+    if (SUB == 0) {
+        nsum = sum_wave(nsum);
+        hsum = sum_wave(hsum);
+        if (lane == 0) {
+            out[P * 256 + 16 * T + 0] = nsum;
+            out[P * 256 + 16 * T + 1] = hsum;
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_sparse_f64(
+    const double* __restrict__ xc,         // [npad + 64][16 T] centred rows
+    const double* __restrict__ lnrho,      // [K][npad]
+    const double* __restrict__ lse,        // [npad]
+    const double* __restrict__ thr,        // [K]
+    int64_t n_rows, int64_t npad, int K, int KG, int S, int64_t rows_per_split,
+    double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
+    constexpr int WS = mstep_ws(T);
+    constexpr int KPW = mstep_waves(T, true) / WS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x;            // same XCD-aware decode as mstep_mfma_f64
+    const int xcd = bid & 7;
+    const int j = bid >> 3;
+    const int kg = j % KG;
+    const int split = (j / KG) * 8 + xcd;
+    if (split >= S) return;
+    const int k = kg * KPW + wave / WS;
+    if (k >= K) return;
+    const int sub = wave % WS;
+    const int64_t lo = (int64_t)split * rows_per_split;
+    int64_t hi = lo + rows_per_split;
+    if (hi > n_rows) hi = n_rows;
+    const double* lr = lnrho + (int64_t)k * npad;
+    double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
+    const double th = thr[k];
+    if constexpr (WS == 1) {
+        mstep_sparse_body<T, 1, 0>(xc, lr, lse, th, lo, hi, out);
+    } else {
+        if (sub == 0) mstep_sparse_body<T, 2, 0>(xc, lr, lse, th, lo, hi, out);
+        else mstep_sparse_body<T, 2, 1>(xc, lr, lse, th, lo, hi, out);
+    }
+}
+
 }  // namespace gmmvb

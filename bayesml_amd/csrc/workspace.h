@@ -16,9 +16,15 @@ struct gmmvb_workspace {
     double* lse = nullptr;     // [npad]
     double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
     int img_len = 0;
-    int estep_variant = 0;     // kEstepLds8 (default); env GMMVB_ESTEP_VARIANT=direct|lds4 selects the others
+    int estep_variant = 0;     // kEstepLds8 (default); env GMMVB_ESTEP_VARIANT=direct|lds4|i8 selects the others
+    unsigned char* img_i8 = nullptr;   // [K][img_i8_len] int8-digit parameter images (estep_i8.h), variant kEstepI8 only
+    int img_i8_len = 0;
+    double* pivot_i8 = nullptr;        // [D] the pivot those images (and the sample digits) are centred on
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
+    double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)
+    double* thr = nullptr;     // [K] M-step skip thresholds: max_n ln r_nk - 100 ln 2 (valid while e_state == 1)
+    bool sparse = true;        // env GMMVB_MSTEP_SPARSE=0: always run the dense M-step
     double* slabs = nullptr;   // [S_cap][K][slab_len]
     double* xc = nullptr;      // [npad][16T] centred f64 copy of the sample matrix (M-step operand), optional
     const void* xc_src = nullptr;   // the x it was made from (null = not prepared)

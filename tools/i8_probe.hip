@@ -22,9 +22,22 @@ __global__ void one_tile(const signed char* A /*[32][32]*/, const signed char* B
     for (int g = 0; g < 16; ++g) C[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r] = acc[g];
 }
 
-__global__ __launch_bounds__(256) void rate(int* out, int iters) {
+__device__ unsigned mix(unsigned v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+
+// random = 1: operands are random 7-bit digits per lane (realistic toggling); 0: near-constant data
+__global__ __launch_bounds__(256) void rate(int* out, int iters, int random) {
     i4 a = {(int)threadIdx.x * 0x01010101, 0x01020304, 0x05060708, 0x090a0b0c};
     i4 b = {0x11121314, (int)threadIdx.x, 0x0a0b0c0d, 0x01010101};
+    if (random) {
+        const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+        for (int i = 0; i < 4; ++i) {
+            a[i] = (int)(mix(t * 8 + i) & 0x7f7f7f7fu) - 0x40404040;
+            b[i] = (int)(mix(t * 8 + 4 + i) & 0x7f7f7f7fu) - 0x40404040;
+        }
+    }
     i16 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = i16{0};
     for (int it = 0; it < iters; ++it) {
@@ -65,21 +78,23 @@ int main() {
     int* out;
     hipMalloc(&out, 4 * 256 * p.multiProcessorCount * 2);
     const int iters = 200000;
-    for (int wpc : {1, 2}) {
+    for (int cfg : {1, 2, 6}) {
+        const int wpc = cfg & 3, random = cfg >> 2;
         const int grid = p.multiProcessorCount * wpc;
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
         hipEventCreate(&e1);
-        hipLaunchKernelGGL(rate, dim3(grid), dim3(256), 0, 0, out, iters);
+        hipLaunchKernelGGL(rate, dim3(grid), dim3(256), 0, 0, out, iters, random);
         hipDeviceSynchronize();
+        for (int rep = 0; rep < 8; ++rep) hipLaunchKernelGGL(rate, dim3(grid), dim3(256), 0, 0, out, iters, random);   // let the clocks settle
         hipEventRecord(e0);
-        hipLaunchKernelGGL(rate, dim3(grid), dim3(256), 0, 0, out, iters);
+        hipLaunchKernelGGL(rate, dim3(grid), dim3(256), 0, 0, out, iters, random);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         const double n = 4.0 * iters * wpc;
-        printf("i8 32x32x32, %d wave/SIMD: %.2f ms, %.1f cycles/MFMA/SIMD at %d MHz, %.0f Tops/s\n", wpc, ms,
+        printf("i8 32x32x32, %s data, %d wave/SIMD: %.2f ms, %.1f cycles/MFMA/SIMD at %d MHz, %.0f Tops/s\n", random ? "random" : "constant", wpc, ms,
                ms * 1e-3 * p.clockRate * 1e3 / n, p.clockRate / 1000, 65536.0 * n * 4 * p.multiProcessorCount / ms / 1e9);
     }
     return 0;
