@@ -48,9 +48,14 @@ __global__ void center_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_
 // ln r_nk = lnrho[k][n] - lse[n] of every component (dpart[block][k]); thr_kernel turns those into the M-step's
 // skip thresholds.
 constexpr int kLseRows = 1024;      // rows per block (256 threads x 4)
+// apart[block] = number of (row, component) pairs of the block with ln r >= -100 ln 2 (how sparse r is: the next
+// E-step prunes only when that fraction is small).
 __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
-                                                      int K, double* __restrict__ lse, double* __restrict__ dpart) {
+                                                      int K, double* __restrict__ lse, double* __restrict__ dpart,
+                                                      double* __restrict__ apart) {
     __shared__ double wmax[4];
+    __shared__ int wcnt[4];
+    int active = 0;
     const int64_t base = (int64_t)blockIdx.x * kLseRows + threadIdx.x;
     double l[4];
 #pragma unroll
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__
             if (n < n_rows) {
                 const double v = lnrho[(int64_t)k * npad + n] - l[q];
                 d = (v > d || v != v) ? v : d;          // NaN wins: the threshold becomes NaN = nothing is skipped
+                active += !(v < -69.314718055994530942);
             }
         }
 #pragma unroll
@@ -97,18 +103,182 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = active;
+    __syncthreads();
+    if (threadIdx.x == 0) apart[blockIdx.x] = (double)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
 }
 
-// thr[k] = max over blocks of dpart[.][k] - 100 ln 2 (mstep.h, sparse responsibilities)
-__global__ void thr_kernel(const double* __restrict__ dpart, int blocks, int K, double* __restrict__ thr) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+// thr[k] = max over blocks of dpart[.][k] - 100 ln 2 (mstep.h, sparse responsibilities); act_total = sum of apart.
+// One 256-thread workgroup per component (workgroup K sums apart).
+__global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpart, const double* __restrict__ apart,
+                                                  int blocks, int K, double* __restrict__ thr,
+                                                  double* __restrict__ act_total) {
+    __shared__ double part[256];
+    const int k = blockIdx.x;
+    if (k == K) {
+        double a = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += 256) a += apart[b];
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 256; ++i) t += part[i];      // fixed order
+            *act_total = t;
+        }
+        return;
+    }
     double d = -__builtin_huge_val();
-    for (int b = 0; b < blocks; ++b) {
+    for (int b = threadIdx.x; b < blocks; b += 256) {
         const double v = dpart[(int64_t)b * K + k];
         d = (v > d || v != v) ? v : d;
     }
-    thr[k] = d - 69.314718055994530942;
+    part[threadIdx.x] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) d = (part[i] > d || part[i] != part[i]) ? part[i] : d;
+        thr[k] = d - 69.314718055994530942;
+    }
+}
+
+// ---- pruned E-step (estep.h): candidate selection --------------------------------------------------------------
+// Three small passes build the per-component sample lists without atomics (and in a fixed order):
+//   select_mask_kernel   one thread per sample: which components are candidates (bit mask, 64 components per word),
+//                        and how many candidates each 256-sample block has per component;
+//   scan_counts_kernel   exclusive scan of those block counts per component -> block bases and list lengths;
+//   fill_lists_kernel    every block writes its candidates at its bases.
+constexpr int kSelRows = 256;
+
+__device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+
+// NEAR = false: the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
+// NEAR = true : ln rho[khat_n][n] is exact now; the mask holds every other k with u[k][n] >= it - 100 ln 2.
+template <bool NEAR>
+__global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __restrict__ u, int64_t npad, int64_t n_rows,
+                                                               int K, int* __restrict__ khat,
+                                                               unsigned long long* __restrict__ masks /*[W][npad]*/,
+                                                               int* __restrict__ blk_cnt /*[blocks][K]*/) {
+    __shared__ int wcnt[4][256];
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
+    const bool valid = n < n_rows;
+    const int W = (K + 63) / 64;
+    const int wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    int kh = -1;
+    double lim = 0.0;
+    if (NEAR && valid) {
+        kh = khat[n];
+        lim = u[(int64_t)kh * npad + n] - 69.314718055994530942;
+    }
+    if (!NEAR) {
+        int arg = 0;
+        if (valid) {
+            double best = u[n];
+            for (int k = 1; k < K; ++k) {
+                const double v = u[(int64_t)k * npad + n];
+                const bool up = v > best;
+                best = up ? v : best;
+                arg = up ? k : arg;
+            }
+            khat[n] = arg;
+        }
+        kh = arg;
+    }
+    for (int w = 0; w < W; ++w) {
+        unsigned long long mk = 0;
+        if (valid) {
+            if (NEAR) {
+                const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
+                for (int b = 0; b < kend; ++b) {
+                    const double v = u[(int64_t)(64 * w + b) * npad + n];
+                    mk |= (unsigned long long)(!(v < lim)) << b;          // NaN: evaluated, not skipped
+                }
+                if ((kh >> 6) == w) mk &= ~(1ull << (kh & 63));
+            } else if ((kh >> 6) == w) {
+                mk = 1ull << (kh & 63);
+            }
+            masks[(int64_t)w * npad + n] = mk;
+        }
+        unsigned long long present = wave_or(mk);
+        while (present) {
+            const int b = __builtin_ctzll(present);
+            present &= present - 1;
+            const int c = __builtin_popcountll(__ballot((mk >> b) & 1ull));
+            if ((threadIdx.x & 63) == 0) wcnt[wave][64 * w + b] = c;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += kSelRows)
+        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+}
+
+// per component (one workgroup each): blk[b][k] <- sum of blk[b'][k] over b' < b; counts[k] = the total
+__global__ __launch_bounds__(256) void scan_counts_kernel(int* __restrict__ blk, int blocks, int K, int* __restrict__ counts) {
+    __shared__ int part[256];
+    const int k = blockIdx.x;
+    const int per = (blocks + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = (b0 + per < blocks) ? b0 + per : blocks;
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += blk[(int64_t)b * K + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        counts[k] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) {
+        const int v = blk[(int64_t)b * K + k];
+        blk[(int64_t)b * K + k] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned long long* __restrict__ masks, int64_t npad,
+                                                              int64_t n_rows, int K, const int* __restrict__ blk_base,
+                                                              int* __restrict__ lists, int64_t cap) {
+    __shared__ int wcnt[4][256];
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
+    const bool valid = n < n_rows;
+    const int W = (K + 63) / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = lane; k < K; k += 64) wcnt[wave][k] = 0;
+    for (int w = 0; w < W; ++w) {
+        const unsigned long long mk = valid ? masks[(int64_t)w * npad + n] : 0ull;
+        unsigned long long present = wave_or(mk);
+        while (present) {
+            const int b = __builtin_ctzll(present);
+            present &= present - 1;
+            const int c = __builtin_popcountll(__ballot((mk >> b) & 1ull));
+            if (lane == 0) wcnt[wave][64 * w + b] = c;
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < W; ++w) {
+        const unsigned long long mk = valid ? masks[(int64_t)w * npad + n] : 0ull;
+        unsigned long long present = wave_or(mk);
+        while (present) {
+            const int b = __builtin_ctzll(present);
+            present &= present - 1;
+            const int k = 64 * w + b;
+            const unsigned long long bal = __ballot((mk >> b) & 1ull);
+            int off = blk_base[(int64_t)blockIdx.x * K + k];
+            for (int v = 0; v < wave; ++v) off += wcnt[v][k];
+            if ((mk >> b) & 1ull)
+                lists[(int64_t)k * cap + off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int)n;
+        }
+    }
 }
 
 // r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0

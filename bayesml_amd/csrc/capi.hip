@@ -104,7 +104,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->cvec, K},                      {&ws->pivot, D},
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
         {&ws->xc, 0},
-        {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K}};
+        {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K},
+        {&ws->apart, (ws->npad + kLseRows - 1) / kLseRows}, {&ws->act_total, 1}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
         if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
@@ -112,6 +113,9 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     {
         const char* v = std::getenv("GMMVB_MSTEP_SPARSE");         // "0" = always the dense M-step
         ws->sparse = !(v && std::strcmp(v, "0") == 0);
+        v = std::getenv("GMMVB_ESTEP_PRUNE");
+        ws->prune = (v && std::strcmp(v, "0") == 0) ? 0 : ((v && std::strcmp(v, "force") == 0) ? 2 : 1);
+        if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;
     }
     for (auto& b : bufs) {
         if (b.n == 0) continue;
@@ -133,7 +137,12 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
-    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr};
+    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
+                      ws->apart, ws->act_total};
+    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk};
+    for (int* p : ibufs)
+        if (p) (void)hipFree(p);
+    if (ws->masks) (void)hipFree(ws->masks);
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (ws->img_i8) (void)hipFree(ws->img_i8);
@@ -206,6 +215,19 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
     return GMMVB_OK;
 }
 
+// active-pair count of the last E-step (one 8-byte read behind a stream sync, cached until the next E-step)
+static int fetch_active(gmmvb_workspace* ws, hipStream_t st, double* out) {
+    if (ws->act_host < 0.0) {
+        double act = 0.0;
+        hipError_t e = hipMemcpyAsync(&act, ws->act_total, sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "reading the active-pair count", e);
+        ws->act_host = act;
+    }
+    *out = ws->act_host;
+    return GMMVB_OK;
+}
+
 static int check_x(const gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, bool* vec) {
     if (!ws || !x_dev) return fail(GMMVB_EINVAL, "null argument");
     if (n_rows < 1 || n_rows > ws->max_rows) return fail(GMMVB_EINVAL, "n_rows must be in [1, max_rows]");
@@ -249,35 +271,91 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     hipStream_t st = (hipStream_t)stream;
     const int is64 = ws->x_dtype == GMMVB_F64;
     const bool i8 = ws->estep_variant == kEstepI8;
-    const int rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
-    int64_t grid = (n_rows + rpw - 1) / rpw;
-    if (grid > (1 << 20)) grid = 1 << 20;
     EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
     EstepI8Args a8{x_dev, ldx, n_rows, ws->D, ws->img_i8, ws->pivot_i8, ws->cvec, ws->K, ws->lnrho, ws->npad};
     const char* name = "";
+    hipError_t e = hipSuccess;
+    // Prune?  Needs the default f64 kernel family, and (unless forced) evidence from the previous E-step over
+    // these rows that at most a quarter of the (sample, component) pairs matter.
+    bool prune = ws->prune != 0 && ws->estep_variant == kEstepLds8;
+    if (prune && ws->prune == 1) {
+        prune = false;
+        if (n_rows * (int64_t)ws->K >= (int64_t(1) << 23) && ws->act_rows == n_rows) {
+            double act = 0.0;
+            rc = fetch_active(ws, st, &act);
+            if (rc) return rc;
+            prune = act <= 0.25 * (double)n_rows * ws->K;
+        }
+    }
+    if (prune && !ws->lists) {
+        e = hipMalloc((void**)&ws->lists, (size_t)ws->K * ws->npad * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->khat, (size_t)ws->npad * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->counts, (size_t)ws->K * sizeof(int));
+        const int64_t sel_blocks = (ws->npad + kSelRows - 1) / kSelRows, words = (ws->K + 63) / 64;
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->blk, (size_t)sel_blocks * ws->K * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * ws->npad * sizeof(unsigned long long));
+        if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (E-step sample lists)", e);
+        ws->bytes += ((int64_t)ws->K * ws->npad + ws->npad + ws->K + sel_blocks * ws->K) * (int64_t)sizeof(int) +
+                     words * ws->npad * 8;
+    }
+    int rpw = 0;
+    int64_t grid = 0;
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
-    hipError_t e = i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
-                      : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name);
-    if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
+    if (prune) {
+        rpw = estep_bound_rows_per_wg(ws->T, is64);
+        grid = (n_rows + rpw - 1) / rpw;
+        if (grid > (1 << 20)) grid = 1 << 20;
+        e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
+        int counts_host[256];
+        const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
+        for (int round = 0; round < 2; ++round) {
+            if (round == 0)
+                hipLaunchKernelGGL(select_mask_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
+                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
+            else
+                hipLaunchKernelGGL(select_mask_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
+                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
+            hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
+            hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
+                               ws->blk, ws->lists, ws->npad);
+            e = hipGetLastError();
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(counts_host, ws->counts, (size_t)ws->K * sizeof(int), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate selection", e);
+            e = launch_estep_gather(ws->T, is64, vec, st, a, ws->lists, ws->npad, ws->counts, counts_host);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_gather launch", e);
+        }
+    } else {
+        rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
+        grid = (n_rows + rpw - 1) / rpw;
+        if (grid > (1 << 20)) grid = 1 << 20;
+        e = i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
+               : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
+    }
     if (ws->prof) {
         (void)hipEventRecord(ws->ev[1], st);
         ws->ev_e = true;
     }
     const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
     hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)lse_blocks), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                       ws->lse, ws->sparse ? ws->dpart : nullptr);
+                       ws->lse, ws->sparse ? ws->dpart : nullptr, ws->apart);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
     if (ws->sparse) {
-        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)((ws->K + 63) / 64)), dim3(64), 0, st, ws->dpart, lse_blocks, ws->K,
-                           ws->thr);
+        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)(ws->K + 1)), dim3(256), 0, st, ws->dpart, ws->apart, lse_blocks,
+                           ws->K, ws->thr, ws->act_total);
         e = hipGetLastError();
         if (e != hipSuccess) return fail(GMMVB_EHIP, "thr_kernel launch", e);
+        ws->act_rows = n_rows;
+        ws->act_host = -1.0;
     }
     ws->e_state = 1;
     ws->e_rows = n_rows;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
-                  i8 ? 512 : estep_threads(ws->estep_variant), rpw);
+                  (i8 || prune) ? 512 : estep_threads(ws->estep_variant), rpw);
     return GMMVB_OK;
 }
 
@@ -329,7 +407,14 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const char* name = "";
     if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
     hipError_t e;
-    if (ws->sparse && pre && ws->e_state == 1) {     // E-step output: skip samples that cannot change the f64 sums
+    bool sparse = ws->sparse && pre && ws->e_state == 1 && ws->act_rows == n_rows;
+    if (sparse) {      // worth it only when most pairs are negligible (the sparse loop is ~2x slower per active sample)
+        double act = 0.0;
+        rc = fetch_active(ws, st, &act);
+        if (rc) return rc;
+        sparse = act <= 0.35 * (double)n_rows * ws->K;
+    }
+    if (sparse) {      // E-step output: skip samples that cannot change the f64 sums
         a.aux = ws->thr;
         e = launch_mstep_sparse(ws->T, (int)grid, st, a, &name);
     } else {

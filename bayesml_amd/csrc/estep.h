@@ -43,14 +43,13 @@ __host__ __device__ constexpr int estep_kb(int t) {
     return kb < 1 ? 1 : (kb > 16 ? 16 : kb);
 }
 
-template <int T, int NB, typename XT, bool VEC>
-__device__ __forceinline__ void load_x_tile(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D, int64_t n0,
-                                            int n, int g, XT (&xr)[NB][T][4]) {
+// rows[nb] = row of x this lane's sample (n, nb) is read from (always a valid row)
+template <int T, int NB, typename XT, bool VEC>      // T = feature blocks to load (the first 16 T features)
+__device__ __forceinline__ void load_x_tile(const XT* __restrict__ x, int64_t ldx, int D, const int64_t (&rows)[NB],
+                                            int g, XT (&xr)[NB][T][4]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        int64_t row = n0 + 16 * nb + n;
-        if (row >= n_rows) row = n_rows - 1;      // clamp: padded samples are never stored
-        const XT* xp = x + row * ldx + 4 * g;
+        const XT* xp = x + rows[nb] * ldx + 4 * g;
 #pragma unroll
         for (int b = 0; b < T; ++b) {
             if constexpr (VEC) {
@@ -69,22 +68,37 @@ __device__ __forceinline__ void load_x_tile(const XT* __restrict__ x, int64_t ld
     }
 }
 
-// One component for one wave tile: image pointer `im` (global or LDS) -> ln rho stores.
-template <int T, int NB, typename XT, typename ImgPtr>
-__device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][T][4], double ck, int lane, int n, int g,
-                                                int64_t n0, int64_t n_rows, double* __restrict__ lnrho_k) {
-    constexpr int P = tri_pairs(T);
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    d4 acc[T][NB];
+// rows of a contiguous wave tile starting at n0: load rows clamp to the last valid row, store rows are -1 past the end
+template <int NB>
+__device__ __forceinline__ void tile_rows(int64_t n0, int n, int64_t n_rows, int64_t (&ld)[NB], int64_t (&stv)[NB]) {
 #pragma unroll
-    for (int jt = 0; jt < T; ++jt) {
+    for (int nb = 0; nb < NB; ++nb) {
+        const int64_t row = n0 + 16 * nb + n;
+        ld[nb] = row < n_rows ? row : n_rows - 1;
+        stv[nb] = row < n_rows ? row : -1;
+    }
+}
+
+// One component for one wave tile: image pointer `im` (global or LDS) -> ln rho stores.
+// JB < T evaluates only the first JB output blocks (16 JB rows of y): the stored value c_k - q_JB / 2 is then an
+// upper bound of ln rho (q_JB <= q), which the pruned E-step (below) uses to discard components.
+// `rows[nb]` = this lane's sample row (or -1: no store).
+// The tile pairs of blocks 0 .. JB-1 are the first tri_pairs(JB) of the image; BOFF = offset of the bias block.
+template <int NB, typename XT, int JB, int BOFF, typename ImgPtr>
+__device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB][4], double ck, int lane, int g,
+                                                const int64_t (&rows)[NB], double* __restrict__ lnrho_k) {
+    constexpr int P = BOFF / 256;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d4 acc[JB][NB];
+#pragma unroll
+    for (int jt = 0; jt < JB; ++jt) {
         const d2 b01 = *reinterpret_cast<const d2*>(im + P * 256 + (jt * 4 + g) * 4);
         const d2 b23 = *reinterpret_cast<const d2*>(im + P * 256 + (jt * 4 + g) * 4 + 2);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[jt][nb] = d4{b01[0], b01[1], b23[0], b23[1]};
     }
 #pragma unroll
-    for (int jt = 0; jt < T; ++jt) {
+    for (int jt = 0; jt < JB; ++jt) {
 #pragma unroll
         for (int b = 0; b <= jt; ++b) {
             const int p = pair_index(jt, b);
@@ -102,13 +116,12 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][T]
     for (int nb = 0; nb < NB; ++nb) {
         double q = 0.0;
 #pragma unroll
-        for (int jt = 0; jt < T; ++jt) {
+        for (int jt = 0; jt < JB; ++jt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) q = fma(acc[jt][nb][r], acc[jt][nb][r], q);
         }
         q = sum_groups(q);
-        const int64_t row = n0 + 16 * nb + n;
-        if (g == 0 && row < n_rows) lnrho_k[row] = ck - 0.5 * q;
+        if (g == 0 && rows[nb] >= 0) lnrho_k[rows[nb]] = ck - 0.5 * q;
     }
 }
 
@@ -127,11 +140,13 @@ __global__ __launch_bounds__(256) void estep_mfma_f64(const XT* __restrict__ x, 
     const int64_t n_tiles = (n_rows + rows_per_wave - 1) / rows_per_wave;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t n0 = tile * rows_per_wave;
+        int64_t ld[NB], stv[NB];
+        tile_rows<NB>(n0, n, n_rows, ld, stv);
         XT xr[NB][T][4];
-        load_x_tile<T, NB, XT, VEC>(x, ldx, n_rows, D, n0, n, g, xr);
+        load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
         for (int k = 0; k < K; ++k)
-            estep_component<T, NB, XT>(img + (int64_t)k * IMG, xr, cvec[k], lane, n, g, n0, n_rows,
-                                       lnrho + (int64_t)k * npad);
+            estep_component<NB, XT, T, tri_pairs(T) * 256>(img + (int64_t)k * IMG, xr, cvec[k], lane, g, stv,
+                                                           lnrho + (int64_t)k * npad);
     }
 }
 
@@ -174,8 +189,10 @@ __global__ __launch_bounds__(64 * NW) void estep_lds_f64(const XT* __restrict__ 
 
     for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
         const int64_t n0 = wt * rows_per_wg + (int64_t)wave * 16 * NB;   // may lie past n_rows: rows clamp, stores mask
+        int64_t ld[NB], stv[NB];
+        tile_rows<NB>(n0, n, n_rows, ld, stv);
         XT xr[NB][T][4];
-        load_x_tile<T, NB, XT, VEC>(x, ldx, n_rows, D, n0, n, g, xr);
+        load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -187,13 +204,154 @@ __global__ __launch_bounds__(64 * NW) void estep_lds_f64(const XT* __restrict__ 
             for (int kk = 0; kk < KB; ++kk) {
                 const int k = k0 + kk;
                 if (k >= K) break;
-                estep_component<T, NB, XT>(buf + kk * IMG, xr, cvec[k], lane, n, g, n0, n_rows,
-                                           lnrho + (int64_t)k * npad);
+                estep_component<NB, XT, T, tri_pairs(T) * 256>(buf + kk * IMG, xr, cvec[k], lane, g, stv,
+                                                               lnrho + (int64_t)k * npad);
             }
             // the prefetched block must have landed, and every wave must be done reading this one
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+    }
+}
+
+// ---- pruned E-step -----------------------------------------------------------------------------------------------
+// Once the responsibilities are sparse, almost every (sample, component) pair only has to be shown irrelevant:
+//   1. estep_bound_f64: the first JB output blocks of y for ALL pairs -> u_nk = c_k - q_JB / 2 >= ln rho_nk
+//      (tri_pairs(JB) of the tri_pairs(T) tile pairs: 6 of 36 at D = 128, JB = 3), written to the ln rho array;
+//   2. select_best_kernel: khat_n = argmax_k u_nk, samples appended to per-component lists;
+//      estep_gather_f64 evaluates those pairs exactly (component fixed per workgroup, sample rows gathered);
+//   3. select_near_kernel: every k with u_nk >= ln rho_{n,khat} - 100 ln 2 joins the lists, evaluated exactly too.
+// Every other pair keeps its upper bound, which proves r_nk < 2^-100: it changes neither lse_n nor (mstep.h) any
+// statistic beyond the last bit, and it is below the M-step's skip threshold of every component whose largest
+// responsibility exceeds 2^-100.  The results of the exact pairs do not depend on list order (one MFMA column per
+// sample), so the lists are filled with wave-aggregated atomics.
+template <int JB>
+__host__ __device__ constexpr int bound_img_doubles() { return tri_pairs(JB) * 256 + 128; }
+template <int JB>
+__host__ __device__ constexpr int bound_kb() {
+    const int kb = (64 * 1024) / (bound_img_doubles<JB>() * 8);
+    return kb < 1 ? 1 : (kb > 16 ? 16 : kb);
+}
+template <typename XT>
+__host__ __device__ constexpr int bound_nb(int jb) {      // accumulators 8 JB NB, x registers JB NB 4 (x sizeof/4)
+    const int cap = (sizeof(XT) == 4 ? 12 : 8) / jb;
+    return cap < 1 ? 1 : (cap > 4 ? 4 : cap);
+}
+
+template <int T, int JB, typename XT, bool VEC>
+__global__ __launch_bounds__(512) void estep_bound_f64(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                                       const double* __restrict__ img /*[K][img_doubles(T)]*/,
+                                                       const double* __restrict__ cvec, int K,
+                                                       double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
+    constexpr int NW = 8;
+    constexpr int NB = bound_nb<XT>(JB);
+    constexpr int IMG = img_doubles(T);
+    constexpr int IMJ = bound_img_doubles<JB>();
+    constexpr int PJ = tri_pairs(JB);
+    constexpr int KB = bound_kb<JB>();
+    __shared__ __attribute__((aligned(16))) double smem[2][KB * IMJ];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t rows_per_wg = NW * 16 * NB;
+    const int64_t n_wg_tiles = (n_rows + rows_per_wg - 1) / rows_per_wg;
+    const int n_blocks = (K + KB - 1) / KB;
+
+    // per component: the first 2 PJ 1-KB pieces of the image (its first PJ tile pairs) and the bias piece
+    auto stage = [&](int kb, int buf) {
+        const int k0 = kb * KB;
+        const int kcount = (K - k0 < KB) ? (K - k0) : KB;
+        const int pieces = kcount * (2 * PJ + 1);
+        for (int piece = wave; piece < pieces; piece += NW) {
+            const int kk = piece / (2 * PJ + 1), q = piece - kk * (2 * PJ + 1);
+            const double* src = img + (int64_t)(k0 + kk) * IMG + (q < 2 * PJ ? q * 128 : tri_pairs(T) * 256) + lane * 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(&smem[buf][kk * IMJ + q * 128]),
+                                             16, 0, 0);
+        }
+    };
+
+    for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
+        const int64_t n0 = wt * rows_per_wg + (int64_t)wave * 16 * NB;
+        int64_t ld[NB], stv[NB];
+        tile_rows<NB>(n0, n, n_rows, ld, stv);
+        XT xr[NB][JB][4];
+        load_x_tile<JB, NB, XT, VEC>(x, ldx, D, ld, g, xr);
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = 0; kb < n_blocks; ++kb) {
+            if (kb + 1 < n_blocks) stage(kb + 1, (kb + 1) & 1);
+            const double* buf = smem[kb & 1];
+            const int k0 = kb * KB;
+#pragma unroll 1
+            for (int kk = 0; kk < KB; ++kk) {
+                const int k = k0 + kk;
+                if (k >= K) break;
+                estep_component<NB, XT, JB, PJ * 256>(buf + kk * IMJ, xr, cvec[k], lane, g, stv, lnrho + (int64_t)k * npad);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+}
+
+// Exact ln rho for listed (sample, component) pairs.  Workgroup b handles component k = the segment of `first`
+// (first[k] = index of k's first workgroup, first[K] = grid) that b falls in, and the chunk b - first[k] of that
+// component's sample list; the component's image is staged once and kept for the whole chunk.
+struct GatherPlan {
+    int first[257];       // K <= 256
+};
+constexpr int kGatherTiles = 8;      // wave tiles per workgroup wave -> 8 waves x 16 NB x 8 samples per chunk
+
+template <int T, typename XT, bool VEC>
+__global__ __launch_bounds__(512) void estep_gather_f64(const XT* __restrict__ x, int64_t ldx, int D,
+                                                        const double* __restrict__ img, const double* __restrict__ cvec,
+                                                        int K, const int* __restrict__ lists /*[K][cap]*/, int64_t cap,
+                                                        const int* __restrict__ counts /*[K]*/, GatherPlan plan,
+                                                        double* __restrict__ lnrho, int64_t npad) {
+    constexpr int NW = 8;
+    constexpr int NB = estep_nb_w<XT>(T, NW);
+    constexpr int IMG = img_doubles(T);
+    __shared__ __attribute__((aligned(16))) double smem[IMG];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    int k = 0;
+    {
+        int lo = 0, hi = K;                      // largest k with first[k] <= blockIdx.x
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (plan.first[mid] <= (int)blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        k = lo;
+    }
+    const int count = counts[k];
+    const int64_t chunk0 = (int64_t)(blockIdx.x - plan.first[k]) * (NW * 16 * NB * kGatherTiles);
+    const double* src = img + (int64_t)k * IMG + lane * 2;
+    for (int piece = wave; piece < IMG / 128; piece += NW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 128),
+                                         (__attribute__((address_space(3))) void*)(&smem[piece * 128]), 16, 0, 0);
+    const int* list = lists + (int64_t)k * cap;
+    const double ck = cvec[k];
+    double* out = lnrho + (int64_t)k * npad;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < kGatherTiles; ++t) {
+        const int64_t e0 = chunk0 + ((int64_t)t * NW + wave) * 16 * NB;
+        if (e0 >= count) break;
+        int64_t ld[NB], stv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int64_t e = e0 + 16 * nb + n;
+            const int row = list[e < count ? e : count - 1];
+            ld[nb] = row;
+            stv[nb] = e < count ? row : -1;
+        }
+        XT xr[NB][T][4];
+        load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
+        estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
     }
 }
 

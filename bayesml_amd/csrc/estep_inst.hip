@@ -48,4 +48,70 @@ hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hi
     return hipErrorInvalidValue;
 }
 
+// ---- pruned E-step -------------------------------------------------------------------------------------------
+int estep_bound_blocks(int T) { return T >= 6 ? 3 : (T >= 4 ? 2 : 0); }
+int estep_bound_rows_per_wg(int T, int x_is_f64) {
+    const int jb = estep_bound_blocks(T);
+    return jb ? 8 * 16 * (x_is_f64 ? bound_nb<double>(jb) : bound_nb<float>(jb)) : 0;
+}
+int estep_gather_rows_per_wg(int T, int x_is_f64) {
+    return 8 * 16 * (x_is_f64 ? estep_nb_w<double>(T, 8) : estep_nb_w<float>(T, 8)) * kGatherTiles;
+}
+
+template <int T, int JB, typename XT, bool VEC>
+static hipError_t go_bound(int grid, hipStream_t st, const EstepArgs& a) {
+    hipLaunchKernelGGL((estep_bound_f64<T, JB, XT, VEC>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x), a.ldx,
+                       a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
+    return hipGetLastError();
+}
+template <int T, typename XT, bool VEC>
+static hipError_t go_gather(int grid, hipStream_t st, const EstepArgs& a, const int* lists, int64_t cap,
+                            const int* counts, const GatherPlan& plan) {
+    hipLaunchKernelGGL((estep_gather_f64<T, XT, VEC>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x), a.ldx,
+                       a.D, a.img, a.cvec, a.K, lists, cap, counts, plan, a.lnrho, a.npad);
+    return hipGetLastError();
+}
+
+#define BCASE(TT, JB)                                                                                              \
+    case TT:                                                                                                       \
+        *name = "estep_bound_f64<T=" #TT ",blocks=" #JB ">";                                                       \
+        if (x_is_f64) return vec ? go_bound<TT, JB, double, true>(grid, st, a) : go_bound<TT, JB, double, false>(grid, st, a); \
+        return vec ? go_bound<TT, JB, float, true>(grid, st, a) : go_bound<TT, JB, float, false>(grid, st, a);
+
+hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
+                              const char** name) {
+    switch (T) {
+        BCASE(4, 2) BCASE(5, 2) BCASE(6, 3) BCASE(7, 3) BCASE(8, 3)
+    }
+    return hipErrorInvalidValue;
+}
+
+#define GCASE(TT)                                                                                                            \
+    case TT:                                                                                                                 \
+        if (x_is_f64)                                                                                                        \
+            return vec ? go_gather<TT, double, true>(grid, st, a, lists, cap, counts_dev, plan)                              \
+                       : go_gather<TT, double, false>(grid, st, a, lists, cap, counts_dev, plan);                            \
+        return vec ? go_gather<TT, float, true>(grid, st, a, lists, cap, counts_dev, plan)                                   \
+                   : go_gather<TT, float, false>(grid, st, a, lists, cap, counts_dev, plan);
+
+hipError_t launch_estep_gather(int T, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a, const int* lists,
+                               int64_t cap, const int* counts_dev, const int* counts_host) {
+    if (a.K > 256) return hipErrorInvalidValue;
+    const int per_wg = estep_gather_rows_per_wg(T, x_is_f64);
+    GatherPlan plan;
+    int64_t total = 0;
+    for (int k = 0; k < a.K; ++k) {
+        plan.first[k] = (int)total;
+        total += (counts_host[k] + per_wg - 1) / per_wg;
+    }
+    for (int k = a.K; k <= 256; ++k) plan.first[k] = (int)total;
+    if (total == 0) return hipSuccess;
+    if (total > 0x7fffffff) return hipErrorInvalidValue;
+    const int grid = (int)total;
+    switch (T) {
+        GCASE(4) GCASE(5) GCASE(6) GCASE(7) GCASE(8)
+    }
+    return hipErrorInvalidValue;
+}
+
 }  // namespace gmmvb

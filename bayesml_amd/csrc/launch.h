@@ -21,6 +21,15 @@ enum EstepVariant { kEstepLds = 0, kEstepDirect = 1, kEstepLds8 = 2, kEstepI8 = 
 int estep_rows_per_wg(int variant, int T, int x_is_f64);
 int estep_threads(int variant);
 int estep_image_doubles(int T);
+// pruned E-step (estep.h): bound kernel over all pairs, exact kernel over per-component sample lists
+int estep_bound_blocks(int T);                    // JB, 0 = the pruned path is not built for this T
+int estep_bound_rows_per_wg(int T, int x_is_f64);
+int estep_gather_rows_per_wg(int T, int x_is_f64);
+hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
+                              const char** name);
+// counts_host[k] samples in list k (device lists [K][cap], device counts); launches nothing when all are empty
+hipError_t launch_estep_gather(int T, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a, const int* lists,
+                               int64_t cap, const int* counts_dev, const int* counts_host);
 // int8-digit E-step (estep_i8.h): own parameter image (bytes per component), 256 rows per workgroup
 struct EstepI8Args {
     const void* x; int64_t ldx; int64_t n_rows; int D;

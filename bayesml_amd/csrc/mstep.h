@@ -250,9 +250,17 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
 // than 2^40 terms and the sums are at least as large as their largest term), so the statistics are unchanged to the
 // last bit of rounding when such samples are skipped - and skipping them removes their row loads and MFMAs.
 // `thr` = max_n (ln rho_nk - lse_n) - 100 ln 2 (row_lse_kernel / thr_kernel).  The wave scans its rows 64 at a time,
-// ballots the active ones and feeds them to the MFMAs four at a time (a short last group of a batch is padded with
-// r = 0); batches with no active sample cost one load, one compare and one ballot.  Dense input degenerates to the
-// dense kernel's work plus a few scalar instructions per step.  Centred-copy rows only (PRE form).
+// ballots the active ones and feeds them to the MFMAs four at a time, packing across batches; batches with no
+// active sample cost one load, one compare and one ballot.  On dense input this loop is about 2x slower than the
+// dense kernel (measured), so gmmvb_mstep only takes it when at most 35 % of the pairs are active.
+// Centred-copy rows only (PRE form).
+__device__ __forceinline__ double readlane_f64(double v, int lane) {      // lane must be wave uniform
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 template <int T, int WS, int SUB>
 __device__ __forceinline__ void mstep_sparse_body(const double* __restrict__ xc, const double* __restrict__ lr,
                                                   const double* __restrict__ lse, double thr, int64_t lo, int64_t hi,
@@ -293,37 +301,43 @@ __device__ __forceinline__ void mstep_sparse_body(const double* __restrict__ xc,
     int64_t c0 = lo - 64;
     unsigned long long m = 0;
     double r_l = 0.0;
-    int64_t grow = 0;      // next group: row of this lane's sample slot g, and its responsibility
+    int64_t grow = lo;     // next group: row of this lane's sample slot g, and its responsibility
     double grr = 0.0;
+    // Fill the four sample slots of the next group with the next four active samples, across batch boundaries
+    // (a group is only padded with r = 0 at the very end of the row range).
     auto advance = [&]() -> bool {
-        while (m == 0) {
-            c0 += 64;
-            if (c0 >= hi) return false;
-            const int64_t nl = c0 + lane;
-            bool act = false;
-            double t = 0.0;
-            if (nl < hi) {
-                t = lr[nl] - lse[nl];
-                act = !(t < thr);              // NaN stays active and propagates like in the dense kernel
+        int fill = 0;
+        while (fill < 4) {
+            if (m == 0) {
+                c0 += 64;
+                if (c0 >= hi) break;
+                const int64_t nl = c0 + lane;
+                bool act = false;
+                double t = 0.0;
+                if (nl < hi) {
+                    t = lr[nl] - lse[nl];
+                    act = !(t < thr);              // NaN stays active and propagates like in the dense kernel
+                }
+                r_l = act ? exp(t) : 0.0;
+                if (act) hsum = fma(r_l, t, hsum);  // r ln r, with ln r = ln rho - lse exactly
+                nsum += r_l;
+                m = __ballot(act);
+                continue;
             }
-            r_l = act ? exp(t) : 0.0;
-            if (act) hsum = fma(r_l, t, hsum);  // r ln r, with ln r = ln rho - lse exactly
-            nsum += r_l;
-            m = __ballot(act);
+            const int pos = __builtin_ctzll(m);
+            m &= m - 1;
+            const double rv = readlane_f64(r_l, pos);
+            if (g == fill) {
+                grow = c0 + pos;
+                grr = rv;
+            }
+            ++fill;
         }
-        int pos[4];
-        bool ok[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ok[q] = m != 0;
-            pos[q] = ok[q] ? __builtin_ctzll(m) : 0;
-            if (ok[q]) m &= m - 1;
+        if (fill == 0) return false;
+        if (g >= fill) {
+            grow = lo;
+            grr = 0.0;
         }
-        const int my = g == 0 ? pos[0] : (g == 1 ? pos[1] : (g == 2 ? pos[2] : pos[3]));
-        const bool mine = g == 0 ? ok[0] : (g == 1 ? ok[1] : (g == 2 ? ok[2] : ok[3]));
-        grow = c0 + my;
-        const double rv = __shfl(r_l, my);
-        grr = mine ? rv : 0.0;
         return true;
     };
 

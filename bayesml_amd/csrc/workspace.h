@@ -25,6 +25,18 @@ struct gmmvb_workspace {
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)
     double* thr = nullptr;     // [K] M-step skip thresholds: max_n ln r_nk - 100 ln 2 (valid while e_state == 1)
     bool sparse = true;        // env GMMVB_MSTEP_SPARSE=0: always run the dense M-step
+    double* apart = nullptr;   // [ceil(npad / 1024)] pairs with ln r >= -100 ln 2 per row block
+    double* act_total = nullptr;   // their sum, written by thr_kernel after every E-step
+    int64_t act_rows = 0;      // rows of the E-step act_total belongs to (0 = none yet)
+    double act_host = -1.0;    // host copy of act_total for that E-step (-1 = not fetched yet)
+    // pruned E-step (estep.h): env GMMVB_ESTEP_PRUNE = 0 never | force always | default: when the previous E-step
+    // over the same rows left at most a quarter of the pairs relevant and N K >= 2^23
+    int prune = 1;
+    int* lists = nullptr;      // [K][npad] sample lists, allocated at first use
+    int* khat = nullptr;       // [npad]
+    int* counts = nullptr;     // [K]
+    int* blk = nullptr;        // [ceil(npad / 256)][K] candidates per selection block -> block bases
+    unsigned long long* masks = nullptr;   // [ceil(K / 64)][npad] candidate components of every sample
     double* slabs = nullptr;   // [S_cap][K][slab_len]
     double* xc = nullptr;      // [npad][16T] centred f64 copy of the sample matrix (M-step operand), optional
     const void* xc_src = nullptr;   // the x it was made from (null = not prepared)

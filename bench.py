@@ -168,12 +168,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ker = []
+    ker, launches = [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         vl = step()
         ker.append(eng.last_kernel_ms())        # events already complete: step() ended with a host sync
+        launches.append(eng.launch_info)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -227,6 +228,8 @@ def main():
                          "note": "achieved = algorithmic (dense) flops of SURVEY 8d / HIP-event kernel time; the kernels "
                                  "execute ~0.56x of them (triangular whitening factor, symmetric second moment)"},
             "cpu_baseline": cpu_base, "parity": parity, "final_vl": vl, "launch": eng.launch_info,
+            "per_step": {"estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
+                         "estep_kernel": [l.split("<")[0] for l in launches]},
         }
         print(json.dumps(out))
     if world > 1:

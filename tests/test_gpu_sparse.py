@@ -1,0 +1,118 @@
+"""The sparse-responsibility M-step and the pruned E-step against the dense kernels.
+
+Both only drop work that cannot change the f64 results (responsibilities below 2^-100 of the component's / the
+sample's largest one), so everything that leaves the data pass has to agree with the dense path to rounding:
+statistics, responsibilities, hard assignments, posterior hyper-parameters.  ln rho itself is allowed to be an
+upper bound for pruned pairs, at least 100 ln 2 below the sample's best component.
+The switches are environment variables read when a workspace is created."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import gmm_vb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DENSE = dict(GMMVB_ESTEP_PRUNE="0", GMMVB_MSTEP_SPARSE="0")
+SPARSE = dict(GMMVB_ESTEP_PRUNE="force")          # M-step: sparse whenever at most 35 % of the pairs are active
+
+
+class _env:
+    def __init__(self, kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE")}
+        for k in self.old:
+            os.environ.pop(k, None)
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def _fit(x, K, iters, env, seed=0):
+    from bayesml_amd import gaussianmixture as gm
+    with _env(env):
+        m = gm.LearnModel(K, x.shape[1], seed=seed, device=torch.device("cuda", 0), verbose=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.update_posterior(x, max_itr=iters, num_init=1, tolerance=0.0)
+    return m
+
+
+@pytest.mark.parametrize("K,K_data,D,N,dtype,iters", [
+    (32, 32, 96, 40_000, np.float32, 5),
+    (16, 16, 64, 30_000, np.float64, 4),
+    (24, 6, 128, 20_001, np.float32, 6),        # four components per true cluster: most of them die
+])
+def test_driver_sparse_equals_dense(K, K_data, D, N, dtype, iters):
+    x = orc.synth_gmm(K_data, D, N, dtype)
+    a = _fit(x, K, iters, DENSE)
+    b = _fit(x, K, iters, SPARSE)
+    assert "estep_bound_f64" in b._engine.launch_info and "estep_bound_f64" not in a._engine.launch_info
+    ha, hb = a.get_hn_params(), b.get_hn_params()
+    for k in ha:
+        assert rel_err(hb[k], ha[k]) < 1e-11, k
+    ra = a._engine.responsibilities().cpu().numpy()
+    rb = b._engine.responsibilities().cpu().numpy()
+    assert np.max(np.abs(ra - rb)) < 1e-11
+    assert np.array_equal(a._engine.argmax().cpu().numpy(), b._engine.argmax().cpu().numpy())
+    # pruned pairs hold upper bounds of ln rho, far below the row's best; exact pairs agree to rounding
+    la = a._engine.ln_rho().cpu().numpy()
+    lb = b._engine.ln_rho().cpu().numpy()
+    same = np.abs(la - lb) <= 1e-9 * np.maximum(1.0, np.abs(la))
+    assert np.all(lb[~same] >= la[~same])
+    best = la.max(axis=1, keepdims=True)
+    assert np.all((lb <= best - 69.0) | same)
+    if K == K_data:        # (with several components per cluster every pair may be a candidate)
+        assert same.mean() < 0.9, "the pruned path did not prune anything"
+
+
+def _pass(xd, qd, env, pivot):
+    from bayesml_amd._engine import DataPass
+    K, D = qd.m.shape
+    with _env(env):
+        eng = DataPass(K, D, xd.dtype, xd.shape[0], xd.device)
+    eng.set_pivot(pivot)
+    eng.prepare_rows(xd)
+    eng.set_params(qd.c, qd.m, qd.u)
+    out = []
+    for _ in range(2):           # the second pass is the one that may prune (it needs the first one's sparsity count)
+        stats = eng.estep_mstep(xd).clone()
+        out.append((stats.cpu().numpy(), eng.responsibilities().cpu().numpy(), eng.launch_info))
+    eng.close()
+    return out
+
+
+def test_data_pass_statistics_and_nan_rows():
+    from bayesml_amd import _kside
+    K, D, N = 32, 96, 32_000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    m = _fit(x, K, 6, DENSE)
+    dev = torch.device("cuda", 0)
+    hn = m.get_hn_params()
+    t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+    qd = _kside.features(_kside.PostT(t(hn["hn_alpha_vec"]), t(hn["hn_m_vecs"]), t(hn["hn_kappas"]), t(hn["hn_nus"]),
+                                      t(np.linalg.inv(hn["hn_w_mats"]))))
+    xd = torch.from_numpy(x).to(dev)
+    pivot = xd[:4096].to(torch.float64).mean(dim=0)
+    dense = _pass(xd, qd, DENSE, pivot)
+    sparse = _pass(xd, qd, SPARSE, pivot)
+    assert "mstep_sparse_f64" in sparse[1][2] and "estep_bound_f64" in sparse[1][2]
+    assert "mstep_mfma_f64" in dense[1][2]
+    for (sa, ra, _), (sb, rb, _) in zip(dense, sparse):
+        assert rel_err(sb, sa) < 1e-12
+        assert np.max(np.abs(ra - rb)) < 1e-12
+    # a non-finite sample poisons the statistics on both paths alike (nothing is silently skipped)
+    xd[1234, 5] = float("nan")
+    for env in (DENSE, SPARSE):
+        out = _pass(xd, qd, env, pivot)
+        assert np.isnan(out[1][0][:K]).all()
