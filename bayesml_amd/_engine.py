@@ -38,6 +38,7 @@ SYMBOLS = {
     "gmmvb_ln_rho": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gmmvb_argmax": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gmmvb_last_launch_info": (ctypes.c_char_p, [_vp]),
+    "gmmvb_last_sparsity": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
     "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -147,6 +148,14 @@ class DataPass:
     def launch_info(self) -> str:
         s = self.lib.gmmvb_last_launch_info(self._ws)
         return s.decode() if s else ""
+
+    def sparsity(self):
+        """(active pairs, exactly evaluated pairs) of the last E-step; see gmmvb_last_sparsity."""
+        a, e = ctypes.c_double(), ctypes.c_double()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_last_sparsity(self._ws, self._stream(), ctypes.byref(a), ctypes.byref(e)),
+                   "gmmvb_last_sparsity")
+        return float(a.value), float(e.value)
 
     def profile(self, on: bool = True):
         _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")

@@ -156,13 +156,16 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
     return v;
 }
 
-// NEAR = false: the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
-// NEAR = true : ln rho[khat_n][n] is exact now; the mask holds every other k with u[k][n] >= it - 100 ln 2.
-template <bool NEAR>
+// MODE 0 (best)  : the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
+// MODE 1 (near)  : ln rho[khat_n][n] is exact now; the mask holds every other k with u[k][n] >= it - 100 ln 2.
+// MODE 2 (active): the M-step's samples: every k with ln r_nk = u[k][n] - lse[n] >= thr[k] (mstep.h).
+template <int MODE>
 __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __restrict__ u, int64_t npad, int64_t n_rows,
                                                                int K, int* __restrict__ khat,
+                                                               const double* __restrict__ lse, const double* __restrict__ thr,
                                                                unsigned long long* __restrict__ masks /*[W][npad]*/,
                                                                int* __restrict__ blk_cnt /*[blocks][K]*/) {
+    constexpr bool NEAR = MODE == 1;
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
         kh = khat[n];
         lim = u[(int64_t)kh * npad + n] - 69.314718055994530942;
     }
-    if (!NEAR) {
+    if (MODE == 2 && valid) lim = lse[n];
+    if (MODE == 0) {
         int arg = 0;
         if (valid) {
             double best = u[n];
@@ -192,7 +196,13 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
     for (int w = 0; w < W; ++w) {
         unsigned long long mk = 0;
         if (valid) {
-            if (NEAR) {
+            if (MODE == 2) {
+                const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
+                for (int b = 0; b < kend; ++b) {
+                    const double t = u[(int64_t)(64 * w + b) * npad + n] - lim;
+                    mk |= (unsigned long long)(!(t < thr[64 * w + b])) << b;   // NaN stays active
+                }
+            } else if (NEAR) {
                 const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
                 for (int b = 0; b < kend; ++b) {
                     const double v = u[(int64_t)(64 * w + b) * npad + n];

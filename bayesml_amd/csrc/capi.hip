@@ -215,6 +215,21 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
     return GMMVB_OK;
 }
 
+// sample lists of the pruned E-step and the sparse M-step (allocated at first use)
+static int ensure_lists(gmmvb_workspace* ws) {
+    if (ws->lists) return GMMVB_OK;
+    const int64_t sel_blocks = (ws->npad + kSelRows - 1) / kSelRows, words = (ws->K + 63) / 64;
+    hipError_t e = hipMalloc((void**)&ws->lists, (size_t)ws->K * ws->npad * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->khat, (size_t)ws->npad * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->counts, (size_t)ws->K * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->blk, (size_t)sel_blocks * ws->K * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * ws->npad * sizeof(unsigned long long));
+    if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (sample lists)", e);
+    ws->bytes += ((int64_t)ws->K * ws->npad + ws->npad + ws->K + sel_blocks * ws->K) * (int64_t)sizeof(int) +
+                 words * ws->npad * 8;
+    return GMMVB_OK;
+}
+
 // active-pair count of the last E-step (one 8-byte read behind a stream sync, cached until the next E-step)
 static int fetch_active(gmmvb_workspace* ws, hipStream_t st, double* out) {
     if (ws->act_host < 0.0) {
@@ -226,6 +241,13 @@ static int fetch_active(gmmvb_workspace* ws, hipStream_t st, double* out) {
     }
     *out = ws->act_host;
     return GMMVB_OK;
+}
+
+int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs) {
+    if (!ws || !active_pairs || !evaluated_pairs) return fail(GMMVB_EINVAL, "null argument");
+    if (ws->e_state == 0 || ws->act_rows == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    *evaluated_pairs = ws->evaluated;
+    return fetch_active(ws, (hipStream_t)stream, active_pairs);
 }
 
 static int check_x(const gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, bool* vec) {
@@ -287,20 +309,14 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             prune = act <= 0.25 * (double)n_rows * ws->K;
         }
     }
-    if (prune && !ws->lists) {
-        e = hipMalloc((void**)&ws->lists, (size_t)ws->K * ws->npad * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void**)&ws->khat, (size_t)ws->npad * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void**)&ws->counts, (size_t)ws->K * sizeof(int));
-        const int64_t sel_blocks = (ws->npad + kSelRows - 1) / kSelRows, words = (ws->K + 63) / 64;
-        if (e == hipSuccess) e = hipMalloc((void**)&ws->blk, (size_t)sel_blocks * ws->K * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * ws->npad * sizeof(unsigned long long));
-        if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (E-step sample lists)", e);
-        ws->bytes += ((int64_t)ws->K * ws->npad + ws->npad + ws->K + sel_blocks * ws->K) * (int64_t)sizeof(int) +
-                     words * ws->npad * 8;
+    if (prune) {
+        rc = ensure_lists(ws);
+        if (rc) return rc;
     }
     int rpw = 0;
     int64_t grid = 0;
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
+    ws->evaluated = prune ? 0.0 : (double)n_rows * ws->K;
     if (prune) {
         rpw = estep_bound_rows_per_wg(ws->T, is64);
         grid = (n_rows + rpw - 1) / rpw;
@@ -311,11 +327,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
         for (int round = 0; round < 2; ++round) {
             if (round == 0)
-                hipLaunchKernelGGL(select_mask_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
+                hipLaunchKernelGGL(select_mask_kernel<0>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
+                                   n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
             else
-                hipLaunchKernelGGL(select_mask_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
+                hipLaunchKernelGGL(select_mask_kernel<1>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
+                                   n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
             hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
             hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
                                ws->blk, ws->lists, ws->npad);
@@ -324,6 +340,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 e = hipMemcpyAsync(counts_host, ws->counts, (size_t)ws->K * sizeof(int), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate selection", e);
+            for (int k = 0; k < ws->K; ++k) ws->evaluated += counts_host[k];
             e = launch_estep_gather(ws->T, is64, vec, st, a, ws->lists, ws->npad, ws->counts, counts_host);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_gather launch", e);
         }
@@ -391,7 +408,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool pre = ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     const int kpw = mstep_components_per_wg(ws->T, pre);
     const int KG = (ws->K + kpw - 1) / kpw;
-    const int64_t grid = 8 * ((S + 7) / 8) * KG;
+    int64_t grid = 8 * ((S + 7) / 8) * KG;
     MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, nullptr, ws->npad, ws->K, KG, (int)S,
                 rows_per_split, ws->e_state == 2 ? 1 : 0, ws->slabs};
     if (ws->e_state == 3) {          // HMM: responsibilities = gamma from the forward-backward pass, h = sum gamma ln rho
@@ -405,19 +422,38 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         a.D = 16 * ws->T;
     }
     const char* name = "";
-    if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
     hipError_t e;
     bool sparse = ws->sparse && pre && ws->e_state == 1 && ws->act_rows == n_rows;
-    if (sparse) {      // worth it only when most pairs are negligible (the sparse loop is ~2x slower per active sample)
+    if (sparse) {      // the lists pay off when most pairs are negligible
         double act = 0.0;
         rc = fetch_active(ws, st, &act);
         if (rc) return rc;
         sparse = act <= 0.35 * (double)n_rows * ws->K;
     }
-    if (sparse) {      // E-step output: skip samples that cannot change the f64 sums
-        a.aux = ws->thr;
-        e = launch_mstep_sparse(ws->T, (int)grid, st, a, &name);
+    if (sparse && ws->K > 256) sparse = false;
+    if (sparse) {      // E-step output: only the samples that can change the f64 sums, through per-component lists
+        rc = ensure_lists(ws);
+        if (rc) return rc;
+        // a split = a whole number of 256-row selection blocks
+        const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
+        int bps = (int)((rows_per_split + kSelRows - 1) / kSelRows);
+        if (bps < 1) bps = 1;
+        rows_per_split = (int64_t)bps * kSelRows;
+        S = (n_rows + rows_per_split - 1) / rows_per_split;
+        if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
+        hipLaunchKernelGGL(select_mask_kernel<2>, dim3(nblk), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                           ws->khat, ws->lse, ws->thr, ws->masks, ws->blk);
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, nblk, ws->K, ws->counts);
+        hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
+                           ws->blk, ws->lists, ws->npad);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);
+        grid = 8 * ((S + 7) / 8) * KG;
+        MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->blk, ws->counts, nblk, bps,
+                         ws->npad, ws->K, KG, (int)S, ws->slabs};
+        e = launch_mstep_list(ws->T, (int)grid, st, la, &name);
     } else {
+        if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
         e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
     }
     if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);

@@ -51,7 +51,12 @@ hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hi
 hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipStream_t st, const MstepArgs& a,
                         const char** name);
 
-// sparse-responsibility M-step over the centred copy (mstep.h); a.x = xc, a.aux = thr[K]
-hipError_t launch_mstep_sparse(int T, int grid, hipStream_t st, const MstepArgs& a, const char** name);
+// sparse-responsibility M-step over the centred copy and per-component lists of active rows (mstep.h)
+struct MstepListArgs {
+    const double* xc; const double* lnrho; const double* lse;
+    const int* lists; int64_t cap; const int* blk; const int* counts; int nblk; int blocks_per_split;
+    int64_t npad; int K; int KG; int S; double* slabs;
+};
+hipError_t launch_mstep_list(int T, int grid, hipStream_t st, const MstepListArgs& a, const char** name);
 
 }  // namespace gmmvb

@@ -56,11 +56,14 @@ __host__ __device__ constexpr int mstep_owned(int ws, int sub, int t) {
 
 // PRE = true: rows come from the workspace's centred f64 copy xc[n][16T] = (double)x - pivot (zero padded),
 // made once per sample matrix by center_rows_kernel, so the loop has no convert/subtract/mask work.
-template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE>
+// LIST = true: [lo, hi) are positions in `list` (ascending rows of x whose responsibility for this component is not
+// negligible, see "sparse responsibilities" below); entry e stands for row list[e].
+template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE, bool LIST = false>
 __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                            const double* __restrict__ pivot, const double* __restrict__ lr,
                                            const double* __restrict__ lse, const double* __restrict__ aux_k,
-                                           int64_t lo, int64_t hi, int direct_r, double* __restrict__ out) {
+                                           int64_t lo, int64_t hi, int direct_r, double* __restrict__ out,
+                                           const int* __restrict__ list = nullptr) {
     constexpr int P = tri_pairs(T);
     constexpr int NP = mstep_owned(WS, SUB, T);   // tile pairs owned by this wave
     const int lane = threadIdx.x & 63;
@@ -115,21 +118,26 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     // s+1 are issued before the MFMAs of step s and consumed after them.  The sched_barriers keep hipcc
     // from hoisting those loads above the VALU block, where a register it then reuses forces a
     // vmcnt(0) right behind the issue (measured: -7 % on the whole kernel).
-    RawRow nxt = load_row(lo + g);
+    int idx_n = 0;                         // LIST: rows of the next batch of 64 entries, one per lane
+    if constexpr (LIST) idx_n = (lo + lane < hi) ? list[lo + lane] : 0;
+    RawRow nxt = load_row(LIST ? (int64_t)__shfl(idx_n, g) : lo + g);
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         // responsibilities of 64 samples, one per lane
         const int64_t nl = c0 + lane;
+        const int idx_l = idx_n;
+        if constexpr (LIST) idx_n = (nl + 64 < hi) ? list[nl + 64] : 0;
         double r_l = 0.0;
         if (nl < hi) {
-            const double v = lr[nl];
+            const int64_t src = LIST ? (int64_t)idx_l : nl;
+            const double v = lr[src];
             if (direct_r == 2) {                 // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
                 r_l = v;
-                if (v > 0.0) hsum = fma(v, aux_k[nl], hsum);
+                if (v > 0.0) hsum = fma(v, aux_k[src], hsum);
             } else if (direct_r) {
                 r_l = v;
                 if (v > 0.0) hsum = fma(v, log(v), hsum);
             } else {
-                const double t = v - lse[nl];
+                const double t = v - lse[src];
                 r_l = exp(t);
                 hsum = fma(r_l, t, hsum);        // r ln r, with ln r = ln rho - lse exactly
             }
@@ -138,6 +146,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
         double rr_n = __shfl(r_l, g);
 #pragma unroll 2
         for (int st = 0; st < 16; ++st) {
+            if (LIST && c0 + 4 * st >= hi) break;      // the list ended inside this batch (wave uniform)
             const RawRow cur = nxt;
             const double rr = rr_n;
             double xq[T];
@@ -157,7 +166,10 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            nxt = load_row(c0 + 4 * (st + 1) + g);
+            if constexpr (LIST)
+                nxt = load_row((int64_t)__shfl(st == 15 ? idx_n : idx_l, (4 * (st + 1) + g) & 63));
+            else
+                nxt = load_row(c0 + 4 * (st + 1) + g);
             rr_n = __shfl(r_l, (4 * (st + 1) + g) & 63);      // st = 15: unused (next batch recomputes)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -249,175 +261,21 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
 // components.  A term with r_nk < 2^-100 max_n r_nk cannot change any of component k's f64 sums (there are fewer
 // than 2^40 terms and the sums are at least as large as their largest term), so the statistics are unchanged to the
 // last bit of rounding when such samples are skipped - and skipping them removes their row loads and MFMAs.
-// `thr` = max_n (ln rho_nk - lse_n) - 100 ln 2 (row_lse_kernel / thr_kernel).  The wave scans its rows 64 at a time,
-// ballots the active ones and feeds them to the MFMAs four at a time, packing across batches; batches with no
-// active sample cost one load, one compare and one ballot.  On dense input this loop is about 2x slower than the
-// dense kernel (measured), so gmmvb_mstep only takes it when at most 35 % of the pairs are active.
-// Centred-copy rows only (PRE form).
-__device__ __forceinline__ double readlane_f64(double v, int lane) {      // lane must be wave uniform
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, lane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
-template <int T, int WS, int SUB>
-__device__ __forceinline__ void mstep_sparse_body(const double* __restrict__ xc, const double* __restrict__ lr,
-                                                  const double* __restrict__ lse, double thr, int64_t lo, int64_t hi,
-                                                  double* __restrict__ out) {
-    constexpr int P = tri_pairs(T);
-    constexpr int NP = mstep_owned(WS, SUB, T);
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 15;
-    const int g = lane >> 4;
-
-    d4 acc[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) acc[p] = d4{0.0, 0.0, 0.0, 0.0};
-    double asum[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) asum[t] = 0.0;
-    double nsum = 0.0, hsum = 0.0;
-
-    struct RawRow { double v[T]; };
-    auto load_row = [&](int64_t row) {
-        const double* xp = xc + row * (16 * T) + T * i;
-        RawRow o;
-        typedef double v2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int t = 0; t < T; t += 2) {
-            if (t + 1 < T) {
-                const v2 v = *reinterpret_cast<const v2*>(xp + t);
-                o.v[t] = v[0];
-                o.v[t + 1] = v[1];
-            } else {
-                o.v[t] = xp[t];
-            }
-        }
-        return o;
-    };
-
-    // scan state: batch [c0, c0 + 64), its not yet consumed active lanes m (wave uniform), its r per lane
-    int64_t c0 = lo - 64;
-    unsigned long long m = 0;
-    double r_l = 0.0;
-    int64_t grow = lo;     // next group: row of this lane's sample slot g, and its responsibility
-    double grr = 0.0;
-    // Fill the four sample slots of the next group with the next four active samples, across batch boundaries
-    // (a group is only padded with r = 0 at the very end of the row range).
-    auto advance = [&]() -> bool {
-        int fill = 0;
-        while (fill < 4) {
-            if (m == 0) {
-                c0 += 64;
-                if (c0 >= hi) break;
-                const int64_t nl = c0 + lane;
-                bool act = false;
-                double t = 0.0;
-                if (nl < hi) {
-                    t = lr[nl] - lse[nl];
-                    act = !(t < thr);              // NaN stays active and propagates like in the dense kernel
-                }
-                r_l = act ? exp(t) : 0.0;
-                if (act) hsum = fma(r_l, t, hsum);  // r ln r, with ln r = ln rho - lse exactly
-                nsum += r_l;
-                m = __ballot(act);
-                continue;
-            }
-            const int pos = __builtin_ctzll(m);
-            m &= m - 1;
-            const double rv = readlane_f64(r_l, pos);
-            if (g == fill) {
-                grow = c0 + pos;
-                grr = rv;
-            }
-            ++fill;
-        }
-        if (fill == 0) return false;
-        if (g >= fill) {
-            grow = lo;
-            grr = 0.0;
-        }
-        return true;
-    };
-
-    bool have = advance();
-    RawRow nxt;
-    double rr_n = 0.0;
-    if (have) {
-        nxt = load_row(grow);
-        rr_n = grr;
-    }
-    while (have) {
-        const RawRow cur = nxt;
-        const double rr = rr_n;
-        double xq[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) xq[t] = cur.v[t];
-        double ra[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (mstep_owner(WS, t) == SUB) {
-                ra[t] = rr * xq[t];
-                asum[t] += ra[t];
-            } else {
-                ra[t] = 0.0;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        have = advance();
-        if (have) {
-            nxt = load_row(grow);
-            rr_n = grr;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t2 = 0; t2 < T; ++t2) {
-#pragma unroll
-            for (int t1 = 0; t1 <= t2; ++t1) {
-                if (mstep_owner(WS, t1) == SUB)
-                    acc[mstep_slot(WS, t2, t1)] = mfma_f64(ra[t1], xq[t2], acc[mstep_slot(WS, t2, t1)]);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t) asm volatile("" ::"v"(xq[t]));
-    }
-
-#pragma unroll
-    for (int t2 = 0; t2 < T; ++t2) {
-#pragma unroll
-        for (int t1 = 0; t1 <= t2; ++t1) {
-            if (mstep_owner(WS, t1) == SUB) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    out[(pair_index(t2, t1) * 4 + r) * 64 + lane] = acc[mstep_slot(WS, t2, t1)][r];
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (mstep_owner(WS, t) == SUB) {
-            const double v = sum_groups(asum[t]);
-            if (g == 0) out[P * 256 + T * i + t] = v;
-        }
-    }
-    if (SUB == 0) {
-        nsum = sum_wave(nsum);
-        hsum = sum_wave(hsum);
-        if (lane == 0) {
-            out[P * 256 + 16 * T + 0] = nsum;
-            out[P * 256 + 16 * T + 1] = hsum;
-        }
-    }
-}
-
+// thr[k] = max_n (ln rho_nk - lse_n) - 100 ln 2 (row_lse_kernel / thr_kernel); select_mask_kernel<2>, scan_counts
+// and fill_lists (aux_kernels.h) write, per component, the ascending list of its active rows; mstep_list_f64 is
+// mstep_body over list positions instead of rows (LIST form: one index load per 64 entries, the row addresses go
+// through it), with the same slabs and the same fixed summation order.  A row split is a whole number of selection
+// blocks, so its piece of list k is [blk[b0][k], blk[b1][k]).
 template <int T>
-__global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_sparse_f64(
+__global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
     const double* __restrict__ xc,         // [npad + 64][16 T] centred rows
     const double* __restrict__ lnrho,      // [K][npad]
     const double* __restrict__ lse,        // [npad]
-    const double* __restrict__ thr,        // [K]
-    int64_t n_rows, int64_t npad, int K, int KG, int S, int64_t rows_per_split,
+    const int* __restrict__ lists,         // [K][cap] active rows, ascending
+    int64_t cap,
+    const int* __restrict__ blk,           // [nblk][K] list position of every selection block's first entry
+    const int* __restrict__ counts,        // [K] list lengths
+    int nblk, int blocks_per_split, int64_t npad, int K, int KG, int S,
     double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
     constexpr int WS = mstep_ws(T);
     constexpr int KPW = mstep_waves(T, true) / WS;
@@ -431,17 +289,19 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_sparse_f64(
     const int k = kg * KPW + wave / WS;
     if (k >= K) return;
     const int sub = wave % WS;
-    const int64_t lo = (int64_t)split * rows_per_split;
-    int64_t hi = lo + rows_per_split;
-    if (hi > n_rows) hi = n_rows;
+    const int b0 = split * blocks_per_split, b1 = b0 + blocks_per_split;
+    const int64_t lo = blk[(int64_t)b0 * K + k];
+    const int64_t hi = b1 < nblk ? blk[(int64_t)b1 * K + k] : counts[k];
     const double* lr = lnrho + (int64_t)k * npad;
+    const int* list = lists + (int64_t)k * cap;
     double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
-    const double th = thr[k];
     if constexpr (WS == 1) {
-        mstep_sparse_body<T, 1, 0>(xc, lr, lse, th, lo, hi, out);
+        mstep_body<T, 1, 0, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, 0, out, list);
     } else {
-        if (sub == 0) mstep_sparse_body<T, 2, 0>(xc, lr, lse, th, lo, hi, out);
-        else mstep_sparse_body<T, 2, 1>(xc, lr, lse, th, lo, hi, out);
+        if (sub == 0)
+            mstep_body<T, 2, 0, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, 0, out, list);
+        else
+            mstep_body<T, 2, 1, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, 0, out, list);
     }
 }
 

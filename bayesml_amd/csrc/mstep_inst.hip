@@ -43,21 +43,20 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
 }
 
 template <int T>
-static hipError_t go_sparse(int grid, hipStream_t st, const MstepArgs& a) {
-    hipLaunchKernelGGL((mstep_sparse_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st,
-                       static_cast<const double*>(a.x), a.lnrho, a.lse, a.aux, a.n_rows, a.npad, a.K, a.KG, a.S,
-                       a.rows_per_split, a.slabs);
+static hipError_t go_list(int grid, hipStream_t st, const MstepListArgs& a) {
+    hipLaunchKernelGGL((mstep_list_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.xc, a.lnrho, a.lse,
+                       a.lists, a.cap, a.blk, a.counts, a.nblk, a.blocks_per_split, a.npad, a.K, a.KG, a.S, a.slabs);
     return hipGetLastError();
 }
 
-#define SCASE(TT)                                          \
-    case TT:                                               \
-        *name = "mstep_sparse_f64<T=" #TT ",centred-f64>"; \
-        return go_sparse<TT>(grid, st, a);
+#define LCASE(TT)                                        \
+    case TT:                                             \
+        *name = "mstep_list_f64<T=" #TT ",centred-f64>"; \
+        return go_list<TT>(grid, st, a);
 
-hipError_t launch_mstep_sparse(int T, int grid, hipStream_t st, const MstepArgs& a, const char** name) {
+hipError_t launch_mstep_list(int T, int grid, hipStream_t st, const MstepListArgs& a, const char** name) {
     switch (T) {
-        SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8)
+        LCASE(1) LCASE(2) LCASE(3) LCASE(4) LCASE(5) LCASE(6) LCASE(7) LCASE(8)
     }
     return hipErrorInvalidValue;
 }

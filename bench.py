@@ -168,13 +168,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ker, launches = [], []
+    ker, launches, spars = [], [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         vl = step()
         ker.append(eng.last_kernel_ms())        # events already complete: step() ended with a host sync
         launches.append(eng.launch_info)
+        spars.append(eng.sparsity())
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -229,7 +230,9 @@ def main():
                                  "execute ~0.56x of them (triangular whitening factor, symmetric second moment)"},
             "cpu_baseline": cpu_base, "parity": parity, "final_vl": vl, "launch": eng.launch_info,
             "per_step": {"estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
-                         "estep_kernel": [l.split("<")[0] for l in launches]},
+                         "estep_kernel": [l.split("<")[0] for l in launches],
+                         "active_components_per_sample": [round(a / n_local, 2) for a, _ in spars],
+                         "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars]},
         }
         print(json.dumps(out))
     if world > 1:

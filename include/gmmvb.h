@@ -140,6 +140,11 @@ int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms)
  * static string such as "estep_mfma_f64<8,2,f32,vec> grid=1024x256". */
 const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
 
+/* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
+ * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
+ * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  Synchronises the stream. */
+int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs);
+
 #ifdef __cplusplus
 }
 #endif

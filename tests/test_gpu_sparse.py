@@ -106,7 +106,7 @@ def test_data_pass_statistics_and_nan_rows():
     pivot = xd[:4096].to(torch.float64).mean(dim=0)
     dense = _pass(xd, qd, DENSE, pivot)
     sparse = _pass(xd, qd, SPARSE, pivot)
-    assert "mstep_sparse_f64" in sparse[1][2] and "estep_bound_f64" in sparse[1][2]
+    assert "mstep_list_f64" in sparse[1][2] and "estep_bound_f64" in sparse[1][2]
     assert "mstep_mfma_f64" in dense[1][2]
     for (sa, ra, _), (sb, rb, _) in zip(dense, sparse):
         assert rel_err(sb, sa) < 1e-12
