@@ -88,15 +88,9 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v && std::strcmp(v, "lds4") == 0) ws->estep_variant = kEstepLds;
         if (v && std::strcmp(v, "i8") == 0) ws->estep_variant = kEstepI8;
     }
-    if (ws->estep_variant == kEstepI8) {
-        ws->img_i8_len = estep_i8_image_bytes(D);
-        e = hipMalloc((void**)&ws->img_i8, (size_t)K * ws->img_i8_len);
-        if (e == hipSuccess) e = hipMalloc((void**)&ws->pivot_i8, (size_t)D * sizeof(double));
-        if (e != hipSuccess) {
-            gmmvb_workspace_destroy(ws);
-            return fail(GMMVB_ENOMEM, "hipMalloc (int8 images)", e);
-        }
-        ws->bytes += (int64_t)K * ws->img_i8_len + D * (int64_t)sizeof(double);
+    {
+        const char* v = std::getenv("GMMVB_ESTEP_BOUND");
+        ws->bound_i8 = !(v && std::strcmp(v, "f64") == 0);
     }
     struct { double** p; int64_t n; } bufs[] = {
         {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},
@@ -116,6 +110,28 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         v = std::getenv("GMMVB_ESTEP_PRUNE");
         ws->prune = (v && std::strcmp(v, "0") == 0) ? 0 : ((v && std::strcmp(v, "force") == 0) ? 2 : 1);
         if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;
+    }
+    {
+        const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0 && ws->bound_i8;
+        hipError_t e8 = hipSuccess;
+        if (full) {
+            ws->img_i8_len = estep_i8_image_bytes(D, 0);
+            e8 = hipMalloc((void**)&ws->img_i8, (size_t)K * ws->img_i8_len);
+            ws->bytes += (int64_t)K * ws->img_i8_len;
+        }
+        if (bound && e8 == hipSuccess) {
+            ws->img_i8b_len = estep_i8_image_bytes(D, 1);
+            e8 = hipMalloc((void**)&ws->img_i8b, (size_t)K * ws->img_i8b_len);
+            ws->bytes += (int64_t)K * ws->img_i8b_len;
+        }
+        if ((full || bound) && e8 == hipSuccess) {
+            e8 = hipMalloc((void**)&ws->pivot_i8, (size_t)D * sizeof(double));
+            ws->bytes += D * (int64_t)sizeof(double);
+        }
+        if (e8 != hipSuccess) {
+            gmmvb_workspace_destroy(ws);
+            return fail(GMMVB_ENOMEM, "hipMalloc (int8 images)", e8);
+        }
     }
     for (auto& b : bufs) {
         if (b.n == 0) continue;
@@ -146,6 +162,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (ws->img_i8) (void)hipFree(ws->img_i8);
+    if (ws->img_i8b) (void)hipFree(ws->img_i8b);
     if (ws->pivot_i8) (void)hipFree(ws->pivot_i8);
     for (hipEvent_t e : ws->ev)
         if (e) (void)hipEventDestroy(e);
@@ -205,10 +222,11 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
                        ws->img_len, ws->img);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_kernel", e);
-    if (ws->estep_variant == kEstepI8) {
-        // the digits are taken about the pivot in force now; the E-step reads this copy, not ws->pivot
+    if (ws->pivot_i8) {
+        // the digits are taken about the pivot in force now; the int8 kernels read this copy, not ws->pivot
         e = hipMemcpyAsync(ws->pivot_i8, ws->pivot, (size_t)ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
-        if (e == hipSuccess) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8, st);
+        if (e == hipSuccess && ws->img_i8) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8, 0, st);
+        if (e == hipSuccess && ws->img_i8b) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8b, 1, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_i8_kernel", e);
     }
     ws->have_params = true;
@@ -318,10 +336,16 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
     ws->evaluated = prune ? 0.0 : (double)n_rows * ws->K;
     if (prune) {
-        rpw = estep_bound_rows_per_wg(ws->T, is64);
+        rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
         grid = (n_rows + rpw - 1) / rpw;
         if (grid > (1 << 20)) grid = 1 << 20;
-        e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
+        if (ws->img_i8b) {
+            EstepI8Args ab = a8;
+            ab.img = ws->img_i8b;
+            e = launch_estep_i8_bound(is64, vec, (int)grid, st, ab, &name);
+        } else {
+            e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
+        }
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
         int counts_host[256];
         const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);

@@ -24,26 +24,42 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace gmmvb {
 
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i16v __attribute__((ext_vector_type(16)));
 
-constexpr int kDigits = 6;
+constexpr int kDigits = 6;        // the E-step proper: 42-bit operands
+constexpr int kBoundDigits = 3;   // the pruned E-step's bound pass: 21-bit operands and a rigorous error term
+// Image tails.  ND = 6: [jt][h][g][2] doubles (2^ej, b_j).  ND = 3 (bound pass): one exponent per 32-row output block
+// (rows are digitised against the block's largest entry - coarser for small rows, and the error term says so), then
+//   [jt][h][g][2] floats (b_j, beta_j)   and   [jt] floats 2^e_jt
+// so that a lane reads 8 bytes per output row instead of 16 and no per-row scale.
 
 __host__ __device__ constexpr int i8_blocks(int D) { return (D + 31) / 32; }
-__host__ __device__ constexpr int i8_img_bytes(int t32) {
-    return (tri_pairs(t32) * kDigits * 1024 + t32 * 512 + 1023) / 1024 * 1024;
+__host__ __device__ constexpr int i8_img_bytes(int nd, int t32) {
+    return (tri_pairs(t32) * nd * 1024 + (nd == kBoundDigits ? t32 * 256 + 16 : t32 * 512) + 1023) / 1024 * 1024;
 }
-__host__ __device__ constexpr int i8_kb(int t32) {
-    const int kb = (64 * 1024) / i8_img_bytes(t32);
+__host__ __device__ constexpr int i8_kb(int nd, int t32) {
+    const int kb = (64 * 1024) / i8_img_bytes(nd, t32);
     return kb < 1 ? 1 : (kb > 8 ? 8 : kb);
 }
+// With ND digits per operand and the digit pairs a + b <= ND - 1 kept, every term U~ x~ (both in (-1, 1)) is off by
+// at most 2^(-7 ND) (|x~| + |U~| + 1.02 (ND - 1)): two operand truncations and the dropped pairs.  Over the at most
+// 32 T32 terms of a row, times 2^(ej + en): |y_j - y^_j| <= 2^ej 2^en i8_err(ND, T32).
+__host__ __device__ constexpr double i8_err(int nd, int t32) {
+    double w = 1.0;
+    for (int i = 0; i < 7 * nd; ++i) w *= 0.5;
+    return w * (2.0 + 1.02 * (nd - 1)) * 32.0 * t32 * 1.000001;
+}
 
-// kDigits balanced base-128 digits of t (|t| <= 64): t = d0 + d1/128 + d2/128^2 + ...; returns them as bytes
-__device__ __forceinline__ void digits_of(double t, int (&d)[kDigits]) {
+// ND balanced base-128 digits of t (|t| <= 64): t = d0 + d1/128 + d2/128^2 + ...; returns them as bytes
+template <int ND>
+__device__ __forceinline__ void digits_of(double t, int (&d)[ND]) {
 #pragma unroll
-    for (int a = 0; a < kDigits; ++a) {
+    for (int a = 0; a < ND; ++a) {
         const double r = __builtin_rint(t);
         d[a] = (int)r;
         t = (t - r) * 128.0;
@@ -51,6 +67,7 @@ __device__ __forceinline__ void digits_of(double t, int (&d)[kDigits]) {
 }
 
 // K-side: digits of u, row exponents, bias.  One block per component.
+template <int ND>
 __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double* __restrict__ m,
                                       const double* __restrict__ pivot, int K, int D, int T32, int img_bytes,
                                       unsigned char* __restrict__ img) {
@@ -60,9 +77,11 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
     const double* uk = u + (int64_t)k * D * D;
     const double* mk = m + (int64_t)k * D;
     unsigned char* im = img + (int64_t)k * img_bytes;
-    double* consts = reinterpret_cast<double*>(im + P * kDigits * 1024);
+    double* consts = reinterpret_cast<double*>(im + P * ND * 1024);
+    __shared__ double row_max[128];
+    __shared__ int row_bad[128];
     for (int j = threadIdx.x; j < 32 * T32; j += blockDim.x) {
-        double mx = 0.0, bias = 0.0;
+        double mx = 0.0, bias = 0.0, abias = 0.0;
         bool bad = false;
         if (j < D) {
             for (int i = 0; i <= j; ++i) {
@@ -70,16 +89,53 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
                 bad |= !(fabs(v) <= 1.7976931348623157e308);
                 mx = fmax(mx, fabs(v));
                 bias = fma(v, mk[i] - pivot[i], bias);
+                abias = fma(fabs(v), fabs(mk[i] - pivot[i]), abias);
             }
         }
         int e = 0;
         if (mx > 0.0) (void)frexp(mx, &e);          // mx = f 2^e, f in [0.5, 1)
-        row_scale[j] = (mx > 0.0 && !bad) ? ldexp(1.0, 6 - e) : 0.0;
         const int jt = j >> 5, w = j & 31;
         const int h = (w >> 2) & 1, g = (w & 3) + 4 * (w >> 3);      // w = (g & 3) + 8 (g >> 2) + 4 h
-        double* cp = consts + ((jt * 2 + h) * 16 + g) * 2;
-        cp[0] = bad ? __builtin_nan("") : (mx > 0.0 ? ldexp(1.0, e) : 0.0);
-        cp[1] = bias;
+        if constexpr (ND == kBoundDigits) {
+            // (b_j, beta_j) in f32; beta_j >= 2^-20 |b_j| + the f64 rounding of b_j covers every f32 rounding of the
+            // epilogue that scales with the bias (i8_rows_bound); +inf = "no bound" (non-finite row or bias)
+            float* cp = reinterpret_cast<float*>(consts) + ((jt * 2 + h) * 16 + g) * 2;
+            const bool wide = bad || !(fabs(bias) < 1e30) || !(abias < 1e30);
+            cp[0] = wide ? 0.0f : (float)bias;
+            cp[1] = wide ? __builtin_huge_valf()
+                         : (float)((fabs(bias) * 9.5367431640625e-7 + abias * 2.9e-14) * 1.0001) + 1e-37f;
+            row_max[j] = mx;
+            row_bad[j] = bad;
+        } else {
+            row_scale[j] = (mx > 0.0 && !bad) ? ldexp(1.0, 6 - e) : 0.0;
+            double* cp = consts + ((jt * 2 + h) * 16 + g) * 2;
+            cp[0] = bad ? __builtin_nan("") : (mx > 0.0 ? ldexp(1.0, e) : 0.0);
+            cp[1] = bias;
+        }
+    }
+    if constexpr (ND == kBoundDigits) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < 32 * T32; j += blockDim.x) {
+            const int jt = j >> 5;
+            double mx = 0.0;
+            bool bad = false;
+            for (int r = 0; r < 32; ++r) {
+                mx = fmax(mx, row_max[32 * jt + r]);
+                bad |= row_bad[32 * jt + r] != 0;
+            }
+            int e = 0;
+            if (mx > 0.0) (void)frexp(mx, &e);
+            // f32 products of powers of two stay exact for |e| <= 45; outside (or with a non-finite row) the block
+            // gives no bound: scale 0 (all digits 0) and every beta of the block +inf
+            const bool wide = bad || e < -45 || e > 45;
+            row_scale[j] = (mx > 0.0 && !wide) ? ldexp(1.0, 6 - e) : 0.0;
+            float* tail = reinterpret_cast<float*>(consts) + T32 * 64;
+            if ((j & 31) == 0) tail[jt] = (mx > 0.0 && !wide) ? (float)ldexp(1.0, e) : 0.0f;
+            if (wide) {
+                const int w = j & 31, h = (w >> 2) & 1, g = (w & 3) + 4 * (w >> 3);
+                reinterpret_cast<float*>(consts)[((jt * 2 + h) * 16 + g) * 2 + 1] = __builtin_huge_valf();
+            }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < P * 1024; e += blockDim.x) {
@@ -89,20 +145,23 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
         const int it = p - tri_pairs(jt);
         const int jj = 32 * jt + (lane & 31), ii = 32 * it + 16 * (lane >> 5) + b;
         const double v = (jj < D && ii <= jj) ? uk[(int64_t)jj * D + ii] * row_scale[jj] : 0.0;
-        int d[kDigits];
-        digits_of(v, d);
+        int d[ND];
+        digits_of<ND>(v, d);
 #pragma unroll
-        for (int a = 0; a < kDigits; ++a) im[((p * kDigits + a) * 64 + lane) * 16 + b] = (unsigned char)(d[a] & 0xff);
+        for (int a = 0; a < ND; ++a) im[((p * ND + a) * 64 + lane) * 16 + b] = (unsigned char)(d[a] & 0xff);
     }
-    for (int e = P * kDigits * 1024 + T32 * 512 + threadIdx.x; e < img_bytes; e += blockDim.x) im[e] = 0;
+    for (int e = P * ND * 1024 + (ND == kBoundDigits ? T32 * 256 + 4 * T32 : T32 * 512) + threadIdx.x; e < img_bytes;
+         e += blockDim.x)
+        im[e] = 0;
 }
 
-// Sample digits for one wave tile.  xd[a][it] = 16 bytes = digit a of features 32 it + 16 h + (0..15); c2 = 2^(en - 47)
-// (NaN when the sample holds a non-finite value, so that its ln rho comes out NaN like the f64 path's).
-template <int T32, typename XT, bool VEC>
+// Sample digits for one wave tile.  xd[a][it] = 16 bytes = digit a of features 32 it + 16 h + (0..15);
+// c2 = 2^(en - 12 - 7 (ND - 1)), the weight of the last kept digit pair class (NaN when the sample holds a non-finite
+// value, so that its ln rho comes out NaN like the f64 path's); sn = 2^en.
+template <int ND, int T32, typename XT, bool VEC>
 __device__ __forceinline__ void load_x_digits(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                               const double* __restrict__ pivot, int64_t n0, int c, int h,
-                                              i4v (&xd)[kDigits][T32], double& c2) {
+                                              i4v (&xd)[ND][T32], double& c2, double& sn) {
     int64_t row = n0 + c;
     if (row >= n_rows) row = n_rows - 1;          // clamp: padded samples are never stored
     const XT* xp = x + row * ldx + 16 * h;
@@ -146,25 +205,26 @@ __device__ __forceinline__ void load_x_digits(const XT* __restrict__ x, int64_t 
     int en = 0;
     if (mx > 0.0) (void)frexp(mx, &en);
     const double scale = bad ? 0.0 : ldexp(1.0, 6 - en);
-    c2 = bad ? __builtin_nan("") : ldexp(1.0, en - 47);
+    c2 = bad ? __builtin_nan("") : ldexp(1.0, en - 12 - 7 * (ND - 1));
+    sn = ldexp(1.0, en);
 #pragma unroll
     for (int it = 0; it < T32; ++it) {
         double v[16];
         load_block(it, v);
-        unsigned w[kDigits][4];
+        unsigned w[ND][4];
 #pragma unroll
-        for (int a = 0; a < kDigits; ++a)
+        for (int a = 0; a < ND; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[a][q] = 0u;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            int d[kDigits];
-            digits_of(bad ? 0.0 : v[e] * scale, d);
+            int d[ND];
+            digits_of<ND>(bad ? 0.0 : v[e] * scale, d);
 #pragma unroll
-            for (int a = 0; a < kDigits; ++a) w[a][e >> 2] |= (unsigned)(d[a] & 0xff) << (8 * (e & 3));
+            for (int a = 0; a < ND; ++a) w[a][e >> 2] |= (unsigned)(d[a] & 0xff) << (8 * (e & 3));
         }
 #pragma unroll
-        for (int a = 0; a < kDigits; ++a) xd[a][it] = i4v{(int)w[a][0], (int)w[a][1], (int)w[a][2], (int)w[a][3]};
+        for (int a = 0; a < ND; ++a) xd[a][it] = i4v{(int)w[a][0], (int)w[a][1], (int)w[a][2], (int)w[a][3]};
     }
 }
 
@@ -191,24 +251,24 @@ union pair_bits {
 };
 
 // MFMAs of step (JT, IT, A) with U digit fragment `ua`
-template <int T32, int IT, int A>
-__device__ __forceinline__ void i8_step_mfma(const i4v& ua, const i4v (&xd)[kDigits][T32], i16v (&acc)[kDigits]) {
+template <int ND, int T32, int IT, int A>
+__device__ __forceinline__ void i8_step_mfma(const i4v& ua, const i4v (&xd)[ND][T32], i16v (&acc)[ND]) {
 #pragma unroll
-    for (int b = 0; b + A < kDigits; ++b)
+    for (int b = 0; b + A < ND; ++b)
         acc[A + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ua, xd[b][IT], acc[A + b], 0, 0, 0);
 }
 
 // Execution order of the steps.  Output blocks run in ascending order (REV = false) or descending order (REV = true):
 // the two waves that share a SIMD take opposite orders, so that one's epilogues (vector ALU) fall into the other's
 // long MFMA runs instead of both leaving the matrix pipe idle at the same time.  Step e (execution index) of a
-// component -> its output block, and its position in the image (layout step = 6 pair + digit).
-template <int T32, bool REV>
+// component -> its output block, and its position in the image (layout step = ND pair + digit).
+template <int ND, int T32, bool REV>
 struct i8_order {
     static constexpr int block_of(int e) {
         int o = 0, base = 0;
         while (true) {
             const int jt = REV ? T32 - 1 - o : o;
-            const int n = (jt + 1) * kDigits;
+            const int n = (jt + 1) * ND;
             if (e < base + n) return jt;
             base += n;
             ++o;
@@ -219,41 +279,51 @@ struct i8_order {
         for (int o = 0; o < T32; ++o) {
             const int b = REV ? T32 - 1 - o : o;
             if (b == jt) return base;
-            base += (b + 1) * kDigits;
+            base += (b + 1) * ND;
         }
         return base;
     }
     static constexpr int layout_of(int e) {
         const int jt = block_of(e);
-        return tri_pairs(jt) * kDigits + (e - first_of(jt));
+        return tri_pairs(jt) * ND + (e - first_of(jt));
     }
 };
 
 // Steps E .. end of its output block (recursion over the compile-time execution index: offsets and wait counts are
 // immediates).  ua[e % 3] holds step e; step e + 2 is requested before step e runs.
-template <int T32, bool REV, int E>
-__device__ __forceinline__ void i8_steps(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3],
-                                         const i4v (&xd)[kDigits][T32], i16v (&acc)[kDigits], i4v (&sb)[2][2]) {
-    using ord = i8_order<T32, REV>;
-    constexpr int NS = tri_pairs(T32) * kDigits;
+template <int ND, int T32, bool REV, int E>
+__device__ __forceinline__ void i8_steps(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3], const i4v (&xd)[ND][T32],
+                                         i16v (&acc)[ND], i4v (&sb)[2][2]) {
+    constexpr int CSTRIDE = ND == kBoundDigits ? 256 : 512;       // bytes of row constants per output block
+    using ord = i8_order<ND, T32, REV>;
+    constexpr int NS = tri_pairs(T32) * ND;
     constexpr int JT = ord::block_of(E), S = ord::layout_of(E);
-    constexpr int IT = S / kDigits - tri_pairs(JT), A = S % kDigits;
-    constexpr bool last = (IT == JT && A == kDigits - 1);
+    constexpr int IT = S / ND - tri_pairs(JT), A = S % ND;
+    constexpr bool last = (IT == JT && A == ND - 1);
     if constexpr (E + 2 < NS) lds_read16<1024 * ord::layout_of(E + 2 < NS ? E + 2 : 0)>(ua[(E + 2) % 3], frag_addr);
     if constexpr (last) {
-        lds_read16<JT * 512 + 0>(sb[0][0], const_addr);
-        lds_read16<JT * 512 + 16>(sb[0][1], const_addr);
+        lds_read16<JT * CSTRIDE + 0>(sb[0][0], const_addr);
+        lds_read16<JT * CSTRIDE + 16>(sb[0][1], const_addr);
     }
     lds_wait<(E + 1 < NS) + (E + 2 < NS) + (last ? 2 : 0)>(ua[E % 3]);
-    i8_step_mfma<T32, IT, A>(ua[E % 3], xd, acc);
+    i8_step_mfma<ND, T32, IT, A>(ua[E % 3], xd, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!last) i8_steps<T32, REV, E + 1>(frag_addr, const_addr, ua, xd, acc, sb);
+    if constexpr (!last) i8_steps<ND, T32, REV, E + 1>(frag_addr, const_addr, ua, xd, acc, sb);
 }
 
-// Epilogue of output block JT, rows 2 GP and 2 GP + 1 of this lane: integer digit sums -> y -> q
-template <int JT, int GP>
-__device__ __forceinline__ void i8_rows(unsigned const_addr, const i16v (&acc)[kDigits], i4v (&sb)[2][2], double c0,
-                                        double c1, double c2, double& q) {
+// per-lane constants of the epilogue: digit-class weights (c[0] for the heaviest pair of classes) and, for the bound
+// pass, ce = 2^en i8_err
+struct i8_lane_consts {
+    double c[3];
+    float c2f;      // bound pass: 2^(en - 26)
+    float cef;      // bound pass: 2^en i8_err (rounded up), +inf = no bound for this sample
+};
+
+// Epilogue of output block JT, rows 2 GP and 2 GP + 1 of this lane: integer digit sums -> y -> q (f64, ND = 6).
+template <int ND, int JT, int GP>
+__device__ __forceinline__ void i8_rows(unsigned const_addr, const i16v (&acc)[ND], i4v (&sb)[2][2],
+                                        const i8_lane_consts& lc, double& q) {
+    static_assert(ND == 6, "the f64 epilogue combines six digit classes");
     if constexpr (GP + 1 < 8) {
         lds_read16<JT * 512 + 32 * (GP + 1)>(sb[(GP + 1) & 1][0], const_addr);
         lds_read16<JT * 512 + 32 * (GP + 1) + 16>(sb[(GP + 1) & 1][1], const_addr);
@@ -265,59 +335,110 @@ __device__ __forceinline__ void i8_rows(unsigned const_addr, const i16v (&acc)[k
         const int t0 = (acc[0][g] << 7) + acc[1][g];
         const int t1 = (acc[2][g] << 7) + acc[3][g];
         const int t2 = (acc[4][g] << 7) + acc[5][g];
-        const double z = fma((double)t0, c0, fma((double)t1, c1, (double)t2 * c2));
+        const double z = fma((double)t0, lc.c[0], fma((double)t1, lc.c[1], (double)t2 * lc.c[2]));
         pair_bits u;
         u.v = sb[GP & 1][e];
         const double y = fma(z, u.d[0], -u.d[1]);
         q = fma(y, y, q);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (GP + 1 < 8) i8_rows<JT, GP + 1>(const_addr, acc, sb, c0, c1, c2, q);
+    if constexpr (GP + 1 < 8) i8_rows<ND, JT, GP + 1>(const_addr, acc, sb, lc, q);
 }
 
-template <int T32, bool REV, int O>
-__device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3],
-                                               const i4v (&xd)[kDigits][T32], double c0, double c1, double c2,
-                                               double& q) {
-    constexpr int JT = REV ? T32 - 1 - O : O;
-    i16v acc[kDigits];
+// Bound-pass epilogue (ND = 3) in plain f32 (measured with tools/overlap_probe.hip: next to int8 MFMAs, f32, f64 and
+// integer vector instructions overlap with the matrix pipe, packed-f32 ones do not).  With I = 128 t0 + acc2 (the exact
+// integer digit sum), m = 2^(en - 26) 2^e_jt and the row constants (b, beta) of the image:
+//   y = I m - b,   a = max(|y| (1 - 2^-20) - beta - 2^e_jt cef, 0)  <=  |y_exact|,
+// because  |y_exact - y| <= 2^e_jt 2^en i8_err  (digits)  + 2^-22 (|y| + |b|)  (f32: I to 24 bits, b to 24 bits, one
+// fma)  + the f64 rounding of b, and beta >= 2^-20 |b| + that rounding.  q accumulates a^2 in f32 (the caller takes off
+// 2^-16 of it).  A NaN y or an infinite cef / beta gives a = 0: the bound degrades to c_k, never lies.
+// Step GP covers this lane's rows 4 GP .. 4 GP + 3 of block JT: two 16-byte reads of (b, beta) pairs.
+template <int JT, int GP>
+__device__ __forceinline__ void i8_rows_bound(unsigned const_addr, const i16v (&acc)[kBoundDigits], i4v (&sb)[2][2],
+                                              float m, float ebc, float& q) {
+    if constexpr (GP + 1 < 4) {
+        lds_read16<JT * 256 + 32 * (GP + 1)>(sb[(GP + 1) & 1][0], const_addr);
+        lds_read16<JT * 256 + 32 * (GP + 1) + 16>(sb[(GP + 1) & 1][1], const_addr);
+    }
+    lds_wait<(GP + 1 < 4) ? 2 : 0>(sb[GP & 1][0], sb[GP & 1][1]);
+    union { i4v v; float f[4]; } r[2];
+    r[0].v = sb[GP & 1][0];
+    r[1].v = sb[GP & 1][1];
 #pragma unroll
-    for (int w = 0; w < kDigits; ++w) acc[w] = i16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = 0; e < 4; ++e) {
+        const int g = 4 * GP + e;
+        const float b = r[e >> 1].f[2 * (e & 1)], beta = r[e >> 1].f[2 * (e & 1) + 1];
+        const float tf = (float)((acc[0][g] << 7) + acc[1][g]);
+        const float I = __builtin_fmaf(tf, 128.0f, (float)acc[2][g]);
+        const float y = __builtin_fmaf(I, m, -b);
+        const float d = __builtin_fmaf(__builtin_fabsf(y), 0.99999904632568359375f, -beta) - ebc;
+        const float a = __builtin_fmaxf(d, 0.0f);
+        q = __builtin_fmaf(a, a, q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (GP + 1 < 4) i8_rows_bound<JT, GP + 1>(const_addr, acc, sb, m, ebc, q);
+}
+
+template <int ND, bool BOUND, int T32, bool REV, int O, typename QT>
+__device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3],
+                                               const i4v (&xd)[ND][T32], const i8_lane_consts& lc, const i4v& scales,
+                                               QT& q) {
+    constexpr int JT = REV ? T32 - 1 - O : O;
+    i16v acc[ND];
+#pragma unroll
+    for (int w = 0; w < ND; ++w) acc[w] = i16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     i4v sb[2][2];
-    i8_steps<T32, REV, i8_order<T32, REV>::first_of(JT)>(frag_addr, const_addr, ua, xd, acc, sb);
-    i8_rows<JT, 0>(const_addr, acc, sb, c0, c1, c2, q);
-    if constexpr (O + 1 < T32) i8_blocks_from<T32, REV, O + 1>(frag_addr, const_addr, ua, xd, c0, c1, c2, q);
+    i8_steps<ND, T32, REV, i8_order<ND, T32, REV>::first_of(JT)>(frag_addr, const_addr, ua, xd, acc, sb);
+    if constexpr (BOUND) {
+        union { i4v v; float f[4]; } sc;
+        sc.v = scales;                                   // 2^e_jt of the component's output blocks
+        i8_rows_bound<JT, 0>(const_addr, acc, sb, sc.f[JT] * lc.c2f, sc.f[JT] * lc.cef, q);
+    } else {
+        i8_rows<ND, JT, 0>(const_addr, acc, sb, lc, q);
+    }
+    if constexpr (O + 1 < T32) i8_blocks_from<ND, BOUND, T32, REV, O + 1>(frag_addr, const_addr, ua, xd, lc, scales, q);
 }
 
 // One component for one wave tile; `im_lds` is the LDS byte address of the component's image.
-// The U digits are requested two steps (one step = one digit a of one block pair = 6 - a MFMAs) ahead of their
+// The U digits are requested two steps (one step = one digit a of one block pair = ND - a MFMAs) ahead of their
 // use and the epilogue's row constants one pair of rows ahead, so that with only two waves per SIMD the LDS
 // latency sits behind MFMAs instead of in front of them.
-template <int T32, bool REV>
-__device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&xd)[kDigits][T32], double ck, double c0,
-                                                   double c1, double c2, int lane, int c, int h, int64_t n0,
+template <int ND, bool BOUND, int T32, bool REV>
+__device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&xd)[ND][T32], double ck,
+                                                   const i8_lane_consts& lc, int lane, int c, int h, int64_t n0,
                                                    int64_t n_rows, double* __restrict__ lnrho_k) {
-    using ord = i8_order<T32, REV>;
+    using ord = i8_order<ND, T32, REV>;
     constexpr int P = tri_pairs(T32);
     const unsigned frag_addr = im_lds + lane * 16;                              // layout step s at + 1024 s
-    const unsigned const_addr = im_lds + P * kDigits * 1024 + h * 256;          // (jt, g) at + 512 jt + 16 g
-    double q = 0.0;
+    // row constants: ND = 6 (jt, g) at + 512 jt + 256 h + 16 g; bound pass (jt, g) at + 256 jt + 128 h + 8 g
+    const unsigned const_addr = im_lds + P * ND * 1024 + h * (BOUND ? 128 : 256);
+    typename std::conditional<BOUND, float, double>::type q = 0;
+    i4v scales = {0, 0, 0, 0};
+    if constexpr (BOUND) {
+        lds_read16<0>(scales, im_lds + P * ND * 1024 + T32 * 256);
+        lds_wait<0>(scales);
+    }
     i4v ua[3];
     lds_read16<1024 * ord::layout_of(0)>(ua[0], frag_addr);
     lds_read16<1024 * ord::layout_of(1)>(ua[1], frag_addr);
-    i8_blocks_from<T32, REV, 0>(frag_addr, const_addr, ua, xd, c0, c1, c2, q);
+    i8_blocks_from<ND, BOUND, T32, REV, 0>(frag_addr, const_addr, ua, xd, lc, scales, q);
     q += __shfl_xor(q, 32);
     const int64_t row = n0 + c;
-    if (h == 0 && row < n_rows) lnrho_k[row] = ck - 0.5 * q;
+    // BOUND: an upper bound of ln rho; 2^-16 of q covers the f32 rounding of its 128 squares and additions
+    const double v = BOUND ? fma(-0.5 * (double)q, 1.0 - 1.52587890625e-05, ck + 1e-12 * fabs(ck)) : ck - 0.5 * (double)q;
+    if (h == 0 && row < n_rows) lnrho_k[row] = v;
 }
 
-template <int T32, typename XT, bool VEC, int NW>
+// ND = 6: the E-step.  ND = 3, BOUND: upper bounds of ln rho for the pruned E-step (estep.h) from three digits per
+// operand - every row and feature takes part, unlike the f64 bound pass's leading blocks, at 6 instead of 21 MFMAs
+// per block pair; the error term keeps the bound rigorous whatever the conditioning.
+template <int ND, bool BOUND, int T32, typename XT, bool VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                                     const unsigned char* __restrict__ img /*[K][IMGB]*/,
                                                     const double* __restrict__ pivot, const double* __restrict__ cvec,
                                                     int K, double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
-    constexpr int IMGB = i8_img_bytes(T32);
-    constexpr int KB = i8_kb(T32);
+    constexpr int IMGB = i8_img_bytes(ND, T32);
+    constexpr int KB = i8_kb(ND, T32);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][KB * IMGB];   // the ONLY LDS object of the kernel
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -340,10 +461,22 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
     for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
         const int64_t n0 = wt * rows_per_wg + (int64_t)wave * 32;
         stage(0, 0);
-        i4v xd[kDigits][T32];
-        double c2;
-        load_x_digits<T32, XT, VEC>(x, ldx, n_rows, D, pivot, n0, c, h, xd, c2);
-        const double c1 = c2 * 16384.0, c0 = c2 * 268435456.0;
+        i4v xd[ND][T32];
+        double c2, sn;
+        load_x_digits<ND, T32, XT, VEC>(x, ldx, n_rows, D, pivot, n0, c, h, xd, c2, sn);
+        i8_lane_consts lc;
+        lc.c[2] = c2;
+        lc.c[1] = c2 * (ND == 6 ? 16384.0 : 128.0);      // weight of t1 (ND = 6) / of t0 = 128 acc0 + acc1 (ND = 3)
+        lc.c[0] = c2 * 268435456.0;
+        {
+            // bound pass: f32 products of powers of two stay exact for |en| <= 45 (and the image keeps |ej| <= 45);
+            // outside, or for a non-finite sample, cef = +inf turns the bound into the trivial one
+            int en = 0;
+            (void)frexp(sn, &en);
+            const bool ok = (c2 == c2) && en >= -44 && en <= 46;
+            lc.c2f = ok ? (float)c2 : 0.0f;
+            lc.cef = ok ? (float)(sn * i8_err(ND, T32) * 1.0001) : __builtin_huge_valf();
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int kb = 0; kb < n_blocks; ++kb) {
@@ -355,11 +488,11 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
                 const int k = k0 + kk;
                 if (k >= K) break;
                 if (T32 > 1 && wave >= NW / 2)      // the second wave of each SIMD (wave uniform: no divergence)
-                    estep_i8_component<T32, true>(buf + kk * IMGB, xd, cvec[k], c0, c1, c2, lane, c, h, n0, n_rows,
-                                                  lnrho + (int64_t)k * npad);
+                    estep_i8_component<ND, BOUND, T32, true>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0, n_rows,
+                                                             lnrho + (int64_t)k * npad);
                 else
-                    estep_i8_component<T32, false>(buf + kk * IMGB, xd, cvec[k], c0, c1, c2, lane, c, h, n0, n_rows,
-                                                   lnrho + (int64_t)k * npad);
+                    estep_i8_component<ND, BOUND, T32, false>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0, n_rows,
+                                                              lnrho + (int64_t)k * npad);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -36,11 +36,14 @@ struct EstepI8Args {
     const unsigned char* img; const double* pivot; const double* cvec; int K;
     double* lnrho; int64_t npad;
 };
-int estep_i8_image_bytes(int D);
+// bound = 1: the 3-digit image / kernel of the pruned E-step's bound pass
+int estep_i8_image_bytes(int D, int bound);
 int estep_i8_rows_per_wg();
 hipError_t launch_pack_i8(const double* u, const double* m, const double* pivot, int K, int D, unsigned char* img,
-                          hipStream_t st);
+                          int bound, hipStream_t st);
 hipError_t launch_estep_i8(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const char** name);
+hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a,
+                                 const char** name);
 // components handled by one M-step workgroup for T feature tiles (4 waves / waves-per-component)
 int mstep_components_per_wg(int T, bool pre);
 int mstep_threads(int T, bool pre);

@@ -20,6 +20,9 @@ struct gmmvb_workspace {
     unsigned char* img_i8 = nullptr;   // [K][img_i8_len] int8-digit parameter images (estep_i8.h), variant kEstepI8 only
     int img_i8_len = 0;
     double* pivot_i8 = nullptr;        // [D] the pivot those images (and the sample digits) are centred on
+    unsigned char* img_i8b = nullptr;  // [K][img_i8b_len] 3-digit images of the pruned E-step's bound pass
+    int img_i8b_len = 0;
+    bool bound_i8 = true;              // env GMMVB_ESTEP_BOUND=f64: bound pass = leading blocks in f64 instead
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)

@@ -57,7 +57,7 @@ def test_driver_sparse_equals_dense(K, K_data, D, N, dtype, iters):
     x = orc.synth_gmm(K_data, D, N, dtype)
     a = _fit(x, K, iters, DENSE)
     b = _fit(x, K, iters, SPARSE)
-    assert "estep_bound_f64" in b._engine.launch_info and "estep_bound_f64" not in a._engine.launch_info
+    assert "_bound" in b._engine.launch_info and "_bound" not in a._engine.launch_info
     ha, hb = a.get_hn_params(), b.get_hn_params()
     for k in ha:
         assert rel_err(hb[k], ha[k]) < 1e-11, k
@@ -106,7 +106,7 @@ def test_data_pass_statistics_and_nan_rows():
     pivot = xd[:4096].to(torch.float64).mean(dim=0)
     dense = _pass(xd, qd, DENSE, pivot)
     sparse = _pass(xd, qd, SPARSE, pivot)
-    assert "mstep_list_f64" in sparse[1][2] and "estep_bound_f64" in sparse[1][2]
+    assert "mstep_list_f64" in sparse[1][2] and "_bound" in sparse[1][2]
     assert "mstep_mfma_f64" in dense[1][2]
     for (sa, ra, _), (sb, rb, _) in zip(dense, sparse):
         assert rel_err(sb, sa) < 1e-12
