@@ -327,6 +327,29 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             prune = act <= 0.25 * (double)n_rows * ws->K;
         }
     }
+    if (prune && ws->img_i8b) {
+        // how many output blocks the bound pass evaluates: one fewer while the last pass left hardly any more
+        // candidates than there were active pairs, one more (and not below that for 8 passes) once they doubled
+        const int t32 = (ws->D + 31) / 32;
+        if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
+        if (ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
+            double act = 0.0;
+            rc = fetch_active(ws, st, &act);
+            if (rc) return rc;
+            const double ratio = ws->evaluated_prev / (act > 1.0 ? act : 1.0);
+            if (++ws->tb_age >= 8 && ws->tb_floor > 1) {
+                --ws->tb_floor;
+                ws->tb_age = 0;
+            }
+            if (ratio > 2.0 && ws->bound_tb < t32) {
+                ws->tb_floor = ++ws->bound_tb;
+                ws->tb_age = 0;
+            } else if (ratio < 1.25 && ws->bound_tb > ws->tb_floor) {
+                --ws->bound_tb;
+            }
+        }
+    }
+    ws->evaluated_prev = -1.0;
     if (prune) {
         rc = ensure_lists(ws);
         if (rc) return rc;
@@ -342,7 +365,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (ws->img_i8b) {
             EstepI8Args ab = a8;
             ab.img = ws->img_i8b;
-            e = launch_estep_i8_bound(is64, vec, (int)grid, st, ab, &name);
+            e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, &name);
         } else {
             e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
         }
@@ -365,6 +388,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate selection", e);
             for (int k = 0; k < ws->K; ++k) ws->evaluated += counts_host[k];
+            ws->evaluated_prev = ws->evaluated;
             e = launch_estep_gather(ws->T, is64, vec, st, a, ws->lists, ws->npad, ws->counts, counts_host);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_gather launch", e);
         }

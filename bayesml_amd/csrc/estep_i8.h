@@ -403,19 +403,21 @@ __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned cons
 // The U digits are requested two steps (one step = one digit a of one block pair = ND - a MFMAs) ahead of their
 // use and the epilogue's row constants one pair of rows ahead, so that with only two waves per SIMD the LDS
 // latency sits behind MFMAs instead of in front of them.
-template <int ND, bool BOUND, int T32, bool REV>
+// T32 = output blocks evaluated (and x blocks held), TI >= T32 = blocks of the image (its leading tri_pairs(T32) block
+// pairs are exactly the ones needed).
+template <int ND, bool BOUND, int T32, int TI, bool REV>
 __device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&xd)[ND][T32], double ck,
                                                    const i8_lane_consts& lc, int lane, int c, int h, int64_t n0,
                                                    int64_t n_rows, double* __restrict__ lnrho_k) {
     using ord = i8_order<ND, T32, REV>;
-    constexpr int P = tri_pairs(T32);
+    constexpr int P = tri_pairs(TI);
     const unsigned frag_addr = im_lds + lane * 16;                              // layout step s at + 1024 s
     // row constants: ND = 6 (jt, g) at + 512 jt + 256 h + 16 g; bound pass (jt, g) at + 256 jt + 128 h + 8 g
     const unsigned const_addr = im_lds + P * ND * 1024 + h * (BOUND ? 128 : 256);
     typename std::conditional<BOUND, float, double>::type q = 0;
     i4v scales = {0, 0, 0, 0};
     if constexpr (BOUND) {
-        lds_read16<0>(scales, im_lds + P * ND * 1024 + T32 * 256);
+        lds_read16<0>(scales, im_lds + P * ND * 1024 + TI * 256);
         lds_wait<0>(scales);
     }
     i4v ua[3];
@@ -430,9 +432,11 @@ __device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&
 }
 
 // ND = 6: the E-step.  ND = 3, BOUND: upper bounds of ln rho for the pruned E-step (estep.h) from three digits per
-// operand - every row and feature takes part, unlike the f64 bound pass's leading blocks, at 6 instead of 21 MFMAs
-// per block pair; the error term keeps the bound rigorous whatever the conditioning.
-template <int ND, bool BOUND, int T32, typename XT, bool VEC, int NW>
+// operand at 6 instead of 21 MFMAs per block pair; the error term keeps the bound rigorous whatever the
+// conditioning.  The bound pass may stop after TB < T32 output blocks (32 TB rows of y and the leading
+// tri_pairs(TB) block pairs): dropping rows only loosens the bound - more candidates for the exact pass, less work in
+// the pass every pair goes through; gmmvb_estep moves TB up and down with the candidate / active ratio it observes.
+template <int ND, bool BOUND, int T32, int TB, typename XT, bool VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                                     const unsigned char* __restrict__ img /*[K][IMGB]*/,
                                                     const double* __restrict__ pivot, const double* __restrict__ cvec,
@@ -461,9 +465,10 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
     for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
         const int64_t n0 = wt * rows_per_wg + (int64_t)wave * 32;
         stage(0, 0);
-        i4v xd[ND][T32];
+        static_assert(TB >= 1 && TB <= T32 && (BOUND || TB == T32), "only the bound pass may stop early");
+        i4v xd[ND][TB];
         double c2, sn;
-        load_x_digits<ND, T32, XT, VEC>(x, ldx, n_rows, D, pivot, n0, c, h, xd, c2, sn);
+        load_x_digits<ND, TB, XT, VEC>(x, ldx, n_rows, D, pivot, n0, c, h, xd, c2, sn);
         i8_lane_consts lc;
         lc.c[2] = c2;
         lc.c[1] = c2 * (ND == 6 ? 16384.0 : 128.0);      // weight of t1 (ND = 6) / of t0 = 128 acc0 + acc1 (ND = 3)
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
             (void)frexp(sn, &en);
             const bool ok = (c2 == c2) && en >= -44 && en <= 46;
             lc.c2f = ok ? (float)c2 : 0.0f;
-            lc.cef = ok ? (float)(sn * i8_err(ND, T32) * 1.0001) : __builtin_huge_valf();
+            lc.cef = ok ? (float)(sn * i8_err(ND, TB) * 1.0001) : __builtin_huge_valf();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -488,11 +493,11 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
                 const int k = k0 + kk;
                 if (k >= K) break;
                 if (T32 > 1 && wave >= NW / 2)      // the second wave of each SIMD (wave uniform: no divergence)
-                    estep_i8_component<ND, BOUND, T32, true>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0, n_rows,
-                                                             lnrho + (int64_t)k * npad);
+                    estep_i8_component<ND, BOUND, TB, T32, true>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
+                                                                 n_rows, lnrho + (int64_t)k * npad);
                 else
-                    estep_i8_component<ND, BOUND, T32, false>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0, n_rows,
-                                                              lnrho + (int64_t)k * npad);
+                    estep_i8_component<ND, BOUND, TB, T32, false>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
+                                                                  n_rows, lnrho + (int64_t)k * npad);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

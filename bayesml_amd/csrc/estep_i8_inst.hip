@@ -20,38 +20,50 @@ hipError_t launch_pack_i8(const double* u, const double* m, const double* pivot,
     return hipGetLastError();
 }
 
-template <int ND, bool BOUND, int T32, typename XT, bool VEC>
+template <int ND, bool BOUND, int T32, int TB, typename XT, bool VEC>
 static hipError_t go(int grid, hipStream_t st, const EstepI8Args& a) {
-    hipLaunchKernelGGL((estep_i8<ND, BOUND, T32, XT, VEC, 8>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x),
-                       a.ldx, a.n_rows, a.D, a.img, a.pivot, a.cvec, a.K, a.lnrho, a.npad);
+    hipLaunchKernelGGL((estep_i8<ND, BOUND, T32, TB, XT, VEC, 8>), dim3(grid), dim3(512), 0, st,
+                       static_cast<const XT*>(a.x), a.ldx, a.n_rows, a.D, a.img, a.pivot, a.cvec, a.K, a.lnrho, a.npad);
     return hipGetLastError();
 }
 
-template <int ND, bool BOUND>
-static hipError_t pick(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a) {
-#define CASE(TT)                                                                                                    \
-    case TT:                                                                                                        \
-        if (x_is_f64) return vec ? go<ND, BOUND, TT, double, true>(grid, st, a) : go<ND, BOUND, TT, double, false>(grid, st, a); \
-        return vec ? go<ND, BOUND, TT, float, true>(grid, st, a) : go<ND, BOUND, TT, float, false>(grid, st, a);
-    switch (i8_blocks(a.D)) {
-        CASE(1) CASE(2) CASE(3) CASE(4)
-    }
-#undef CASE
-    return hipErrorInvalidValue;
+template <int ND, bool BOUND, int T32, int TB>
+static hipError_t pick_x(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a) {
+    if (x_is_f64) return vec ? go<ND, BOUND, T32, TB, double, true>(grid, st, a) : go<ND, BOUND, T32, TB, double, false>(grid, st, a);
+    return vec ? go<ND, BOUND, T32, TB, float, true>(grid, st, a) : go<ND, BOUND, T32, TB, float, false>(grid, st, a);
 }
 
 hipError_t launch_estep_i8(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const char** name) {
     static const char* names[] = {"", "estep_i8<T32=1>", "estep_i8<T32=2>", "estep_i8<T32=3>", "estep_i8<T32=4>"};
-    *name = names[i8_blocks(a.D) <= 4 ? i8_blocks(a.D) : 0];
-    return pick<kDigits, false>(x_is_f64, vec, grid, st, a);
+    const int t32 = i8_blocks(a.D);
+    *name = names[t32 <= 4 ? t32 : 0];
+    switch (t32) {
+        case 1: return pick_x<kDigits, false, 1, 1>(x_is_f64, vec, grid, st, a);
+        case 2: return pick_x<kDigits, false, 2, 2>(x_is_f64, vec, grid, st, a);
+        case 3: return pick_x<kDigits, false, 3, 3>(x_is_f64, vec, grid, st, a);
+        case 4: return pick_x<kDigits, false, 4, 4>(x_is_f64, vec, grid, st, a);
+    }
+    return hipErrorInvalidValue;
 }
 
-hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a,
+// tb = output blocks the bound pass evaluates, 1 .. ceil(D / 32)
+hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int tb, int grid, hipStream_t st, const EstepI8Args& a,
                                  const char** name) {
-    static const char* names[] = {"", "estep_i8_bound<T32=1>", "estep_i8_bound<T32=2>", "estep_i8_bound<T32=3>",
-                                  "estep_i8_bound<T32=4>"};
-    *name = names[i8_blocks(a.D) <= 4 ? i8_blocks(a.D) : 0];
-    return pick<kBoundDigits, true>(x_is_f64, vec, grid, st, a);
+    static const char* names[5][5] = {
+        {"", "", "", "", ""},
+        {"", "estep_i8_bound<T32=1,blocks=1>", "", "", ""},
+        {"", "estep_i8_bound<T32=2,blocks=1>", "estep_i8_bound<T32=2,blocks=2>", "", ""},
+        {"", "estep_i8_bound<T32=3,blocks=1>", "estep_i8_bound<T32=3,blocks=2>", "estep_i8_bound<T32=3,blocks=3>", ""},
+        {"", "estep_i8_bound<T32=4,blocks=1>", "estep_i8_bound<T32=4,blocks=2>", "estep_i8_bound<T32=4,blocks=3>",
+         "estep_i8_bound<T32=4,blocks=4>"}};
+    const int t32 = i8_blocks(a.D);
+    if (t32 < 1 || t32 > 4 || tb < 1 || tb > t32) return hipErrorInvalidValue;
+    *name = names[t32][tb];
+#define BC(T, B) \
+    if (t32 == T && tb == B) return pick_x<kBoundDigits, true, T, B>(x_is_f64, vec, grid, st, a);
+    BC(1, 1) BC(2, 1) BC(2, 2) BC(3, 1) BC(3, 2) BC(3, 3) BC(4, 1) BC(4, 2) BC(4, 3) BC(4, 4)
+#undef BC
+    return hipErrorInvalidValue;
 }
 
 }  // namespace gmmvb

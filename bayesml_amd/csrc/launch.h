@@ -42,7 +42,8 @@ int estep_i8_rows_per_wg();
 hipError_t launch_pack_i8(const double* u, const double* m, const double* pivot, int K, int D, unsigned char* img,
                           int bound, hipStream_t st);
 hipError_t launch_estep_i8(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const char** name);
-hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a,
+// tb = output blocks (32 rows of y each) the bound pass evaluates, 1 .. ceil(D / 32)
+hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int tb, int grid, hipStream_t st, const EstepI8Args& a,
                                  const char** name);
 // components handled by one M-step workgroup for T feature tiles (4 waves / waves-per-component)
 int mstep_components_per_wg(int T, bool pre);

@@ -23,6 +23,11 @@ struct gmmvb_workspace {
     unsigned char* img_i8b = nullptr;  // [K][img_i8b_len] 3-digit images of the pruned E-step's bound pass
     int img_i8b_len = 0;
     bool bound_i8 = true;              // env GMMVB_ESTEP_BOUND=f64: bound pass = leading blocks in f64 instead
+    // output blocks the int8 bound pass evaluates, steered by the candidates / active pairs ratio of the last pruned
+    // E-step (fewer blocks: cheaper pass, looser bound); tb_floor = lowest level currently allowed, tb_age counts the
+    // pruned E-steps since a level last proved too loose
+    int bound_tb = 0, tb_floor = 1, tb_age = 0;
+    double evaluated_prev = -1.0;      // candidates of the last pruned E-step (-1: it did not prune)
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)
