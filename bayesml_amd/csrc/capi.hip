@@ -263,8 +263,12 @@ static int fetch_active(gmmvb_workspace* ws, hipStream_t st, double* out) {
 
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs) {
     if (!ws || !active_pairs || !evaluated_pairs) return fail(GMMVB_EINVAL, "null argument");
-    if (ws->e_state == 0 || ws->act_rows == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    if (ws->e_state != 1) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     *evaluated_pairs = ws->evaluated;
+    if (!ws->sparse || ws->act_rows != ws->e_rows) {      // GMMVB_MSTEP_SPARSE=0: the pairs are not counted
+        *active_pairs = -1.0;
+        return GMMVB_OK;
+    }
     return fetch_active(ws, (hipStream_t)stream, active_pairs);
 }
 

@@ -11,9 +11,17 @@ Single GPU (default): N = 1e7 rows of f32 (BASELINE.json configs[2], the config 
 on; it fits one GPU).  N GPUs: every rank holds its own 1e7 rows (weak scaling), statistics are
 combined by ONE all-reduce(sum, f64) of K(2 + D + D^2) doubles per step over RCCL.
 
+The data pass is sparse where the responsibilities are: once a VB iteration has left
+at most a quarter of the (sample, component) pairs with r >= 2^-100, the next E-step proves the other pairs
+irrelevant with an int8-digit bound pass and evaluates only the candidates in f64, and the M-step runs over the
+active samples of each component.  Results equal the dense kernels' to rounding; ``sparse_check`` re-runs the last
+iteration's data pass with the dense kernels and reports the difference of the statistics.  ``--dense`` switches
+both off (every pair evaluated in f64: the round-1 v5 numbers).  ``per_step`` / ``warmup_steps`` list every
+iteration's kernel times and sparsity, including the dense first iterations.
+
 Also reported on the same JSON line:
-  roofline      dominant kernel against the f64 MFMA peak, duration from HIP events recorded in the
-                library around that kernel's launch on its stream (gmmvb_profile_last_ms)
+  roofline      dominant phase against the f64 MFMA peak, duration from HIP events recorded in the
+                library around that phase's launches on their stream (gmmvb_profile_last_ms)
   cpu_baseline  the oracle (NumPy port of the reference's formulation) timed on this host's cores
                 over 10 VB iterations of the first N_ref = 20000 rows (rank 0, N = 1 only)
   parity        max relative error of the posterior hyper-parameters after those 10 iterations, GPU
@@ -38,6 +46,7 @@ from bayesml_amd import gaussianmixture as gm                 # noqa: E402
 
 SEED = 20250711
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X datasheet FP64 matrix (MI355X_MICROARCH.md lists no f64 row)
+PEAK_I8_MFMA_TOPS = 5000.0       # dense int8 = fp8 rate (MI355X_MICROARCH.md); tools/i8_probe.hip sustains 4950 / 3600
 
 
 def recipe_means(K, D):
@@ -120,7 +129,11 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="storage dtype of x in HBM")
     ap.add_argument("--ref-rows", type=int, default=20_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
     args = ap.parse_args()
+    if args.dense:
+        os.environ["GMMVB_ESTEP_PRUNE"] = "0"
+        os.environ["GMMVB_MSTEP_SPARSE"] = "0"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,8 +173,18 @@ def main():
         ns, x_bar, s, h = m._pass(eng, xd, q, s)
         return float(_kside.lower_bound(prior, q, ns, x_bar, s, h)["vl"])
 
+    def snapshot():
+        a, e = eng.sparsity()
+        em, mm = eng.last_kernel_ms()
+        return dict(estep_ms=round(em, 2), mstep_ms=round(mm, 2), kernels=[p.strip().split(" ")[0] for p in eng.launch_info.split("|")],
+                    active_components_per_sample=round(a / n_local, 2) if a >= 0 else None,
+                    evaluated_components_per_sample=round(e / n_local, 2))
+
+    torch.cuda.synchronize()
+    warm = [dict(snapshot(), what="pass after the subsampling initialisation")]
     for _ in range(args.warmup):
         step()
+        warm.append(dict(snapshot(), what="warm-up iteration"))
 
     def fence():
         if world > 1:
@@ -190,27 +213,60 @@ def main():
         # algorithmic flops per sample: E = K(2D^2+3D) + 6K, M = K(2D^2+2D) + 2KD
         fl_e = K * (2 * D * D + 3 * D) + 6 * K
         fl_m = K * (2 * D * D + 2 * D) + 2 * K * D
-        names = [part.strip().split("<")[0] for part in eng.launch_info.split("|")]      # kernels actually launched
-        # executed MFMA flops: T(T+1)/2 tile pairs of 16x16, x4 (E: per 16 samples) or x1 (M: per 4 samples) MFMAs of 2048 flops
+        names = [part.strip().split("<")[0] for part in eng.launch_info.split("|")]      # kernels of the last step
+        # executed f64 MFMA flops per evaluated (sample, component) pair: T(T+1)/2 tile pairs of 16x16 x 512 flops
         tiles = (D + 15) // 16
-        fl_exec = K * 512 * tiles * (tiles + 1) // 2
-        kern = {names[0]: dict(ms=e_ms, algorithmic_tflops=fl_e * n_local / (e_ms * 1e-3) / 1e12,
-                               executed_mfma_tflops=fl_exec * n_local / (e_ms * 1e-3) / 1e12),
-                names[1]: dict(ms=m_ms, algorithmic_tflops=fl_m * n_local / (m_ms * 1e-3) / 1e12,
-                               executed_mfma_tflops=fl_exec * n_local / (m_ms * 1e-3) / 1e12)}
+        fl_pair = 512 * tiles * (tiles + 1) // 2
+        ev = float(np.mean([e for _, e in spars]))          # pairs evaluated exactly per E-step
+        ac = float(np.mean([a for a, _ in spars]))          # active pairs (the M-step's, when it runs sparse)
+        m_sparse = names[1].startswith("mstep_list")
+        kern = {"estep": dict(ms=e_ms, kernels=names[0] + ("+select+estep_gather_f64" if "bound" in names[0] else ""),
+                              algorithmic_tflops=fl_e * n_local / (e_ms * 1e-3) / 1e12,
+                              exact_pairs_f64_tflops=fl_pair * ev / (e_ms * 1e-3) / 1e12),
+                "mstep": dict(ms=m_ms, kernels=names[1] + ("+select" if m_sparse else ""),
+                              algorithmic_tflops=fl_m * n_local / (m_ms * 1e-3) / 1e12,
+                              executed_f64_tflops=fl_pair * (ac if m_sparse else n_local * K) / (m_ms * 1e-3) / 1e12)}
+        if "bound" in names[0] and "i8" in names[0]:
+            # int8 bound pass: 6 MFMAs of 65536 ops per 32x32x32 block pair, tri_pairs(blocks) pairs, per 32 samples
+            blocks = int(eng.launch_info.split("blocks=")[1].split(">")[0])
+            kern["estep"]["bound_pass_i8_ops"] = 6 * 65536 * blocks * (blocks + 1) // 2 * K * n_local / 32
+            kern["estep"]["bound_pass_i8_peak_tops"] = PEAK_I8_MFMA_TOPS
         dom = max(kern, key=lambda k: kern[k]["ms"])
         ach = kern[dom]["algorithmic_tflops"]
-        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
-        # take them from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py)
+        # HBM-side bytes per launch of the phase's dominant kernel: PMC counters cannot be read from inside this process,
+        # so take them from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py)
         traffic = traffic_src = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f).get(dom)
+                pm = json.load(f).get(names[0 if dom == "estep" else 1])
             if pm and K == 64 and D == 128 and n_local == 10_000_000 and args.dtype == "f32":
                 traffic = pm["fetch_bytes"] + pm["write_bytes"]
                 traffic_src = "profiles/pmc_traffic.json: " + pm["note"]
         except (OSError, ValueError, KeyError):
             pass
+        sparse_check = None
+        if not args.dense and world == 1:
+            # the last iteration's data pass again, every pair in f64 with the dense kernels, on the same parameters
+            from bayesml_amd._engine import DataPass
+            os.environ["GMMVB_ESTEP_PRUNE"] = "0"
+            os.environ["GMMVB_MSTEP_SPARSE"] = "0"
+            ref = DataPass(K, D, xd.dtype, n_local, dev)
+            ref.set_pivot(eng.pivot)
+            ref.prepare_rows(xd)
+            f = q                                   # update_q() returns the posterior with its features
+            ref.set_params(f.c, f.m, f.u)
+            st_ref = ref.estep_mstep(xd)
+            ref_info = ref.launch_info
+            eng.set_params(f.c, f.m, f.u)
+            st_new = eng.estep_mstep(xd)
+            num = float((st_new - st_ref).abs().max())
+            den = float(st_ref.abs().max())
+            blocks_rel = []
+            for a_, b_ in zip(eng.split_stats(st_new), ref.split_stats(st_ref)):
+                blocks_rel.append(float((a_ - b_).abs().max() / b_.abs().max()))
+            sparse_check = {"max_rel_diff_of_statistics": num / den,
+                            "per_block_ns_h_a_B": blocks_rel, "dense_kernels": ref_info, "sparse_kernels": eng.launch_info}
+            ref.close()
         bytes_per_sample = D * x.element_size()
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
@@ -221,17 +277,22 @@ def main():
                                    "one VB iteration per step (configs[2] of BASELINE.json)",
                        "classes": K, "degree": D, "rows_per_gpu": n_local, "x_storage": args.dtype,
                        "parallelism": f"rows{world}"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": kern[dom]["kernels"], "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernels": kern,
                          "hbm_algorithmic_GBps": bytes_per_sample * n_local / ((e_ms + m_ms) * 1e-3) / 1e9,
-                         "note": "achieved = algorithmic (dense) flops of SURVEY 8d / HIP-event kernel time; the kernels "
-                                 "execute ~0.56x of them (triangular whitening factor, symmetric second moment)"},
-            "cpu_baseline": cpu_base, "parity": parity, "final_vl": vl, "launch": eng.launch_info,
+                         "note": "achieved = algorithmic (dense) flops of SURVEY 8d / HIP-event time of the phase.  The "
+                                 "dense kernels execute 0.56x of them (triangular whitening factor, symmetric second "
+                                 "moment) at 87-90 % of the f64 MFMA issue rate (--dense); the sparse path executes only "
+                                 "the pairs that can matter (exact_pairs_f64_tflops / executed_f64_tflops) plus the "
+                                 "int8 bound pass, so frac is far above 1 and says how much work was avoided, not "
+                                 "how busy the pipe is"},
+            "cpu_baseline": cpu_base, "parity": parity, "sparse_check": sparse_check, "final_vl": vl,
+            "launch": eng.launch_info, "warmup_steps": warm,
             "per_step": {"estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
                          "estep_kernel": [l.split("<")[0] for l in launches],
-                         "active_components_per_sample": [round(a / n_local, 2) for a, _ in spars],
+                         "active_components_per_sample": [round(a / n_local, 2) if a >= 0 else None for a, _ in spars],
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars]},
         }
         print(json.dumps(out))

@@ -142,7 +142,8 @@ const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
 
 /* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
  * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
- * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  Synchronises the stream. */
+ * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  *active_pairs = -1 when the
+ * library was told not to count (GMMVB_MSTEP_SPARSE=0).  Synchronises the stream. */
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs);
 
 #ifdef __cplusplus
