@@ -320,7 +320,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const char* name = "";
     hipError_t e = hipSuccess;
     // Prune?  Needs the default f64 kernel family, and (unless forced) evidence from the previous E-step over
-    // these rows that at most a quarter of the (sample, component) pairs matter.
+    // these rows that at most half of the (sample, component) pairs matter.
     bool prune = ws->prune != 0 && ws->estep_variant == kEstepLds8;
     if (prune && ws->prune == 1) {
         prune = false;
@@ -328,7 +328,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             double act = 0.0;
             rc = fetch_active(ws, st, &act);
             if (rc) return rc;
-            prune = act <= 0.25 * (double)n_rows * ws->K;
+            prune = act <= 0.5 * (double)n_rows * ws->K;
         }
     }
     if (prune && ws->img_i8b) {
@@ -336,7 +336,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // candidates than there were active pairs, one more (and not below that for 8 passes) once they doubled
         const int t32 = (ws->D + 31) / 32;
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
-        if (ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
+        const char* pin = std::getenv("GMMVB_ESTEP_BOUND_BLOCKS");      // pins the level (1 .. ceil(D/32))
+        if (pin && std::atoi(pin) >= 1 && std::atoi(pin) <= t32) {
+            ws->bound_tb = std::atoi(pin);
+        } else if (ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
             double act = 0.0;
             rc = fetch_active(ws, st, &act);
             if (rc) return rc;

@@ -39,7 +39,7 @@ struct gmmvb_workspace {
     double act_host = -1.0;    // host copy of act_total for that E-step (-1 = not fetched yet)
     double evaluated = 0.0;    // pairs the last E-step evaluated exactly
     // pruned E-step (estep.h): env GMMVB_ESTEP_PRUNE = 0 never | force always | default: when the previous E-step
-    // over the same rows left at most a quarter of the pairs relevant and N K >= 2^23
+    // over the same rows left at most half of the pairs relevant and N K >= 2^23
     int prune = 1;
     int* lists = nullptr;      // [K][npad] sample lists, allocated at first use
     int* khat = nullptr;       // [npad]

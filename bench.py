@@ -12,7 +12,7 @@ on; it fits one GPU).  N GPUs: every rank holds its own 1e7 rows (weak scaling),
 combined by ONE all-reduce(sum, f64) of K(2 + D + D^2) doubles per step over RCCL.
 
 The data pass is sparse where the responsibilities are: once a VB iteration has left
-at most a quarter of the (sample, component) pairs with r >= 2^-100, the next E-step proves the other pairs
+at most half of the (sample, component) pairs with r >= 2^-100, the next E-step proves the other pairs
 irrelevant with an int8-digit bound pass and evaluates only the candidates in f64, and the M-step runs over the
 active samples of each component.  Results equal the dense kernels' to rounding; ``sparse_check`` re-runs the last
 iteration's data pass with the dense kernels and reports the difference of the statistics.  ``--dense`` switches
