@@ -321,7 +321,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     hipError_t e = hipSuccess;
     // Prune?  Needs the default f64 kernel family, and (unless forced) evidence from the previous E-step over
     // these rows that at most half of the (sample, component) pairs matter.
-    bool prune = ws->prune != 0 && ws->estep_variant == kEstepLds8;
+    // (never for an HMM workspace: forward-backward consumes every emission ln rho, bounds will not do)
+    bool prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr;
     if (prune && ws->prune == 1) {
         prune = false;
         if (n_rows * (int64_t)ws->K >= (int64_t(1) << 23) && ws->act_rows == n_rows) {
@@ -394,7 +395,21 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 e = hipMemcpyAsync(counts_host, ws->counts, (size_t)ws->K * sizeof(int), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate selection", e);
-            for (int k = 0; k < ws->K; ++k) ws->evaluated += counts_host[k];
+            double listed = 0.0;
+            for (int k = 0; k < ws->K; ++k) listed += counts_host[k];
+            if (round == 1 && ws->prune != 2 && ws->evaluated + listed > 0.6 * (double)n_rows * ws->K) {
+                // the parameters moved a long way since the last E-step (a new restart): most pairs are candidates
+                // again, so evaluate everything with the dense kernel instead of gathering almost everything
+                const int rpd = estep_rows_per_wg(ws->estep_variant, ws->T, is64);
+                int64_t gd = (n_rows + rpd - 1) / rpd;
+                if (gd > (1 << 20)) gd = 1 << 20;
+                e = launch_estep(ws->estep_variant, ws->T, is64, vec, (int)gd, st, a, &name);
+                if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
+                ws->evaluated = (double)n_rows * ws->K;
+                ws->evaluated_prev = -1.0;
+                break;
+            }
+            ws->evaluated += listed;
             ws->evaluated_prev = ws->evaluated;
             e = launch_estep_gather(ws->T, is64, vec, st, a, ws->lists, ws->npad, ws->counts, counts_host);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_gather launch", e);

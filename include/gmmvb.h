@@ -99,7 +99,11 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
 int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows,
                       double* stats_dev, void* stream);
 
-/* Read-outs for rows [row0, row0 + n_rows) of the last E-step, row-major [n_rows][K]. */
+/* Read-outs for rows [row0, row0 + n_rows) of the last E-step, row-major [n_rows][K].
+ * When the E-step pruned (large N K, sparse responsibilities; see gmmvb_last_sparsity), gmmvb_ln_rho returns, for the
+ * pairs it did not evaluate, an upper bound of ln rho that lies at least 100 ln 2 below the row's largest value:
+ * responsibilities, hard assignments and statistics are unaffected (r < 2^-100 for those pairs).  Pruning is never
+ * used once hmmvb_enable has been called, or with GMMVB_ESTEP_PRUNE=0 in the environment. */
 int gmmvb_responsibilities(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* r_dev, void* stream);
 int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
 int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_dev, void* stream);

@@ -116,3 +116,23 @@ def test_data_pass_statistics_and_nan_rows():
     for env in (DENSE, SPARSE):
         out = _pass(xd, qd, env, pivot)
         assert np.isnan(out[1][0][:K]).all()
+
+
+def test_restarts_and_default_policy():
+    """The default policy over several restarts: every restart begins dense (broad initial components), turns sparse
+    after a few iterations, and the next restart's first pass must notice that nothing can be pruned any more.
+    N K is just above the library's 2^23 floor for pruning."""
+    K, D, N = 48, 64, 180_000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    from bayesml_amd import gaussianmixture as gm
+    out = {}
+    for tag, env in (("dense", DENSE), ("default", {})):
+        with _env(env):
+            m = gm.LearnModel(K, D, seed=3, device=torch.device("cuda", 0), verbose=False)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m.update_posterior(x, max_itr=7, num_init=3, tolerance=0.0)
+        out[tag] = (m.get_hn_params(), m._engine.launch_info)
+    assert "_bound" in out["default"][1] and "mstep_list_f64" in out["default"][1]
+    for k in out["dense"][0]:
+        assert rel_err(out["default"][0][k], out["dense"][0][k]) < 1e-11, k
