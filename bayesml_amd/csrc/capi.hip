@@ -333,28 +333,45 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
     }
     if (prune && ws->img_i8b) {
-        // how many output blocks the bound pass evaluates: one fewer while the last pass left hardly any more
-        // candidates than there were active pairs, one more (and not below that for 8 passes) once they doubled
+        // How many output blocks the bound pass evaluates.  Cost model per (sample, component) pair, in units of
+        // 1e-11 s measured at C3 (profiles/r1_v6_*): bound pass 0.12 per block pair + 0.039 per row of y; exact pass
+        // 0.81 per f64 tile pair of every candidate.  Take the cheapest level among those observed in the last 32
+        // pruned passes; look one level down when the current one leaves hardly any spare candidates (two levels
+        // exist below) or one level up when more than half of its candidates are spare, if that level is unknown.
         const int t32 = (ws->D + 31) / 32;
-        if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
         const char* pin = std::getenv("GMMVB_ESTEP_BOUND_BLOCKS");      // pins the level (1 .. ceil(D/32))
+        if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
         if (pin && std::atoi(pin) >= 1 && std::atoi(pin) <= t32) {
             ws->bound_tb = std::atoi(pin);
         } else if (ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
             double act = 0.0;
             rc = fetch_active(ws, st, &act);
             if (rc) return rc;
-            const double ratio = ws->evaluated_prev / (act > 1.0 ? act : 1.0);
-            if (++ws->tb_age >= 8 && ws->tb_floor > 1) {
-                --ws->tb_floor;
-                ws->tb_age = 0;
+            const double pairs = (double)n_rows * ws->K;
+            const int cur = ws->bound_tb;
+            ws->tb_cand[cur] = ws->evaluated_prev / pairs;
+            ws->tb_act[cur] = act / pairs;
+            ws->tb_seen[cur] = 0;
+            // an observation is forgotten after 32 passes, or once the sparsity is no longer what it was made at
+            for (int l = 1; l <= t32; ++l)
+                if (l != cur && (++ws->tb_seen[l] > 32 || ws->tb_act[l] > 1.5 * ws->tb_act[cur] ||
+                                 ws->tb_act[l] < ws->tb_act[cur] / 1.5))
+                    ws->tb_cand[l] = -1.0;
+            const double gpp = 0.81 * tri_pairs(ws->T);
+            auto cost = [&](int l) { return 0.12 * tri_pairs(l) + 0.039 * 32 * l + gpp * ws->tb_cand[l]; };
+            int best = cur;
+            for (int l = 1; l <= t32; ++l)
+                if (ws->tb_cand[l] >= 0.0 && cost(l) < cost(best)) best = l;
+            const double spare = ws->tb_cand[cur] - act / pairs;         // candidates that turned out irrelevant
+            if (best == cur) {
+                if (cur > 1 && ws->tb_cand[cur - 1] < 0.0 && spare * ws->K < 0.25)
+                    best = cur - 1;        // under a quarter of a spare candidate per sample: the bound is tight,
+                                           // try the cheaper one (candidates grow steeply once rows are dropped)
+                else if (cur < t32 && ws->tb_cand[cur + 1] < 0.0 &&
+                         spare * gpp > 0.12 * (tri_pairs(cur + 1) - tri_pairs(cur)) + 0.039 * 32)
+                    best = cur + 1;        // the spare candidates cost more than a tighter bound would
             }
-            if (ratio > 2.0 && ws->bound_tb < t32) {
-                ws->tb_floor = ++ws->bound_tb;
-                ws->tb_age = 0;
-            } else if (ratio < 1.25 && ws->bound_tb > ws->tb_floor) {
-                --ws->bound_tb;
-            }
+            ws->bound_tb = best;
         }
     }
     ws->evaluated_prev = -1.0;
@@ -366,6 +383,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int64_t grid = 0;
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
     ws->evaluated = prune ? 0.0 : (double)n_rows * ws->K;
+    if (!prune)      // a dense pass: whatever was learnt about the bound levels belongs to another regime
+        for (double& c : ws->tb_cand) c = -1.0;
     if (prune) {
         rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
         grid = (n_rows + rpw - 1) / rpw;
@@ -407,6 +426,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
                 ws->evaluated = (double)n_rows * ws->K;
                 ws->evaluated_prev = -1.0;
+                if (ws->img_i8b) {          // this level left everything a candidate: remember, and go back up
+                    ws->tb_cand[ws->bound_tb] = 1.0;
+                    ws->tb_seen[ws->bound_tb] = 0;
+                    if (ws->bound_tb < (ws->D + 31) / 32) ++ws->bound_tb;
+                }
                 break;
             }
             ws->evaluated += listed;

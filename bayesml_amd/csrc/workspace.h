@@ -23,10 +23,13 @@ struct gmmvb_workspace {
     unsigned char* img_i8b = nullptr;  // [K][img_i8b_len] 3-digit images of the pruned E-step's bound pass
     int img_i8b_len = 0;
     bool bound_i8 = true;              // env GMMVB_ESTEP_BOUND=f64: bound pass = leading blocks in f64 instead
-    // output blocks the int8 bound pass evaluates, steered by the candidates / active pairs ratio of the last pruned
-    // E-step (fewer blocks: cheaper pass, looser bound); tb_floor = lowest level currently allowed, tb_age counts the
-    // pruned E-steps since a level last proved too loose
-    int bound_tb = 0, tb_floor = 1, tb_age = 0;
+    // output blocks the int8 bound pass evaluates (fewer blocks: cheaper pass, looser bound, more candidates for the
+    // exact pass).  tb_cand[L] = candidates per pair the last pass at level L left, tb_seen[L] = pruned E-steps since
+    // (levels not seen for 32 passes count as unknown); gmmvb_estep picks the level with the lowest modelled cost
+    int bound_tb = 0;
+    double tb_cand[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};
+    double tb_act[5] = {0.0, 0.0, 0.0, 0.0, 0.0};      // active pairs per pair when tb_cand[L] was observed
+    int tb_seen[5] = {0, 0, 0, 0, 0};
     double evaluated_prev = -1.0;      // candidates of the last pruned E-step (-1: it did not prune)
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]

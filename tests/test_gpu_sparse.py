@@ -136,3 +136,38 @@ def test_restarts_and_default_policy():
     assert "_bound" in out["default"][1] and "mstep_list_f64" in out["default"][1]
     for k in out["dense"][0]:
         assert rel_err(out["default"][0][k], out["dense"][0][k]) < 1e-11, k
+
+
+def test_int8_digit_estep_variant():
+    """GMMVB_ESTEP_VARIANT=i8 (opt-in): six base-128 digits per operand on the int8 matrix pipe.  Not bit-equivalent
+    to f64: fixed point relative to (row max of U) x (sample max), ~1e-8 absolute on ln rho for well-conditioned
+    components, a few 1e-12 of the largest |ln rho| in general."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    dev = torch.device("cuda", 0)
+    for K, D, N, dt in ((16, 32, 4096, np.float64), (8, 64, 5000, np.float32), (12, 128, 6000, np.float32), (5, 33, 777, np.float32)):
+        x = orc.synth_gmm(K, D, N, dt)
+        p = orc.Prior.default(K, D)
+        q = orc.Posterior.from_prior(p)
+        orc.init_subsampling(x.astype(np.float64), q, np.random.default_rng(0))
+        t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+        qd = _kside.features(_kside.PostT(t(q.alpha), t(q.m), t(q.kappa), t(q.nu), t(q.w_inv)))
+        xd = torch.from_numpy(x).to(dev)
+        res = {}
+        for tag, env in (("f64", {}), ("i8", {"GMMVB_ESTEP_VARIANT": "i8"})):
+            os.environ.pop("GMMVB_ESTEP_VARIANT", None)
+            os.environ.update(env)
+            try:
+                eng = DataPass(K, D, xd.dtype, N, dev)
+            finally:
+                os.environ.pop("GMMVB_ESTEP_VARIANT", None)
+            eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+            eng.set_params(qd.c, qd.m, qd.u)
+            eng.estep(xd)
+            res[tag] = (eng.ln_rho().cpu().numpy(), eng.launch_info)
+            eng.close()
+        assert "estep_i8" in res["i8"][1]
+        a, b = res["f64"][0], res["i8"][0]
+        assert np.max(np.abs(a - b)) < 2e-11 * np.max(np.abs(a))
+        if N >= D * D:       # sqrt(N) >= D: full-rank initial covariances, well conditioned
+            assert np.max(np.abs(a - b)) < 1e-7
