@@ -39,6 +39,8 @@ int64_t gmmvb_stats_len(int K, int D) {
     return (int64_t)K * (2 + (int64_t)D + (int64_t)D * D);
 }
 
+static int ensure_lists(gmmvb_workspace* ws);
+
 int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace** out) {
     if (!out) return fail(GMMVB_EINVAL, "out is null");
     *out = nullptr;
@@ -141,6 +143,10 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
             return fail(GMMVB_ENOMEM, "hipMalloc (workspace)", e);
         }
         ws->bytes += b.n * (int64_t)sizeof(double);
+    }
+    if (ws->sparse && K <= 256 && ensure_lists(ws) != GMMVB_OK) {      // not inside somebody's timed iteration
+        gmmvb_workspace_destroy(ws);
+        return GMMVB_ENOMEM;
     }
     e = hipMemset(ws->pivot, 0, (size_t)D * sizeof(double));
     if (e != hipSuccess) {

@@ -35,12 +35,12 @@ constexpr int kDigits = 6;        // the E-step proper: 42-bit operands
 constexpr int kBoundDigits = 3;   // the pruned E-step's bound pass: 21-bit operands and a rigorous error term
 // Image tails.  ND = 6: [jt][h][g][2] doubles (2^ej, b_j).  ND = 3 (bound pass): one exponent per 32-row output block
 // (rows are digitised against the block's largest entry - coarser for small rows, and the error term says so), then
-//   [jt][h][g][2] floats (b_j, beta_j)   and   [jt] floats 2^e_jt
-// so that a lane reads 8 bytes per output row instead of 16 and no per-row scale.
+//   [jt][h][g] floats b_j   and   [jt][2] floats (2^e_jt, beta_jt)
+// so that a lane reads 4 bytes per output row instead of 16 and no per-row scale.
 
 __host__ __device__ constexpr int i8_blocks(int D) { return (D + 31) / 32; }
 __host__ __device__ constexpr int i8_img_bytes(int nd, int t32) {
-    return (tri_pairs(t32) * nd * 1024 + (nd == kBoundDigits ? t32 * 256 + 16 : t32 * 512) + 1023) / 1024 * 1024;
+    return (tri_pairs(t32) * nd * 1024 + (nd == kBoundDigits ? t32 * 128 + 32 : t32 * 512) + 1023) / 1024 * 1024;
 }
 __host__ __device__ constexpr int i8_kb(int nd, int t32) {
     const int kb = (64 * 1024) / i8_img_bytes(nd, t32);
@@ -79,6 +79,7 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
     unsigned char* im = img + (int64_t)k * img_bytes;
     double* consts = reinterpret_cast<double*>(im + P * ND * 1024);
     __shared__ double row_max[128];
+    __shared__ double row_beta[128];
     __shared__ int row_bad[128];
     for (int j = threadIdx.x; j < 32 * T32; j += blockDim.x) {
         double mx = 0.0, bias = 0.0, abias = 0.0;
@@ -97,13 +98,12 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
         const int jt = j >> 5, w = j & 31;
         const int h = (w >> 2) & 1, g = (w & 3) + 4 * (w >> 3);      // w = (g & 3) + 8 (g >> 2) + 4 h
         if constexpr (ND == kBoundDigits) {
-            // (b_j, beta_j) in f32; beta_j >= 2^-20 |b_j| + the f64 rounding of b_j covers every f32 rounding of the
-            // epilogue that scales with the bias (i8_rows_bound); +inf = "no bound" (non-finite row or bias)
-            float* cp = reinterpret_cast<float*>(consts) + ((jt * 2 + h) * 16 + g) * 2;
+            // b_j in f32; beta_j >= 2^-20 |b_j| + the f64 rounding of b_j covers every f32 rounding of the epilogue
+            // that scales with the bias (i8_rows_bound) - the block keeps the largest of its rows' beta_j;
+            // +inf = "no bound" (non-finite row or bias)
             const bool wide = bad || !(fabs(bias) < 1e30) || !(abias < 1e30);
-            cp[0] = wide ? 0.0f : (float)bias;
-            cp[1] = wide ? __builtin_huge_valf()
-                         : (float)((fabs(bias) * 9.5367431640625e-7 + abias * 2.9e-14) * 1.0001) + 1e-37f;
+            reinterpret_cast<float*>(consts)[(jt * 2 + h) * 16 + g] = wide ? 0.0f : (float)bias;
+            row_beta[j] = wide ? __builtin_huge_val() : (fabs(bias) * 9.5367431640625e-7 + abias * 2.9e-14) * 1.0001 + 1e-37;
             row_max[j] = mx;
             row_bad[j] = bad;
         } else {
@@ -117,23 +117,23 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
         __syncthreads();
         for (int j = threadIdx.x; j < 32 * T32; j += blockDim.x) {
             const int jt = j >> 5;
-            double mx = 0.0;
+            double mx = 0.0, beta = 0.0;
             bool bad = false;
             for (int r = 0; r < 32; ++r) {
                 mx = fmax(mx, row_max[32 * jt + r]);
+                beta = fmax(beta, row_beta[32 * jt + r]);
                 bad |= row_bad[32 * jt + r] != 0;
             }
             int e = 0;
             if (mx > 0.0) (void)frexp(mx, &e);
             // f32 products of powers of two stay exact for |e| <= 45; outside (or with a non-finite row) the block
-            // gives no bound: scale 0 (all digits 0) and every beta of the block +inf
+            // gives no bound: scale 0 (all digits 0) and beta +inf
             const bool wide = bad || e < -45 || e > 45;
             row_scale[j] = (mx > 0.0 && !wide) ? ldexp(1.0, 6 - e) : 0.0;
-            float* tail = reinterpret_cast<float*>(consts) + T32 * 64;
-            if ((j & 31) == 0) tail[jt] = (mx > 0.0 && !wide) ? (float)ldexp(1.0, e) : 0.0f;
-            if (wide) {
-                const int w = j & 31, h = (w >> 2) & 1, g = (w & 3) + 4 * (w >> 3);
-                reinterpret_cast<float*>(consts)[((jt * 2 + h) * 16 + g) * 2 + 1] = __builtin_huge_valf();
+            float* tail = reinterpret_cast<float*>(consts) + T32 * 32;
+            if ((j & 31) == 0) {
+                tail[2 * jt] = (mx > 0.0 && !wide) ? (float)ldexp(1.0, e) : 0.0f;
+                tail[2 * jt + 1] = wide ? __builtin_huge_valf() : (float)(beta * 1.0001);
             }
         }
     }
@@ -150,7 +150,7 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
 #pragma unroll
         for (int a = 0; a < ND; ++a) im[((p * ND + a) * 64 + lane) * 16 + b] = (unsigned char)(d[a] & 0xff);
     }
-    for (int e = P * ND * 1024 + (ND == kBoundDigits ? T32 * 256 + 4 * T32 : T32 * 512) + threadIdx.x; e < img_bytes;
+    for (int e = P * ND * 1024 + (ND == kBoundDigits ? T32 * 128 + 8 * T32 : T32 * 512) + threadIdx.x; e < img_bytes;
          e += blockDim.x)
         im[e] = 0;
 }
@@ -294,7 +294,8 @@ struct i8_order {
 template <int ND, int T32, bool REV, int E>
 __device__ __forceinline__ void i8_steps(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3], const i4v (&xd)[ND][T32],
                                          i16v (&acc)[ND], i4v (&sb)[2][2]) {
-    constexpr int CSTRIDE = ND == kBoundDigits ? 256 : 512;       // bytes of row constants per output block
+    constexpr bool BND = ND == kBoundDigits;
+    constexpr int CSTRIDE = BND ? 128 : 512;                      // bytes of row constants per output block
     using ord = i8_order<ND, T32, REV>;
     constexpr int NS = tri_pairs(T32) * ND;
     constexpr int JT = ord::block_of(E), S = ord::layout_of(E);
@@ -303,9 +304,9 @@ __device__ __forceinline__ void i8_steps(unsigned frag_addr, unsigned const_addr
     if constexpr (E + 2 < NS) lds_read16<1024 * ord::layout_of(E + 2 < NS ? E + 2 : 0)>(ua[(E + 2) % 3], frag_addr);
     if constexpr (last) {
         lds_read16<JT * CSTRIDE + 0>(sb[0][0], const_addr);
-        lds_read16<JT * CSTRIDE + 16>(sb[0][1], const_addr);
+        if constexpr (!BND) lds_read16<JT * CSTRIDE + 16>(sb[0][1], const_addr);
     }
-    lds_wait<(E + 1 < NS) + (E + 2 < NS) + (last ? 2 : 0)>(ua[E % 3]);
+    lds_wait<(E + 1 < NS) + (E + 2 < NS) + (last ? (BND ? 1 : 2) : 0)>(ua[E % 3]);
     i8_step_mfma<ND, T32, IT, A>(ua[E % 3], xd, acc);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!last) i8_steps<ND, T32, REV, E + 1>(frag_addr, const_addr, ua, xd, acc, sb);
@@ -347,42 +348,37 @@ __device__ __forceinline__ void i8_rows(unsigned const_addr, const i16v (&acc)[N
 
 // Bound-pass epilogue (ND = 3) in plain f32 (measured with tools/overlap_probe.hip: next to int8 MFMAs, f32, f64 and
 // integer vector instructions overlap with the matrix pipe, packed-f32 ones do not).  With I = 128 t0 + acc2 (the exact
-// integer digit sum), m = 2^(en - 26) 2^e_jt and the row constants (b, beta) of the image:
-//   y = I m - b,   a = max(|y| (1 - 2^-20) - beta - 2^e_jt cef, 0)  <=  |y_exact|,
-// because  |y_exact - y| <= 2^e_jt 2^en i8_err  (digits)  + 2^-22 (|y| + |b|)  (f32: I to 24 bits, b to 24 bits, one
-// fma)  + the f64 rounding of b, and beta >= 2^-20 |b| + that rounding.  q accumulates a^2 in f32 (the caller takes off
-// 2^-16 of it).  A NaN y or an infinite cef / beta gives a = 0: the bound degrades to c_k, never lies.
-// Step GP covers this lane's rows 4 GP .. 4 GP + 3 of block JT: two 16-byte reads of (b, beta) pairs.
+// integer digit sum), m = 2^(en - 26) 2^e_jt and the row constant b of the image, y = I m - b satisfies
+//   |y_exact - y| <= c := 2^e_jt 2^en i8_err  (digits)  + 2^-22 (|y| + |b|)  (f32: I to 24 bits, b to 24 bits, one fma)
+//                          + the f64 rounding of b   <=   2^-20 |y| + beta_jt + 2^e_jt cef,
+// and with u = |y| (1 - 2^-20), e = beta_jt + 2^e_jt cef:   y_exact^2 >= (u - e)_+^2 >= u^2 - 2 e u.
+// So a block only accumulates Y2 = sum y^2 and A = sum |y| (7 instructions per row), and the caller forms
+// q >= (1 - 2^-19) Y2 - 2 (beta_jt + 2^e_jt cef) A.  A NaN y poisons Y2; an infinite cef / beta makes q = -inf, i.e.
+// the bound +inf ("candidate"): it never lies.  Step GP covers this lane's rows 4 GP .. 4 GP + 3 of block JT.
 template <int JT, int GP>
 __device__ __forceinline__ void i8_rows_bound(unsigned const_addr, const i16v (&acc)[kBoundDigits], i4v (&sb)[2][2],
-                                              float m, float ebc, float& q) {
-    if constexpr (GP + 1 < 4) {
-        lds_read16<JT * 256 + 32 * (GP + 1)>(sb[(GP + 1) & 1][0], const_addr);
-        lds_read16<JT * 256 + 32 * (GP + 1) + 16>(sb[(GP + 1) & 1][1], const_addr);
-    }
-    lds_wait<(GP + 1 < 4) ? 2 : 0>(sb[GP & 1][0], sb[GP & 1][1]);
-    union { i4v v; float f[4]; } r[2];
-    r[0].v = sb[GP & 1][0];
-    r[1].v = sb[GP & 1][1];
+                                              float m, float& y2, float& ya) {
+    if constexpr (GP + 1 < 4) lds_read16<JT * 128 + 16 * (GP + 1)>(sb[(GP + 1) & 1][0], const_addr);
+    lds_wait<(GP + 1 < 4) ? 1 : 0>(sb[GP & 1][0]);
+    union { i4v v; float f[4]; } r;
+    r.v = sb[GP & 1][0];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int g = 4 * GP + e;
-        const float b = r[e >> 1].f[2 * (e & 1)], beta = r[e >> 1].f[2 * (e & 1) + 1];
         const float tf = (float)((acc[0][g] << 7) + acc[1][g]);
         const float I = __builtin_fmaf(tf, 128.0f, (float)acc[2][g]);
-        const float y = __builtin_fmaf(I, m, -b);
-        const float d = __builtin_fmaf(__builtin_fabsf(y), 0.99999904632568359375f, -beta) - ebc;
-        const float a = __builtin_fmaxf(d, 0.0f);
-        q = __builtin_fmaf(a, a, q);
+        const float y = __builtin_fmaf(I, m, -r.f[e]);
+        y2 = __builtin_fmaf(y, y, y2);
+        ya += __builtin_fabsf(y);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (GP + 1 < 4) i8_rows_bound<JT, GP + 1>(const_addr, acc, sb, m, ebc, q);
+    if constexpr (GP + 1 < 4) i8_rows_bound<JT, GP + 1>(const_addr, acc, sb, m, y2, ya);
 }
 
 template <int ND, bool BOUND, int T32, bool REV, int O, typename QT>
 __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3],
                                                const i4v (&xd)[ND][T32], const i8_lane_consts& lc, const i4v& scales,
-                                               QT& q) {
+                                               const i4v& scales2, QT& q) {
     constexpr int JT = REV ? T32 - 1 - O : O;
     i16v acc[ND];
 #pragma unroll
@@ -390,13 +386,18 @@ __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned cons
     i4v sb[2][2];
     i8_steps<ND, T32, REV, i8_order<ND, T32, REV>::first_of(JT)>(frag_addr, const_addr, ua, xd, acc, sb);
     if constexpr (BOUND) {
+        // (2^e_jt, beta_jt) of the component's output blocks: `scales` holds blocks 0, 1; `scales2` blocks 2, 3
         union { i4v v; float f[4]; } sc;
-        sc.v = scales;                                   // 2^e_jt of the component's output blocks
-        i8_rows_bound<JT, 0>(const_addr, acc, sb, sc.f[JT] * lc.c2f, sc.f[JT] * lc.cef, q);
+        sc.v = JT < 2 ? scales : scales2;
+        const float sj = sc.f[2 * (JT & 1)], beta = sc.f[2 * (JT & 1) + 1];
+        float y2 = 0.0f, ya = 0.0f;
+        i8_rows_bound<JT, 0>(const_addr, acc, sb, sj * lc.c2f, y2, ya);
+        q = __builtin_fmaf(-2.0f * ya, __builtin_fmaf(sj, lc.cef, beta), __builtin_fmaf(y2, 0.9999980926513671875f, q));
     } else {
         i8_rows<ND, JT, 0>(const_addr, acc, sb, lc, q);
     }
-    if constexpr (O + 1 < T32) i8_blocks_from<ND, BOUND, T32, REV, O + 1>(frag_addr, const_addr, ua, xd, lc, scales, q);
+    if constexpr (O + 1 < T32)
+        i8_blocks_from<ND, BOUND, T32, REV, O + 1>(frag_addr, const_addr, ua, xd, lc, scales, scales2, q);
 }
 
 // One component for one wave tile; `im_lds` is the LDS byte address of the component's image.
@@ -412,19 +413,21 @@ __device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&
     using ord = i8_order<ND, T32, REV>;
     constexpr int P = tri_pairs(TI);
     const unsigned frag_addr = im_lds + lane * 16;                              // layout step s at + 1024 s
-    // row constants: ND = 6 (jt, g) at + 512 jt + 256 h + 16 g; bound pass (jt, g) at + 256 jt + 128 h + 8 g
-    const unsigned const_addr = im_lds + P * ND * 1024 + h * (BOUND ? 128 : 256);
+    // row constants: ND = 6 (jt, g) at + 512 jt + 256 h + 16 g; bound pass (jt, g) at + 128 jt + 64 h + 4 g
+    const unsigned const_addr = im_lds + P * ND * 1024 + h * (BOUND ? 64 : 256);
     typename std::conditional<BOUND, float, double>::type q = 0;
-    i4v scales = {0, 0, 0, 0};
+    i4v scales = {0, 0, 0, 0}, scales2 = {0, 0, 0, 0};
     if constexpr (BOUND) {
-        lds_read16<0>(scales, im_lds + P * ND * 1024 + TI * 256);
-        lds_wait<0>(scales);
+        lds_read16<0>(scales, im_lds + P * ND * 1024 + TI * 128);
+        lds_read16<16>(scales2, im_lds + P * ND * 1024 + TI * 128);
+        lds_wait<0>(scales, scales2);
     }
     i4v ua[3];
     lds_read16<1024 * ord::layout_of(0)>(ua[0], frag_addr);
     lds_read16<1024 * ord::layout_of(1)>(ua[1], frag_addr);
-    i8_blocks_from<ND, BOUND, T32, REV, 0>(frag_addr, const_addr, ua, xd, lc, scales, q);
+    i8_blocks_from<ND, BOUND, T32, REV, 0>(frag_addr, const_addr, ua, xd, lc, scales, scales2, q);
     q += __shfl_xor(q, 32);
+    if constexpr (BOUND) q = (q < 0) ? 0 : q;       // a negative lower bound of a square says nothing (NaN passes)
     const int64_t row = n0 + c;
     // BOUND: an upper bound of ln rho; 2^-16 of q covers the f32 rounding of its 128 squares and additions
     const double v = BOUND ? fma(-0.5 * (double)q, 1.0 - 1.52587890625e-05, ck + 1e-12 * fabs(ck)) : ck - 0.5 * (double)q;
