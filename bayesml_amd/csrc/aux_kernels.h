@@ -159,6 +159,7 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
 // MODE 0 (best)  : the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
 // MODE 1 (near)  : ln rho[khat_n][n] is exact now; the mask holds every other k with u[k][n] >= it - 100 ln 2.
 // MODE 2 (active): the M-step's samples: every k with ln r_nk = u[k][n] - lse[n] >= thr[k] (mstep.h).
+// MODE 3 (given) : like MODE 0 with khat already written (by the bound kernel): u is not read.
 template <int MODE>
 __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __restrict__ u, int64_t npad, int64_t n_rows,
                                                                int K, int* __restrict__ khat,
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
         lim = u[(int64_t)kh * npad + n] - 69.314718055994530942;
     }
     if (MODE == 2 && valid) lim = lse[n];
+    if (MODE == 3 && valid) kh = khat[n];
     if (MODE == 0) {
         int arg = 0;
         if (valid) {

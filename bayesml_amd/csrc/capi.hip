@@ -398,6 +398,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (ws->img_i8b) {
             EstepI8Args ab = a8;
             ab.img = ws->img_i8b;
+            ab.khat = ws->khat;             // the bound kernel also finds every row's best component
             e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, &name);
         } else {
             e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
@@ -406,7 +407,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         int counts_host[256];
         const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
         for (int round = 0; round < 2; ++round) {
-            if (round == 0)
+            if (round == 0 && ws->img_i8b)
+                hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
+                                   n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
+            else if (round == 0)
                 hipLaunchKernelGGL(select_mask_kernel<0>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
                                    n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
             else

@@ -407,7 +407,7 @@ __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned cons
 // T32 = output blocks evaluated (and x blocks held), TI >= T32 = blocks of the image (its leading tri_pairs(T32) block
 // pairs are exactly the ones needed).
 template <int ND, bool BOUND, int T32, int TI, bool REV>
-__device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&xd)[ND][T32], double ck,
+__device__ __forceinline__ double estep_i8_component(unsigned im_lds, const i4v (&xd)[ND][T32], double ck,
                                                    const i8_lane_consts& lc, int lane, int c, int h, int64_t n0,
                                                    int64_t n_rows, double* __restrict__ lnrho_k) {
     using ord = i8_order<ND, T32, REV>;
@@ -432,6 +432,7 @@ __device__ __forceinline__ void estep_i8_component(unsigned im_lds, const i4v (&
     // BOUND: an upper bound of ln rho; 2^-16 of q covers the f32 rounding of its 128 squares and additions
     const double v = BOUND ? fma(-0.5 * (double)q, 1.0 - 1.52587890625e-05, ck + 1e-12 * fabs(ck)) : ck - 0.5 * (double)q;
     if (h == 0 && row < n_rows) lnrho_k[row] = v;
+    return v;
 }
 
 // ND = 6: the E-step.  ND = 3, BOUND: upper bounds of ln rho for the pruned E-step (estep.h) from three digits per
@@ -443,7 +444,8 @@ template <int ND, bool BOUND, int T32, int TB, typename XT, bool VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                                     const unsigned char* __restrict__ img /*[K][IMGB]*/,
                                                     const double* __restrict__ pivot, const double* __restrict__ cvec,
-                                                    int K, double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
+                                                    int K, double* __restrict__ lnrho /*[K][npad]*/, int64_t npad,
+                                                    int* __restrict__ khat /*[n_rows] first maximiser over k, or null*/) {
     constexpr int IMGB = i8_img_bytes(ND, T32);
     constexpr int KB = i8_kb(ND, T32);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][KB * IMGB];   // the ONLY LDS object of the kernel
@@ -487,6 +489,8 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        double best = -__builtin_huge_val();
+        int arg = 0;
         for (int kb = 0; kb < n_blocks; ++kb) {
             if (kb + 1 < n_blocks) stage(kb + 1, (kb + 1) & 1);
             const unsigned buf = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem[kb & 1]);
@@ -495,16 +499,22 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
             for (int kk = 0; kk < KB; ++kk) {
                 const int k = k0 + kk;
                 if (k >= K) break;
+                double v;
                 if (T32 > 1 && wave >= NW / 2)      // the second wave of each SIMD (wave uniform: no divergence)
-                    estep_i8_component<ND, BOUND, TB, T32, true>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
-                                                                 n_rows, lnrho + (int64_t)k * npad);
+                    v = estep_i8_component<ND, BOUND, TB, T32, true>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
+                                                                     n_rows, lnrho + (int64_t)k * npad);
                 else
-                    estep_i8_component<ND, BOUND, TB, T32, false>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
-                                                                  n_rows, lnrho + (int64_t)k * npad);
+                    v = estep_i8_component<ND, BOUND, TB, T32, false>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
+                                                                      n_rows, lnrho + (int64_t)k * npad);
+                if (v > best) {
+                    best = v;
+                    arg = k;
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        if (khat && h == 0 && n0 + c < n_rows) khat[n0 + c] = arg;
     }
 }
 
