@@ -50,13 +50,15 @@ __global__ void center_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_
 constexpr int kLseRows = 1024;      // rows per block (256 threads x 4)
 // apart[block] = number of (row, component) pairs of the block with ln r >= -100 ln 2 (how sparse r is: the next
 // E-step prunes only when that fraction is small).
+// `stride` > 1: only every stride-th block of rows is visited (a sample of the rows: its maxima are lower bounds of the
+// true ones, which is all a skip threshold needs; see lse_mask_kernel).
 __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
                                                       int K, double* __restrict__ lse, double* __restrict__ dpart,
-                                                      double* __restrict__ apart) {
+                                                      double* __restrict__ apart, int stride) {
     __shared__ double wmax[4];
     __shared__ int wcnt[4];
     int active = 0;
-    const int64_t base = (int64_t)blockIdx.x * kLseRows + threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * stride * kLseRows + threadIdx.x;
     double l[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__
     for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o);
     if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = active;
     __syncthreads();
-    if (threadIdx.x == 0) apart[blockIdx.x] = (double)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+    if (threadIdx.x == 0 && apart) apart[blockIdx.x] = (double)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
 }
 
 // thr[k] = max over blocks of dpart[.][k] - 100 ln 2 (mstep.h, sparse responsibilities); act_total = sum of apart.
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpa
     __shared__ double part[256];
     const int k = blockIdx.x;
     if (k == K) {
+        if (!apart) return;
         double a = 0.0;
         for (int b = threadIdx.x; b < blocks; b += 256) a += apart[b];
         part[threadIdx.x] = a;
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpa
         }
         return;
     }
+    if (!dpart) return;
     double d = -__builtin_huge_val();
     for (int b = threadIdx.x; b < blocks; b += 256) {
         const double v = dpart[(int64_t)b * K + k];
@@ -291,6 +295,65 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
                 lists[(int64_t)k * cap + off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int)n;
         }
     }
+}
+
+// lse[n] for every row, and in the same pass the M-step's active mask (ln r_nk >= thr[k], as select_mask_kernel<2>),
+// its block counts, and the number of pairs with ln r >= -100 ln 2 per block (apart).  thr comes from a sample of
+// the rows (row_lse_kernel with a stride): a maximum over fewer rows is smaller, the threshold lower, the lists at
+// worst a little longer - never a relevant sample dropped.  One thread per row, 256 rows per block.
+__global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
+                                                            int K, const double* __restrict__ thr, double* __restrict__ lse,
+                                                            unsigned long long* __restrict__ masks,
+                                                            int* __restrict__ blk_cnt, double* __restrict__ apart) {
+    __shared__ int wcnt[4][256];
+    __shared__ int wact[4];
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
+    const bool valid = n < n_rows;
+    const int W = (K + 63) / 64;
+    const int wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    double l = 0.0;
+    if (valid) {
+        double mx = lnrho[n], s = 1.0;
+        for (int k = 1; k < K; ++k) {
+            const double v = lnrho[(int64_t)k * npad + n];
+            if (v > mx) {
+                s = fma(s, exp(mx - v), 1.0);
+                mx = v;
+            } else {
+                s += exp(v - mx);
+            }
+        }
+        l = mx + log(s);
+        lse[n] = l;
+    }
+    int active = 0;
+    for (int w = 0; w < W; ++w) {
+        unsigned long long mk = 0;
+        if (valid) {
+            const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
+            for (int b = 0; b < kend; ++b) {
+                const double t = lnrho[(int64_t)(64 * w + b) * npad + n] - l;
+                mk |= (unsigned long long)(!(t < thr[64 * w + b])) << b;   // NaN stays active
+                active += !(t < -69.314718055994530942);
+            }
+            masks[(int64_t)w * npad + n] = mk;
+        }
+        unsigned long long present = wave_or(mk);
+        while (present) {
+            const int b = __builtin_ctzll(present);
+            present &= present - 1;
+            const int c = __builtin_popcountll(__ballot((mk >> b) & 1ull));
+            if ((threadIdx.x & 63) == 0) wcnt[wave][64 * w + b] = c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o);
+    if ((threadIdx.x & 63) == 0) wact[wave] = active;
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += kSelRows)
+        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    if (threadIdx.x == 0) apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
 }
 
 // r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0

@@ -101,7 +101,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
         {&ws->xc, 0},
         {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K},
-        {&ws->apart, (ws->npad + kLseRows - 1) / kLseRows}, {&ws->act_total, 1}};
+        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->act_total, 1}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
         if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
@@ -461,17 +461,29 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->ev_e = true;
     }
     const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
-    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)lse_blocks), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                       ws->lse, ws->sparse ? ws->dpart : nullptr, ws->apart);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
-    if (ws->sparse) {
-        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)(ws->K + 1)), dim3(256), 0, st, ws->dpart, ws->apart, lse_blocks,
-                           ws->K, ws->thr, ws->act_total);
+    if (ws->sparse && ws->masks) {
+        // thresholds from a sample of the rows (every 16th block of 1024), then lse + active masks + counts in one pass
+        const int stride = lse_blocks >= 64 ? 16 : 1;
+        const int sampled = (lse_blocks + stride - 1) / stride;
+        const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
+        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)sampled), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                           ws->lse, ws->dpart, nullptr, stride);
+        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)ws->K), dim3(256), 0, st, ws->dpart, nullptr, sampled, ws->K, ws->thr,
+                           ws->act_total);
+        hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)nblk), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                           ws->thr, ws->lse, ws->masks, ws->blk, ws->apart);
+        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)(ws->K + 1)), dim3(256), 0, st, nullptr, ws->apart, nblk, ws->K,
+                           ws->thr, ws->act_total);
         e = hipGetLastError();
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "thr_kernel launch", e);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse / lse_mask launch", e);
         ws->act_rows = n_rows;
         ws->act_host = -1.0;
+        ws->active_lists = false;
+    } else {
+        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)lse_blocks), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                           ws->lse, nullptr, nullptr, 1);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
     }
     ws->e_state = 1;
     ws->e_rows = n_rows;
@@ -527,7 +539,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     const char* name = "";
     hipError_t e;
-    bool sparse = ws->sparse && pre && ws->e_state == 1 && ws->act_rows == n_rows;
+    bool sparse = ws->sparse && ws->masks && pre && ws->e_state == 1 && ws->act_rows == n_rows;
     if (sparse) {      // the lists pay off when most pairs are negligible
         double act = 0.0;
         rc = fetch_active(ws, st, &act);
@@ -545,13 +557,15 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         rows_per_split = (int64_t)bps * kSelRows;
         S = (n_rows + rows_per_split - 1) / rows_per_split;
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
-        hipLaunchKernelGGL(select_mask_kernel<2>, dim3(nblk), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->khat, ws->lse, ws->thr, ws->masks, ws->blk);
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, nblk, ws->K, ws->counts);
-        hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
-                           ws->blk, ws->lists, ws->npad);
-        e = hipGetLastError();
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);
+        // masks and block counts of the active pairs were written by lse_mask_kernel at the end of the E-step
+        if (!ws->active_lists) {
+            hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, nblk, ws->K, ws->counts);
+            hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
+                               ws->blk, ws->lists, ws->npad);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);
+            ws->active_lists = true;
+        }
         grid = 8 * ((S + 7) / 8) * KG;
         MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->blk, ws->counts, nblk, bps,
                          ws->npad, ws->K, KG, (int)S, ws->slabs};

@@ -44,7 +44,8 @@ struct gmmvb_workspace {
     // pruned E-step (estep.h): env GMMVB_ESTEP_PRUNE = 0 never | force always | default: when the previous E-step
     // over the same rows left at most half of the pairs relevant and N K >= 2^23
     int prune = 1;
-    int* lists = nullptr;      // [K][npad] sample lists, allocated at first use
+    int* lists = nullptr;      // [K][npad] sample lists (E-step candidates, then the M-step's active rows)
+    bool active_lists = false; // the lists currently hold the active rows of the last E-step (scan + fill done)
     int* khat = nullptr;       // [npad]
     int* counts = nullptr;     // [K]
     int* blk = nullptr;        // [ceil(npad / 256)][K] candidates per selection block -> block bases
