@@ -332,14 +332,18 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
                                  '"subsampling" and "random_responsibility"')
             s_prev = s
             terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
+            # the next K-side update only needs the statistics: enqueue it before the lower bound is read back, so
+            # that the GPU runs it while the host would otherwise be waiting (it is dropped if the loop ends here)
+            q_next = _kside.update_q(prior, ns, x_bar, s) if max_itr > 0 else None
             vl = float(terms["vl"])
             self._say(f"\r{i}. VL: {vl}")
             for t in range(max_itr):
                 vl_before = vl
-                q = _kside.update_q(prior, ns, x_bar, s)
+                q = q_next
                 ns, x_bar, s, h = self._pass(eng, xd, q, s_prev)
                 s_prev = s
                 terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
+                q_next = _kside.update_q(prior, ns, x_bar, s) if t + 1 < max_itr else None
                 vl = float(terms["vl"])                      # the one host sync per iteration
                 self._say(f"\r{i}. VL: {vl} t={t} ")
                 with np.errstate(divide="ignore", invalid="ignore"):

@@ -167,11 +167,16 @@ def main():
     s_prev = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
     ns, x_bar, s, h = m._pass(eng, xd, q, s_prev)
 
+    q_next = _kside.update_q(prior, ns, x_bar, s)
+
     def step():
-        nonlocal q, ns, x_bar, s, h
-        q = _kside.update_q(prior, ns, x_bar, s)
+        # as in update_posterior's loop: the next K-side update is enqueued before the lower bound is read back
+        nonlocal q, q_next, ns, x_bar, s, h
+        q = q_next
         ns, x_bar, s, h = m._pass(eng, xd, q, s)
-        return float(_kside.lower_bound(prior, q, ns, x_bar, s, h)["vl"])
+        vl = _kside.lower_bound(prior, q, ns, x_bar, s, h)["vl"]
+        q_next = _kside.update_q(prior, ns, x_bar, s)
+        return float(vl)
 
     def snapshot():
         a, e = eng.sparsity()
