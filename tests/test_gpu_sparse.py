@@ -171,3 +171,50 @@ def test_int8_digit_estep_variant():
         assert np.max(np.abs(a - b)) < 2e-11 * np.max(np.abs(a))
         if N >= D * D:       # sqrt(N) >= D: full-rank initial covariances, well conditioned
             assert np.max(np.abs(a - b)) < 1e-7
+
+
+@pytest.mark.parametrize("K,D,N,dtype,pad", [
+    (3, 49, 5000, np.float32, 0),        # smallest D that prunes (two 32-row blocks, masked loads)
+    (70, 64, 3000, np.float64, 0),       # more than 64 components: two mask words
+    (130, 80, 2049, np.float32, 3),      # three mask words, T32 = 3, misaligned rows (ldx = 83)
+    (9, 100, 4097, np.float32, 0),       # D % 16 != 0 at T32 = 4
+    (17, 128, 2500, np.float64, 0),      # f64 rows at the widest D
+    (2, 96, 70, np.float32, 0),          # fewer rows than one selection block
+    (256, 64, 1500, np.float32, 0),      # the largest K the lists support
+])
+def test_sparse_path_shapes(K, D, N, dtype, pad):
+    """Forced pruning on ragged shapes: the statistics of one data pass (second call, so that the first one's
+    sparsity count is there) equal the dense kernels' for parameters a few iterations into a fit."""
+    from bayesml_amd import _kside
+    rng = np.random.default_rng(K * 1000 + D)
+    K_data = max(2, min(K, 12))
+    wide = np.zeros((N, D + pad), dtype=dtype)
+    wide[:, :D] = orc.synth_gmm(K_data, D, N, dtype)
+    x = wide[:, :D]
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(wide).to(dev)[:, :D]
+    # parameters: components on the data's clusters (some duplicated / empty when K > K_data), unit-ish covariances
+    means = 2.0 * np.random.default_rng(20250711).standard_normal((K_data, D))
+    p = orc.Prior.default(K, D)
+    q = orc.Posterior.from_prior(p)
+    q.m = means[rng.integers(0, K_data, K)] + 0.05 * rng.standard_normal((K, D))
+    a = 0.05 * rng.standard_normal((K, D, D))
+    q.nu = q.nu + 50.0
+    q.w_inv = (np.eye(D) + a @ np.swapaxes(a, 1, 2)) * q.nu[:, None, None]
+    q.w = np.linalg.inv(q.w_inv)
+    q.kappa = q.kappa + 50.0
+    q.alpha = q.alpha + rng.uniform(1, 50, K)
+    q.refresh_pi()
+    q.refresh_lambda()
+    t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+    qd = _kside.features(_kside.PostT(t(q.alpha), t(q.m), t(q.kappa), t(q.nu), t(q.w_inv)))
+    pivot = xd[:4096].to(torch.float64).mean(dim=0)
+    dense = _pass(xd, qd, DENSE, pivot)
+    sparse = _pass(xd, qd, SPARSE, pivot)
+    assert "_bound" in sparse[1][2], sparse[1][2]
+    for (sa, ra, _), (sb, rb, _) in zip(dense, sparse):
+        assert rel_err(sb, sa) < 1e-12
+        assert np.max(np.abs(ra - rb)) < 1e-12
+    # and against the oracle's formulation
+    st = orc.data_pass(x.astype(np.float64), q)
+    assert np.max(np.abs(sparse[1][1] - st.r)) < 1e-9
