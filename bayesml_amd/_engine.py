@@ -29,6 +29,7 @@ SYMBOLS = {
     "gmmvb_workspace_bytes": (_i64, [_vp]),
     "gmmvb_set_pivot": (_int, [_vp, _vp, _vp]),
     "gmmvb_set_params": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "gmmvb_set_drift": (_int, [_vp, _vp, _vp, _vp]),
     "gmmvb_prepare_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_estep": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_load_responsibilities": (_int, [_vp, _vp, _i64, _vp]),
@@ -189,6 +190,14 @@ class DataPass:
             _check(self.lib, self.lib.gmmvb_set_params(self._ws, c.data_ptr(), m.data_ptr(), u.data_ptr(),
                                                        self._stream()), "gmmvb_set_params")
         self._keep = [c, m, u]
+
+    def set_drift(self, gamma, delta):
+        """Hint for the pruned E-step (gmmvb_set_drift): call before the set_params of the updated parameters."""
+        g = _f64(gamma, (self.K,), self.device)
+        d = _f64(delta, (self.K,), self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_set_drift(self._ws, g.data_ptr(), d.data_ptr(), self._stream()),
+                   "gmmvb_set_drift")
 
     def estep(self, x: torch.Tensor):
         x, ldx = self._x(x)

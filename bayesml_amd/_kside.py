@@ -115,6 +115,37 @@ def post_from_prior(p: PriorT) -> PostT:
     return features(PostT(p.alpha.clone(), p.m.clone(), p.kappa.clone(), p.nu.clone(), p.w_inv.clone()))
 
 
+def drift(q_old, q_new, squarings: int = 8):
+    """(gamma, delta) of gmmvb_set_drift for the parameter update q_old -> q_new: per component
+    gamma <= sigma_min(u_new u_old^-1) and delta >= ||u_new (m_new - m_old)||, so that
+    ||u_new (x - m_new)|| >= gamma ||u_old (x - m_old)|| - delta for every x.
+
+    sigma_min(u_new u_old^-1) = 1 / ||A||_2 with A = u_old u_new^-1 (triangular solve), and
+    ||A||_2^2 = lambda_max(G), G = A^T A, is bounded from above by ||G^(2^s)||_F^(1/2^s): s repeated squarings with
+    the Frobenius norms divided out (their logarithms summed with weights 2^-i), 1.9 % above the true value at
+    D = 128, s = 8.  Everything is K batched D x D products: a few tens of microseconds."""
+    a = torch.linalg.solve_triangular(q_new.u, q_old.u, upper=False, left=False)      # A u_new = u_old
+    g = a.transpose(1, 2) @ a
+    f = torch.linalg.matrix_norm(g)
+    log_lmax = torch.log(f)
+    g = g / f[:, None, None]
+    w = 0.5
+    for _ in range(squarings):
+        g = g @ g
+        f = torch.linalg.matrix_norm(g)
+        log_lmax = log_lmax + w * torch.log(f)
+        g = g / f[:, None, None]
+        w *= 0.5
+    gamma = torch.exp(-0.5 * log_lmax) * (1.0 - 1e-9)
+    d = (q_new.u @ (q_new.m - q_old.m)[:, :, None])[:, :, 0]
+    delta = torch.linalg.vector_norm(d, dim=1) * (1.0 + 1e-9)
+    # anything non-finite: no information (gamma = 0 makes every carried bound the trivial one)
+    bad = ~(torch.isfinite(gamma) & torch.isfinite(delta))
+    gamma = torch.where(bad, torch.zeros_like(gamma), gamma)
+    delta = torch.where(bad, torch.zeros_like(delta), delta)
+    return gamma, delta
+
+
 def moments_from_stats(ns, a, B, pivot, s_prev):
     """Engine statistics (about ``pivot``) -> the reference's (x_bar_vecs, s_mats).
 

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
 __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
                                                             int K, const double* __restrict__ thr, double* __restrict__ lse,
                                                             unsigned long long* __restrict__ masks,
-                                                            int* __restrict__ blk_cnt, double* __restrict__ apart) {
+                                                            int* __restrict__ blk_cnt, double* __restrict__ apart,
+                                                            int* __restrict__ khat /*first maximiser, or null*/) {
     __shared__ int wcnt[4][256];
     __shared__ int wact[4];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
@@ -315,17 +316,20 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
     double l = 0.0;
     if (valid) {
         double mx = lnrho[n], s = 1.0;
+        int arg = 0;
         for (int k = 1; k < K; ++k) {
             const double v = lnrho[(int64_t)k * npad + n];
             if (v > mx) {
                 s = fma(s, exp(mx - v), 1.0);
                 mx = v;
+                arg = k;
             } else {
                 s += exp(v - mx);
             }
         }
         l = mx + log(s);
         lse[n] = l;
+        if (khat) khat[n] = arg;
     }
     int active = 0;
     for (int w = 0; w < W; ++w) {
@@ -354,6 +358,25 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
     for (int k = threadIdx.x; k < K; k += kSelRows)
         blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (threadIdx.x == 0) apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
+}
+
+// Pruned E-step without a bound pass (gmmvb_set_drift): v = value or upper bound of ln rho under the old parameters,
+// so q_old >= 2 (c_old - v); with || u' (x - m') || >= gamma || u (x - m) || - delta the new parameters give
+// q' >= (gamma sqrt(2 (c_old - v)) - delta)_+^2, i.e. the upper bound c' - q'/2.  The slack factors cover the
+// rounding of this line; a NaN turns into "no bound" (c'), never into a finite lie.
+__global__ void carry_bounds_kernel(double* __restrict__ lnrho, int64_t npad, int64_t n_rows, int K,
+                                    const double* __restrict__ drift /*gamma, delta, c_old*/,
+                                    const double* __restrict__ c_new) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (n >= n_rows) return;
+    const double gamma = drift[k], delta = drift[K + k], c_old = drift[2 * K + k], cn = c_new[k];
+    const double v = lnrho[(int64_t)k * npad + n];
+    double q = 2.0 * (c_old - v);
+    q = q > 0.0 ? q : 0.0;                                    // also NaN -> 0
+    double y = gamma * sqrt(q) * (1.0 - 1e-12) - delta;
+    y = y > 0.0 ? y : 0.0;
+    lnrho[(int64_t)k * npad + n] = cn - 0.5 * y * y * (1.0 - 1e-12) + 1e-12 * fabs(cn);
 }
 
 // r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0

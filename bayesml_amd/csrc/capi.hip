@@ -101,7 +101,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
         {&ws->xc, 0},
         {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K},
-        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->act_total, 1}};
+        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->act_total, 1}, {&ws->drift, 3 * (int64_t)K}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
         if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
@@ -160,7 +160,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
-                      ws->apart, ws->act_total};
+                      ws->apart, ws->act_total, ws->drift};
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk};
     for (int* p : ibufs)
         if (p) (void)hipFree(p);
@@ -218,6 +218,20 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
     return GMMVB_OK;
 }
 
+int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* delta_dev, void* stream) {
+    if (!ws || !gamma_dev || !delta_dev) return fail(GMMVB_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(ws->drift, gamma_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(ws->drift + ws->K, delta_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
+    // the constants of the parameters the ln rho array belongs to (the next gmmvb_set_params overwrites cvec)
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(ws->drift + 2 * ws->K, ws->cvec, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(drift)", e);
+    ws->have_drift = ws->have_params && ws->params_used;     // else: not the parameters the ln rho array belongs to
+    return GMMVB_OK;
+}
+
 int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_dev, const double* u_dev,
                      void* stream) {
     if (!ws || !c_dev || !m_dev || !u_dev) return fail(GMMVB_EINVAL, "null argument");
@@ -236,6 +250,7 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
         if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_i8_kernel", e);
     }
     ws->have_params = true;
+    ws->params_used = false;
     return GMMVB_OK;
 }
 
@@ -349,7 +364,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
         if (pin && std::atoi(pin) >= 1 && std::atoi(pin) <= t32) {
             ws->bound_tb = std::atoi(pin);
-        } else if (ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
+        } else if (ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows && ws->prev_pass == 1) {
             double act = 0.0;
             rc = fetch_active(ws, st, &act);
             if (rc) return rc;
@@ -380,6 +395,21 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             ws->bound_tb = best;
         }
     }
+    // Carry the previous pass's values / bounds over the parameter update instead of bounding every pair again
+    // (gmmvb_set_drift)?  Up to 8 passes in a row, and not once the spare candidates of the last carried pass
+    // (candidates that turned out inactive; they grow by about half per pass) would cost the exact pass more than
+    // a real bound pass costs (same cost model as for the bound level): then the bounds are refreshed.
+    bool carry = prune && ws->have_drift && ws->bounds_rows == n_rows && ws->masks && ws->carried < 8 &&
+                 std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
+    if (carry && ws->prev_pass == 2 && ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
+        double act = 0.0;
+        rc = fetch_active(ws, st, &act);
+        if (rc) return rc;
+        const double pairs = (double)n_rows * ws->K;
+        const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
+        const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
+        carry = 1.5 * gpp * (ws->evaluated_prev - act) / pairs < bound_cost;
+    }
     ws->evaluated_prev = -1.0;
     if (prune) {
         rc = ensure_lists(ws);
@@ -387,27 +417,41 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     int rpw = 0;
     int64_t grid = 0;
+    bool pruned_fell_back = false;
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
     ws->evaluated = prune ? 0.0 : (double)n_rows * ws->K;
     if (!prune)      // a dense pass: whatever was learnt about the bound levels belongs to another regime
         for (double& c : ws->tb_cand) c = -1.0;
     if (prune) {
-        rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
-        grid = (n_rows + rpw - 1) / rpw;
-        if (grid > (1 << 20)) grid = 1 << 20;
-        if (ws->img_i8b) {
-            EstepI8Args ab = a8;
-            ab.img = ws->img_i8b;
-            ab.khat = ws->khat;             // the bound kernel also finds every row's best component
-            e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, &name);
+        if (carry) {
+            rpw = 256;
+            grid = (n_rows + 255) / 256;
+            hipLaunchKernelGGL(carry_bounds_kernel, dim3((unsigned)grid, (unsigned)ws->K), dim3(256), 0, st, ws->lnrho,
+                               ws->npad, n_rows, ws->K, ws->drift, ws->cvec);
+            e = hipGetLastError();
+            name = "estep_carried_bounds";
+            ++ws->carried;
         } else {
-            e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
+            rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
+            grid = (n_rows + rpw - 1) / rpw;
+            if (grid > (1 << 20)) grid = 1 << 20;
+            if (ws->img_i8b) {
+                EstepI8Args ab = a8;
+                ab.img = ws->img_i8b;
+                ab.khat = ws->khat;             // the bound kernel also finds every row's best component
+                e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, &name);
+            } else {
+                e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
+            }
+            ws->carried = 0;
         }
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
+        const bool have_khat = carry || ws->img_i8b != nullptr;
+        bool& fell_back = pruned_fell_back;
         int counts_host[256];
         const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
         for (int round = 0; round < 2; ++round) {
-            if (round == 0 && ws->img_i8b)
+            if (round == 0 && have_khat)
                 hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
                                    n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
             else if (round == 0)
@@ -436,7 +480,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
                 ws->evaluated = (double)n_rows * ws->K;
                 ws->evaluated_prev = -1.0;
-                if (ws->img_i8b) {          // this level left everything a candidate: remember, and go back up
+                fell_back = true;
+                if (ws->img_i8b && !carry) {   // this level left everything a candidate: remember, and go back up
                     ws->tb_cand[ws->bound_tb] = 1.0;
                     ws->tb_seen[ws->bound_tb] = 0;
                     if (ws->bound_tb < (ws->D + 31) / 32) ++ws->bound_tb;
@@ -471,7 +516,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         hipLaunchKernelGGL(thr_kernel, dim3((unsigned)ws->K), dim3(256), 0, st, ws->dpart, nullptr, sampled, ws->K, ws->thr,
                            ws->act_total);
         hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)nblk), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->thr, ws->lse, ws->masks, ws->blk, ws->apart);
+                           ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
         hipLaunchKernelGGL(thr_kernel, dim3((unsigned)(ws->K + 1)), dim3(256), 0, st, nullptr, ws->apart, nblk, ws->K,
                            ws->thr, ws->act_total);
         e = hipGetLastError();
@@ -487,6 +532,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     ws->e_state = 1;
     ws->e_rows = n_rows;
+    ws->params_used = true;
+    ws->have_drift = false;
+    ws->bounds_rows = n_rows;          // the ln rho array now belongs to the parameters in force
+    if (!prune || pruned_fell_back) ws->carried = 0;
+    ws->prev_pass = (!prune || pruned_fell_back) ? 0 : (ws->carried > 0 ? 2 : 1);
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
                   (i8 || prune) ? 512 : estep_threads(ws->estep_variant), rpw);
     return GMMVB_OK;

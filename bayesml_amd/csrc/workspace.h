@@ -31,6 +31,15 @@ struct gmmvb_workspace {
     double tb_act[5] = {0.0, 0.0, 0.0, 0.0, 0.0};      // active pairs per pair when tb_cand[L] was observed
     int tb_seen[5] = {0, 0, 0, 0, 0};
     double evaluated_prev = -1.0;      // candidates of the last pruned E-step (-1: it did not prune)
+    // carrying bounds over a parameter update (gmmvb_set_drift): gamma / delta of the pending update, the c vector of
+    // the last E-step, whether the ln rho array holds values / bounds for those parameters on `bounds_rows` rows,
+    // and how many E-steps in a row have lived on carried bounds
+    double* drift = nullptr;           // [3][K]: gamma, delta, c of the last E-step
+    bool have_drift = false;
+    bool params_used = false;          // the parameters in force were the ones of the last E-step
+    int64_t bounds_rows = 0;
+    int carried = 0;
+    int prev_pass = 0;                 // last E-step: 0 dense, 1 bound pass, 2 carried bounds
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)

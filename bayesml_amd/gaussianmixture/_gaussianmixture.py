@@ -301,9 +301,13 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._ln_b_hn_w_nus[:] = _np(q.ln_b_w_nu)
 
     # ------------------------------------------------------------------ device plumbing (see _device.py)
-    def _pass(self, eng, xd, q, s_prev, estep=True):
-        """One data pass: statistics block -> all-reduce over row shards -> reference moments."""
+    def _pass(self, eng, xd, q, s_prev, estep=True, q_from=None):
+        """One data pass: statistics block -> all-reduce over row shards -> reference moments.
+        ``q_from``: the posterior of the previous data pass over these rows, if this one continues it (lets the
+        engine carry its ln rho bounds over the update instead of recomputing them, see gmmvb_set_drift)."""
         if estep:
+            if q_from is not None and hasattr(eng, "set_drift"):
+                eng.set_drift(*_kside.drift(q_from, q))
             eng.set_params(q.c, q.m, q.u)
             stats = eng.estep_mstep(xd)
         else:
@@ -356,8 +360,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             self._say(f"\r{i}. VL: {vl}")
             for t in range(max_itr):
                 vl_before = vl
-                q = q_next
-                ns, x_bar, s, h = self._pass(eng, xd, q, s_prev)
+                q_last, q = q, q_next
+                ns, x_bar, s, h = self._pass(eng, xd, q, s_prev, q_from=q_last if init_type == "subsampling" or t > 0 else None)
                 s_prev = s
                 terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
                 q_next = _kside.update_q(prior, ns, x_bar, s) if t + 1 < max_itr else None

@@ -172,8 +172,8 @@ def main():
     def step():
         # as in update_posterior's loop: the next K-side update is enqueued before the lower bound is read back
         nonlocal q, q_next, ns, x_bar, s, h
-        q = q_next
-        ns, x_bar, s, h = m._pass(eng, xd, q, s)
+        q_last, q = q, q_next
+        ns, x_bar, s, h = m._pass(eng, xd, q, s, q_from=q_last)
         vl = _kside.lower_bound(prior, q, ns, x_bar, s, h)["vl"]
         q_next = _kside.update_q(prior, ns, x_bar, s)
         return float(vl)

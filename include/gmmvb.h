@@ -144,6 +144,15 @@ int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms)
  * static string such as "estep_mfma_f64<8,2,f32,vec> grid=1024x256". */
 const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
 
+/* Optional hint for the pruned E-step, to be given BEFORE the gmmvb_set_params of new parameters: for every component k
+ * gamma[k] <= sigma_min(u_new u_old^-1) and delta[k] >= || u_new (m_new - m_old) ||_2, where (m_old, u_old) are the
+ * parameters of the last gmmvb_estep.  Then || u_new (x - m_new) || >= gamma || u_old (x - m_old) || - delta for every
+ * x, which lets the next gmmvb_estep carry the previous pass's values and upper bounds of ln rho over to the new
+ * parameters (one elementwise pass) instead of bounding every pair afresh; pairs whose carried bound is no longer
+ * good enough are evaluated exactly as usual.  Loose values only cost candidates, wrong ones (gamma too large,
+ * delta too small) break the bounds.  The hint is consumed by the next gmmvb_estep. */
+int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev /*[K]*/, const double* delta_dev /*[K]*/, void* stream);
+
 /* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
  * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
  * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  *active_pairs = -1 when the

@@ -218,3 +218,56 @@ def test_sparse_path_shapes(K, D, N, dtype, pad):
     # and against the oracle's formulation
     st = orc.data_pass(x.astype(np.float64), q)
     assert np.max(np.abs(sparse[1][1] - st.r)) < 1e-9
+
+
+def test_carried_bounds_pass():
+    """gmmvb_set_drift: after a parameter update the E-step carries the previous pass's ln rho values / bounds over
+    (one elementwise pass) instead of bounding every pair again.  Three successive updates of a fitted posterior
+    (shrinking steps, like VB iterations), each pass compared with the dense kernels on the same parameters."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    K, D, N = 32, 96, 32_000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    m = _fit(x, K, 6, DENSE)
+    dev = torch.device("cuda", 0)
+    hn = m.get_hn_params()
+    t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+    base = (t(hn["hn_alpha_vec"]), t(hn["hn_m_vecs"]), t(hn["hn_kappas"]), t(hn["hn_nus"]), t(np.linalg.inv(hn["hn_w_mats"])))
+    gen = torch.Generator(device=dev).manual_seed(1)
+
+    def perturbed(scale):
+        a, mm, kap, nu, winv = (v.clone() for v in base)
+        mm += scale * torch.randn(mm.shape, dtype=torch.float64, device=dev, generator=gen)
+        e = scale * torch.randn(winv.shape, dtype=torch.float64, device=dev, generator=gen)
+        winv = winv + 0.5 * (e + e.transpose(1, 2)) * winv.diagonal(dim1=1, dim2=2).mean(dim=1)[:, None, None]
+        return _kside.features(_kside.PostT(a, mm, kap, nu, winv))
+
+    qs = [_kside.features(_kside.PostT(*(v.clone() for v in base)))] + [perturbed(s) for s in (0.05, 0.02, 0.01)]
+    xd = torch.from_numpy(x).to(dev)
+    pivot = xd[:4096].to(torch.float64).mean(dim=0)
+    engines = {}
+    for tag, env in (("dense", DENSE), ("sparse", SPARSE)):
+        with _env(env):
+            eng = DataPass(K, D, xd.dtype, N, dev)
+        eng.set_pivot(pivot)
+        eng.prepare_rows(xd)
+        engines[tag] = eng
+    carried = 0
+    for i, q in enumerate(qs):
+        out = {}
+        for tag, eng in engines.items():
+            if i > 0:
+                eng.set_drift(*_kside.drift(qs[i - 1], q))
+            eng.set_params(q.c, q.m, q.u)
+            out[tag] = (eng.estep_mstep(xd).cpu().numpy(), eng.responsibilities().cpu().numpy(), eng.launch_info)
+        carried += "estep_carried_bounds" in out["sparse"][2]
+        assert rel_err(out["sparse"][0], out["dense"][0]) < 1e-12, (i, out["sparse"][2])
+        assert np.max(np.abs(out["sparse"][1] - out["dense"][1])) < 1e-12
+    assert carried >= 2, "the drift hint was not used"
+    for eng in engines.values():
+        eng.close()
+    # the hint itself: gamma <= sigma_min(u_new u_old^-1) (checked against the SVD), tight to a few per cent
+    g, d = _kside.drift(qs[0], qs[1])
+    a = torch.linalg.solve_triangular(qs[0].u, qs[1].u, upper=False, left=False)       # u_new u_old^-1
+    smin = torch.linalg.svdvals(a)[:, -1]
+    assert bool(torch.all(g <= smin)) and bool(torch.all(g >= 0.95 * smin))
