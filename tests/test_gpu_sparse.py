@@ -238,8 +238,10 @@ def test_carried_bounds_pass():
     def perturbed(scale):
         a, mm, kap, nu, winv = (v.clone() for v in base)
         mm += scale * torch.randn(mm.shape, dtype=torch.float64, device=dev, generator=gen)
-        e = scale * torch.randn(winv.shape, dtype=torch.float64, device=dev, generator=gen)
-        winv = winv + 0.5 * (e + e.transpose(1, 2)) * winv.diagonal(dim1=1, dim2=2).mean(dim=1)[:, None, None]
+        rot = torch.eye(D, dtype=torch.float64, device=dev) + scale / np.sqrt(D) * torch.randn(
+            winv.shape, dtype=torch.float64, device=dev, generator=gen)
+        winv = rot @ winv @ rot.transpose(1, 2)                      # stays symmetric positive definite
+        winv = 0.5 * (winv + winv.transpose(1, 2))
         return _kside.features(_kside.PostT(a, mm, kap, nu, winv))
 
     qs = [_kside.features(_kside.PostT(*(v.clone() for v in base)))] + [perturbed(s) for s in (0.05, 0.02, 0.01)]
