@@ -325,6 +325,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->xc_src = x_dev;
     ws->xc_rows = n_rows;
     ws->xc_ldx = ldx;
+    ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
     return GMMVB_OK;
 }
 
@@ -399,7 +400,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // (gmmvb_set_drift)?  Up to 8 passes in a row, and not once the spare candidates of the last carried pass
     // (candidates that turned out inactive; they grow by about half per pass) would cost the exact pass more than
     // a real bound pass costs (same cost model as for the bound level): then the bounds are refreshed.
-    bool carry = prune && ws->have_drift && ws->bounds_rows == n_rows && ws->masks && ws->carried < 8 &&
+    bool carry = prune && ws->have_drift && ws->bounds_rows == n_rows && ws->bounds_x == x_dev &&
+                 ws->bounds_ldx == ldx && ws->masks && ws->carried < 8 &&
                  std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
     if (carry && ws->prev_pass == 2 && ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
         double act = 0.0;
@@ -534,7 +536,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->e_rows = n_rows;
     ws->params_used = true;
     ws->have_drift = false;
-    ws->bounds_rows = n_rows;          // the ln rho array now belongs to the parameters in force
+    ws->bounds_rows = n_rows;          // the ln rho array now belongs to the parameters in force, on these rows
+    ws->bounds_x = x_dev;
+    ws->bounds_ldx = ldx;
     if (!prune || pruned_fell_back) ws->carried = 0;
     ws->prev_pass = (!prune || pruned_fell_back) ? 0 : (ws->carried > 0 ? 2 : 1);
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
@@ -552,6 +556,7 @@ int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_
     if (e != hipSuccess) return fail(GMMVB_EHIP, "load_r launch", e);
     ws->e_state = 2;
     ws->e_rows = n_rows;
+    ws->bounds_rows = 0;               // the array holds responsibilities now, nothing a later E-step may carry over
     return GMMVB_OK;
 }
 

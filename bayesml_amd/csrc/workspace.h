@@ -37,7 +37,9 @@ struct gmmvb_workspace {
     double* drift = nullptr;           // [3][K]: gamma, delta, c of the last E-step
     bool have_drift = false;
     bool params_used = false;          // the parameters in force were the ones of the last E-step
-    int64_t bounds_rows = 0;
+    int64_t bounds_rows = 0;           // ... and of which matrix (0 / null: the array holds nothing that can be carried)
+    const void* bounds_x = nullptr;
+    int64_t bounds_ldx = 0;
     int carried = 0;
     int prev_pass = 0;                 // last E-step: 0 dense, 1 bound pass, 2 carried bounds
     double* cvec = nullptr;    // [K]
