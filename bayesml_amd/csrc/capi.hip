@@ -308,6 +308,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     bool vec = false;
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
     if (rc) return rc;
+    ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
     if (!ws->xc) return GMMVB_OK;      // disabled: the M-step reads x directly
     const int Dp = 16 * ws->T;
     const int64_t pad_rows = round_up(n_rows, 64) + 64;
@@ -325,7 +326,6 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->xc_src = x_dev;
     ws->xc_rows = n_rows;
     ws->xc_ldx = ldx;
-    ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
     return GMMVB_OK;
 }
 

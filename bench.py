@@ -218,7 +218,7 @@ def main():
         # algorithmic flops per sample: E = K(2D^2+3D) + 6K, M = K(2D^2+2D) + 2KD
         fl_e = K * (2 * D * D + 3 * D) + 6 * K
         fl_m = K * (2 * D * D + 2 * D) + 2 * K * D
-        names = [part.strip().split("<")[0] for part in eng.launch_info.split("|")]      # kernels of the last step
+        names = [part.strip().split("<")[0].split(" ")[0] for part in eng.launch_info.split("|")]   # kernels of the last step
         # executed f64 MFMA flops per evaluated (sample, component) pair: T(T+1)/2 tile pairs of 16x16 x 512 flops
         tiles = (D + 15) // 16
         fl_pair = 512 * tiles * (tiles + 1) // 2
@@ -226,6 +226,8 @@ def main():
         ac = float(np.mean([a for a, _ in spars]))          # active pairs (the M-step's, when it runs sparse)
         m_sparse = names[1].startswith("mstep_list")
         kern = {"estep": dict(ms=e_ms, kernels=names[0] + ("+select+estep_gather_f64" if "bound" in names[0] else ""),
+                              passes={k: sum(1 for l in launches if l.startswith(k)) for k in
+                                      ("estep_lds_f64", "estep_i8_bound", "estep_carried_bounds")},
                               algorithmic_tflops=fl_e * n_local / (e_ms * 1e-3) / 1e12,
                               exact_pairs_f64_tflops=fl_pair * ev / (e_ms * 1e-3) / 1e12),
                 "mstep": dict(ms=m_ms, kernels=names[1] + ("+select" if m_sparse else ""),
@@ -296,7 +298,7 @@ def main():
             "cpu_baseline": cpu_base, "parity": parity, "sparse_check": sparse_check, "final_vl": vl,
             "launch": eng.launch_info, "warmup_steps": warm,
             "per_step": {"estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
-                         "estep_kernel": [l.split("<")[0] for l in launches],
+                         "estep_kernel": [l.split("<")[0].split(" ")[0] for l in launches],
                          "active_components_per_sample": [round(a / n_local, 2) if a >= 0 else None for a, _ in spars],
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars]},
         }
