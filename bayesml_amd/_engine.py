@@ -30,6 +30,7 @@ SYMBOLS = {
     "gmmvb_set_pivot": (_int, [_vp, _vp, _vp]),
     "gmmvb_set_params": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "gmmvb_set_drift": (_int, [_vp, _vp, _vp, _vp]),
+    "gmmvb_wants_drift": (_int, [_vp, _i64]),
     "gmmvb_prepare_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_estep": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_load_responsibilities": (_int, [_vp, _vp, _i64, _vp]),
@@ -190,6 +191,9 @@ class DataPass:
             _check(self.lib, self.lib.gmmvb_set_params(self._ws, c.data_ptr(), m.data_ptr(), u.data_ptr(),
                                                        self._stream()), "gmmvb_set_params")
         self._keep = [c, m, u]
+
+    def wants_drift(self, n_rows: int) -> bool:
+        return bool(self.lib.gmmvb_wants_drift(self._ws, int(n_rows)))
 
     def set_drift(self, gamma, delta):
         """Hint for the pruned E-step (gmmvb_set_drift): call before the set_params of the updated parameters."""

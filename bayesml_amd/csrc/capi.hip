@@ -218,6 +218,12 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
     return GMMVB_OK;
 }
 
+int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows) {
+    if (!ws || ws->prune == 0 || ws->estep_variant != kEstepLds8 || ws->hmm != nullptr || !ws->masks) return 0;
+    if (std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr) return 0;
+    return (ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23)) ? 1 : 0;
+}
+
 int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* delta_dev, void* stream) {
     if (!ws || !gamma_dev || !delta_dev) return fail(GMMVB_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -508,7 +514,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->ev_e = true;
     }
     const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
-    if (ws->sparse && ws->masks) {
+    // small passes are launch-bound: no pair counting, no lists (the dense M-step takes microseconds there)
+    const bool count_pairs = ws->sparse && ws->masks && (prune || n_rows * (int64_t)ws->K >= (int64_t(1) << 18));
+    if (count_pairs) {
         // thresholds from a sample of the rows (every 16th block of 1024), then lse + active masks + counts in one pass
         const int stride = lse_blocks >= 64 ? 16 : 1;
         const int sampled = (lse_blocks + stride - 1) / stride;
@@ -531,6 +539,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                            ws->lse, nullptr, nullptr, 1);
         e = hipGetLastError();
         if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
+        ws->act_rows = 0;              // nothing counted: dense M-step, no pruning decision from this pass
     }
     ws->e_state = 1;
     ws->e_rows = n_rows;

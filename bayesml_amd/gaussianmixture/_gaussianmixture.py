@@ -306,7 +306,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         ``q_from``: the posterior of the previous data pass over these rows, if this one continues it (lets the
         engine carry its ln rho bounds over the update instead of recomputing them, see gmmvb_set_drift)."""
         if estep:
-            if q_from is not None and hasattr(eng, "set_drift"):
+            if q_from is not None and hasattr(eng, "wants_drift") and eng.wants_drift(xd.shape[0]):
                 eng.set_drift(*_kside.drift(q_from, q))
             eng.set_params(q.c, q.m, q.u)
             stats = eng.estep_mstep(xd)

@@ -152,6 +152,9 @@ const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
  * good enough are evaluated exactly as usual.  Loose values only cost candidates, wrong ones (gamma too large,
  * delta too small) break the bounds.  The hint is consumed by the next gmmvb_estep. */
 int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev /*[K]*/, const double* delta_dev /*[K]*/, void* stream);
+/* 1 if an E-step over n_rows rows of this workspace can make use of gmmvb_set_drift (pruning is possible at all),
+ * else 0: lets the caller skip computing the hint. */
+int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows);
 
 /* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
  * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
