@@ -109,6 +109,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     {
         const char* v = std::getenv("GMMVB_MSTEP_SPARSE");         // "0" = always the dense M-step
         ws->sparse = !(v && std::strcmp(v, "0") == 0);
+        if (max_rows > 2000000000) ws->sparse = false;             // the sample lists hold 32-bit row numbers
         v = std::getenv("GMMVB_ESTEP_PRUNE");
         ws->prune = (v && std::strcmp(v, "0") == 0) ? 0 : ((v && std::strcmp(v, "force") == 0) ? 2 : 1);
         if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;

@@ -301,13 +301,19 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._ln_b_hn_w_nus[:] = _np(q.ln_b_w_nu)
 
     # ------------------------------------------------------------------ device plumbing (see _device.py)
-    def _pass(self, eng, xd, q, s_prev, estep=True, q_from=None):
+    def _drift_hint(self, eng, xd, q_from, q):
+        """(gamma, delta) of gmmvb_set_drift for the update q_from -> q, or None when the engine cannot use it."""
+        if q_from is None or q is None or not hasattr(eng, "wants_drift") or not eng.wants_drift(xd.shape[0]):
+            return None
+        return _kside.drift(q_from, q)
+
+    def _pass(self, eng, xd, q, s_prev, estep=True, hint=None):
         """One data pass: statistics block -> all-reduce over row shards -> reference moments.
-        ``q_from``: the posterior of the previous data pass over these rows, if this one continues it (lets the
-        engine carry its ln rho bounds over the update instead of recomputing them, see gmmvb_set_drift)."""
+        ``hint``: ``_drift_hint(previous posterior of these rows, q)`` if this pass continues the previous one (lets
+        the engine carry its ln rho bounds over the update instead of recomputing them, see gmmvb_set_drift)."""
         if estep:
-            if q_from is not None and hasattr(eng, "wants_drift") and eng.wants_drift(xd.shape[0]):
-                eng.set_drift(*_kside.drift(q_from, q))
+            if hint is not None:
+                eng.set_drift(*hint)
             eng.set_params(q.c, q.m, q.u)
             stats = eng.estep_mstep(xd)
         else:
@@ -356,15 +362,17 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             # the next K-side update only needs the statistics: enqueue it before the lower bound is read back, so
             # that the GPU runs it while the host would otherwise be waiting (it is dropped if the loop ends here)
             q_next = _kside.update_q(prior, ns, x_bar, s) if max_itr > 0 else None
+            hint = self._drift_hint(eng, xd, q if init_type == "subsampling" else None, q_next)
             vl = float(terms["vl"])
             self._say(f"\r{i}. VL: {vl}")
             for t in range(max_itr):
                 vl_before = vl
-                q_last, q = q, q_next
-                ns, x_bar, s, h = self._pass(eng, xd, q, s_prev, q_from=q_last if init_type == "subsampling" or t > 0 else None)
+                q = q_next
+                ns, x_bar, s, h = self._pass(eng, xd, q, s_prev, hint=hint)
                 s_prev = s
                 terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
                 q_next = _kside.update_q(prior, ns, x_bar, s) if t + 1 < max_itr else None
+                hint = self._drift_hint(eng, xd, q, q_next)
                 vl = float(terms["vl"])                      # the one host sync per iteration
                 self._say(f"\r{i}. VL: {vl} t={t} ")
                 with np.errstate(divide="ignore", invalid="ignore"):

@@ -168,14 +168,17 @@ def main():
     ns, x_bar, s, h = m._pass(eng, xd, q, s_prev)
 
     q_next = _kside.update_q(prior, ns, x_bar, s)
+    hint = m._drift_hint(eng, xd, q, q_next)
 
     def step():
-        # as in update_posterior's loop: the next K-side update is enqueued before the lower bound is read back
-        nonlocal q, q_next, ns, x_bar, s, h
-        q_last, q = q, q_next
-        ns, x_bar, s, h = m._pass(eng, xd, q, s, q_from=q_last)
+        # as in update_posterior's loop: the next K-side update (and its drift hint for the E-step) is enqueued before
+        # the lower bound is read back
+        nonlocal q, q_next, hint, ns, x_bar, s, h
+        q = q_next
+        ns, x_bar, s, h = m._pass(eng, xd, q, s, hint=hint)
         vl = _kside.lower_bound(prior, q, ns, x_bar, s, h)["vl"]
         q_next = _kside.update_q(prior, ns, x_bar, s)
+        hint = m._drift_hint(eng, xd, q, q_next)
         return float(vl)
 
     def snapshot():
