@@ -516,7 +516,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
     // small passes are launch-bound: no pair counting, no lists (the dense M-step takes microseconds there)
-    const bool count_pairs = ws->sparse && ws->masks && (prune || n_rows * (int64_t)ws->K >= (int64_t(1) << 18));
+    const bool count_pairs = ws->sparse && ws->masks && ws->hmm == nullptr &&
+                             (prune || n_rows * (int64_t)ws->K >= (int64_t(1) << 18));
     if (count_pairs) {
         // thresholds from a sample of the rows (every 16th block of 1024), then lse + active masks + counts in one pass
         const int stride = lse_blocks >= 64 ? 16 : 1;
