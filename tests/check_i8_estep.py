@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""int8-digit E-step against the f64 E-step on the same parameters: ln rho differences and kernel times.
+"""[test utility, run by hand on a GPU box: python tests/check_i8_estep.py]
+int8-digit E-step against the f64 E-step on the same parameters: ln rho differences and kernel times.
 
 The variant is chosen per process (env GMMVB_ESTEP_VARIANT), so each case runs in a child process and hands
 its ln rho back through a file."""
@@ -11,7 +12,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 
 CASES = [(3, 2, 1000, "float64"), (16, 32, 4096, "float64"), (5, 33, 777, "float32"), (7, 100, 3000, "float32"),

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Pruned E-step / sparse M-step against the dense kernels: same model, same data, a few VB iterations; the
+"""[test utility, run by hand on a GPU box: python tests/check_sparse_vs_dense.py]
+Pruned E-step / sparse M-step against the dense kernels: same model, same data, a few VB iterations; the
 posterior hyper-parameters, the responsibilities and the hard assignments must agree to rounding.
 Each configuration runs in a child process (the switches are environment variables read at workspace creation)."""
 import json
@@ -11,7 +12,7 @@ import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 
 CASES = [(64, 128, 200_000, "float32", 6), (16, 64, 100_000, "float64", 5), (32, 96, 50_000, "float32", 5),

@@ -60,11 +60,14 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
 
-    from oracle import hmm_vb_oracle as orc
-    x_ref, _ = orc.synth_hmm(K, D, min(args.ref_rows, T), np.float32)
+    cpu = parity = None
+    x_ref = None
+    if not args.no_cpu:
+        # the oracle is only touched by this cpu_baseline / parity leg (it also supplies the rows both sides see)
+        from oracle import hmm_vb_oracle as orc
+        x_ref, _ = orc.synth_hmm(K, D, min(args.ref_rows, T), np.float32)
     x = synth_device(K, D, T, torch.float32, dev, head=x_ref)
 
-    cpu = parity = None
     if not args.no_cpu:
         x64 = x_ref.astype(np.float64)
         p = orc.HmmPrior.default(K, D)
