@@ -36,12 +36,14 @@ struct gmmvb_workspace {
     // and how many E-steps in a row have lived on carried bounds
     double* drift = nullptr;           // [3][K]: gamma, delta, c of the last E-step
     bool have_drift = false;
+    double typical_gamma = -1.0;       // mean gamma of the pending update if the caller knew it (<= 0: unknown)
     bool params_used = false;          // the parameters in force were the ones of the last E-step
     int64_t bounds_rows = 0;           // ... and of which matrix (0 / null: the array holds nothing that can be carried)
     const void* bounds_x = nullptr;
     int64_t bounds_ldx = 0;
     int carried = 0;
     int prev_pass = 0;                 // last E-step: 0 dense, 1 bound pass, 2 carried bounds
+    double spare_last = -1.0, spare_before = -1.0;   // spare candidates per pair of the last two pruned passes
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)

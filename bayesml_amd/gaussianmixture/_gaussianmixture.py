@@ -307,13 +307,22 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             return None
         return _kside.drift(q_from, q)
 
+    @staticmethod
+    def _read_vl(terms, hint):
+        """The lower bound as a host float - and, in the same device-to-host copy, the mean gamma of the pending
+        drift hint (it tells the engine how fast the components are moving)."""
+        if hint is None:
+            return float(terms["vl"]), None
+        vl, gmean = torch.stack([terms["vl"].reshape(()), hint[0].mean()]).tolist()
+        return vl, (hint[0], hint[1], gmean)
+
     def _pass(self, eng, xd, q, s_prev, estep=True, hint=None):
         """One data pass: statistics block -> all-reduce over row shards -> reference moments.
         ``hint``: ``_drift_hint(previous posterior of these rows, q)`` if this pass continues the previous one (lets
         the engine carry its ln rho bounds over the update instead of recomputing them, see gmmvb_set_drift)."""
         if estep:
             if hint is not None:
-                eng.set_drift(*hint)
+                eng.set_drift(*hint)           # (gamma, delta[, mean gamma as a host float])
             eng.set_params(q.c, q.m, q.u)
             stats = eng.estep_mstep(xd)
         else:
@@ -363,7 +372,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             # that the GPU runs it while the host would otherwise be waiting (it is dropped if the loop ends here)
             q_next = _kside.update_q(prior, ns, x_bar, s) if max_itr > 0 else None
             hint = self._drift_hint(eng, xd, q if init_type == "subsampling" else None, q_next)
-            vl = float(terms["vl"])
+            vl, hint = self._read_vl(terms, hint)
             self._say(f"\r{i}. VL: {vl}")
             for t in range(max_itr):
                 vl_before = vl
@@ -373,7 +382,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
                 terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
                 q_next = _kside.update_q(prior, ns, x_bar, s) if t + 1 < max_itr else None
                 hint = self._drift_hint(eng, xd, q, q_next)
-                vl = float(terms["vl"])                      # the one host sync per iteration
+                vl, hint = self._read_vl(terms, hint)        # the one host sync per iteration
                 self._say(f"\r{i}. VL: {vl} t={t} ")
                 with np.errstate(divide="ignore", invalid="ignore"):
                     if np.abs((vl - vl_before) / vl_before) < tolerance:

@@ -176,10 +176,11 @@ def main():
         nonlocal q, q_next, hint, ns, x_bar, s, h
         q = q_next
         ns, x_bar, s, h = m._pass(eng, xd, q, s, hint=hint)
-        vl = _kside.lower_bound(prior, q, ns, x_bar, s, h)["vl"]
+        terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
         q_next = _kside.update_q(prior, ns, x_bar, s)
         hint = m._drift_hint(eng, xd, q, q_next)
-        return float(vl)
+        vl, hint = m._read_vl(terms, hint)          # one device-to-host copy: the lower bound and the mean gamma
+        return vl
 
     def snapshot():
         a, e = eng.sparsity()

@@ -150,8 +150,11 @@ const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
  * x, which lets the next gmmvb_estep carry the previous pass's values and upper bounds of ln rho over to the new
  * parameters (one elementwise pass) instead of bounding every pair afresh; pairs whose carried bound is no longer
  * good enough are evaluated exactly as usual.  Loose values only cost candidates, wrong ones (gamma too large,
- * delta too small) break the bounds.  The hint is consumed by the next gmmvb_estep. */
-int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev /*[K]*/, const double* delta_dev /*[K]*/, void* stream);
+ * delta too small) break the bounds.  typical_gamma: the mean of gamma if the caller has it on the host (it steers
+ * the choice between carrying and a fresh bound pass: below 0.9 the parameters are judged to move too fast), or a
+ * value <= 0 if not.  The hint is consumed by the next gmmvb_estep. */
+int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev /*[K]*/, const double* delta_dev /*[K]*/,
+                    double typical_gamma, void* stream);
 /* 1 if an E-step over n_rows rows of this workspace can make use of gmmvb_set_drift (pruning is possible at all),
  * else 0: lets the caller skip computing the hint. */
 int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows);
