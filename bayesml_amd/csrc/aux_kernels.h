@@ -162,12 +162,10 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
 
 // MODE 0 (best)  : the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
 // MODE 1 (near)  : ln rho[khat_n][n] is exact now; the mask holds every other k with u[k][n] >= it - 100 ln 2.
-// MODE 2 (active): the M-step's samples: every k with ln r_nk = u[k][n] - lse[n] >= thr[k] (mstep.h).
 // MODE 3 (given) : like MODE 0 with khat already written (by the bound kernel): u is not read.
 template <int MODE>
 __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __restrict__ u, int64_t npad, int64_t n_rows,
                                                                int K, int* __restrict__ khat,
-                                                               const double* __restrict__ lse, const double* __restrict__ thr,
                                                                unsigned long long* __restrict__ masks /*[W][npad]*/,
                                                                int* __restrict__ blk_cnt /*[blocks][K]*/) {
     constexpr bool NEAR = MODE == 1;
@@ -183,7 +181,6 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
         kh = khat[n];
         lim = u[(int64_t)kh * npad + n] - 69.314718055994530942;
     }
-    if (MODE == 2 && valid) lim = lse[n];
     if (MODE == 3 && valid) kh = khat[n];
     if (MODE == 0) {
         int arg = 0;
@@ -202,13 +199,7 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
     for (int w = 0; w < W; ++w) {
         unsigned long long mk = 0;
         if (valid) {
-            if (MODE == 2) {
-                const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
-                for (int b = 0; b < kend; ++b) {
-                    const double t = u[(int64_t)(64 * w + b) * npad + n] - lim;
-                    mk |= (unsigned long long)(!(t < thr[64 * w + b])) << b;   // NaN stays active
-                }
-            } else if (NEAR) {
+            if (NEAR) {
                 const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
                 for (int b = 0; b < kend; ++b) {
                     const double v = u[(int64_t)(64 * w + b) * npad + n];
@@ -297,7 +288,7 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
     }
 }
 
-// lse[n] for every row, and in the same pass the M-step's active mask (ln r_nk >= thr[k], as select_mask_kernel<2>),
+// lse[n] for every row, and in the same pass the M-step's active mask (ln r_nk = lnrho[k][n] - lse[n] >= thr[k], mstep.h),
 // its block counts, and the number of pairs with ln r >= -100 ln 2 per block (apart).  thr comes from a sample of
 // the rows (row_lse_kernel with a stride): a maximum over fewer rows is smaller, the threshold lower, the lists at
 // worst a little longer - never a relevant sample dropped.  One thread per row, 256 rows per block.

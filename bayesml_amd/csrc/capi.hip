@@ -494,13 +494,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         for (int round = 0; round < 2; ++round) {
             if (round == 0 && (carry || i8_bound))
                 hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
+                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
             else if (round == 0)
                 hipLaunchKernelGGL(select_mask_kernel<0>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
+                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
             else
                 hipLaunchKernelGGL(select_mask_kernel<1>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, nullptr, nullptr, ws->masks, ws->blk);
+                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
             hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
             hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
                                ws->blk, ws->lists, ws->npad);
