@@ -273,3 +273,27 @@ def test_carried_bounds_pass():
     a = torch.linalg.solve_triangular(qs[0].u, qs[1].u, upper=False, left=False)       # u_new u_old^-1
     smin = torch.linalg.svdvals(a)[:, -1]
     assert bool(torch.all(g <= smin)) and bool(torch.all(g >= 0.95 * smin))
+
+
+def test_sparse_path_ill_conditioned_components():
+    """Rank-deficient initial covariances (sqrt(N) < D: W^-1 = singular sample covariance + 1e-5 I, condition ~1e9,
+    whitening factors with entries in the hundreds): the int8 bound pass has to stay a bound there (its error term
+    scales with the row and sample exponents), so the sparse path must still reproduce the dense statistics."""
+    from bayesml_amd import _kside
+    K, D, N = 8, 64, 3000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    p = orc.Prior.default(K, D)
+    q = orc.Posterior.from_prior(p)
+    orc.init_subsampling(x.astype(np.float64), q, np.random.default_rng(0))
+    dev = torch.device("cuda", 0)
+    t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+    qd = _kside.features(_kside.PostT(t(q.alpha), t(q.m), t(q.kappa), t(q.nu), t(q.w_inv)))
+    assert float(qd.u.abs().max()) > 50.0            # the case is what it claims to be
+    xd = torch.from_numpy(x).to(dev)
+    pivot = xd.to(torch.float64).mean(dim=0)
+    dense = _pass(xd, qd, DENSE, pivot)
+    sparse = _pass(xd, qd, SPARSE, pivot)
+    assert "_bound" in sparse[1][2]
+    for (sa, ra, _), (sb, rb, _) in zip(dense, sparse):
+        assert rel_err(sb, sa) < 1e-11
+        assert np.max(np.abs(ra - rb)) < 1e-11
