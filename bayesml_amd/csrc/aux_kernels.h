@@ -163,12 +163,20 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
 // MODE 0 (best)  : the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
 // MODE 1 (near)  : ln rho[khat_n][n] is exact now; the mask holds every other k with u[k][n] >= it - 100 ln 2.
 // MODE 3 (given) : like MODE 0 with khat already written (by the bound kernel): u is not read.
+// MODE 4 (carry) : MODE 1 on carried bounds (gmmvb_set_drift), made on the way: every v = u[k][n] other than the freshly
+//                  evaluated u[khat_n][n] is a value or upper bound of ln rho under the OLD parameters, so
+//                  q_old >= 2 (c_old - v); with || u' (x - m') || >= gamma || u (x - m) || - delta the new parameters
+//                  give q' >= (gamma sqrt(2 (c_old - v)) - delta)_+^2, i.e. the upper bound c' - q'/2, which replaces v
+//                  before it is compared.  The slack factors cover the rounding of that line; a NaN turns into "no
+//                  bound" (c'), never into a finite lie.  drift = [gamma | delta | c_old], K doubles each.
 template <int MODE>
-__global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __restrict__ u, int64_t npad, int64_t n_rows,
+__global__ __launch_bounds__(kSelRows) void select_mask_kernel(double* __restrict__ u, int64_t npad, int64_t n_rows,
                                                                int K, int* __restrict__ khat,
                                                                unsigned long long* __restrict__ masks /*[W][npad]*/,
-                                                               int* __restrict__ blk_cnt /*[blocks][K]*/) {
-    constexpr bool NEAR = MODE == 1;
+                                                               int* __restrict__ blk_cnt /*[blocks][K]*/,
+                                                               const double* __restrict__ drift = nullptr,
+                                                               const double* __restrict__ c_new = nullptr) {
+    constexpr bool NEAR = MODE == 1 || MODE == 4;
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
@@ -202,7 +210,16 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
             if (NEAR) {
                 const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
                 for (int b = 0; b < kend; ++b) {
-                    const double v = u[(int64_t)(64 * w + b) * npad + n];
+                    const int k = 64 * w + b;
+                    double v = u[(int64_t)k * npad + n];
+                    if (MODE == 4 && k != kh) {
+                        double q = 2.0 * (drift[2 * K + k] - v);
+                        q = q > 0.0 ? q : 0.0;                                    // also NaN -> 0
+                        double y = drift[k] * sqrt(q) * (1.0 - 1e-12) - drift[K + k];
+                        y = y > 0.0 ? y : 0.0;
+                        v = c_new[k] - 0.5 * y * y * (1.0 - 1e-12) + 1e-12 * fabs(c_new[k]);
+                        u[(int64_t)k * npad + n] = v;
+                    }
                     mk |= (unsigned long long)(!(v < lim)) << b;          // NaN: evaluated, not skipped
                 }
                 if ((kh >> 6) == w) mk &= ~(1ull << (kh & 63));
@@ -349,25 +366,6 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
     for (int k = threadIdx.x; k < K; k += kSelRows)
         blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (threadIdx.x == 0) apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
-}
-
-// Pruned E-step without a bound pass (gmmvb_set_drift): v = value or upper bound of ln rho under the old parameters,
-// so q_old >= 2 (c_old - v); with || u' (x - m') || >= gamma || u (x - m) || - delta the new parameters give
-// q' >= (gamma sqrt(2 (c_old - v)) - delta)_+^2, i.e. the upper bound c' - q'/2.  The slack factors cover the
-// rounding of this line; a NaN turns into "no bound" (c'), never into a finite lie.
-__global__ void carry_bounds_kernel(double* __restrict__ lnrho, int64_t npad, int64_t n_rows, int K,
-                                    const double* __restrict__ drift /*gamma, delta, c_old*/,
-                                    const double* __restrict__ c_new) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = blockIdx.y;
-    if (n >= n_rows) return;
-    const double gamma = drift[k], delta = drift[K + k], c_old = drift[2 * K + k], cn = c_new[k];
-    const double v = lnrho[(int64_t)k * npad + n];
-    double q = 2.0 * (c_old - v);
-    q = q > 0.0 ? q : 0.0;                                    // also NaN -> 0
-    double y = gamma * sqrt(q) * (1.0 - 1e-12) - delta;
-    y = y > 0.0 ? y : 0.0;
-    lnrho[(int64_t)k * npad + n] = cn - 0.5 * y * y * (1.0 - 1e-12) + 1e-12 * fabs(cn);
 }
 
 // r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0

@@ -465,11 +465,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         for (double& c : ws->tb_cand) c = -1.0;
     if (prune) {
         if (carry) {
-            rpw = 256;
-            grid = (n_rows + 255) / 256;
-            hipLaunchKernelGGL(carry_bounds_kernel, dim3((unsigned)grid, (unsigned)ws->K), dim3(256), 0, st, ws->lnrho,
-                               ws->npad, n_rows, ws->K, ws->drift, ws->cvec);
-            e = hipGetLastError();
+            // nothing to launch here: the previous pass's best components are evaluated first (round 0), and the second
+            // selection carries every other value over the update as it reads it (select_mask_kernel<4>)
+            rpw = kSelRows;
+            grid = (n_rows + kSelRows - 1) / kSelRows;
             name = "estep_carried_bounds";
             ++ws->carried;
         } else {
@@ -498,6 +497,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             else if (round == 0)
                 hipLaunchKernelGGL(select_mask_kernel<0>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
                                    n_rows, ws->K, ws->khat, ws->masks, ws->blk);
+            else if (carry)
+                hipLaunchKernelGGL(select_mask_kernel<4>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
+                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk, ws->drift, ws->cvec);
             else
                 hipLaunchKernelGGL(select_mask_kernel<1>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
                                    n_rows, ws->K, ws->khat, ws->masks, ws->blk);
