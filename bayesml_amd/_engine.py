@@ -40,6 +40,7 @@ SYMBOLS = {
     "gmmvb_ln_rho": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gmmvb_argmax": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gmmvb_last_launch_info": (ctypes.c_char_p, [_vp]),
+    "gmmvb_pass_counts": (_int, [_vp, ctypes.POINTER(_i64)]),
     "gmmvb_last_sparsity": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
@@ -48,6 +49,8 @@ SYMBOLS = {
     "hmmvb_viterbi": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "gmmvb_profile_enable": (_int, [_vp, _int]),
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    "gmmvb_profile_spans": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_int)]),
+    "gmmvb_profile_span_name": (ctypes.c_char_p, [_int]),
 }
 
 
@@ -151,6 +154,15 @@ class DataPass:
         s = self.lib.gmmvb_last_launch_info(self._ws)
         return s.decode() if s else ""
 
+    PASS_NAMES = ("estep_dense", "estep_bound", "estep_carried", "estep_fell_back_dense", "estep_rebound",
+                  "mstep_dense", "mstep_list", "estep_gather")
+
+    def pass_counts(self) -> dict:
+        """Launch counts since the workspace was created (gmmvb_pass_counts)."""
+        out = (_i64 * 8)()
+        _check(self.lib, self.lib.gmmvb_pass_counts(self._ws, out), "gmmvb_pass_counts")
+        return dict(zip(self.PASS_NAMES, (int(v) for v in out)))
+
     def sparsity(self):
         """(active pairs, exactly evaluated pairs) of the last E-step; see gmmvb_last_sparsity."""
         a, e = ctypes.c_double(), ctypes.c_double()
@@ -168,6 +180,17 @@ class DataPass:
         _check(self.lib, self.lib.gmmvb_profile_last_ms(self._ws, ctypes.byref(e), ctypes.byref(m)),
                "gmmvb_profile_last_ms")
         return float(e.value), float(m.value)
+
+    def kernel_spans(self) -> dict:
+        """{group: (ms, launch groups)} of the last estep + mstep (gmmvb_profile_spans; needs profile(True))."""
+        ms, cnt = (ctypes.c_float * 8)(), (_int * 8)()
+        _check(self.lib, self.lib.gmmvb_profile_spans(self._ws, ms, cnt), "gmmvb_profile_spans")
+        out = {}
+        for i in range(8):
+            name = self.lib.gmmvb_profile_span_name(i).decode()
+            if name and cnt[i]:
+                out[name] = (float(ms[i]), int(cnt[i]))
+        return out
 
     # -- C ABI
     def set_pivot(self, pivot):

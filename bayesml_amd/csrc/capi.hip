@@ -41,6 +41,22 @@ int64_t gmmvb_stats_len(int K, int D) {
 
 static int ensure_lists(gmmvb_workspace* ws);
 
+// profiling spans (gmmvb_profile_spans): HIP events on the launch stream around groups of kernels
+enum { kSpanEstepMain = 0, kSpanSelect = 1, kSpanGather = 2, kSpanLse = 3, kSpanLists = 4, kSpanMstepMain = 5,
+       kSpanReduce = 6, kSpanSlots = 8 };
+static const char* const kSpanNames[kSpanSlots] = {"estep_main", "estep_select", "estep_gather", "estep_lse_mask",
+                                                   "mstep_lists", "mstep_main", "mstep_reduce", ""};
+static void span_begin(gmmvb_workspace* ws, int slot, hipStream_t st) {
+    if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans) return;
+    ws->span_slot[ws->n_spans] = slot;
+    (void)hipEventRecord(ws->span_ev[2 * ws->n_spans], st);
+}
+static void span_end(gmmvb_workspace* ws, hipStream_t st) {
+    if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans) return;
+    (void)hipEventRecord(ws->span_ev[2 * ws->n_spans + 1], st);
+    ++ws->n_spans;
+}
+
 int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace** out) {
     if (!out) return fail(GMMVB_EINVAL, "out is null");
     *out = nullptr;
@@ -173,6 +189,8 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (ws->pivot_i8) (void)hipFree(ws->pivot_i8);
     for (hipEvent_t e : ws->ev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ws->span_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ws->hmm) hmm_state_destroy(ws->hmm);
     delete ws;
     return GMMVB_OK;
@@ -182,6 +200,12 @@ int64_t gmmvb_workspace_bytes(const gmmvb_workspace* ws) { return ws ? ws->bytes
 
 const char* gmmvb_last_launch_info(const gmmvb_workspace* ws) { return ws ? ws->info : ""; }
 
+int gmmvb_pass_counts(const gmmvb_workspace* ws, int64_t* out /*[8]*/) {
+    if (!ws || !out) return fail(GMMVB_EINVAL, "null argument");
+    for (int i = 0; i < 8; ++i) out[i] = ws->passes[i];
+    return GMMVB_OK;
+}
+
 int gmmvb_profile_enable(gmmvb_workspace* ws, int on) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     if (on && !ws->ev[0]) {
@@ -189,8 +213,32 @@ int gmmvb_profile_enable(gmmvb_workspace* ws, int on) {
             hipError_t rc = hipEventCreate(&e);
             if (rc != hipSuccess) return fail(GMMVB_EHIP, "hipEventCreate", rc);
         }
+        for (auto& e : ws->span_ev) {
+            hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) return fail(GMMVB_EHIP, "hipEventCreate", rc);
+        }
     }
     ws->prof = on != 0;
+    ws->n_spans = 0;
+    return GMMVB_OK;
+}
+
+const char* gmmvb_profile_span_name(int slot) { return (slot >= 0 && slot < kSpanSlots) ? kSpanNames[slot] : ""; }
+
+int gmmvb_profile_spans(gmmvb_workspace* ws, float* ms /*[8]*/, int* launches /*[8]*/) {
+    if (!ws || !ms || !launches) return fail(GMMVB_EINVAL, "null argument");
+    for (int i = 0; i < kSpanSlots; ++i) {
+        ms[i] = 0.0f;
+        launches[i] = 0;
+    }
+    for (int i = 0; i < ws->n_spans; ++i) {
+        float t = 0.0f;
+        hipError_t rc = hipEventSynchronize(ws->span_ev[2 * i + 1]);
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&t, ws->span_ev[2 * i], ws->span_ev[2 * i + 1]);
+        if (rc != hipSuccess) return fail(GMMVB_EHIP, "event timing (span)", rc);
+        ms[ws->span_slot[i]] += t;
+        ++launches[ws->span_slot[i]];
+    }
     return GMMVB_OK;
 }
 
@@ -460,6 +508,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int64_t grid = 0;
     bool pruned_fell_back = false;
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
+    ws->n_spans = 0;
     ws->evaluated = prune ? 0.0 : (double)n_rows * ws->K;
     if (!prune)      // a dense pass: whatever was learnt about the bound levels belongs to another regime
         for (double& c : ws->tb_cand) c = -1.0;
@@ -471,10 +520,12 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             grid = (n_rows + kSelRows - 1) / kSelRows;
             name = "estep_carried_bounds";
             ++ws->carried;
+            ++ws->passes[2];
         } else {
             rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
             grid = (n_rows + rpw - 1) / rpw;
             if (grid > (1 << 20)) grid = 1 << 20;
+            span_begin(ws, kSpanEstepMain, st);
             if (ws->img_i8b) {
                 EstepI8Args ab = a8;
                 ab.img = ws->img_i8b;
@@ -483,7 +534,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             } else {
                 e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
             }
+            span_end(ws, st);
             ws->carried = 0;
+            ++ws->passes[1];
         }
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
         const bool i8_bound = ws->img_i8b != nullptr;
@@ -491,6 +544,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         int counts_host[256];
         const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
         for (int round = 0; round < 2; ++round) {
+            span_begin(ws, kSpanSelect, st);
             if (round == 0 && (carry || i8_bound))
                 hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
                                    n_rows, ws->K, ws->khat, ws->masks, ws->blk);
@@ -507,6 +561,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
                                ws->blk, ws->lists, ws->npad);
             e = hipGetLastError();
+            span_end(ws, st);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(counts_host, ws->counts, (size_t)ws->K * sizeof(int), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -521,6 +576,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
                 grid = (n_rows + rpw - 1) / rpw;
                 if (grid > (1 << 20)) grid = 1 << 20;
+                span_begin(ws, kSpanEstepMain, st);
                 if (ws->img_i8b) {
                     EstepI8Args ab = a8;
                     ab.img = ws->img_i8b;
@@ -529,7 +585,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 } else {
                     e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
                 }
+                span_end(ws, st);
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
+                ++ws->passes[1];
+                ++ws->passes[4];
                 ws->evaluated = 0.0;
                 round = -1;                 // start the selection over
                 continue;
@@ -540,11 +599,14 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 const int rpd = estep_rows_per_wg(ws->estep_variant, ws->T, is64);
                 int64_t gd = (n_rows + rpd - 1) / rpd;
                 if (gd > (1 << 20)) gd = 1 << 20;
+                span_begin(ws, kSpanEstepMain, st);
                 e = launch_estep(ws->estep_variant, ws->T, is64, vec, (int)gd, st, a, &name);
+                span_end(ws, st);
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
                 ws->evaluated = (double)n_rows * ws->K;
                 ws->evaluated_prev = -1.0;
                 fell_back = true;
+                ++ws->passes[3];
                 if (ws->img_i8b && !carry) {   // this level left everything a candidate: remember, and go back up
                     ws->tb_cand[ws->bound_tb] = 1.0;
                     ws->tb_seen[ws->bound_tb] = 0;
@@ -554,16 +616,22 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             }
             ws->evaluated += listed;
             ws->evaluated_prev = ws->evaluated;
+            span_begin(ws, kSpanGather, st);
             e = launch_estep_gather(ws->T, is64, vec, st, a, ws->lists, ws->npad, ws->counts, counts_host);
+            span_end(ws, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_gather launch", e);
+            ++ws->passes[7];
         }
     } else {
         rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
         grid = (n_rows + rpw - 1) / rpw;
         if (grid > (1 << 20)) grid = 1 << 20;
+        span_begin(ws, kSpanEstepMain, st);
         e = i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
                : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name);
+        span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
+        ++ws->passes[0];
     }
     if (ws->prof) {
         (void)hipEventRecord(ws->ev[1], st);
@@ -573,6 +641,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // small passes are launch-bound: no pair counting, no lists (the dense M-step takes microseconds there)
     const bool count_pairs = ws->sparse && ws->masks && ws->hmm == nullptr &&
                              (prune || n_rows * (int64_t)ws->K >= (int64_t(1) << 18));
+    span_begin(ws, kSpanLse, st);
     if (count_pairs) {
         // thresholds from a sample of the rows (every 16th block of 1024), then lse + active masks + counts in one pass
         const int stride = lse_blocks >= 64 ? 16 : 1;
@@ -598,6 +667,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
         ws->act_rows = 0;              // nothing counted: dense M-step, no pruning decision from this pass
     }
+    span_end(ws, st);
     ws->e_state = 1;
     ws->e_rows = n_rows;
     ws->params_used = true;
@@ -622,6 +692,7 @@ int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_
     if (e != hipSuccess) return fail(GMMVB_EHIP, "load_r launch", e);
     ws->e_state = 2;
     ws->e_rows = n_rows;
+    ws->n_spans = 0;
     ws->bounds_rows = 0;               // the array holds responsibilities now, nothing a later E-step may carry over
     return GMMVB_OK;
 }
@@ -680,20 +751,28 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
         // masks and block counts of the active pairs were written by lse_mask_kernel at the end of the E-step
         if (!ws->active_lists) {
+            span_begin(ws, kSpanLists, st);
             hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, nblk, ws->K, ws->counts);
             hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
                                ws->blk, ws->lists, ws->npad);
             e = hipGetLastError();
+            span_end(ws, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);
             ws->active_lists = true;
         }
         grid = 8 * ((S + 7) / 8) * KG;
         MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->blk, ws->counts, nblk, bps,
                          ws->npad, ws->K, KG, (int)S, ws->slabs};
+        span_begin(ws, kSpanMstepMain, st);
         e = launch_mstep_list(ws->T, (int)grid, st, la, &name);
+        span_end(ws, st);
+        ++ws->passes[6];
     } else {
+        ++ws->passes[5];
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
+        span_begin(ws, kSpanMstepMain, st);
         e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
+        span_end(ws, st);
     }
     if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);
     if (ws->prof) {
@@ -701,8 +780,10 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->ev_m = true;
     }
     const int elems = tri_pairs(ws->T) * 256 + 16 * ws->T + 2;
+    span_begin(ws, kSpanReduce, st);
     hipLaunchKernelGGL(reduce_stats_kernel, dim3((elems + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, (int)S,
                        ws->K, ws->D, ws->T, stats_dev);
+    span_end(ws, st);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "reduce_stats launch", e);
     const size_t used = std::strlen(ws->info);

@@ -72,9 +72,18 @@ struct gmmvb_workspace {
     int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly, 3 HMM gamma
     int64_t e_rows = 0;
     char info[512] = {0};
+    // launches since the workspace was created (gmmvb_pass_counts): E dense, E bound pass, E carried bounds,
+    // pruned E-step that fell back to the dense kernel, carried pass that had to bound afresh, M dense, M lists,
+    // candidate gathers
+    int64_t passes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool prof = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // E begin/end, M begin/end
     bool ev_e = false, ev_m = false;
+    // per-kernel-group spans of the last E-step + M-step (gmmvb_profile_spans): slot, begin/end event
+    static constexpr int kMaxSpans = 24;
+    int n_spans = 0;
+    int span_slot[kMaxSpans] = {0};
+    hipEvent_t span_ev[2 * kMaxSpans] = {nullptr};
     gmmvb_hmm_state* hmm = nullptr;
 };
 

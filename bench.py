@@ -2,69 +2,118 @@
 """GMM-VB E+M samples/sec at K=64, D=128 (BASELINE.json metric), one process per GPU.
 
 A "step" is one full VB iteration of ``gaussianmixture.LearnModel.update_posterior``'s inner loop
-(reference ``_gaussianmixture.py:864-867``): K-side posterior update -> parameter packing ->
-E-step kernel -> row log-normaliser -> M-step kernel -> slab reduction -> (all-reduce over row
-shards) -> moments -> variational lower bound (one host sync).  x is resident in HBM before the
-timed region.  ``value`` = rows processed by all ranks per second.
+(reference ``_gaussianmixture.py:864-867``): K-side posterior update -> parameter packing -> E-step ->
+row log-normaliser -> M-step statistics -> slab reduction -> (all-reduce over row shards) -> moments ->
+variational lower bound (one host sync).  x is resident in HBM before the timed region.
+``value`` = rows processed by all ranks per second.
 
-Single GPU (default): N = 1e7 rows of f32 (BASELINE.json configs[2], the config the metric is quoted
-on; it fits one GPU).  N GPUs: every rank holds its own 1e7 rows (weak scaling), statistics are
-combined by ONE all-reduce(sum, f64) of K(2 + D + D^2) doubles per step over RCCL.
+    python bench.py --gpus N --steps K --warmup W [--config c3|c4|c2] [--scaling weak|strong] [--overlap] [--dense]
 
-The data pass is sparse where the responsibilities are: once a VB iteration has left
-at most half of the (sample, component) pairs with r >= 2^-100, the next E-step proves the other pairs
-irrelevant with an int8-digit bound pass and evaluates only the candidates in f64, and the M-step runs over the
-active samples of each component.  Results equal the dense kernels' to rounding; ``sparse_check`` re-runs the last
-iteration's data pass with the dense kernels and reports the difference of the statistics.  ``--dense`` switches
-both off (every pair evaluated in f64: the round-1 v5 numbers).  ``per_step`` / ``warmup_steps`` list every
-iteration's kernel times and sparsity, including the dense first iterations.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N rank processes itself (before this
+process touches a GPU); under ``python -m torch.distributed.run`` the ranks come from the environment.  Every rank
+joins an RCCL ("nccl") process group and the JSON line reports ``rccl_ranks``.
 
-Also reported on the same JSON line:
-  roofline      dominant phase against the f64 MFMA peak, duration from HIP events recorded in the
-                library around that phase's launches on their stream (gmmvb_profile_last_ms)
-  cpu_baseline  the oracle (NumPy port of the reference's formulation) timed on this host's cores
-                over 10 VB iterations of the first N_ref = 20000 rows (rank 0, N = 1 only)
-  parity        max relative error of the posterior hyper-parameters after those 10 iterations, GPU
-                path vs oracle on the same N_ref rows (north_star tolerance 1e-5)
+Configurations (BASELINE.json ``configs``): c3 = K64 D128 N1e7 f32 (default, the one the metric is quoted on),
+c4 = K256 D64 1.25e7 rows per GPU (N = 1e8 over 8 GPUs), c2 = K16 D32 N1e6 f64.  ``--scaling weak`` (default):
+every rank holds the configuration's rows; ``--scaling strong``: ``--total-rows`` are split over the ranks.
+
+Legs of the default single-GPU run, all on the same JSON line:
+  value/roofline  the default policy (sparse where the responsibilities are), timed
+  dense           the same data pass with the dense f64 MFMA kernels (every pair evaluated): the floor the policy
+                  falls back to, its executed TFLOP/s against the f64 MFMA peak, and the difference of the
+                  statistics block between the two paths on identical parameters
+  hard_workload   heavily overlapping clusters (means 0.3 * randn): what the policy does when nothing can be pruned
+  cpu_baseline    the oracle (NumPy port of the reference's formulation) on this host's cores, 10 VB iterations over
+                  the first N_ref rows
+  parity          GPU driver vs oracle on those rows after 10 iterations (north_star tolerance 1e-5), twice: with the
+                  default policy (dense kernels at that size) and with the sparse path forced (int8 bound pass,
+                  carried bounds, candidate gathers, list M-step - the kernels of the timed steps)
+
+roofline: the sparse step is bandwidth/latency bound, so the yardstick is HBM: ``achieved`` =
+algorithmic bytes of the dominant kernel group per launch (rows it has to read x D x s) / its HIP-event
+time; ``step_hbm_frac`` = the whole step's N D s bytes / step time / 8 TB/s (= value / HBM-roofline samples/s).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import warnings
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bayesml_amd import RowShard, _kside                      # noqa: E402
-from bayesml_amd import gaussianmixture as gm                 # noqa: E402
-
 SEED = 20250711
-PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X datasheet FP64 matrix (MI355X_MICROARCH.md lists no f64 row; see DESIGN.md)
-PEAK_I8_MFMA_TOPS = 5000.0       # dense int8 = fp8 rate (MI355X_MICROARCH.md); tools/i8_probe.hip sustains 4950 / 3600
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X datasheet FP64 matrix (the guide lists no f64 row; tools/peak_probe.hip: 72.7-74.2)
+CONFIGS = {"c2": dict(classes=16, degree=32, rows=1_000_000, dtype="f64", total=1_000_000),
+           "c3": dict(classes=64, degree=128, rows=10_000_000, dtype="f32", total=10_000_000),
+           "c4": dict(classes=256, degree=64, rows=12_500_000, dtype="f32", total=100_000_000)}
 
 
-def recipe_means(K, D):
-    """First draw of the synthetic recipe: mu = 2 * standard_normal((K, D))."""
-    return 2.0 * np.random.default_rng(SEED).standard_normal((K, D))
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--total-rows", type=int, default=None, help="strong scaling: rows of the whole job")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (overrides the configuration)")
+    ap.add_argument("--classes", type=int, default=None)
+    ap.add_argument("--degree", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["f32", "f64"], help="storage dtype of x in HBM")
+    ap.add_argument("--ref-rows", type=int, default=20_000)
+    ap.add_argument("--overlap", action="store_true", help="hard workload: cluster means 0.3 * randn instead of 2 * randn")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the dense and hard-workload legs")
+    ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
+    return ap.parse_args()
 
 
-def recipe_rows_host(K, D, n, dtype):
+def launch_ranks(n):
+    """Start n rank processes of this script (rank r on GPU r).  The parent never initialises a GPU."""
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the runtime
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def recipe_means(K, D, spread):
+    """First draw of the synthetic recipe: mu = spread * standard_normal((K, D))."""
+    return spread * np.random.default_rng(SEED).standard_normal((K, D))
+
+
+def recipe_rows_host(K, D, n, dtype, spread):
     """First n rows of the recipe, drawn on the host exactly like oracle.synth_gmm (chunk boundary 2**20 > n)."""
     rng = np.random.default_rng(SEED)
-    mu = 2.0 * rng.standard_normal((K, D))
+    mu = spread * rng.standard_normal((K, D))
     z = rng.integers(0, K, n)
     return (mu[z] + rng.standard_normal((n, D))).astype(dtype)
 
 
-def device_rows(K, D, n, dtype, dev, seed, head=None):
+def device_rows(K, D, n, dtype, dev, seed, spread, head=None):
     """Same mixture drawn with the device generator, in chunks; the first len(head) rows are `head`."""
-    mu = torch.from_numpy(recipe_means(K, D)).to(dev)
+    import torch
+    mu = torch.from_numpy(recipe_means(K, D, spread)).to(dev)
     x = torch.empty((n, D), dtype=dtype, device=dev)
     gen = torch.Generator(device=dev).manual_seed(seed)
     step = 1 << 20
@@ -77,8 +126,28 @@ def device_rows(K, D, n, dtype, dev, seed, head=None):
     return x
 
 
+class env_vars:
+    """Library switches are read when a workspace is created (GMMVB_ESTEP_CARRY_OFF: at every E-step)."""
+    KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE")
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.KEYS}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
 def cpu_baseline_and_parity(K, D, x_ref, dev, iters=10):
-    """Oracle (test infrastructure) on the host cores vs the GPU driver on the same rows."""
+    """Oracle (test infrastructure) on the host cores vs the GPU driver on the same rows: with the default policy and
+    with the sparse path forced (the kernels of the timed steps: int8 bound pass, carried bounds, gathers, lists)."""
+    from bayesml_amd import gaussianmixture as gm
     from oracle import gmm_vb_oracle as orc
     x64 = x_ref.astype(np.float64)
     p = orc.Prior.default(K, D)
@@ -97,218 +166,341 @@ def cpu_baseline_and_parity(K, D, x_ref, dev, iters=10):
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:      # noqa: BLE001
         threads = os.cpu_count() or 1
-    m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        m.update_posterior(x_ref, max_itr=iters, num_init=1, tolerance=0.0)
-
-    def rel(a, b):
-        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
-
-    errs = dict(hn_alpha_vec=rel(m.hn_alpha_vec, q.alpha), hn_m_vecs=rel(m.hn_m_vecs, q.m),
-                hn_kappas=rel(m.hn_kappas, q.kappa), hn_nus=rel(m.hn_nus, q.nu),
-                hn_w_mats=rel(m.hn_w_mats, q.w), hn_w_mats_inv=rel(m.hn_w_mats_inv, q.w_inv))
     base = dict(value=x_ref.shape[0] * iters / cpu_s, unit="samples/s", cores=int(threads), kind="port",
                 sample=f"{iters} VB iterations (K-side + E + M + lower bound, fp64 NumPy/OpenBLAS, "
                        f"{threads} threads of {os.cpu_count()} cores) over the first {x_ref.shape[0]} rows of the workload",
                 seconds=cpu_s)
-    par = dict(max_rel_err=max(errs.values()), tolerance=1e-5, passed=max(errs.values()) < 1e-5, per_array=errs,
-               rows=int(x_ref.shape[0]), iterations=iters)
-    m._engine.close()
-    return base, par
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+    def gpu_run(label, **switches):
+        with env_vars(**switches):
+            m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m.update_posterior(x_ref, max_itr=iters, num_init=1, tolerance=0.0)
+        errs = dict(hn_alpha_vec=rel(m.hn_alpha_vec, q.alpha), hn_m_vecs=rel(m.hn_m_vecs, q.m),
+                    hn_kappas=rel(m.hn_kappas, q.kappa), hn_nus=rel(m.hn_nus, q.nu),
+                    hn_w_mats=rel(m.hn_w_mats, q.w), hn_w_mats_inv=rel(m.hn_w_mats_inv, q.w_inv))
+        counts = m._engine.pass_counts()
+        m._engine.close()
+        return dict(max_rel_err=max(errs.values()), tolerance=1e-5, passed=max(errs.values()) < 1e-5, per_array=errs,
+                    rows=int(x_ref.shape[0]), iterations=iters, kernel_launches=counts,
+                    path=label + ": " + ", ".join(f"{k} x{v}" for k, v in counts.items() if v))
+
+    return base, gpu_run("default policy"), gpu_run("GMMVB_ESTEP_PRUNE=force", GMMVB_ESTEP_PRUNE="force")
+
+
+class Workload:
+    """One model + sample matrix driven through the same internals update_posterior uses."""
+
+    def __init__(self, K, D, x, dev, comm):
+        import torch
+        from bayesml_amd import _kside
+        from bayesml_amd import gaussianmixture as gm
+        self.K, self.D, self.n = K, D, x.shape[0]
+        self.kside = _kside
+        self.m = gm.LearnModel(K, D, seed=0, device=dev, comm=comm, verbose=False)
+        self.eng, self.xd = self.m._open(x)
+        self.eng.profile(True)
+        self.prior = self.m._prior_tensors(dev)
+        q = _kside.post_from_prior(self.prior)
+        self.q = self.m._init_subsampling(self.eng, self.xd, q, self.m._comm.global_rows)
+        s_prev = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
+        self.ns, self.x_bar, self.s, self.h = self.m._pass(self.eng, self.xd, self.q, s_prev)
+        self.q_next = _kside.update_q(self.prior, self.ns, self.x_bar, self.s)
+        self.hint = self.m._drift_hint(self.eng, self.xd, self.q, self.q_next)
+
+    def step(self):
+        # as in update_posterior's loop: the next K-side update (and its drift hint for the E-step) is enqueued before
+        # the lower bound is read back
+        m, ks = self.m, self.kside
+        self.q = self.q_next
+        self.ns, self.x_bar, self.s, self.h = m._pass(self.eng, self.xd, self.q, self.s, hint=self.hint)
+        terms = ks.lower_bound(self.prior, self.q, self.ns, self.x_bar, self.s, self.h)
+        self.q_next = ks.update_q(self.prior, self.ns, self.x_bar, self.s)
+        self.hint = m._drift_hint(self.eng, self.xd, self.q, self.q_next)
+        vl, self.hint = m._read_vl(terms, self.hint)      # one device-to-host copy: the lower bound and the mean gamma
+        return vl
+
+    def snapshot(self):
+        a, e = self.eng.sparsity()
+        em, mm = self.eng.last_kernel_ms()
+        return dict(estep_ms=round(em, 2), mstep_ms=round(mm, 2),
+                    kernels=[p.strip().split(" ")[0] for p in self.eng.launch_info.split("|")],
+                    active_components_per_sample=round(a / self.n, 2) if a >= 0 else None,
+                    evaluated_components_per_sample=round(e / self.n, 2))
+
+    def close(self):
+        self.eng.close()
+        self.m._engine = None
+
+
+def kernel_name(info_part):
+    return info_part.strip().split("<")[0].split(" ")[0]
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
-    ap.add_argument("--classes", type=int, default=64)
-    ap.add_argument("--degree", type=int, default=128)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="storage dtype of x in HBM")
-    ap.add_argument("--ref-rows", type=int, default=20_000)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
-    ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
-    args = ap.parse_args()
-    if args.dense:
-        os.environ["GMMVB_ESTEP_PRUNE"] = "0"
-        os.environ["GMMVB_MSTEP_SPARSE"] = "0"
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from bayesml_amd import RowShard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus != 1:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        args.gpus = world
+    if args.dense:
+        os.environ["GMMVB_ESTEP_PRUNE"] = "0"
+        os.environ["GMMVB_MSTEP_SPARSE"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
         comm = RowShard()
-    K, D, n_local = args.classes, args.degree, args.rows
-    tdtype = torch.float32 if args.dtype == "f32" else torch.float64
-    ndtype = np.float32 if args.dtype == "f32" else np.float64
+        # every rank contributes 1: proves the RCCL group really spans `world` processes
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == world
+
+    cfg = CONFIGS[args.config]
+    K = args.classes or cfg["classes"]
+    D = args.degree or cfg["degree"]
+    dt = args.dtype or cfg["dtype"]
+    if args.scaling == "strong":
+        total = args.total_rows or cfg["total"]
+        n_local = total // world + (1 if rank < total % world else 0)
+    else:
+        n_local = args.rows or cfg["rows"]
+    spread = 0.3 if args.overlap else 2.0
+    tdtype = torch.float32 if dt == "f32" else torch.float64
+    ndtype = np.float32 if dt == "f32" else np.float64
+    esz = 4 if dt == "f32" else 8
 
     # ---- workload, resident in HBM before anything is timed
-    x_ref = recipe_rows_host(K, D, min(args.ref_rows, n_local), ndtype)
-    x = device_rows(K, D, n_local, tdtype, dev, SEED + 1 + rank, head=x_ref if rank == 0 else None)
+    x_ref = recipe_rows_host(K, D, min(args.ref_rows, n_local), ndtype, spread)
+    x = device_rows(K, D, n_local, tdtype, dev, SEED + 1 + rank, spread, head=x_ref if rank == 0 else None)
 
-    cpu_base = parity = None
+    cpu_base = parity = parity_sparse = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu_base, parity = cpu_baseline_and_parity(K, D, x_ref, dev)
+        cpu_base, parity, parity_sparse = cpu_baseline_and_parity(K, D, x_ref, dev)
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu
 
-    # ---- the model, driven through the same internals update_posterior uses
-    m = gm.LearnModel(K, D, seed=0, device=dev, comm=comm, verbose=False)
-    eng, xd = m._open(x)
-    eng.profile(True)
-    prior = m._prior_tensors(dev)
-    q = _kside.post_from_prior(prior)
-    q = m._init_subsampling(eng, xd, q, m._comm.global_rows)
-    s_prev = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
-    ns, x_bar, s, h = m._pass(eng, xd, q, s_prev)
-
-    q_next = _kside.update_q(prior, ns, x_bar, s)
-    hint = m._drift_hint(eng, xd, q, q_next)
-
-    def step():
-        # as in update_posterior's loop: the next K-side update (and its drift hint for the E-step) is enqueued before
-        # the lower bound is read back
-        nonlocal q, q_next, hint, ns, x_bar, s, h
-        q = q_next
-        ns, x_bar, s, h = m._pass(eng, xd, q, s, hint=hint)
-        terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
-        q_next = _kside.update_q(prior, ns, x_bar, s)
-        hint = m._drift_hint(eng, xd, q, q_next)
-        vl, hint = m._read_vl(terms, hint)          # one device-to-host copy: the lower bound and the mean gamma
-        return vl
-
-    def snapshot():
-        a, e = eng.sparsity()
-        em, mm = eng.last_kernel_ms()
-        return dict(estep_ms=round(em, 2), mstep_ms=round(mm, 2), kernels=[p.strip().split(" ")[0] for p in eng.launch_info.split("|")],
-                    active_components_per_sample=round(a / n_local, 2) if a >= 0 else None,
-                    evaluated_components_per_sample=round(e / n_local, 2))
-
+    w = Workload(K, D, x, dev, comm)
+    eng = w.eng
     torch.cuda.synchronize()
-    warm = [dict(snapshot(), what="pass after the subsampling initialisation")]
+    warm = [dict(w.snapshot(), what="pass after the subsampling initialisation")]
     for _ in range(args.warmup):
-        step()
-        warm.append(dict(snapshot(), what="warm-up iteration"))
+        w.step()
+        warm.append(dict(w.snapshot(), what="warm-up iteration"))
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ker, launches, spars = [], [], []
+    ker, launches, spars, spans = [], [], [], []
+    counts0 = eng.pass_counts()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        vl = step()
+        vl = w.step()
         ker.append(eng.last_kernel_ms())        # events already complete: step() ended with a host sync
+        spans.append(eng.kernel_spans())
         launches.append(eng.launch_info)
         spars.append(eng.sparsity())
     fence()
     elapsed = time.perf_counter() - t0
+    counts1 = eng.pass_counts()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        tot = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        n_total = int(tot.item())
+    else:
+        n_total = n_local
 
     if rank == 0:
-        n_total = n_local * world
+        steps = args.steps
+        step_ms = elapsed / steps * 1e3
         e_ms = float(np.mean([k[0] for k in ker]))
         m_ms = float(np.mean([k[1] for k in ker]))
-        # algorithmic flops per sample: E = K(2D^2+3D) + 6K, M = K(2D^2+2D) + 2KD
-        fl_e = K * (2 * D * D + 3 * D) + 6 * K
-        fl_m = K * (2 * D * D + 2 * D) + 2 * K * D
-        names = [part.strip().split("<")[0].split(" ")[0] for part in eng.launch_info.split("|")]   # kernels of the last step
-        # executed f64 MFMA flops per evaluated (sample, component) pair: T(T+1)/2 tile pairs of 16x16 x 512 flops
+        names = [kernel_name(p) for p in eng.launch_info.split("|")]      # kernels of the last step
         tiles = (D + 15) // 16
-        fl_pair = 512 * tiles * (tiles + 1) // 2
-        ev = float(np.mean([e for _, e in spars]))          # pairs evaluated exactly per E-step
-        ac = float(np.mean([a for a, _ in spars]))          # active pairs (the M-step's, when it runs sparse)
-        m_sparse = names[1].startswith("mstep_list")
-        kern = {"estep": dict(ms=e_ms, kernels=names[0] + ("+select+estep_gather_f64" if "bound" in names[0] else ""),
-                              passes={k: sum(1 for l in launches if l.startswith(k)) for k in
-                                      ("estep_lds_f64", "estep_i8_bound", "estep_carried_bounds")},
-                              algorithmic_tflops=fl_e * n_local / (e_ms * 1e-3) / 1e12,
-                              exact_pairs_f64_tflops=fl_pair * ev / (e_ms * 1e-3) / 1e12),
-                "mstep": dict(ms=m_ms, kernels=names[1] + ("+select" if m_sparse else ""),
-                              algorithmic_tflops=fl_m * n_local / (m_ms * 1e-3) / 1e12,
-                              executed_f64_tflops=fl_pair * (ac if m_sparse else n_local * K) / (m_ms * 1e-3) / 1e12)}
-        if "bound" in names[0] and "i8" in names[0]:
-            # int8 bound pass: 6 MFMAs of 65536 ops per 32x32x32 block pair, tri_pairs(blocks) pairs, per 32 samples
-            blocks = int(eng.launch_info.split("blocks=")[1].split(">")[0])
-            kern["estep"]["bound_pass_i8_ops"] = 6 * 65536 * blocks * (blocks + 1) // 2 * K * n_local / 32
-            kern["estep"]["bound_pass_i8_peak_tops"] = PEAK_I8_MFMA_TOPS
-        dom = max(kern, key=lambda k: kern[k]["ms"])
-        ach = kern[dom]["algorithmic_tflops"]
-        # HBM-side bytes per launch of the phase's dominant kernel: PMC counters cannot be read from inside this process,
-        # so take them from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py)
+        fl_pair = 512 * tiles * (tiles + 1) // 2        # executed f64 MFMA flops per exactly evaluated (sample, component)
+        ev = float(np.mean([e for _, e in spars]))      # pairs evaluated exactly per E-step
+        ac = float(np.mean([a for a, _ in spars]))      # active pairs (the M-step's, when it runs over lists)
+        timed_counts = {k: counts1[k] - counts0[k] for k in counts1}
+        m_sparse = timed_counts["mstep_list"] > 0
+        # ---- per kernel group: mean HIP-event ms per step, algorithmic bytes per step (rows the group must read x D x s)
+        groups = {}
+        for g in sorted({g for s in spans for g in s}):
+            groups[g] = dict(ms=float(np.mean([s.get(g, (0.0, 0))[0] for s in spans])),
+                             launch_groups_per_step=float(np.mean([s.get(g, (0.0, 0))[1] for s in spans])))
+        row_bytes = D * esz
+        sparse_e = timed_counts["estep_bound"] + timed_counts["estep_carried"] > 0
+        alg = {"estep_main": n_local * row_bytes * (timed_counts["estep_dense"] + timed_counts["estep_bound"]
+                                                    + timed_counts["estep_fell_back_dense"]) / steps,
+               "estep_gather": ev * row_bytes if sparse_e else 0.0,
+               "mstep_main": (ac if m_sparse else n_local) * row_bytes}
+        for g, b in alg.items():
+            if g in groups and groups[g]["ms"] > 0:
+                groups[g]["algorithmic_bytes"] = b
+                groups[g]["algorithmic_GBps"] = b / (groups[g]["ms"] * 1e-3) / 1e9
+        if groups.get("estep_gather", {}).get("ms", 0) > 0:
+            groups["estep_gather"]["executed_f64_tflops"] = fl_pair * ev / groups["estep_gather"]["ms"] / 1e9
+        if "mstep_main" in groups:
+            groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (ac if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
+        cand = [g for g in ("estep_main", "estep_gather", "mstep_main") if g in groups and "algorithmic_GBps" in groups[g]]
+        dom = max(cand, key=lambda g: groups[g]["ms"])
+        dom_kernel = {"estep_main": names[0], "estep_gather": "estep_gather_f64", "mstep_main": names[1]}[dom]
+        ach = groups[dom]["algorithmic_GBps"]
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so they come
+        # from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py), and only when that
+        # file was made for the kernel that actually ran here
         traffic = traffic_src = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f).get(names[0 if dom == "estep" else 1])
-            if pm and K == 64 and D == 128 and n_local == 10_000_000 and args.dtype == "f32":
+                pm = json.load(f).get({"estep_i8_bound": "estep_i8"}.get(dom_kernel, dom_kernel))
+            ran = dom_kernel == "estep_gather_f64" or any(dom_kernel in l for l in launches)
+            if pm and pm.get("config") == f"K{K} D{D} N{n_local} {dt}" and ran:
                 traffic = pm["fetch_bytes"] + pm["write_bytes"]
                 traffic_src = "profiles/pmc_traffic.json: " + pm["note"]
         except (OSError, ValueError, KeyError):
             pass
-        sparse_check = None
-        if not args.dense and world == 1:
-            # the last iteration's data pass again, every pair in f64 with the dense kernels, on the same parameters
-            from bayesml_amd._engine import DataPass
-            os.environ["GMMVB_ESTEP_PRUNE"] = "0"
-            os.environ["GMMVB_MSTEP_SPARSE"] = "0"
-            ref = DataPass(K, D, xd.dtype, n_local, dev)
-            ref.set_pivot(eng.pivot)
-            ref.prepare_rows(xd)
-            f = q                                   # update_q() returns the posterior with its features
-            ref.set_params(f.c, f.m, f.u)
-            st_ref = ref.estep_mstep(xd)
-            ref_info = ref.launch_info
-            eng.set_params(f.c, f.m, f.u)
-            st_new = eng.estep_mstep(xd)
-            num = float((st_new - st_ref).abs().max())
-            den = float(st_ref.abs().max())
-            blocks_rel = []
-            for a_, b_ in zip(eng.split_stats(st_new), ref.split_stats(st_ref)):
-                blocks_rel.append(float((a_ - b_).abs().max() / b_.abs().max()))
-            sparse_check = {"max_rel_diff_of_statistics": num / den,
-                            "per_block_ns_h_a_B": blocks_rel, "dense_kernels": ref_info, "sparse_kernels": eng.launch_info}
-            ref.close()
-        bytes_per_sample = D * x.element_size()
+        step_bytes = n_local * row_bytes
+        roof = {"bound": "hbm", "kernel": dom_kernel, "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "step_algorithmic_bytes": step_bytes,
+                "step_hbm_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
+                "step_hbm_frac": step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                "hbm_roofline_samples_per_s": PEAK_HBM_GBPS * 1e9 / row_bytes,
+                "f64_mfma_ceiling_samples_per_s": (PEAK_F64_MFMA_TFLOPS * 1e12 / (fl_pair * (ev + ac) / n_local)
+                                                   if (ev + ac) > 0 else None),
+                "kernel_groups": groups,
+                "events_ms_per_step": sum(g["ms"] for g in groups.values()),
+                "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
+                "phase_ms": {"estep": e_ms, "mstep": m_ms},
+                "timed_kernel_launches": timed_counts,
+                "note": "achieved = algorithmic bytes of the dominant kernel group per step (rows it must read x D x s, "
+                        "SURVEY 8d) / its HIP-event time per step; frac <= 1 by construction.  step_hbm_frac = value / "
+                        "hbm_roofline_samples_per_s.  f64_mfma_ceiling = the rate at which the f64 matrix pipe alone could "
+                        "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M)"}
+        if args.dense or not sparse_e:
+            # the dense kernels are MFMA-bound: executed flops against the f64 MFMA peak
+            ex = fl_pair * n_local * K
+            roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_F64_MFMA_TFLOPS,
+                        achieved=ex / (groups[dom]["ms"] * 1e-3) / 1e12,
+                        frac=ex / (groups[dom]["ms"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS)
+        assert roof["frac"] <= 1.0 + 1e-9, roof
+
+        last_launch = eng.launch_info
+        dense_leg = hard = None
+        if not args.dense and world == 1 and not args.no_legs:
+            dense_leg = dense_leg_run(w, K, D, n_local, fl_pair)
+            w.close()
+            del w, x
+            torch.cuda.empty_cache()
+            if not args.overlap:
+                hard = hard_workload_leg(K, D, n_local, tdtype, ndtype, dev, parity=do_cpu)
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
-            "value": n_total * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"GMM-VB K={K} D={D} N={n_local} rows/GPU x {world} GPU, x stored {args.dtype}, "
-                                   "one VB iteration per step (configs[2] of BASELINE.json)",
-                       "classes": K, "degree": D, "rows_per_gpu": n_local, "x_storage": args.dtype,
-                       "parallelism": f"rows{world}"},
-            "roofline": {"bound": "mfma", "kernel": kern[dom]["kernels"], "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "kernels": kern,
-                         "hbm_algorithmic_GBps": bytes_per_sample * n_local / ((e_ms + m_ms) * 1e-3) / 1e9,
-                         "note": "achieved = algorithmic (dense) flops of SURVEY 8d / HIP-event time of the phase.  The "
-                                 "dense kernels execute 0.56x of them (triangular whitening factor, symmetric second "
-                                 "moment) at 87-90 % of the f64 MFMA issue rate (--dense); the sparse path executes only "
-                                 "the pairs that can matter (exact_pairs_f64_tflops / executed_f64_tflops) plus the "
-                                 "int8 bound pass, so frac is far above 1 and says how much work was avoided, not "
-                                 "how busy the pipe is"},
-            "cpu_baseline": cpu_base, "parity": parity, "sparse_check": sparse_check, "final_vl": vl,
-            "launch": eng.launch_info, "warmup_steps": warm,
+            "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "steps": steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"GMM-VB K={K} D={D} N={n_local} rows/GPU x {world} GPU, x stored {dt}, "
+                                   f"one VB iteration per step ({args.config} of BASELINE.json configs"
+                                   f"{', overlapping clusters' if args.overlap else ''})",
+                       "classes": K, "degree": D, "rows_per_gpu": n_local, "rows_total": n_total, "x_storage": dt,
+                       "cluster_spread": spread, "parallelism": f"rows{world}"},
+            "roofline": roof, "dense": dense_leg, "hard_workload": hard,
+            "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,
+            "launch": last_launch, "warmup_steps": warm,
             "per_step": {"estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
-                         "estep_kernel": [l.split("<")[0].split(" ")[0] for l in launches],
+                         "estep_kernel": [kernel_name(l) for l in launches],
                          "active_components_per_sample": [round(a / n_local, 2) if a >= 0 else None for a, _ in spars],
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars]},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def dense_leg_run(w, K, D, n_local, fl_pair):
+    """The last iteration's data pass again, every pair in f64 with the dense kernels, on the same parameters: the
+    floor the policy falls back to, its MFMA utilisation, and the difference between the two paths' statistics."""
+    from bayesml_amd._engine import DataPass
+    eng, xd, q = w.eng, w.xd, w.q
+    with env_vars(GMMVB_ESTEP_PRUNE="0", GMMVB_MSTEP_SPARSE="0"):
+        ref = DataPass(K, D, xd.dtype, n_local, xd.device)
+    ref.profile(True)
+    ref.set_pivot(eng.pivot)
+    ref.prepare_rows(xd)
+    ref.set_params(q.c, q.m, q.u)
+    st_ref = ref.estep_mstep(xd)
+    st_ref = ref.estep_mstep(xd)            # second pass: warm instruction caches / clocks
+    e_ms, m_ms = ref.last_kernel_ms()
+    ref_info = ref.launch_info
+    eng.set_params(q.c, q.m, q.u)
+    st_new = eng.estep_mstep(xd)
+    num = float((st_new - st_ref).abs().max())
+    den = float(st_ref.abs().max())
+    blocks_rel = [float((a_ - b_).abs().max() / b_.abs().max())
+                  for a_, b_ in zip(eng.split_stats(st_new), ref.split_stats(st_ref))]
+    ex = fl_pair * n_local * K
+    leg = {"estep": {"kernel": ref_info.split("|")[0].strip(), "ms": e_ms, "executed_f64_tflops": ex / e_ms / 1e9,
+                     "frac_of_f64_mfma_peak": ex / e_ms / 1e9 / PEAK_F64_MFMA_TFLOPS},
+           "mstep": {"kernel": ref_info.split("|")[1].strip(), "ms": m_ms, "executed_f64_tflops": ex / m_ms / 1e9,
+                     "frac_of_f64_mfma_peak": ex / m_ms / 1e9 / PEAK_F64_MFMA_TFLOPS},
+           "peak_f64_mfma_tflops": PEAK_F64_MFMA_TFLOPS,
+           "kernel_only_samples_per_s": n_local / ((e_ms + m_ms) * 1e-3),
+           "sparse_vs_dense_statistics": {"max_rel_diff": num / den, "per_block_ns_h_a_B": blocks_rel,
+                                          "sparse_kernels": eng.launch_info}}
+    ref.close()
+    return leg
+
+
+def hard_workload_leg(K, D, n_local, tdtype, ndtype, dev, warmup=2, steps=3, parity=True):
+    """Same shape, cluster means 0.3 * randn: the components overlap, (almost) every pair matters and the policy has to
+    stay on (or fall back to) the dense kernels."""
+    import torch
+    x = device_rows(K, D, n_local, tdtype, dev, SEED + 77, 0.3)
+    w = Workload(K, D, x, dev, None)
+    for _ in range(warmup):
+        w.step()
+    c0 = w.eng.pass_counts()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    snaps = []
+    for _ in range(steps):
+        w.step()
+        snaps.append(w.snapshot())
+    torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    c1 = w.eng.pass_counts()
+    out = {"workload": f"K={K} D={D} N={n_local}, cluster means 0.3 * randn (overlapping)", "steps": steps, "warmup": warmup,
+           "samples_per_s": n_local * steps / dt_s, "ms_per_step": dt_s / steps * 1e3,
+           "kernel_launches": {k: c1[k] - c0[k] for k in c1}, "per_step": snaps}
+    w.close()
+    if parity:       # a bounded oracle run on overlapping rows (6 iterations over 6000 rows), both policies
+        x_ref = recipe_rows_host(K, D, min(6000, n_local), ndtype, 0.3)
+        _base, out["parity"], out["parity_sparse_path"] = cpu_baseline_and_parity(K, D, x_ref, dev, iters=6)
+    return out
 
 
 if __name__ == "__main__":

@@ -134,15 +134,29 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
  * 16b + (g + 4r) at position 16b + 4g + r), 1 c' ([n_rows]), 2 row shift max_k ln rho ([n_rows]). */
 int hmmvb_debug_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
 
-/* Optional in-library timing of the two dominant kernels with HIP events recorded on the launch
- * stream immediately before/after the estep_mfma_f64 / mstep_mfma_f64 launches (bench.py's
- * roofline leg).  gmmvb_profile_last_ms waits for the events of the last estep / mstep. */
+/* Optional in-library timing with HIP events recorded on the launch stream: gmmvb_profile_last_ms gives the
+ * E-step phase (first launch of gmmvb_estep to its last exact evaluation, i.e. the dense kernel estep_lds_f64, or
+ * bound pass + selections + gathers) and the M-step phase (list building + mstep_mfma_f64 / mstep_list_f64) of the
+ * last passes (bench.py's roofline leg); it waits for those events. */
 int gmmvb_profile_enable(gmmvb_workspace* ws, int on);
 int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms);
+
+/* Finer view of the same profile: HIP-event time (ms, summed over the launches of a group) and number of launch
+ * groups per slot for the last gmmvb_estep + gmmvb_mstep; gmmvb_profile_span_name(slot) names the slots
+ * ("estep_main" = dense / bound kernel, "estep_select", "estep_gather", "estep_lse_mask", "mstep_lists",
+ * "mstep_main" = dense / list kernel, "mstep_reduce"; "" = unused).  Waits for the last recorded event. */
+int gmmvb_profile_spans(gmmvb_workspace* ws, float* ms /*[8]*/, int* launches /*[8]*/);
+const char* gmmvb_profile_span_name(int slot);
 
 /* Kernel names and launch geometry of the last estep/mstep (for profiling reports); returns a
  * static string such as "estep_mfma_f64<8,2,f32,vec> grid=1024x256". */
 const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
+
+/* Which kernels have run in this workspace since it was created (for tests and profiling reports):
+ *   out[0] dense E-steps, out[1] bound passes of the pruned E-step, out[2] E-steps on carried bounds, out[3] pruned
+ *   E-steps that fell back to the dense kernel, out[4] carried passes that had to bound afresh, out[5] dense M-steps,
+ *   out[6] M-steps over active-row lists, out[7] candidate gathers (exact f64 evaluation of listed pairs). */
+int gmmvb_pass_counts(const gmmvb_workspace* ws, int64_t* out /*[8]*/);
 
 /* Optional hint for the pruned E-step, to be given BEFORE the gmmvb_set_params of new parameters: for every component k
  * gamma[k] <= sigma_min(u_new u_old^-1) and delta[k] >= || u_new (m_new - m_old) ||_2, where (m_old, u_old) are the

@@ -331,12 +331,13 @@ def estimate_latent_vars(x: np.ndarray, q: Posterior, loss: str = "0-1") -> np.n
 
 # --------------------------------------------------------------------------- workloads
 def synth_gmm(K: int, D: int, N: int, dtype=np.float64, seed: int = 20250711,
-              chunk: int = 1 << 20) -> np.ndarray:
+              chunk: int = 1 << 20, spread: float = 2.0) -> np.ndarray:
     """The benchmark's synthetic sample matrix:
     ``mu = 2*standard_normal((K,D))``, ``z = integers(0,K,N)``,
-    ``x = mu[z] + standard_normal((N,D))`` drawn in fixed 2**20-row chunks."""
+    ``x = mu[z] + standard_normal((N,D))`` drawn in fixed 2**20-row chunks.
+    ``spread`` scales the means (2 = the benchmark; 0.3 = heavily overlapping clusters, the hard workload)."""
     rng = np.random.default_rng(seed)
-    mu = 2.0 * rng.standard_normal((K, D))
+    mu = spread * rng.standard_normal((K, D))
     x = np.empty((N, D), dtype=dtype)
     for lo in range(0, N, chunk):
         hi = min(N, lo + chunk)

@@ -31,3 +31,11 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def mat_functionals(a):
+    """What tests/golden/make_golden_large.py stores of a [K, D, D] array instead of the array itself: the first two
+    matrices, every diagonal, three fixed (seeded) projections and the log-determinants."""
+    a = np.asarray(a, dtype=float)
+    v = np.random.default_rng(7).standard_normal((a.shape[-1], 3))
+    return dict(head=a[:2], diag=np.diagonal(a, axis1=1, axis2=2), proj=a @ v, logabsdet=np.linalg.slogdet(a)[1])

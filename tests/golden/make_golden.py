@@ -123,11 +123,8 @@ def parse_trace(text):
     return traces, winners, converged
 
 
-def full_driver(name, K, D, x, seed, store_x, readouts=True, **kw):
-    """The reference is fed x.astype(float64): for float32 rows its _init_subsampling would otherwise sum
-    the subsample in float32 (`_subsample.sum(axis=0)`, _gaussianmixture.py:790), a 1e-7 perturbation of
-    the start point that the VB transient amplifies to ~2e-6.  "Identical inputs" means identical values
-    (SURVEY.md section 7); the engine stores the same float32 values and widens them on load."""
+def full_driver_state(K, D, x, seed, **kw):
+    """Run the reference's update_posterior on x.astype(float64) and collect what the driver fixtures hold."""
     m = ref_gm.LearnModel(K, D, seed=seed)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
@@ -146,6 +143,18 @@ def full_driver(name, K, D, x, seed, store_x, readouts=True, **kw):
                kw=json.dumps(kw))
     out.update(hn_state(m))
     out.update(feat_state(m))
+    out["_model"] = m
+    return out
+
+
+def full_driver(name, K, D, x, seed, store_x, readouts=True, **kw):
+    """The reference is fed x.astype(float64): for float32 rows its _init_subsampling would otherwise sum
+    the subsample in float32 (`_subsample.sum(axis=0)`, _gaussianmixture.py:790), a 1e-7 perturbation of
+    the start point that the VB transient amplifies to ~2e-6.  "Identical inputs" means identical values
+    (SURVEY.md section 7); the engine stores the same float32 values and widens them on load."""
+    out = full_driver_state(K, D, x, seed, **kw)
+    m = out.pop("_model")
+    winner, warned, traces = out["winner"], out["result_warning"], out["vl_trace"]
     if not readouts:
         out.pop("e_lambda_mats")          # = hn_nus * hn_w_mats; keep the big-D fixture small
         np.savez_compressed(os.path.join(HERE, name), **out)
@@ -170,7 +179,7 @@ def full_driver(name, K, D, x, seed, store_x, readouts=True, **kw):
     if store_x:
         out["x"] = x
     np.savez_compressed(os.path.join(HERE, name), **out)
-    print("wrote", name, "winner", winner, "vl", m.vl, "warned", warned, "iters", [len(t) for t in traces])
+    print("wrote", name, "winner", winner, "vl", m.vl, "warned", warned, "iters", traces.shape)
 
 
 # ------------------------------------------------------------------ F5: boundary errors

@@ -1,0 +1,188 @@
+"""The sparse data pass (int8 bound pass -> candidate lists -> exact f64 gathers -> carried bounds -> M-step over
+active-row lists) against the REFERENCE's outputs - not against the repo's own dense kernels.
+
+Every case runs the public driver (reference ``_gaussianmixture.py:802-896``) on a fixture the reference itself
+produced (tests/golden/make_golden.py, make_golden_large.py), asserts from the library's launch counters that the
+kernels under test really ran, and compares posterior, VL trace and responsibilities with the fixture.  Tolerances are
+relative (max|a-b| / max|b|); north_star asks for 1e-5 on the posterior.
+"""
+import io
+import json
+import os
+import warnings
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, mat_functionals, rel_err
+from oracle import gmm_vb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF")
+VARIANTS = {
+    "default": {},
+    "force": {"GMMVB_ESTEP_PRUNE": "force"},
+    "force_nocarry": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_CARRY_OFF": "1"},
+    "dense": {"GMMVB_ESTEP_PRUNE": "0", "GMMVB_MSTEP_SPARSE": "0"},
+}
+
+
+class env:
+    def __init__(self, kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in ENV_KEYS}
+        for k in ENV_KEYS:
+            os.environ.pop(k, None)
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def run_driver(g, x, variant):
+    from bayesml_amd import gaussianmixture as gm
+    K, D = int(g["K"]), int(g["D"])
+    kw = json.loads(str(g["kw"]))
+    buf = io.StringIO()
+    with env(VARIANTS[variant]):
+        m = gm.LearnModel(K, D, seed=int(g["seed"]), device=torch.device("cuda", 0))
+        with warnings.catch_warnings(), redirect_stdout(buf):
+            warnings.simplefilter("ignore")
+            m.update_posterior(x, **kw)
+            counts = m._engine.pass_counts()
+    lines = [ln for ln in buf.getvalue().split("\n") if ln.strip()]
+    trace = [[float(seg.split("VL: ")[1].split(" ")[0].rstrip("*").replace("(converged)", ""))
+              for seg in ln.split("\r") if seg] for ln in lines]
+    return m, counts, trace
+
+
+def check_trace(trace, g, rtol):
+    tr = g["vl_trace"]
+    assert len(trace) == tr.shape[0]
+    for i, vals in enumerate(trace):
+        ref = tr[i][~np.isnan(tr[i])]
+        assert len(vals) == len(ref)
+        assert np.allclose(vals, ref, rtol=rtol, atol=0), (i, np.max(np.abs(np.array(vals) / ref - 1)))
+
+
+def expect_kernels(counts, variant, min_carried=1):
+    if variant == "dense":
+        assert counts["estep_bound"] == counts["estep_carried"] == counts["mstep_list"] == 0, counts
+        return
+    assert counts["estep_bound"] >= 1 and counts["estep_gather"] >= 2 and counts["mstep_list"] >= 1, counts
+    if variant == "force_nocarry":
+        assert counts["estep_carried"] == 0, counts
+    else:
+        assert counts["estep_carried"] >= min_carried, counts
+
+
+@pytest.mark.parametrize("variant", ["force", "force_nocarry"])
+def test_small_fixture_forced_sparse_matches_reference(variant):
+    """K=8, D=128, N=32768 (f32 rows), 10 iterations: the reference's posterior through the forced sparse path."""
+    g = load_golden("gmm_f3_k8_d128_n32768_f32.npz")
+    x = orc.synth_gmm(8, 128, 32768, np.float32)
+    m, counts, trace = run_driver(g, x, variant)
+    expect_kernels(counts, variant)
+    check_trace(trace, g, 1e-8)
+    hn = m.get_hn_params()
+    for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+        assert rel_err(hn[key], g[key]) < 1e-6, key
+    assert rel_err(m.hn_w_mats_inv, g["hn_w_mats_inv"]) < 1e-6
+    assert rel_err(m.ns, g["ns"]) < 1e-6 and rel_err(m.s_mats, g["s_mats"]) < 1e-5
+    assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
+    assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+
+
+LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n140000_f32.npz", "force_nocarry"),
+         ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
+         ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "dense")]
+
+
+@pytest.mark.parametrize("name,variant", LARGE)
+def test_large_fixture_matches_reference(name, variant):
+    """The benchmark's shape (K=64, D=128) and config 4's (K=256, D=64) at the smallest N where the DEFAULT policy
+    prunes and carries (N K >= 2^23), and overlapping clusters (spread 0.3) where it has to fall back."""
+    g = load_golden(name)
+    K, D, N = int(g["K"]), int(g["D"]), int(g["N"])
+    x = orc.synth_gmm(int(g["K_data"]), D, N, np.float32, spread=float(g["spread"]))
+    m, counts, trace = run_driver(g, x, variant)
+    if "overlap" in name:
+        if variant == "force":          # everything is a candidate: the pruned E-step must still be exact
+            assert counts["estep_bound"] >= 1, counts
+    else:
+        expect_kernels(counts, variant)
+    check_trace(trace, g, 1e-8)
+    hn = m.get_hn_params()
+    for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus"):
+        assert rel_err(hn[key], g[key]) < 1e-6, key
+    for key, got in (("hn_w_mats", hn["hn_w_mats"]), ("hn_w_mats_inv", m.hn_w_mats_inv), ("s_mats", m.s_mats)):
+        for fn, val in mat_functionals(got).items():
+            ref = g[f"{key}_{fn}"]
+            if fn == "logabsdet":
+                assert np.max(np.abs(val - ref)) < 1e-6 * max(1.0, float(np.max(np.abs(ref)))), (key, fn)
+            else:
+                assert rel_err(val, ref) < (1e-5 if key == "s_mats" else 1e-6), (key, fn)
+    assert rel_err(m.ns, g["ns"]) < 1e-6 and rel_err(m.x_bar_vecs, g["x_bar_vecs"]) < 1e-6
+    assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
+    assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
+    assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+
+
+def _oracle_post(q):
+    """Device posterior (bayesml_amd._kside.PostT) -> the oracle's Posterior with its own derived features."""
+    n = lambda t: t.detach().cpu().numpy().copy()   # noqa: E731
+    o = orc.Posterior(alpha=n(q.alpha), m=n(q.m), kappa=n(q.kappa), nu=n(q.nu), w=n(q.w), w_inv=n(q.w_inv))
+    o.refresh_pi()
+    o.refresh_lambda()
+    return o
+
+
+def test_carried_bounds_are_upper_bounds_of_the_oracle():
+    """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
+    the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
+    bound of it lying at least 100 ln 2 below the row's best component; responsibilities and statistics equal the
+    oracle's.  The loop is update_posterior's (K-side update -> drift hint -> data pass)."""
+    from bayesml_amd import _kside
+    from bayesml_amd import gaussianmixture as gm
+    K, D, N = 12, 64, 9000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    x64 = x.astype(np.float64)
+    dev = torch.device("cuda", 0)
+    with env(VARIANTS["force"]):
+        m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
+        eng, xd = m._open(x)
+    prior = m._prior_tensors(dev)
+    q = m._init_subsampling(eng, xd, _kside.post_from_prior(prior), N)
+    s = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
+    ns, x_bar, s, _h = m._pass(eng, xd, q, s)
+    checked = 0
+    for it in range(10):
+        q_new = _kside.update_q(prior, ns, x_bar, s)
+        hint = m._drift_hint(eng, xd, q, q_new)
+        assert hint is not None
+        before = eng.pass_counts()["estep_carried"]
+        q = q_new
+        ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=(hint[0], hint[1], float(hint[0].mean())))
+        if eng.pass_counts()["estep_carried"] == before:
+            continue
+        lb = eng.ln_rho().cpu().numpy()
+        oq = _oracle_post(q)
+        st = orc.data_pass(x64, oq)
+        la = st.ln_rho
+        same = np.abs(la - lb) <= 1e-8 * np.maximum(1.0, np.abs(la))
+        assert same.mean() < 0.9, "nothing was pruned"
+        assert np.all(lb[~same] >= la[~same]), (it, "a carried value is not an upper bound")
+        best = la.max(axis=1, keepdims=True)
+        assert np.all((lb <= best - 69.0) | same), it
+        assert np.max(np.abs(eng.responsibilities().cpu().numpy() - st.r)) < 1e-9
+        assert rel_err(ns.cpu().numpy(), st.ns) < 1e-10 and rel_err(s.cpu().numpy(), st.s) < 1e-9
+        checked += 1
+    assert checked >= 3, eng.pass_counts()

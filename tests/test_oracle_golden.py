@@ -141,3 +141,25 @@ def test_error_fixture_is_present_and_sane():
     assert e["x_wrong_last_dim"] == "DataFormatError"
     assert e["bad_init_type"] == "ValueError"
     assert e["x_int_dtype"] is None
+
+
+def test_full_driver_overlapping_clusters_compact_fixture():
+    """tests/golden/make_golden_large.py fixture on heavily overlapping clusters (means 0.3 * randn): the oracle's
+    driver against the reference's, matrices compared through the stored functionals.  (The two larger fixtures of
+    that script - K=64 D=128 N=140000 and K=256 D=64 N=36000 - take the oracle minutes; they pin the GPU path in
+    tests/test_gpu_sparse_parity.py, and the oracle is pinned to the reference at those K, D by the F1/F3 cases.)"""
+    from conftest import mat_functionals
+    g = load_golden("gmm_f3_k16_d64_n32768_f32_overlap.npz")
+    K, D, N = int(g["K"]), int(g["D"]), int(g["N"])
+    x = orc.synth_gmm(int(g["K_data"]), D, N, np.float32, spread=float(g["spread"]))
+    assert sha(x) == str(g["x_sha256"])
+    p = orc.Prior.default(K, D)
+    res = orc.update_posterior(x.astype(np.float64), p, orc.Posterior.from_prior(p),
+                               np.random.default_rng(int(g["seed"])), **json.loads(str(g["kw"])))
+    ref = g["vl_trace"][0]
+    assert np.allclose(res.vl_trace[0], ref[~np.isnan(ref)], rtol=1e-9, atol=0)
+    q = res.posterior
+    assert rel_err(q.alpha, g["hn_alpha_vec"]) < 1e-9 and rel_err(q.m, g["hn_m_vecs"]) < 1e-9
+    for key, got in (("hn_w_mats", q.w), ("hn_w_mats_inv", q.w_inv), ("s_mats", res.stats.s)):
+        for fn, val in mat_functionals(got).items():
+            assert rel_err(val, g[f"{key}_{fn}"]) < 1e-7, (key, fn)

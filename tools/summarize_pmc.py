@@ -18,6 +18,11 @@ def main():
         i = sys.argv.index("--json")
         json_out = sys.argv[i + 1]
         del sys.argv[i:i + 2]
+    config = None
+    if "--config" in sys.argv:          # stamp of the workload the passes were made on, e.g. "K64 D128 N10000000 f32"
+        i = sys.argv.index("--config")
+        config = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     rows = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> values (largest grid only)
     grid = {}
     dur = defaultdict(list)
@@ -65,7 +70,7 @@ def main():
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 out[name.replace("gmmvb::", "").split("<")[0]] = dict(
                     kernel=name, grid_threads=grid[name], fetch_bytes_raw=c["FETCH_SIZE"] * 1024,
-                    fetch_bytes=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024,
+                    fetch_bytes=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024, config=config,
                     note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, FETCH x2 (gfx950)")
         with open(json_out, "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
