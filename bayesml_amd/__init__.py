@@ -4,10 +4,10 @@ Only the path named by BASELINE.json's ``north_star`` lives here: ``gaussianmixt
 ``gaussianmixture.LearnModel`` (and ``hiddenmarkovnormal`` for config 5) with the reference's API, backed by hand-written gfx950 HIP kernels
 (``csrc/``) behind the C ABI of ``include/gmmvb.h``.  The rest of BayesML is out of scope.
 """
-from . import gaussianmixture, hiddenmarkovnormal
+from . import gaussianmixture, hiddenmarkovnormal, multivariate_normal
 from ._dist import RowShard
 from ._exceptions import (CriteriaError, DataFormatError, ParameterFormatError, ParameterFormatWarning,
                           ResultWarning)
 
-__all__ = ["gaussianmixture", "hiddenmarkovnormal", "RowShard", "ParameterFormatError", "DataFormatError", "CriteriaError",
+__all__ = ["gaussianmixture", "hiddenmarkovnormal", "multivariate_normal", "RowShard", "ParameterFormatError", "DataFormatError", "CriteriaError",
            "ResultWarning", "ParameterFormatWarning"]

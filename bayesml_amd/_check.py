@@ -35,6 +35,13 @@ def pos_int(val, name, exc):
     raise exc(name + " must be int. Its value must be positive (not including 0).")
 
 
+def pos_float(val, name, exc):
+    """_check.py:19-26 — positive real scalar (integers are cast to float)."""
+    if _is_real(val) and val > 0.0:
+        return float(val) if _is_int(val) else val
+    raise exc(name + " must be positive (not including 0.0).")
+
+
 def floats(val, name, exc):
     """_check.py:163-173 — real scalar or real ndarray (ints are cast); no sign condition."""
     if _is_real(val):
@@ -91,6 +98,18 @@ def pos_def_sym_mats(val, name, exc):
     """_check.py:140-154 — stack of symmetric (np.allclose) positive-definite (batched Cholesky) matrices."""
     ok = (type(val) is np.ndarray and val.ndim >= 2 and val.shape[-1] == val.shape[-2]
           and np.allclose(val, np.swapaxes(val, -1, -2)))
+    if not ok:
+        raise exc(name + " must be a symmetric 2-dimensional numpy.ndarray.")
+    try:
+        np.linalg.cholesky(val)
+    except np.linalg.LinAlgError:
+        raise exc(name + " must be a positive definite symmetric 2-dimensional numpy.ndarray.") from None
+    return val
+
+
+def pos_def_sym_mat(val, name, exc):
+    """_check.py:124-138 — one symmetric (np.allclose) positive-definite (Cholesky) matrix."""
+    ok = type(val) is np.ndarray and val.ndim == 2 and val.shape[0] == val.shape[1] and np.allclose(val, val.T)
     if not ok:
         raise exc(name + " must be a symmetric 2-dimensional numpy.ndarray.")
     try:

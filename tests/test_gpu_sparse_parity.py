@@ -73,11 +73,13 @@ def check_trace(trace, g, rtol):
         assert np.allclose(vals, ref, rtol=rtol, atol=0), (i, np.max(np.abs(np.array(vals) / ref - 1)))
 
 
-def expect_kernels(counts, variant, min_carried=1):
+def expect_kernels(counts, variant, min_carried=1, lists=True):
     if variant == "dense":
         assert counts["estep_bound"] == counts["estep_carried"] == counts["mstep_list"] == 0, counts
         return
-    assert counts["estep_bound"] >= 1 and counts["estep_gather"] >= 2 and counts["mstep_list"] >= 1, counts
+    assert counts["estep_bound"] >= 1 and counts["estep_gather"] >= 2, counts
+    if lists:           # (the M-step runs over lists only while at most 35 % of the pairs are active)
+        assert counts["mstep_list"] >= 1, counts
     if variant == "force_nocarry":
         assert counts["estep_carried"] == 0, counts
     else:
@@ -90,7 +92,7 @@ def test_small_fixture_forced_sparse_matches_reference(variant):
     g = load_golden("gmm_f3_k8_d128_n32768_f32.npz")
     x = orc.synth_gmm(8, 128, 32768, np.float32)
     m, counts, trace = run_driver(g, x, variant)
-    expect_kernels(counts, variant)
+    expect_kernels(counts, variant, lists=False)       # 8 broad components: more than 35 % of the pairs stay active
     check_trace(trace, g, 1e-8)
     hn = m.get_hn_params()
     for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
