@@ -41,6 +41,7 @@ SYMBOLS = {
     "gmmvb_argmax": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gmmvb_last_launch_info": (ctypes.c_char_p, [_vp]),
     "gmmvb_pass_counts": (_int, [_vp, ctypes.POINTER(_i64)]),
+    "gmmvb_kside_factor": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_last_sparsity": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
@@ -95,6 +96,22 @@ def _f64(t: torch.Tensor, shape, device) -> torch.Tensor:
     if tuple(t.shape) != tuple(shape):
         raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
     return t
+
+
+def kside_factor(w_inv: torch.Tensor):
+    """(G, G^-1, ln det) of a batch of SPD matrices on the GPU (gmmvb_kside_factor): W^-1 = G G^T, lower triangular.
+    Plain kernels on the current stream - no MAGMA / rocSOLVER handles, so the K-side can be captured in a hipGraph."""
+    lib = load_library()
+    K, D, _ = w_inv.shape
+    w_inv = w_inv.contiguous()
+    g = torch.empty_like(w_inv)
+    g_inv = torch.empty_like(w_inv)
+    logdet = torch.empty(K, dtype=torch.float64, device=w_inv.device)
+    with torch.cuda.device(w_inv.device):
+        st = _vp(torch.cuda.current_stream(w_inv.device).cuda_stream)
+        _check(lib, lib.gmmvb_kside_factor(K, D, w_inv.data_ptr(), g.data_ptr(), g_inv.data_ptr(), logdet.data_ptr(), st),
+               "gmmvb_kside_factor")
+    return g, g_inv, logdet
 
 
 class DataPass:
@@ -244,17 +261,24 @@ class DataPass:
         self.rows = r.shape[0]
         self._keep.append(r)
 
-    def mstep(self, x: torch.Tensor) -> torch.Tensor:
+    def _stats_out(self, out):
+        if out is None:
+            return torch.empty(self.stats_len, dtype=torch.float64, device=self.device)
+        if out.dtype != torch.float64 or out.numel() != self.stats_len or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous float64 tensor of stats_len elements on the engine's device")
+        return out
+
+    def mstep(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         x, ldx = self._x(x)
-        stats = torch.empty(self.stats_len, dtype=torch.float64, device=self.device)
+        stats = self._stats_out(out)
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.gmmvb_mstep(self._ws, x.data_ptr(), ldx, x.shape[0], stats.data_ptr(),
                                                   self._stream()), "gmmvb_mstep")
         return stats
 
-    def estep_mstep(self, x: torch.Tensor) -> torch.Tensor:
+    def estep_mstep(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         x, ldx = self._x(x)
-        stats = torch.empty(self.stats_len, dtype=torch.float64, device=self.device)
+        stats = self._stats_out(out)
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.gmmvb_estep_mstep(self._ws, x.data_ptr(), ldx, x.shape[0], stats.data_ptr(),
                                                         self._stream()), "gmmvb_estep_mstep")

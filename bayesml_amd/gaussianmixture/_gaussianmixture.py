@@ -301,29 +301,31 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._ln_b_hn_w_nus[:] = _np(q.ln_b_w_nu)
 
     # ------------------------------------------------------------------ device plumbing (see _device.py)
-    def _drift_hint(self, eng, xd, q_from, q):
-        """(gamma, delta) of gmmvb_set_drift for the update q_from -> q, or None when the engine cannot use it."""
-        if q_from is None or q is None or not hasattr(eng, "wants_drift") or not eng.wants_drift(xd.shape[0]):
-            return None
-        return _kside.drift(q_from, q)
+    def _stepper(self, eng, prior, xd) -> _kside.KStepper:
+        """The K-side of one VB iteration as one unit (a replayed hipGraph on the GPU, see _kside.KStepper)."""
+        want = bool(hasattr(eng, "wants_drift") and eng.wants_drift(xd.shape[0]))
+        return _kside.KStepper(prior, eng.pivot, eng.stats_len, want)
 
-    @staticmethod
-    def _read_vl(terms, hint):
-        """The lower bound as a host float - and, in the same device-to-host copy, the mean gamma of the pending
-        drift hint (it tells the engine how fast the components are moving)."""
-        if hint is None:
-            return float(terms["vl"]), None
-        vl, gmean = torch.stack([terms["vl"].reshape(()), hint[0].mean()]).tolist()
-        return vl, (hint[0], hint[1], gmean)
+    def _data_pass(self, eng, xd, ks, estep=True):
+        """One data pass under the parameters the engine holds: statistics block into ``ks.stats``, summed over the
+        row shards (the one collective per VB iteration)."""
+        if estep:
+            eng.estep_mstep(xd, out=ks.stats)
+        else:
+            eng.mstep(xd, out=ks.stats)
+        self._comm.all_reduce_(ks.stats)
+
+    def _give_params(self, eng, q, hint=None):
+        """Hand a posterior's E-step parameters to the engine; ``hint`` = (gamma, delta, mean gamma) of the update
+        that led to it from the parameters of the engine's last E-step (gmmvb_set_drift), or None."""
+        if hint is not None:
+            eng.set_drift(*hint)
+        eng.set_params(q.c, q.m, q.u)
 
     def _pass(self, eng, xd, q, s_prev, estep=True, hint=None):
-        """One data pass: statistics block -> all-reduce over row shards -> reference moments.
-        ``hint``: ``_drift_hint(previous posterior of these rows, q)`` if this pass continues the previous one (lets
-        the engine carry its ln rho bounds over the update instead of recomputing them, see gmmvb_set_drift)."""
+        """One stand-alone data pass (read-outs, tests): statistics -> all-reduce -> reference moments."""
         if estep:
-            if hint is not None:
-                eng.set_drift(*hint)           # (gamma, delta[, mean gamma as a host float])
-            eng.set_params(q.c, q.m, q.u)
+            self._give_params(eng, q, hint)
             stats = eng.estep_mstep(xd)
         else:
             stats = eng.mstep(xd)
@@ -332,6 +334,13 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         x_bar, s = _kside.moments_from_stats(ns, a, B, eng.pivot, s_prev)
         return ns, x_bar, s, h.sum()
 
+    @staticmethod
+    def _drift_hint(eng, xd, q_from, q):
+        """(gamma, delta) of gmmvb_set_drift for the update q_from -> q, or None when the engine cannot use it."""
+        if q_from is None or q is None or not hasattr(eng, "wants_drift") or not eng.wants_drift(xd.shape[0]):
+            return None
+        return _kside.drift(q_from, q)
+
     # ------------------------------------------------------------------ the hot path
     def update_posterior(self, x, max_itr=100, num_init=10, tolerance=1.0E-8, init_type="subsampling"):
         """Variational-Bayes update of ``hn_*`` from data (driver of ref:802-896).
@@ -339,13 +348,17 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         ``x``: ``(sample_size, c_degree)`` real ndarray (float32 stays float32 in HBM and is widened
         on load; integers are cast to float64), or a torch tensor already on the GPU.
         ``init_type``: ``'subsampling'`` or ``'random_responsibility'``.
-        """
+
+        Per VB iteration the host does: one parameter hand-over, one data-pass call, (one all-reduce), one K-side
+        step (a hipGraph replay) and ONE device-to-host copy of nine doubles (the lower bound's terms and the mean
+        drift)."""
         eng, xd = self._open(x)
         K, D = self.c_num_classes, self.c_degree
         dev = xd.device
         n_global = self._comm.global_rows
         prior = self._prior_tensors(dev)
-        s_prev = torch.as_tensor(self.s_mats, dtype=torch.float64, device=dev)
+        ks = self._stepper(eng, prior, xd)
+        ks.s_prev.copy_(torch.as_tensor(self.s_mats, dtype=torch.float64, device=dev))
 
         best_host = {k: np.array(v) for k, v in self.get_hn_params().items()}
         best_host["hn_w_mats_inv"] = np.array(self.hn_w_mats_inv)
@@ -357,32 +370,34 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             self._reset_hn_from(q)
             if init_type == "subsampling":
                 q = self._init_subsampling(eng, xd, q, n_global)
-                ns, x_bar, s, h = self._pass(eng, xd, q, s_prev)
+                ks.load(q)
+                self._give_params(eng, q)
+                self._data_pass(eng, xd, ks)
             elif init_type == "random_responsibility":
                 r = self.rng.dirichlet(np.ones(K), n_global)
                 lo = self._comm.row_offset
                 eng.load_responsibilities(torch.from_numpy(r[lo: lo + xd.shape[0]]).to(dev))
-                ns, x_bar, s, h = self._pass(eng, xd, q, s_prev, estep=False)
+                ks.load(q)
+                self._data_pass(eng, xd, ks, estep=False)
             else:
                 raise ValueError(f"init_type={init_type} is unsupported. This function supports only "
                                  '"subsampling" and "random_responsibility"')
-            s_prev = s
-            terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
-            # the next K-side update only needs the statistics: enqueue it before the lower bound is read back, so
-            # that the GPU runs it while the host would otherwise be waiting (it is dropped if the loop ends here)
-            q_next = _kside.update_q(prior, ns, x_bar, s) if max_itr > 0 else None
-            hint = self._drift_hint(eng, xd, q if init_type == "subsampling" else None, q_next)
-            vl, hint = self._read_vl(terms, hint)
+            # lower bound under the current posterior, the next posterior and its drift hint: one K-side step
+            ks.step()
+            terms, gmean = ks.read()
+            vl = terms["vl"]
+            carried = init_type == "subsampling"      # the engine's last E-step belongs to ks.q
             self._say(f"\r{i}. VL: {vl}")
             for t in range(max_itr):
                 vl_before = vl
-                q = q_next
-                ns, x_bar, s, h = self._pass(eng, xd, q, s_prev, hint=hint)
-                s_prev = s
-                terms = _kside.lower_bound(prior, q, ns, x_bar, s, h)
-                q_next = _kside.update_q(prior, ns, x_bar, s) if t + 1 < max_itr else None
-                hint = self._drift_hint(eng, xd, q, q_next)
-                vl, hint = self._read_vl(terms, hint)        # the one host sync per iteration
+                hint = (ks.gamma, ks.delta, gmean) if (ks.want_drift and carried) else None
+                self._give_params(eng, ks.q_next, hint)
+                ks.advance()
+                carried = True
+                self._data_pass(eng, xd, ks)
+                ks.step()
+                terms, gmean = ks.read()                     # the one host sync per iteration
+                vl = terms["vl"]
                 self._say(f"\r{i}. VL: {vl} t={t} ")
                 with np.errstate(divide="ignore", invalid="ignore"):
                     if np.abs((vl - vl_before) / vl_before) < tolerance:
@@ -391,7 +406,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
                         break
             if i == 0 or vl > best_vl:
                 self._say("*", end="\n")
-                best_vl, best_q = vl, q.clone()
+                best_vl, best_q = vl, ks.current()
             else:
                 self._say("", end="\n")
             self.vl = vl
@@ -410,7 +425,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             for k, v in terms.items():
                 setattr(self, "vl" if k == "vl" else "_vl_" + k, float(v))
         # ref:895 — final E+M pass so that r_vecs / ns / x_bar_vecs / s_mats match the kept posterior
-        ns, x_bar, s, _h = self._pass(eng, xd, q, s_prev)
+        ns, x_bar, s, _h = self._pass(eng, xd, q, ks.s_prev)
         self.ns[:], self.x_bar_vecs[:], self.s_mats[:] = _np(ns), _np(x_bar), _np(s)
         return self
 

@@ -196,33 +196,36 @@ class Workload:
     """One model + sample matrix driven through the same internals update_posterior uses."""
 
     def __init__(self, K, D, x, dev, comm):
-        import torch
         from bayesml_amd import _kside
         from bayesml_amd import gaussianmixture as gm
         self.K, self.D, self.n = K, D, x.shape[0]
-        self.kside = _kside
         self.m = gm.LearnModel(K, D, seed=0, device=dev, comm=comm, verbose=False)
         self.eng, self.xd = self.m._open(x)
         self.eng.profile(True)
-        self.prior = self.m._prior_tensors(dev)
-        q = _kside.post_from_prior(self.prior)
-        self.q = self.m._init_subsampling(self.eng, self.xd, q, self.m._comm.global_rows)
-        s_prev = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
-        self.ns, self.x_bar, self.s, self.h = self.m._pass(self.eng, self.xd, self.q, s_prev)
-        self.q_next = _kside.update_q(self.prior, self.ns, self.x_bar, self.s)
-        self.hint = self.m._drift_hint(self.eng, self.xd, self.q, self.q_next)
+        prior = self.m._prior_tensors(dev)
+        self.ks = self.m._stepper(self.eng, prior, self.xd)
+        q = self.m._init_subsampling(self.eng, self.xd, _kside.post_from_prior(prior), self.m._comm.global_rows)
+        self.ks.load(q)
+        self.m._give_params(self.eng, q)
+        self.m._data_pass(self.eng, self.xd, self.ks)
+        self.ks.step()
+        self.terms, self.gmean = self.ks.read()
+
+    @property
+    def q(self):
+        return self.ks.q
 
     def step(self):
-        # as in update_posterior's loop: the next K-side update (and its drift hint for the E-step) is enqueued before
-        # the lower bound is read back
-        m, ks = self.m, self.kside
-        self.q = self.q_next
-        self.ns, self.x_bar, self.s, self.h = m._pass(self.eng, self.xd, self.q, self.s, hint=self.hint)
-        terms = ks.lower_bound(self.prior, self.q, self.ns, self.x_bar, self.s, self.h)
-        self.q_next = ks.update_q(self.prior, self.ns, self.x_bar, self.s)
-        self.hint = m._drift_hint(self.eng, self.xd, self.q, self.q_next)
-        vl, self.hint = m._read_vl(terms, self.hint)      # one device-to-host copy: the lower bound and the mean gamma
-        return vl
+        # update_posterior's loop body: parameter hand-over (+ drift hint) -> data pass (+ all-reduce) -> K-side step
+        # (one hipGraph replay) -> ONE device-to-host copy (lower bound terms, mean drift)
+        m, ks = self.m, self.ks
+        hint = (ks.gamma, ks.delta, self.gmean) if ks.want_drift else None
+        m._give_params(self.eng, ks.q_next, hint)
+        ks.advance()
+        m._data_pass(self.eng, self.xd, ks)
+        ks.step()
+        self.terms, self.gmean = ks.read()
+        return self.terms["vl"]
 
     def snapshot(self):
         a, e = self.eng.sparsity()

@@ -152,6 +152,13 @@ const char* gmmvb_profile_span_name(int slot);
  * static string such as "estep_mfma_f64<8,2,f32,vec> grid=1024x256". */
 const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
 
+/* K-sized linear algebra of the posterior update (replaces np.linalg.inv + slogdet of _gaussianmixture.py:746-756,
+ * 769): for each of K symmetric positive definite D x D matrices W^-1 (row-major, lower triangle read) the Cholesky
+ * factor G (W^-1 = G G^T), its inverse G^-1 (both lower triangular, upper part zero) and ln det W^-1.  The caller forms
+ * u = sqrt(nu) G^-1, W = G^-T G^-1.  D <= 128; one workgroup per matrix; no workspace, no synchronisation (graph-capturable). */
+int gmmvb_kside_factor(int K, int D, const double* w_inv_dev /*[K][D][D]*/, double* g_dev /*[K][D][D]*/,
+                       double* g_inv_dev /*[K][D][D]*/, double* logdet_dev /*[K]*/, void* stream);
+
 /* Which kernels have run in this workspace since it was created (for tests and profiling reports):
  *   out[0] dense E-steps, out[1] bound passes of the pruned E-step, out[2] E-steps on carried bounds, out[3] pruned
  *   E-steps that fell back to the dense kernel, out[4] carried passes that had to bound afresh, out[5] dense M-steps,

@@ -114,11 +114,11 @@ class CpuDataPass:
     def hmm_debug(self, what, row0=0, n=None):
         return self._alpha
 
-    def mstep(self, x):
+    def mstep(self, x, out=None):
         K, D = self.K, self.D
         r = self.responsibilities()
         xp = x.to(torch.float64) - self.pivot
-        stats = torch.empty(self.stats_len, dtype=torch.float64)
+        stats = torch.empty(self.stats_len, dtype=torch.float64) if out is None else out
         stats[:K] = r.sum(dim=0)
         if getattr(self, "_hmm_gamma", None) is not None and self._direct is self._hmm_gamma:
             stats[K:2 * K] = (r * self._ln_rho).sum(dim=0)          # HMM mode: h = sum gamma ln rho
@@ -130,9 +130,9 @@ class CpuDataPass:
         stats[2 * K + K * D:] = torch.einsum("nk,ni,nj->kij", r, xp, xp).reshape(-1)
         return stats
 
-    def estep_mstep(self, x):
+    def estep_mstep(self, x, out=None):
         self.estep(x)
-        return self.mstep(x)
+        return self.mstep(x, out)
 
     def split_stats(self, stats):
         K, D = self.K, self.D
