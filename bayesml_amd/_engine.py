@@ -29,7 +29,8 @@ SYMBOLS = {
     "gmmvb_workspace_bytes": (_i64, [_vp]),
     "gmmvb_set_pivot": (_int, [_vp, _vp, _vp]),
     "gmmvb_set_params": (_int, [_vp, _vp, _vp, _vp, _vp]),
-    "gmmvb_set_drift": (_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
+    "gmmvb_set_drift": (_int, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp]),
+    "gmmvb_forget": (_int, [_vp]),
     "gmmvb_wants_drift": (_int, [_vp, _i64]),
     "gmmvb_prepare_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_estep": (_int, [_vp, _vp, _i64, _i64, _vp]),
@@ -235,14 +236,19 @@ class DataPass:
     def wants_drift(self, n_rows: int) -> bool:
         return bool(self.lib.gmmvb_wants_drift(self._ws, int(n_rows)))
 
-    def set_drift(self, gamma, delta, typical_gamma: float = -1.0):
+    def set_drift(self, gamma, delta, big_gamma, typical_gamma: float = -1.0):
         """Hint for the pruned E-step (gmmvb_set_drift): call before the set_params of the updated parameters.
         ``typical_gamma``: mean of gamma as a host float if it is at hand without an extra sync, else <= 0."""
         g = _f64(gamma, (self.K,), self.device)
         d = _f64(delta, (self.K,), self.device)
+        G = _f64(big_gamma, (self.K,), self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.gmmvb_set_drift(self._ws, g.data_ptr(), d.data_ptr(), float(typical_gamma),
-                                                      self._stream()), "gmmvb_set_drift")
+            _check(self.lib, self.lib.gmmvb_set_drift(self._ws, g.data_ptr(), d.data_ptr(), G.data_ptr(),
+                                                      float(typical_gamma), self._stream()), "gmmvb_set_drift")
+
+    def forget(self):
+        """The next parameters are unrelated to the last E-step's (a new restart): see gmmvb_forget."""
+        _check(self.lib, self.lib.gmmvb_forget(self._ws), "gmmvb_forget")
 
     def estep(self, x: torch.Tensor):
         x, ldx = self._x(x)

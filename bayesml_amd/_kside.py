@@ -121,18 +121,10 @@ def post_from_prior(p: PriorT) -> PostT:
     return features(PostT(p.alpha.clone(), p.m.clone(), p.kappa.clone(), p.nu.clone(), p.w_inv.clone()))
 
 
-def drift(q_old, q_new, squarings: int = 8):
-    """(gamma, delta) of gmmvb_set_drift for the parameter update q_old -> q_new: per component
-    gamma <= sigma_min(u_new u_old^-1) and delta >= ||u_new (m_new - m_old)||, so that
-    ||u_new (x - m_new)|| >= gamma ||u_old (x - m_old)|| - delta for every x.
-
-    sigma_min(u_new u_old^-1) = 1 / ||A||_2 with A = u_old u_new^-1 (u^-1 = G / sqrt(nu) is kept by niw_features, so
-    no triangular solve), and ||A||_2^2 = lambda_max(G), G = A^T A, is bounded from above by ||G^(2^s)||_F^(1/2^s):
-    s repeated squarings with the Frobenius norms divided out (their logarithms summed with weights 2^-i), at most
-    D^(1/2^(s+1)) = 1.01 above the true norm at D = 128, s = 8.  (Bounds through A = alpha I + E were tried: the
-    triangle inequality costs 15 % in the first iterations, where the singular values of A spread from 0.9 to 1.4.)
-    Ten batched D x D products."""
-    a = q_old.u @ q_new.u_inv
+def _norm2_upper(a, squarings: int):
+    """Upper bound of the spectral norm of every matrix of the batch ``a``: ||A||_2^2 = lambda_max(G), G = A^T A, is
+    bounded from above by ||G^(2^s)||_F^(1/2^s): s repeated squarings with the Frobenius norms divided out (their
+    logarithms summed with weights 2^-i), at most D^(1/2^(s+1)) above the true norm (1.01 at D = 128, s = 8)."""
     g = a.transpose(1, 2) @ a
     tiny = torch.finfo(g.dtype).tiny
     f = torch.linalg.matrix_norm(g).clamp_min(tiny)
@@ -145,14 +137,30 @@ def drift(q_old, q_new, squarings: int = 8):
         log_lmax = log_lmax + w * torch.log(f)
         g = g / f[:, None, None]
         w *= 0.5
-    gamma = torch.exp(-0.5 * log_lmax) * (1.0 - 1e-9)
+    return torch.exp(0.5 * log_lmax)
+
+
+def drift(q_old, q_new, squarings: int = 8, squarings_big: int = 6):
+    """(gamma, delta, big_gamma) of gmmvb_set_drift for the parameter update q_old -> q_new: per component
+    gamma <= sigma_min(u_new u_old^-1), big_gamma >= sigma_max(u_new u_old^-1), delta >= ||u_new (m_new - m_old)||, so that
+    gamma ||u_old (x - m_old)|| - delta <= ||u_new (x - m_new)|| <= big_gamma ||u_old (x - m_old)|| + delta for every x.
+
+    sigma_min(u_new u_old^-1) = 1 / ||A||_2 with A = u_old u_new^-1 (u^-1 = G / sqrt(nu) is kept by niw_features, so
+    no triangular solve); sigma_max = ||u_new u_old^-1||_2.  Both norms by _norm2_upper (rigorous, a per cent or so
+    loose).  (Bounds through A = alpha I + E were tried: the triangle inequality costs 15 % in the first iterations,
+    where the singular values of A spread from 0.9 to 1.4.)  big_gamma only sets how far below the carried best value
+    the E-step has to look, so it gets fewer squarings (4 % loose)."""
+    gamma = (1.0 - 1e-9) / _norm2_upper(q_old.u @ q_new.u_inv, squarings)
+    big = (1.0 + 1e-9) * _norm2_upper(q_new.u @ q_old.u_inv, squarings_big)
     d = (q_new.u @ (q_new.m - q_old.m)[:, :, None])[:, :, 0]
     delta = torch.linalg.vector_norm(d, dim=1) * (1.0 + 1e-9)
-    # anything non-finite: no information (gamma = 0 makes every carried bound the trivial one)
-    bad = ~(torch.isfinite(gamma) & torch.isfinite(delta))
+    # anything non-finite: no information (gamma = 0 makes every carried bound the trivial one, big_gamma = inf leaves
+    # no lower bound of the best value: the row is evaluated in full)
+    bad = ~(torch.isfinite(gamma) & torch.isfinite(delta) & torch.isfinite(big))
     gamma = torch.where(bad, torch.zeros_like(gamma), gamma)
     delta = torch.where(bad, torch.zeros_like(delta), delta)
-    return gamma, delta
+    big = torch.where(bad, torch.full_like(big, float("inf")), big)
+    return gamma, delta, big
 
 
 def moments_from_stats(ns, a, B, pivot, s_prev):
@@ -380,6 +388,7 @@ class KStepper:
         self.s = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
         self.gamma = torch.zeros(K, dtype=torch.float64, device=dev)
         self.delta = torch.zeros(K, dtype=torch.float64, device=dev)
+        self.big_gamma = torch.zeros(K, dtype=torch.float64, device=dev)
         self.scal = torch.zeros(len(TERM_KEYS) + 1, dtype=torch.float64, device=dev)
         self._graph = None
         self._calls = 0
@@ -399,9 +408,10 @@ class KStepper:
         terms = lower_bound(self.prior, self.q, ns, x_bar, s, h.sum())
         qn = update_q(self.prior, ns, x_bar, s)
         if self.want_drift:
-            gamma, delta = drift(self.q, qn)
+            gamma, delta, big = drift(self.q, qn)
             self.gamma.copy_(gamma)
             self.delta.copy_(delta)
+            self.big_gamma.copy_(big)
             gmean = gamma.mean()
         else:
             gmean = torch.zeros((), dtype=torch.float64, device=st.device)
@@ -413,7 +423,8 @@ class KStepper:
         self.scal.copy_(torch.stack([terms[k].reshape(()) for k in TERM_KEYS] + [gmean.reshape(())]))
 
     def step(self):
-        """Run the K-side on ``self.stats`` (already all-reduced).  Results: ns, x_bar, s, q_next, gamma, delta, scal."""
+        """Run the K-side on ``self.stats`` (already all-reduced).  Results: ns, x_bar, s, q_next, gamma, delta,
+        big_gamma, scal."""
         self._calls += 1
         if self._use_graph and self._graph is None and self._calls >= 2:
             try:                                    # the first call ran eagerly (library / BLAS warm-up)
@@ -436,6 +447,10 @@ class KStepper:
         """(dict of the lower bound's terms as host floats, mean gamma) - the iteration's one host sync."""
         v = self.scal.tolist()
         return dict(zip(TERM_KEYS, v[:-1])), v[-1]
+
+    def hint(self, gmean):
+        """The drift hint of q -> q_next for DataPass.set_drift, or None when the engine cannot use one."""
+        return (self.gamma, self.delta, self.big_gamma, gmean) if self.want_drift else None
 
     def advance(self):
         """q <- q_next (after the engine has been given q_next's parameters)."""

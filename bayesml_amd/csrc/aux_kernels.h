@@ -161,22 +161,14 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
 }
 
 // MODE 0 (best)  : the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
-// MODE 1 (near)  : ln rho[khat_n][n] is exact now; the mask holds every other k with u[k][n] >= it - 100 ln 2.
 // MODE 3 (given) : like MODE 0 with khat already written (by the bound kernel): u is not read.
-// MODE 4 (carry) : MODE 1 on carried bounds (gmmvb_set_drift), made on the way: every v = u[k][n] other than the freshly
-//                  evaluated u[khat_n][n] is a value or upper bound of ln rho under the OLD parameters, so
-//                  q_old >= 2 (c_old - v); with || u' (x - m') || >= gamma || u (x - m) || - delta the new parameters
-//                  give q' >= (gamma sqrt(2 (c_old - v)) - delta)_+^2, i.e. the upper bound c' - q'/2, which replaces v
-//                  before it is compared.  The slack factors cover the rounding of that line; a NaN turns into "no
-//                  bound" (c'), never into a finite lie.  drift = [gamma | delta | c_old], K doubles each.
+// (Every further candidate is selected from the per-row records, records.h.)
 template <int MODE>
-__global__ __launch_bounds__(kSelRows) void select_mask_kernel(double* __restrict__ u, int64_t npad, int64_t n_rows,
+__global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __restrict__ u, int64_t npad, int64_t n_rows,
                                                                int K, int* __restrict__ khat,
                                                                unsigned long long* __restrict__ masks /*[W][npad]*/,
-                                                               int* __restrict__ blk_cnt /*[blocks][K]*/,
-                                                               const double* __restrict__ drift = nullptr,
-                                                               const double* __restrict__ c_new = nullptr) {
-    constexpr bool NEAR = MODE == 1 || MODE == 4;
+                                                               int* __restrict__ blk_cnt /*[blocks][K]*/) {
+    static_assert(MODE == 0 || MODE == 3, "only the best-component modes exist");
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
@@ -184,11 +176,6 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(double* __restric
     const int wave = threadIdx.x >> 6;
     for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
     int kh = -1;
-    double lim = 0.0;
-    if (NEAR && valid) {
-        kh = khat[n];
-        lim = u[(int64_t)kh * npad + n] - 69.314718055994530942;
-    }
     if (MODE == 3 && valid) kh = khat[n];
     if (MODE == 0) {
         int arg = 0;
@@ -207,25 +194,7 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(double* __restric
     for (int w = 0; w < W; ++w) {
         unsigned long long mk = 0;
         if (valid) {
-            if (NEAR) {
-                const int kend = K - 64 * w < 64 ? K - 64 * w : 64;
-                for (int b = 0; b < kend; ++b) {
-                    const int k = 64 * w + b;
-                    double v = u[(int64_t)k * npad + n];
-                    if (MODE == 4 && k != kh) {
-                        double q = 2.0 * (drift[2 * K + k] - v);
-                        q = q > 0.0 ? q : 0.0;                                    // also NaN -> 0
-                        double y = drift[k] * sqrt(q) * (1.0 - 1e-12) - drift[K + k];
-                        y = y > 0.0 ? y : 0.0;
-                        v = c_new[k] - 0.5 * y * y * (1.0 - 1e-12) + 1e-12 * fabs(c_new[k]);
-                        u[(int64_t)k * npad + n] = v;
-                    }
-                    mk |= (unsigned long long)(!(v < lim)) << b;          // NaN: evaluated, not skipped
-                }
-                if ((kh >> 6) == w) mk &= ~(1ull << (kh & 63));
-            } else if ((kh >> 6) == w) {
-                mk = 1ull << (kh & 63);
-            }
+            if ((kh >> 6) == w) mk = 1ull << (kh & 63);
             masks[(int64_t)w * npad + n] = mk;
         }
         unsigned long long present = wave_or(mk);

@@ -11,6 +11,7 @@
 
 #include "aux_kernels.h"
 #include "launch.h"
+#include "records.h"
 
 using namespace gmmvb;
 
@@ -117,7 +118,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
         {&ws->xc, 0},
         {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K},
-        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->act_total, 1}, {&ws->drift, 3 * (int64_t)K}};
+        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->ctr, 4}, {&ws->drift, 4 * (int64_t)K}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
         if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
@@ -166,9 +167,12 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         return GMMVB_ENOMEM;
     }
     e = hipMemset(ws->pivot, 0, (size_t)D * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 4 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 4 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ctr_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         gmmvb_workspace_destroy(ws);
-        return fail(GMMVB_EHIP, "hipMemset(pivot)", e);
+        return fail(GMMVB_EHIP, "workspace initialisation", e);
     }
     *out = ws;
     return GMMVB_OK;
@@ -177,8 +181,13 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
-                      ws->apart, ws->act_total, ws->drift};
-    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk};
+                      ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart};
+    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan};
+    void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_R, ws->rec_exact, ws->rec_sel, ws->rec_flags};
+    for (void* p : rbufs)
+        if (p) (void)hipFree(p);
+    if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
+    if (ws->ctr_ev) (void)hipEventDestroy(ws->ctr_ev);
     for (int* p : ibufs)
         if (p) (void)hipFree(p);
     if (ws->masks) (void)hipFree(ws->masks);
@@ -268,24 +277,29 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
 }
 
 int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows) {
-    if (!ws || ws->prune == 0 || ws->estep_variant != kEstepLds8 || ws->hmm != nullptr || !ws->masks) return 0;
+    if (!ws || ws->prune == 0 || ws->estep_variant != kEstepLds8 || ws->hmm != nullptr || !ws->rec_k) return 0;
     if (std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr) return 0;
     return (ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23)) ? 1 : 0;
 }
 
-int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* delta_dev, double typical_gamma,
-                    void* stream) {
-    if (!ws || !gamma_dev || !delta_dev) return fail(GMMVB_EINVAL, "null argument");
+int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* delta_dev, const double* big_gamma_dev,
+                    double typical_gamma, void* stream) {
+    if (!ws || !gamma_dev || !delta_dev || !big_gamma_dev) return fail(GMMVB_EINVAL, "null argument");
     ws->typical_gamma = typical_gamma;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemcpyAsync(ws->drift, gamma_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(ws->drift + ws->K, delta_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
-    // the constants of the parameters the ln rho array belongs to (the next gmmvb_set_params overwrites cvec)
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(ws->drift + 2 * ws->K, ws->cvec, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
+    const size_t kb = (size_t)ws->K * sizeof(double);
+    hipError_t e = hipMemcpyAsync(ws->drift, gamma_dev, kb, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + ws->K, delta_dev, kb, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + 3 * ws->K, big_gamma_dev, kb, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(drift)", e);
-    ws->have_drift = ws->have_params && ws->params_used;     // else: not the parameters the ln rho array belongs to
+    ws->have_drift = ws->have_params && ws->params_used;     // else: not the parameters the records belong to
+    return GMMVB_OK;
+}
+
+int gmmvb_forget(gmmvb_workspace* ws) {
+    if (!ws) return fail(GMMVB_EINVAL, "null argument");
+    ws->forget = true;
+    ws->have_drift = false;
     return GMMVB_OK;
 }
 
@@ -311,43 +325,68 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
     return GMMVB_OK;
 }
 
-// sample lists of the pruned E-step and the sparse M-step (allocated at first use)
+// sample lists of the pruned E-step and the sparse M-step, candidate records, gather plan, per-block counters
 static int ensure_lists(gmmvb_workspace* ws) {
     if (ws->lists) return GMMVB_OK;
     const int64_t sel_blocks = (ws->npad + kSelRows - 1) / kSelRows, words = (ws->K + 63) / 64;
-    hipError_t e = hipMalloc((void**)&ws->lists, (size_t)ws->K * ws->npad * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&ws->khat, (size_t)ws->npad * sizeof(int));
+    const int64_t np = ws->npad;
+    hipError_t e = hipMalloc((void**)&ws->lists, (size_t)ws->K * np * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->khat, (size_t)np * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->counts, (size_t)ws->K * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->plan, (size_t)(ws->K + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->blk, (size_t)sel_blocks * ws->K * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * ws->npad * sizeof(unsigned long long));
-    if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (sample lists)", e);
-    ws->bytes += ((int64_t)ws->K * ws->npad + ws->npad + ws->K + sel_blocks * ws->K) * (int64_t)sizeof(int) +
-                 words * ws->npad * 8;
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * np * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->epart, (size_t)sel_blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->opart, (size_t)sel_blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_k, (size_t)kRecSlots * np * sizeof(unsigned short));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_d, (size_t)kRecSlots * np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_R, (size_t)np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_exact, (size_t)np);
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_sel, (size_t)np);
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_flags, (size_t)np);
+    if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (sample lists / records)", e);
+    ws->bytes += ((int64_t)ws->K * np + np + 2 * ws->K + 1 + sel_blocks * ws->K) * (int64_t)sizeof(int) + words * np * 8 +
+                 2 * sel_blocks * 8 + np * (kRecSlots * 6 + 4 + 3);
     return GMMVB_OK;
 }
 
-// active-pair count of the last E-step (one 8-byte read behind a stream sync, cached until the next E-step)
-static int fetch_active(gmmvb_workspace* ws, hipStream_t st, double* out) {
-    if (ws->act_host < 0.0) {
-        double act = 0.0;
-        hipError_t e = hipMemcpyAsync(&act, ws->act_total, sizeof(double), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "reading the active-pair count", e);
-        ws->act_host = act;
+// Counters of the last E-step, blocking: waits for the copy that the E-step enqueued (gmmvb_last_sparsity, and the
+// M-step right after a dense E-step, where the host has been waiting for the dense kernel anyway).
+static int fetch_counters(gmmvb_workspace* ws) {
+    if (ws->ctr_pending) {
+        hipError_t e = hipEventSynchronize(ws->ctr_ev);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "waiting for the E-step counters", e);
+        ws->lag_act = ws->ctr_host[0];
+        if (ws->pend_mode == 0) {              // dense pass: every pair evaluated, no records involved
+            ws->lag_eval = (double)ws->pend_rows * ws->K;
+            ws->lag_over = 0.0;
+        } else {                               // a bound pass also evaluated every row's best component
+            ws->lag_eval = ws->ctr_host[1] + (ws->pend_mode == 1 ? (double)ws->pend_rows : 0.0);
+            ws->lag_over = ws->ctr_host[2];
+        }
+        ws->lag_rows = ws->pend_rows;
+        ws->lag_mode = ws->pend_mode;
+        ws->lag_valid = true;
+        ws->ctr_pending = false;
     }
-    *out = ws->act_host;
     return GMMVB_OK;
+}
+
+// The same without waiting: takes the counters over if their copy has completed (the driver synchronises once per
+// VB iteration, so by the next E-step it always has).
+static void poll_counters(gmmvb_workspace* ws) {
+    if (ws->ctr_pending && hipEventQuery(ws->ctr_ev) == hipSuccess) (void)fetch_counters(ws);
 }
 
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs) {
+    (void)stream;
     if (!ws || !active_pairs || !evaluated_pairs) return fail(GMMVB_EINVAL, "null argument");
     if (ws->e_state != 1) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
-    *evaluated_pairs = ws->evaluated;
-    if (!ws->sparse || ws->act_rows != ws->e_rows) {      // GMMVB_MSTEP_SPARSE=0: the pairs are not counted
-        *active_pairs = -1.0;
-        return GMMVB_OK;
-    }
-    return fetch_active(ws, (hipStream_t)stream, active_pairs);
+    int rc = fetch_counters(ws);
+    if (rc) return rc;
+    *evaluated_pairs = ws->lag_mode == 0 ? (double)ws->e_rows * ws->K : ws->lag_eval;
+    *active_pairs = (ws->sparse && ws->act_rows == ws->e_rows) ? ws->lag_act : -1.0;   // GMMVB_MSTEP_SPARSE=0: not counted
+    return GMMVB_OK;
 }
 
 static int check_x(const gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, bool* vec) {
@@ -366,6 +405,8 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
     if (rc) return rc;
     ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
+    ws->rec_valid = false;
+    ws->lag_valid = false;
     if (!ws->xc) return GMMVB_OK;      // disabled: the M-step reads x directly
     const int Dp = 16 * ws->T;
     const int64_t pad_rows = round_up(n_rows, 64) + 64;
@@ -386,6 +427,44 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     return GMMVB_OK;
 }
 
+// bound pass of the pruned E-step: an upper bound of ln rho for every pair (int8 digits, or leading f64 blocks) and khat
+static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepArgs& a, const EstepI8Args& a8, int is64, bool vec,
+                                    hipStream_t st, const char** name, int* rpw_out, int64_t* grid_out) {
+    const int rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
+    int64_t grid = (a.n_rows + rpw - 1) / rpw;
+    if (grid > (1 << 20)) grid = 1 << 20;
+    *rpw_out = rpw;
+    *grid_out = grid;
+    hipError_t e;
+    if (ws->img_i8b) {
+        EstepI8Args ab = a8;
+        ab.img = ws->img_i8b;
+        ab.khat = ws->khat;             // the bound kernel also finds every row's best component
+        e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, name);
+    } else {
+        e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, name);
+    }
+    return e;
+}
+
+// masks -> per-component lists -> chunk plan -> exact f64 evaluation of the listed pairs (all sized on the device)
+static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int is64, bool vec, int sel_grid, hipStream_t st) {
+    span_begin(ws, kSpanSelect, st);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
+    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, a.n_rows, ws->K, ws->blk,
+                       ws->lists, ws->npad);
+    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
+                       estep_gather_rows_per_wg(ws->T, is64), ws->plan);
+    hipError_t e = hipGetLastError();
+    span_end(ws, st);
+    if (e != hipSuccess) return e;
+    span_begin(ws, kSpanGather, st);
+    e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan);
+    span_end(ws, st);
+    ++ws->passes[7];
+    return e;
+}
+
 int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream) {
     bool vec = false;
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
@@ -398,48 +477,75 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     EstepI8Args a8{x_dev, ldx, n_rows, ws->D, ws->img_i8, ws->pivot_i8, ws->cvec, ws->K, ws->lnrho, ws->npad};
     const char* name = "";
     hipError_t e = hipSuccess;
-    // Prune?  Needs the default f64 kernel family, and (unless forced) evidence from the previous E-step over
-    // these rows that at most half of the (sample, component) pairs matter.
-    // (never for an HMM workspace: forward-backward consumes every emission ln rho, bounds will not do)
-    bool prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr;
-    if (prune && ws->prune == 1) {
-        prune = false;
-        if (n_rows * (int64_t)ws->K >= (int64_t(1) << 23) && ws->act_rows == n_rows) {
-            double act = 0.0;
-            rc = fetch_active(ws, st, &act);
-            if (rc) return rc;
-            prune = act <= 0.5 * (double)n_rows * ws->K;
+    const double pairs = (double)n_rows * ws->K;
+
+    // ---- which kind of pass?  Decided from what the host knows WITHOUT waiting for the device: the counters of the
+    // last E-step whose copy has arrived (they lag by one pass when the caller never synchronises; results do not
+    // depend on the choice, only the time does).
+    poll_counters(ws);
+    enum { kDense = 0, kBound = 1, kCarry = 2 };
+    int mode = kDense;
+    const bool can_prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr && ws->rec_k != nullptr;
+    const bool big = ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23);
+    const bool same_rows = ws->bounds_rows == n_rows && ws->bounds_x == x_dev && ws->bounds_ldx == ldx;
+    const bool known = ws->lag_valid && ws->lag_rows == n_rows && !ws->ctr_pending;     // counters of the previous pass
+    if (can_prune && big) {
+        // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
+        bool sparse_ok = ws->prune == 2;
+        if (!sparse_ok && known && !ws->forget) sparse_ok = ws->lag_act <= 0.5 * pairs;
+        if (sparse_ok) {
+            mode = kBound;
+            bool carry = ws->rec_valid && same_rows && ws->have_drift && std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
+            // early in a fit the components still move by tens of per cent per iteration (mean gamma 0.3, 0.7, 0.87,
+            // 0.91, 0.94 ... at C3): carried distances shrink by gamma and leave a dozen candidates per sample
+            if (carry && ws->typical_gamma > 0.0 && ws->typical_gamma < 0.9) carry = false;
+            if (carry && known && ws->lag_mode != kDense) {
+                // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
+                // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
+                const double spare = std::max(0.0, ws->lag_eval - ws->lag_act) / pairs;
+                ws->spare_last = spare;
+                const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
+                const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
+                if (gpp * spare * 1.5 >= bound_cost) carry = false;
+                if (ws->lag_over > 0.10 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = false;
+            }
+            if (carry && known && ws->lag_mode == kDense && ws->lag_act > 0.1 * pairs) carry = false;
+            if (carry) mode = kCarry;
+            // a bound pass that left most pairs candidates (the parameters jumped): back to the dense kernel
+            if (mode == kBound && ws->prune != 2 && known && ws->lag_mode == kBound && ws->lag_eval > 0.6 * pairs) {
+                mode = kDense;
+                ++ws->passes[3];
+            }
         }
     }
-    if (prune && ws->img_i8b) {
+    ws->forget = false;
+    if (std::getenv("GMMVB_DEBUG"))
+        std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g) gamma=%.3f rec_valid=%d drift=%d\n",
+                     mode, (int)known, ws->lag_mode, ws->lag_act / n_rows, ws->lag_eval / n_rows, ws->lag_over / n_rows,
+                     ws->typical_gamma, (int)ws->rec_valid, (int)ws->have_drift);
+    if (mode == kBound && ws->img_i8b) {
         // How many output blocks the bound pass evaluates.  Cost model per (sample, component) pair, in units of
         // 1e-11 s measured at C3 (profiles/r1_v6_*): bound pass 0.12 per block pair + 0.039 per row of y; exact pass
         // 0.81 per f64 tile pair of every candidate.  Take the cheapest level among those observed in the last 32
-        // pruned passes; look one level down when the current one leaves hardly any spare candidates (two levels
-        // exist below) or one level up when more than half of its candidates are spare, if that level is unknown.
+        // bound passes; look one level down when the current one leaves hardly any spare candidates or one level up
+        // when more than half of its candidates are spare, if that level is unknown.
         const int t32 = (ws->D + 31) / 32;
         const char* pin = std::getenv("GMMVB_ESTEP_BOUND_BLOCKS");      // pins the level (1 .. ceil(D/32))
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
         if (pin && std::atoi(pin) >= 1 && std::atoi(pin) <= t32) {
             ws->bound_tb = std::atoi(pin);
-        } else if (ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows && ws->prev_pass == 1) {
-            double act = 0.0;
-            rc = fetch_active(ws, st, &act);
-            if (rc) return rc;
-            const double pairs = (double)n_rows * ws->K;
+        } else if (known && ws->lag_mode == kBound) {
             const int cur = ws->bound_tb;
-            ws->tb_cand[cur] = ws->evaluated_prev / pairs;
-            ws->tb_act[cur] = act / pairs;
+            ws->tb_cand[cur] = ws->lag_eval / pairs;
+            ws->tb_act[cur] = ws->lag_act / pairs;
             ws->tb_seen[cur] = 0;
-            // an observation is forgotten after 32 passes, or once the sparsity is no longer what it was made at
             for (int l = 1; l <= t32; ++l)
                 if (l != cur && (++ws->tb_seen[l] > 32 || ws->tb_act[l] > 1.5 * ws->tb_act[cur] ||
                                  ws->tb_act[l] < ws->tb_act[cur] / 1.5))
                     ws->tb_cand[l] = -1.0;
             const double gpp = 0.81 * tri_pairs(ws->T);
-            // with drift hints in use a few carried passes follow a bound pass and inherit its spare candidates: a
-            // tighter bound pays for part of itself there
-            const double heirs = ws->have_drift ? 3.0 : 0.0;
+            // carried passes follow a bound pass and inherit its spare candidates: a tighter bound pays for part of itself
+            const double heirs = gmmvb_wants_drift(ws, n_rows) ? 3.0 : 0.0;
             auto cost = [&](int l) {
                 const double spare_l = ws->tb_cand[l] > ws->tb_act[l] ? ws->tb_cand[l] - ws->tb_act[l] : 0.0;
                 return 0.12 * tri_pairs(l) + 0.039 * 32 * l + gpp * (ws->tb_cand[l] + heirs * spare_l);
@@ -447,182 +553,28 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             int best = cur;
             for (int l = 1; l <= t32; ++l)
                 if (ws->tb_cand[l] >= 0.0 && cost(l) < cost(best)) best = l;
-            const double spare = ws->tb_cand[cur] - act / pairs;         // candidates that turned out irrelevant
+            const double spare = ws->tb_cand[cur] - ws->tb_act[cur];
             if (best == cur) {
-                if (cur > 1 && ws->tb_cand[cur - 1] < 0.0 && spare * ws->K < (ws->have_drift ? 0.02 : 0.25))
-                    best = cur - 1;        // under a quarter of a spare candidate per sample: the bound is tight,
-                                           // try the cheaper one (candidates grow steeply once rows are dropped)
+                if (cur > 1 && ws->tb_cand[cur - 1] < 0.0 && spare * ws->K < (heirs > 0.0 ? 0.02 : 0.25))
+                    best = cur - 1;
                 else if (cur < t32 && ws->tb_cand[cur + 1] < 0.0 &&
                          spare * gpp > 0.12 * (tri_pairs(cur + 1) - tri_pairs(cur)) + 0.039 * 32)
-                    best = cur + 1;        // the spare candidates cost more than a tighter bound would
+                    best = cur + 1;
             }
             ws->bound_tb = best;
         }
     }
-    // Carry the previous pass's values / bounds over the parameter update instead of bounding every pair again
-    // (gmmvb_set_drift)?  Up to 8 passes in a row, and not once the spare candidates predicted for this pass would
-    // cost the exact pass more than a real bound pass costs: then the bounds are refreshed (see below).
-    bool carry = prune && ws->have_drift && ws->bounds_rows == n_rows && ws->bounds_x == x_dev &&
-                 ws->bounds_ldx == ldx && ws->masks && ws->carried < 8 &&
-                 std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
-    // early in a fit the components still move by tens of per cent per iteration (mean gamma 0.3, 0.7, 0.87, 0.91,
-    // 0.94 ... at C3): carried bounds shrink by gamma^2 and leave a dozen candidates per sample; bound afresh then
-    if (carry && ws->typical_gamma > 0.0 && ws->typical_gamma < 0.9) carry = false;
-    if (prune && ws->prev_pass != 0 && ws->evaluated_prev >= 0.0 && ws->act_rows == n_rows) {
-        // spare candidates (listed but inactive) per pair of the last pruned pass, and of the one before
-        double act = 0.0;
-        rc = fetch_active(ws, st, &act);
-        if (rc) return rc;
-        const double pairs = (double)n_rows * ws->K;
-        ws->spare_before = ws->spare_last;
-        ws->spare_last = (ws->evaluated_prev - act) / pairs;
-        if (ws->spare_last < 0.0) ws->spare_last = 0.0;
-        if (carry && ws->prev_pass == 2) {
-            // the spare candidates grow from pass to pass (by a factor of two to three at the benchmark's scale):
-            // carry on only while the exact pass over the predicted spare ones costs less than a bound pass
-            const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
-            const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
-            carry = gpp * ws->spare_last * 2.5 < bound_cost;
-        }
-        if (std::getenv("GMMVB_DEBUG"))
-            std::fprintf(stderr, "[gmmvb] estep: prev_pass=%d evaluated_prev=%.3g act=%.3g spare %.4g <- %.4g carry=%d carried=%d\n",
-                         ws->prev_pass, ws->evaluated_prev / n_rows, act / n_rows, ws->spare_last, ws->spare_before,
-                         (int)carry, ws->carried);
-    } else if (ws->prev_pass == 0) {
-        ws->spare_last = ws->spare_before = -1.0;
-        if (carry && ws->act_rows == n_rows) {
-            // out of a dense pass the parameters are still moving fast (the second or third iteration of a fit):
-            // carried values would leave most pairs candidates unless the responsibilities are sparse already
-            double act = 0.0;
-            rc = fetch_active(ws, st, &act);
-            if (rc) return rc;
-            carry = act <= 0.1 * (double)n_rows * ws->K;
-        }
-    }
-    ws->evaluated_prev = -1.0;
-    if (prune) {
-        rc = ensure_lists(ws);
-        if (rc) return rc;
-    }
+    if (mode == kDense)      // whatever was learnt about the bound levels belongs to another regime
+        for (double& c : ws->tb_cand) c = -1.0;
+
     int rpw = 0;
     int64_t grid = 0;
-    bool pruned_fell_back = false;
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
     ws->n_spans = 0;
-    ws->evaluated = prune ? 0.0 : (double)n_rows * ws->K;
-    if (!prune)      // a dense pass: whatever was learnt about the bound levels belongs to another regime
-        for (double& c : ws->tb_cand) c = -1.0;
-    if (prune) {
-        if (carry) {
-            // nothing to launch here: the previous pass's best components are evaluated first (round 0), and the second
-            // selection carries every other value over the update as it reads it (select_mask_kernel<4>)
-            rpw = kSelRows;
-            grid = (n_rows + kSelRows - 1) / kSelRows;
-            name = "estep_carried_bounds";
-            ++ws->carried;
-            ++ws->passes[2];
-        } else {
-            rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
-            grid = (n_rows + rpw - 1) / rpw;
-            if (grid > (1 << 20)) grid = 1 << 20;
-            span_begin(ws, kSpanEstepMain, st);
-            if (ws->img_i8b) {
-                EstepI8Args ab = a8;
-                ab.img = ws->img_i8b;
-                ab.khat = ws->khat;             // the bound kernel also finds every row's best component
-                e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, &name);
-            } else {
-                e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
-            }
-            span_end(ws, st);
-            ws->carried = 0;
-            ++ws->passes[1];
-        }
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
-        const bool i8_bound = ws->img_i8b != nullptr;
-        bool& fell_back = pruned_fell_back;
-        int counts_host[256];
-        const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
-        for (int round = 0; round < 2; ++round) {
-            span_begin(ws, kSpanSelect, st);
-            if (round == 0 && (carry || i8_bound))
-                hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
-            else if (round == 0)
-                hipLaunchKernelGGL(select_mask_kernel<0>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
-            else if (carry)
-                hipLaunchKernelGGL(select_mask_kernel<4>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk, ws->drift, ws->cvec);
-            else
-                hipLaunchKernelGGL(select_mask_kernel<1>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad,
-                                   n_rows, ws->K, ws->khat, ws->masks, ws->blk);
-            hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
-            hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
-                               ws->blk, ws->lists, ws->npad);
-            e = hipGetLastError();
-            span_end(ws, st);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(counts_host, ws->counts, (size_t)ws->K * sizeof(int), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate selection", e);
-            double listed = 0.0;
-            for (int k = 0; k < ws->K; ++k) listed += counts_host[k];
-            if (round == 1 && carry && ws->evaluated + listed > 0.35 * (double)n_rows * ws->K) {
-                // the carried bounds have become too loose: bound afresh (the exact values written so far stay valid
-                // upper bounds until the bound kernel overwrites them) and select again
-                carry = false;
-                ws->carried = 0;
-                rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
-                grid = (n_rows + rpw - 1) / rpw;
-                if (grid > (1 << 20)) grid = 1 << 20;
-                span_begin(ws, kSpanEstepMain, st);
-                if (ws->img_i8b) {
-                    EstepI8Args ab = a8;
-                    ab.img = ws->img_i8b;
-                    ab.khat = ws->khat;
-                    e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, &name);
-                } else {
-                    e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, &name);
-                }
-                span_end(ws, st);
-                if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
-                ++ws->passes[1];
-                ++ws->passes[4];
-                ws->evaluated = 0.0;
-                round = -1;                 // start the selection over
-                continue;
-            }
-            if (round == 1 && ws->prune != 2 && ws->evaluated + listed > 0.6 * (double)n_rows * ws->K) {
-                // the parameters moved a long way since the last E-step (a new restart): most pairs are candidates
-                // again, so evaluate everything with the dense kernel instead of gathering almost everything
-                const int rpd = estep_rows_per_wg(ws->estep_variant, ws->T, is64);
-                int64_t gd = (n_rows + rpd - 1) / rpd;
-                if (gd > (1 << 20)) gd = 1 << 20;
-                span_begin(ws, kSpanEstepMain, st);
-                e = launch_estep(ws->estep_variant, ws->T, is64, vec, (int)gd, st, a, &name);
-                span_end(ws, st);
-                if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
-                ws->evaluated = (double)n_rows * ws->K;
-                ws->evaluated_prev = -1.0;
-                fell_back = true;
-                ++ws->passes[3];
-                if (ws->img_i8b && !carry) {   // this level left everything a candidate: remember, and go back up
-                    ws->tb_cand[ws->bound_tb] = 1.0;
-                    ws->tb_seen[ws->bound_tb] = 0;
-                    if (ws->bound_tb < (ws->D + 31) / 32) ++ws->bound_tb;
-                }
-                break;
-            }
-            ws->evaluated += listed;
-            ws->evaluated_prev = ws->evaluated;
-            span_begin(ws, kSpanGather, st);
-            e = launch_estep_gather(ws->T, is64, vec, st, a, ws->lists, ws->npad, ws->counts, counts_host);
-            span_end(ws, st);
-            if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_gather launch", e);
-            ++ws->passes[7];
-        }
-    } else {
+    const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
+    const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_R, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
+    bool counted = false;
+    if (mode == kDense) {
         rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
         grid = (n_rows + rpw - 1) / rpw;
         if (grid > (1 << 20)) grid = 1 << 20;
@@ -632,53 +584,125 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
         ++ws->passes[0];
-    }
-    if (ws->prof) {
-        (void)hipEventRecord(ws->ev[1], st);
-        ws->ev_e = true;
-    }
-    const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
-    // small passes are launch-bound: no pair counting, no lists (the dense M-step takes microseconds there)
-    const bool count_pairs = ws->sparse && ws->masks && ws->hmm == nullptr &&
-                             (prune || n_rows * (int64_t)ws->K >= (int64_t(1) << 18));
-    span_begin(ws, kSpanLse, st);
-    if (count_pairs) {
-        // thresholds from a sample of the rows (every 16th block of 1024), then lse + active masks + counts in one pass
-        const int stride = lse_blocks >= 64 ? 16 : 1;
-        const int sampled = (lse_blocks + stride - 1) / stride;
-        const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
-        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)sampled), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->lse, ws->dpart, nullptr, stride);
-        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)ws->K), dim3(256), 0, st, ws->dpart, nullptr, sampled, ws->K, ws->thr,
-                           ws->act_total);
-        hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)nblk), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
-        hipLaunchKernelGGL(thr_kernel, dim3((unsigned)(ws->K + 1)), dim3(256), 0, st, nullptr, ws->apart, nblk, ws->K,
-                           ws->thr, ws->act_total);
-        e = hipGetLastError();
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse / lse_mask launch", e);
-        ws->act_rows = n_rows;
-        ws->act_host = -1.0;
-        ws->active_lists = false;
+        if (ws->prof) {
+            (void)hipEventRecord(ws->ev[1], st);
+            ws->ev_e = true;
+        }
+        const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
+        // small passes are launch-bound: no pair counting, no lists (the dense M-step takes microseconds there)
+        const bool count_pairs = ws->sparse && ws->masks && ws->hmm == nullptr &&
+                                 n_rows * (int64_t)ws->K >= (int64_t(1) << 18);
+        span_begin(ws, kSpanLse, st);
+        if (count_pairs) {
+            // thresholds from a sample of the rows (every 16th block of 1024), then lse + active masks + counts in one pass
+            const int stride = lse_blocks >= 64 ? 16 : 1;
+            const int sampled = (lse_blocks + stride - 1) / stride;
+            hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)sampled), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                               ws->lse, ws->dpart, nullptr, stride);
+            hipLaunchKernelGGL(thr_kernel, dim3((unsigned)ws->K), dim3(256), 0, st, ws->dpart, nullptr, sampled, ws->K, ws->thr,
+                               ws->ctr);
+            hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                               ws->K, ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, st, ws->apart, nullptr, nullptr, sel_grid, ws->ctr);
+            // records for the next pass (one more sweep of the array, ~1 % of the dense kernel's time)
+            if (can_prune && big)
+                hipLaunchKernelGGL(rec_build_kernel<false>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
+                                   ws->npad, n_rows, ws->K, ws->cvec, nullptr, rec);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse / lse_mask launch", e);
+            counted = true;
+            ws->rec_valid = can_prune && big;
+        } else {
+            hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)lse_blocks), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                               ws->lse, nullptr, nullptr, 1);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
+            ws->rec_valid = false;
+        }
+        span_end(ws, st);
+        ws->rec_live = false;
+        ws->evaluated = pairs;
     } else {
-        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)lse_blocks), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->lse, nullptr, nullptr, 1);
+        rc = ensure_lists(ws);
+        if (rc) return rc;
+        if (mode == kBound) {
+            span_begin(ws, kSpanEstepMain, st);
+            e = launch_bound_pass(ws, a, a8, is64, vec, st, &name, &rpw, &grid);
+            span_end(ws, st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
+            ++ws->passes[1];
+            // the best component of every row, exactly
+            span_begin(ws, kSpanSelect, st);
+            if (ws->img_i8b)
+                hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                                   ws->K, ws->khat, ws->masks, ws->blk);
+            else
+                hipLaunchKernelGGL(select_mask_kernel<0>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                                   ws->K, ws->khat, ws->masks, ws->blk);
+            span_end(ws, st);
+            e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step best-component evaluation", e);
+            // records from the bounds (+ the one exact value), then every other candidate
+            span_begin(ws, kSpanSelect, st);
+            hipLaunchKernelGGL(rec_build_kernel<true>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
+                               ws->npad, n_rows, ws->K, ws->cvec, ws->khat, rec);
+            hipLaunchKernelGGL(rec_select_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
+                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart);
+            span_end(ws, st);
+        } else {
+            rpw = kSelRows;
+            grid = sel_grid;
+            name = "estep_carried_bounds";
+            ++ws->passes[2];
+            span_begin(ws, kSpanSelect, st);
+            hipLaunchKernelGGL(rec_select_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
+                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart);
+            span_end(ws, st);
+        }
+        e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate evaluation", e);
+        if (ws->prof) {
+            (void)hipEventRecord(ws->ev[1], st);
+            ws->ev_e = true;
+        }
+        span_begin(ws, kSpanLse, st);
+        hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
+                           ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(3), dim3(256), 0, st, ws->apart, ws->epart, ws->opart, sel_grid, ws->ctr);
         e = hipGetLastError();
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse launch", e);
+        span_end(ws, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "rec_finish launch", e);
+        counted = true;
+        ws->rec_valid = true;
+        ws->rec_live = true;
+        ws->evaluated = -1.0;
+    }
+    // counters -> pinned host memory, behind an event (read by the next pass, or by gmmvb_last_sparsity)
+    if (counted) {
+        e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 4 * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(ws->ctr_ev, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step counters", e);
+        ws->ctr_pending = true;
+        ws->pend_mode = mode;
+        ws->pend_rows = n_rows;
+        ws->act_rows = n_rows;
+    } else {
+        ws->ctr_pending = false;
+        ws->lag_valid = false;
         ws->act_rows = 0;              // nothing counted: dense M-step, no pruning decision from this pass
     }
-    span_end(ws, st);
+    ws->act_host = -1.0;
+    ws->active_lists = false;
     ws->e_state = 1;
     ws->e_rows = n_rows;
     ws->params_used = true;
     ws->have_drift = false;
-    ws->bounds_rows = n_rows;          // the ln rho array now belongs to the parameters in force, on these rows
+    ws->bounds_rows = n_rows;          // the records / the ln rho array now belong to the parameters in force, on these rows
     ws->bounds_x = x_dev;
     ws->bounds_ldx = ldx;
-    if (!prune || pruned_fell_back) ws->carried = 0;
-    ws->prev_pass = (!prune || pruned_fell_back) ? 0 : (ws->carried > 0 ? 2 : 1);
+    ws->prev_pass = mode;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
-                  (i8 || prune) ? 512 : estep_threads(ws->estep_variant), rpw);
+                  (i8 || mode != kDense) ? 512 : estep_threads(ws->estep_variant), rpw);
     return GMMVB_OK;
 }
 
@@ -694,6 +718,9 @@ int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_
     ws->e_rows = n_rows;
     ws->n_spans = 0;
     ws->bounds_rows = 0;               // the array holds responsibilities now, nothing a later E-step may carry over
+    ws->rec_valid = false;
+    ws->rec_live = false;
+    ws->act_rows = 0;
     return GMMVB_OK;
 }
 
@@ -732,11 +759,18 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const char* name = "";
     hipError_t e;
     bool sparse = ws->sparse && ws->masks && pre && ws->e_state == 1 && ws->act_rows == n_rows;
-    if (sparse) {      // the lists pay off when most pairs are negligible
-        double act = 0.0;
-        rc = fetch_active(ws, st, &act);
-        if (rc) return rc;
-        sparse = act <= 0.35 * (double)n_rows * ws->K;
+    if (sparse) {      // the lists pay off when most pairs are negligible (at most 35 % active)
+        const double pairs = (double)n_rows * ws->K;
+        if (ws->rec_live) {
+            // a pass on records is sparse by construction; the last counters that have arrived can still veto
+            poll_counters(ws);
+            if (ws->lag_valid && ws->lag_rows == n_rows && ws->lag_act > 0.35 * pairs) sparse = false;
+        } else {
+            // after a dense E-step the host has been waiting for that kernel anyway: read this pass's own count
+            rc = fetch_counters(ws);
+            if (rc) return rc;
+            sparse = ws->lag_valid && ws->lag_act <= 0.35 * pairs;
+        }
     }
     if (sparse && ws->K > 256) sparse = false;
     if (sparse) {      // E-step output: only the samples that can change the f64 sums, through per-component lists
@@ -806,6 +840,14 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
     if (mode == 0 && ws->e_state == 2) return fail(GMMVB_ESTATE, "ln rho is undefined after gmmvb_load_responsibilities");
     const int64_t total = n_rows * ws->K;
     const bool hmm_gamma = ws->e_state == 3 && mode == 1;      // responsibilities of an HMM pass = gamma
+    if (ws->e_state == 1 && ws->rec_live) {                    // the pass lived on records: only listed pairs are exact
+        const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_R, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
+        hipLaunchKernelGGL(rec_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec,
+                           ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out);
+        hipError_t er = hipGetLastError();
+        if (er != hipSuccess) return fail(GMMVB_EHIP, "rec_readout launch", er);
+        return GMMVB_OK;
+    }
     hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        hmm_gamma ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->lse, ws->npad, row0, n_rows, ws->K, mode,
                        (ws->e_state == 2 || hmm_gamma) ? 1 : 0, out);
@@ -826,9 +868,16 @@ int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_d
     if (!ws || !z_dev) return fail(GMMVB_EINVAL, "null argument");
     if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
+    hipError_t e;
+    if (ws->e_state == 1 && ws->rec_live) {        // rec_finish_kernel left every row's first maximiser in khat
+        e = hipMemcpyAsync(z_dev, ws->khat + row0, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax copy", e);
+        return GMMVB_OK;
+    }
     hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->npad, row0, n_rows, ws->K, z_dev);
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax launch", e);
     return GMMVB_OK;
 }

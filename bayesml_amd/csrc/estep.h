@@ -222,9 +222,9 @@ __global__ __launch_bounds__(64 * NW) void estep_lds_f64(const XT* __restrict__ 
 //      estep_gather_f64 evaluates those pairs exactly (component fixed per workgroup, sample rows gathered);
 //   3. select_near_kernel: every k with u_nk >= ln rho_{n,khat} - 100 ln 2 joins the lists, evaluated exactly too.
 // Every other pair keeps its upper bound, which proves r_nk < 2^-100: it changes neither lse_n nor (mstep.h) any
-// statistic beyond the last bit, and it is below the M-step's skip threshold of every component whose largest
-// responsibility exceeds 2^-100.  The results of the exact pairs do not depend on list order (one MFMA column per
-// sample), so the lists are filled with wave-aggregated atomics.
+// statistic beyond the last bit.  The results of the exact pairs do not depend on list order (one MFMA column per
+// sample); the lists are filled without atomics, in a fixed order (aux_kernels.h).  Which pairs are candidates is
+// decided per row from the records of records.h.
 template <int JB>
 __host__ __device__ constexpr int bound_img_doubles() { return tri_pairs(JB) * 256 + 128; }
 template <int JB>
@@ -296,62 +296,69 @@ __global__ __launch_bounds__(512) void estep_bound_f64(const XT* __restrict__ x,
     }
 }
 
-// Exact ln rho for listed (sample, component) pairs.  Workgroup b handles component k = the segment of `first`
-// (first[k] = index of k's first workgroup, first[K] = grid) that b falls in, and the chunk b - first[k] of that
-// component's sample list; the component's image is staged once and kept for the whole chunk.
-struct GatherPlan {
-    int first[257];       // K <= 256
-};
-constexpr int kGatherTiles = 8;      // wave tiles per workgroup wave -> 8 waves x 16 NB x 8 samples per chunk
+// Exact ln rho for listed (sample, component) pairs: a component's image is staged once and kept while a workgroup works
+// through that component's list, 8 waves x 16 NB x kGatherTiles entries per chunk.
+constexpr int kGatherTiles = 8;
 
+// The work distribution is read from the device (no host knowledge of the list lengths):
+// plan[k] = index of component k's first chunk of kGatherTiles x 8 waves x 16 NB list entries, plan[K] = total
+// (gather_plan_kernel, records.h).  A fixed grid of persistent workgroups takes contiguous runs of chunks, restaging
+// the component image only when the component changes.
 template <int T, typename XT, bool VEC>
-__global__ __launch_bounds__(512) void estep_gather_f64(const XT* __restrict__ x, int64_t ldx, int D,
-                                                        const double* __restrict__ img, const double* __restrict__ cvec,
-                                                        int K, const int* __restrict__ lists /*[K][cap]*/, int64_t cap,
-                                                        const int* __restrict__ counts /*[K]*/, GatherPlan plan,
-                                                        double* __restrict__ lnrho, int64_t npad) {
+__global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict__ x, int64_t ldx, int D,
+                                                            const double* __restrict__ img, const double* __restrict__ cvec,
+                                                            int K, const int* __restrict__ lists /*[K][cap]*/, int64_t cap,
+                                                            const int* __restrict__ counts /*[K]*/,
+                                                            const int* __restrict__ plan /*[K + 1]*/,
+                                                            double* __restrict__ lnrho, int64_t npad) {
     constexpr int NW = 8;
     constexpr int NB = estep_nb_w<XT>(T, NW);
     constexpr int IMG = img_doubles(T);
+    constexpr int CHUNK = NW * 16 * NB * kGatherTiles;
     __shared__ __attribute__((aligned(16))) double smem[IMG];
+    __shared__ int s_first[257];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
-    int k = 0;
-    {
-        int lo = 0, hi = K;                      // largest k with first[k] <= blockIdx.x
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (plan.first[mid] <= (int)blockIdx.x) lo = mid;
-            else hi = mid;
-        }
-        k = lo;
-    }
-    const int count = counts[k];
-    const int64_t chunk0 = (int64_t)(blockIdx.x - plan.first[k]) * (NW * 16 * NB * kGatherTiles);
-    const double* src = img + (int64_t)k * IMG + lane * 2;
-    for (int piece = wave; piece < IMG / 128; piece += NW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 128),
-                                         (__attribute__((address_space(3))) void*)(&smem[piece * 128]), 16, 0, 0);
-    const int* list = lists + (int64_t)k * cap;
-    const double ck = cvec[k];
-    double* out = lnrho + (int64_t)k * npad;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k = threadIdx.x; k <= K; k += 512) s_first[k] = plan[k];
     __syncthreads();
-    for (int t = 0; t < kGatherTiles; ++t) {
-        const int64_t e0 = chunk0 + ((int64_t)t * NW + wave) * 16 * NB;
-        if (e0 >= count) break;
-        int64_t ld[NB], stv[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int64_t e = e0 + 16 * nb + n;
-            const int row = list[e < count ? e : count - 1];
-            ld[nb] = row;
-            stv[nb] = e < count ? row : -1;
+    const int total = s_first[K];
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c0 = (int)blockIdx.x * per;
+    const int c1 = c0 + per < total ? c0 + per : total;
+    int k = 0, kcur = -1;
+    for (int c = c0; c < c1; ++c) {
+        while (s_first[k + 1] <= c) ++k;                 // component of chunk c (empty components are skipped)
+        if (k != kcur) {
+            __syncthreads();                             // every wave is done with the previous image
+            const double* src = img + (int64_t)k * IMG + lane * 2;
+            for (int piece = wave; piece < IMG / 128; piece += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 128),
+                                                 (__attribute__((address_space(3))) void*)(&smem[piece * 128]), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            kcur = k;
         }
-        XT xr[NB][T][4];
-        load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
-        estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
+        const int count = counts[k];
+        const int64_t chunk0 = (int64_t)(c - s_first[k]) * CHUNK;
+        const int* list = lists + (int64_t)k * cap;
+        const double ck = cvec[k];
+        double* out = lnrho + (int64_t)k * npad;
+        for (int t = 0; t < kGatherTiles; ++t) {
+            const int64_t e0 = chunk0 + ((int64_t)t * NW + wave) * 16 * NB;
+            if (e0 >= count) break;
+            int64_t ld[NB], stv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int64_t e = e0 + 16 * nb + n;
+                const int row = list[e < count ? e : count - 1];
+                ld[nb] = row;
+                stv[nb] = e < count ? row : -1;
+            }
+            XT xr[NB][T][4];
+            load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
+            estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
+        }
     }
 }
 

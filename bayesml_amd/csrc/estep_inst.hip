@@ -64,14 +64,6 @@ static hipError_t go_bound(int grid, hipStream_t st, const EstepArgs& a) {
                        a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
     return hipGetLastError();
 }
-template <int T, typename XT, bool VEC>
-static hipError_t go_gather(int grid, hipStream_t st, const EstepArgs& a, const int* lists, int64_t cap,
-                            const int* counts, const GatherPlan& plan) {
-    hipLaunchKernelGGL((estep_gather_f64<T, XT, VEC>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x), a.ldx,
-                       a.D, a.img, a.cvec, a.K, lists, cap, counts, plan, a.lnrho, a.npad);
-    return hipGetLastError();
-}
-
 #define BCASE(TT, JB)                                                                                              \
     case TT:                                                                                                       \
         *name = "estep_bound_f64<T=" #TT ",blocks=" #JB ">";                                                       \
@@ -86,30 +78,27 @@ hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream
     return hipErrorInvalidValue;
 }
 
-#define GCASE(TT)                                                                                                            \
+template <int T, typename XT, bool VEC>
+static hipError_t go_gather_dev(int grid, hipStream_t st, const EstepArgs& a, const int* lists, int64_t cap,
+                                const int* counts, const int* plan) {
+    hipLaunchKernelGGL((estep_gather_dev_f64<T, XT, VEC>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x), a.ldx,
+                       a.D, a.img, a.cvec, a.K, lists, cap, counts, plan, a.lnrho, a.npad);
+    return hipGetLastError();
+}
+
+#define GDCASE(TT)                                                                                                           \
     case TT:                                                                                                                 \
         if (x_is_f64)                                                                                                        \
-            return vec ? go_gather<TT, double, true>(grid, st, a, lists, cap, counts_dev, plan)                              \
-                       : go_gather<TT, double, false>(grid, st, a, lists, cap, counts_dev, plan);                            \
-        return vec ? go_gather<TT, float, true>(grid, st, a, lists, cap, counts_dev, plan)                                   \
-                   : go_gather<TT, float, false>(grid, st, a, lists, cap, counts_dev, plan);
+            return vec ? go_gather_dev<TT, double, true>(grid, st, a, lists, cap, counts_dev, plan_dev)                      \
+                       : go_gather_dev<TT, double, false>(grid, st, a, lists, cap, counts_dev, plan_dev);                    \
+        return vec ? go_gather_dev<TT, float, true>(grid, st, a, lists, cap, counts_dev, plan_dev)                           \
+                   : go_gather_dev<TT, float, false>(grid, st, a, lists, cap, counts_dev, plan_dev);
 
-hipError_t launch_estep_gather(int T, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a, const int* lists,
-                               int64_t cap, const int* counts_dev, const int* counts_host) {
+hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
+                                   const int* lists, int64_t cap, const int* counts_dev, const int* plan_dev) {
     if (a.K > 256) return hipErrorInvalidValue;
-    const int per_wg = estep_gather_rows_per_wg(T, x_is_f64);
-    GatherPlan plan;
-    int64_t total = 0;
-    for (int k = 0; k < a.K; ++k) {
-        plan.first[k] = (int)total;
-        total += (counts_host[k] + per_wg - 1) / per_wg;
-    }
-    for (int k = a.K; k <= 256; ++k) plan.first[k] = (int)total;
-    if (total == 0) return hipSuccess;
-    if (total > 0x7fffffff) return hipErrorInvalidValue;
-    const int grid = (int)total;
     switch (T) {
-        GCASE(4) GCASE(5) GCASE(6) GCASE(7) GCASE(8)
+        GDCASE(4) GDCASE(5) GDCASE(6) GDCASE(7) GDCASE(8)
     }
     return hipErrorInvalidValue;
 }

@@ -27,9 +27,10 @@ int estep_bound_rows_per_wg(int T, int x_is_f64);
 int estep_gather_rows_per_wg(int T, int x_is_f64);
 hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
                               const char** name);
-// counts_host[k] samples in list k (device lists [K][cap], device counts); launches nothing when all are empty
-hipError_t launch_estep_gather(int T, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a, const int* lists,
-                               int64_t cap, const int* counts_dev, const int* counts_host);
+// exact f64 evaluation of listed pairs (device lists [K][cap], device counts), chunk plan on the device
+// (records.h: gather_plan_kernel), a fixed grid of persistent workgroups
+hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
+                                   const int* lists, int64_t cap, const int* counts_dev, const int* plan_dev);
 // int8-digit E-step (estep_i8.h): own parameter image (bytes per component), 256 rows per workgroup
 struct EstepI8Args {
     const void* x; int64_t ldx; int64_t n_rows; int D;

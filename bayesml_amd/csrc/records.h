@@ -1,0 +1,428 @@
+// Per-row candidate records of the pruned E-step: what is carried from one E-step to the next.
+//
+// Once the responsibilities are sparse (a handful of the K components matter per sample), the E-step only has to
+// PROVE the other pairs irrelevant (r_nk < 2^-100, invisible in every f64 sum of the reference's _update_q_z /
+// _calc_n_x_bar_s, bayesml/gaussianmixture/_gaussianmixture.py:772-784, 725-732).  The proof object per row n is
+//   up to C = 8 slots (k_j, d_j):   d_j <= || U_k (x_n - m_k) ||  (a lower bound of the whitened distance; for slots
+//                                   evaluated exactly in the last pass it is the distance itself, flagged "exact")
+//   one rest bound R:               R <= || U_k (x_n - m_k) ||  for EVERY component k that has no slot
+// 55 bytes per row instead of the K x 8 bytes of a dense ln rho row.  A parameter update (m, U) -> (m', U') with
+//   gamma_k <= sigma_min(U'_k U_k^-1),  Gamma_k >= sigma_max(U'_k U_k^-1),  delta_k >= || U'_k (m'_k - m_k) ||
+// (gmmvb_set_drift) turns them into records for the new parameters without touching x:
+//   d'_j = (gamma_k d_j - delta_k)_+,  R' = (min_k gamma_k * R - max_k delta_k)_+,   upper bounds of ln rho':
+//   ub_j = c'_k - d'_j^2 / 2,  ub_rest = max_k c'_k - R'^2 / 2,  and for an exact slot a LOWER bound of the new value
+//   lb_j = c'_k - (Gamma_k d_j + delta_k)^2 / 2.
+// With thr = max_j lb_j - 100 ln 2 (a lower bound of the row's best value, minus the 2^-100 margin):
+//   ub_j < thr    -> pair (n, k_j) is irrelevant this pass, nothing to compute;
+//   ub_j >= thr   -> the pair is a candidate: listed, evaluated exactly (f64 MFMA, estep_gather_dev_f64);
+//   ub_rest >= thr-> the rest bound has become too loose for this row: ALL K pairs of the row are evaluated exactly
+//                    ("overflow row") and its record is rebuilt from the exact values.
+// Nothing here needs the host: lists, gather grid and statistics are sized on the device, so an E-step is a fixed
+// sequence of launches without a synchronisation.  The dense [K][npad] ln rho array stays the exchange buffer for
+// exact values (gather kernel -> rec_finish_kernel / M-step / read-outs); only listed entries of it are touched.
+#pragma once
+#include "aux_kernels.h"
+
+namespace gmmvb {
+
+constexpr int kRecSlots = 8;
+constexpr unsigned short kRecEmpty = 0xFFFF;
+constexpr double k100Ln2 = 69.314718055994530942;
+
+struct RecArrays {
+    unsigned short* k;      // [C][npad] component of slot j (kRecEmpty: unused)
+    float* d;               // [C][npad] lower bound of the whitened distance, rounded towards zero
+    float* R;               // [npad] lower bound for every component without a slot (+inf: there is none)
+    unsigned char* exact;   // [npad] bit j: d_j is the distance itself: d_j <= dist <= d_j (1 + 2^-22)
+    unsigned char* sel;     // [npad] bit j: slot j was listed for exact evaluation in the current pass
+    unsigned char* flags;   // [npad] bit 0: overflow row of the current pass (all K pairs evaluated exactly)
+    int64_t npad;
+};
+
+__device__ __forceinline__ float f32_down(double v) { return __double2float_rd(v); }      // v >= 0: towards zero
+
+// whitened distance (lower bound if v is an upper bound of ln rho) from a stored value; NaN -> 0 (always a candidate)
+__device__ __forceinline__ double dist_of(double c, double v) {
+    const double q = 2.0 * (c - v);
+    return q > 0.0 ? sqrt(q) : 0.0;
+}
+
+// sorted insertion of (cd, ck) into the ascending list ds[0..C] (C + 1 entries: the slots and the best of the rest)
+__device__ __forceinline__ void rec_insert(float (&ds)[kRecSlots + 1], unsigned short (&ks)[kRecSlots + 1], float cd,
+                                           unsigned short ck) {
+#pragma unroll
+    for (int j = 0; j <= kRecSlots; ++j) {
+        const bool lt = cd < ds[j];
+        const float td = lt ? ds[j] : cd;
+        const unsigned short tk = lt ? ks[j] : ck;
+        ds[j] = lt ? cd : ds[j];
+        ks[j] = lt ? ck : ks[j];
+        cd = td;
+        ck = tk;
+    }
+}
+
+// From a dense ln rho row (exact values and / or upper bounds under the parameters in force) to a record:
+// the C components of smallest distance get slots, R = the next distance.  GIVEN: khat[n] is the one pair known to
+// be exact (the bound pass evaluated it), it gets a slot and the exact flag; otherwise every value is exact (dense
+// pass), all slots are flagged and khat is not read.
+template <bool GIVEN>
+__global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
+                                                        int K, const double* __restrict__ cvec,
+                                                        const int* __restrict__ khat, RecArrays rec) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_rows) return;
+    float ds[kRecSlots + 1];
+    unsigned short ks[kRecSlots + 1];
+#pragma unroll
+    for (int j = 0; j <= kRecSlots; ++j) {
+        ds[j] = __builtin_huge_valf();
+        ks[j] = kRecEmpty;
+    }
+    for (int k = 0; k < K; ++k) rec_insert(ds, ks, f32_down(dist_of(cvec[k], lnrho[(int64_t)k * npad + n])), (unsigned short)k);
+    float R = ds[kRecSlots];
+    unsigned ex = 0;
+    if (GIVEN) {
+        const int kb = khat[n];
+        int at = -1;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) at = (ks[j] == kb) ? j : at;
+        if (at < 0) {          // the exact pair is not among the C nearest: it takes the last slot, which joins the rest
+            at = kRecSlots - 1;
+            R = ds[at] < R ? ds[at] : R;
+            ks[at] = (unsigned short)kb;
+            ds[at] = f32_down(dist_of(cvec[kb], lnrho[(int64_t)kb * npad + n]));
+        }
+        ex = 1u << at;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) ex |= (ks[j] != kRecEmpty) ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kRecSlots; ++j) {
+        rec.k[(int64_t)j * rec.npad + n] = ks[j];
+        rec.d[(int64_t)j * rec.npad + n] = ds[j];
+    }
+    rec.R[n] = R;
+    rec.exact[n] = (unsigned char)ex;
+    rec.sel[n] = 0;
+    rec.flags[n] = 0;
+}
+
+// per-block component counts of a 64-bit mask word (as in select_mask_kernel)
+__device__ __forceinline__ void count_word(unsigned long long mk, int w, int wave, int (*wcnt)[256]) {
+    unsigned long long present = wave_or(mk);
+    while (present) {
+        const int b = __builtin_ctzll(present);
+        present &= present - 1;
+        const int c = __builtin_popcountll(__ballot((mk >> b) & 1ull));
+        if ((threadIdx.x & 63) == 0) wcnt[wave][64 * w + b] = c;
+    }
+}
+
+// Carry the records over a parameter update and select this pass's candidates (header comment).
+// drift = [gamma K | delta K | (unused K) | Gamma K]; IDENT: no update happened (the records were just built from a
+// bound pass): gamma = Gamma = 1, delta = 0, and exact slots are already evaluated (never listed again).
+// Outputs: masks (candidate components per row, all K for overflow rows), per-block counts for scan_counts /
+// fill_lists, epart[block] = listed pairs, opart[block] = overflow rows.
+template <bool IDENT>
+__global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int64_t n_rows, int K,
+                                                              const double* __restrict__ drift,
+                                                              const double* __restrict__ c_new,
+                                                              unsigned long long* __restrict__ masks, int64_t npad,
+                                                              int* __restrict__ blk_cnt, double* __restrict__ epart,
+                                                              double* __restrict__ opart) {
+    __shared__ int wcnt[4][256];
+    __shared__ double sg[256], sdl[256], sG[256], sc[256];
+    __shared__ double sred[3][4];
+    __shared__ int wsum[2][4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int W = (K + 63) / 64;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    double gmin = __builtin_huge_val(), dmax = 0.0, cmax = -__builtin_huge_val();
+    for (int k = tid; k < K; k += kSelRows) {
+        const double g = IDENT ? 1.0 : drift[k], dl = IDENT ? 0.0 : drift[K + k], G = IDENT ? 1.0 : drift[3 * K + k];
+        const double c = c_new[k];
+        sg[k] = g;
+        sdl[k] = dl;
+        sG[k] = G;
+        sc[k] = c;
+        gmin = (g < gmin || g != g) ? g : gmin;          // NaN wins: every rest bound becomes useless, rows overflow
+        dmax = (dl > dmax || dl != dl) ? dl : dmax;
+        cmax = (c > cmax || c != c) ? c : cmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(gmin, o), b = __shfl_xor(dmax, o), c = __shfl_xor(cmax, o);
+        gmin = (a < gmin || a != a) ? a : gmin;
+        dmax = (b > dmax || b != b) ? b : dmax;
+        cmax = (c > cmax || c != c) ? c : cmax;
+    }
+    if ((tid & 63) == 0) {
+        sred[0][wave] = gmin;
+        sred[1][wave] = dmax;
+        sred[2][wave] = cmax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const double a = sred[0][v], b = sred[1][v], c = sred[2][v];
+        gmin = (a < gmin || a != a) ? a : gmin;
+        dmax = (b > dmax || b != b) ? b : dmax;
+        cmax = (c > cmax || c != c) ? c : cmax;
+    }
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
+    const bool valid = n < n_rows;
+    unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+    int listed = 0, over_i = 0;
+    if (valid) {
+        const unsigned ex = rec.exact[n];
+        const double ninf = -__builtin_huge_val();
+        double lb = ninf;
+        double ub[kRecSlots];
+        unsigned short kk[kRecSlots];
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            const unsigned short k = rec.k[(int64_t)j * rec.npad + n];
+            kk[j] = k;
+            ub[j] = ninf;
+            if (k == kRecEmpty) continue;
+            const double d = (double)rec.d[(int64_t)j * rec.npad + n];
+            double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
+            y = y > 0.0 ? y : 0.0;                                   // also NaN -> 0: the trivial bound c'
+            const float yf = f32_down(y);
+            const double c = sc[k];
+            ub[j] = c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c);
+            if (!IDENT) rec.d[(int64_t)j * rec.npad + n] = yf;
+            if ((ex >> j) & 1u) {
+                const double du = sG[k] * d * (1.0 + 2.4e-7) * (1.0 + 1e-12) + sdl[k];
+                const double l = c - 0.5 * du * du * (1.0 + 1e-12) - 1e-12 * fabs(c);
+                lb = l > lb ? l : lb;                                // NaN never raises the threshold
+            }
+        }
+        const float R = rec.R[n];
+        double rest_ub = ninf;
+        if (R < __builtin_huge_valf() || R != R) {                  // there are components without a slot
+            double y = gmin * (double)R * (1.0 - 1e-12) - dmax;
+            y = y > 0.0 ? y : 0.0;
+            const float yf = f32_down(y);
+            rest_ub = cmax - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(cmax);
+            if (!IDENT) rec.R[n] = yf;
+        }
+        const double thr = lb - k100Ln2;
+        const bool over = !(rest_ub < thr);                          // also: no exact slot (lb = -inf), any NaN
+        unsigned sel = 0;
+        if (over) {
+            for (int w = 0; w < W; ++w) mk[w] = (K - 64 * w >= 64) ? ~0ull : ((1ull << (K - 64 * w)) - 1ull);
+            listed = K;
+            over_i = 1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kRecSlots; ++j) {
+                if (kk[j] == kRecEmpty) continue;
+                if (IDENT && ((ex >> j) & 1u)) continue;             // already exact under these parameters
+                if (!(ub[j] < thr)) {
+                    sel |= 1u << j;
+                    mk[kk[j] >> 6] |= 1ull << (kk[j] & 63);
+                    ++listed;
+                }
+            }
+        }
+        rec.sel[n] = (unsigned char)sel;
+        rec.flags[n] = (unsigned char)(over ? 1 : 0);
+        if (!IDENT) rec.exact[n] = 0;          // carried distances are one-sided until the pair is evaluated again
+        for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
+    }
+    for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        listed += __shfl_xor(listed, o);
+        over_i += __shfl_xor(over_i, o);
+    }
+    if ((tid & 63) == 0) {
+        wsum[0][wave] = listed;
+        wsum[1][wave] = over_i;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += kSelRows)
+        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    if (tid == 0) {
+        epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
+        opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
+    }
+}
+
+// first[k] = index of component k's first gather chunk (chunk = per_wg list entries), first[K] = number of chunks
+__global__ void gather_plan_kernel(const int* __restrict__ counts, int K, int per_wg, int* __restrict__ first) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int total = 0;
+    for (int k = 0; k < K; ++k) {
+        first[k] = total;
+        total += (counts[k] + per_wg - 1) / per_wg;
+    }
+    first[K] = total;
+}
+
+// After the exact evaluation of the listed pairs: refresh the records from the exact values (distances, exact
+// flags; overflow rows are rebuilt from all K values), and produce what the rest of the pass needs per row:
+// lse_n, the best component, the M-step's active mask (r_nk >= 2^-100) with its block counts, apart[block] = active pairs.
+__global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, const double* __restrict__ lnrho, int64_t npad,
+                                                              int64_t n_rows, int K, const double* __restrict__ cvec,
+                                                              double* __restrict__ lse, int* __restrict__ khat,
+                                                              unsigned long long* __restrict__ masks,
+                                                              int* __restrict__ blk_cnt, double* __restrict__ apart) {
+    __shared__ int wcnt[4][256];
+    __shared__ int wact[4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int W = (K + 63) / 64;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
+    const bool valid = n < n_rows;
+    unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+    int active = 0;
+    if (valid && !(rec.flags[n] & 1)) {
+        unsigned live = (unsigned)rec.sel[n] | (unsigned)rec.exact[n];
+        double v[kRecSlots];
+        unsigned short kk[kRecSlots];
+        double mx = -__builtin_huge_val();
+        int arg = 0x7fffffff;
+        bool nan = false;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            kk[j] = rec.k[(int64_t)j * rec.npad + n];
+            v[j] = 0.0;
+            if (!((live >> j) & 1u)) continue;
+            const double x = lnrho[(int64_t)kk[j] * npad + n];
+            v[j] = x;
+            rec.d[(int64_t)j * rec.npad + n] = f32_down(dist_of(cvec[kk[j]], x));
+            nan = nan || x != x;
+            if (x > mx || (x == mx && (int)kk[j] < arg)) {          // first maximiser, like numpy.argmax
+                mx = x;
+                arg = kk[j];
+            }
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j)
+            if ((live >> j) & 1u) s += exp(v[j] - mx);
+        double l = mx + log(s);
+        if (nan) {                                                  // poisoned row: NaN everywhere, like the dense path
+            l = __builtin_nan("");
+            arg = arg == 0x7fffffff ? 0 : arg;
+        }
+        lse[n] = l;
+        khat[n] = arg == 0x7fffffff ? 0 : arg;
+        rec.exact[n] = (unsigned char)live;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            if (!((live >> j) & 1u)) continue;
+            if (!(v[j] - l < -k100Ln2)) {                           // NaN stays active
+                mk[kk[j] >> 6] |= 1ull << (kk[j] & 63);
+                ++active;
+            }
+        }
+    } else if (valid) {
+        // overflow row: every value of the dense row is exact.  One sweep: running max / sum and the C + 1 nearest
+        float ds[kRecSlots + 1];
+        unsigned short ks[kRecSlots + 1];
+#pragma unroll
+        for (int j = 0; j <= kRecSlots; ++j) {
+            ds[j] = __builtin_huge_valf();
+            ks[j] = kRecEmpty;
+        }
+        double mx = lnrho[n], s = 1.0;
+        int arg = 0;
+        rec_insert(ds, ks, f32_down(dist_of(cvec[0], mx)), 0);
+        for (int k = 1; k < K; ++k) {
+            const double x = lnrho[(int64_t)k * npad + n];
+            rec_insert(ds, ks, f32_down(dist_of(cvec[k], x)), (unsigned short)k);
+            if (x > mx) {
+                s = fma(s, exp(mx - x), 1.0);
+                mx = x;
+                arg = k;
+            } else {
+                s += exp(x - mx);
+            }
+        }
+        const double l = mx + log(s);
+        lse[n] = l;
+        khat[n] = arg;
+        unsigned ex = 0;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            rec.k[(int64_t)j * rec.npad + n] = ks[j];
+            rec.d[(int64_t)j * rec.npad + n] = ds[j];
+            ex |= (ks[j] != kRecEmpty) ? (1u << j) : 0u;
+        }
+        rec.R[n] = ds[kRecSlots];
+        rec.exact[n] = (unsigned char)ex;
+        rec.sel[n] = (unsigned char)ex;
+        for (int k = 0; k < K; ++k) {
+            const double t = lnrho[(int64_t)k * npad + n] - l;
+            if (!(t < -k100Ln2)) {
+                mk[k >> 6] |= 1ull << (k & 63);
+                ++active;
+            }
+        }
+    }
+    if (valid)
+        for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
+    for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o);
+    if ((tid & 63) == 0) wact[wave] = active;
+    __syncthreads();
+    for (int k = tid; k < K; k += kSelRows)
+        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    if (tid == 0) apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
+}
+
+// ctr[0] = sum apart (active pairs), ctr[1] = sum epart (exactly evaluated pairs), ctr[2] = sum opart (overflow rows);
+// a null part leaves its counter as it is.  One workgroup per counter, fixed summation order.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
+                                                        const double* __restrict__ opart, int blocks,
+                                                        double* __restrict__ ctr) {
+    __shared__ double part[256];
+    const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : opart);
+    if (!src) return;
+    double a = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) a += src[b];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += part[i];
+        ctr[blockIdx.x] = t;
+    }
+}
+
+// Read-outs of a pass that lived on records.  mode 0: ln rho (exact for evaluated pairs, otherwise the record's upper
+// bound - at least 100 ln 2 below the row's best); mode 1: responsibilities (exactly 0 for pruned pairs: < 2^-100).
+__global__ void rec_readout_kernel(RecArrays rec, const double* __restrict__ lnrho, const double* __restrict__ lse,
+                                   const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
+                                   int mode, double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * K) return;
+    const int64_t n = row0 + e / K;
+    const int k = (int)(e % K);
+    bool exact = (rec.flags[n] & 1) != 0;
+    double bound = (double)rec.R[n];
+    if (!exact) {
+        const unsigned live = rec.exact[n];
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            if (rec.k[(int64_t)j * rec.npad + n] == k) {
+                exact = (live >> j) & 1u;
+                bound = (double)rec.d[(int64_t)j * rec.npad + n];
+            }
+        }
+    }
+    if (exact) {
+        const double v = lnrho[(int64_t)k * npad + n];
+        out[e] = mode == 0 ? v : exp(v - lse[n]);
+    } else {
+        out[e] = mode == 0 ? cvec[k] - 0.5 * bound * bound : 0.0;
+    }
+}
+
+}  // namespace gmmvb

@@ -30,30 +30,50 @@ struct gmmvb_workspace {
     double tb_cand[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};
     double tb_act[5] = {0.0, 0.0, 0.0, 0.0, 0.0};      // active pairs per pair when tb_cand[L] was observed
     int tb_seen[5] = {0, 0, 0, 0, 0};
-    double evaluated_prev = -1.0;      // candidates of the last pruned E-step (-1: it did not prune)
-    // carrying bounds over a parameter update (gmmvb_set_drift): gamma / delta of the pending update, the c vector of
-    // the last E-step, whether the ln rho array holds values / bounds for those parameters on `bounds_rows` rows,
-    // and how many E-steps in a row have lived on carried bounds
-    double* drift = nullptr;           // [3][K]: gamma, delta, c of the last E-step
+    // carrying the E-step over a parameter update (gmmvb_set_drift, records.h): gamma / delta / Gamma of the pending
+    // update, whether the records belong to the parameters of the last E-step on `bounds_rows` rows of `bounds_x`
+    double* drift = nullptr;           // [4][K]: gamma, delta, (unused), Gamma
     bool have_drift = false;
     double typical_gamma = -1.0;       // mean gamma of the pending update if the caller knew it (<= 0: unknown)
     bool params_used = false;          // the parameters in force were the ones of the last E-step
-    int64_t bounds_rows = 0;           // ... and of which matrix (0 / null: the array holds nothing that can be carried)
+    int64_t bounds_rows = 0;           // rows / matrix the records (and the ln rho array) belong to (0: nothing to carry)
     const void* bounds_x = nullptr;
     int64_t bounds_ldx = 0;
-    int carried = 0;
-    int prev_pass = 0;                 // last E-step: 0 dense, 1 bound pass, 2 carried bounds
-    double spare_last = -1.0, spare_before = -1.0;   // spare candidates per pair of the last two pruned passes
+    int prev_pass = 0;                 // last E-step: 0 dense, 1 bound pass, 2 carried records
+    // per-row candidate records (records.h), allocated with the sample lists
+    unsigned short* rec_k = nullptr;   // [8][npad]
+    float* rec_d = nullptr;            // [8][npad]
+    float* rec_R = nullptr;            // [npad]
+    unsigned char* rec_exact = nullptr, *rec_sel = nullptr, *rec_flags = nullptr;   // [npad] each
+    bool rec_valid = false;            // the records describe the last E-step's parameters on bounds_rows rows
+    bool rec_live = false;             // the last E-step lived on records (read-outs go through them)
+    int* plan = nullptr;               // [K + 1] gather chunk plan (device)
+    double* epart = nullptr;           // [ceil(npad / 256)] listed pairs per selection block
+    double* opart = nullptr;           // [ceil(npad / 256)] overflow rows per selection block
+    // counters of an E-step: [0] active pairs (r >= 2^-100), [1] pairs evaluated exactly, [2] overflow rows.
+    // Written on the device at the end of every E-step and copied to pinned host memory behind an event; the NEXT
+    // E-step / M-step reads whatever has arrived (policy decisions lag one pass, results never depend on them).
+    double* ctr = nullptr;             // [4] device
+    double* ctr_host = nullptr;        // [4] pinned
+    hipEvent_t ctr_ev = nullptr;
+    bool ctr_pending = false;          // a copy is in flight ...
+    int pend_mode = 0;                 // ... of an E-step of this mode over pend_rows rows
+    int64_t pend_rows = 0;
+    bool lag_valid = false;            // lag_* = counters of the most recent E-step whose copy has arrived
+    double lag_act = 0.0, lag_eval = 0.0, lag_over = 0.0;
+    int64_t lag_rows = 0;
+    int lag_mode = 0;
+    bool forget = false;               // gmmvb_forget: the next parameters are unrelated to the last E-step's
+    double spare_last = -1.0;          // spare candidates per pair of the last pruned pass (diagnostics)
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)
     double* thr = nullptr;     // [K] M-step skip thresholds: max_n ln r_nk - 100 ln 2 (valid while e_state == 1)
     bool sparse = true;        // env GMMVB_MSTEP_SPARSE=0: always run the dense M-step
-    double* apart = nullptr;   // [ceil(npad / 1024)] pairs with ln r >= -100 ln 2 per row block
-    double* act_total = nullptr;   // their sum, written by thr_kernel after every E-step
-    int64_t act_rows = 0;      // rows of the E-step act_total belongs to (0 = none yet)
-    double act_host = -1.0;    // host copy of act_total for that E-step (-1 = not fetched yet)
-    double evaluated = 0.0;    // pairs the last E-step evaluated exactly
+    double* apart = nullptr;   // [ceil(npad / 256)] pairs with ln r >= -100 ln 2 per selection block
+    int64_t act_rows = 0;      // rows of the E-step whose active pairs were counted (0 = not counted)
+    double act_host = -1.0;    // host copy of ctr[0] for that E-step (-1 = not fetched yet)
+    double evaluated = 0.0;    // pairs the last E-step evaluated exactly (-1: on the device, see gmmvb_last_sparsity)
     // pruned E-step (estep.h): env GMMVB_ESTEP_PRUNE = 0 never | force always | default: when the previous E-step
     // over the same rows left at most half of the pairs relevant and N K >= 2^23
     int prune = 1;

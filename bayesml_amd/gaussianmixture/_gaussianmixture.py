@@ -316,7 +316,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._comm.all_reduce_(ks.stats)
 
     def _give_params(self, eng, q, hint=None):
-        """Hand a posterior's E-step parameters to the engine; ``hint`` = (gamma, delta, mean gamma) of the update
+        """Hand a posterior's E-step parameters to the engine; ``hint`` = (gamma, delta, big_gamma, mean gamma) of the update
         that led to it from the parameters of the engine's last E-step (gmmvb_set_drift), or None."""
         if hint is not None:
             eng.set_drift(*hint)
@@ -336,7 +336,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
 
     @staticmethod
     def _drift_hint(eng, xd, q_from, q):
-        """(gamma, delta) of gmmvb_set_drift for the update q_from -> q, or None when the engine cannot use it."""
+        """(gamma, delta, big_gamma) of gmmvb_set_drift for the update q_from -> q, or None when the engine cannot use it."""
         if q_from is None or q is None or not hasattr(eng, "wants_drift") or not eng.wants_drift(xd.shape[0]):
             return None
         return _kside.drift(q_from, q)
@@ -368,6 +368,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         for i in range(num_init):
             q = _kside.post_from_prior(prior)
             self._reset_hn_from(q)
+            if hasattr(eng, "forget"):
+                eng.forget()            # a restart's parameters are unrelated to the last pass: expect dense responsibilities
             if init_type == "subsampling":
                 q = self._init_subsampling(eng, xd, q, n_global)
                 ks.load(q)
@@ -390,8 +392,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             self._say(f"\r{i}. VL: {vl}")
             for t in range(max_itr):
                 vl_before = vl
-                hint = (ks.gamma, ks.delta, gmean) if (ks.want_drift and carried) else None
-                self._give_params(eng, ks.q_next, hint)
+                self._give_params(eng, ks.q_next, ks.hint(gmean) if carried else None)
                 ks.advance()
                 carried = True
                 self._data_pass(eng, xd, ks)

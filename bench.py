@@ -219,8 +219,7 @@ class Workload:
         # update_posterior's loop body: parameter hand-over (+ drift hint) -> data pass (+ all-reduce) -> K-side step
         # (one hipGraph replay) -> ONE device-to-host copy (lower bound terms, mean drift)
         m, ks = self.m, self.ks
-        hint = (ks.gamma, ks.delta, self.gmean) if ks.want_drift else None
-        m._give_params(self.eng, ks.q_next, hint)
+        m._give_params(self.eng, ks.q_next, ks.hint(self.gmean))
         ks.advance()
         m._data_pass(self.eng, self.xd, ks)
         ks.step()

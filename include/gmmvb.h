@@ -12,8 +12,11 @@
  *
  * Conventions
  *   - every pointer argument named *_dev is a DEVICE pointer owned by the caller; `stream` is a
- *     hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work; they never
- *     synchronise, never allocate (only gmmvb_workspace_create/destroy touch the allocator) and never throw.
+ *     hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work: they do not allocate (only
+ *     gmmvb_workspace_create/destroy and hmmvb_enable touch the allocator), do not throw and - with the exceptions
+ *     listed at gmmvb_last_sparsity - do not synchronise.  Policy decisions inside gmmvb_estep / gmmvb_mstep (dense
+ *     kernel, bound pass or carried records; dense or list M-step) use counters of EARLIER passes that have already
+ *     arrived in pinned host memory; results never depend on them.
  *   - return value: GMMVB_OK or an error code; gmmvb_last_error() gives a thread-local message.
  *   - all K-sized quantities and all outputs are IEEE binary64.  The sample matrix x stays in its
  *     storage dtype (f32 or f64) in HBM and is widened on load; all arithmetic is f64
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GMMVB_ABI_VERSION 1
+#define GMMVB_ABI_VERSION 2
 
 enum gmmvb_status {
     GMMVB_OK = 0,
@@ -101,8 +104,8 @@ int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64
 
 /* Read-outs for rows [row0, row0 + n_rows) of the last E-step, row-major [n_rows][K].
  * When the E-step pruned (large N K, sparse responsibilities; see gmmvb_last_sparsity), gmmvb_ln_rho returns, for the
- * pairs it did not evaluate, an upper bound of ln rho that lies at least 100 ln 2 below the row's largest value:
- * responsibilities, hard assignments and statistics are unaffected (r < 2^-100 for those pairs).  Pruning is never
+ * pairs it did not evaluate, an upper bound of ln rho that lies at least 100 ln 2 below the row's largest value, and
+ * gmmvb_responsibilities returns exactly 0 for them (r < 2^-100): hard assignments and statistics are unaffected.  Pruning is never
  * used once hmmvb_enable has been called, or with GMMVB_ESTEP_PRUNE=0 in the environment. */
 int gmmvb_responsibilities(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* r_dev, void* stream);
 int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
@@ -166,24 +169,31 @@ int gmmvb_kside_factor(int K, int D, const double* w_inv_dev /*[K][D][D]*/, doub
 int gmmvb_pass_counts(const gmmvb_workspace* ws, int64_t* out /*[8]*/);
 
 /* Optional hint for the pruned E-step, to be given BEFORE the gmmvb_set_params of new parameters: for every component k
- * gamma[k] <= sigma_min(u_new u_old^-1) and delta[k] >= || u_new (m_new - m_old) ||_2, where (m_old, u_old) are the
- * parameters of the last gmmvb_estep.  Then || u_new (x - m_new) || >= gamma || u_old (x - m_old) || - delta for every
- * x, which lets the next gmmvb_estep carry the previous pass's values and upper bounds of ln rho over to the new
- * parameters (one elementwise pass) instead of bounding every pair afresh; pairs whose carried bound is no longer
- * good enough are evaluated exactly as usual.  Loose values only cost candidates, wrong ones (gamma too large,
- * delta too small) break the bounds.  typical_gamma: the mean of gamma if the caller has it on the host (it steers
- * the choice between carrying and a fresh bound pass: below 0.9 the parameters are judged to move too fast), or a
- * value <= 0 if not.  The hint is consumed by the next gmmvb_estep. */
+ *   gamma[k] <= sigma_min(u_new u_old^-1),  big_gamma[k] >= sigma_max(u_new u_old^-1),  delta[k] >= || u_new (m_new - m_old) ||_2
+ * where (m_old, u_old) are the parameters of the last gmmvb_estep.  Then for every x
+ *   gamma || u_old (x - m_old) || - delta  <=  || u_new (x - m_new) ||  <=  big_gamma || u_old (x - m_old) || + delta,
+ * which lets the next gmmvb_estep carry its per-row candidate records (csrc/records.h: up to 8 (component, distance)
+ * slots and one bound for all other components, 55 bytes per row) over to the new parameters instead of bounding every
+ * pair afresh: pairs whose carried bound proves r < 2^-100 are skipped, the others are evaluated exactly, and a row
+ * whose record has become too loose has all K pairs evaluated.  Loose values only cost candidates, wrong ones (gamma too
+ * large, big_gamma or delta too small) break the bounds.  typical_gamma: the mean of gamma if the caller has it on the
+ * host (below 0.9 the parameters are judged to move too fast for carrying), or a value <= 0 if not.  The hint is consumed
+ * by the next gmmvb_estep. */
 int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev /*[K]*/, const double* delta_dev /*[K]*/,
-                    double typical_gamma, void* stream);
+                    const double* big_gamma_dev /*[K]*/, double typical_gamma, void* stream);
 /* 1 if an E-step over n_rows rows of this workspace can make use of gmmvb_set_drift (pruning is possible at all),
  * else 0: lets the caller skip computing the hint. */
 int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows);
+/* The parameters given next are unrelated to those of the last E-step (a new restart): the next gmmvb_estep does not
+ * assume that the responsibilities are still as sparse as they were and runs the dense kernel. */
+int gmmvb_forget(gmmvb_workspace* ws);
 
 /* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
  * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
  * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  *active_pairs = -1 when the
- * library was told not to count (GMMVB_MSTEP_SPARSE=0).  Synchronises the stream. */
+ * library did not count (GMMVB_MSTEP_SPARSE=0, tiny passes).  Waits for the E-step's counters (the one entry point
+ * besides gmmvb_profile_* that blocks; gmmvb_mstep blocks the same way right after a DENSE gmmvb_estep of N K >= 2^18,
+ * to choose between its dense and its list form). */
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs);
 
 #ifdef __cplusplus

@@ -269,10 +269,12 @@ def test_carried_bounds_pass():
     for eng in engines.values():
         eng.close()
     # the hint itself: gamma <= sigma_min(u_new u_old^-1) (checked against the SVD), tight to a few per cent
-    g, d = _kside.drift(qs[0], qs[1])
+    g, d, big = _kside.drift(qs[0], qs[1])
     a = torch.linalg.solve_triangular(qs[0].u, qs[1].u, upper=False, left=False)       # u_new u_old^-1
-    smin = torch.linalg.svdvals(a)[:, -1]
+    sv = torch.linalg.svdvals(a)
+    smin, smax = sv[:, -1], sv[:, 0]
     assert bool(torch.all(g <= smin)) and bool(torch.all(g >= 0.95 * smin))
+    assert bool(torch.all(big >= smax)) and bool(torch.all(big <= 1.08 * smax))
 
 
 def test_sparse_path_ill_conditioned_components():
