@@ -43,6 +43,7 @@ SYMBOLS = {
     "gmmvb_last_launch_info": (ctypes.c_char_p, [_vp]),
     "gmmvb_pass_counts": (_int, [_vp, ctypes.POINTER(_i64)]),
     "gmmvb_kside_factor": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "gmmvb_kside_drift": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_last_sparsity": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
@@ -62,6 +63,25 @@ class EngineUnavailableError(RuntimeError):
 
 class EngineError(RuntimeError):
     """A C-ABI call returned a non-zero status."""
+
+
+class EngineLimitError(ValueError):
+    """The model's shape is outside what this version of the engine supports (the reference has no such limit)."""
+
+
+MAX_DEGREE = 128          # include/gmmvb.h: 1 <= D <= 128 (8 feature tiles of 16)
+MAX_HMM_CLASSES = 64      # hmmvb_enable: K <= 64
+
+
+def check_limits(c_degree: int, c_num_classes: int = 1, hmm: bool = False):
+    """Raised at model construction, so that an unsupported shape does not surface as an EngineError from inside
+    update_posterior after the sample matrix has already been copied to the GPU."""
+    if c_degree > MAX_DEGREE:
+        raise EngineLimitError(f"bayesml_amd supports c_degree <= {MAX_DEGREE} in this version (got {c_degree}); "
+                               "bayesml itself has no such limit")
+    if hmm and c_num_classes > MAX_HMM_CLASSES:
+        raise EngineLimitError(f"bayesml_amd.hiddenmarkovnormal supports c_num_classes <= {MAX_HMM_CLASSES} in this "
+                               f"version (got {c_num_classes}); bayesml itself has no such limit")
 
 
 _lib = None
@@ -113,6 +133,25 @@ def kside_factor(w_inv: torch.Tensor):
         _check(lib, lib.gmmvb_kside_factor(K, D, w_inv.data_ptr(), g.data_ptr(), g_inv.data_ptr(), logdet.data_ptr(), st),
                "gmmvb_kside_factor")
     return g, g_inv, logdet
+
+
+def kside_drift(q_old, q_new, squarings: int, squarings_big: int):
+    """(gamma, delta, big_gamma) of the update q_old -> q_new on the GPU in one launch (gmmvb_kside_drift)."""
+    lib = load_library()
+    K, D = q_old.m.shape
+    dev = q_old.m.device
+    t = [x.contiguous() for x in (q_old.u, q_old.u_inv, q_old.m, q_new.u, q_new.u_inv, q_new.m)]
+    out = torch.empty(4, K, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        st = _vp(torch.cuda.current_stream(dev).cuda_stream)
+        _check(lib, lib.gmmvb_kside_drift(K, D, *(x.data_ptr() for x in t), int(squarings), int(squarings_big),
+                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), st),
+               "gmmvb_kside_drift")
+    # u_new u_old^-1 = I + E: 1 -/+ ||E|| bounds its extreme singular values, tightly once the components hardly move
+    e = out[3] * (1.0 + 1e-9)
+    gamma = torch.maximum(out[0], (1.0 - e) * (1.0 - 1e-9))
+    big = torch.minimum(out[2], (1.0 + e) * (1.0 + 1e-9))
+    return gamma, out[1], big
 
 
 class DataPass:

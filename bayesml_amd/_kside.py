@@ -150,8 +150,16 @@ def drift(q_old, q_new, squarings: int = 8, squarings_big: int = 6):
     loose).  (Bounds through A = alpha I + E were tried: the triangle inequality costs 15 % in the first iterations,
     where the singular values of A spread from 0.9 to 1.4.)  big_gamma only sets how far below the carried best value
     the E-step has to look, so it gets fewer squarings (4 % loose)."""
+    if q_old.u.is_cuda and q_old.m.shape[1] <= 128:
+        from ._engine import kside_drift             # the library's one-launch kernel (csrc/kside.hip)
+        return kside_drift(q_old, q_new, squarings, squarings_big)
     gamma = (1.0 - 1e-9) / _norm2_upper(q_old.u @ q_new.u_inv, squarings)
-    big = (1.0 + 1e-9) * _norm2_upper(q_new.u @ q_old.u_inv, squarings_big)
+    b = q_new.u @ q_old.u_inv
+    big = (1.0 + 1e-9) * _norm2_upper(b, squarings_big)
+    # u_new u_old^-1 = I + E: 1 -/+ ||E|| bounds its extreme singular values, tightly once the components hardly move
+    e = _norm2_upper(b - torch.eye(b.shape[-1], dtype=b.dtype, device=b.device), squarings) * (1.0 + 1e-9)
+    gamma = torch.maximum(gamma, (1.0 - e) * (1.0 - 1e-9))
+    big = torch.minimum(big, (1.0 + e) * (1.0 + 1e-9))
     d = (q_new.u @ (q_new.m - q_old.m)[:, :, None])[:, :, 0]
     delta = torch.linalg.vector_norm(d, dim=1) * (1.0 + 1e-9)
     # anything non-finite: no information (gamma = 0 makes every carried bound the trivial one, big_gamma = inf leaves

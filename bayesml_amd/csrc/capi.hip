@@ -183,7 +183,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart};
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan};
-    void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_R, ws->rec_exact, ws->rec_sel, ws->rec_flags};
+    void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -291,6 +291,8 @@ int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* 
     hipError_t e = hipMemcpyAsync(ws->drift, gamma_dev, kb, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + ws->K, delta_dev, kb, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + 3 * ws->K, big_gamma_dev, kb, hipMemcpyDeviceToDevice, st);
+    // the constants of the parameters the records belong to (the next gmmvb_set_params overwrites cvec)
+    if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + 2 * ws->K, ws->cvec, kb, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(drift)", e);
     ws->have_drift = ws->have_params && ws->params_used;     // else: not the parameters the records belong to
     return GMMVB_OK;
@@ -340,7 +342,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->opart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_k, (size_t)kRecSlots * np * sizeof(unsigned short));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_d, (size_t)kRecSlots * np * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_R, (size_t)np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_B, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_exact, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_sel, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_flags, (size_t)np);
@@ -496,9 +498,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (sparse_ok) {
             mode = kBound;
             bool carry = ws->rec_valid && same_rows && ws->have_drift && std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
-            // early in a fit the components still move by tens of per cent per iteration (mean gamma 0.3, 0.7, 0.87,
-            // 0.91, 0.94 ... at C3): carried distances shrink by gamma and leave a dozen candidates per sample
-            if (carry && ws->typical_gamma > 0.0 && ws->typical_gamma < 0.9) carry = false;
+            // early in a fit the components still move by tens of per cent per iteration (mean gamma 0.35, 0.72, 0.87,
+            // 0.91, 0.94, 0.95, 0.96, 0.97, 0.98 ... at C3): below ~0.975 most rest bounds fail after one carried pass
+            // and whole rows have to be evaluated (68 % of the rows at 0.94, 20 % at 0.96, 5 % at 0.98)
+            if (carry && ws->typical_gamma > 0.0 && ws->typical_gamma < 0.975) carry = false;
             if (carry && known && ws->lag_mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
@@ -507,7 +510,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
                 if (gpp * spare * 1.5 >= bound_cost) carry = false;
-                if (ws->lag_over > 0.10 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = false;
+                // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
+                // (x4 - x8 observed): stop carrying well before they dominate
+                if (ws->lag_over > 0.02 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = false;
             }
             if (carry && known && ws->lag_mode == kDense && ws->lag_act > 0.1 * pairs) carry = false;
             if (carry) mode = kCarry;
@@ -572,7 +577,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
     ws->n_spans = 0;
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
-    const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_R, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
+    const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
     bool counted = false;
     if (mode == kDense) {
         rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
@@ -841,9 +846,9 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
     const int64_t total = n_rows * ws->K;
     const bool hmm_gamma = ws->e_state == 3 && mode == 1;      // responsibilities of an HMM pass = gamma
     if (ws->e_state == 1 && ws->rec_live) {                    // the pass lived on records: only listed pairs are exact
-        const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_R, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
+        const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
         hipLaunchKernelGGL(rec_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec,
-                           ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out);
+                           ws->masks, ws->khat, ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out);
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return fail(GMMVB_EHIP, "rec_readout launch", er);
         return GMMVB_OK;

@@ -5,18 +5,23 @@
 // _calc_n_x_bar_s, bayesml/gaussianmixture/_gaussianmixture.py:772-784, 725-732).  The proof object per row n is
 //   up to C = 8 slots (k_j, d_j):   d_j <= || U_k (x_n - m_k) ||  (a lower bound of the whitened distance; for slots
 //                                   evaluated exactly in the last pass it is the distance itself, flagged "exact")
-//   one rest bound R:               R <= || U_k (x_n - m_k) ||  for EVERY component k that has no slot
+//   one rest bound B:               ln rho_nk <= B  for EVERY component k that has no slot
 // 55 bytes per row instead of the K x 8 bytes of a dense ln rho row.  A parameter update (m, U) -> (m', U') with
 //   gamma_k <= sigma_min(U'_k U_k^-1),  Gamma_k >= sigma_max(U'_k U_k^-1),  delta_k >= || U'_k (m'_k - m_k) ||
 // (gmmvb_set_drift) turns them into records for the new parameters without touching x:
-//   d'_j = (gamma_k d_j - delta_k)_+,  R' = (min_k gamma_k * R - max_k delta_k)_+,   upper bounds of ln rho':
-//   ub_j = c'_k - d'_j^2 / 2,  ub_rest = max_k c'_k - R'^2 / 2,  and for an exact slot a LOWER bound of the new value
-//   lb_j = c'_k - (Gamma_k d_j + delta_k)^2 / 2.
+//   d'_j = (gamma_k d_j - delta_k)_+  and the upper bound  ub_j = c'_k - d'_j^2 / 2  of the new ln rho;
+//   for a component without a slot B gives  || U_k (x - m_k) || >= sqrt(2 (c_k - B)_+) =: r_k, hence
+//   B' = max over those k of  c'_k - (gamma_k r_k - delta_k)_+^2 / 2   (K square roots per row, no memory traffic:
+//   every component keeps its own gamma, delta and constants - an aggregate over the components would be ruined by
+//   a single empty component, whose c is 170 above the others at the benchmark's shape);
+//   and for an exact slot a LOWER bound of the new value  lb_j = c'_k - (Gamma_k d_j + delta_k)^2 / 2.
 // With thr = max_j lb_j - 100 ln 2 (a lower bound of the row's best value, minus the 2^-100 margin):
 //   ub_j < thr    -> pair (n, k_j) is irrelevant this pass, nothing to compute;
 //   ub_j >= thr   -> the pair is a candidate: listed, evaluated exactly (f64 MFMA, estep_gather_dev_f64);
-//   ub_rest >= thr-> the rest bound has become too loose for this row: ALL K pairs of the row are evaluated exactly
-//                    ("overflow row") and its record is rebuilt from the exact values.
+//   a component without a slot whose own bound c'_k - (gamma_k r_k - delta_k)_+^2 / 2 is >= thr is listed as well
+//                    ("refreshed row": its exact value may win it a slot; B' = max over the components NOT listed);
+//   no exact slot at all (no lower bound of the best value), or more than 24 such components:
+//                    ALL K pairs of the row are evaluated exactly ("overflow row"), its record rebuilt from them.
 // Nothing here needs the host: lists, gather grid and statistics are sized on the device, so an E-step is a fixed
 // sequence of launches without a synchronisation.  The dense [K][npad] ln rho array stays the exchange buffer for
 // exact values (gather kernel -> rec_finish_kernel / M-step / read-outs); only listed entries of it are touched.
@@ -32,14 +37,16 @@ constexpr double k100Ln2 = 69.314718055994530942;
 struct RecArrays {
     unsigned short* k;      // [C][npad] component of slot j (kRecEmpty: unused)
     float* d;               // [C][npad] lower bound of the whitened distance, rounded towards zero
-    float* R;               // [npad] lower bound for every component without a slot (+inf: there is none)
+    float* B;               // [npad] upper bound of ln rho for every component without a slot (-inf: there is none)
     unsigned char* exact;   // [npad] bit j: d_j is the distance itself: d_j <= dist <= d_j (1 + 2^-22)
     unsigned char* sel;     // [npad] bit j: slot j was listed for exact evaluation in the current pass
-    unsigned char* flags;   // [npad] bit 0: overflow row of the current pass (all K pairs evaluated exactly)
+    unsigned char* flags;   // [npad] bit 0: overflow row of the current pass (all K pairs evaluated exactly);
+                            //        bit 1: refreshed row (components without a slot were listed too)
     int64_t npad;
 };
 
 __device__ __forceinline__ float f32_down(double v) { return __double2float_rd(v); }      // v >= 0: towards zero
+__device__ __forceinline__ float f32_up(double v) { return __double2float_ru(v); }
 
 // whitened distance (lower bound if v is an upper bound of ln rho) from a stored value; NaN -> 0 (always a candidate)
 __device__ __forceinline__ double dist_of(double c, double v) {
@@ -47,52 +54,56 @@ __device__ __forceinline__ double dist_of(double c, double v) {
     return q > 0.0 ? sqrt(q) : 0.0;
 }
 
-// sorted insertion of (cd, ck) into the ascending list ds[0..C] (C + 1 entries: the slots and the best of the rest)
-__device__ __forceinline__ void rec_insert(float (&ds)[kRecSlots + 1], unsigned short (&ks)[kRecSlots + 1], float cd,
-                                           unsigned short ck) {
+// Sorted insertion of (distance cd, component ck, value cv) into the ascending list of the C nearest components;
+// whatever falls off its end belongs to the rest, whose largest value is kept in `rest` (NaN sticks).
+__device__ __forceinline__ void rec_insert(float (&ds)[kRecSlots], unsigned short (&ks)[kRecSlots], float (&vs)[kRecSlots],
+                                           float& rest, float cd, unsigned short ck, float cv) {
 #pragma unroll
-    for (int j = 0; j <= kRecSlots; ++j) {
+    for (int j = 0; j < kRecSlots; ++j) {
         const bool lt = cd < ds[j];
-        const float td = lt ? ds[j] : cd;
+        const float td = lt ? ds[j] : cd, tv = lt ? vs[j] : cv;
         const unsigned short tk = lt ? ks[j] : ck;
         ds[j] = lt ? cd : ds[j];
+        vs[j] = lt ? cv : vs[j];
         ks[j] = lt ? ck : ks[j];
         cd = td;
+        cv = tv;
         ck = tk;
     }
+    if (ck != kRecEmpty) rest = (cv > rest || cv != cv) ? cv : rest;
 }
 
 // From a dense ln rho row (exact values and / or upper bounds under the parameters in force) to a record:
-// the C components of smallest distance get slots, R = the next distance.  GIVEN: khat[n] is the one pair known to
-// be exact (the bound pass evaluated it), it gets a slot and the exact flag; otherwise every value is exact (dense
-// pass), all slots are flagged and khat is not read.
+// the C components of smallest distance get slots, B = the largest value among the others.  GIVEN: khat[n] is the one
+// pair known to be exact (the bound pass evaluated it), it gets a slot and the exact flag; otherwise every value is
+// exact (dense pass), all slots are flagged and khat is not read.
 template <bool GIVEN>
 __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
                                                         int K, const double* __restrict__ cvec,
                                                         const int* __restrict__ khat, RecArrays rec) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= n_rows) return;
-    float ds[kRecSlots + 1];
-    unsigned short ks[kRecSlots + 1];
+    float ds[kRecSlots], vs[kRecSlots];
+    unsigned short ks[kRecSlots];
 #pragma unroll
-    for (int j = 0; j <= kRecSlots; ++j) {
+    for (int j = 0; j < kRecSlots; ++j) {
         ds[j] = __builtin_huge_valf();
+        vs[j] = -__builtin_huge_valf();
         ks[j] = kRecEmpty;
     }
-    for (int k = 0; k < K; ++k) rec_insert(ds, ks, f32_down(dist_of(cvec[k], lnrho[(int64_t)k * npad + n])), (unsigned short)k);
-    float R = ds[kRecSlots];
+    float rest = -__builtin_huge_valf();
+    const int kb = GIVEN ? khat[n] : -1;
+    for (int k = 0; k < K; ++k) {
+        if (GIVEN && k == kb) continue;
+        const double v = lnrho[(int64_t)k * npad + n];
+        rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], v)), (unsigned short)k, f32_up(v));
+    }
     unsigned ex = 0;
-    if (GIVEN) {
-        const int kb = khat[n];
-        int at = -1;
-#pragma unroll
-        for (int j = 0; j < kRecSlots; ++j) at = (ks[j] == kb) ? j : at;
-        if (at < 0) {          // the exact pair is not among the C nearest: it takes the last slot, which joins the rest
-            at = kRecSlots - 1;
-            R = ds[at] < R ? ds[at] : R;
-            ks[at] = (unsigned short)kb;
-            ds[at] = f32_down(dist_of(cvec[kb], lnrho[(int64_t)kb * npad + n]));
-        }
+    if (GIVEN) {               // the exact pair takes the last slot; what was there joins the rest
+        const int at = kRecSlots - 1;
+        if (ks[at] != kRecEmpty) rest = (vs[at] > rest || vs[at] != vs[at]) ? vs[at] : rest;
+        ks[at] = (unsigned short)kb;
+        ds[at] = f32_down(dist_of(cvec[kb], lnrho[(int64_t)kb * npad + n]));
         ex = 1u << at;
     } else {
 #pragma unroll
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
         rec.k[(int64_t)j * rec.npad + n] = ks[j];
         rec.d[(int64_t)j * rec.npad + n] = ds[j];
     }
-    rec.R[n] = R;
+    rec.B[n] = rest;
     rec.exact[n] = (unsigned char)ex;
     rec.sel[n] = 0;
     rec.flags[n] = 0;
@@ -121,8 +132,8 @@ __device__ __forceinline__ void count_word(unsigned long long mk, int w, int wav
 }
 
 // Carry the records over a parameter update and select this pass's candidates (header comment).
-// drift = [gamma K | delta K | (unused K) | Gamma K]; IDENT: no update happened (the records were just built from a
-// bound pass): gamma = Gamma = 1, delta = 0, and exact slots are already evaluated (never listed again).
+// drift = [gamma K | delta K | c of the last E-step K | Gamma K]; IDENT: no update happened (the records were just built
+// from a bound pass): gamma = Gamma = 1, delta = 0, c_old = c_new, and exact slots are already evaluated (never listed again).
 // Outputs: masks (candidate components per row, all K for overflow rows), per-block counts for scan_counts /
 // fill_lists, epart[block] = listed pairs, opart[block] = overflow rows.
 template <bool IDENT>
@@ -133,44 +144,19 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
                                                               int* __restrict__ blk_cnt, double* __restrict__ epart,
                                                               double* __restrict__ opart) {
     __shared__ int wcnt[4][256];
-    __shared__ double sg[256], sdl[256], sG[256], sc[256];
-    __shared__ double sred[3][4];
+    __shared__ double sg[256], sdl[256], sG[256], sc[256], sco[256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
     for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
-    double gmin = __builtin_huge_val(), dmax = 0.0, cmax = -__builtin_huge_val();
     for (int k = tid; k < K; k += kSelRows) {
-        const double g = IDENT ? 1.0 : drift[k], dl = IDENT ? 0.0 : drift[K + k], G = IDENT ? 1.0 : drift[3 * K + k];
-        const double c = c_new[k];
-        sg[k] = g;
-        sdl[k] = dl;
-        sG[k] = G;
-        sc[k] = c;
-        gmin = (g < gmin || g != g) ? g : gmin;          // NaN wins: every rest bound becomes useless, rows overflow
-        dmax = (dl > dmax || dl != dl) ? dl : dmax;
-        cmax = (c > cmax || c != c) ? c : cmax;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_xor(gmin, o), b = __shfl_xor(dmax, o), c = __shfl_xor(cmax, o);
-        gmin = (a < gmin || a != a) ? a : gmin;
-        dmax = (b > dmax || b != b) ? b : dmax;
-        cmax = (c > cmax || c != c) ? c : cmax;
-    }
-    if ((tid & 63) == 0) {
-        sred[0][wave] = gmin;
-        sred[1][wave] = dmax;
-        sred[2][wave] = cmax;
+        sg[k] = IDENT ? 1.0 : drift[k];
+        sdl[k] = IDENT ? 0.0 : drift[K + k];
+        sG[k] = IDENT ? 1.0 : drift[3 * K + k];
+        sc[k] = c_new[k];
+        sco[k] = IDENT ? c_new[k] : drift[2 * K + k];
     }
     __syncthreads();
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const double a = sred[0][v], b = sred[1][v], c = sred[2][v];
-        gmin = (a < gmin || a != a) ? a : gmin;
-        dmax = (b > dmax || b != b) ? b : dmax;
-        cmax = (c > cmax || c != c) ? c : cmax;
-    }
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
     const bool valid = n < n_rows;
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
@@ -200,36 +186,56 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
                 lb = l > lb ? l : lb;                                // NaN never raises the threshold
             }
         }
-        const float R = rec.R[n];
-        double rest_ub = ninf;
-        if (R < __builtin_huge_valf() || R != R) {                  // there are components without a slot
-            double y = gmin * (double)R * (1.0 - 1e-12) - dmax;
-            y = y > 0.0 ? y : 0.0;
-            const float yf = f32_down(y);
-            rest_ub = cmax - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(cmax);
-            if (!IDENT) rec.R[n] = yf;
-        }
         const double thr = lb - k100Ln2;
-        const bool over = !(rest_ub < thr);                          // also: no exact slot (lb = -inf), any NaN
         unsigned sel = 0;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            if (kk[j] == kRecEmpty) continue;
+            if (IDENT && ((ex >> j) & 1u)) continue;                 // already exact under these parameters
+            if (!(ub[j] < thr)) {
+                sel |= 1u << j;
+                mk[kk[j] >> 6] |= 1ull << (kk[j] & 63);
+                ++listed;
+            }
+        }
+        // every component without a slot: from ln rho_k <= B under the old parameters to a bound under the new ones;
+        // those whose bound is not good enough are listed too, the others define the new B
+        const double B = (double)rec.B[n];
+        bool over = !(lb > ninf);                                    // no exact slot: nothing to compare with
+        int extra = 0;
+        if (!over && (B > ninf || B != B)) {
+            unsigned long long inslot[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+            for (int j = 0; j < kRecSlots; ++j)
+                if (kk[j] != kRecEmpty) inslot[kk[j] >> 6] |= 1ull << (kk[j] & 63);
+            double keep = ninf;
+            for (int k = 0; k < K; ++k) {
+                if ((inslot[k >> 6] >> (k & 63)) & 1ull) continue;
+                const double q = 2.0 * (sco[k] - B);
+                const double r = q > 0.0 ? sqrt(q) : 0.0;                    // also NaN -> 0
+                double y = sg[k] * r * (1.0 - 1e-12) - sdl[k];
+                y = y > 0.0 ? y : 0.0;
+                const double c = sc[k];
+                const double f = c - 0.5 * y * y * (1.0 - 1e-12) + 1e-12 * fabs(c);
+                if (f < thr) {
+                    keep = f > keep ? f : keep;
+                } else {                                                     // also NaN
+                    mk[k >> 6] |= 1ull << (k & 63);
+                    ++extra;
+                }
+            }
+            rec.B[n] = f32_up(keep);
+            over = extra > 24;
+        }
+        listed += extra;
         if (over) {
             for (int w = 0; w < W; ++w) mk[w] = (K - 64 * w >= 64) ? ~0ull : ((1ull << (K - 64 * w)) - 1ull);
             listed = K;
             over_i = 1;
-        } else {
-#pragma unroll
-            for (int j = 0; j < kRecSlots; ++j) {
-                if (kk[j] == kRecEmpty) continue;
-                if (IDENT && ((ex >> j) & 1u)) continue;             // already exact under these parameters
-                if (!(ub[j] < thr)) {
-                    sel |= 1u << j;
-                    mk[kk[j] >> 6] |= 1ull << (kk[j] & 63);
-                    ++listed;
-                }
-            }
+            sel = 0;
         }
         rec.sel[n] = (unsigned char)sel;
-        rec.flags[n] = (unsigned char)(over ? 1 : 0);
+        rec.flags[n] = (unsigned char)(over ? 1 : (extra > 0 ? 2 : 0));
         if (!IDENT) rec.exact[n] = 0;          // carried distances are one-sided until the pair is evaluated again
         for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
     }
@@ -280,7 +286,86 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     const bool valid = n < n_rows;
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
     int active = 0;
-    if (valid && !(rec.flags[n] & 1)) {
+    const unsigned fl = valid ? rec.flags[n] : 0u;
+    if (valid && fl == 2u) {
+        // refreshed row: slots (exact where listed, carried bounds otherwise) and the listed components without a slot
+        // compete for the C slots again; what does not get one joins the rest bound (B holds the unlisted ones already)
+        const unsigned live = (unsigned)rec.sel[n] | (unsigned)rec.exact[n];
+        float ds[kRecSlots], vs[kRecSlots];
+        unsigned short ks[kRecSlots];
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            ds[j] = __builtin_huge_valf();
+            vs[j] = -__builtin_huge_valf();
+            ks[j] = kRecEmpty;
+        }
+        float rest = rec.B[n];
+        unsigned long long cand[4] = {0ull, 0ull, 0ull, 0ull}, ev[4] = {0ull, 0ull, 0ull, 0ull};
+        for (int w = 0; w < W; ++w) cand[w] = masks[(int64_t)w * npad + n];
+        double mx = -__builtin_huge_val(), ssum = 0.0;
+        int arg = 0x7fffffff;
+        bool nan = false;
+        auto take_exact = [&](int k) {
+            const double x = lnrho[(int64_t)k * npad + n];
+            ev[k >> 6] |= 1ull << (k & 63);
+            nan = nan || x != x;
+            if (x > mx) {
+                ssum = fma(ssum, exp(mx - x), 1.0);
+                arg = k;
+                mx = x;
+            } else {
+                if (x == mx && k < arg) arg = k;
+                ssum += exp(x - mx);
+            }
+            rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], x)), (unsigned short)(k | 0x8000), f32_up(x));
+        };
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            const unsigned short k = rec.k[(int64_t)j * rec.npad + n];
+            if (k == kRecEmpty) continue;
+            cand[k >> 6] &= ~(1ull << (k & 63));
+            if ((live >> j) & 1u) {
+                take_exact(k);
+            } else {
+                const float d = rec.d[(int64_t)j * rec.npad + n];
+                rec_insert(ds, ks, vs, rest, d, k, f32_up(cvec[k] - 0.5 * (double)d * (double)d));
+            }
+        }
+        for (int w = 0; w < W; ++w) {
+            unsigned long long m = cand[w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                take_exact(64 * w + b);
+            }
+        }
+        double l = mx + log(ssum);
+        if (nan) l = __builtin_nan("");
+        lse[n] = l;
+        khat[n] = arg == 0x7fffffff ? 0 : arg;
+        unsigned ex = 0;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            const bool e1 = ks[j] != kRecEmpty && (ks[j] & 0x8000);
+            rec.k[(int64_t)j * rec.npad + n] = ks[j] == kRecEmpty ? kRecEmpty : (unsigned short)(ks[j] & 0x7fff);
+            rec.d[(int64_t)j * rec.npad + n] = ds[j];
+            ex |= e1 ? (1u << j) : 0u;
+        }
+        rec.B[n] = rest;
+        rec.exact[n] = (unsigned char)ex;
+        for (int w = 0; w < W; ++w) {
+            unsigned long long m = ev[w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const double t = lnrho[(int64_t)(64 * w + b) * npad + n] - l;
+                if (!(t < -k100Ln2)) {
+                    mk[w] |= 1ull << b;
+                    ++active;
+                }
+            }
+        }
+    } else if (valid && fl == 0u) {
         unsigned live = (unsigned)rec.sel[n] | (unsigned)rec.exact[n];
         double v[kRecSlots];
         unsigned short kk[kRecSlots];
@@ -322,20 +407,22 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
             }
         }
     } else if (valid) {
-        // overflow row: every value of the dense row is exact.  One sweep: running max / sum and the C + 1 nearest
-        float ds[kRecSlots + 1];
-        unsigned short ks[kRecSlots + 1];
+        // overflow row: every value of the dense row is exact.  One sweep: running max / sum and the C nearest
+        float ds[kRecSlots], vs[kRecSlots];
+        unsigned short ks[kRecSlots];
 #pragma unroll
-        for (int j = 0; j <= kRecSlots; ++j) {
+        for (int j = 0; j < kRecSlots; ++j) {
             ds[j] = __builtin_huge_valf();
+            vs[j] = -__builtin_huge_valf();
             ks[j] = kRecEmpty;
         }
+        float rest = -__builtin_huge_valf();
         double mx = lnrho[n], s = 1.0;
         int arg = 0;
-        rec_insert(ds, ks, f32_down(dist_of(cvec[0], mx)), 0);
+        rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[0], mx)), 0, f32_up(mx));
         for (int k = 1; k < K; ++k) {
             const double x = lnrho[(int64_t)k * npad + n];
-            rec_insert(ds, ks, f32_down(dist_of(cvec[k], x)), (unsigned short)k);
+            rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], x)), (unsigned short)k, f32_up(x));
             if (x > mx) {
                 s = fma(s, exp(mx - x), 1.0);
                 mx = x;
@@ -354,7 +441,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
             rec.d[(int64_t)j * rec.npad + n] = ds[j];
             ex |= (ks[j] != kRecEmpty) ? (1u << j) : 0u;
         }
-        rec.R[n] = ds[kRecSlots];
+        rec.B[n] = rest;
         rec.exact[n] = (unsigned char)ex;
         rec.sel[n] = (unsigned char)ex;
         for (int k = 0; k < K; ++k) {
@@ -396,33 +483,42 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict
     }
 }
 
-// Read-outs of a pass that lived on records.  mode 0: ln rho (exact for evaluated pairs, otherwise the record's upper
-// bound - at least 100 ln 2 below the row's best); mode 1: responsibilities (exactly 0 for pruned pairs: < 2^-100).
-__global__ void rec_readout_kernel(RecArrays rec, const double* __restrict__ lnrho, const double* __restrict__ lse,
+// Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-100) marks the pairs
+// whose exact value is in the dense array.  mode 0: ln rho - exact for active pairs and for exact slots, otherwise the
+// record's upper bound (at least 100 ln 2 below the row's best); mode 1: responsibilities, exactly 0 for inactive pairs.
+__global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __restrict__ masks,
+                                   const int* __restrict__ khat, const double* __restrict__ lnrho,
+                                   const double* __restrict__ lse,
                                    const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
                                    int mode, double* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rows * K) return;
     const int64_t n = row0 + e / K;
     const int k = (int)(e % K);
-    bool exact = (rec.flags[n] & 1) != 0;
-    double bound = (double)rec.R[n];
+    bool exact = ((masks[(int64_t)(k >> 6) * npad + n] >> (k & 63)) & 1ull) != 0 || (rec.flags[n] & 1) != 0;
+    if (mode == 1) {
+        out[e] = exact ? exp(lnrho[(int64_t)k * npad + n] - lse[n]) : 0.0;
+        return;
+    }
+    double ub = (double)rec.B[n];
     if (!exact) {
         const unsigned live = rec.exact[n];
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
             if (rec.k[(int64_t)j * rec.npad + n] == k) {
                 exact = (live >> j) & 1u;
-                bound = (double)rec.d[(int64_t)j * rec.npad + n];
+                const double d = (double)rec.d[(int64_t)j * rec.npad + n];
+                ub = cvec[k] - 0.5 * d * d;
             }
         }
     }
-    if (exact) {
-        const double v = lnrho[(int64_t)k * npad + n];
-        out[e] = mode == 0 ? v : exp(v - lse[n]);
-    } else {
-        out[e] = mode == 0 ? cvec[k] - 0.5 * bound * bound : 0.0;
+    if (!exact) {
+        // every pair that is not active lies at least 100 ln 2 below the row's best value (evaluated and found so, or
+        // proven so by its bound): B alone may be the value of a ninth near component
+        const double cap = lnrho[(int64_t)khat[n] * npad + n] - k100Ln2;
+        ub = cap < ub ? cap : ub;
     }
+    out[e] = exact ? lnrho[(int64_t)k * npad + n] : ub;
 }
 
 }  // namespace gmmvb

@@ -32,7 +32,7 @@ struct gmmvb_workspace {
     int tb_seen[5] = {0, 0, 0, 0, 0};
     // carrying the E-step over a parameter update (gmmvb_set_drift, records.h): gamma / delta / Gamma of the pending
     // update, whether the records belong to the parameters of the last E-step on `bounds_rows` rows of `bounds_x`
-    double* drift = nullptr;           // [4][K]: gamma, delta, (unused), Gamma
+    double* drift = nullptr;           // [4][K]: gamma, delta, c of the last E-step, Gamma
     bool have_drift = false;
     double typical_gamma = -1.0;       // mean gamma of the pending update if the caller knew it (<= 0: unknown)
     bool params_used = false;          // the parameters in force were the ones of the last E-step
@@ -43,7 +43,7 @@ struct gmmvb_workspace {
     // per-row candidate records (records.h), allocated with the sample lists
     unsigned short* rec_k = nullptr;   // [8][npad]
     float* rec_d = nullptr;            // [8][npad]
-    float* rec_R = nullptr;            // [npad]
+    float* rec_B = nullptr;            // [npad]
     unsigned char* rec_exact = nullptr, *rec_sel = nullptr, *rec_flags = nullptr;   // [npad] each
     bool rec_valid = false;            // the records describe the last E-step's parameters on bounds_rows rows
     bool rec_live = false;             // the last E-step lived on records (read-outs go through them)

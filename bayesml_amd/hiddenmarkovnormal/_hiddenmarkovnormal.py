@@ -174,6 +174,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
                  h0_kappas=None, h0_nus=None, h0_w_mats=None, seed=None, device=None, verbose=True):
         self.c_degree = _check.pos_int(c_degree, "c_degree", ParameterFormatError)
         self.c_num_classes = _check.pos_int(c_num_classes, "c_num_classes", ParameterFormatError)
+        from .._engine import check_limits
+        check_limits(self.c_degree, self.c_num_classes, hmm=True)
         self.rng = np.random.default_rng(seed)
         self._device, self._comm, self._verbose = device, SingleProcess(), verbose
         self._data_pass_factory = None          # test seam only (see gaussianmixture.LearnModel)

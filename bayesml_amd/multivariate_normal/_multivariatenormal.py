@@ -114,6 +114,8 @@ class LearnModel(base.Posterior, base.PredictiveMixin):
 
     def __init__(self, c_degree, h0_m_vec=None, h0_kappa=1.0, h0_nu=None, h0_w_mat=None, *, device=None):
         self.c_degree = _check.pos_int(c_degree, "c_degree", ParameterFormatError)
+        from .._engine import check_limits
+        check_limits(self.c_degree)
         D = self.c_degree
         self._device = device
         self._engine = None

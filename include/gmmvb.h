@@ -162,6 +162,17 @@ const char* gmmvb_last_launch_info(const gmmvb_workspace* ws);
 int gmmvb_kside_factor(int K, int D, const double* w_inv_dev /*[K][D][D]*/, double* g_dev /*[K][D][D]*/,
                        double* g_inv_dev /*[K][D][D]*/, double* logdet_dev /*[K]*/, void* stream);
 
+/* The drift hint of gmmvb_set_drift for the update (m_old, u_old) -> (m_new, u_new) of K components, in one launch:
+ * gamma = 1 / ub(|| u_old u_new^-1 ||_2), big_gamma = ub(|| u_new u_old^-1 ||_2), delta = || u_new (m_new - m_old) ||, where
+ * ub is the rigorous upper bound || (A^T A)^(2^s) ||_F^(1/2^(s+1)) (s = squarings resp. squarings_big repeated
+ * squarings; at most D^(1/2^(s+1)) above the true norm), and enorm = ub(|| u_new u_old^-1 - I ||_2): the caller may
+ * sharpen the hint to gamma = max(gamma, 1 - enorm), big_gamma = min(big_gamma, 1 + enorm), which is far tighter once
+ * the components hardly move.  u, u^-1: [K][D][D] row-major (lower triangular); D <= 128. */
+int gmmvb_kside_drift(int K, int D, const double* u_old_dev, const double* uinv_old_dev, const double* m_old_dev,
+                      const double* u_new_dev, const double* uinv_new_dev, const double* m_new_dev, int squarings,
+                      int squarings_big, double* gamma_dev /*[K]*/, double* delta_dev /*[K]*/,
+                      double* big_gamma_dev /*[K]*/, double* enorm_dev /*[K]*/, void* stream);
+
 /* Which kernels have run in this workspace since it was created (for tests and profiling reports):
  *   out[0] dense E-steps, out[1] bound passes of the pruned E-step, out[2] E-steps on carried bounds, out[3] pruned
  *   E-steps that fell back to the dense kernel, out[4] carried passes that had to bound afresh, out[5] dense M-steps,

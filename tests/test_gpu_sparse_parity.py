@@ -92,7 +92,7 @@ def test_small_fixture_forced_sparse_matches_reference(variant):
     g = load_golden("gmm_f3_k8_d128_n32768_f32.npz")
     x = orc.synth_gmm(8, 128, 32768, np.float32)
     m, counts, trace = run_driver(g, x, variant)
-    expect_kernels(counts, variant, lists=False)       # 8 broad components: more than 35 % of the pairs stay active
+    expect_kernels(counts, variant, min_carried=0, lists=False)   # 8 broad components: over 35 % of the pairs stay active
     check_trace(trace, g, 1e-8)
     hn = m.get_hn_params()
     for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
