@@ -15,10 +15,15 @@ import torch.distributed as dist
 class RowShard:
     """Describes which rows of the global sample matrix this process holds."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, native: bool = False):
+        """``native=True``: the per-iteration all-reduce of the statistics block goes through the library's own RCCL
+        communicator (C ABI ``gmmvb_allreduce_stats``, bootstrapped over the process group) instead of
+        ``torch.distributed.all_reduce``; everything else (row counts, sub-sample moments) stays on the group."""
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
         self.group = group
+        self.native = native
+        self._rccl = None
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.row_offset = 0
@@ -38,6 +43,11 @@ class RowShard:
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         """In-place sum over ranks of a contiguous f64 tensor (the per-iteration collective)."""
+        if self.native and t.is_cuda:
+            if self._rccl is None:
+                from ._engine import RcclComm
+                self._rccl = RcclComm(self.rank, self.world, t.device)
+            return self._rccl.all_reduce_(t)
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t

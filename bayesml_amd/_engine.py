@@ -45,6 +45,10 @@ SYMBOLS = {
     "gmmvb_kside_factor": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_kside_drift": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_last_sparsity": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "gmmvb_comm_unique_id": (_int, [_vp]),
+    "gmmvb_comm_create": (_int, [_vp, _int, _int, ctypes.POINTER(_vp)]),
+    "gmmvb_comm_destroy": (_int, [_vp]),
+    "gmmvb_allreduce_stats": (_int, [_vp, _vp, _i64, _vp]),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
     "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -117,6 +121,47 @@ def _f64(t: torch.Tensor, shape, device) -> torch.Tensor:
     if tuple(t.shape) != tuple(shape):
         raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
     return t
+
+
+class RcclComm:
+    """The C ABI's row-shard communicator (gmmvb_comm_*): RCCL all-reduce of the statistics block, enqueued on the
+    current torch stream.  ``bootstrap`` hands rank 0's 128-byte id to the other ranks; by default it is a
+    ``torch.distributed`` broadcast over the default process group (any backend)."""
+
+    def __init__(self, rank: int, world: int, device, bootstrap=None):
+        self.lib = load_library()
+        self.device = torch.device(device)
+        buf = (ctypes.c_ubyte * 128)()
+        if rank == 0:
+            _check(self.lib, self.lib.gmmvb_comm_unique_id(buf), "gmmvb_comm_unique_id")
+        if bootstrap is None:
+            import torch.distributed as dist
+            t = torch.tensor(list(buf), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.to(self.device)
+            dist.broadcast(t, src=0)
+            raw = bytes(t.cpu().tolist())
+        else:
+            raw = bootstrap(bytes(buf))
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(raw)
+        handle = _vp()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_comm_create(buf, int(world), int(rank), ctypes.byref(handle)), "gmmvb_comm_create")
+        self._comm = handle
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.device:
+            raise ValueError("the statistics block must be a contiguous float64 tensor on the communicator's device")
+        with torch.cuda.device(self.device):
+            st = _vp(torch.cuda.current_stream(self.device).cuda_stream)
+            _check(self.lib, self.lib.gmmvb_allreduce_stats(self._comm, t.data_ptr(), t.numel(), st), "gmmvb_allreduce_stats")
+        return t
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.gmmvb_comm_destroy(self._comm)
+            self._comm = None
 
 
 def kside_factor(w_inv: torch.Tensor):
@@ -211,7 +256,7 @@ class DataPass:
         s = self.lib.gmmvb_last_launch_info(self._ws)
         return s.decode() if s else ""
 
-    PASS_NAMES = ("estep_dense", "estep_bound", "estep_carried", "estep_fell_back_dense", "estep_rebound",
+    PASS_NAMES = ("estep_dense", "estep_bound", "estep_carried", "estep_fell_back_dense", "estep_sweep",
                   "mstep_dense", "mstep_list", "estep_gather")
 
     def pass_counts(self) -> dict:

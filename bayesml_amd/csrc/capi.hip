@@ -408,6 +408,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     if (rc) return rc;
     ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
     ws->rec_valid = false;
+    ws->dense_valid = false;
     ws->lag_valid = false;
     if (!ws->xc) return GMMVB_OK;      // disabled: the M-step reads x directly
     const int Dp = 16 * ws->T;
@@ -485,7 +486,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // last E-step whose copy has arrived (they lag by one pass when the caller never synchronises; results do not
     // depend on the choice, only the time does).
     poll_counters(ws);
-    enum { kDense = 0, kBound = 1, kCarry = 2 };
+    enum { kDense = 0, kBound = 1, kCarry = 2, kSweep = 3 };
     int mode = kDense;
     const bool can_prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr && ws->rec_k != nullptr;
     const bool big = ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23);
@@ -497,25 +498,31 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (!sparse_ok && known && !ws->forget) sparse_ok = ws->lag_act <= 0.5 * pairs;
         if (sparse_ok) {
             mode = kBound;
-            bool carry = ws->rec_valid && same_rows && ws->have_drift && std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
-            // early in a fit the components still move by tens of per cent per iteration (mean gamma 0.35, 0.72, 0.87,
-            // 0.91, 0.94, 0.95, 0.96, 0.97, 0.98 ... at C3): below ~0.975 most rest bounds fail after one carried pass
-            // and whole rows have to be evaluated (68 % of the rows at 0.94, 20 % at 0.96, 5 % at 0.98)
-            if (carry && ws->typical_gamma > 0.0 && ws->typical_gamma < 0.975) carry = false;
-            if (carry && known && ws->lag_mode != kDense) {
+            const bool hinted = same_rows && ws->have_drift && std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
+            // Two ways of carrying the previous pass over the parameter update (gmmvb_set_drift):
+            //   records (records.h)  55 bytes per row, one aggregate bound for the components without a slot: tight once
+            //                        the components hardly move (mean gamma >= 0.975: at C3 from the 8th iteration on);
+            //   dense sweep          every entry of the ln rho array carried with its own component's drift: one sweep
+            //                        of the array (2.5 ms at C3), robust while the components still move by per cents
+            //                        (mean gamma 0.35, 0.72, 0.87, 0.91, 0.94, 0.95, 0.96, 0.97 ... over the iterations).
+            const double tg = ws->typical_gamma;
+            bool carry = hinted && ws->rec_valid && !(tg > 0.0 && tg < 0.975);
+            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.6) && ws->sweeps < 8;
+            if ((carry || sweep) && known && ws->lag_mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
                 const double spare = std::max(0.0, ws->lag_eval - ws->lag_act) / pairs;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
-                if (gpp * spare * 1.5 >= bound_cost) carry = false;
+                if (gpp * spare * 2.5 >= bound_cost) carry = sweep = false;
                 // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
                 // (x4 - x8 observed): stop carrying well before they dominate
-                if (ws->lag_over > 0.02 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = false;
+                if (ws->lag_over > 0.02 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = sweep = false;
             }
-            if (carry && known && ws->lag_mode == kDense && ws->lag_act > 0.1 * pairs) carry = false;
+            if ((carry || sweep) && known && ws->lag_mode == kDense && ws->lag_act > 0.1 * pairs) carry = sweep = false;
             if (carry) mode = kCarry;
+            else if (sweep) mode = kSweep;
             // a bound pass that left most pairs candidates (the parameters jumped): back to the dense kernel
             if (mode == kBound && ws->prune != 2 && known && ws->lag_mode == kBound && ws->lag_eval > 0.6 * pairs) {
                 mode = kDense;
@@ -654,6 +661,16 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             hipLaunchKernelGGL(rec_select_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
                                ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart);
             span_end(ws, st);
+        } else if (mode == kSweep) {
+            rpw = kSelRows;
+            grid = sel_grid;
+            name = "estep_sweep_bounds";
+            ++ws->passes[4];
+            ++ws->sweeps;
+            span_begin(ws, kSpanSelect, st);
+            hipLaunchKernelGGL(rec_sweep_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                               ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
+            span_end(ws, st);
         } else {
             rpw = kSelRows;
             grid = sel_grid;
@@ -706,6 +723,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->bounds_x = x_dev;
     ws->bounds_ldx = ldx;
     ws->prev_pass = mode;
+    // the dense array holds a value or bound under the parameters in force for EVERY pair after a dense pass, a bound
+    // pass or a sweep; a pass on records only refreshes the listed entries
+    ws->dense_valid = mode != kCarry;
+    if (mode == kDense || mode == kBound) ws->sweeps = 0;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
                   (i8 || mode != kDense) ? 512 : estep_threads(ws->estep_variant), rpw);
     return GMMVB_OK;
@@ -724,6 +745,7 @@ int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_
     ws->n_spans = 0;
     ws->bounds_rows = 0;               // the array holds responsibilities now, nothing a later E-step may carry over
     ws->rec_valid = false;
+    ws->dense_valid = false;
     ws->rec_live = false;
     ws->act_rows = 0;
     return GMMVB_OK;
@@ -848,7 +870,7 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
     if (ws->e_state == 1 && ws->rec_live) {                    // the pass lived on records: only listed pairs are exact
         const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
         hipLaunchKernelGGL(rec_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec,
-                           ws->masks, ws->khat, ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out);
+                           ws->masks, ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out);
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return fail(GMMVB_EHIP, "rec_readout launch", er);
         return GMMVB_OK;

@@ -32,6 +32,7 @@ namespace gmmvb {
 
 constexpr int kRecSlots = 8;
 constexpr unsigned short kRecEmpty = 0xFFFF;
+constexpr unsigned short kRecListed = 0x4000, kRecExactBit = 0x8000, kRecCompMask = 0x3FFF;
 constexpr double k100Ln2 = 69.314718055994530942;
 
 struct RecArrays {
@@ -55,7 +56,9 @@ __device__ __forceinline__ double dist_of(double c, double v) {
 }
 
 // Sorted insertion of (distance cd, component ck, value cv) into the ascending list of the C nearest components;
-// whatever falls off its end belongs to the rest, whose largest value is kept in `rest` (NaN sticks).
+// whatever falls off its end belongs to the rest, whose largest value is kept in `rest` (NaN sticks) - unless it is
+// marked kRecListed (it is being evaluated exactly in this pass and will compete for a slot again in rec_finish_kernel).
+// Component codes: bits 0..13 the component, kRecListed, kRecExactBit (value is exact).
 __device__ __forceinline__ void rec_insert(float (&ds)[kRecSlots], unsigned short (&ks)[kRecSlots], float (&vs)[kRecSlots],
                                            float& rest, float cd, unsigned short ck, float cv) {
 #pragma unroll
@@ -70,7 +73,7 @@ __device__ __forceinline__ void rec_insert(float (&ds)[kRecSlots], unsigned shor
         cv = tv;
         ck = tk;
     }
-    if (ck != kRecEmpty) rest = (cv > rest || cv != cv) ? cv : rest;
+    if (ck != kRecEmpty && !(ck & kRecListed)) rest = (cv > rest || cv != cv) ? cv : rest;
 }
 
 // From a dense ln rho row (exact values and / or upper bounds under the parameters in force) to a record:
@@ -258,6 +261,110 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
     }
 }
 
+// The early-regime form of the carried E-step: while the components still move by several per cent per iteration the
+// single rest bound of a record is too coarse (most rows would have to be re-evaluated in full), but the dense ln rho
+// array still holds, for EVERY pair, a value or upper bound under the previous parameters.  One sweep over it
+//   carries every entry over the update with its own component's (gamma, delta):  u' = c'_k - (gamma_k d - delta_k)_+^2 / 2,
+//     d = sqrt(2 (c_k - u)_+), and writes it back (the array stays valid for the next sweep);
+//   takes the row's previous best component (exact in the last pass) for the lower bound lb of the new best value;
+//   lists every pair with u' >= lb - 100 ln 2, and builds the row's record (C nearest components + rest bound) on the way,
+// so that the pass continues exactly like one on records (gather -> rec_finish_kernel) and later passes can switch to them.
+__global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict__ u, int64_t npad, int64_t n_rows, int K,
+                                                             const double* __restrict__ drift,
+                                                             const double* __restrict__ c_new,
+                                                             const int* __restrict__ khat, RecArrays rec,
+                                                             unsigned long long* __restrict__ masks,
+                                                             int* __restrict__ blk_cnt, double* __restrict__ epart,
+                                                             double* __restrict__ opart) {
+    __shared__ int wcnt[4][256];
+    __shared__ double sg[256], sdl[256], sG[256], sc[256], sco[256];
+    __shared__ int wsum[2][4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int W = (K + 63) / 64;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    for (int k = tid; k < K; k += kSelRows) {
+        sg[k] = drift[k];
+        sdl[k] = drift[K + k];
+        sG[k] = drift[3 * K + k];
+        sc[k] = c_new[k];
+        sco[k] = drift[2 * K + k];
+    }
+    __syncthreads();
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
+    const bool valid = n < n_rows;
+    unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+    int listed = 0, over_i = 0;
+    if (valid) {
+        const double ninf = -__builtin_huge_val();
+        const int kb = khat[n];
+        double thr = ninf;
+        {
+            const double d = dist_of(sco[kb], u[(int64_t)kb * npad + n]);
+            const double du = sG[kb] * d * (1.0 + 1e-12) + sdl[kb];
+            const double lb = sc[kb] - 0.5 * du * du * (1.0 + 1e-12) - 1e-12 * fabs(sc[kb]);
+            thr = lb - k100Ln2;
+        }
+        const bool over = !(thr > ninf);                       // NaN / -inf: no lower bound of the best value
+        float ds[kRecSlots], vs[kRecSlots];
+        unsigned short ks[kRecSlots];
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            ds[j] = __builtin_huge_valf();
+            vs[j] = -__builtin_huge_valf();
+            ks[j] = kRecEmpty;
+        }
+        float rest = -__builtin_huge_valf();
+        for (int k = 0; k < K; ++k) {
+            const double d = dist_of(sco[k], u[(int64_t)k * npad + n]);
+            double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
+            y = y > 0.0 ? y : 0.0;                               // also NaN -> 0: the trivial bound c'
+            const float yf = f32_down(y);
+            const double c = sc[k];
+            const double ub = c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c);
+            u[(int64_t)k * npad + n] = ub;
+            const bool cand = over || k == kb || !(ub < thr);
+            if (cand) {
+                mk[k >> 6] |= 1ull << (k & 63);
+                ++listed;
+            }
+            rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), f32_up(ub));
+        }
+        unsigned sel = 0;
+        int in_slots = 0;
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            const bool c1 = ks[j] != kRecEmpty && (ks[j] & kRecListed);
+            sel |= c1 ? (1u << j) : 0u;
+            in_slots += c1 ? 1 : 0;
+            rec.k[(int64_t)j * rec.npad + n] = ks[j] == kRecEmpty ? kRecEmpty : (unsigned short)(ks[j] & kRecCompMask);
+            rec.d[(int64_t)j * rec.npad + n] = ds[j];
+        }
+        rec.B[n] = rest;
+        rec.exact[n] = 0;
+        rec.sel[n] = (unsigned char)(over ? 0 : sel);
+        rec.flags[n] = (unsigned char)(over ? 1 : (listed > in_slots ? 2 : 0));
+        over_i = over ? 1 : 0;
+        for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
+    }
+    for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        listed += __shfl_xor(listed, o);
+        over_i += __shfl_xor(over_i, o);
+    }
+    if ((tid & 63) == 0) {
+        wsum[0][wave] = listed;
+        wsum[1][wave] = over_i;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += kSelRows)
+        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    if (tid == 0) {
+        epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
+        opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
+    }
+}
+
 // first[k] = index of component k's first gather chunk (chunk = per_wg list entries), first[K] = number of chunks
 __global__ void gather_plan_kernel(const int* __restrict__ counts, int K, int per_wg, int* __restrict__ first) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -317,7 +424,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                 if (x == mx && k < arg) arg = k;
                 ssum += exp(x - mx);
             }
-            rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], x)), (unsigned short)(k | 0x8000), f32_up(x));
+            rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], x)), (unsigned short)(k | kRecExactBit), f32_up(x));
         };
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
@@ -346,8 +453,8 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         unsigned ex = 0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
-            const bool e1 = ks[j] != kRecEmpty && (ks[j] & 0x8000);
-            rec.k[(int64_t)j * rec.npad + n] = ks[j] == kRecEmpty ? kRecEmpty : (unsigned short)(ks[j] & 0x7fff);
+            const bool e1 = ks[j] != kRecEmpty && (ks[j] & kRecExactBit);
+            rec.k[(int64_t)j * rec.npad + n] = ks[j] == kRecEmpty ? kRecEmpty : (unsigned short)(ks[j] & kRecCompMask);
             rec.d[(int64_t)j * rec.npad + n] = ds[j];
             ex |= e1 ? (1u << j) : 0u;
         }
@@ -485,10 +592,9 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict
 
 // Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-100) marks the pairs
 // whose exact value is in the dense array.  mode 0: ln rho - exact for active pairs and for exact slots, otherwise the
-// record's upper bound (at least 100 ln 2 below the row's best); mode 1: responsibilities, exactly 0 for inactive pairs.
+// record's upper bound (at least 100 ln 2 below the row's log-normaliser); mode 1: responsibilities, exactly 0 for inactive pairs.
 __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __restrict__ masks,
-                                   const int* __restrict__ khat, const double* __restrict__ lnrho,
-                                   const double* __restrict__ lse,
+                                   const double* __restrict__ lnrho, const double* __restrict__ lse,
                                    const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
                                    int mode, double* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -513,9 +619,9 @@ __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __re
         }
     }
     if (!exact) {
-        // every pair that is not active lies at least 100 ln 2 below the row's best value (evaluated and found so, or
-        // proven so by its bound): B alone may be the value of a ninth near component
-        const double cap = lnrho[(int64_t)khat[n] * npad + n] - k100Ln2;
+        // every pair that is not active lies at least 100 ln 2 below the row's log-normaliser (evaluated and found so,
+        // or proven so by its bound): B alone may be the value of a ninth near component
+        const double cap = lse[n] - k100Ln2;
         ub = cap < ub ? cap : ub;
     }
     out[e] = exact ? lnrho[(int64_t)k * npad + n] : ub;

@@ -39,7 +39,7 @@ struct gmmvb_workspace {
     int64_t bounds_rows = 0;           // rows / matrix the records (and the ln rho array) belong to (0: nothing to carry)
     const void* bounds_x = nullptr;
     int64_t bounds_ldx = 0;
-    int prev_pass = 0;                 // last E-step: 0 dense, 1 bound pass, 2 carried records
+    int prev_pass = 0;                 // last E-step: 0 dense, 1 bound pass, 2 carried records, 3 dense sweep
     // per-row candidate records (records.h), allocated with the sample lists
     unsigned short* rec_k = nullptr;   // [8][npad]
     float* rec_d = nullptr;            // [8][npad]
@@ -47,6 +47,8 @@ struct gmmvb_workspace {
     unsigned char* rec_exact = nullptr, *rec_sel = nullptr, *rec_flags = nullptr;   // [npad] each
     bool rec_valid = false;            // the records describe the last E-step's parameters on bounds_rows rows
     bool rec_live = false;             // the last E-step lived on records (read-outs go through them)
+    bool dense_valid = false;          // EVERY entry of the ln rho array is a value / bound under the last E-step's parameters
+    int sweeps = 0;                    // dense sweeps since the last bound / dense pass (their bounds erode: at most 8)
     int* plan = nullptr;               // [K + 1] gather chunk plan (device)
     double* epart = nullptr;           // [ceil(npad / 256)] listed pairs per selection block
     double* opart = nullptr;           // [ceil(npad / 256)] overflow rows per selection block
@@ -93,7 +95,7 @@ struct gmmvb_workspace {
     int64_t e_rows = 0;
     char info[512] = {0};
     // launches since the workspace was created (gmmvb_pass_counts): E dense, E bound pass, E carried bounds,
-    // pruned E-step that fell back to the dense kernel, carried pass that had to bound afresh, M dense, M lists,
+    // pruned E-step that fell back to the dense kernel, E sweep of carried bounds, M dense, M lists,
     // candidate gathers
     int64_t passes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool prof = false;

@@ -354,7 +354,7 @@ def main():
             groups[g] = dict(ms=float(np.mean([s.get(g, (0.0, 0))[0] for s in spans])),
                              launch_groups_per_step=float(np.mean([s.get(g, (0.0, 0))[1] for s in spans])))
         row_bytes = D * esz
-        sparse_e = timed_counts["estep_bound"] + timed_counts["estep_carried"] > 0
+        sparse_e = timed_counts["estep_bound"] + timed_counts["estep_carried"] + timed_counts["estep_sweep"] > 0
         alg = {"estep_main": n_local * row_bytes * (timed_counts["estep_dense"] + timed_counts["estep_bound"]
                                                     + timed_counts["estep_fell_back_dense"]) / steps,
                "estep_gather": ev * row_bytes if sparse_e else 0.0,

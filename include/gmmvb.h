@@ -104,12 +104,25 @@ int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64
 
 /* Read-outs for rows [row0, row0 + n_rows) of the last E-step, row-major [n_rows][K].
  * When the E-step pruned (large N K, sparse responsibilities; see gmmvb_last_sparsity), gmmvb_ln_rho returns, for the
- * pairs it did not evaluate, an upper bound of ln rho that lies at least 100 ln 2 below the row's largest value, and
+ * pairs it did not evaluate, an upper bound of ln rho that lies at least 100 ln 2 below the row's log-normaliser, and
  * gmmvb_responsibilities returns exactly 0 for them (r < 2^-100): hard assignments and statistics are unaffected.  Pruning is never
  * used once hmmvb_enable has been called, or with GMMVB_ESTEP_PRUNE=0 in the environment. */
 int gmmvb_responsibilities(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* r_dev, void* stream);
 int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
 int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_dev, void* stream);
+
+/* ---- row sharding over one process per GPU (the reference has no distributed code) -----------
+ * The statistics block is linear in the rows: rank g runs gmmvb_estep / gmmvb_mstep on its own rows and ONE in-place
+ * all-reduce(sum, f64) of the block per VB iteration makes every rank hold the statistics of the whole matrix (the
+ * K-sized update is then computed identically on every rank).  RCCL over xGMI; librccl.so.1 is resolved at run time.
+ *   rank 0:      gmmvb_comm_unique_id(id)  -> hand the 128 bytes to every rank (MPI / TCP / a file: the caller's choice)
+ *   every rank:  gmmvb_comm_create(id, n_ranks, rank, &comm)      (collective; the current HIP device is the rank's GPU)
+ *   per pass:    gmmvb_allreduce_stats(comm, stats_dev, gmmvb_stats_len(K, D), stream)     (enqueued on `stream`) */
+typedef struct gmmvb_comm gmmvb_comm;
+int gmmvb_comm_unique_id(unsigned char* id_out /*[128]*/);
+int gmmvb_comm_create(const unsigned char* id /*[128]*/, int n_ranks, int rank, gmmvb_comm** out);
+int gmmvb_comm_destroy(gmmvb_comm* comm);
+int gmmvb_allreduce_stats(gmmvb_comm* comm, double* stats_dev, int64_t len, void* stream);
 
 /* ---- Gaussian-emission HMM (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py) -------------------------
  * The emission term is the GMM E-step without E[ln pi]: call gmmvb_set_params with
@@ -174,8 +187,9 @@ int gmmvb_kside_drift(int K, int D, const double* u_old_dev, const double* uinv_
                       double* big_gamma_dev /*[K]*/, double* enorm_dev /*[K]*/, void* stream);
 
 /* Which kernels have run in this workspace since it was created (for tests and profiling reports):
- *   out[0] dense E-steps, out[1] bound passes of the pruned E-step, out[2] E-steps on carried bounds, out[3] pruned
- *   E-steps that fell back to the dense kernel, out[4] carried passes that had to bound afresh, out[5] dense M-steps,
+ *   out[0] dense E-steps, out[1] bound passes of the pruned E-step, out[2] E-steps on carried records, out[3] E-steps
+ *   sent back to the dense kernel after a bound pass that pruned nothing, out[4] E-steps on a sweep of carried bounds
+ *   over the dense ln rho array, out[5] dense M-steps,
  *   out[6] M-steps over active-row lists, out[7] candidate gathers (exact f64 evaluation of listed pairs). */
 int gmmvb_pass_counts(const gmmvb_workspace* ws, int64_t* out /*[8]*/);
 

@@ -59,3 +59,32 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
             assert rel_err(res[key], one.get_hn_params()[key]) < 1e-9, (r, key)
         assert rel_err(res["ns"], one.ns) < 1e-9
         assert abs(float(res["vl"]) - one.vl) < 1e-9 * abs(one.vl)
+
+
+@pytest.mark.gpu
+def test_c_abi_rccl_communicator_single_rank():
+    """gmmvb_comm_* / gmmvb_allreduce_stats (include/gmmvb.h): librccl is resolved at run time, a one-rank communicator
+    is created on the GPU and the in-place all-reduce of a statistics block leaves it unchanged.  (Two RCCL ranks need
+    two GPUs; the N > 1 path is what bench.py --gpus N runs.)"""
+    import torch
+    from bayesml_amd._engine import RcclComm
+    dev = torch.device("cuda", 0)
+    comm = RcclComm(0, 1, dev, bootstrap=lambda b: b)
+    t = torch.arange(64 * (2 + 128 + 128 * 128), dtype=torch.float64, device=dev)
+    ref = t.clone()
+    comm.all_reduce_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref)
+    comm.close()
+
+
+def test_c_abi_comm_argument_errors():
+    import ctypes
+    from bayesml_amd import _engine
+    lib = _engine.load_library()
+    h = ctypes.c_void_p()
+    buf = (ctypes.c_ubyte * 128)()
+    assert lib.gmmvb_comm_create(buf, 2, 2, ctypes.byref(h)) == 1          # rank outside [0, n_ranks)
+    assert lib.gmmvb_comm_create(None, 1, 0, ctypes.byref(h)) == 1
+    assert lib.gmmvb_allreduce_stats(None, None, 0, None) == 1
+    assert lib.gmmvb_comm_destroy(None) == 0
