@@ -411,4 +411,40 @@ __global__ void reduce_stats_kernel(const double* __restrict__ slabs, int S, int
     }
 }
 
+// The same for the list M-step's chunk slabs (mstep.h): component k owns slabs plan[k] .. plan[k + 1] - 1.
+__global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int* __restrict__ plan, int K, int D, int T,
+                                     double* __restrict__ stats) {
+    const int k = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = tri_pairs(T);
+    const int L = slab_len(T);
+    if (e >= P * 256 + 16 * T + 2) return;
+    double v = 0.0;
+    const int c0 = plan[k], c1 = plan[k + 1];
+    for (int c = c0; c < c1; ++c) v += slabs[(int64_t)c * L + e];
+    double* ns = stats;
+    double* h = stats + K;
+    double* a = stats + 2 * (int64_t)K;
+    double* B = a + (int64_t)K * D;
+    if (e < P * 256) {
+        const int p = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+        int t2 = 0;
+        while (tri_pairs(t2 + 1) <= p) ++t2;
+        const int t1 = p - tri_pairs(t2);
+        const int col = lane & 15, row = (lane >> 4) + 4 * r;     // f64 MFMA C/D map
+        const int f1 = T * row + t1, f2 = T * col + t2;
+        if (f1 >= D || f2 >= D) return;
+        if (t1 == t2 && row > col) return;   // diagonal tiles: keep one triangle, mirror it (exact symmetry)
+        B[((int64_t)k * D + f1) * D + f2] = v;
+        B[((int64_t)k * D + f2) * D + f1] = v;
+    } else if (e < P * 256 + 16 * T) {
+        const int f = e - P * 256;
+        if (f < D) a[(int64_t)k * D + f] = v;
+    } else if (e == P * 256 + 16 * T) {
+        ns[k] = v;
+    } else {
+        h[k] = v;
+    }
+}
+
 }  // namespace gmmvb

@@ -182,7 +182,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart};
-    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan};
+    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan, ws->plan_m};
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
@@ -336,6 +336,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->khat, (size_t)np * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->counts, (size_t)ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->plan, (size_t)(ws->K + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->plan_m, (size_t)(ws->K + 2) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->blk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->epart, (size_t)sel_blocks * sizeof(double));
@@ -362,8 +363,8 @@ static int fetch_counters(gmmvb_workspace* ws) {
         if (ws->pend_mode == 0) {              // dense pass: every pair evaluated, no records involved
             ws->lag_eval = (double)ws->pend_rows * ws->K;
             ws->lag_over = 0.0;
-        } else {                               // a bound pass also evaluated every row's best component
-            ws->lag_eval = ws->ctr_host[1] + (ws->pend_mode == 1 ? (double)ws->pend_rows : 0.0);
+        } else {                               // a bound pass / sweep also evaluated every row's (previous) best component
+            ws->lag_eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? (double)ws->pend_rows : 0.0);
             ws->lag_over = ws->ctr_host[2];
         }
         ws->lag_rows = ws->pend_rows;
@@ -667,6 +668,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             name = "estep_sweep_bounds";
             ++ws->passes[4];
             ++ws->sweeps;
+            // the previous best component of every row, exactly under the new parameters (the sweep's reference value)
+            span_begin(ws, kSpanSelect, st);
+            hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                               ws->khat, ws->masks, ws->blk);
+            span_end(ws, st);
+            e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step best-component evaluation", e);
             span_begin(ws, kSpanSelect, st);
             hipLaunchKernelGGL(rec_sweep_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
                                ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
@@ -803,14 +811,9 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (sparse) {      // E-step output: only the samples that can change the f64 sums, through per-component lists
         rc = ensure_lists(ws);
         if (rc) return rc;
-        // a split = a whole number of 256-row selection blocks
         const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
-        int bps = (int)((rows_per_split + kSelRows - 1) / kSelRows);
-        if (bps < 1) bps = 1;
-        rows_per_split = (int64_t)bps * kSelRows;
-        S = (n_rows + rows_per_split - 1) / rows_per_split;
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
-        // masks and block counts of the active pairs were written by lse_mask_kernel at the end of the E-step
+        // masks and block counts of the active pairs were written by lse_mask_kernel / rec_finish_kernel at the end of the E-step
         if (!ws->active_lists) {
             span_begin(ws, kSpanLists, st);
             hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, nblk, ws->K, ws->counts);
@@ -821,9 +824,15 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);
             ws->active_lists = true;
         }
-        grid = 8 * ((S + 7) / 8) * KG;
-        MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->blk, ws->counts, nblk, bps,
-                         ws->npad, ws->K, KG, (int)S, ws->slabs};
+        // chunks of list entries (mstep.h): as many slabs as the workspace holds, at least 1024 entries per chunk
+        const int cap_chunks = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
+        grid = (cap_chunks + kpw - 1) / kpw;
+        const int64_t most = (n_rows * (int64_t)ws->K + 1023) / 1024 + ws->K;      // no more chunks than this can exist
+        if ((most + kpw - 1) / kpw < grid) grid = (most + kpw - 1) / kpw;
+        S = 0;
+        rows_per_split = 1024;
+        MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks, 1024,
+                         ws->npad, ws->K, ws->slabs};
         span_begin(ws, kSpanMstepMain, st);
         e = launch_mstep_list(ws->T, (int)grid, st, la, &name);
         span_end(ws, st);
@@ -842,8 +851,12 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     const int elems = tri_pairs(ws->T) * 256 + 16 * ws->T + 2;
     span_begin(ws, kSpanReduce, st);
-    hipLaunchKernelGGL(reduce_stats_kernel, dim3((elems + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, (int)S,
-                       ws->K, ws->D, ws->T, stats_dev);
+    if (sparse)
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3((elems + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, ws->plan_m,
+                           ws->K, ws->D, ws->T, stats_dev);
+    else
+        hipLaunchKernelGGL(reduce_stats_kernel, dim3((elems + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, (int)S,
+                           ws->K, ws->D, ws->T, stats_dev);
     span_end(ws, st);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "reduce_stats launch", e);

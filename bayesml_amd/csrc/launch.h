@@ -60,8 +60,8 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
 // sparse-responsibility M-step over the centred copy and per-component lists of active rows (mstep.h)
 struct MstepListArgs {
     const double* xc; const double* lnrho; const double* lse;
-    const int* lists; int64_t cap; const int* blk; const int* counts; int nblk; int blocks_per_split;
-    int64_t npad; int K; int KG; int S; double* slabs;
+    const int* lists; int64_t cap; const int* counts; int* plan; int cap_chunks; int r_min;
+    int64_t npad; int K; double* slabs;
 };
 hipError_t launch_mstep_list(int T, int grid, hipStream_t st, const MstepListArgs& a, const char** name);
 

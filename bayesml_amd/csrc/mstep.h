@@ -264,8 +264,28 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
 // thr[k] = max_n (ln rho_nk - lse_n) - 100 ln 2 over a sample of the rows (row_lse_kernel / thr_kernel); lse_mask_kernel,
 // scan_counts and fill_lists (aux_kernels.h) write, per component, the ascending list of its active rows; mstep_list_f64 is
 // mstep_body over list positions instead of rows (LIST form: one index load per 64 entries, the row addresses go
-// through it), with the same slabs and the same fixed summation order.  A row split is a whole number of selection
-// blocks, so its piece of list k is [blk[b0][k], blk[b1][k]).
+// through it).
+// Work distribution: the list of component k is cut into chunks of R entries; plan[k] = index of its first chunk,
+// plan[K] = number of chunks, plan[K + 1] = R (mstep_plan_kernel: R >= r_min, raised so that the chunks fit the slab
+// capacity).  Chunk c is one (component, list range) whatever rows it spans, so the work is balanced whether the rows
+// of a component are scattered over the matrix or (after the rows were grouped by component) contiguous; every chunk
+// writes one slab, reduce_chunks_kernel adds a component's slabs in chunk order (fixed order: run-to-run identical).
+__global__ void mstep_plan_kernel(const int* __restrict__ counts, int K, int cap_chunks, int r_min, int* __restrict__ plan) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long total = 0;
+    for (int k = 0; k < K; ++k) total += counts[k];
+    long long R = r_min;
+    const long long room = cap_chunks - K > 0 ? cap_chunks - K : 1;      // every component may end on a partial chunk
+    if ((total + R - 1) / R > room) R = ((total + room - 1) / room + 63) / 64 * 64;
+    int c = 0;
+    for (int k = 0; k < K; ++k) {
+        plan[k] = c;
+        c += (int)((counts[k] + R - 1) / R);
+    }
+    plan[K] = c;
+    plan[K + 1] = (int)R;
+}
+
 template <int T>
 __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
     const double* __restrict__ xc,         // [npad + 64][16 T] centred rows
@@ -273,28 +293,33 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
     const double* __restrict__ lse,        // [npad]
     const int* __restrict__ lists,         // [K][cap] active rows, ascending
     int64_t cap,
-    const int* __restrict__ blk,           // [nblk][K] list position of every selection block's first entry
     const int* __restrict__ counts,        // [K] list lengths
-    int nblk, int blocks_per_split, int64_t npad, int K, int KG, int S,
-    double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
+    const int* __restrict__ plan,          // [K + 2] chunk plan
+    int64_t npad, int K,
+    double* __restrict__ slabs /*[chunks][slab_len(T)]*/) {
     constexpr int WS = mstep_ws(T);
     constexpr int KPW = mstep_waves(T, true) / WS;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bid = blockIdx.x;            // same XCD-aware decode as mstep_mfma_f64
-    const int xcd = bid & 7;
-    const int j = bid >> 3;
-    const int kg = j % KG;
-    const int split = (j / KG) * 8 + xcd;
-    if (split >= S) return;
-    const int k = kg * KPW + wave / WS;
-    if (k >= K) return;
+    const int c = (int)blockIdx.x * KPW + wave / WS;
+    if (c >= plan[K]) return;
+    int k = 0;
+    {
+        int lo = 0, hi = K;                      // largest k with plan[k] <= c (empty components share their successor's start)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (plan[mid] <= c) lo = mid;
+            else hi = mid;
+        }
+        k = lo;
+    }
+    const int R = plan[K + 1];
     const int sub = wave % WS;
-    const int b0 = split * blocks_per_split, b1 = b0 + blocks_per_split;
-    const int64_t lo = blk[(int64_t)b0 * K + k];
-    const int64_t hi = b1 < nblk ? blk[(int64_t)b1 * K + k] : counts[k];
+    const int64_t lo = (int64_t)(c - plan[k]) * R;
+    int64_t hi = lo + R;
+    if (hi > counts[k]) hi = counts[k];
     const double* lr = lnrho + (int64_t)k * npad;
     const int* list = lists + (int64_t)k * cap;
-    double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
+    double* out = slabs + (int64_t)c * slab_len(T);
     if constexpr (WS == 1) {
         mstep_body<T, 1, 0, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, 0, out, list);
     } else {

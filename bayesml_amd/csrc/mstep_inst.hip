@@ -44,8 +44,9 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
 
 template <int T>
 static hipError_t go_list(int grid, hipStream_t st, const MstepListArgs& a) {
+    hipLaunchKernelGGL(mstep_plan_kernel, dim3(1), dim3(64), 0, st, a.counts, a.K, a.cap_chunks, a.r_min, a.plan);
     hipLaunchKernelGGL((mstep_list_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.xc, a.lnrho, a.lse,
-                       a.lists, a.cap, a.blk, a.counts, a.nblk, a.blocks_per_split, a.npad, a.K, a.KG, a.S, a.slabs);
+                       a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs);
     return hipGetLastError();
 }
 

@@ -266,8 +266,10 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
 // array still holds, for EVERY pair, a value or upper bound under the previous parameters.  One sweep over it
 //   carries every entry over the update with its own component's (gamma, delta):  u' = c'_k - (gamma_k d - delta_k)_+^2 / 2,
 //     d = sqrt(2 (c_k - u)_+), and writes it back (the array stays valid for the next sweep);
-//   takes the row's previous best component (exact in the last pass) for the lower bound lb of the new best value;
-//   lists every pair with u' >= lb - 100 ln 2, and builds the row's record (C nearest components + rest bound) on the way,
+//   reads the row's previous best component, which the host has just had evaluated exactly under the NEW parameters
+//     (this early the components still shrink by factors - Gamma = 2 .. 4 -, a lower bound of the best value carried
+//     through Gamma would be hundreds of nats too low), as the reference value v;
+//   lists every other pair with u' >= v - 100 ln 2, and builds the row's record (C nearest components + rest bound) on the way,
 // so that the pass continues exactly like one on records (gather -> rec_finish_kernel) and later passes can switch to them.
 __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict__ u, int64_t npad, int64_t n_rows, int K,
                                                              const double* __restrict__ drift,
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
                                                              int* __restrict__ blk_cnt, double* __restrict__ epart,
                                                              double* __restrict__ opart) {
     __shared__ int wcnt[4][256];
-    __shared__ double sg[256], sdl[256], sG[256], sc[256], sco[256];
+    __shared__ double sg[256], sdl[256], sc[256], sco[256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
@@ -285,7 +287,6 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
     for (int k = tid; k < K; k += kSelRows) {
         sg[k] = drift[k];
         sdl[k] = drift[K + k];
-        sG[k] = drift[3 * K + k];
         sc[k] = c_new[k];
         sco[k] = drift[2 * K + k];
     }
@@ -297,14 +298,9 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
     if (valid) {
         const double ninf = -__builtin_huge_val();
         const int kb = khat[n];
-        double thr = ninf;
-        {
-            const double d = dist_of(sco[kb], u[(int64_t)kb * npad + n]);
-            const double du = sG[kb] * d * (1.0 + 1e-12) + sdl[kb];
-            const double lb = sc[kb] - 0.5 * du * du * (1.0 + 1e-12) - 1e-12 * fabs(sc[kb]);
-            thr = lb - k100Ln2;
-        }
-        const bool over = !(thr > ninf);                       // NaN / -inf: no lower bound of the best value
+        const double vb = u[(int64_t)kb * npad + n];           // exact, new parameters
+        const double thr = vb - k100Ln2;
+        const bool over = !(thr > ninf);                       // NaN / -inf: nothing to compare with
         float ds[kRecSlots], vs[kRecSlots];
         unsigned short ks[kRecSlots];
 #pragma unroll
@@ -315,32 +311,37 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
         }
         float rest = -__builtin_huge_valf();
         for (int k = 0; k < K; ++k) {
+            const double c = sc[k];
+            if (k == kb && !over) {
+                rec_insert(ds, ks, vs, rest, f32_down(dist_of(c, vb)), (unsigned short)(k | kRecExactBit), f32_up(vb));
+                continue;
+            }
             const double d = dist_of(sco[k], u[(int64_t)k * npad + n]);
             double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
             y = y > 0.0 ? y : 0.0;                               // also NaN -> 0: the trivial bound c'
             const float yf = f32_down(y);
-            const double c = sc[k];
             const double ub = c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c);
             u[(int64_t)k * npad + n] = ub;
-            const bool cand = over || k == kb || !(ub < thr);
+            const bool cand = over || !(ub < thr);
             if (cand) {
                 mk[k >> 6] |= 1ull << (k & 63);
                 ++listed;
             }
             rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), f32_up(ub));
         }
-        unsigned sel = 0;
+        unsigned sel = 0, ex = 0;
         int in_slots = 0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
             const bool c1 = ks[j] != kRecEmpty && (ks[j] & kRecListed);
             sel |= c1 ? (1u << j) : 0u;
+            ex |= (ks[j] != kRecEmpty && (ks[j] & kRecExactBit)) ? (1u << j) : 0u;
             in_slots += c1 ? 1 : 0;
             rec.k[(int64_t)j * rec.npad + n] = ks[j] == kRecEmpty ? kRecEmpty : (unsigned short)(ks[j] & kRecCompMask);
             rec.d[(int64_t)j * rec.npad + n] = ds[j];
         }
         rec.B[n] = rest;
-        rec.exact[n] = 0;
+        rec.exact[n] = (unsigned char)(over ? 0 : ex);
         rec.sel[n] = (unsigned char)(over ? 0 : sel);
         rec.flags[n] = (unsigned char)(over ? 1 : (listed > in_slots ? 2 : 0));
         over_i = over ? 1 : 0;

@@ -50,6 +50,7 @@ struct gmmvb_workspace {
     bool dense_valid = false;          // EVERY entry of the ln rho array is a value / bound under the last E-step's parameters
     int sweeps = 0;                    // dense sweeps since the last bound / dense pass (their bounds erode: at most 8)
     int* plan = nullptr;               // [K + 1] gather chunk plan (device)
+    int* plan_m = nullptr;             // [K + 2] chunk plan of the list M-step
     double* epart = nullptr;           // [ceil(npad / 256)] listed pairs per selection block
     double* opart = nullptr;           // [ceil(npad / 256)] overflow rows per selection block
     // counters of an E-step: [0] active pairs (r >= 2^-100), [1] pairs evaluated exactly, [2] overflow rows.
