@@ -31,6 +31,7 @@ SYMBOLS = {
     "gmmvb_set_params": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "gmmvb_set_drift": (_int, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp]),
     "gmmvb_forget": (_int, [_vp]),
+    "gmmvb_debug_record": (_int, [_vp, _i64, ctypes.POINTER(ctypes.c_double)]),
     "gmmvb_wants_drift": (_int, [_vp, _i64]),
     "gmmvb_prepare_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_estep": (_int, [_vp, _vp, _i64, _i64, _vp]),
@@ -329,6 +330,13 @@ class DataPass:
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.gmmvb_set_drift(self._ws, g.data_ptr(), d.data_ptr(), G.data_ptr(),
                                                       float(typical_gamma), self._stream()), "gmmvb_set_drift")
+
+    def debug_record(self, row: int) -> dict:
+        out = (ctypes.c_double * 26)()
+        _check(self.lib, self.lib.gmmvb_debug_record(self._ws, int(row), out), "gmmvb_debug_record")
+        v = list(out)
+        return dict(k=[int(x) for x in v[:8]], d=[round(x, 3) for x in v[8:16]], B=v[16], exact=int(v[17]), sel=int(v[18]),
+                    flags=int(v[19]), khat=int(v[20]), lse=v[21], masks=[int(x) for x in v[22:26]])
 
     def forget(self):
         """The next parameters are unrelated to the last E-step's (a new restart): see gmmvb_forget."""

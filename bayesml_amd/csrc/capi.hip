@@ -298,6 +298,42 @@ int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* 
     return GMMVB_OK;
 }
 
+// test / diagnostic read-out of one row's candidate record (blocking): out[0..7] slot components (-1 empty), out[8..15]
+// slot distances, out[16] B, out[17] exact bits, out[18] selected bits, out[19] flags, out[20] khat, out[21] lse,
+// out[22..25] the row's mask words
+int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26] host*/) {
+    if (!ws || !out || !ws->rec_k || row < 0 || row >= ws->npad) return fail(GMMVB_EINVAL, "bad argument");
+    (void)hipDeviceSynchronize();
+    for (int j = 0; j < kRecSlots; ++j) {
+        unsigned short k = 0;
+        float d = 0.0f;
+        (void)hipMemcpy(&k, ws->rec_k + (int64_t)j * ws->npad + row, sizeof(k), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&d, ws->rec_d + (int64_t)j * ws->npad + row, sizeof(d), hipMemcpyDeviceToHost);
+        out[j] = k == kRecEmpty ? -1.0 : (double)k;
+        out[8 + j] = d;
+    }
+    float B = 0.0f;
+    unsigned char ex = 0, sel = 0, fl = 0;
+    int kh = 0;
+    (void)hipMemcpy(&B, ws->rec_B + row, sizeof(B), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&ex, ws->rec_exact + row, 1, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&sel, ws->rec_sel + row, 1, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&fl, ws->rec_flags + row, 1, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&kh, ws->khat + row, sizeof(kh), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(out + 21, ws->lse + row, sizeof(double), hipMemcpyDeviceToHost);
+    out[16] = B;
+    out[17] = ex;
+    out[18] = sel;
+    out[19] = fl;
+    out[20] = kh;
+    for (int w = 0; w < 4; ++w) {
+        unsigned long long m = 0;
+        if (w < (ws->K + 63) / 64) (void)hipMemcpy(&m, ws->masks + (int64_t)w * ws->npad + row, sizeof(m), hipMemcpyDeviceToHost);
+        out[22 + w] = (double)m;
+    }
+    return GMMVB_OK;
+}
+
 int gmmvb_forget(gmmvb_workspace* ws) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     ws->forget = true;

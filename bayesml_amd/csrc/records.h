@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
         for (int k = 0; k < K; ++k) {
             const double c = sc[k];
             if (k == kb && !over) {
-                rec_insert(ds, ks, vs, rest, f32_down(dist_of(c, vb)), (unsigned short)(k | kRecExactBit), f32_up(vb));
+                rec_insert(ds, ks, vs, rest, -1.0f, (unsigned short)(k | kRecExactBit), f32_up(vb));
                 continue;
             }
             const double d = dist_of(sco[k], u[(int64_t)k * npad + n]);
@@ -328,6 +328,11 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
                 ++listed;
             }
             rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), f32_up(ub));
+        }
+        if (!over) {          // the reference pair was inserted at distance -1 so that it always keeps a slot
+#pragma unroll
+            for (int j = 0; j < kRecSlots; ++j)
+                if (ks[j] != kRecEmpty && (ks[j] & kRecExactBit)) ds[j] = f32_down(dist_of(sc[kb], vb));
         }
         unsigned sel = 0, ex = 0;
         int in_slots = 0;

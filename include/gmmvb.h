@@ -213,6 +213,11 @@ int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows);
  * assume that the responsibilities are still as sparse as they were and runs the dense kernel. */
 int gmmvb_forget(gmmvb_workspace* ws);
 
+/* test / diagnostic read-out (blocking) of one row's candidate record, 26 doubles to HOST memory: slot components
+ * (-1 = empty) [0..7], slot distances [8..15], rest bound B [16], exact / selected bits [17] [18], flags [19], best
+ * component [20], lse [21], the row's mask words [22..25]. */
+int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26], host*/);
+
 /* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
  * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
  * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  *active_pairs = -1 when the
