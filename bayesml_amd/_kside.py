@@ -371,7 +371,8 @@ class KStepper:
                          -> lower bound under q            _calc_vl                         ref :671-723
                          -> q' = closed-form update        _update_q_mu_lambda/_update_q_pi ref :741-770
                          -> drift hint (gamma, delta) of q -> q' for the engine (gmmvb_set_drift)
-                         -> [p_x .. vl | mean gamma] in one small vector (the iteration's single device-to-host copy)
+                         -> [p_x .. vl | min_k (gamma_k - delta_k / 30)] in one small vector (the iteration's single
+                            device-to-host copy)
 
     On a GPU the sequence (about 150 small torch kernels) is captured once in a hipGraph and replayed: the K-side
     costs one graph launch per iteration instead of ~2 ms of launches.  The factorisation inside is the library's
@@ -420,7 +421,9 @@ class KStepper:
             self.gamma.copy_(gamma)
             self.delta.copy_(delta)
             self.big_gamma.copy_(big)
-            gmean = gamma.mean()
+            # one pessimistic scalar for the engine's choice of carrying scheme: the slowest component decides how
+            # fast a row's shared rest bound erodes (delta in whitened units; 30 ~ a typical distance to the rest)
+            gmean = (gamma - delta / 30.0).min()
         else:
             gmean = torch.zeros((), dtype=torch.float64, device=st.device)
         _copy_post(self.q_next, qn)
@@ -452,7 +455,8 @@ class KStepper:
             self._body()
 
     def read(self):
-        """(dict of the lower bound's terms as host floats, mean gamma) - the iteration's one host sync."""
+        """(dict of the lower bound's terms as host floats, the drift summary min_k (gamma_k - delta_k / 30)) - the
+        iteration's one host sync."""
         v = self.scal.tolist()
         return dict(zip(TERM_KEYS, v[:-1])), v[-1]
 

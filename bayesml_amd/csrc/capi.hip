@@ -537,14 +537,17 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             mode = kBound;
             const bool hinted = same_rows && ws->have_drift && std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
             // Two ways of carrying the previous pass over the parameter update (gmmvb_set_drift):
-            //   records (records.h)  55 bytes per row, one aggregate bound for the components without a slot: tight once
-            //                        the components hardly move (mean gamma >= 0.975: at C3 from the 8th iteration on);
+            //   records (records.h)  55 bytes per row, ONE bound for all components without a slot: it erodes at the pace
+            //                        of the fastest-moving component (a 300-sample component with gamma 0.95 costs every
+            //                        row ~40 nats per pass), so it is used once even the slowest gamma is >= 0.985;
             //   dense sweep          every entry of the ln rho array carried with its own component's drift: one sweep
-            //                        of the array (2.5 ms at C3), robust while the components still move by per cents
-            //                        (mean gamma 0.35, 0.72, 0.87, 0.91, 0.94, 0.95, 0.96, 0.97 ... over the iterations).
+            //                        of the array (2.5 ms at C3) + the previous best evaluated first, robust while
+            //                        components still move by per cents.
+            // typical_gamma is the caller's pessimistic summary min_k (gamma_k - delta_k / 30) (0.3, 0.6, 0.7, 0.8 in
+            // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th).
             const double tg = ws->typical_gamma;
-            bool carry = hinted && ws->rec_valid && !(tg > 0.0 && tg < 0.975);
-            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.6) && ws->sweeps < 8;
+            bool carry = hinted && ws->rec_valid && !(tg > 0.0 && tg < 0.985);
+            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && ws->sweeps < 8;
             if ((carry || sweep) && known && ws->lag_mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow

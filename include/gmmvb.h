@@ -201,9 +201,10 @@ int gmmvb_pass_counts(const gmmvb_workspace* ws, int64_t* out /*[8]*/);
  * slots and one bound for all other components, 55 bytes per row) over to the new parameters instead of bounding every
  * pair afresh: pairs whose carried bound proves r < 2^-100 are skipped, the others are evaluated exactly, and a row
  * whose record has become too loose has all K pairs evaluated.  Loose values only cost candidates, wrong ones (gamma too
- * large, big_gamma or delta too small) break the bounds.  typical_gamma: the mean of gamma if the caller has it on the
- * host (below 0.9 the parameters are judged to move too fast for carrying), or a value <= 0 if not.  The hint is consumed
- * by the next gmmvb_estep. */
+ * large, big_gamma or delta too small) break the bounds.  typical_gamma: a pessimistic summary of the drift if the
+ * caller has one on the host - min_k (gamma_k - delta_k / 30) is what bayesml_amd passes - or a value <= 0 if not: below
+ * 0.985 the library carries by a sweep of its dense ln rho array (every pair with its own component's drift) instead of the
+ * records, below 0.5 it bounds afresh.  The hint is consumed by the next gmmvb_estep. */
 int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev /*[K]*/, const double* delta_dev /*[K]*/,
                     const double* big_gamma_dev /*[K]*/, double typical_gamma, void* stream);
 /* 1 if an E-step over n_rows rows of this workspace can make use of gmmvb_set_drift (pruning is possible at all),

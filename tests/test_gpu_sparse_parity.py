@@ -174,7 +174,7 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle():
         assert hint is not None
         before = eng.pass_counts()["estep_carried"] + eng.pass_counts()["estep_sweep"]
         q = q_new
-        ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=(*hint, float(hint[0].mean())))
+        ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=(*hint, float((hint[0] - hint[1] / 30.0).min())))
         if eng.pass_counts()["estep_carried"] + eng.pass_counts()["estep_sweep"] == before:
             continue
         lb = eng.ln_rho().cpu().numpy()

@@ -21,13 +21,13 @@ for it in range(5):
     q_new = _kside.update_q(prior, ns, x_bar, s)
     hint = m._drift_hint(eng, xd, q, q_new)
     q = q_new
-    ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=(*hint, float(hint[0].mean())))
+    ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=(*hint, float((hint[0] - hint[1] / 30.0).min())))
     lb = eng.ln_rho().cpu().numpy(); rb = eng.responsibilities().cpu().numpy()
     st = orc.data_pass(x64, _oracle_post(q)); la = st.ln_rho
     same = np.abs(la - lb) <= 1e-8 * np.maximum(1.0, np.abs(la))
     bad = (~same) & (lb < la)
     rows, ks = np.nonzero(bad)
-    print(it, eng.launch_info.split(" ")[0], "gmean %.3f" % float(hint[0].mean()), "bad", bad.sum(), "rows", np.unique(rows).size,
+    print(it, eng.launch_info.split(" ")[0], "gmean %.3f" % float((hint[0] - hint[1] / 30.0).min()), "bad", bad.sum(), "rows", np.unique(rows).size,
           "max|dr|", np.abs(rb - st.r).max(), "ns err", float(np.abs(ns.cpu().numpy() - st.ns).max()), eng.pass_counts())
     for r, k in list(zip(rows, ks))[:6]:
         print("   rec", eng.debug_record(int(r)))

@@ -16,11 +16,11 @@ for stage in "$@"; do
     dense) timeout 600 python bench.py --dense --no-cpu > $OUT/${TAG}_bench_line_dense.json 2> $OUT/${TAG}_dense.err; head -c 600 $OUT/${TAG}_bench_line_dense.json; echo ;;
     c4) timeout 900 python bench.py --config c4 --no-cpu > $OUT/${TAG}_bench_line_c4.json 2> $OUT/${TAG}_c4.err; tail -c 600 $OUT/${TAG}_c4.err; head -c 600 $OUT/${TAG}_bench_line_c4.json; echo ;;
     c2) timeout 600 python bench.py --config c2 > $OUT/${TAG}_bench_line_c2.json 2> $OUT/${TAG}_c2.err; tail -c 600 $OUT/${TAG}_c2.err; head -c 600 $OUT/${TAG}_bench_line_c2.json; echo ;;
-    trace) rm -rf $OUT/${TAG}_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_trace.err)
+    trace) rm -rf $OUT/${TAG}_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_trace.err)
            python tools/summarize_rocprof.py $OUT/${TAG}_trace > $OUT/${TAG}_bench_kernel_summary.md 2>> $OUT/${TAG}_trace.err; head -30 $OUT/${TAG}_bench_kernel_summary.md
            find $OUT/${TAG}_trace -name "*kernel_trace.csv" -size +20M -delete ;;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/${TAG}_pmc_$c
-           (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c.err); done
+           (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c.err); done
          python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE --config "K64 D128 N10000000 f32" --json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.md 2> $OUT/${TAG}_pmc.err; head -60 $OUT/${TAG}_pmc_summary.md
          find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*.csv" -size +20M -delete ;;
     hmm) timeout 900 python tools/bench_hmm.py > $OUT/${TAG}_hmm_bench_line.json 2> $OUT/${TAG}_hmm.err; tail -c 400 $OUT/${TAG}_hmm.err; head -c 800 $OUT/${TAG}_hmm_bench_line.json; echo ;;
