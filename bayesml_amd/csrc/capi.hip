@@ -400,7 +400,7 @@ static int fetch_counters(gmmvb_workspace* ws) {
             ws->lag_eval = (double)ws->pend_rows * ws->K;
             ws->lag_over = 0.0;
         } else {                               // a bound pass / sweep also evaluated every row's (previous) best component
-            ws->lag_eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? (double)ws->pend_rows : 0.0);
+            ws->lag_eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? ws->pend_round0 : 0.0);
             ws->lag_over = ws->ctr_host[2];
         }
         ws->lag_rows = ws->pend_rows;
@@ -529,6 +529,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool big = ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23);
     const bool same_rows = ws->bounds_rows == n_rows && ws->bounds_x == x_dev && ws->bounds_ldx == ldx;
     const bool known = ws->lag_valid && ws->lag_rows == n_rows && !ws->ctr_pending;     // counters of the previous pass
+    // the previous pass's M-step left its per-component lists of active rows (and their masks) in the workspace
+    const bool prev_lists = ws->active_lists && ws->e_state == 1 && ws->act_rows == n_rows && same_rows;
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
         bool sparse_ok = ws->prune == 2;
@@ -707,17 +709,37 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             name = "estep_sweep_bounds";
             ++ws->passes[4];
             ++ws->sweeps;
-            // the previous best component of every row, exactly under the new parameters (the sweep's reference value)
-            span_begin(ws, kSpanSelect, st);
-            hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                               ws->khat, ws->masks, ws->blk);
-            span_end(ws, st);
-            e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
-            if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step best-component evaluation", e);
-            span_begin(ws, kSpanSelect, st);
-            hipLaunchKernelGGL(rec_sweep_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
-                               ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
-            span_end(ws, st);
+            // round 0: pairs to evaluate exactly under the new parameters before the sweep (its reference values).
+            // If the previous pass's M-step ran over lists, those lists - every pair that was active - are still in the
+            // workspace with their masks: evaluate them as they are (no list building); else the previous best
+            // component of every row.
+            if (prev_lists) {
+                span_begin(ws, kSpanSelect, st);
+                hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
+                                   estep_gather_rows_per_wg(ws->T, is64), ws->plan);
+                span_end(ws, st);
+                span_begin(ws, kSpanGather, st);
+                e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan);
+                span_end(ws, st);
+                ++ws->passes[7];
+                if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step active-pair evaluation", e);
+                span_begin(ws, kSpanSelect, st);
+                hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                                   ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
+                span_end(ws, st);
+            } else {
+                span_begin(ws, kSpanSelect, st);
+                hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                                   ws->K, ws->khat, ws->masks, ws->blk);
+                span_end(ws, st);
+                e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
+                if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step best-component evaluation", e);
+                span_begin(ws, kSpanSelect, st);
+                hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                                   ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
+                span_end(ws, st);
+            }
+            ws->sweep_prev = prev_lists;
         } else {
             rpw = kSelRows;
             grid = sel_grid;
@@ -754,6 +776,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->ctr_pending = true;
         ws->pend_mode = mode;
         ws->pend_rows = n_rows;
+        // pairs evaluated before the counted selection: every row's best component, or (sweep over the previous
+        // pass's lists) the previous pass's active pairs
+        ws->pend_round0 = (mode == kSweep && ws->sweep_prev && known) ? ws->lag_act : (double)n_rows;
         ws->act_rows = n_rows;
     } else {
         ws->ctr_pending = false;

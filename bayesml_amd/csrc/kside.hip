@@ -24,17 +24,18 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double* __restrict_
         sm[i * ld + j] = j <= i ? a[base + e] : 0.0;
     }
     __syncthreads();
-    // right-looking Cholesky, column by column
+    // right-looking Cholesky, column by column; the trailing update runs on a 16 x 16 thread grid (rows ti + 16 a,
+    // columns tj + 16 b of the trailing block: no index division, conflict-free column reads)
+    const int ti = tid >> 4, tj = tid & 15;
     for (int j = 0; j < D; ++j) {
         if (tid == 0) sm[j * ld + j] = sqrt(sm[j * ld + j]);
         __syncthreads();
         const double inv = 1.0 / sm[j * ld + j];
         for (int i = j + 1 + tid; i < D; i += 256) sm[i * ld + j] *= inv;
         __syncthreads();
-        const int m = D - j - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            const int i = e / m, c = e - i * m;
-            if (c <= i) sm[(j + 1 + i) * ld + j + 1 + c] -= sm[(j + 1 + i) * ld + j] * sm[(j + 1 + c) * ld + j];
+        for (int i = j + 1 + ti; i < D; i += 16) {
+            const double lij = sm[i * ld + j];
+            for (int c = j + 1 + tj; c <= i; c += 16) sm[i * ld + c] = fma(-lij, sm[c * ld + j], sm[i * ld + c]);
         }
         __syncthreads();
     }

@@ -271,6 +271,10 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
 //     through Gamma would be hundreds of nats too low), as the reference value v;
 //   lists every other pair with u' >= v - 100 ln 2, and builds the row's record (C nearest components + rest bound) on the way,
 // so that the pass continues exactly like one on records (gather -> rec_finish_kernel) and later passes can switch to them.
+// PREV: instead of only the previous best component, ALL pairs that were active in the previous pass (the M-step's
+// lists, still in the workspace: no list building for this round) have just been evaluated under the new parameters;
+// `masks` holds them on entry.  The reference value is the largest of them.
+template <bool PREV>
 __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict__ u, int64_t npad, int64_t n_rows, int K,
                                                              const double* __restrict__ drift,
                                                              const double* __restrict__ c_new,
@@ -297,8 +301,24 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
     int listed = 0, over_i = 0;
     if (valid) {
         const double ninf = -__builtin_huge_val();
-        const int kb = khat[n];
-        const double vb = u[(int64_t)kb * npad + n];           // exact, new parameters
+        const int kb = PREV ? -1 : khat[n];
+        unsigned long long fresh[4] = {0ull, 0ull, 0ull, 0ull};      // pairs already exact under the new parameters
+        double vb = ninf;
+        if (PREV) {
+            for (int w = 0; w < W; ++w) {
+                fresh[w] = masks[(int64_t)w * npad + n];
+                unsigned long long m = fresh[w];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const double v = u[(int64_t)(64 * w + b) * npad + n];
+                    vb = (v > vb || v != v) ? v : vb;
+                }
+            }
+        } else {
+            fresh[kb >> 6] = 1ull << (kb & 63);
+            vb = u[(int64_t)kb * npad + n];
+        }
         const double thr = vb - k100Ln2;
         const bool over = !(thr > ninf);                       // NaN / -inf: nothing to compare with
         float ds[kRecSlots], vs[kRecSlots];
@@ -312,8 +332,12 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
         float rest = -__builtin_huge_valf();
         for (int k = 0; k < K; ++k) {
             const double c = sc[k];
-            if (k == kb && !over) {
-                rec_insert(ds, ks, vs, rest, -1.0f, (unsigned short)(k | kRecExactBit), f32_up(vb));
+            if (!over && ((fresh[k >> 6] >> (k & 63)) & 1ull)) {
+                // exact already: competes for a slot by its distance (the single reference pair of the !PREV form is
+                // inserted at distance -1 so that it always keeps one)
+                const double v = u[(int64_t)k * npad + n];
+                rec_insert(ds, ks, vs, rest, PREV ? f32_down(dist_of(c, v)) : -1.0f, (unsigned short)(k | kRecExactBit | kRecListed),
+                           f32_up(v));
                 continue;
             }
             const double d = dist_of(sco[k], u[(int64_t)k * npad + n]);
@@ -329,10 +353,23 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
             }
             rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), f32_up(ub));
         }
-        if (!over) {          // the reference pair was inserted at distance -1 so that it always keeps a slot
+        if (!over) {
+            // exact pairs that did not get a slot are listed again (rec_finish_kernel finds the evaluated pairs of a row
+            // through its slots and its candidate mask); those in slots are exact and need nothing
+            unsigned long long in_slot[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
-            for (int j = 0; j < kRecSlots; ++j)
-                if (ks[j] != kRecEmpty && (ks[j] & kRecExactBit)) ds[j] = f32_down(dist_of(sc[kb], vb));
+            for (int j = 0; j < kRecSlots; ++j) {
+                if (ks[j] == kRecEmpty || !(ks[j] & kRecExactBit)) continue;
+                const int k = ks[j] & kRecCompMask;
+                in_slot[k >> 6] |= 1ull << (k & 63);
+                ks[j] = (unsigned short)(ks[j] & ~kRecListed);               // exact, in a slot: not a candidate
+                if (!PREV) ds[j] = f32_down(dist_of(sc[k], vb));
+            }
+            for (int w = 0; w < W; ++w) {
+                const unsigned long long lost = fresh[w] & ~in_slot[w];
+                mk[w] |= lost;
+                listed += __builtin_popcountll(lost);
+            }
         }
         unsigned sel = 0, ex = 0;
         int in_slots = 0;

@@ -62,6 +62,8 @@ struct gmmvb_workspace {
     bool ctr_pending = false;          // a copy is in flight ...
     int pend_mode = 0;                 // ... of an E-step of this mode over pend_rows rows
     int64_t pend_rows = 0;
+    double pend_round0 = 0.0;          // pairs that E-step evaluated before its counted selection round
+    bool sweep_prev = false;           // the last sweep's first round used the previous pass's M-step lists
     bool lag_valid = false;            // lag_* = counters of the most recent E-step whose copy has arrived
     double lag_act = 0.0, lag_eval = 0.0, lag_over = 0.0;
     int64_t lag_rows = 0;
