@@ -338,35 +338,46 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
 }
 
 // r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0
+// (iperm: the caller's row -> internal row, null = identity; see "rows grouped by their dominant component")
 __global__ void load_r_kernel(const double* __restrict__ r, int64_t n_rows, int K, double* __restrict__ buf,
-                              int64_t npad, double* __restrict__ lse) {
+                              int64_t npad, double* __restrict__ lse, const int* __restrict__ iperm) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_rows) return;
-    for (int k = 0; k < K; ++k) buf[(int64_t)k * npad + n] = r[n * K + k];
-    lse[n] = 0.0;
+    const int64_t m = iperm ? iperm[n] : n;
+    for (int k = 0; k < K; ++k) buf[(int64_t)k * npad + m] = r[n * K + k];
+    lse[m] = 0.0;
 }
 
 // mode 0: ln rho; mode 1: r = exp(ln rho - lse) (or the stored r in direct mode)
 __global__ void readout_kernel(const double* __restrict__ buf, const double* __restrict__ lse, int64_t npad,
                                int64_t row0, int64_t n_rows, int K, int mode, int direct_r,
-                               double* __restrict__ out) {
+                               double* __restrict__ out, const int* __restrict__ iperm) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rows * K) return;
     const int64_t n = e / K;
     const int k = (int)(e - n * K);
-    const double v = buf[(int64_t)k * npad + row0 + n];
-    out[e] = (mode == 0 || direct_r) ? v : exp(v - lse[row0 + n]);
+    const int64_t m = iperm ? iperm[row0 + n] : row0 + n;
+    const double v = buf[(int64_t)k * npad + m];
+    out[e] = (mode == 0 || direct_r) ? v : exp(v - lse[m]);
+}
+
+// z[i] = src[iperm[row0 + i]] (the best components rec_finish_kernel left, in the caller's row order)
+__global__ void gather_int_kernel(const int* __restrict__ src, int64_t row0, int64_t n_rows, const int* __restrict__ iperm,
+                                  int32_t* __restrict__ z) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_rows) z[n] = src[iperm ? iperm[row0 + n] : row0 + n];
 }
 
 // first maximiser over k, like numpy.argmax on the reference's r_vecs (_gaussianmixture.py:1191)
 __global__ void argmax_kernel(const double* __restrict__ buf, int64_t npad, int64_t row0, int64_t n_rows, int K,
-                              int32_t* __restrict__ z) {
+                              int32_t* __restrict__ z, const int* __restrict__ iperm) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_rows) return;
-    double best = buf[row0 + n];
+    const int64_t m = iperm ? iperm[row0 + n] : row0 + n;
+    double best = buf[m];
     int arg = 0;
     for (int k = 1; k < K; ++k) {
-        const double v = buf[(int64_t)k * npad + row0 + n];
+        const double v = buf[(int64_t)k * npad + m];
         if (v > best) {
             best = v;
             arg = k;
@@ -445,6 +456,45 @@ __global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int
     } else {
         h[k] = v;
     }
+}
+
+// ---- rows grouped by their dominant component ----------------------------------------------------------------------
+// Once the responsibilities are sparse, almost all work is per (row, dominant component) pair; with the rows of a
+// component scattered over the matrix every list-driven access (x rows in the gather and in the list M-step, ln rho /
+// lse entries) is a random 0.5 - 1 KB or 8-byte access.  At a bound pass the workspace therefore regroups its INTERNAL
+// row order: internal row i holds the caller's row perm[i], rows with the same best component are contiguous (in
+// ascending original order within a component: the grouping is a stable counting sort, deterministic).  Lists of
+// ascending internal rows then are (almost) contiguous runs.  The caller never sees the internal order: read-outs and
+// gmmvb_load_responsibilities translate through iperm.  Statistics are sums over rows: only their rounding changes.
+//
+// perm_new[start_k + j] = perm_old[lists[k][j]] (perm_old null: identity); lists[k] = ascending internal rows whose
+// best component is k (select_mask_kernel<3> + scan_counts + fill_lists).  gridDim = (blocks over j, K).
+__global__ __launch_bounds__(256) void perm_compose_kernel(const int* __restrict__ lists, int64_t cap,
+                                                           const int* __restrict__ counts, const int* __restrict__ perm_old,
+                                                           int* __restrict__ perm_new) {
+    const int k = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= counts[k]) return;
+    int64_t start = 0;
+    for (int q = 0; q < k; ++q) start += counts[q];
+    const int src = lists[(int64_t)k * cap + j];
+    perm_new[start + j] = perm_old ? perm_old[src] : src;
+}
+
+__global__ void perm_invert_kernel(const int* __restrict__ perm, int64_t n_rows, int* __restrict__ iperm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) iperm[perm[i]] = (int)i;
+}
+
+// xp[i][:] = x[perm[i]][:] (packed, ld = D)
+template <typename XT>
+__global__ void permute_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                    const int* __restrict__ perm, XT* __restrict__ xp) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * D) return;
+    const int64_t i = e / D;
+    const int f = (int)(e - i * D);
+    xp[e] = x[(int64_t)perm[i] * ldx + f];
 }
 
 }  // namespace gmmvb

@@ -127,6 +127,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         const char* v = std::getenv("GMMVB_MSTEP_SPARSE");         // "0" = always the dense M-step
         ws->sparse = !(v && std::strcmp(v, "0") == 0);
         if (max_rows > 2000000000) ws->sparse = false;             // the sample lists hold 32-bit row numbers
+        v = std::getenv("GMMVB_SORT_ROWS");
+        ws->sort_rows = !(v && std::strcmp(v, "0") == 0) && (int64_t)max_rows <= 2000000000;
         v = std::getenv("GMMVB_ESTEP_PRUNE");
         ws->prune = (v && std::strcmp(v, "0") == 0) ? 0 : ((v && std::strcmp(v, "force") == 0) ? 2 : 1);
         if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;
@@ -182,7 +184,8 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart};
-    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan, ws->plan_m};
+    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
+    if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
@@ -383,6 +386,14 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_exact, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_sel, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_flags, (size_t)np);
+    const size_t esz = ws->x_dtype == GMMVB_F64 ? 8 : 4;
+    if (ws->sort_rows) {
+        if (e == hipSuccess) e = hipMalloc(&ws->xp, (size_t)ws->max_rows * ws->D * esz);
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->perm, (size_t)np * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->iperm, (size_t)np * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->perm_tmp, (size_t)np * sizeof(int));
+        if (e == hipSuccess) ws->bytes += (int64_t)ws->max_rows * ws->D * (int64_t)esz + 3 * np * (int64_t)sizeof(int);
+    }
     if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (sample lists / records)", e);
     ws->bytes += ((int64_t)ws->K * np + np + 2 * ws->K + 1 + sel_blocks * ws->K) * (int64_t)sizeof(int) + words * np * 8 +
                  2 * sel_blocks * 8 + np * (kRecSlots * 6 + 4 + 3);
@@ -444,6 +455,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
     if (rc) return rc;
     ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
+    ws->sorted = false;                // ... and the internal row order is the caller's again
     ws->rec_valid = false;
     ws->dense_valid = false;
     ws->lag_valid = false;
@@ -465,6 +477,44 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->xc_rows = n_rows;
     ws->xc_ldx = ldx;
     return GMMVB_OK;
+}
+
+// Regroup the internal row order by the best component of the last E-step (aux_kernels.h): new permutation, permuted copy
+// of x, centred copy rebuilt from it.  Everything row-indexed in the workspace is stale afterwards: the caller (a bound
+// pass) rebuilds it.
+static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, hipStream_t st) {
+    const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
+    hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K, ws->khat,
+                       ws->masks, ws->blk);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
+    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K, ws->blk,
+                       ws->lists, ws->npad);
+    hipLaunchKernelGGL(perm_compose_kernel, dim3((unsigned)((n_rows + 255) / 256), ws->K), dim3(256), 0, st, ws->lists, ws->npad,
+                       ws->counts, ws->sorted ? ws->perm : nullptr, ws->perm_tmp);
+    std::swap(ws->perm, ws->perm_tmp);
+    hipLaunchKernelGGL(perm_invert_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->perm, n_rows, ws->iperm);
+    const int64_t total = n_rows * ws->D;
+    const unsigned pg = (unsigned)((total + 255) / 256);
+    if (ws->x_dtype == GMMVB_F64)
+        hipLaunchKernelGGL(permute_rows_kernel<double>, dim3(pg), dim3(256), 0, st, (const double*)x_dev, ldx, n_rows, ws->D,
+                           ws->perm, (double*)ws->xp);
+    else
+        hipLaunchKernelGGL(permute_rows_kernel<float>, dim3(pg), dim3(256), 0, st, (const float*)x_dev, ldx, n_rows, ws->D,
+                           ws->perm, (float*)ws->xp);
+    if (ws->xc) {
+        const int Dp = 16 * ws->T;
+        const int64_t pad_rows = round_up(n_rows, 64) + 64;
+        const unsigned cg = (unsigned)((pad_rows * Dp + 255) / 256);
+        if (ws->x_dtype == GMMVB_F64)
+            hipLaunchKernelGGL(center_rows_kernel<double>, dim3(cg), dim3(256), 0, st, (const double*)ws->xp, (int64_t)ws->D, n_rows,
+                               pad_rows, ws->D, Dp, ws->pivot, ws->xc);
+        else
+            hipLaunchKernelGGL(center_rows_kernel<float>, dim3(cg), dim3(256), 0, st, (const float*)ws->xp, (int64_t)ws->D, n_rows,
+                               pad_rows, ws->D, Dp, ws->pivot, ws->xc);
+    }
+    ws->sorted = true;
+    ++ws->sorts;
+    return hipGetLastError();
 }
 
 // bound pass of the pruned E-step: an upper bound of ln rho for every pair (int8 digits, or leading f64 blocks) and khat
@@ -515,6 +565,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool i8 = ws->estep_variant == kEstepI8;
     EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
     EstepI8Args a8{x_dev, ldx, n_rows, ws->D, ws->img_i8, ws->pivot_i8, ws->cvec, ws->K, ws->lnrho, ws->npad};
+    if (ws->sorted && ws->xc_src != x_dev) ws->sorted = false;      // another matrix: the caller's order
     const char* name = "";
     hipError_t e = hipSuccess;
     const double pairs = (double)n_rows * ws->K;
@@ -625,6 +676,20 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int64_t grid = 0;
     if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
     ws->n_spans = 0;
+    // a bound pass rebuilds everything row-indexed anyway: the moment to regroup the internal row order by the best
+    // component of the previous pass (once at most 4 components per row are active: later passes are list-driven)
+    if (mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
+        ws->lag_act <= 4.0 * (double)n_rows && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx) {
+        span_begin(ws, kSpanSelect, st);
+        e = regroup_rows(ws, x_dev, ldx, n_rows, st);
+        span_end(ws, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "regrouping the rows", e);
+    }
+    if (ws->sorted) {           // the kernels read the workspace's permuted copy
+        a.x = a8.x = ws->xp;
+        a.ldx = a8.ldx = ws->D;
+        vec = ws->D % 16 == 0;
+    }
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
     const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
     bool counted = false;
@@ -809,7 +874,7 @@ int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_
     if (n_rows < 1 || n_rows > ws->max_rows) return fail(GMMVB_EINVAL, "n_rows must be in [1, max_rows]");
     const int tb = 256;
     hipLaunchKernelGGL(load_r_kernel, dim3((unsigned)((n_rows + tb - 1) / tb)), dim3(tb), 0, (hipStream_t)stream,
-                       r_dev, n_rows, ws->K, ws->lnrho, ws->npad, ws->lse);
+                       r_dev, n_rows, ws->K, ws->lnrho, ws->npad, ws->lse, ws->sorted ? ws->iperm : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "load_r launch", e);
     ws->e_state = 2;
@@ -854,6 +919,8 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         a.x = ws->xc;
         a.ldx = 16 * ws->T;
         a.D = 16 * ws->T;
+    } else if (ws->sorted) {
+        return fail(GMMVB_ESTATE, "the workspace's rows are regrouped for another sample matrix: call gmmvb_prepare_rows first");
     }
     const char* name = "";
     hipError_t e;
@@ -947,14 +1014,15 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
     if (ws->e_state == 1 && ws->rec_live) {                    // the pass lived on records: only listed pairs are exact
         const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
         hipLaunchKernelGGL(rec_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec,
-                           ws->masks, ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out);
+                           ws->masks, ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out,
+                           ws->sorted ? ws->iperm : nullptr);
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return fail(GMMVB_EHIP, "rec_readout launch", er);
         return GMMVB_OK;
     }
     hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        hmm_gamma ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->lse, ws->npad, row0, n_rows, ws->K, mode,
-                       (ws->e_state == 2 || hmm_gamma) ? 1 : 0, out);
+                       (ws->e_state == 2 || hmm_gamma) ? 1 : 0, out, ws->sorted ? ws->iperm : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "readout launch", e);
     return GMMVB_OK;
@@ -973,14 +1041,16 @@ int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_d
     if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
     hipError_t e;
+    const int* iperm = ws->sorted ? ws->iperm : nullptr;
     if (ws->e_state == 1 && ws->rec_live) {        // rec_finish_kernel left every row's first maximiser in khat
-        e = hipMemcpyAsync(z_dev, ws->khat + row0, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice,
-                           (hipStream_t)stream);
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax copy", e);
+        hipLaunchKernelGGL(gather_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           ws->khat, row0, n_rows, iperm, z_dev);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax read-out", e);
         return GMMVB_OK;
     }
     hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->npad, row0, n_rows, ws->K, z_dev);
+                       ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->npad, row0, n_rows, ws->K, z_dev, iperm);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax launch", e);
     return GMMVB_OK;

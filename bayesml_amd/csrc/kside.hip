@@ -57,8 +57,16 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double* __restrict_
         double v = 0.0;
         const int i = j + 1 + tid;
         if (i < D) {
-            for (int p = j + 1; p <= i; ++p) v = fma(sm[i * ld + p], sm[p * ld + j], v);
-            v = -v * xjj;
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;          // four independent chains: the LDS latency is the cost here
+            int p = j + 1;
+            for (; p + 3 <= i; p += 4) {
+                v = fma(sm[i * ld + p], sm[p * ld + j], v);
+                v1 = fma(sm[i * ld + p + 1], sm[(p + 1) * ld + j], v1);
+                v2 = fma(sm[i * ld + p + 2], sm[(p + 2) * ld + j], v2);
+                v3 = fma(sm[i * ld + p + 3], sm[(p + 3) * ld + j], v3);
+            }
+            for (; p <= i; ++p) v = fma(sm[i * ld + p], sm[p * ld + j], v);
+            v = -((v + v1) + (v2 + v3)) * xjj;
         }
         __syncthreads();
         if (i < D) sm[i * ld + j] = v;

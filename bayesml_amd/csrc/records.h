@@ -639,10 +639,10 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict
 __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __restrict__ masks,
                                    const double* __restrict__ lnrho, const double* __restrict__ lse,
                                    const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
-                                   int mode, double* __restrict__ out) {
+                                   int mode, double* __restrict__ out, const int* __restrict__ iperm) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rows * K) return;
-    const int64_t n = row0 + e / K;
+    const int64_t n = iperm ? iperm[row0 + e / K] : row0 + e / K;
     const int k = (int)(e % K);
     bool exact = ((masks[(int64_t)(k >> 6) * npad + n] >> (k & 63)) & 1ull) != 0 || (rec.flags[n] & 1) != 0;
     if (mode == 1) {

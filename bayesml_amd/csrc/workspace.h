@@ -89,6 +89,12 @@ struct gmmvb_workspace {
     int* blk = nullptr;        // [ceil(npad / 256)][K] candidates per selection block -> block bases
     unsigned long long* masks = nullptr;   // [ceil(K / 64)][npad] candidate components of every sample
     double* slabs = nullptr;   // [S_cap][K][slab_len]
+    // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
+    void* xp = nullptr;        // [max_rows][D] x in internal row order (storage dtype), allocated with the lists
+    int* perm = nullptr, *iperm = nullptr, *perm_tmp = nullptr;   // [npad] each
+    bool sorted = false;       // xp / perm / iperm are in force for the matrix xc_src (else the internal order is the caller's)
+    bool sort_rows = true;     // env GMMVB_SORT_ROWS=0: never regroup
+    int64_t sorts = 0;         // regroupings since the workspace was created
     double* xc = nullptr;      // [npad][16T] centred f64 copy of the sample matrix (M-step operand), optional
     const void* xc_src = nullptr;   // the x it was made from (null = not prepared)
     int64_t xc_rows = 0, xc_ldx = 0;
