@@ -183,7 +183,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
-                      ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart};
+                      ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart};
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags};
@@ -380,6 +380,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->epart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->opart, (size_t)sel_blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->mpart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_k, (size_t)kRecSlots * np * sizeof(unsigned short));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_d, (size_t)kRecSlots * np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_B, (size_t)np * sizeof(float));
@@ -413,6 +414,9 @@ static int fetch_counters(gmmvb_workspace* ws) {
         } else {                               // a bound pass / sweep also evaluated every row's (previous) best component
             ws->lag_eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? ws->pend_round0 : 0.0);
             ws->lag_over = ws->ctr_host[2];
+            // rows whose best component changed: after a regrouping they no longer sit with their component's rows.
+            // (the first pass after a regrouping compares with the bound kernel's guess, not with a previous best)
+            if (ws->sorted && !ws->pend_first_sorted) ws->moved_since_sort += ws->ctr_host[3];
         }
         ws->lag_rows = ws->pend_rows;
         ws->lag_mode = ws->pend_mode;
@@ -600,7 +604,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th).
             const double tg = ws->typical_gamma;
             bool carry = hinted && ws->rec_valid && !(tg > 0.0 && tg < 0.985);
-            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && ws->sweeps < 8;
+            // (the sweep's bounds erode by each component's own gamma: the spare-candidate rule below ends a run of
+            // sweeps when a fresh bound pass has become cheaper; 24 in a row at most)
+            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && ws->sweeps < 24;
             if ((carry || sweep) && known && ws->lag_mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
@@ -678,12 +684,16 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->n_spans = 0;
     // a bound pass rebuilds everything row-indexed anyway: the moment to regroup the internal row order by the best
     // component of the previous pass (once at most 4 components per row are active: later passes are list-driven)
+    bool sorted_now = false;
     if (mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
-        ws->lag_act <= 4.0 * (double)n_rows && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx) {
+        ws->lag_act <= 4.0 * (double)n_rows && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
+        (!ws->sorted || ws->moved_since_sort > 0.05 * (double)n_rows)) {     // (again once 5 % of the rows have moved on)
         span_begin(ws, kSpanSelect, st);
         e = regroup_rows(ws, x_dev, ldx, n_rows, st);
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "regrouping the rows", e);
+        ws->moved_since_sort = 0.0;
+        sorted_now = true;
     }
     if (ws->sorted) {           // the kernels read the workspace's permuted copy
         a.x = a8.x = ws->xp;
@@ -722,7 +732,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                ws->ctr);
             hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
                                ws->K, ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
-            hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, st, ws->apart, nullptr, nullptr, sel_grid, ws->ctr);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, st, ws->apart, nullptr, nullptr, nullptr, sel_grid, ws->ctr);
             // records for the next pass (one more sweep of the array, ~1 % of the dense kernel's time)
             if (can_prune && big)
                 hipLaunchKernelGGL(rec_build_kernel<false>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
@@ -823,8 +833,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
         span_begin(ws, kSpanLse, st);
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(3), dim3(256), 0, st, ws->apart, ws->epart, ws->opart, sel_grid, ws->ctr);
+                           ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(4), dim3(256), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, sel_grid,
+                           ws->ctr);
         e = hipGetLastError();
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "rec_finish launch", e);
@@ -843,6 +854,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->pend_rows = n_rows;
         // pairs evaluated before the counted selection: every row's best component, or (sweep over the previous
         // pass's lists) the previous pass's active pairs
+        ws->pend_first_sorted = sorted_now;
         ws->pend_round0 = (mode == kSweep && ws->sweep_prev && known) ? ws->lag_act : (double)n_rows;
         ws->act_rows = n_rows;
     } else {

@@ -426,9 +426,10 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               int64_t n_rows, int K, const double* __restrict__ cvec,
                                                               double* __restrict__ lse, int* __restrict__ khat,
                                                               unsigned long long* __restrict__ masks,
-                                                              int* __restrict__ blk_cnt, double* __restrict__ apart) {
+                                                              int* __restrict__ blk_cnt, double* __restrict__ apart,
+                                                              double* __restrict__ mpart /*rows whose best component changed*/) {
     __shared__ int wcnt[4][256];
-    __shared__ int wact[4];
+    __shared__ int wact[4], wmov[4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
     for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     const bool valid = n < n_rows;
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
     int active = 0;
+    const int khat_before = valid ? khat[n] : 0;
     const unsigned fl = valid ? rec.flags[n] : 0u;
     if (valid && fl == 2u) {
         // refreshed row: slots (exact where listed, carried bounds otherwise) and the listed components without a slot
@@ -605,22 +607,33 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     if (valid)
         for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
     for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+    int moved = (valid && khat[n] != khat_before) ? 1 : 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o);
-    if ((tid & 63) == 0) wact[wave] = active;
+    for (int o = 32; o > 0; o >>= 1) {
+        active += __shfl_xor(active, o);
+        moved += __shfl_xor(moved, o);
+    }
+    if ((tid & 63) == 0) {
+        wact[wave] = active;
+        wmov[wave] = moved;
+    }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
         blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
-    if (tid == 0) apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
+    if (tid == 0) {
+        apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
+        mpart[blockIdx.x] = (double)(wmov[0] + wmov[1] + wmov[2] + wmov[3]);
+    }
 }
 
-// ctr[0] = sum apart (active pairs), ctr[1] = sum epart (exactly evaluated pairs), ctr[2] = sum opart (overflow rows);
-// a null part leaves its counter as it is.  One workgroup per counter, fixed summation order.
+// ctr[0] = sum apart (active pairs), ctr[1] = sum epart (exactly evaluated pairs), ctr[2] = sum opart (overflow rows),
+// ctr[3] = sum mpart (rows whose best component changed); a null part leaves its counter as it is.  One workgroup per
+// counter, fixed summation order.
 __global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
-                                                        const double* __restrict__ opart, int blocks,
-                                                        double* __restrict__ ctr) {
+                                                        const double* __restrict__ opart, const double* __restrict__ mpart,
+                                                        int blocks, double* __restrict__ ctr) {
     __shared__ double part[256];
-    const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : opart);
+    const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : (blockIdx.x == 2 ? opart : mpart));
     if (!src) return;
     double a = 0.0;
     for (int b = threadIdx.x; b < blocks; b += 256) a += src[b];

@@ -53,7 +53,11 @@ struct gmmvb_workspace {
     int* plan_m = nullptr;             // [K + 2] chunk plan of the list M-step
     double* epart = nullptr;           // [ceil(npad / 256)] listed pairs per selection block
     double* opart = nullptr;           // [ceil(npad / 256)] overflow rows per selection block
-    // counters of an E-step: [0] active pairs (r >= 2^-100), [1] pairs evaluated exactly, [2] overflow rows.
+    double* mpart = nullptr;           // [ceil(npad / 256)] rows whose best component changed, per selection block
+    double moved_since_sort = 0.0;     // their sum over the passes since the rows were last regrouped
+    bool pend_first_sorted = false;    // the E-step whose counters are in flight regrouped the rows
+    // counters of an E-step: [0] active pairs (r >= 2^-100), [1] pairs evaluated exactly, [2] overflow rows,
+    // [3] rows whose best component changed.
     // Written on the device at the end of every E-step and copied to pinned host memory behind an event; the NEXT
     // E-step / M-step reads whatever has arrived (policy decisions lag one pass, results never depend on them).
     double* ctr = nullptr;             // [4] device
