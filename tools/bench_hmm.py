@@ -121,12 +121,25 @@ def main():
         vl = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # HBM roofline (the chunked scan is bandwidth / latency bound, K^2 flops per byte of state are far below the MFMA
+    # balance): algorithmic bytes per time step = the row of x read once (D * 4) + one [K] f64 state vector written by the
+    # forward recursion and read back by the backward one (the reference materialises ln_rho, alpha, beta, gamma [T, K]
+    # and xi [T, K, K]); the kernels of DESIGN.md section 5b sweep about twelve [T][16 ceil(K/16)] f64 arrays per iteration.
+    Kp = 16 * ((K + 15) // 16)
+    alg = D * 4 + 2 * K * 8
+    swept = 12 * Kp * 8 + D * 4 + 16 * ((D + 15) // 16) * 8
+    ms = el / args.steps * 1e3
+    roofline = {"bound": "hbm", "kernel": "whole HMM iteration (emission + chunk products + boundary scan + replays + xi sum + M-step)",
+                "achieved": alg * T / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": alg * T / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_time_step": alg,
+                "estimated_swept_bytes_per_time_step": swept, "estimated_swept_GBps": swept * T / (ms * 1e-3) / 1e9,
+                "hbm_roofline_time_steps_per_s": 8e12 / alg, "traffic": None}
     print(json.dumps({
         "metric": "HMM-VB time steps/sec at K=32,D=16,T=1e7 (BASELINE.json configs[4])", "value": T * args.steps / el,
         "unit": "time steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"HMM-VB K={K} D={D} T={T}, x stored f32, one VB iteration per step"},
-        "cpu_baseline": cpu, "parity": parity, "final_vl": vl}))
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "final_vl": vl}))
 
 
 if __name__ == "__main__":
