@@ -5,9 +5,9 @@ Only the path named by BASELINE.json's ``north_star`` lives here: ``gaussianmixt
 (``csrc/``) behind the C ABI of ``include/gmmvb.h``.  The rest of BayesML is out of scope.
 """
 from . import gaussianmixture, hiddenmarkovnormal, multivariate_normal
-from ._dist import RowShard
+from ._dist import RestartShard, RowShard
 from ._exceptions import (CriteriaError, DataFormatError, ParameterFormatError, ParameterFormatWarning,
                           ResultWarning)
 
-__all__ = ["gaussianmixture", "hiddenmarkovnormal", "multivariate_normal", "RowShard", "ParameterFormatError", "DataFormatError", "CriteriaError",
+__all__ = ["gaussianmixture", "hiddenmarkovnormal", "multivariate_normal", "RowShard", "RestartShard", "ParameterFormatError", "DataFormatError", "CriteriaError",
            "ResultWarning", "ParameterFormatWarning"]

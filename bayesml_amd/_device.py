@@ -66,7 +66,7 @@ class DeviceModel:
         if self._verbose and self._comm.rank == 0:
             print(text, end=end)
 
-    def _subsample_moments(self, eng, xd, n_global):
+    def _subsample_moments(self, eng, xd, n_global, draw_only=False):
         """Raw moments about the pivot of the K sub-samples of the 'subsampling' restart (gaussianmixture
         ref:786-796 / hiddenmarkovnormal ref:952-964).  The host draws the row INDICES with the model's
         Generator — ``rng.choice(x, size, replace=False, axis=0, shuffle=False)`` consumes the stream exactly
@@ -76,7 +76,10 @@ class DeviceModel:
         dev = xd.device
         ab = torch.zeros(K, D + D * D, dtype=torch.float64, device=dev)
         for k in range(K):
-            idx = torch.from_numpy(self.rng.choice(n_global, size=size, replace=False, shuffle=False)).to(dev)
+            draw = self.rng.choice(n_global, size=size, replace=False, shuffle=False)
+            if draw_only:              # another process runs this restart: only keep the Generator's stream in step
+                continue
+            idx = torch.from_numpy(draw).to(dev)
             rows = xd.index_select(0, self._comm.local_indices(idx)).to(torch.float64) - eng.pivot
             ab[k, :D] = rows.sum(dim=0)
             ab[k, D:] = (rows.T @ rows).reshape(-1)

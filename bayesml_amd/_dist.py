@@ -58,6 +58,47 @@ class RowShard:
         return global_idx[sel] - self.row_offset
 
 
+class RestartShard:
+    """Restart-level parallelism for sample matrices small enough to be replicated: every
+    process holds ALL rows; restart i of ``update_posterior`` runs on rank i mod world (each rank still draws every
+    restart's random numbers, so the streams - and the result - are those of a single process), the winner is chosen
+    with the reference's rule over the gathered lower bounds and its posterior is broadcast from its owner.
+    No collective inside a VB iteration."""
+
+    restart_parallel = True
+    row_offset = 0
+
+    def __init__(self, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.local_rows = self.global_rows = 0
+
+    def bind_rows(self, local_rows: int, device) -> "RestartShard":
+        self.local_rows = self.global_rows = int(local_rows)
+        return self
+
+    def all_reduce_(self, t):
+        return t                      # rows are not sharded
+
+    def local_indices(self, global_idx):
+        return global_idx
+
+    def owner(self, restart: int) -> int:
+        return restart % self.world
+
+    def gather(self, obj) -> list:
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def broadcast_(self, tensors, src: int):
+        for t in tensors:
+            dist.broadcast(t, src=src, group=self.group)
+
+
 class SingleProcess:
     """The world_size == 1 stand-in with the same surface (no torch.distributed needed)."""
 

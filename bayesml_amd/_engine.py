@@ -44,6 +44,7 @@ SYMBOLS = {
     "gmmvb_last_launch_info": (ctypes.c_char_p, [_vp]),
     "gmmvb_pass_counts": (_int, [_vp, ctypes.POINTER(_i64)]),
     "gmmvb_kside_factor": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "gmmvb_kside_step": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_kside_drift": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_last_sparsity": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "gmmvb_comm_unique_id": (_int, [_vp]),
@@ -179,6 +180,36 @@ def kside_factor(w_inv: torch.Tensor):
         _check(lib, lib.gmmvb_kside_factor(K, D, w_inv.data_ptr(), g.data_ptr(), g_inv.data_ptr(), logdet.data_ptr(), st),
                "gmmvb_kside_factor")
     return g, g_inv, logdet
+
+
+class _PriorView(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("alpha", "m", "kappa", "nu", "w_inv", "ln_b_w_nu")] + [("ln_c_alpha", ctypes.c_double)]
+
+
+class _PostView(ctypes.Structure):
+    FIELDS = ("alpha", "m", "kappa", "nu", "w_inv", "w", "u", "u_inv", "e_ln_pi", "e_ln_lambda_det", "ln_b_w_nu", "c")
+    _fields_ = [(n, _vp) for n in FIELDS]
+
+
+def post_view(q) -> _PostView:
+    return _PostView(*(getattr(q, f).data_ptr() for f in _PostView.FIELDS))
+
+
+def prior_view(p) -> _PriorView:
+    return _PriorView(p.alpha.data_ptr(), p.m.data_ptr(), p.kappa.data_ptr(), p.nu.data_ptr(), p.w_inv.data_ptr(),
+                      p.ln_b_w_nu.data_ptr(), float(p.ln_c_alpha))
+
+
+def kside_step(K, D, prior_v, q_v, qn_v, stats, pivot, s_prev, ns, x_bar, s, want_drift, gamma, delta, big, scal, scratch):
+    """gmmvb_kside_step on the current stream of ``stats``' device (every tensor contiguous float64 there)."""
+    lib = load_library()
+    dev = stats.device
+    with torch.cuda.device(dev):
+        st = _vp(torch.cuda.current_stream(dev).cuda_stream)
+        _check(lib, lib.gmmvb_kside_step(K, D, ctypes.byref(prior_v), ctypes.byref(q_v), ctypes.byref(qn_v), stats.data_ptr(),
+                                         pivot.data_ptr(), s_prev.data_ptr(), ns.data_ptr(), x_bar.data_ptr(), s.data_ptr(),
+                                         int(want_drift), gamma.data_ptr(), delta.data_ptr(), big.data_ptr(), scal.data_ptr(),
+                                         scratch.data_ptr(), st), "gmmvb_kside_step")
 
 
 def kside_drift(q_old, q_new, squarings: int, squarings_big: int):

@@ -374,13 +374,13 @@ class KStepper:
                          -> [p_x .. vl | min_k (gamma_k - delta_k / 30)] in one small vector (the iteration's single
                             device-to-host copy)
 
-    On a GPU the sequence (about 150 small torch kernels) is captured once in a hipGraph and replayed: the K-side
-    costs one graph launch per iteration instead of ~2 ms of launches.  The factorisation inside is the library's
-    own kernel (csrc/kside.hip), so nothing in the graph needs MAGMA / rocSOLVER handles.  ``q`` (the posterior
-    whose parameters the engine currently holds) and ``q_next`` live in fixed buffers; ``advance()`` makes q_next
-    the current one.  On the CPU (host-logic tests) the same functions run eagerly.
-
-    BAYESML_AMD_KSIDE_GRAPH=0 disables the capture."""
+    On a GPU (D <= 128) all of it is ONE C-ABI call, gmmvb_kside_step (csrc/kside.hip): one workgroup per component
+    assembles, factorises and inverts W'^-1 in LDS and forms the lower bound's traces on the way; a second launch gives
+    the drift hint, a third adds the per-component terms.  ``q`` (the posterior whose parameters the engine holds) and
+    ``q_next`` are two fixed buffer sets that ``advance()`` swaps.  The functions of this module remain the executable
+    specification: they run eagerly on the CPU (host-logic tests), and on a GPU - captured once in a hipGraph and
+    replayed - with BAYESML_AMD_KSIDE_FUSED=0 (BAYESML_AMD_KSIDE_GRAPH=0: eagerly); tests/test_gpu_kside.py holds the
+    kernel to them."""
 
     def __init__(self, prior: PriorT, pivot: torch.Tensor, stats_len: int, want_drift: bool):
         import os
@@ -402,6 +402,12 @@ class KStepper:
         self._graph = None
         self._calls = 0
         self._use_graph = dev.type == "cuda" and os.environ.get("BAYESML_AMD_KSIDE_GRAPH", "1") != "0"
+        self._fused = dev.type == "cuda" and D <= 128 and os.environ.get("BAYESML_AMD_KSIDE_FUSED", "1") != "0"
+        if self._fused:
+            from . import _engine
+            self._eng = _engine
+            self._prior_v = _engine.prior_view(prior)
+            self._scratch = torch.zeros(13 * K, dtype=torch.float64, device=dev)
 
     def load(self, q: PostT):
         """Make ``q`` (with its features) the current posterior."""
@@ -437,6 +443,12 @@ class KStepper:
         """Run the K-side on ``self.stats`` (already all-reduced).  Results: ns, x_bar, s, q_next, gamma, delta,
         big_gamma, scal."""
         self._calls += 1
+        if self._fused:
+            e = self._eng
+            e.kside_step(self.K, self.D, self._prior_v, e.post_view(self.q), e.post_view(self.q_next), self.stats, self.pivot,
+                         self.s_prev, self.ns, self.x_bar, self.s, self.want_drift, self.gamma, self.delta, self.big_gamma,
+                         self.scal, self._scratch)
+            return
         if self._use_graph and self._graph is None and self._calls >= 2:
             try:                                    # the first call ran eagerly (library / BLAS warm-up)
                 torch.cuda.synchronize()
@@ -466,7 +478,10 @@ class KStepper:
 
     def advance(self):
         """q <- q_next (after the engine has been given q_next's parameters)."""
-        _copy_post(self.q, self.q_next)
+        if self._fused:
+            self.q, self.q_next = self.q_next, self.q          # two fixed buffer sets: no copy
+        else:
+            _copy_post(self.q, self.q_next)
 
     def current(self) -> PostT:
         return _clone_post(self.q)

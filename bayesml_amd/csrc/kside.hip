@@ -7,6 +7,8 @@
 // no host synchronisation, no allocation: the whole K-side can be captured in a hipGraph.
 #include "workspace.h"
 
+#include <cstring>
+
 namespace gmmvb {
 
 // One workgroup per matrix.  a [K][D][D] symmetric positive definite (row-major; only the lower triangle is read).
@@ -207,6 +209,245 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
     }
 }
 
+// ---- the whole K-side of one VB iteration in one launch per component ---------------------------------------------------
+// What the reference does between two data passes (bayesml/gaussianmixture/_gaussianmixture.py):
+//   _calc_n_x_bar_s's finishing (:729-732)  x_bar = p + a/ns,  S = B/ns - (a/ns)(a/ns)^T   (ns > 0; else 0 / the previous S)
+//   _calc_vl (:671-723)                      the lower bound's K-sized terms under the CURRENT posterior q
+//   _update_q_mu_lambda, _update_q_pi (:741-770)   q' from the prior and (ns, x_bar, S)
+//   _calc_q_*_features (:738-756)            E[ln pi], E[ln det Lambda], ln B(W, nu) of q', and what the E-step kernel
+//                                            consumes: u' = sqrt(nu') G^-1 (W'^-1 = G G^T), c'
+// One workgroup per component: W'^-1 is assembled straight into LDS, factorised and inverted there (as in
+// chol_inv_kernel), W' = G^-T G^-1 formed from it; the traces / quadratic forms of the lower bound are one pass over
+// the D x D entries with a fixed-order block reduction.  kside_finish_kernel adds the per-component partial terms in
+// component order (deterministic) and forms the eight lower-bound terms, their sum, and the drift summary.
+struct PriorView {
+    const double *alpha, *m, *kappa, *nu, *w_inv, *ln_b_w_nu;
+    double ln_c_alpha;
+};
+struct PostView {
+    double *alpha, *m, *kappa, *nu, *w_inv, *w, *u, *u_inv, *e_ln_pi, *e_ln_lambda_det, *ln_b_w_nu, *c;
+};
+constexpr int kPartials = 12;      // per component: p_x, p_z, (a0-1)E[ln pi], p_mu_lambda, h, lgamma(a), (a-1)psi(a), a, q_mu_lambda
+
+// psi(x), x > 0: recurrence up to x >= 10, then the asymptotic series to x^-14 (remainder < 2e-16 there)
+__device__ inline double digamma_pos(double x) {
+    double r = 0.0;
+    while (x < 10.0) {
+        r -= 1.0 / x;
+        x += 1.0;
+    }
+    const double i2 = 1.0 / (x * x);
+    const double ser = i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0 -
+                       i2 * (691.0 / 32760.0 - i2 * (1.0 / 12.0)))))));
+    return r + log(x) - 0.5 / x - ser;
+}
+
+// deterministic block sum of NV values per thread (256 threads): wave shuffles, then the four wave results in order
+template <int NV>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /*[4 * NV]*/) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[(threadIdx.x >> 6) * NV + q] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = (red[q] + red[NV + q]) + (red[2 * NV + q] + red[3 * NV + q]);
+}
+
+__global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView pr, PostView q, PostView qn,
+                                                         const double* __restrict__ stats, const double* __restrict__ pivot,
+                                                         double* __restrict__ s_prev, double* __restrict__ ns_out,
+                                                         double* __restrict__ x_bar_out, double* __restrict__ s_out,
+                                                         double* __restrict__ partials /*[K][kPartials]*/) {
+    extern __shared__ double sm[];           // mat [D][D + 1] | abar, xbar, dev0, dq, dm [D] each | red [32]
+    const int ld = D + 1;
+    double* mat = sm;
+    double* abar = sm + (size_t)D * ld;
+    double* xbar = abar + D;
+    double* dev0 = xbar + D;
+    double* dq = dev0 + D;
+    double* dm = dq + D;
+    double* red = dm + D;
+    const int tid = threadIdx.x, k = blockIdx.x;
+    const int64_t vb = (int64_t)k * D, mb = (int64_t)k * D * D;
+    const double LN_2PI = 1.8378770664093454835606594728112, LN_2 = 0.69314718055994530941723212145818,
+                 LN_PI = 1.1447298858494001741434273513531;
+    const double ns = stats[k], h = stats[K + k];
+    const double* a = stats + 2 * (int64_t)K + vb;
+    const double* B = stats + 2 * (int64_t)K + (int64_t)K * D + mb;
+    const bool pos = ns > 0.0;
+    const double safe = pos ? ns : 1.0;
+    const double kap0 = pr.kappa[k], nu0 = pr.nu[k], al0 = pr.alpha[k];
+    const double kapq = q.kappa[k], nuq = q.nu[k], alq = q.alpha[k], elpq = q.e_ln_pi[k], eldq = q.e_ln_lambda_det[k];
+    for (int i = tid; i < D; i += 256) {
+        const double ab = a[i] / safe;
+        const double xb = pos ? pivot[i] + ab : 0.0;
+        abar[i] = ab;
+        xbar[i] = xb;
+        dev0[i] = xb - pr.m[vb + i];
+        dq[i] = xb - q.m[vb + i];
+        dm[i] = q.m[vb + i] - pr.m[vb + i];
+        x_bar_out[vb + i] = xb;
+    }
+    __syncthreads();
+    const double kapn = kap0 + ns, nun = nu0 + ns, aln = al0 + ns;
+    const double coef = kap0 * ns / kapn;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};          // tr(S nu W), dq' nu W dq, dm' nu W dm, tr(W0^-1 nu W)
+    for (int e = tid; e < D * D; e += 256) {
+        const int i = e / D, j = e - i * D;
+        const double sij = pos ? B[e] / safe - abar[i] * abar[j] : s_prev[mb + e];
+        s_out[mb + e] = sij;
+        s_prev[mb + e] = sij;
+        const double ew = nuq * q.w[mb + e];
+        const double w0 = pr.w_inv[mb + e];
+        acc[0] = fma(sij, ew, acc[0]);
+        acc[1] = fma(dq[i] * dq[j], ew, acc[1]);
+        acc[2] = fma(dm[i] * dm[j], ew, acc[2]);
+        acc[3] = fma(w0, ew, acc[3]);
+        const double wn = w0 + ns * sij + coef * (dev0[i] * dev0[j]);
+        qn.w_inv[mb + e] = wn;
+        mat[i * ld + j] = j <= i ? wn : 0.0;
+    }
+    block_sum_n<4>(acc, red);
+    if (tid == 0) {
+        double* pt = partials + (int64_t)k * kPartials;
+        pt[0] = 0.5 * ns * (eldq - D / kapq - acc[0] - acc[1] - D * LN_2PI);                                   // p_x
+        pt[1] = ns * elpq;                                                                                     // p_z
+        pt[2] = (al0 - 1.0) * elpq;                                                                            // -> p_pi
+        pt[3] = 0.5 * (D * (log(kap0) - LN_2PI - kap0 / kapq) - kap0 * acc[2] + 2.0 * pr.ln_b_w_nu[k] +
+                       (nu0 - D) * eldq - acc[3]);                                                             // p_mu_lambda
+        pt[4] = h;                                                                                             // -> q_z
+        pt[5] = lgamma(alq);
+        pt[6] = (alq - 1.0) * digamma_pos(alq);
+        pt[7] = alq;
+        pt[8] = 0.5 * (D * (1.0 + LN_2PI - log(kapq)) - 2.0 * q.ln_b_w_nu[k] - (nuq - D) * eldq + nuq * D);    // q_mu_lambda
+        ns_out[k] = ns;
+        qn.alpha[k] = aln;
+        qn.kappa[k] = kapn;
+        qn.nu[k] = nun;
+    }
+    for (int i = tid; i < D; i += 256) qn.m[vb + i] = (kap0 * pr.m[vb + i] + ns * xbar[i]) / kapn;
+    __syncthreads();
+    // ---- Cholesky of W'^-1 in LDS (as in chol_inv_kernel)
+    const int ti = tid >> 4, tj = tid & 15;
+    for (int j = 0; j < D; ++j) {
+        if (tid == 0) mat[j * ld + j] = sqrt(mat[j * ld + j]);
+        __syncthreads();
+        const double inv = 1.0 / mat[j * ld + j];
+        for (int i = j + 1 + tid; i < D; i += 256) mat[i * ld + j] *= inv;
+        __syncthreads();
+        for (int i = j + 1 + ti; i < D; i += 16) {
+            const double lij = mat[i * ld + j];
+            for (int c = j + 1 + tj; c <= i; c += 16) mat[i * ld + c] = fma(-lij, mat[c * ld + j], mat[i * ld + c]);
+        }
+        __syncthreads();
+    }
+    const double sq = sqrt(nun), isq = 1.0 / sq;
+    for (int e = tid; e < D * D; e += 256) {
+        const int i = e / D, j = e - i * D;
+        qn.u_inv[mb + e] = mat[i * ld + j] * isq;             // u'^-1 = G / sqrt(nu')
+    }
+    // log det W'^-1 and the digamma / lgamma sums over d < D
+    double f[3] = {0.0, 0.0, 0.0};
+    for (int d = tid; d < D; d += 256) {
+        f[0] += log(mat[d * ld + d]);
+        f[1] += digamma_pos(0.5 * (nun - d));
+        f[2] += lgamma(0.5 * (nun - d));
+    }
+    block_sum_n<3>(f, red);
+    const double logdet = 2.0 * f[0];
+    const double eld = f[1] + D * LN_2 - logdet;
+    if (tid == 0) {
+        double asum = 0.0;
+        for (int c = 0; c < K; ++c) asum += pr.alpha[c] + stats[c];
+        const double elp = digamma_pos(aln) - digamma_pos(asum);
+        qn.e_ln_pi[k] = elp;
+        qn.e_ln_lambda_det[k] = eld;
+        qn.ln_b_w_nu[k] = 0.5 * (nun * logdet - nun * D * LN_2 - 0.5 * D * (D - 1) * LN_PI - 2.0 * f[2]);
+        qn.c[k] = elp + 0.5 * (eld - D * LN_2PI - D / kapn);
+    }
+    __syncthreads();
+    // ---- in-place inverse of the factor
+    for (int j = D - 1; j >= 0; --j) {
+        const double xjj = 1.0 / mat[j * ld + j];
+        double v = 0.0;
+        const int i = j + 1 + tid;
+        if (i < D) {
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int p = j + 1;
+            for (; p + 3 <= i; p += 4) {
+                v = fma(mat[i * ld + p], mat[p * ld + j], v);
+                v1 = fma(mat[i * ld + p + 1], mat[(p + 1) * ld + j], v1);
+                v2 = fma(mat[i * ld + p + 2], mat[(p + 2) * ld + j], v2);
+                v3 = fma(mat[i * ld + p + 3], mat[(p + 3) * ld + j], v3);
+            }
+            for (; p <= i; ++p) v = fma(mat[i * ld + p], mat[p * ld + j], v);
+            v = -((v + v1) + (v2 + v3)) * xjj;
+        }
+        __syncthreads();
+        if (i < D) mat[i * ld + j] = v;
+        if (tid == 0) mat[j * ld + j] = xjj;
+        __syncthreads();
+    }
+    // u' = sqrt(nu') G^-1 and W' = G^-T G^-1 (upper triangle computed, mirrored: exactly symmetric)
+    for (int e = tid; e < D * D; e += 256) {
+        const int i = e / D, j = e - i * D;
+        qn.u[mb + e] = mat[i * ld + j] * sq;
+        if (i <= j) {
+            double w = 0.0;
+            for (int p = j; p < D; ++p) w = fma(mat[p * ld + i], mat[p * ld + j], w);
+            qn.w[mb + e] = w;
+            qn.w[mb + (int64_t)j * D + i] = w;
+        }
+    }
+}
+
+// scal = [p_x, p_z, p_pi, p_mu_lambda, q_z, q_pi, q_mu_lambda, vl, drift summary min_k (gamma_k - delta_k / 30)]
+__global__ void kside_finish_kernel(int K, const double* __restrict__ partials, double ln_c_alpha,
+                                    const double* __restrict__ gamma, const double* __restrict__ delta,
+                                    double* __restrict__ scal) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double t[kPartials];
+    for (int q = 0; q < kPartials; ++q) t[q] = 0.0;
+    for (int k = 0; k < K; ++k)
+        for (int q = 0; q < 9; ++q) t[q] += partials[(int64_t)k * kPartials + q];
+    const double a0 = t[7];
+    const double p_x = t[0], p_z = t[1], p_pi = ln_c_alpha + t[2], p_ml = t[3], q_z = -t[4];
+    const double q_pi = (t[5] - lgamma(a0)) + (a0 - K) * digamma_pos(a0) - t[6];      // entropy of Dirichlet(alpha)
+    const double q_ml = t[8];
+    scal[0] = p_x;
+    scal[1] = p_z;
+    scal[2] = p_pi;
+    scal[3] = p_ml;
+    scal[4] = q_z;
+    scal[5] = q_pi;
+    scal[6] = q_ml;
+    scal[7] = p_x + p_z + p_pi + p_ml + q_z + q_pi + q_ml;
+    double g = 0.0;
+    if (gamma) {
+        g = __builtin_huge_val();
+        for (int k = 0; k < K; ++k) {
+            const double v = gamma[k] - delta[k] / 30.0;
+            g = (v < g || v != v) ? v : g;
+        }
+    }
+    scal[8] = g;
+}
+
+// gamma = max(gamma, 1 - e), big = min(big, 1 + e) (drift_kernel's third direction)
+__global__ void drift_combine_kernel(int K, double* __restrict__ gamma, double* __restrict__ big, const double* __restrict__ enorm) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const double e = enorm[k] * (1.0 + 1e-9);
+    const double g2 = (1.0 - e) * (1.0 - 1e-9), b2 = (1.0 + e) * (1.0 + 1e-9);
+    gamma[k] = g2 > gamma[k] ? g2 : gamma[k];
+    big[k] = b2 < big[k] ? b2 : big[k];
+}
+
 }  // namespace gmmvb
 
 using namespace gmmvb;
@@ -252,5 +493,47 @@ extern "C" int gmmvb_kside_drift(int K, int D, const double* u_old_dev, const do
                        enorm_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "drift_kernel launch", e);
+    return GMMVB_OK;
+}
+
+extern "C" int gmmvb_kside_step(int K, int D, const gmmvb_prior_view* prior, const gmmvb_post_view* q, const gmmvb_post_view* q_next,
+                                const double* stats_dev, const double* pivot_dev, double* s_prev_dev, double* ns_dev,
+                                double* x_bar_dev, double* s_dev, int want_drift, double* gamma_dev, double* delta_dev,
+                                double* big_gamma_dev, double* scal_dev, double* scratch_dev, void* stream) {
+    if (K < 1 || D < 1) return fail(GMMVB_EINVAL, "K and D must be positive");
+    if (D > 128) return fail(GMMVB_EUNSUPPORTED, "gmmvb_kside_step: D > 128 (the matrices are kept in LDS)");
+    if (!prior || !q || !q_next || !stats_dev || !pivot_dev || !s_prev_dev || !ns_dev || !x_bar_dev || !s_dev || !scal_dev ||
+        !scratch_dev || (want_drift && (!gamma_dev || !delta_dev || !big_gamma_dev)))
+        return fail(GMMVB_EINVAL, "null argument");
+    static_assert(sizeof(gmmvb_prior_view) == sizeof(PriorView) && sizeof(gmmvb_post_view) == sizeof(PostView), "view layouts");
+    PriorView pr;
+    PostView qa, qb;
+    std::memcpy(&pr, prior, sizeof(pr));
+    std::memcpy(&qa, q, sizeof(qa));
+    std::memcpy(&qb, q_next, sizeof(qb));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)D * (D + 1) + 5 * (size_t)D + 32) * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kside_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "hipFuncSetAttribute(kside_step_kernel)", e);
+        lds_set = lds;
+    }
+    double* partials = scratch_dev;                       // [K][kPartials]
+    double* enorm = scratch_dev + (size_t)K * kPartials;  // [K]
+    hipLaunchKernelGGL(kside_step_kernel, dim3(K), dim3(256), lds, st, K, D, pr, qa, qb, stats_dev, pivot_dev, s_prev_dev, ns_dev,
+                       x_bar_dev, s_dev, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "kside_step_kernel launch", e);
+    if (want_drift) {
+        int rc = gmmvb_kside_drift(K, D, qa.u, qa.u_inv, qa.m, qb.u, qb.u_inv, qb.m, 8, 6, gamma_dev, delta_dev, big_gamma_dev, enorm,
+                                   stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(drift_combine_kernel, dim3((K + 255) / 256), dim3(256), 0, st, K, gamma_dev, big_gamma_dev, enorm);
+    }
+    hipLaunchKernelGGL(kside_finish_kernel, dim3(1), dim3(64), 0, st, K, partials, pr.ln_c_alpha, want_drift ? gamma_dev : nullptr,
+                       want_drift ? delta_dev : nullptr, scal_dev);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "kside_finish_kernel launch", e);
     return GMMVB_OK;
 }

@@ -401,18 +401,31 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         best_q, best_vl = None, 0.0
         never_converged = True
         terms = None
+        # restart-level parallelism (comm = RestartShard): restart i runs on rank i mod world, its progress line is
+        # kept and printed in order afterwards
+        par = getattr(self._comm, "restart_parallel", False)
+        mine = {}                                # restart -> (vl, converged, progress text, posterior, terms)
         for i in range(num_init):
+            skip = par and self._comm.owner(i) != self._comm.rank
+            text = []
+            say = (lambda t, end="": text.append(t + end)) if par else self._say
             q = _kside.post_from_prior(prior)
-            self._reset_hn_from(q)
+            if not skip:
+                self._reset_hn_from(q)
             if hasattr(eng, "forget"):
                 eng.forget()            # a restart's parameters are unrelated to the last pass: expect dense responsibilities
             if init_type == "subsampling":
+                if skip:
+                    self._subsample_moments(eng, xd, n_global, draw_only=True)
+                    continue
                 q = self._init_subsampling(eng, xd, q, n_global)
                 ks.load(q)
                 self._give_params(eng, q)
                 self._data_pass(eng, xd, ks)
             elif init_type == "random_responsibility":
                 r = self.rng.dirichlet(np.ones(K), n_global)
+                if skip:
+                    continue
                 lo = self._comm.row_offset
                 eng.load_responsibilities(torch.from_numpy(r[lo: lo + xd.shape[0]]).to(dev))
                 ks.load(q)
@@ -425,7 +438,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             terms, gmean = ks.read()
             vl = terms["vl"]
             carried = init_type == "subsampling"      # the engine's last E-step belongs to ks.q
-            self._say(f"\r{i}. VL: {vl}")
+            converged = False
+            say(f"\r{i}. VL: {vl}")
             for t in range(max_itr):
                 vl_before = vl
                 self._give_params(eng, ks.q_next, ks.hint(gmean) if carried else None)
@@ -435,18 +449,24 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
                 ks.step()
                 terms, gmean = ks.read()                     # the one host sync per iteration
                 vl = terms["vl"]
-                self._say(f"\r{i}. VL: {vl} t={t} ")
+                say(f"\r{i}. VL: {vl} t={t} ")
                 with np.errstate(divide="ignore", invalid="ignore"):
                     if np.abs((vl - vl_before) / vl_before) < tolerance:
-                        never_converged = False
-                        self._say("(converged)")
+                        converged = True
+                        say("(converged)")
                         break
+            never_converged = never_converged and not converged
+            if par:
+                mine[i] = (vl, converged, "".join(text), ks.current(), terms)
+                continue
             if i == 0 or vl > best_vl:
                 self._say("*", end="\n")
                 best_vl, best_q = vl, ks.current()
             else:
                 self._say("", end="\n")
             self.vl = vl
+        if par and num_init > 0:
+            best_q, terms, never_converged = self._merge_restarts(mine, num_init, dev)
         if never_converged:
             warnings.warn("Algorithm has not converged even once.", ResultWarning)
 
@@ -465,6 +485,29 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         ns, x_bar, s, _h = self._pass(eng, xd, q, ks.s_prev)
         self.ns[:], self.x_bar_vecs[:], self.s_mats[:] = _np(ns), _np(x_bar), _np(s)
         return self
+
+    def _merge_restarts(self, mine, num_init, dev):
+        """RestartShard: gather every restart's (lower bound, converged, progress line), replay the reference's winner
+        rule (ref:873: ``i == 0 or vl > best``) in restart order, print the lines, broadcast the winner's posterior."""
+        comm = self._comm
+        table = {}
+        for part in comm.gather({i: (v[0], v[1], v[2]) for i, v in mine.items()}):
+            table.update(part)
+        winner, best_vl = 0, 0.0
+        for i in range(num_init):
+            vl, _conv, text = table[i]
+            star = i == 0 or vl > best_vl
+            if star:
+                winner, best_vl = i, vl
+            self._say(text + ("*" if star else ""), end="\n")
+        self.vl = table[num_init - 1][0]                       # the reference leaves the LAST restart's bound (ref:882)
+        owner = comm.owner(winner)
+        # (ranks that do not own the winner receive into a posterior of the right shapes)
+        q = mine[winner][3] if owner == comm.rank else _kside._clone_post(_kside.post_from_prior(self._prior_tensors(dev)))
+        comm.broadcast_([getattr(q, f) for f in _kside._POST_FIELDS], owner)
+        last = comm.gather(mine[num_init - 1][4] if (num_init - 1) in mine else None)
+        terms = next(t for t in last if t is not None)
+        return q, terms, not any(table[i][1] for i in range(num_init))
 
     def _init_subsampling(self, eng, xd, q, n_global):
         """ref:786-796 on the GPU (index draw on the host, see _device.DeviceModel._subsample_moments)."""

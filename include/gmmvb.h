@@ -186,6 +186,29 @@ int gmmvb_kside_drift(int K, int D, const double* u_old_dev, const double* uinv_
                       int squarings_big, double* gamma_dev /*[K]*/, double* delta_dev /*[K]*/,
                       double* big_gamma_dev /*[K]*/, double* enorm_dev /*[K]*/, void* stream);
 
+/* The whole K-sized part of one VB iteration (everything update_posterior does between two data passes,
+ * _gaussianmixture.py:671-770 minus the N-sized sums) in one call - three launches, no synchronisation:
+ *   moments    x_bar = pivot + a/ns, S = B/ns - (a/ns)(a/ns)^T from the statistics block (ns > 0; else 0 / the previous S)
+ *   scal[0..7] the lower bound's terms p_x, p_z, p_pi, p_mu_lambda, q_z, q_pi, q_mu_lambda and their sum under q
+ *   q_next     the closed-form update from the prior and the moments, with its derived expectations, the whitening factor
+ *              u (u^T u = E[Lambda]), u^-1 and the E-step constant c - ready for gmmvb_set_params
+ *   drift      (want_drift) gamma / delta / big_gamma of q -> q_next for gmmvb_set_drift; scal[8] = min_k (gamma_k - delta_k/30)
+ * All pointers are device pointers; q and q_next must not alias.  s_prev [K][D][D] is read (components with ns = 0 keep
+ * their previous S, like the reference's stale s_mats) and overwritten with S.  scratch: 13 K doubles.  D <= 128. */
+typedef struct gmmvb_prior_view {
+    const double *alpha, *m, *kappa, *nu, *w_inv, *ln_b_w_nu;      /* [K], [K][D], [K], [K], [K][D][D], [K] */
+    double ln_c_alpha;                                             /* ln C(alpha_0), _gaussianmixture.py:662 */
+} gmmvb_prior_view;
+typedef struct gmmvb_post_view {
+    double *alpha, *m, *kappa, *nu, *w_inv, *w, *u, *u_inv;       /* [K], [K][D], [K], [K], then four [K][D][D] */
+    double *e_ln_pi, *e_ln_lambda_det, *ln_b_w_nu, *c;            /* [K] each */
+} gmmvb_post_view;
+int gmmvb_kside_step(int K, int D, const gmmvb_prior_view* prior, const gmmvb_post_view* q, const gmmvb_post_view* q_next,
+                     const double* stats_dev, const double* pivot_dev, double* s_prev_dev, double* ns_dev /*[K]*/,
+                     double* x_bar_dev /*[K][D]*/, double* s_dev /*[K][D][D]*/, int want_drift, double* gamma_dev,
+                     double* delta_dev, double* big_gamma_dev, double* scal_dev /*[9]*/, double* scratch_dev /*[13 K]*/,
+                     void* stream);
+
 /* Which kernels have run in this workspace since it was created (for tests and profiling reports):
  *   out[0] dense E-steps, out[1] bound passes of the pruned E-step, out[2] E-steps on carried records, out[3] E-steps
  *   sent back to the dense kernel after a bound pass that pruned nothing, out[4] E-steps on a sweep of carried bounds

@@ -44,6 +44,9 @@ def main():
     mu = 2.0 * rng.standard_normal((16, 32))
     x2 = torch.from_numpy(mu[rng.integers(0, 16, 1_000_000)] + rng.standard_normal((1_000_000, 32))).to(dev)
     m = gm.LearnModel(16, 32, seed=0, device=dev, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.update_posterior(x2, max_itr=3, num_init=1, tolerance=0.0)      # warm-up (workspace, x copy)
     for itr in (5, 35):
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -31,7 +31,7 @@ def main():
         os.environ["GMMVB_MSTEP_SPARSE"] = "0"
     dev = torch.device("cuda", 0)
     K, D, N = args.classes, args.degree, args.rows
-    x = bench.device_rows(K, D, N, torch.float32, dev, bench.SEED + 1)
+    x = bench.device_rows(K, D, N, torch.float32, dev, bench.SEED + 1, 2.0)
     m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
