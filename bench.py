@@ -72,6 +72,10 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the dense and hard-workload legs")
     ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="join an RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--native-allreduce", action="store_true",
+                    help="per-iteration all-reduce through the library's own RCCL communicator (gmmvb_allreduce_stats)")
     return ap.parse_args()
 
 
@@ -266,11 +270,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     comm = None
     rccl_ranks = 1
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
-        comm = RowShard()
+        comm = RowShard(native=args.native_allreduce)
         # every rank contributes 1: proves the RCCL group really spans `world` processes
         one = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(one)
@@ -309,7 +315,7 @@ def main():
         warm.append(dict(w.snapshot(), what="warm-up iteration"))
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -326,7 +332,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     counts1 = eng.pass_counts()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -422,6 +428,8 @@ def main():
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
             "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "allreduce": (("gmmvb_allreduce_stats (C ABI, RCCL)" if args.native_allreduce else "torch.distributed nccl (RCCL)")
+                          if use_dist else None),
             "steps": steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"GMM-VB K={K} D={D} N={n_local} rows/GPU x {world} GPU, x stored {dt}, "
@@ -438,7 +446,7 @@ def main():
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars]},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
