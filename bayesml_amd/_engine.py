@@ -55,6 +55,7 @@ SYMBOLS = {
     "hmmvb_enable": (_int, [_vp]),
     "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "hmmvb_debug_readout": (_int, [_vp, _int, _i64, _i64, _vp, _vp]),
+    "hmmvb_readout": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp]),
     "hmmvb_viterbi": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "gmmvb_profile_enable": (_int, [_vp, _int]),
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
@@ -443,6 +444,20 @@ class DataPass:
                                                     self._stream()), "hmmvb_viterbi")
         torch.cuda.current_stream(self.device).synchronize()     # pi / a must outlive the kernels
         return z
+
+    def hmm_readout(self, what: str, row0=0, n=None, a_tilde=None) -> torch.Tensor:
+        """alpha / beta [n, K] or xi [n, K, K] of the last forward_backward for rows [row0, row0 + n) (hmmvb_readout)."""
+        code = {"alpha": 0, "beta": 1, "xi": 3}[what]
+        n = self.rows - row0 if n is None else n
+        K = self.K
+        out = torch.empty((n, K, K) if code == 3 else (n, K), dtype=torch.float64, device=self.device)
+        a = _f64(a_tilde, (K, K), self.device) if code == 3 else None
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.hmmvb_readout(self._ws, code, row0, n, a.data_ptr() if a is not None else None,
+                                                    out.data_ptr(), self._stream()), "hmmvb_readout")
+        if a is not None:
+            torch.cuda.current_stream(self.device).synchronize()          # a must outlive the kernel
+        return out
 
     def hmm_debug(self, what, row0=0, n=None):
         n = self.rows - row0 if n is None else n

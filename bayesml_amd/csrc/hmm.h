@@ -484,6 +484,35 @@ __global__ void hmm_gamma_to_cm_kernel(const double* __restrict__ gamma_tm, int6
     }
 }
 
+// Row-range read-outs of the last pass in natural state order (the reference keeps alpha_vecs, beta_vecs [T, K] and
+// xi_mats [T, K, K] as attributes, _hiddenmarkovnormal.py:1063-1069; here they are formed on demand):
+//   what 0  alpha_t                       [n][K]
+//   what 1  beta_t = gamma_t / alpha_t    [n][K]   (the reference's scaling: gamma = alpha o beta, :1013-1014; 0 where alpha = 0)
+//   what 3  xi_t = (alpha_{t-1}^T w_t) o A~   [n][K][K], xi_0 = 0 (the reference's convention, :1068)
+__global__ void hmm_readout_kernel(const double* __restrict__ alpha_tm, const double* __restrict__ gamma_tm,
+                                   const double* __restrict__ w_tm, const double* __restrict__ a_tilde, int K, int Kp,
+                                   int what, int64_t row0, int64_t n_rows, double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto pos = [](int s) { return (s & ~15) + 4 * ((s & 15) & 3) + ((s & 15) >> 2); };
+    if (what == 3) {
+        if (e >= n_rows * K * K) return;
+        const int64_t t = row0 + e / ((int64_t)K * K);
+        const int i = (int)((e / K) % K), j = (int)(e % K);
+        out[e] = t == 0 ? 0.0 : alpha_tm[(t - 1) * Kp + pos(i)] * a_tilde[i * K + j] * w_tm[t * Kp + pos(j)];
+        return;
+    }
+    if (e >= n_rows * K) return;
+    const int64_t t = row0 + e / K;
+    const int s = (int)(e % K);
+    const double al = alpha_tm[t * Kp + pos(s)];
+    if (what == 0) {
+        out[e] = al;
+    } else {
+        const double g = gamma_tm[t * Kp + pos(s)];
+        out[e] = al > 0.0 ? g / al : 0.0;
+    }
+}
+
 // ---- Viterbi (estimate_latent_vars(loss="0-1", viterbi=True), _hiddenmarkovnormal.py:1465-1481) ----------
 // First version: the max-plus recursion is run sequentially by ONE wave (lane = state), 8 time steps of
 // ln rho prefetched per lane; the back-pointers are chased through LDS-staged blocks.  A chunked max-plus

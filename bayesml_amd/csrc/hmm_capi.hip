@@ -183,6 +183,22 @@ int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi
     return GMMVB_OK;
 }
 
+int hmmvb_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, const double* a_tilde_dev, double* out_dev,
+                  void* stream) {
+    if (!ws || !ws->hmm || !out_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (what != 0 && what != 1 && what != 3) return fail(GMMVB_EINVAL, "what must be 0 (alpha), 1 (beta) or 3 (xi)");
+    if (what == 3 && !a_tilde_dev) return fail(GMMVB_EINVAL, "a_tilde_dev is needed for xi");
+    if (ws->e_state != 3 || row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows)
+        return fail(GMMVB_ESTATE, "row range outside the last hmmvb_forward_backward");
+    gmmvb_hmm_state* h = ws->hmm;
+    const int64_t total = n_rows * h->K * (what == 3 ? h->K : 1);
+    hipLaunchKernelGGL(hmm_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->alpha_tm,
+                       h->gamma_tm, h->w_tm, a_tilde_dev, h->K, h->Kp, what, row0, n_rows, out_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "hmm_readout launch", e);
+    return GMMVB_OK;
+}
+
 /* Read-outs of the last forward-backward pass for rows [row0, row0 + n_rows): alpha / beta~ are not kept in
  * natural order; this returns alpha (mode 0) or c' (mode 1, [n_rows]) for tests. */
 int hmmvb_debug_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, double* out_dev, void* stream) {

@@ -10,8 +10,8 @@ and ``Generator`` consumption order are kept.  The N-sized work runs on the GPU 
   (``csrc/hmm.h``); ``xi_mats`` ([T, K, K], 82 GB at T=1e7, K=32) is never formed, only its sum ``ms``;
 * NIW statistics (ref:837-845): the GMM M-step kernel with ``gamma`` as the responsibilities.
 
-Not provided (they would be T x K / T x K x K host arrays): ``beta_vecs``, ``xi_mats``; ``alpha_vecs`` and
-``gamma_vecs`` are fetched from the GPU on access.
+``alpha_vecs``, ``beta_vecs``, ``gamma_vecs`` and ``xi_mats`` (``xi_rows(row0, n)`` for a row range) are formed on the GPU and
+fetched on access; nothing T-sized is kept on the host.
 """
 from __future__ import annotations
 
@@ -387,7 +387,29 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
 
     @property
     def alpha_vecs(self):
-        return None if self._engine is None else _np(self._engine.hmm_debug(0))
+        return None if self._engine is None else _np(self._engine.hmm_readout("alpha"))
+
+    @property
+    def beta_vecs(self):
+        """The reference's scaled backward variables (gamma = alpha o beta, ref:1013-1014), formed on access."""
+        return None if self._engine is None else _np(self._engine.hmm_readout("beta"))
+
+    def xi_rows(self, row0=0, n=None):
+        """``xi_mats[row0:row0 + n]`` of the last pass ([n, K, K]; xi_mats[0] = 0 as in the reference, ref:1068).  The
+        whole array is T K^2 doubles (82 GB at T = 1e7, K = 32): it is never materialised, ask for the rows needed."""
+        if self._engine is None:
+            return None
+        return _np(self._engine.hmm_readout("xi", row0, n, self._a_tilde_mat))
+
+    @property
+    def xi_mats(self):
+        """The full [T, K, K] array, for sizes that fit the host (<= 2 GiB); use ``xi_rows`` otherwise."""
+        if self._engine is None:
+            return None
+        T, K = self._engine.rows, self.c_num_classes
+        if T * K * K * 8 > 2 ** 31:
+            raise MemoryError(f"xi_mats would be {T * K * K * 8 / 2 ** 30:.1f} GiB; use xi_rows(row0, n)")
+        return self.xi_rows(0, T)
 
     # ------------------------------------------------------------------ read-outs
     def estimate_params(self, loss="squared"):

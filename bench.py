@@ -383,11 +383,14 @@ def main():
         traffic = traffic_src = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f).get({"estep_i8_bound": "estep_i8"}.get(dom_kernel, dom_kernel))
-            ran = dom_kernel == "estep_gather_f64" or any(dom_kernel in l for l in launches)
+                pm = json.load(f).get({"estep_i8_bound": "estep_i8", "estep_gather_f64": "estep_gather_dev_f64"}.get(dom_kernel, dom_kernel))
+            ran = (dom_kernel == "estep_gather_f64" and timed_counts["estep_gather"] > 0) or any(dom_kernel in l for l in launches)
             if pm and pm.get("config") == f"K{K} D{D} N{n_local} {dt}" and ran:
-                traffic = pm["fetch_bytes"] + pm["write_bytes"]
-                traffic_src = "profiles/pmc_traffic.json: " + pm["note"]
+                # per step like `achieved`: the counters' average per launch x this run's launches of the group per step
+                per_step = groups[dom]["launch_groups_per_step"]
+                traffic = (pm["fetch_bytes"] + pm["write_bytes"]) * per_step
+                traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, average per launch x {per_step:.2f} launches per "
+                               "step): " + pm["note"])
         except (OSError, ValueError, KeyError):
             pass
         step_bytes = n_local * row_bytes

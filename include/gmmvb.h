@@ -146,6 +146,15 @@ int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi
 int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde_dev, const double* ln_a_tilde_dev,
                   int32_t* z_dev, void* stream);
 
+/* Row-range read-outs of the last hmmvb_forward_backward, natural state order, rows [row0, row0 + n_rows) - the
+ * reference's alpha_vecs / beta_vecs [T][K] and xi_mats [T][K][K] attributes (_hiddenmarkovnormal.py:1063-1069), formed on
+ * demand instead of being materialised (xi_mats is 82 GB at config 5):
+ *   what 0: alpha_t [n_rows][K];  1: beta_t = gamma_t / alpha_t [n_rows][K] (gamma = alpha o beta as in the reference);
+ *   what 3: xi_t [n_rows][K][K] = (alpha_{t-1}^T w_t) o a_tilde with xi_0 = 0; a_tilde_dev = the matrix given to the
+ *           forward-backward call (ignored for what 0 / 1). */
+int hmmvb_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, const double* a_tilde_dev, double* out_dev,
+                  void* stream);
+
 /* test/diagnostic read-out of the last pass: what = 0 alpha ([n_rows][16 ceil(K/16)], lane order: state
  * 16b + (g + 4r) at position 16b + 4g + r), 1 c' ([n_rows]), 2 row shift max_k ln rho ([n_rows]). */
 int hmmvb_debug_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, double* out_dev, void* stream);

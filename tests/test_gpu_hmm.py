@@ -42,6 +42,9 @@ def device_pass(x, q, dev):
     out = dict(ln_rho=ln_rho, ms=ms.cpu().numpy(), g0=g0.cpu().numpy(), gl=gl.cpu().numpy(), lnc=float(lnc),
                ns=ns.cpu().numpy(), h=float(h.sum()), x_bar=x_bar.cpu().numpy(), s=s.cpu().numpy(),
                gamma=eng.responsibilities().cpu().numpy(), alpha=eng.hmm_debug(0).cpu().numpy(),
+               alpha_nat=eng.hmm_readout("alpha").cpu().numpy(), beta=eng.hmm_readout("beta").cpu().numpy(),
+               xi=eng.hmm_readout("xi", 0, min(T, 300), t(q.a_tilde)).cpu().numpy(),
+               xi_tail=eng.hmm_readout("xi", max(0, T - 7), min(T, 7), t(q.a_tilde)).cpu().numpy(),
                argmax=eng.argmax().cpu().numpy())
     eng.close()
     return out
@@ -69,6 +72,18 @@ def test_forward_backward_matches_reference(name):
     K = int(g["K"])
     assert abs(r["ms"].sum() - (int(g["N"]) - 1)) < 1e-7          # every xi_t sums to one
     assert abs(r["ns"].sum() - int(g["N"])) < 1e-7
+    # row-range read-outs of what the reference keeps as [T, K] / [T, K, K] attributes (ref:1063-1069)
+    assert np.max(np.abs(r["alpha_nat"][:n] - g["alpha_vecs"])) < 1e-10
+    big = g["alpha_vecs"] > 1e-200
+    assert np.max(np.abs(r["beta"][:n][big] / g["beta_vecs"][big] - 1.0)) < 1e-8
+    # xi_t = alpha_{t-1} rho_t a~ beta_t / c_t (ref:1016-1018), rebuilt from the fixture's own arrays
+    m = r["xi"].shape[0]
+    rho = np.exp(g["ln_rho"][:m])
+    xi_ref = g["alpha_vecs"][:m - 1, :, None] * q.a_tilde[None] * (rho[1:] * g["beta_vecs"][1:m])[:, None, :] / g["cs"][1:m, None, None]
+    assert np.all(r["xi"][0] == 0.0)
+    assert np.max(np.abs(r["xi"][1:] - xi_ref)) < 1e-9
+    assert np.max(np.abs(r["xi"][1:].sum(axis=(1, 2)) - 1.0)) < 1e-9
+    assert np.max(np.abs(r["xi_tail"].sum(axis=1)[1:] - r["gamma"][-6:])) < 1e-9        # marginals: sum_i xi_t[i, j] = gamma_t[j]
 
 
 @pytest.mark.parametrize("K,D,T,dtype", [(3, 2, 1, np.float64), (5, 3, 2, np.float64), (7, 4, 17, np.float32),
