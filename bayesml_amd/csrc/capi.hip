@@ -186,7 +186,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart};
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
-    void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags};
+    void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -387,6 +387,8 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_exact, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_sel, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_flags, (size_t)np);
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->ub32, (size_t)ws->K * np * sizeof(float));
+    if (e == hipSuccess) ws->bytes += (int64_t)ws->K * np * (int64_t)sizeof(float);
     const size_t esz = ws->x_dtype == GMMVB_F64 ? 8 : 4;
     if (ws->sort_rows) {
         if (e == hipSuccess) e = hipMalloc(&ws->xp, (size_t)ws->max_rows * ws->D * esz);
@@ -736,7 +738,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // records for the next pass (one more sweep of the array, ~1 % of the dense kernel's time)
             if (can_prune && big)
                 hipLaunchKernelGGL(rec_build_kernel<false>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
-                                   ws->npad, n_rows, ws->K, ws->cvec, nullptr, rec);
+                                   ws->npad, n_rows, ws->K, ws->cvec, nullptr, rec, ws->ub32);
             e = hipGetLastError();
             if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse / lse_mask launch", e);
             counted = true;
@@ -774,7 +776,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // records from the bounds (+ the one exact value), then every other candidate
             span_begin(ws, kSpanSelect, st);
             hipLaunchKernelGGL(rec_build_kernel<true>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
-                               ws->npad, n_rows, ws->K, ws->cvec, ws->khat, rec);
+                               ws->npad, n_rows, ws->K, ws->cvec, ws->khat, rec, ws->ub32);
             hipLaunchKernelGGL(rec_select_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
                                ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart);
             span_end(ws, st);
@@ -799,7 +801,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 ++ws->passes[7];
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step active-pair evaluation", e);
                 span_begin(ws, kSpanSelect, st);
-                hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
                 span_end(ws, st);
             } else {
@@ -810,7 +812,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step best-component evaluation", e);
                 span_begin(ws, kSpanSelect, st);
-                hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
                 span_end(ws, st);
             }
@@ -833,7 +835,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
         span_begin(ws, kSpanLse, st);
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart);
+                           ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32);
         hipLaunchKernelGGL(sum_parts_kernel, dim3(4), dim3(256), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, sel_grid,
                            ws->ctr);
         e = hipGetLastError();
@@ -872,8 +874,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->bounds_x = x_dev;
     ws->bounds_ldx = ldx;
     ws->prev_pass = mode;
-    // the dense array holds a value or bound under the parameters in force for EVERY pair after a dense pass, a bound
-    // pass or a sweep; a pass on records only refreshes the listed entries
+    // the f32 bound array holds a value or bound under the parameters in force for EVERY pair after a dense pass, a
+    // bound pass or a sweep; a pass on records only refreshes the evaluated entries
     ws->dense_valid = mode != kCarry;
     if (mode == kDense || mode == kBound) ws->sweeps = 0;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,

@@ -83,7 +83,8 @@ __device__ __forceinline__ void rec_insert(float (&ds)[kRecSlots], unsigned shor
 template <bool GIVEN>
 __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
                                                         int K, const double* __restrict__ cvec,
-                                                        const int* __restrict__ khat, RecArrays rec) {
+                                                        const int* __restrict__ khat, RecArrays rec,
+                                                        float* __restrict__ ub32 /*[K][npad]: every value rounded up*/) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= n_rows) return;
     float ds[kRecSlots], vs[kRecSlots];
@@ -97,8 +98,9 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
     float rest = -__builtin_huge_valf();
     const int kb = GIVEN ? khat[n] : -1;
     for (int k = 0; k < K; ++k) {
-        if (GIVEN && k == kb) continue;
         const double v = lnrho[(int64_t)k * npad + n];
+        ub32[(int64_t)k * npad + n] = f32_up(v);
+        if (GIVEN && k == kb) continue;
         rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], v)), (unsigned short)k, f32_up(v));
     }
     unsigned ex = 0;
@@ -274,8 +276,12 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
 // PREV: instead of only the previous best component, ALL pairs that were active in the previous pass (the M-step's
 // lists, still in the workspace: no list building for this round) have just been evaluated under the new parameters;
 // `masks` holds them on entry.  The reference value is the largest of them.
+// The per-pair bounds live in their own f32 array ub ([K][npad], every entry rounded UP: 6e-8 relative, 1e-3 nats at
+// most - bounds need no more), so the sweep moves 8 bytes per pair instead of 16; exact values are read from the f64
+// ln rho array, which only the exact kernels write.
 template <bool PREV>
-__global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict__ u, int64_t npad, int64_t n_rows, int K,
+__global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__ ub, const double* __restrict__ u, int64_t npad,
+                                                             int64_t n_rows, int K,
                                                              const double* __restrict__ drift,
                                                              const double* __restrict__ c_new,
                                                              const int* __restrict__ khat, RecArrays rec,
@@ -336,22 +342,23 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(double* __restrict_
                 // exact already: competes for a slot by its distance (the single reference pair of the !PREV form is
                 // inserted at distance -1 so that it always keeps one)
                 const double v = u[(int64_t)k * npad + n];
+                ub[(int64_t)k * npad + n] = f32_up(v);
                 rec_insert(ds, ks, vs, rest, PREV ? f32_down(dist_of(c, v)) : -1.0f, (unsigned short)(k | kRecExactBit | kRecListed),
                            f32_up(v));
                 continue;
             }
-            const double d = dist_of(sco[k], u[(int64_t)k * npad + n]);
+            const double d = dist_of(sco[k], (double)ub[(int64_t)k * npad + n]);
             double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
             y = y > 0.0 ? y : 0.0;                               // also NaN -> 0: the trivial bound c'
             const float yf = f32_down(y);
-            const double ub = c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c);
-            u[(int64_t)k * npad + n] = ub;
-            const bool cand = over || !(ub < thr);
+            const float ubn = f32_up(c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c));
+            ub[(int64_t)k * npad + n] = ubn;
+            const bool cand = over || !((double)ubn < thr);
             if (cand) {
                 mk[k >> 6] |= 1ull << (k & 63);
                 ++listed;
             }
-            rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), f32_up(ub));
+            rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), ubn);
         }
         if (!over) {
             // exact pairs that did not get a slot are listed again (rec_finish_kernel finds the evaluated pairs of a row
@@ -427,7 +434,8 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               double* __restrict__ lse, int* __restrict__ khat,
                                                               unsigned long long* __restrict__ masks,
                                                               int* __restrict__ blk_cnt, double* __restrict__ apart,
-                                                              double* __restrict__ mpart /*rows whose best component changed*/) {
+                                                              double* __restrict__ mpart /*rows whose best component changed*/,
+                                                              float* __restrict__ ub32 /*[K][npad] per-pair bounds (sweeps)*/) {
     __shared__ int wcnt[4][256];
     __shared__ int wact[4], wmov[4];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -459,6 +467,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         bool nan = false;
         auto take_exact = [&](int k) {
             const double x = lnrho[(int64_t)k * npad + n];
+            ub32[(int64_t)k * npad + n] = f32_up(x);
             ev[k >> 6] |= 1ull << (k & 63);
             nan = nan || x != x;
             if (x > mx) {
@@ -531,6 +540,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
             if (!((live >> j) & 1u)) continue;
             const double x = lnrho[(int64_t)kk[j] * npad + n];
             v[j] = x;
+            ub32[(int64_t)kk[j] * npad + n] = f32_up(x);
             rec.d[(int64_t)j * rec.npad + n] = f32_down(dist_of(cvec[kk[j]], x));
             nan = nan || x != x;
             if (x > mx || (x == mx && (int)kk[j] < arg)) {          // first maximiser, like numpy.argmax
@@ -571,9 +581,11 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         float rest = -__builtin_huge_valf();
         double mx = lnrho[n], s = 1.0;
         int arg = 0;
+        ub32[n] = f32_up(mx);
         rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[0], mx)), 0, f32_up(mx));
         for (int k = 1; k < K; ++k) {
             const double x = lnrho[(int64_t)k * npad + n];
+            ub32[(int64_t)k * npad + n] = f32_up(x);
             rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], x)), (unsigned short)k, f32_up(x));
             if (x > mx) {
                 s = fma(s, exp(mx - x), 1.0);

@@ -47,7 +47,8 @@ struct gmmvb_workspace {
     unsigned char* rec_exact = nullptr, *rec_sel = nullptr, *rec_flags = nullptr;   // [npad] each
     bool rec_valid = false;            // the records describe the last E-step's parameters on bounds_rows rows
     bool rec_live = false;             // the last E-step lived on records (read-outs go through them)
-    bool dense_valid = false;          // EVERY entry of the ln rho array is a value / bound under the last E-step's parameters
+    float* ub32 = nullptr;             // [K][npad] upper bound of ln rho for every pair (rounded up), what the sweeps carry
+    bool dense_valid = false;          // EVERY entry of ub32 is a value / bound under the last E-step's parameters
     int sweeps = 0;                    // dense sweeps since the last bound / dense pass (their bounds erode: at most 8)
     int* plan = nullptr;               // [K + 1] gather chunk plan (device)
     int* plan_m = nullptr;             // [K + 2] chunk plan of the list M-step
