@@ -54,6 +54,12 @@ __device__ __forceinline__ double dist_of(double c, double v) {
     const double q = 2.0 * (c - v);
     return q > 0.0 ? sqrt(q) : 0.0;
 }
+// the same as a LOWER bound in f32 (directed rounding all the way: 1e-7 relative looseness), for values that are
+// bounds anyway - the f64 square root is a quarter-rate instruction and the sweep does K of them per row
+__device__ __forceinline__ float dist_lower_f32(double c, double v) {
+    const float q = __double2float_rd(2.0 * (c - v));
+    return q > 0.0f ? sqrtf(q) * (1.0f - 2.4e-7f) : 0.0f;       // two ulps below whatever rounding sqrtf has
+}
 
 // Sorted insertion of (distance cd, component ck, value cv) into the ascending list of the C nearest components;
 // whatever falls off its end belongs to the rest, whose largest value is kept in `rest` (NaN sticks) - unless it is
@@ -61,6 +67,10 @@ __device__ __forceinline__ double dist_of(double c, double v) {
 // Component codes: bits 0..13 the component, kRecListed, kRecExactBit (value is exact).
 __device__ __forceinline__ void rec_insert(float (&ds)[kRecSlots], unsigned short (&ks)[kRecSlots], float (&vs)[kRecSlots],
                                            float& rest, float cd, unsigned short ck, float cv) {
+    if (!(cd < ds[kRecSlots - 1])) {          // not among the C nearest (the usual case: most components are far away)
+        if (ck != kRecEmpty && !(ck & kRecListed)) rest = (cv > rest || cv != cv) ? cv : rest;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < kRecSlots; ++j) {
         const bool lt = cd < ds[j];
@@ -321,7 +331,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                     vb = (v > vb || v != v) ? v : vb;
                 }
             }
-        } else {
+        }
+        if constexpr (!PREV) {
             fresh[kb >> 6] = 1ull << (kb & 63);
             vb = u[(int64_t)kb * npad + n];
         }
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                            f32_up(v));
                 continue;
             }
-            const double d = dist_of(sco[k], (double)ub[(int64_t)k * npad + n]);
+            const double d = (double)dist_lower_f32(sco[k], (double)ub[(int64_t)k * npad + n]);
             double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
             y = y > 0.0 ? y : 0.0;                               // also NaN -> 0: the trivial bound c'
             const float yf = f32_down(y);
