@@ -31,6 +31,7 @@ SYMBOLS = {
     "gmmvb_set_params": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "gmmvb_set_drift": (_int, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp]),
     "gmmvb_forget": (_int, [_vp]),
+    "gmmvb_regroup_count": (_i64, [_vp]),
     "gmmvb_debug_record": (_int, [_vp, _i64, ctypes.POINTER(ctypes.c_double)]),
     "gmmvb_wants_drift": (_int, [_vp, _i64]),
     "gmmvb_prepare_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
@@ -362,6 +363,10 @@ class DataPass:
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.gmmvb_set_drift(self._ws, g.data_ptr(), d.data_ptr(), G.data_ptr(),
                                                       float(typical_gamma), self._stream()), "gmmvb_set_drift")
+
+    @property
+    def regroup_count(self) -> int:
+        return int(self.lib.gmmvb_regroup_count(self._ws))
 
     def debug_record(self, row: int) -> dict:
         out = (ctypes.c_double * 26)()

@@ -337,6 +337,8 @@ int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26] host
     return GMMVB_OK;
 }
 
+int64_t gmmvb_regroup_count(const gmmvb_workspace* ws) { return ws ? ws->sorts : -1; }
+
 int gmmvb_forget(gmmvb_workspace* ws) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     ws->forget = true;

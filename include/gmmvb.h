@@ -246,6 +246,10 @@ int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows);
  * assume that the responsibilities are still as sparse as they were and runs the dense kernel. */
 int gmmvb_forget(gmmvb_workspace* ws);
 
+/* How often the workspace has regrouped its internal row order by dominant component since it was created (DESIGN.md
+ * section 5c; the caller never sees that order: every read-out is in the caller's row order). */
+int64_t gmmvb_regroup_count(const gmmvb_workspace* ws);
+
 /* test / diagnostic read-out (blocking) of one row's candidate record, 26 doubles to HOST memory: slot components
  * (-1 = empty) [0..7], slot distances [8..15], rest bound B [16], exact / selected bits [17] [18], flags [19], best
  * component [20], lse [21], the row's mask words [22..25]. */

@@ -21,7 +21,7 @@ from oracle import gmm_vb_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF")
+ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS")
 VARIANTS = {
     "default": {},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
@@ -47,12 +47,12 @@ class env:
                 os.environ[k] = v
 
 
-def run_driver(g, x, variant):
+def run_driver(g, x, variant, extra_env=None):
     from bayesml_amd import gaussianmixture as gm
     K, D = int(g["K"]), int(g["D"])
     kw = json.loads(str(g["kw"]))
     buf = io.StringIO()
-    with env(VARIANTS[variant]):
+    with env({**VARIANTS[variant], **(extra_env or {})}):
         m = gm.LearnModel(K, D, seed=int(g["seed"]), device=torch.device("cuda", 0))
         with warnings.catch_warnings(), redirect_stdout(buf):
             warnings.simplefilter("ignore")
@@ -138,6 +138,20 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+    if variant == "default" and "overlap" not in name:
+        # the workspace regrouped its internal row order by dominant component on the way: every
+        # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless
+        # in the caller's row order
+        assert m._engine.regroup_count >= 1
+        z = m._engine.argmax().cpu().numpy()
+        r_all = m._engine.responsibilities().cpu().numpy()
+        assert np.array_equal(z, r_all.argmax(axis=1))
+        assert np.array_equal(z[:64], g["r_head"].argmax(axis=1))
+        m2, _c, _t = run_driver(g, x, variant, {"GMMVB_SORT_ROWS": "0"})
+        assert m2._engine.regroup_count == 0
+        assert np.max(np.abs(m2._engine.responsibilities().cpu().numpy() - r_all)) < 1e-9
+        for key in ("hn_m_vecs", "hn_w_mats"):
+            assert rel_err(m2.get_hn_params()[key], hn[key]) < 1e-10, key
 
 
 def _oracle_post(q):
