@@ -107,11 +107,19 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
     }
     float rest = -__builtin_huge_valf();
     const int kb = GIVEN ? khat[n] : -1;
-    for (int k = 0; k < K; ++k) {
-        const double v = lnrho[(int64_t)k * npad + n];
-        ub32[(int64_t)k * npad + n] = f32_up(v);
-        if (GIVEN && k == kb) continue;
-        rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], v)), (unsigned short)k, f32_up(v));
+    for (int k0 = 0; k0 < K; k0 += 8) {            // eight loads in flight per thread
+        double pre[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pre[q] = (k0 + q < K) ? lnrho[(int64_t)(k0 + q) * npad + n] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+            if (k >= K) break;
+            const double v = pre[q];
+            ub32[(int64_t)k * npad + n] = f32_up(v);
+            if (GIVEN && k == kb) continue;
+            rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], v)), (unsigned short)k, f32_up(v));
+        }
     }
     unsigned ex = 0;
     if (GIVEN) {               // the exact pair takes the last slot; what was there joins the rest
@@ -347,29 +355,38 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             ks[j] = kRecEmpty;
         }
         float rest = -__builtin_huge_valf();
-        for (int k = 0; k < K; ++k) {
-            const double c = sc[k];
-            if (!over && ((fresh[k >> 6] >> (k & 63)) & 1ull)) {
-                // exact already: competes for a slot by its distance (the single reference pair of the !PREV form is
-                // inserted at distance -1 so that it always keeps one)
-                const double v = u[(int64_t)k * npad + n];
-                ub[(int64_t)k * npad + n] = f32_up(v);
-                rec_insert(ds, ks, vs, rest, PREV ? f32_down(dist_of(c, v)) : -1.0f, (unsigned short)(k | kRecExactBit | kRecListed),
-                           f32_up(v));
-                continue;
+        // sixteen bound loads in flight per thread: the loop is otherwise a chain of dependent memory round trips
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            float pre[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pre[q] = (k0 + q < K) ? ub[(int64_t)(k0 + q) * npad + n] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = k0 + q;
+                if (k >= K) break;
+                const double c = sc[k];
+                if (!over && ((fresh[k >> 6] >> (k & 63)) & 1ull)) {
+                    // exact already: competes for a slot by its distance (the single reference pair of the !PREV form
+                    // is inserted at distance -1 so that it always keeps one)
+                    const double v = u[(int64_t)k * npad + n];
+                    ub[(int64_t)k * npad + n] = f32_up(v);
+                    rec_insert(ds, ks, vs, rest, PREV ? f32_down(dist_of(c, v)) : -1.0f,
+                               (unsigned short)(k | kRecExactBit | kRecListed), f32_up(v));
+                    continue;
+                }
+                const double d = (double)dist_lower_f32(sco[k], (double)pre[q]);
+                double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
+                y = y > 0.0 ? y : 0.0;                               // also NaN -> 0: the trivial bound c'
+                const float yf = f32_down(y);
+                const float ubn = f32_up(c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c));
+                ub[(int64_t)k * npad + n] = ubn;
+                const bool cand = over || !((double)ubn < thr);
+                if (cand) {
+                    mk[k >> 6] |= 1ull << (k & 63);
+                    ++listed;
+                }
+                rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), ubn);
             }
-            const double d = (double)dist_lower_f32(sco[k], (double)ub[(int64_t)k * npad + n]);
-            double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
-            y = y > 0.0 ? y : 0.0;                               // also NaN -> 0: the trivial bound c'
-            const float yf = f32_down(y);
-            const float ubn = f32_up(c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c));
-            ub[(int64_t)k * npad + n] = ubn;
-            const bool cand = over || !((double)ubn < thr);
-            if (cand) {
-                mk[k >> 6] |= 1ull << (k & 63);
-                ++listed;
-            }
-            rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), ubn);
         }
         if (!over) {
             // exact pairs that did not get a slot are listed again (rec_finish_kernel finds the evaluated pairs of a row
