@@ -282,21 +282,48 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
 }
 
 // The early-regime form of the carried E-step: while the components still move by several per cent per iteration the
-// single rest bound of a record is too coarse (most rows would have to be re-evaluated in full), but the dense ln rho
-// array still holds, for EVERY pair, a value or upper bound under the previous parameters.  One sweep over it
+// single rest bound of a record is too coarse (most rows would have to be re-evaluated in full), but the f32 array ub
+// ([K][npad], every entry rounded UP) still holds, for EVERY pair, an upper bound of ln rho under the previous
+// parameters.  One sweep over it
 //   carries every entry over the update with its own component's (gamma, delta):  u' = c'_k - (gamma_k d - delta_k)_+^2 / 2,
 //     d = sqrt(2 (c_k - u)_+), and writes it back (the array stays valid for the next sweep);
-//   reads the row's previous best component, which the host has just had evaluated exactly under the NEW parameters
-//     (this early the components still shrink by factors - Gamma = 2 .. 4 -, a lower bound of the best value carried
-//     through Gamma would be hundreds of nats too low), as the reference value v;
-//   lists every other pair with u' >= v - 100 ln 2, and builds the row's record (C nearest components + rest bound) on the way,
+//   takes as the row's reference value v the largest of the pairs that have just been evaluated exactly under the NEW
+//     parameters (this early the components still shrink by factors - Gamma = 2 .. 4 -, a lower bound of the best value
+//     carried through Gamma would be hundreds of nats too low):
+//       PREV   all pairs that were active in the previous pass (the M-step's lists, still in the workspace: no list
+//              building for this round); `masks` holds them on entry;
+//       !PREV  the row's previous best component khat[n];
+//   lists every other pair with u' >= v - 100 ln 2, and builds the row's record (C slots + rest bound) on the way,
 // so that the pass continues exactly like one on records (gather -> rec_finish_kernel) and later passes can switch to them.
-// PREV: instead of only the previous best component, ALL pairs that were active in the previous pass (the M-step's
-// lists, still in the workspace: no list building for this round) have just been evaluated under the new parameters;
-// `masks` holds them on entry.  The reference value is the largest of them.
-// The per-pair bounds live in their own f32 array ub ([K][npad], every entry rounded UP: 6e-8 relative, 1e-3 nats at
-// most - bounds need no more), so the sweep moves 8 bytes per pair instead of 16; exact values are read from the f64
-// ln rho array, which only the exact kernels write.
+//
+// The kernel is bound by its instruction count (K pairs per row, 8 bytes of traffic each), so the per-pair work is
+// ~45 f32 / integer instructions and free of branches:
+//   the carry is done in f32 with the rounding slack folded into the per-component constants (gamma (1 - 1e-6) rounded
+//     down, delta and c' rounded up, the old c rounded down; 0.5 (1 - 1e-6); the result pushed up by 2.4e-7 relative) -
+//     v_sqrt_f32 is good to one ulp, every other operation to half an ulp, 1e-6 covers them several times over;
+//   the slots go to the C components of LARGEST carried bound (they are the ones that may matter), selected with a
+//     chain of nine min / max pairs on 32-bit keys: the bound's bits in descending order (upper 24 bits) | component
+//     (K <= 256).  The ninth key is the largest bound without a slot: the rest bound.  Slot distances are recovered
+//     from the keys (bounds rounded up to 15 mantissa bits: 3e-5 relative); exact slots read their value again.
+__device__ __forceinline__ unsigned sweep_key(float ub, unsigned k) {
+    const unsigned bits = __float_as_uint(ub);
+    const unsigned inv = bits ^ (~(unsigned)((int)bits >> 31) & 0x7FFFFFFFu);        // descending in ub, exact
+    return (inv & 0xFFFFFF00u) | k;
+}
+__device__ __forceinline__ float sweep_key_bound(unsigned key) {                     // >= the bound the key was made of
+    const unsigned inv = key & 0xFFFFFF00u;
+    return __uint_as_float(inv ^ (~(unsigned)((int)inv >> 31) & 0x7FFFFFFFu));
+}
+__device__ __forceinline__ void sweep_chain(unsigned (&s)[kRecSlots + 1], unsigned key) {
+#pragma unroll
+    for (int j = 0; j < kRecSlots; ++j) {
+        const unsigned lo = min(s[j], key);
+        key = max(s[j], key);
+        s[j] = lo;
+    }
+    s[kRecSlots] = min(s[kRecSlots], key);
+}
+
 template <bool PREV>
 __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__ ub, const double* __restrict__ u, int64_t npad,
                                                              int64_t n_rows, int K,
@@ -307,16 +334,16 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              int* __restrict__ blk_cnt, double* __restrict__ epart,
                                                              double* __restrict__ opart) {
     __shared__ int wcnt[4][256];
-    __shared__ double sg[256], sdl[256], sc[256], sco[256];
+    __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
+    __shared__ double sc[256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
     for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
     for (int k = tid; k < K; k += kSelRows) {
-        sg[k] = drift[k];
-        sdl[k] = drift[K + k];
+        const double g = drift[k] * (1.0 - 1e-6);
+        sp[k] = make_float4(g > 0.0 ? f32_down(g) : 0.0f, f32_up(drift[K + k]), f32_up(c_new[k]), f32_down(drift[2 * K + k]));
         sc[k] = c_new[k];
-        sco[k] = drift[2 * K + k];
     }
     __syncthreads();
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
@@ -346,75 +373,108 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         }
         const double thr = vb - k100Ln2;
         const bool over = !(thr > ninf);                       // NaN / -inf: nothing to compare with
-        float ds[kRecSlots], vs[kRecSlots];
+        const float thr_f = over ? -__builtin_huge_valf() : f32_down(thr);      // over: every pair is a candidate
+        if (over) fresh[0] = fresh[1] = fresh[2] = fresh[3] = 0ull;
+        unsigned s[kRecSlots + 1];
+#pragma unroll
+        for (int j = 0; j <= kRecSlots; ++j) s[j] = 0xFFFFFFFFu;
+        float restmax = -__builtin_huge_valf();                // largest bound among the pairs that are not listed
+        // uniform base + 32-bit row offset: one address register for the whole loop
+        const bool near = npad < (int64_t(1) << 29);
+        const unsigned off = (unsigned)(near ? n : 0) * 4u;
+        auto pair = [&](int k, int bit, float old, unsigned long long fw, unsigned long long& mw) {
+            const float4 p = sp[k];
+            const float qd = p.w - old;
+            const float sq = __builtin_amdgcn_sqrtf(qd + qd);              // NaN for qd < 0 or NaN: no information
+            const float t = fmaxf(fmaf(p.x, sq, -p.y), 0.0f);              // NaN -> 0: the trivial bound c'
+            const float w = fminf(t * t * 0.4999995f, 3.0e38f);
+            const float r = p.z - w;
+            const float ubn = fmaf(fabsf(r), 2.4e-7f, r);
+            char* base = (char*)(ub + (int64_t)k * npad + (near ? 0 : n));
+            *(float*)(base + off) = ubn;
+            const unsigned long long b1 = 1ull << bit;
+            const bool isf = (fw & b1) != 0ull;                            // (its exact value is written below)
+            const bool cand = !(ubn < thr_f) && !isf;
+            mw |= cand ? b1 : 0ull;
+            restmax = fmaxf(restmax, (cand || isf) ? -__builtin_huge_valf() : ubn);
+            sweep_chain(s, isf ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
+        };
+        auto old_of = [&](int k) {
+            const char* base = (const char*)(ub + (int64_t)k * npad + (near ? 0 : n));
+            return *(const float*)(base + off);
+        };
+        for (int w = 0; w < W; ++w) {
+            const unsigned long long fw = w == 0 ? fresh[0] : (w == 1 ? fresh[1] : (w == 2 ? fresh[2] : fresh[3]));
+            unsigned long long mw = 0ull;
+            const int kend = K < 64 * w + 64 ? K : 64 * w + 64;
+            int k0 = 64 * w;
+            for (; k0 + 8 <= kend; k0 += 8) {
+                float pre[8];                                  // eight loads in flight per thread
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pre[q] = old_of(k0 + q);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pair(k0 + q, k0 + q - 64 * w, pre[q], fw, mw);
+            }
+            for (; k0 < kend; ++k0) pair(k0, k0 - 64 * w, old_of(k0), fw, mw);
+            if (w == 0) mk[0] = mw;
+            else if (w == 1) mk[1] = mw;
+            else if (w == 2) mk[2] = mw;
+            else mk[3] = mw;
+        }
+        // the exact pairs: their values replace the carried bounds, and they compete for slots by value (the single
+        // reference pair of the !PREV form always gets one)
+        for (int w = 0; w < W; ++w) {
+            unsigned long long m = fresh[w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int k = 64 * w + b;
+                const float fu = f32_up(u[(int64_t)k * npad + n]);
+                ub[(int64_t)k * npad + n] = fu;
+                sweep_chain(s, PREV ? sweep_key(fu, (unsigned)k) : (unsigned)k);
+            }
+        }
+        float ds[kRecSlots];
         unsigned short ks[kRecSlots];
-#pragma unroll
-        for (int j = 0; j < kRecSlots; ++j) {
-            ds[j] = __builtin_huge_valf();
-            vs[j] = -__builtin_huge_valf();
-            ks[j] = kRecEmpty;
-        }
-        float rest = -__builtin_huge_valf();
-        // sixteen bound loads in flight per thread: the loop is otherwise a chain of dependent memory round trips
-        for (int k0 = 0; k0 < K; k0 += 16) {
-            float pre[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) pre[q] = (k0 + q < K) ? ub[(int64_t)(k0 + q) * npad + n] : 0.0f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int k = k0 + q;
-                if (k >= K) break;
-                const double c = sc[k];
-                if (!over && ((fresh[k >> 6] >> (k & 63)) & 1ull)) {
-                    // exact already: competes for a slot by its distance (the single reference pair of the !PREV form
-                    // is inserted at distance -1 so that it always keeps one)
-                    const double v = u[(int64_t)k * npad + n];
-                    ub[(int64_t)k * npad + n] = f32_up(v);
-                    rec_insert(ds, ks, vs, rest, PREV ? f32_down(dist_of(c, v)) : -1.0f,
-                               (unsigned short)(k | kRecExactBit | kRecListed), f32_up(v));
-                    continue;
-                }
-                const double d = (double)dist_lower_f32(sco[k], (double)pre[q]);
-                double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
-                y = y > 0.0 ? y : 0.0;                               // also NaN -> 0: the trivial bound c'
-                const float yf = f32_down(y);
-                const float ubn = f32_up(c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c));
-                ub[(int64_t)k * npad + n] = ubn;
-                const bool cand = over || !((double)ubn < thr);
-                if (cand) {
-                    mk[k >> 6] |= 1ull << (k & 63);
-                    ++listed;
-                }
-                rec_insert(ds, ks, vs, rest, yf, (unsigned short)(k | (cand ? kRecListed : 0)), ubn);
-            }
-        }
-        if (!over) {
-            // exact pairs that did not get a slot are listed again (rec_finish_kernel finds the evaluated pairs of a row
-            // through its slots and its candidate mask); those in slots are exact and need nothing
-            unsigned long long in_slot[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-            for (int j = 0; j < kRecSlots; ++j) {
-                if (ks[j] == kRecEmpty || !(ks[j] & kRecExactBit)) continue;
-                const int k = ks[j] & kRecCompMask;
-                in_slot[k >> 6] |= 1ull << (k & 63);
-                ks[j] = (unsigned short)(ks[j] & ~kRecListed);               // exact, in a slot: not a candidate
-                if (!PREV) ds[j] = f32_down(dist_of(sc[k], vb));
-            }
-            for (int w = 0; w < W; ++w) {
-                const unsigned long long lost = fresh[w] & ~in_slot[w];
-                mk[w] |= lost;
-                listed += __builtin_popcountll(lost);
-            }
-        }
+        unsigned long long in_slot[4] = {0ull, 0ull, 0ull, 0ull};
         unsigned sel = 0, ex = 0;
         int in_slots = 0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
-            const bool c1 = ks[j] != kRecEmpty && (ks[j] & kRecListed);
-            sel |= c1 ? (1u << j) : 0u;
-            ex |= (ks[j] != kRecEmpty && (ks[j] & kRecExactBit)) ? (1u << j) : 0u;
-            in_slots += c1 ? 1 : 0;
-            rec.k[(int64_t)j * rec.npad + n] = ks[j] == kRecEmpty ? kRecEmpty : (unsigned short)(ks[j] & kRecCompMask);
+            ks[j] = kRecEmpty;
+            ds[j] = __builtin_huge_valf();
+            if (s[j] == 0xFFFFFFFFu) continue;
+            const int k = (int)(s[j] & 0xFFu);
+            ks[j] = (unsigned short)k;
+            const unsigned long long bit = 1ull << (k & 63);
+            if (fresh[k >> 6] & bit) {                         // exact, in a slot: not a candidate
+                in_slot[k >> 6] |= bit;
+                ex |= 1u << j;
+                ds[j] = f32_down(dist_of(sc[k], PREV ? u[(int64_t)k * npad + n] : vb));
+            } else {
+                ds[j] = dist_lower_f32(sc[k], (double)sweep_key_bound(s[j]));
+                if (mk[k >> 6] & bit) {
+                    sel |= 1u << j;
+                    ++in_slots;
+                }
+            }
+        }
+        // exact pairs that did not get a slot are listed again (rec_finish_kernel finds the evaluated pairs of a row
+        // through its slots and its candidate mask)
+        for (int w = 0; w < W; ++w) {
+            mk[w] |= fresh[w] & ~in_slot[w];
+            listed += __builtin_popcountll(mk[w]);
+        }
+        // rest bound: the ninth key bounds every pair without a slot; if that pair is itself listed (nine or more
+        // candidates: a refreshed row), the largest bound among the pairs that are not listed is the tighter one
+        float rest = -__builtin_huge_valf();
+        if (s[kRecSlots] != 0xFFFFFFFFu) {
+            const int k9 = (int)(s[kRecSlots] & 0xFFu);
+            rest = ((mk[k9 >> 6] >> (k9 & 63)) & 1ull) ? restmax : sweep_key_bound(s[kRecSlots]);
+        }
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) {
+            rec.k[(int64_t)j * rec.npad + n] = ks[j];
             rec.d[(int64_t)j * rec.npad + n] = ds[j];
         }
         rec.B[n] = rest;
