@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpa
 // Three small passes build the per-component sample lists without atomics (and in a fixed order):
 //   select_mask_kernel   one thread per sample: which components are candidates (bit mask, 64 components per word),
 //                        and how many candidates each 256-sample block has per component;
-//   scan_counts_kernel   exclusive scan of those block counts per component -> block bases and list lengths;
+//   scan_parts / scan_apply   exclusive scan of those block counts per component -> block bases and list lengths;
 //   fill_lists_kernel    every block writes its candidates at its bases.
 constexpr int kSelRows = 256;
 
@@ -207,35 +207,65 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
     }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += kSelRows)
-        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
 }
 
-// per component (one workgroup each): blk[b][k] <- sum of blk[b'][k] over b' < b; counts[k] = the total
-__global__ __launch_bounds__(256) void scan_counts_kernel(int* __restrict__ blk, int blocks, int K, int* __restrict__ counts) {
-    __shared__ int part[256];
-    const int k = blockIdx.x;
-    const int per = (blocks + 255) / 256;
-    const int b0 = threadIdx.x * per, b1 = (b0 + per < blocks) ? b0 + per : blocks;
+// Exclusive scan of the block counts per component, blk[k][b] (component-major: a component's counts are contiguous)
+// <- sum of blk[k][b'] over b' < b; counts[k] = the total.  Two launches of K x kScanParts workgroups: sums of the
+// parts, then every part scans its range from the sum of the parts before it.
+constexpr int kScanParts = 16;
+
+__device__ __forceinline__ int block_excl_scan(int v, int* wtot /*[4] shared*/, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        inc += lane >= o ? t : 0;
+    }
+    __syncthreads();                      // wtot may still be read from the previous tile
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_parts_kernel(const int* __restrict__ blk, int blocks, int* __restrict__ parts) {
+    __shared__ int wtot[4];
+    const int k = blockIdx.x, p = blockIdx.y;
+    const int per = (blocks + kScanParts - 1) / kScanParts;
+    const int b0 = p * per, b1 = b0 + per < blocks ? b0 + per : blocks;
     int s = 0;
-    for (int b = b0; b < b1; ++b) s += blk[(int64_t)b * K + k];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int t = 0; t < 256; ++t) {
-            const int v = part[t];
-            part[t] = run;
-            run += v;
-        }
-        counts[k] = run;
+    for (int b = b0 + threadIdx.x; b < b1; b += 256) s += blk[(int64_t)k * blocks + b];
+    int total;
+    (void)block_excl_scan(s, wtot, total);
+    if (threadIdx.x == 0) parts[k * kScanParts + p] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(int* __restrict__ blk, int blocks, const int* __restrict__ parts,
+                                                         int* __restrict__ counts) {
+    __shared__ int wtot[4];
+    const int k = blockIdx.x, p = blockIdx.y;
+    const int per = (blocks + kScanParts - 1) / kScanParts;
+    const int b0 = p * per, b1 = b0 + per < blocks ? b0 + per : blocks;
+    int run = 0;
+    for (int q = 0; q < p; ++q) run += parts[k * kScanParts + q];
+    for (int t0 = b0; t0 < b1; t0 += 256) {
+        const int b = t0 + threadIdx.x;
+        const int v = b < b1 ? blk[(int64_t)k * blocks + b] : 0;
+        int total;
+        const int ex = block_excl_scan(v, wtot, total);
+        if (b < b1) blk[(int64_t)k * blocks + b] = run + ex;
+        run += total;
     }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int b = b0; b < b1; ++b) {
-        const int v = blk[(int64_t)b * K + k];
-        blk[(int64_t)b * K + k] = run;
-        run += v;
-    }
+    if (p == kScanParts - 1 && threadIdx.x == 0) counts[k] = run;
+}
+
+inline void launch_scan_counts(hipStream_t st, int* blk, int blocks, int K, int* counts, int* parts /*[K * kScanParts]*/) {
+    hipLaunchKernelGGL(scan_parts_kernel, dim3(K, kScanParts), dim3(256), 0, st, blk, blocks, parts);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(K, kScanParts), dim3(256), 0, st, blk, blocks, parts, counts);
 }
 
 __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned long long* __restrict__ masks, int64_t npad,
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
             present &= present - 1;
             const int k = 64 * w + b;
             const unsigned long long bal = __ballot((mk >> b) & 1ull);
-            int off = blk_base[(int64_t)blockIdx.x * K + k];
+            int off = blk_base[(int64_t)k * gridDim.x + blockIdx.x];
             for (int v = 0; v < wave; ++v) off += wcnt[v][k];
             if ((mk >> b) & 1ull)
                 lists[(int64_t)k * cap + off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int)n;
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
     if ((threadIdx.x & 63) == 0) wact[wave] = active;
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += kSelRows)
-        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (threadIdx.x == 0) apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
 }
 

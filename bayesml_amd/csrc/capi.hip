@@ -184,7 +184,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart};
-    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
+    int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32};
     for (void* p : rbufs)
@@ -379,6 +379,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->plan, (size_t)(ws->K + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->plan_m, (size_t)(ws->K + 2) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->blk, (size_t)sel_blocks * ws->K * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->scan_parts, (size_t)ws->K * kScanParts * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->epart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->opart, (size_t)sel_blocks * sizeof(double));
@@ -494,7 +495,7 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
     hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K, ws->khat,
                        ws->masks, ws->blk);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
+    launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K, ws->blk,
                        ws->lists, ws->npad);
     hipLaunchKernelGGL(perm_compose_kernel, dim3((unsigned)((n_rows + 255) / 256), ws->K), dim3(256), 0, st, ws->lists, ws->npad,
@@ -548,7 +549,7 @@ static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepArgs& a, con
 // masks -> per-component lists -> chunk plan -> exact f64 evaluation of the listed pairs (all sized on the device)
 static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int is64, bool vec, int sel_grid, hipStream_t st) {
     span_begin(ws, kSpanSelect, st);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, sel_grid, ws->K, ws->counts);
+    launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, a.n_rows, ws->K, ws->blk,
                        ws->lists, ws->npad);
     hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
@@ -736,7 +737,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                ws->ctr);
             hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
                                ws->K, ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
-            hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, st, ws->apart, nullptr, nullptr, nullptr, sel_grid, ws->ctr);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(1024), 0, st, ws->apart, nullptr, nullptr, nullptr, sel_grid, ws->ctr);
             // records for the next pass (one more sweep of the array, ~1 % of the dense kernel's time)
             if (can_prune && big)
                 hipLaunchKernelGGL(rec_build_kernel<false>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
@@ -838,7 +839,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         span_begin(ws, kSpanLse, st);
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
                            ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(4), dim3(256), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, sel_grid,
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(4), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, sel_grid,
                            ws->ctr);
         e = hipGetLastError();
         span_end(ws, st);
@@ -963,7 +964,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // masks and block counts of the active pairs were written by lse_mask_kernel / rec_finish_kernel at the end of the E-step
         if (!ws->active_lists) {
             span_begin(ws, kSpanLists, st);
-            hipLaunchKernelGGL(scan_counts_kernel, dim3(ws->K), dim3(256), 0, st, ws->blk, nblk, ws->K, ws->counts);
+            launch_scan_counts(st, ws->blk, nblk, ws->K, ws->counts, ws->scan_parts);
             hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
                                ws->blk, ws->lists, ws->npad);
             e = hipGetLastError();
@@ -980,6 +981,20 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         rows_per_split = 1024;
         MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks, 1024,
                          ws->npad, ws->K, ws->slabs};
+        // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
+        if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8) &&
+            std::getenv("GMMVB_MSTEP_LIST_XC") == nullptr) {
+            if (ws->sorted) {
+                la.x32 = (const float*)ws->xp;
+                la.ldx = ws->D;
+            } else if (vec) {
+                la.x32 = (const float*)x_dev;
+                la.ldx = ldx;
+            }
+            la.n_rows = n_rows;
+            la.D = ws->D;
+            la.pivot = ws->pivot;
+        }
         span_begin(ws, kSpanMstepMain, st);
         e = launch_mstep_list(ws->T, (int)grid, st, la, &name);
         span_end(ws, st);

@@ -330,4 +330,46 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
     }
 }
 
+// The same over the caller's f32 rows (or the workspace's regrouped f32 copy) instead of the centred f64 copy: with
+// one or two active components per row every listed row is read about once, so the kernel's HBM traffic is the rows
+// themselves - 4 D bytes instead of 8 D - and the conversion and pivot subtraction (the very operations that made the
+// centred copy: identical values) ride in the shadow of the MFMAs.
+template <int T>
+__global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
+    const float* __restrict__ x, int64_t ldx, int64_t n_rows, int D, const double* __restrict__ pivot,
+    const double* __restrict__ lnrho, const double* __restrict__ lse, const int* __restrict__ lists, int64_t cap,
+    const int* __restrict__ counts, const int* __restrict__ plan, int64_t npad, int K, double* __restrict__ slabs) {
+    constexpr int WS = mstep_ws(T);
+    constexpr int KPW = mstep_waves(T, true) / WS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = (int)blockIdx.x * KPW + wave / WS;
+    if (c >= plan[K]) return;
+    int k = 0;
+    {
+        int lo = 0, hi = K;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (plan[mid] <= c) lo = mid;
+            else hi = mid;
+        }
+        k = lo;
+    }
+    const int R = plan[K + 1];
+    const int sub = wave % WS;
+    const int64_t lo = (int64_t)(c - plan[k]) * R;
+    int64_t hi = lo + R;
+    if (hi > counts[k]) hi = counts[k];
+    const double* lr = lnrho + (int64_t)k * npad;
+    const int* list = lists + (int64_t)k * cap;
+    double* out = slabs + (int64_t)c * slab_len(T);
+    if constexpr (WS == 1) {
+        mstep_body<T, 1, 0, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, 0, out, list);
+    } else {
+        if (sub == 0)
+            mstep_body<T, 2, 0, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, 0, out, list);
+        else
+            mstep_body<T, 2, 1, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, 0, out, list);
+    }
+}
+
 }  // namespace gmmvb

@@ -45,14 +45,18 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
 template <int T>
 static hipError_t go_list(int grid, hipStream_t st, const MstepListArgs& a) {
     hipLaunchKernelGGL(mstep_plan_kernel, dim3(1), dim3(64), 0, st, a.counts, a.K, a.cap_chunks, a.r_min, a.plan);
-    hipLaunchKernelGGL((mstep_list_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.xc, a.lnrho, a.lse,
-                       a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs);
+    if (a.x32)
+        hipLaunchKernelGGL((mstep_list_x32_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.x32, a.ldx, a.n_rows,
+                           a.D, a.pivot, a.lnrho, a.lse, a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs);
+    else
+        hipLaunchKernelGGL((mstep_list_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.xc, a.lnrho, a.lse,
+                           a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs);
     return hipGetLastError();
 }
 
 #define LCASE(TT)                                        \
     case TT:                                             \
-        *name = "mstep_list_f64<T=" #TT ",centred-f64>"; \
+        *name = a.x32 ? "mstep_list_f64<T=" #TT ",x=f32>" : "mstep_list_f64<T=" #TT ",centred-f64>"; \
         return go_list<TT>(grid, st, a);
 
 hipError_t launch_mstep_list(int T, int grid, hipStream_t st, const MstepListArgs& a, const char** name) {

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
-        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
         opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
-        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
         opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
-        blk_cnt[(int64_t)blockIdx.x * K + k] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
         mpart[blockIdx.x] = (double)(wmov[0] + wmov[1] + wmov[2] + wmov[3]);
@@ -729,19 +729,21 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
 // ctr[0] = sum apart (active pairs), ctr[1] = sum epart (exactly evaluated pairs), ctr[2] = sum opart (overflow rows),
 // ctr[3] = sum mpart (rows whose best component changed); a null part leaves its counter as it is.  One workgroup per
 // counter, fixed summation order.
-__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
-                                                        const double* __restrict__ opart, const double* __restrict__ mpart,
-                                                        int blocks, double* __restrict__ ctr) {
-    __shared__ double part[256];
+__global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
+                                                         const double* __restrict__ opart, const double* __restrict__ mpart,
+                                                         int blocks, double* __restrict__ ctr) {
+    __shared__ double part[16];
     const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : (blockIdx.x == 2 ? opart : mpart));
     if (!src) return;
-    double a = 0.0;
-    for (int b = threadIdx.x; b < blocks; b += 256) a += src[b];
-    part[threadIdx.x] = a;
+    double a = 0.0;                                   // (integer-valued addends below 2^53: any order is exact)
+    for (int b = threadIdx.x; b < blocks; b += 1024) a += src[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
-        for (int i = 0; i < 256; ++i) t += part[i];
+        for (int i = 0; i < 16; ++i) t += part[i];
         ctr[blockIdx.x] = t;
     }
 }

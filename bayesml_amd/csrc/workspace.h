@@ -91,7 +91,8 @@ struct gmmvb_workspace {
     bool active_lists = false; // the lists currently hold the active rows of the last E-step (scan + fill done)
     int* khat = nullptr;       // [npad]
     int* counts = nullptr;     // [K]
-    int* blk = nullptr;        // [ceil(npad / 256)][K] candidates per selection block -> block bases
+    int* blk = nullptr;        // [K][blocks of 256 rows] candidates per selection block -> block bases
+    int* scan_parts = nullptr; // [K][kScanParts] partial sums of the scan over blk
     unsigned long long* masks = nullptr;   // [ceil(K / 64)][npad] candidate components of every sample
     double* slabs = nullptr;   // [S_cap][K][slab_len]
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
