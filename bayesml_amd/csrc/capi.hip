@@ -975,11 +975,13 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // chunks of list entries (mstep.h): as many slabs as the workspace holds, at least 1024 entries per chunk
         const int cap_chunks = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
         grid = (cap_chunks + kpw - 1) / kpw;
-        const int64_t most = (n_rows * (int64_t)ws->K + 1023) / 1024 + ws->K;      // no more chunks than this can exist
+        int r_min = 1024;
+        if (const char* v = std::getenv("GMMVB_MSTEP_CHUNK")) r_min = std::max(64, atoi(v) / 64 * 64);
+        const int64_t most = (n_rows * (int64_t)ws->K + r_min - 1) / r_min + ws->K;      // no more chunks than this can exist
         if ((most + kpw - 1) / kpw < grid) grid = (most + kpw - 1) / kpw;
         S = 0;
-        rows_per_split = 1024;
-        MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks, 1024,
+        rows_per_split = r_min;
+        MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks, r_min,
                          ws->npad, ws->K, ws->slabs};
         // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
         if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8) &&
