@@ -268,9 +268,12 @@ inline void launch_scan_counts(hipStream_t st, int* blk, int blocks, int K, int*
     hipLaunchKernelGGL(scan_apply_kernel, dim3(K, kScanParts), dim3(256), 0, st, blk, blocks, parts, counts);
 }
 
+// lock (delta lists of the settled-row cache, records.h): rows that leave the cache (state 2) are listed with the sign
+// bit set and become free, rows that enter it (state 3) become settled - every such row is in exactly one list.
 __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned long long* __restrict__ masks, int64_t npad,
                                                               int64_t n_rows, int K, const int* __restrict__ blk_base,
-                                                              int* __restrict__ lists, int64_t cap) {
+                                                              int* __restrict__ lists, int64_t cap,
+                                                              unsigned char* __restrict__ lock = nullptr) {
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
@@ -298,8 +301,15 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
             const unsigned long long bal = __ballot((mk >> b) & 1ull);
             int off = blk_base[(int64_t)k * gridDim.x + blockIdx.x];
             for (int v = 0; v < wave; ++v) off += wcnt[v][k];
-            if ((mk >> b) & 1ull)
-                lists[(int64_t)k * cap + off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int)n;
+            if ((mk >> b) & 1ull) {
+                int entry = (int)n;
+                if (lock) {
+                    const bool leaves = lock[n] == 2;
+                    entry = leaves ? (int)((unsigned)entry | 0x80000000u) : entry;
+                    lock[n] = leaves ? 0 : 1;
+                }
+                lists[(int64_t)k * cap + off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = entry;
+            }
         }
     }
 }
@@ -453,8 +463,10 @@ __global__ void reduce_stats_kernel(const double* __restrict__ slabs, int S, int
 }
 
 // The same for the list M-step's chunk slabs (mstep.h): component k owns slabs plan[k] .. plan[k + 1] - 1.
+// accumulate: stats += the sum (the settled-row cache taking in a pass's delta lists); add: stats = the sum + add (the
+// statistics of a pass = its lists + the cache), add in the layout of stats.
 __global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int* __restrict__ plan, int K, int D, int T,
-                                     double* __restrict__ stats) {
+                                     double* __restrict__ stats, int accumulate = 0, const double* __restrict__ add = nullptr) {
     const int k = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = tri_pairs(T);
@@ -463,10 +475,13 @@ __global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int
     double v = 0.0;
     const int c0 = plan[k], c1 = plan[k + 1];
     for (int c = c0; c < c1; ++c) v += slabs[(int64_t)c * L + e];
-    double* ns = stats;
-    double* h = stats + K;
-    double* a = stats + 2 * (int64_t)K;
-    double* B = a + (int64_t)K * D;
+    auto put = [&](int64_t idx) {
+        double o = v;
+        if (accumulate) o += stats[idx];
+        if (add) o += add[idx];
+        stats[idx] = o;
+    };
+    const int64_t ns0 = 0, h0 = K, a0 = 2 * (int64_t)K, B0 = a0 + (int64_t)K * D;
     if (e < P * 256) {
         const int p = e >> 8, r = (e >> 6) & 3, lane = e & 63;
         int t2 = 0;
@@ -476,15 +491,15 @@ __global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int
         const int f1 = T * row + t1, f2 = T * col + t2;
         if (f1 >= D || f2 >= D) return;
         if (t1 == t2 && row > col) return;   // diagonal tiles: keep one triangle, mirror it (exact symmetry)
-        B[((int64_t)k * D + f1) * D + f2] = v;
-        B[((int64_t)k * D + f2) * D + f1] = v;
+        put(B0 + ((int64_t)k * D + f1) * D + f2);
+        if (f1 != f2) put(B0 + ((int64_t)k * D + f2) * D + f1);
     } else if (e < P * 256 + 16 * T) {
         const int f = e - P * 256;
-        if (f < D) a[(int64_t)k * D + f] = v;
+        if (f < D) put(a0 + (int64_t)k * D + f);
     } else if (e == P * 256 + 16 * T) {
-        ns[k] = v;
+        put(ns0 + k);
     } else {
-        h[k] = v;
+        put(h0 + k);
     }
 }
 

@@ -118,7 +118,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
         {&ws->xc, 0},
         {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K},
-        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->ctr, 4}, {&ws->drift, 4 * (int64_t)K}};
+        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->ctr, 6}, {&ws->drift, 4 * (int64_t)K}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
         if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
@@ -132,6 +132,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         v = std::getenv("GMMVB_ESTEP_PRUNE");
         ws->prune = (v && std::strcmp(v, "0") == 0) ? 0 : ((v && std::strcmp(v, "force") == 0) ? 2 : 1);
         if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;
+        v = std::getenv("GMMVB_SETTLE_MARGIN");                    // nats; negative = never settle rows
+        if (v) ws->settle_margin = std::atof(v);
     }
     {
         const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0 && ws->bound_i8;
@@ -169,8 +171,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         return GMMVB_ENOMEM;
     }
     e = hipMemset(ws->pivot, 0, (size_t)D * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 4 * sizeof(double));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 4 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 6 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 6 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ctr_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         gmmvb_workspace_destroy(ws);
@@ -186,7 +188,8 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart};
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
-    void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32};
+    void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
+                     ws->lock, ws->dlock, ws->dmask, ws->dblk, ws->cache, ws->spart, ws->gpart, ws->rmask, ws->rblk};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -276,6 +279,10 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(pivot)", e);
     ws->xc_src = nullptr;      // the centred copy (if any) is stale now
+    if (ws->lock_live) {               // the settled rows belonged to the previous state of affairs
+        ws->lock_live = false;
+        ws->lock_reset = true;
+    }
     return GMMVB_OK;
 }
 
@@ -343,6 +350,10 @@ int gmmvb_forget(gmmvb_workspace* ws) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     ws->forget = true;
     ws->have_drift = false;
+    if (ws->lock_live) {               // the settled rows belonged to the previous state of affairs
+        ws->lock_live = false;
+        ws->lock_reset = true;
+    }
     return GMMVB_OK;
 }
 
@@ -381,6 +392,15 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->blk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->scan_parts, (size_t)ws->K * kScanParts * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * np * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->lock, (size_t)np);
+    if (e == hipSuccess) e = hipMemset(ws->lock, 0, (size_t)np);
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->dlock, (size_t)np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->dblk, (size_t)sel_blocks * ws->K * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->cache, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->spart, (size_t)sel_blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->gpart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->epart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->opart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mpart, (size_t)sel_blocks * sizeof(double));
@@ -416,7 +436,11 @@ static int fetch_counters(gmmvb_workspace* ws) {
         if (ws->pend_mode == 0) {              // dense pass: every pair evaluated, no records involved
             ws->lag_eval = (double)ws->pend_rows * ws->K;
             ws->lag_over = 0.0;
-        } else {                               // a bound pass / sweep also evaluated every row's (previous) best component
+            ws->lag_settled = 0.0;
+            ws->lag_listed = ws->lag_act;
+        } else {
+            ws->lag_settled = ws->ctr_host[4];
+            ws->lag_listed = ws->ctr_host[5];                               // a bound pass / sweep also evaluated every row's (previous) best component
             ws->lag_eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? ws->pend_round0 : 0.0);
             ws->lag_over = ws->ctr_host[2];
             // rows whose best component changed: after a regrouping they no longer sit with their component's rows.
@@ -464,6 +488,10 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
     if (rc) return rc;
     ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
+    if (ws->lock_live) {               // the settled rows belonged to the previous state of affairs
+        ws->lock_live = false;
+        ws->lock_reset = true;
+    }
     ws->sorted = false;                // ... and the internal row order is the caller's again
     ws->rec_valid = false;
     ws->dense_valid = false;
@@ -611,11 +639,16 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             bool carry = hinted && ws->rec_valid && !(tg > 0.0 && tg < 0.985);
             // (the sweep's bounds erode by each component's own gamma: the spare-candidate rule below ends a run of
             // sweeps when a fresh bound pass has become cheaper; 24 in a row at most)
-            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && ws->sweeps < 24;
+            // (settled rows, workspace.h, live on sweeps: no cap and no switch to records while there are any - their
+            // carried bounds are refreshed whenever a row comes loose)
+            const bool may_settle = ws->settle_margin >= 0.0 && ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
+                                    ws->xc_ldx == ldx;
+            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && (ws->sweeps < 24 || may_settle);
+            if (sweep && may_settle) carry = false;
             if ((carry || sweep) && known && ws->lag_mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
-                const double spare = std::max(0.0, ws->lag_eval - ws->lag_act) / pairs;
+                const double spare = std::max(0.0, ws->lag_eval - (ws->lag_act - ws->lag_settled)) / pairs;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
@@ -635,10 +668,29 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
     }
     ws->forget = false;
+    // Settled rows survive only from sweep to sweep over the same rows, with the M-step in between having applied the
+    // delta lists.  Anything else drops them; the rows then have no active pair on record, which only a pass that
+    // rebuilds everything (bound or dense) can digest.
+    bool settle = false;
+    if (ws->lock) {
+        const bool keep = mode == kSweep && same_rows && !ws->lock_reset && !ws->delta_pending;
+        if (ws->lock_reset || (ws->lock_live && !keep)) {
+            if (mode == kSweep || mode == kCarry) mode = kBound;
+            (void)hipMemsetAsync(ws->lock, 0, (size_t)ws->npad, st);
+            (void)hipMemsetAsync(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double), st);
+            ws->lock_live = false;
+        }
+        ws->lock_reset = false;
+        ws->delta_pending = false;
+        settle = mode == kSweep && ws->settle_margin >= 0.0 && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
+                 ws->xc_rows == n_rows && ws->xc_ldx == ldx;
+    }
+    ws->settled_fresh = false;
     if (std::getenv("GMMVB_DEBUG"))
-        std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g) gamma=%.3f rec_valid=%d drift=%d\n",
+        std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",
                      mode, (int)known, ws->lag_mode, ws->lag_act / n_rows, ws->lag_eval / n_rows, ws->lag_over / n_rows,
-                     ws->typical_gamma, (int)ws->rec_valid, (int)ws->have_drift);
+                     ws->lag_settled / n_rows, ws->lag_listed / n_rows, ws->typical_gamma, (int)ws->rec_valid,
+                     (int)ws->have_drift, (int)settle);
     if (mode == kBound && ws->img_i8b) {
         // How many output blocks the bound pass evaluates.  Cost model per (sample, component) pair, in units of
         // 1e-11 s measured at C3 (profiles/r1_v6_*): bound pass 0.12 per block pair + 0.039 per row of y; exact pass
@@ -737,7 +789,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                ws->ctr);
             hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
                                ws->K, ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
-            hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(1024), 0, st, ws->apart, nullptr, nullptr, nullptr, sel_grid, ws->ctr);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(1024), 0, st, ws->apart, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               sel_grid, ws->ctr);
             // records for the next pass (one more sweep of the array, ~1 % of the dense kernel's time)
             if (can_prune && big)
                 hipLaunchKernelGGL(rec_build_kernel<false>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
@@ -805,7 +858,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step active-pair evaluation", e);
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
-                                   ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
+                                   ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
+                                   settle ? ws->lock : nullptr, ws->dlock);
                 span_end(ws, st);
             } else {
                 span_begin(ws, kSpanSelect, st);
@@ -816,7 +870,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step best-component evaluation", e);
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
-                                   ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart);
+                                   ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
+                                   settle ? ws->lock : nullptr, ws->dlock);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;
@@ -838,9 +893,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
         span_begin(ws, kSpanLse, st);
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
-                           ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(4), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, sel_grid,
-                           ws->ctr);
+                           ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32,
+                           settle ? ws->lock : nullptr, ws->dlock, settle ? ws->settle_margin : -1.0,
+                           settle ? ws->dmask : nullptr, settle ? ws->dblk : nullptr, ws->spart, ws->gpart);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(6), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, ws->spart,
+                           ws->gpart, sel_grid, ws->ctr);
         e = hipGetLastError();
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "rec_finish launch", e);
@@ -848,10 +905,14 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->rec_valid = true;
         ws->rec_live = true;
         ws->evaluated = -1.0;
+        if (settle) {
+            ws->lock_live = true;
+            ws->delta_pending = true;
+        }
     }
     // counters -> pinned host memory, behind an event (read by the next pass, or by gmmvb_last_sparsity)
     if (counted) {
-        e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 4 * sizeof(double), hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 6 * sizeof(double), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(ws->ctr_ev, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step counters", e);
         ws->ctr_pending = true;
@@ -860,7 +921,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // pairs evaluated before the counted selection: every row's best component, or (sweep over the previous
         // pass's lists) the previous pass's active pairs
         ws->pend_first_sorted = sorted_now;
-        ws->pend_round0 = (mode == kSweep && ws->sweep_prev && known) ? ws->lag_act : (double)n_rows;
+        ws->pend_round0 = (mode == kSweep && ws->sweep_prev && known) ? ws->lag_listed : (double)n_rows;
         ws->act_rows = n_rows;
     } else {
         ws->ctr_pending = false;
@@ -898,6 +959,11 @@ int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_
     ws->e_rows = n_rows;
     ws->n_spans = 0;
     ws->bounds_rows = 0;               // the array holds responsibilities now, nothing a later E-step may carry over
+    if (ws->lock_live) {               // the settled rows belonged to the previous state of affairs
+        ws->lock_live = false;
+        ws->lock_reset = true;
+    }
+
     ws->rec_valid = false;
     ws->dense_valid = false;
     ws->rec_live = false;
@@ -947,7 +1013,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (ws->rec_live) {
             // a pass on records is sparse by construction; the last counters that have arrived can still veto
             poll_counters(ws);
-            if (ws->lag_valid && ws->lag_rows == n_rows && ws->lag_act > 0.35 * pairs) sparse = false;
+            if (ws->lag_valid && ws->lag_rows == n_rows && ws->lag_act > 0.35 * pairs && !ws->lock_live) sparse = false;
         } else {
             // after a dense E-step the host has been waiting for that kernel anyway: read this pass's own count
             rc = fetch_counters(ws);
@@ -956,11 +1022,63 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
     }
     if (sparse && ws->K > 256) sparse = false;
+    if (ws->lock_live && !sparse)
+        return fail(GMMVB_ESTATE, "settled rows need the list M-step over the matrix of the E-step (gmmvb_prepare_rows)");
     if (sparse) {      // E-step output: only the samples that can change the f64 sums, through per-component lists
         rc = ensure_lists(ws);
         if (rc) return rc;
         const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
+        const int cap_chunks0 = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
+        int r_min0 = 1024;
+        if (const char* v = std::getenv("GMMVB_MSTEP_CHUNK")) r_min0 = std::max(64, atoi(v) / 64 * 64);
+        MstepListArgs la0{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks0, r_min0,
+                          ws->npad, ws->K, ws->slabs};
+        // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
+        if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8) &&
+            std::getenv("GMMVB_MSTEP_LIST_XC") == nullptr) {
+            if (ws->sorted) {
+                la0.x32 = (const float*)ws->xp;
+                la0.ldx = ws->D;
+            } else if (vec) {
+                la0.x32 = (const float*)x_dev;
+                la0.ldx = ldx;
+            }
+            la0.n_rows = n_rows;
+            la0.D = ws->D;
+            la0.pivot = ws->pivot;
+        }
+        int64_t lgrid = (cap_chunks0 + kpw - 1) / kpw;
+        {
+            const int64_t most = (n_rows * (int64_t)ws->K + r_min0 - 1) / r_min0 + ws->K;      // no more chunks than this can exist
+            if ((most + kpw - 1) / kpw < lgrid) lgrid = (most + kpw - 1) / kpw;
+        }
+        const int elems0 = tri_pairs(ws->T) * 256 + 16 * ws->T + 2;
+        if (ws->lock_live && ws->delta_pending) {
+            // the rows that settled or came loose in this pass (rec_finish_kernel's delta masks) enter / leave the
+            // cache of settled rows - before the pass's own lists are built in the same buffers
+            span_begin(ws, kSpanLists, st);
+            launch_scan_counts(st, ws->dblk, nblk, ws->K, ws->counts, ws->scan_parts);
+            hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->dmask, ws->npad, n_rows, ws->K,
+                               ws->dblk, ws->lists, ws->npad, ws->lock);
+            span_end(ws, st);
+            MstepListArgs ld = la0;
+            ld.direct_r = 3;
+            // at most one entry per row: far fewer chunks than the lists of a pass can have
+            int64_t dgrid = ((n_rows + r_min0 - 1) / r_min0 + ws->K + kpw - 1) / kpw;
+            if (dgrid > lgrid) dgrid = lgrid;
+            const char* dname = "";
+            span_begin(ws, kSpanMstepMain, st);
+            e = launch_mstep_list(ws->T, (int)dgrid, st, ld, &dname);
+            span_end(ws, st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row delta launch", e);
+            span_begin(ws, kSpanReduce, st);
+            hipLaunchKernelGGL(reduce_chunks_kernel, dim3((elems0 + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, ws->plan_m,
+                               ws->K, ws->D, ws->T, ws->cache, 1, nullptr);
+            span_end(ws, st);
+            ws->delta_pending = false;
+            ws->active_lists = false;
+        }
         // masks and block counts of the active pairs were written by lse_mask_kernel / rec_finish_kernel at the end of the E-step
         if (!ws->active_lists) {
             span_begin(ws, kSpanLists, st);
@@ -973,30 +1091,10 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             ws->active_lists = true;
         }
         // chunks of list entries (mstep.h): as many slabs as the workspace holds, at least 1024 entries per chunk
-        const int cap_chunks = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
-        grid = (cap_chunks + kpw - 1) / kpw;
-        int r_min = 1024;
-        if (const char* v = std::getenv("GMMVB_MSTEP_CHUNK")) r_min = std::max(64, atoi(v) / 64 * 64);
-        const int64_t most = (n_rows * (int64_t)ws->K + r_min - 1) / r_min + ws->K;      // no more chunks than this can exist
-        if ((most + kpw - 1) / kpw < grid) grid = (most + kpw - 1) / kpw;
+        grid = lgrid;
         S = 0;
-        rows_per_split = r_min;
-        MstepListArgs la{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks, r_min,
-                         ws->npad, ws->K, ws->slabs};
-        // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
-        if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8) &&
-            std::getenv("GMMVB_MSTEP_LIST_XC") == nullptr) {
-            if (ws->sorted) {
-                la.x32 = (const float*)ws->xp;
-                la.ldx = ws->D;
-            } else if (vec) {
-                la.x32 = (const float*)x_dev;
-                la.ldx = ldx;
-            }
-            la.n_rows = n_rows;
-            la.D = ws->D;
-            la.pivot = ws->pivot;
-        }
+        rows_per_split = r_min0;
+        const MstepListArgs& la = la0;
         span_begin(ws, kSpanMstepMain, st);
         e = launch_mstep_list(ws->T, (int)grid, st, la, &name);
         span_end(ws, st);
@@ -1017,7 +1115,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     span_begin(ws, kSpanReduce, st);
     if (sparse)
         hipLaunchKernelGGL(reduce_chunks_kernel, dim3((elems + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, ws->plan_m,
-                           ws->K, ws->D, ws->T, stats_dev);
+                           ws->K, ws->D, ws->T, stats_dev, 0, ws->lock_live ? ws->cache : nullptr);
     else
         hipLaunchKernelGGL(reduce_stats_kernel, dim3((elems + 255) / 256, ws->K), dim3(256), 0, st, ws->slabs, (int)S,
                            ws->K, ws->D, ws->T, stats_dev);
@@ -1037,6 +1135,46 @@ int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64
     return gmmvb_mstep(ws, x_dev, ldx, n_rows, stats_dev, stream);
 }
 
+// Read-outs while rows are settled: evaluate their component's ln rho for the parameters of the last E-step
+// (records.h, settled_mask_kernel).  Uses the list buffers: the next E-step rebuilds its first round from khat.
+static int refresh_settled(gmmvb_workspace* ws, hipStream_t st) {
+    if (!ws->params_used) return fail(GMMVB_ESTATE, "the parameters changed after the E-step whose settled rows are read");
+    const int64_t n_rows = ws->e_rows;
+    const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
+    const int words = (ws->K + 63) / 64;
+    if (!ws->rmask) {
+        hipError_t em = hipMalloc((void**)&ws->rmask, (size_t)words * ws->npad * sizeof(unsigned long long));
+        if (em == hipSuccess) em = hipMalloc((void**)&ws->rblk, (size_t)((ws->npad + kSelRows - 1) / kSelRows) * ws->K * sizeof(int));
+        if (em != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (settled-row read-out)", em);
+    }
+    const int is64 = ws->x_dtype == GMMVB_F64;
+    bool vec = false;
+    int rc = check_x(ws, ws->bounds_x, ws->bounds_ldx, n_rows, &vec);
+    if (rc) return rc;
+    EstepArgs a{ws->bounds_x, ws->bounds_ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
+    if (ws->sorted) {
+        a.x = ws->xp;
+        a.ldx = ws->D;
+        vec = ws->D % 16 == 0;
+    }
+    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->khat, ws->npad, n_rows, ws->K,
+                       ws->rmask, ws->rblk);
+    launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows, ws->K, ws->rblk,
+                       ws->lists, ws->npad);
+    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K, estep_gather_rows_per_wg(ws->T, is64),
+                       ws->plan);
+    hipError_t e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row evaluation", e);
+    hipLaunchKernelGGL(settled_lse_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lock, ws->khat, ws->lnrho,
+                       ws->npad, n_rows, ws->lse);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row read-out", e);
+    ws->active_lists = false;
+    ws->settled_fresh = true;
+    return GMMVB_OK;
+}
+
 static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out, void* stream, int mode) {
     if (!ws || !out) return fail(GMMVB_EINVAL, "null argument");
     if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
@@ -1045,10 +1183,14 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
     const int64_t total = n_rows * ws->K;
     const bool hmm_gamma = ws->e_state == 3 && mode == 1;      // responsibilities of an HMM pass = gamma
     if (ws->e_state == 1 && ws->rec_live) {                    // the pass lived on records: only listed pairs are exact
+        if (ws->lock_live && !ws->settled_fresh) {
+            const int rc = refresh_settled(ws, (hipStream_t)stream);
+            if (rc) return rc;
+        }
         const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
         hipLaunchKernelGGL(rec_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec,
                            ws->masks, ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out,
-                           ws->sorted ? ws->iperm : nullptr);
+                           ws->sorted ? ws->iperm : nullptr, ws->lock_live ? ws->lock : nullptr, ws->khat);
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return fail(GMMVB_EHIP, "rec_readout launch", er);
         return GMMVB_OK;

@@ -119,8 +119,9 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     // from hoisting those loads above the VALU block, where a register it then reuses forces a
     // vmcnt(0) right behind the issue (measured: -7 % on the whole kernel).
     int idx_n = 0;                         // LIST: rows of the next batch of 64 entries, one per lane
+    // (a list entry's sign bit marks a row that LEAVES the settled-row cache: weight -1, direct_r == 3)
     if constexpr (LIST) idx_n = (lo + lane < hi) ? list[lo + lane] : 0;
-    RawRow nxt = load_row(LIST ? (int64_t)__shfl(idx_n, g) : lo + g);
+    RawRow nxt = load_row(LIST ? (int64_t)(__shfl(idx_n, g) & 0x7FFFFFFF) : lo + g);
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         // responsibilities of 64 samples, one per lane
         const int64_t nl = c0 + lane;
@@ -128,9 +129,11 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
         if constexpr (LIST) idx_n = (nl + 64 < hi) ? list[nl + 64] : 0;
         double r_l = 0.0;
         if (nl < hi) {
-            const int64_t src = LIST ? (int64_t)idx_l : nl;
+            const int64_t src = LIST ? (int64_t)(idx_l & 0x7FFFFFFF) : nl;
             const double v = lr[src];
-            if (direct_r == 2) {                 // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
+            if (LIST && direct_r == 3) {         // delta lists of the settled-row cache: whole rows in or out
+                r_l = idx_l < 0 ? -1.0 : 1.0;
+            } else if (direct_r == 2) {                 // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
                 r_l = v;
                 if (v > 0.0) hsum = fma(v, aux_k[src], hsum);
             } else if (direct_r) {
@@ -167,7 +170,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (LIST)
-                nxt = load_row((int64_t)__shfl(st == 15 ? idx_n : idx_l, (4 * (st + 1) + g) & 63));
+                nxt = load_row((int64_t)(__shfl(st == 15 ? idx_n : idx_l, (4 * (st + 1) + g) & 63) & 0x7FFFFFFF));
             else
                 nxt = load_row(c0 + 4 * (st + 1) + g);
             rr_n = __shfl(r_l, (4 * (st + 1) + g) & 63);      // st = 15: unused (next batch recomputes)
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
     const int* __restrict__ counts,        // [K] list lengths
     const int* __restrict__ plan,          // [K + 2] chunk plan
     int64_t npad, int K,
-    double* __restrict__ slabs /*[chunks][slab_len(T)]*/) {
+    double* __restrict__ slabs /*[chunks][slab_len(T)]*/, int direct_r /*0, or 3: delta lists*/) {
     constexpr int WS = mstep_ws(T);
     constexpr int KPW = mstep_waves(T, true) / WS;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -321,12 +324,12 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
     const int* list = lists + (int64_t)k * cap;
     double* out = slabs + (int64_t)c * slab_len(T);
     if constexpr (WS == 1) {
-        mstep_body<T, 1, 0, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, 0, out, list);
+        mstep_body<T, 1, 0, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, direct_r, out, list);
     } else {
         if (sub == 0)
-            mstep_body<T, 2, 0, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, 0, out, list);
+            mstep_body<T, 2, 0, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, direct_r, out, list);
         else
-            mstep_body<T, 2, 1, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, 0, out, list);
+            mstep_body<T, 2, 1, double, true, true, true>(xc, 16 * T, npad, 16 * T, nullptr, lr, lse, nullptr, lo, hi, direct_r, out, list);
     }
 }
 
@@ -338,7 +341,8 @@ template <int T>
 __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     const float* __restrict__ x, int64_t ldx, int64_t n_rows, int D, const double* __restrict__ pivot,
     const double* __restrict__ lnrho, const double* __restrict__ lse, const int* __restrict__ lists, int64_t cap,
-    const int* __restrict__ counts, const int* __restrict__ plan, int64_t npad, int K, double* __restrict__ slabs) {
+    const int* __restrict__ counts, const int* __restrict__ plan, int64_t npad, int K, double* __restrict__ slabs,
+    int direct_r /*0, or 3: delta lists*/) {
     constexpr int WS = mstep_ws(T);
     constexpr int KPW = mstep_waves(T, true) / WS;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -363,12 +367,12 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     const int* list = lists + (int64_t)k * cap;
     double* out = slabs + (int64_t)c * slab_len(T);
     if constexpr (WS == 1) {
-        mstep_body<T, 1, 0, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, 0, out, list);
+        mstep_body<T, 1, 0, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
     } else {
         if (sub == 0)
-            mstep_body<T, 2, 0, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, 0, out, list);
+            mstep_body<T, 2, 0, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
         else
-            mstep_body<T, 2, 1, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, 0, out, list);
+            mstep_body<T, 2, 1, float, true, false, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
     }
 }
 

@@ -332,9 +332,12 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              const int* __restrict__ khat, RecArrays rec,
                                                              unsigned long long* __restrict__ masks,
                                                              int* __restrict__ blk_cnt, double* __restrict__ epart,
-                                                             double* __restrict__ opart) {
+                                                             double* __restrict__ opart,
+                                                             unsigned char* __restrict__ lock /*null: no settled rows*/,
+                                                             float* __restrict__ dlock) {
     __shared__ int wcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
+    __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
     __shared__ double sc[256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     for (int k = tid; k < K; k += kSelRows) {
         const double g = drift[k] * (1.0 - 1e-6);
         sp[k] = make_float4(g > 0.0 ? f32_down(g) : 0.0f, f32_up(drift[K + k]), f32_up(c_new[k]), f32_down(drift[2 * K + k]));
+        sq[k] = make_float2(f32_up(drift[3 * K + k] * (1.0 + 1e-6)), f32_down(c_new[k]));
         sc[k] = c_new[k];
     }
     __syncthreads();
@@ -372,9 +376,25 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             vb = u[(int64_t)kb * npad + n];
         }
         const double thr = vb - k100Ln2;
-        const bool over = !(thr > ninf);                       // NaN / -inf: nothing to compare with
-        const float thr_f = over ? -__builtin_huge_valf() : f32_down(thr);      // over: every pair is a candidate
+        // A settled row (its single active component kset has r = 1.0 exactly, the row's addend sits in the statistics
+        // cache) has nothing evaluated for it: the reference is a LOWER bound of ln rho under the new parameters, from
+        // the carried upper bound of its distance, d' = Gamma d + delta.  No candidate against it: the row stays settled.
+        const bool settled = lock != nullptr && lock[n] == 1;
+        int kset = -1;
+        float d_set = 0.0f, thr_set = 0.0f;
+        if (settled) {
+            kset = PREV ? khat[n] : kb;
+            const float dn = fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
+            const float lb = sq[kset].y - dn * dn * 0.5000005f;
+            d_set = dn;
+            thr_set = (lb - fabsf(lb) * 2.4e-7f) - 69.5f;
+        }
+        const bool by_bound = settled && PREV;                 // (!PREV: the component has just been evaluated, vb is exact)
+        const bool over = !by_bound && !(thr > ninf);          // NaN / -inf: nothing to compare with
+        const float thr_f = by_bound ? thr_set : (over ? -__builtin_huge_valf() : f32_down(thr));   // over: every pair is a candidate
         if (over) fresh[0] = fresh[1] = fresh[2] = fresh[3] = 0ull;
+        unsigned long long nocand[4] = {fresh[0], fresh[1], fresh[2], fresh[3]};
+        if (by_bound) nocand[kset >> 6] |= 1ull << (kset & 63);
         unsigned s[kRecSlots + 1];
 #pragma unroll
         for (int j = 0; j <= kRecSlots; ++j) s[j] = 0xFFFFFFFFu;
@@ -382,7 +402,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         // uniform base + 32-bit row offset: one address register for the whole loop
         const bool near = npad < (int64_t(1) << 29);
         const unsigned off = (unsigned)(near ? n : 0) * 4u;
-        auto pair = [&](int k, int bit, float old, unsigned long long fw, unsigned long long& mw) {
+        auto pair = [&](int k, int bit, float old, unsigned long long fw, unsigned long long nw, unsigned long long& mw) {
             const float4 p = sp[k];
             const float qd = p.w - old;
             const float sq = __builtin_amdgcn_sqrtf(qd + qd);              // NaN for qd < 0 or NaN: no information
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             *(float*)(base + off) = ubn;
             const unsigned long long b1 = 1ull << bit;
             const bool isf = (fw & b1) != 0ull;                            // (its exact value is written below)
-            const bool cand = !(ubn < thr_f) && !isf;
+            const bool cand = !(ubn < thr_f) && (nw & b1) == 0ull;
             mw |= cand ? b1 : 0ull;
             restmax = fmaxf(restmax, (cand || isf) ? -__builtin_huge_valf() : ubn);
             sweep_chain(s, isf ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
@@ -405,6 +425,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         };
         for (int w = 0; w < W; ++w) {
             const unsigned long long fw = w == 0 ? fresh[0] : (w == 1 ? fresh[1] : (w == 2 ? fresh[2] : fresh[3]));
+            const unsigned long long nw = w == 0 ? nocand[0] : (w == 1 ? nocand[1] : (w == 2 ? nocand[2] : nocand[3]));
             unsigned long long mw = 0ull;
             const int kend = K < 64 * w + 64 ? K : 64 * w + 64;
             int k0 = 64 * w;
@@ -413,13 +434,23 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
 #pragma unroll
                 for (int q = 0; q < 8; ++q) pre[q] = old_of(k0 + q);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) pair(k0 + q, k0 + q - 64 * w, pre[q], fw, mw);
+                for (int q = 0; q < 8; ++q) pair(k0 + q, k0 + q - 64 * w, pre[q], fw, nw, mw);
             }
-            for (; k0 < kend; ++k0) pair(k0, k0 - 64 * w, old_of(k0), fw, mw);
+            for (; k0 < kend; ++k0) pair(k0, k0 - 64 * w, old_of(k0), fw, nw, mw);
             if (w == 0) mk[0] = mw;
             else if (w == 1) mk[1] = mw;
             else if (w == 2) mk[2] = mw;
             else mk[3] = mw;
+        }
+        bool stays = false;
+        if (settled) {
+            stays = (mk[0] | mk[1] | mk[2] | mk[3]) == 0ull;
+            if (stays) {
+                dlock[n] = PREV ? d_set : f32_up(dist_of(sc[kset], vb) * (1.0 + 1e-9));
+            } else {
+                lock[n] = 2;                                   // loose: evaluated like any other row; rec_finish_kernel decides
+                if (PREV) mk[kset >> 6] |= 1ull << (kset & 63);
+            }
         }
         // the exact pairs: their values replace the carried bounds, and they compete for slots by value (the single
         // reference pair of the !PREV form always gets one)
@@ -480,7 +511,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         rec.B[n] = rest;
         rec.exact[n] = (unsigned char)(over ? 0 : ex);
         rec.sel[n] = (unsigned char)(over ? 0 : sel);
-        rec.flags[n] = (unsigned char)(over ? 1 : (listed > in_slots ? 2 : 0));
+        rec.flags[n] = (unsigned char)(stays ? 4 : (over ? 1 : (listed > in_slots ? 2 : 0)));
         over_i = over ? 1 : 0;
         for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
     }
@@ -523,19 +554,34 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               unsigned long long* __restrict__ masks,
                                                               int* __restrict__ blk_cnt, double* __restrict__ apart,
                                                               double* __restrict__ mpart /*rows whose best component changed*/,
-                                                              float* __restrict__ ub32 /*[K][npad] per-pair bounds (sweeps)*/) {
+                                                              float* __restrict__ ub32 /*[K][npad] per-pair bounds (sweeps)*/,
+                                                              unsigned char* __restrict__ lock /*null: rows never settle*/,
+                                                              float* __restrict__ dlock, double settle_margin /*< 0: never*/,
+                                                              unsigned long long* __restrict__ dmask, int* __restrict__ dblk,
+                                                              double* __restrict__ spart, double* __restrict__ gpart) {
     __shared__ int wcnt[4][256];
-    __shared__ int wact[4], wmov[4];
+    __shared__ int dcnt[4][256];
+    __shared__ int wact[4], wmov[4], wset[4], wlist[4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
-    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = dcnt[wave][k] = 0;
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
     const bool valid = n < n_rows;
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
-    int active = 0;
+    unsigned long long dm[4] = {0ull, 0ull, 0ull, 0ull};     // the row enters (its best component) / leaves (khat_before) the cache
+    int active = 0, settled_i = 0;
     const int khat_before = valid ? khat[n] : 0;
     const unsigned fl = valid ? rec.flags[n] : 0u;
-    if (valid && fl == 2u) {
+    // what the decision to settle a row needs: its log-normaliser, best component and value, the largest value or bound
+    // among the other components (+inf: unknown - the row is left alone)
+    double row_l = 0.0, row_best = 0.0, row_second = __builtin_huge_val();
+    int row_arg = -1;
+    if (valid && fl == 4u) {
+        // settled row: nothing was evaluated, nothing changes (lse[n] and the ln rho entries are stale until a read-out
+        // asks for them); it still counts as one active pair
+        active = 1;
+        settled_i = 1;
+    } else if (valid && fl == 2u) {
         // refreshed row: slots (exact where listed, carried bounds otherwise) and the listed components without a slot
         // compete for the C slots again; what does not get one joins the rest bound (B holds the unlisted ones already)
         const unsigned live = (unsigned)rec.sel[n] | (unsigned)rec.exact[n];
@@ -614,6 +660,16 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                 }
             }
         }
+        if (!nan) {
+            float sec = rest;
+#pragma unroll
+            for (int j = 0; j < kRecSlots; ++j)
+                if (ks[j] != kRecEmpty && (int)(ks[j] & kRecCompMask) != arg) sec = (vs[j] > sec || vs[j] != vs[j]) ? vs[j] : sec;
+            row_l = l;
+            row_best = mx;
+            row_arg = arg == 0x7fffffff ? -1 : arg;
+            row_second = (double)sec;
+        }
     } else if (valid && fl == 0u) {
         unsigned live = (unsigned)rec.sel[n] | (unsigned)rec.exact[n];
         double v[kRecSlots];
@@ -655,6 +711,23 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                 mk[kk[j] >> 6] |= 1ull << (kk[j] & 63);
                 ++active;
             }
+        }
+        if (!nan && active == 1 && settle_margin >= 0.0 && lock != nullptr) {
+            double sec = (double)rec.B[n];
+#pragma unroll
+            for (int j = 0; j < kRecSlots; ++j) {
+                if (kk[j] == kRecEmpty || (int)kk[j] == arg) continue;
+                double o = v[j];
+                if (!((live >> j) & 1u)) {
+                    const double d = (double)rec.d[(int64_t)j * rec.npad + n];
+                    o = cvec[kk[j]] - 0.5 * d * d * (1.0 - 1e-6);
+                }
+                sec = (o > sec || o != o) ? o : sec;
+            }
+            row_l = l;
+            row_best = mx;
+            row_arg = arg == 0x7fffffff ? -1 : arg;
+            row_second = sec;
         }
     } else if (valid) {
         // overflow row: every value of the dense row is exact.  One sweep: running max / sum and the C nearest
@@ -704,36 +777,77 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
             }
         }
     }
-    if (valid)
-        for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
-    for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+    int in_lists = 0;
+    if (valid && lock != nullptr && fl != 4u) {
+        const unsigned lk = lock[n];                    // 0 free, 2 came loose in this pass's sweep
+        // settle: exactly one active component (r = 1.0 to the last bit) and every other component at least
+        // settle_margin nats below the 2^-100 line - the slack the next passes' carried bounds will eat into
+        bool worthy = settle_margin >= 0.0 && row_arg >= 0 && active == 1 &&
+                      row_second < row_l - k100Ln2 - settle_margin;
+        if (lk == 2u) {
+            if (worthy && row_arg == khat_before) {
+                lock[n] = 1;                            // still the same single component: it never left the cache
+            } else {
+                dm[khat_before >> 6] |= 1ull << (khat_before & 63);      // leaves the cache (fill_lists clears the state)
+                worthy = false;
+            }
+        } else if (worthy) {
+            lock[n] = 3;                                // enters the cache at this pass's M-step
+            dm[row_arg >> 6] |= 1ull << (row_arg & 63);
+        }
+        if (worthy) {
+            dlock[n] = f32_up(dist_of(cvec[row_arg], row_best) * (1.0 + 1e-9));
+            mk[row_arg >> 6] &= ~(1ull << (row_arg & 63));               // accounted for through the cache, not the lists
+        }
+    }
+    if (valid) {
+        for (int w = 0; w < W; ++w) {
+            masks[(int64_t)w * npad + n] = mk[w];
+            in_lists += __builtin_popcountll(mk[w]);
+            if (dmask) dmask[(int64_t)w * npad + n] = dm[w];
+        }
+    }
+    for (int w = 0; w < W; ++w) {
+        count_word(mk[w], w, wave, wcnt);
+        count_word(dm[w], w, wave, dcnt);
+    }
     int moved = (valid && khat[n] != khat_before) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         active += __shfl_xor(active, o);
         moved += __shfl_xor(moved, o);
+        settled_i += __shfl_xor(settled_i, o);
+        in_lists += __shfl_xor(in_lists, o);
     }
     if ((tid & 63) == 0) {
         wact[wave] = active;
         wmov[wave] = moved;
+        wset[wave] = settled_i;
+        wlist[wave] = in_lists;
     }
     __syncthreads();
-    for (int k = tid; k < K; k += kSelRows)
+    for (int k = tid; k < K; k += kSelRows) {
         blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        if (dblk) dblk[(int64_t)k * gridDim.x + blockIdx.x] = dcnt[0][k] + dcnt[1][k] + dcnt[2][k] + dcnt[3][k];
+    }
     if (tid == 0) {
         apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
         mpart[blockIdx.x] = (double)(wmov[0] + wmov[1] + wmov[2] + wmov[3]);
+        spart[blockIdx.x] = (double)(wset[0] + wset[1] + wset[2] + wset[3]);
+        gpart[blockIdx.x] = (double)(wlist[0] + wlist[1] + wlist[2] + wlist[3]);
     }
 }
 
 // ctr[0] = sum apart (active pairs), ctr[1] = sum epart (exactly evaluated pairs), ctr[2] = sum opart (overflow rows),
-// ctr[3] = sum mpart (rows whose best component changed); a null part leaves its counter as it is.  One workgroup per
-// counter, fixed summation order.
+// ctr[3] = sum mpart (rows whose best component changed), ctr[4] = sum spart (settled rows), ctr[5] = sum gpart (pairs
+// in the M-step's lists); a null part leaves its counter as it is.  One workgroup per counter.
 __global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
                                                          const double* __restrict__ opart, const double* __restrict__ mpart,
+                                                         const double* __restrict__ spart, const double* __restrict__ gpart,
                                                          int blocks, double* __restrict__ ctr) {
     __shared__ double part[16];
-    const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : (blockIdx.x == 2 ? opart : mpart));
+    const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : (blockIdx.x == 2 ? opart :
+                        (blockIdx.x == 3 ? mpart : (blockIdx.x == 4 ? spart : gpart))));
     if (!src) return;
     double a = 0.0;                                   // (integer-valued addends below 2^53: any order is exact)
     for (int b = threadIdx.x; b < blocks; b += 1024) a += src[b];
@@ -748,18 +862,51 @@ __global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restric
     }
 }
 
+// Read-outs while rows are settled: their component's ln rho is evaluated for the parameters in force on request only.
+// settled_mask_kernel lists (row, khat) of every settled row; after the gather settled_lse_kernel sets lse[n] to that
+// value (the row's only active pair: its log-normaliser to the last bit).
+__global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned char* __restrict__ lock,
+                                                                const int* __restrict__ khat, int64_t npad, int64_t n_rows,
+                                                                int K, unsigned long long* __restrict__ masks,
+                                                                int* __restrict__ blk_cnt) {
+    __shared__ int wcnt[4][256];
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
+    const bool valid = n < n_rows;
+    const int W = (K + 63) / 64;
+    const int wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    const int kh = (valid && lock[n] == 1) ? khat[n] : -1;
+    for (int w = 0; w < W; ++w) {
+        const unsigned long long mk = (kh >= 0 && (kh >> 6) == w) ? 1ull << (kh & 63) : 0ull;
+        if (valid) masks[(int64_t)w * npad + n] = mk;
+        count_word(mk, w, wave, wcnt);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += kSelRows)
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+}
+
+__global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const int* __restrict__ khat,
+                                   const double* __restrict__ lnrho, int64_t npad, int64_t n_rows, double* __restrict__ lse) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_rows && lock[n] == 1) lse[n] = lnrho[(int64_t)khat[n] * npad + n];
+}
+
 // Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-100) marks the pairs
 // whose exact value is in the dense array.  mode 0: ln rho - exact for active pairs and for exact slots, otherwise the
 // record's upper bound (at least 100 ln 2 below the row's log-normaliser); mode 1: responsibilities, exactly 0 for inactive pairs.
 __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __restrict__ masks,
                                    const double* __restrict__ lnrho, const double* __restrict__ lse,
                                    const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
-                                   int mode, double* __restrict__ out, const int* __restrict__ iperm) {
+                                   int mode, double* __restrict__ out, const int* __restrict__ iperm,
+                                   const unsigned char* __restrict__ lock, const int* __restrict__ khat) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rows * K) return;
     const int64_t n = iperm ? iperm[row0 + e / K] : row0 + e / K;
     const int k = (int)(e % K);
     bool exact = ((masks[(int64_t)(k >> 6) * npad + n] >> (k & 63)) & 1ull) != 0 || (rec.flags[n] & 1) != 0;
+    // a settled row's pair (in the cache instead of the M-step's mask; refreshed by the caller before this read-out)
+    if (lock && (lock[n] == 1 || lock[n] == 3) && khat[n] == k) exact = true;
     if (mode == 1) {
         out[e] = exact ? exp(lnrho[(int64_t)k * npad + n] - lse[n]) : 0.0;
         return;

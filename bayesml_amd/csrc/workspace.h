@@ -61,8 +61,9 @@ struct gmmvb_workspace {
     // [3] rows whose best component changed.
     // Written on the device at the end of every E-step and copied to pinned host memory behind an event; the NEXT
     // E-step / M-step reads whatever has arrived (policy decisions lag one pass, results never depend on them).
-    double* ctr = nullptr;             // [4] device
-    double* ctr_host = nullptr;        // [4] pinned
+    // [4] settled rows (see below), [5] pairs in the M-step's lists.
+    double* ctr = nullptr;             // [6] device
+    double* ctr_host = nullptr;        // [6] pinned
     hipEvent_t ctr_ev = nullptr;
     bool ctr_pending = false;          // a copy is in flight ...
     int pend_mode = 0;                 // ... of an E-step of this mode over pend_rows rows
@@ -70,7 +71,7 @@ struct gmmvb_workspace {
     double pend_round0 = 0.0;          // pairs that E-step evaluated before its counted selection round
     bool sweep_prev = false;           // the last sweep's first round used the previous pass's M-step lists
     bool lag_valid = false;            // lag_* = counters of the most recent E-step whose copy has arrived
-    double lag_act = 0.0, lag_eval = 0.0, lag_over = 0.0;
+    double lag_act = 0.0, lag_eval = 0.0, lag_over = 0.0, lag_settled = 0.0, lag_listed = 0.0;
     int64_t lag_rows = 0;
     int lag_mode = 0;
     bool forget = false;               // gmmvb_forget: the next parameters are unrelated to the last E-step's
@@ -95,6 +96,23 @@ struct gmmvb_workspace {
     int* scan_parts = nullptr; // [K][kScanParts] partial sums of the scan over blk
     unsigned long long* masks = nullptr;   // [ceil(K / 64)][npad] candidate components of every sample
     double* slabs = nullptr;   // [S_cap][K][slab_len]
+    // Settled rows (records.h): a row with ONE active component has r = 1.0 exactly, its addend to that component's
+    // statistics does not depend on the parameters.  While the carried bounds prove that it stays so, the row is neither
+    // evaluated (E) nor accumulated (M): its addend lives in `cache` (same layout as the statistics), which changes only
+    // through the rows that settle or come loose in a pass (the M-step's delta lists).
+    unsigned char* lock = nullptr;     // [npad] 0 free, 1 settled, 2 came loose in this pass, 3 settled in this pass
+    float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
+    unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
+    int* dblk = nullptr;               // [K][blocks] their block counts
+    double* cache = nullptr;           // [stats_len] statistics of the settled rows
+    double* spart = nullptr, *gpart = nullptr;   // [blocks] settled rows / listed pairs per selection block
+    unsigned long long* rmask = nullptr;   // read-outs of settled rows: their (row, component) pairs ...
+    int* rblk = nullptr;                   // ... and block counts (allocated by the first such read-out)
+    bool lock_live = false;            // some rows may be settled: the list M-step must add the cache
+    bool delta_pending = false;        // an E-step marked rows 2 / 3 and no M-step has applied them yet
+    bool lock_reset = false;           // the settled state belongs to something else now: drop it at the next E-step
+    bool settled_fresh = false;        // read-outs: the settled rows' ln rho / lse were re-evaluated for the parameters in force
+    double settle_margin = 30.0;       // nats of slack demanded before a row is settled (< 0: never settle)
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
     void* xp = nullptr;        // [max_rows][D] x in internal row order (storage dtype), allocated with the lists
     int* perm = nullptr, *iperm = nullptr, *perm_tmp = nullptr;   // [npad] each
