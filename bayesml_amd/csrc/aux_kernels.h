@@ -268,12 +268,14 @@ inline void launch_scan_counts(hipStream_t st, int* blk, int blocks, int K, int*
     hipLaunchKernelGGL(scan_apply_kernel, dim3(K, kScanParts), dim3(256), 0, st, blk, blocks, parts, counts);
 }
 
-// lock (delta lists of the settled-row cache, records.h): rows that leave the cache (state 2) are listed with the sign
-// bit set and become free, rows that enter it (state 3) become settled - every such row is in exactly one list.
+// lock (delta lists of the cache of single-component rows, records.h rec_finish_kernel): a row that leaves its
+// component's cache (state 2, or 4 in the list of a component that is not its best any more) is listed with the sign
+// bit set; one that enters (state 3, or 4 in the list of its new best component khat) without.  State afterwards: 0 / 1.
 __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned long long* __restrict__ masks, int64_t npad,
                                                               int64_t n_rows, int K, const int* __restrict__ blk_base,
                                                               int* __restrict__ lists, int64_t cap,
-                                                              unsigned char* __restrict__ lock = nullptr) {
+                                                              unsigned char* __restrict__ lock = nullptr,
+                                                              const int* __restrict__ khat = nullptr) {
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
@@ -291,6 +293,9 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
         }
     }
     __syncthreads();
+    const unsigned lk0 = (lock && valid) ? lock[n] : 0u;
+    const int kh0 = (lock && valid) ? khat[n] : 0;
+    if (lk0 >= 2u) lock[n] = lk0 == 2u ? 0 : 1;
     for (int w = 0; w < W; ++w) {
         const unsigned long long mk = valid ? masks[(int64_t)w * npad + n] : 0ull;
         unsigned long long present = wave_or(mk);
@@ -304,9 +309,8 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
             if ((mk >> b) & 1ull) {
                 int entry = (int)n;
                 if (lock) {
-                    const bool leaves = lock[n] == 2;
+                    const bool leaves = lk0 == 2u || (lk0 == 4u && kh0 != k);
                     entry = leaves ? (int)((unsigned)entry | 0x80000000u) : entry;
-                    lock[n] = leaves ? 0 : 1;
                 }
                 lists[(int64_t)k * cap + off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = entry;
             }

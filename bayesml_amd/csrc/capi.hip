@@ -134,6 +134,10 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;
         v = std::getenv("GMMVB_SETTLE_MARGIN");                    // nats; negative = never settle rows
         if (v) ws->settle_margin = std::atof(v);
+        v = std::getenv("GMMVB_SETTLE_GAMMA");
+        if (v) ws->settle_gamma = std::atof(v);
+        v = std::getenv("GMMVB_MSTEP_CACHE");
+        ws->cache_on = !(v && std::strcmp(v, "0") == 0);
     }
     {
         const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0 && ws->bound_i8;
@@ -189,7 +193,8 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
-                     ws->lock, ws->dlock, ws->dmask, ws->dblk, ws->cache, ws->spart, ws->gpart, ws->rmask, ws->rblk};
+                     ws->lock, ws->dlock, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart,
+                     ws->rmask, ws->rblk};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -397,6 +402,8 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dlock, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dblk, (size_t)sel_blocks * ws->K * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->mmask, (size_t)words * np * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->mblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->cache, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double));
     if (e == hipSuccess) e = hipMemset(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->spart, (size_t)sel_blocks * sizeof(double));
@@ -618,7 +625,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool same_rows = ws->bounds_rows == n_rows && ws->bounds_x == x_dev && ws->bounds_ldx == ldx;
     const bool known = ws->lag_valid && ws->lag_rows == n_rows && !ws->ctr_pending;     // counters of the previous pass
     // the previous pass's M-step left its per-component lists of active rows (and their masks) in the workspace
-    const bool prev_lists = ws->active_lists && ws->e_state == 1 && ws->act_rows == n_rows && same_rows;
+    // (or the masks and block counts they are built from)
+    const bool prev_lists = (ws->active_lists || ws->blk_fresh) && ws->e_state == 1 && ws->act_rows == n_rows && same_rows;
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
         bool sparse_ok = ws->prune == 2;
@@ -641,7 +649,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // sweeps when a fresh bound pass has become cheaper; 24 in a row at most)
             // (settled rows, workspace.h, live on sweeps: no cap and no switch to records while there are any - their
             // carried bounds are refreshed whenever a row comes loose)
-            const bool may_settle = ws->settle_margin >= 0.0 && ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
+            const bool may_settle = ws->cache_on && ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
                                     ws->xc_ldx == ldx;
             bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && (ws->sweeps < 24 || may_settle);
             if (sweep && may_settle) carry = false;
@@ -679,12 +687,15 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             (void)hipMemsetAsync(ws->lock, 0, (size_t)ws->npad, st);
             (void)hipMemsetAsync(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double), st);
             ws->lock_live = false;
+            ws->skip_used = false;
         }
         ws->lock_reset = false;
         ws->delta_pending = false;
-        settle = mode == kSweep && ws->settle_margin >= 0.0 && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
+        settle = mode == kSweep && ws->cache_on && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
                  ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     }
+    // rows are settled (left out of the E-step as well) only while the parameters move little
+    const double skip_margin = (settle && ws->settle_margin >= 0.0 && ws->typical_gamma >= ws->settle_gamma) ? ws->settle_margin : -1.0;
     ws->settled_fresh = false;
     if (std::getenv("GMMVB_DEBUG"))
         std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",
@@ -848,6 +859,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // component of every row.
             if (prev_lists) {
                 span_begin(ws, kSpanSelect, st);
+                if (!ws->active_lists) {        // (the M-step's lists left out the rows in its cache)
+                    launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+                    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
+                                       ws->blk, ws->lists, ws->npad);
+                }
                 hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
                                    estep_gather_rows_per_wg(ws->T, is64), ws->plan);
                 span_end(ws, st);
@@ -894,8 +910,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         span_begin(ws, kSpanLse, st);
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
                            ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32,
-                           settle ? ws->lock : nullptr, ws->dlock, settle ? ws->settle_margin : -1.0,
-                           settle ? ws->dmask : nullptr, settle ? ws->dblk : nullptr, ws->spart, ws->gpart);
+                           settle ? ws->lock : nullptr, ws->dlock, skip_margin, settle ? ws->dmask : nullptr,
+                           settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart);
         hipLaunchKernelGGL(sum_parts_kernel, dim3(6), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, ws->spart,
                            ws->gpart, sel_grid, ws->ctr);
         e = hipGetLastError();
@@ -930,6 +946,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     ws->act_host = -1.0;
     ws->active_lists = false;
+    ws->mlists_done = ws->mlists_lost = false;
+    if (skip_margin >= 0.0) ws->skip_used = true;
+    ws->blk_fresh = counted;
     ws->e_state = 1;
     ws->e_rows = n_rows;
     ws->params_used = true;
@@ -1060,7 +1079,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             span_begin(ws, kSpanLists, st);
             launch_scan_counts(st, ws->dblk, nblk, ws->K, ws->counts, ws->scan_parts);
             hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->dmask, ws->npad, n_rows, ws->K,
-                               ws->dblk, ws->lists, ws->npad, ws->lock);
+                               ws->dblk, ws->lists, ws->npad, ws->lock, ws->khat);
             span_end(ws, st);
             MstepListArgs ld = la0;
             ld.direct_r = 3;
@@ -1078,9 +1097,26 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             span_end(ws, st);
             ws->delta_pending = false;
             ws->active_lists = false;
+            ws->mlists_done = false;
         }
         // masks and block counts of the active pairs were written by lse_mask_kernel / rec_finish_kernel at the end of the E-step
-        if (!ws->active_lists) {
+        if (ws->lock_live) {
+            // the rows in the cache are left out: the M-step has its own masks (the E-step's next first round builds its
+            // lists from the full ones)
+            if (!ws->mlists_done) {
+                if (ws->mlists_lost)
+                    return fail(GMMVB_ESTATE, "the M-step's lists were used by a read-out of settled rows: call gmmvb_estep again");
+                span_begin(ws, kSpanLists, st);
+                launch_scan_counts(st, ws->mblk, nblk, ws->K, ws->counts, ws->scan_parts);
+                hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->mmask, ws->npad, n_rows, ws->K,
+                                   ws->mblk, ws->lists, ws->npad);
+                e = hipGetLastError();
+                span_end(ws, st);
+                if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);
+                ws->mlists_done = true;
+                ws->active_lists = false;
+            }
+        } else if (!ws->active_lists) {
             span_begin(ws, kSpanLists, st);
             launch_scan_counts(st, ws->blk, nblk, ws->K, ws->counts, ws->scan_parts);
             hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
@@ -1089,6 +1125,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             span_end(ws, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);
             ws->active_lists = true;
+            ws->blk_fresh = false;
         }
         // chunks of list entries (mstep.h): as many slabs as the workspace holds, at least 1024 entries per chunk
         grid = lgrid;
@@ -1157,8 +1194,8 @@ static int refresh_settled(gmmvb_workspace* ws, hipStream_t st) {
         a.ldx = ws->D;
         vec = ws->D % 16 == 0;
     }
-    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->khat, ws->npad, n_rows, ws->K,
-                       ws->rmask, ws->rblk);
+    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->khat, ws->npad, n_rows,
+                       ws->K, ws->rmask, ws->rblk);
     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows, ws->K, ws->rblk,
                        ws->lists, ws->npad);
@@ -1166,11 +1203,13 @@ static int refresh_settled(gmmvb_workspace* ws, hipStream_t st) {
                        ws->plan);
     hipError_t e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row evaluation", e);
-    hipLaunchKernelGGL(settled_lse_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lock, ws->khat, ws->lnrho,
-                       ws->npad, n_rows, ws->lse);
+    hipLaunchKernelGGL(settled_lse_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lock, ws->masks, ws->khat,
+                       ws->lnrho, ws->npad, n_rows, ws->K, ws->lse);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row read-out", e);
     ws->active_lists = false;
+    if (ws->mlists_done) ws->mlists_lost = true;
+    ws->mlists_done = false;
     ws->settled_fresh = true;
     return GMMVB_OK;
 }
@@ -1183,7 +1222,7 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
     const int64_t total = n_rows * ws->K;
     const bool hmm_gamma = ws->e_state == 3 && mode == 1;      // responsibilities of an HMM pass = gamma
     if (ws->e_state == 1 && ws->rec_live) {                    // the pass lived on records: only listed pairs are exact
-        if (ws->lock_live && !ws->settled_fresh) {
+        if (ws->lock_live && ws->skip_used && !ws->settled_fresh) {
             const int rc = refresh_settled(ws, (hipStream_t)stream);
             if (rc) return rc;
         }

@@ -376,20 +376,20 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             vb = u[(int64_t)kb * npad + n];
         }
         const double thr = vb - k100Ln2;
-        // A settled row (its single active component kset has r = 1.0 exactly, the row's addend sits in the statistics
-        // cache) has nothing evaluated for it: the reference is a LOWER bound of ln rho under the new parameters, from
-        // the carried upper bound of its distance, d' = Gamma d + delta.  No candidate against it: the row stays settled.
-        const bool settled = lock != nullptr && lock[n] == 1;
+        // A settled row (cached - its single active component kset has r = 1.0 exactly and its addend sits in the
+        // statistics cache - and left out of the lists by rec_finish_kernel) has nothing evaluated for it: the reference
+        // is a LOWER bound of ln rho under the new parameters, from the carried upper bound of its distance,
+        // d' = Gamma d + delta.  No candidate against it: the row stays settled.
+        const bool by_bound = PREV && lock != nullptr && lock[n] == 1 && (fresh[0] | fresh[1] | fresh[2] | fresh[3]) == 0ull;
         int kset = -1;
         float d_set = 0.0f, thr_set = 0.0f;
-        if (settled) {
-            kset = PREV ? khat[n] : kb;
+        if (by_bound) {
+            kset = khat[n];
             const float dn = fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
             const float lb = sq[kset].y - dn * dn * 0.5000005f;
             d_set = dn;
             thr_set = (lb - fabsf(lb) * 2.4e-7f) - 69.5f;
         }
-        const bool by_bound = settled && PREV;                 // (!PREV: the component has just been evaluated, vb is exact)
         const bool over = !by_bound && !(thr > ninf);          // NaN / -inf: nothing to compare with
         const float thr_f = by_bound ? thr_set : (over ? -__builtin_huge_valf() : f32_down(thr));   // over: every pair is a candidate
         if (over) fresh[0] = fresh[1] = fresh[2] = fresh[3] = 0ull;
@@ -443,14 +443,10 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             else mk[3] = mw;
         }
         bool stays = false;
-        if (settled) {
+        if (by_bound) {
             stays = (mk[0] | mk[1] | mk[2] | mk[3]) == 0ull;
-            if (stays) {
-                dlock[n] = PREV ? d_set : f32_up(dist_of(sc[kset], vb) * (1.0 + 1e-9));
-            } else {
-                lock[n] = 2;                                   // loose: evaluated like any other row; rec_finish_kernel decides
-                if (PREV) mk[kset >> 6] |= 1ull << (kset & 63);
-            }
+            if (stays) dlock[n] = d_set;
+            else mk[kset >> 6] |= 1ull << (kset & 63);         // loose: its component and the candidates are evaluated
         }
         // the exact pairs: their values replace the carried bounds, and they compete for slots by value (the single
         // reference pair of the !PREV form always gets one)
@@ -555,16 +551,18 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               int* __restrict__ blk_cnt, double* __restrict__ apart,
                                                               double* __restrict__ mpart /*rows whose best component changed*/,
                                                               float* __restrict__ ub32 /*[K][npad] per-pair bounds (sweeps)*/,
-                                                              unsigned char* __restrict__ lock /*null: rows never settle*/,
-                                                              float* __restrict__ dlock, double settle_margin /*< 0: never*/,
+                                                              unsigned char* __restrict__ lock /*null: no cache of single-component rows*/,
+                                                              float* __restrict__ dlock, double settle_margin /*< 0: rows never settle*/,
                                                               unsigned long long* __restrict__ dmask, int* __restrict__ dblk,
+                                                              unsigned long long* __restrict__ mmask, int* __restrict__ mblk,
                                                               double* __restrict__ spart, double* __restrict__ gpart) {
     __shared__ int wcnt[4][256];
     __shared__ int dcnt[4][256];
+    __shared__ int mcnt[4][256];
     __shared__ int wact[4], wmov[4], wset[4], wlist[4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
-    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = dcnt[wave][k] = 0;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = dcnt[wave][k] = mcnt[wave][k] = 0;
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
     const bool valid = n < n_rows;
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
@@ -712,6 +710,11 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                 ++active;
             }
         }
+        if (!nan) {
+            row_l = l;
+            row_best = mx;
+            row_arg = arg == 0x7fffffff ? -1 : arg;
+        }
         if (!nan && active == 1 && settle_margin >= 0.0 && lock != nullptr) {
             double sec = (double)rec.B[n];
 #pragma unroll
@@ -724,9 +727,6 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                 }
                 sec = (o > sec || o != o) ? o : sec;
             }
-            row_l = l;
-            row_best = mx;
-            row_arg = arg == 0x7fffffff ? -1 : arg;
             row_second = sec;
         }
     } else if (valid) {
@@ -759,6 +759,9 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         const double l = mx + log(s);
         lse[n] = l;
         khat[n] = arg;
+        row_l = l;
+        row_best = mx;
+        row_arg = (l == l) ? arg : -1;
         unsigned ex = 0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
@@ -777,39 +780,52 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
             }
         }
     }
+    // The cache of single-component rows (workspace.h): a row whose ONLY active component is k has r_nk = 1.0 to the last
+    // bit (the other terms of its log-normaliser are below 2^-100), so its addend to component k's statistics is the same
+    // in every pass in which that holds - it is kept in the cache and the row left out of the M-step's lists (mmask).
+    //   lock 0 -> 3  the row enters the cache of its component;  1 -> 1  it stays;  1 -> 2  it leaves;  1 -> 4  it moves
+    //   to another component (fill_lists_kernel gives the delta lists' entries their signs and settles the state).
+    // Settling goes one step further: if every other component is at least settle_margin nats below the 2^-100 line the
+    // row is also left out of the E-step's lists (masks); the next sweep then only checks its carried bounds.
+    unsigned long long mm[4] = {mk[0], mk[1], mk[2], mk[3]};         // the M-step's lists
     int in_lists = 0;
     if (valid && lock != nullptr && fl != 4u) {
-        const unsigned lk = lock[n];                    // 0 free, 2 came loose in this pass's sweep
-        // settle: exactly one active component (r = 1.0 to the last bit) and every other component at least
-        // settle_margin nats below the 2^-100 line - the slack the next passes' carried bounds will eat into
-        bool worthy = settle_margin >= 0.0 && row_arg >= 0 && active == 1 &&
-                      row_second < row_l - k100Ln2 - settle_margin;
-        if (lk == 2u) {
-            if (worthy && row_arg == khat_before) {
-                lock[n] = 1;                            // still the same single component: it never left the cache
-            } else {
-                dm[khat_before >> 6] |= 1ull << (khat_before & 63);      // leaves the cache (fill_lists clears the state)
-                worthy = false;
+        const unsigned lk = lock[n];
+        const bool single = row_arg >= 0 && active == 1;
+        if (lk == 1u) {
+            if (!(single && row_arg == khat_before)) {
+                dm[khat_before >> 6] |= 1ull << (khat_before & 63);
+                if (single) dm[row_arg >> 6] |= 1ull << (row_arg & 63);
+                lock[n] = single ? 4 : 2;
             }
-        } else if (worthy) {
-            lock[n] = 3;                                // enters the cache at this pass's M-step
+        } else if (single) {
             dm[row_arg >> 6] |= 1ull << (row_arg & 63);
+            lock[n] = 3;
         }
-        if (worthy) {
-            dlock[n] = f32_up(dist_of(cvec[row_arg], row_best) * (1.0 + 1e-9));
-            mk[row_arg >> 6] &= ~(1ull << (row_arg & 63));               // accounted for through the cache, not the lists
+        if (single) {
+            mm[row_arg >> 6] &= ~(1ull << (row_arg & 63));
+            if (settle_margin >= 0.0 && row_second < row_l - k100Ln2 - settle_margin) {
+                dlock[n] = f32_up(dist_of(cvec[row_arg], row_best) * (1.0 + 1e-9));
+                mk[row_arg >> 6] &= ~(1ull << (row_arg & 63));
+            }
         }
     }
     if (valid) {
         for (int w = 0; w < W; ++w) {
             masks[(int64_t)w * npad + n] = mk[w];
             in_lists += __builtin_popcountll(mk[w]);
-            if (dmask) dmask[(int64_t)w * npad + n] = dm[w];
+            if (dmask) {
+                dmask[(int64_t)w * npad + n] = dm[w];
+                mmask[(int64_t)w * npad + n] = mm[w];
+            }
         }
     }
     for (int w = 0; w < W; ++w) {
         count_word(mk[w], w, wave, wcnt);
-        count_word(dm[w], w, wave, dcnt);
+        if (dmask) {
+            count_word(dm[w], w, wave, dcnt);
+            count_word(mm[w], w, wave, mcnt);
+        }
     }
     int moved = (valid && khat[n] != khat_before) ? 1 : 0;
 #pragma unroll
@@ -828,7 +844,10 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows) {
         blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
-        if (dblk) dblk[(int64_t)k * gridDim.x + blockIdx.x] = dcnt[0][k] + dcnt[1][k] + dcnt[2][k] + dcnt[3][k];
+        if (dblk) {
+            dblk[(int64_t)k * gridDim.x + blockIdx.x] = dcnt[0][k] + dcnt[1][k] + dcnt[2][k] + dcnt[3][k];
+            mblk[(int64_t)k * gridDim.x + blockIdx.x] = mcnt[0][k] + mcnt[1][k] + mcnt[2][k] + mcnt[3][k];
+        }
     }
     if (tid == 0) {
         apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
@@ -865,7 +884,16 @@ __global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restric
 // Read-outs while rows are settled: their component's ln rho is evaluated for the parameters in force on request only.
 // settled_mask_kernel lists (row, khat) of every settled row; after the gather settled_lse_kernel sets lse[n] to that
 // value (the row's only active pair: its log-normaliser to the last bit).
+__device__ __forceinline__ bool row_settled(const unsigned char* __restrict__ lock,
+                                            const unsigned long long* __restrict__ emask, int64_t npad, int W, int64_t n) {
+    if (lock[n] != 1) return false;
+    unsigned long long any = 0ull;
+    for (int w = 0; w < W; ++w) any |= emask[(int64_t)w * npad + n];
+    return any == 0ull;                   // in the cache and in none of the E-step's lists
+}
+
 __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned char* __restrict__ lock,
+                                                                const unsigned long long* __restrict__ emask,
                                                                 const int* __restrict__ khat, int64_t npad, int64_t n_rows,
                                                                 int K, unsigned long long* __restrict__ masks,
                                                                 int* __restrict__ blk_cnt) {
@@ -875,7 +903,7 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
     const int W = (K + 63) / 64;
     const int wave = threadIdx.x >> 6;
     for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
-    const int kh = (valid && lock[n] == 1) ? khat[n] : -1;
+    const int kh = (valid && row_settled(lock, emask, npad, W, n)) ? khat[n] : -1;
     for (int w = 0; w < W; ++w) {
         const unsigned long long mk = (kh >= 0 && (kh >> 6) == w) ? 1ull << (kh & 63) : 0ull;
         if (valid) masks[(int64_t)w * npad + n] = mk;
@@ -886,10 +914,11 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
         blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
 }
 
-__global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const int* __restrict__ khat,
-                                   const double* __restrict__ lnrho, int64_t npad, int64_t n_rows, double* __restrict__ lse) {
+__global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const unsigned long long* __restrict__ emask,
+                                   const int* __restrict__ khat, const double* __restrict__ lnrho, int64_t npad,
+                                   int64_t n_rows, int K, double* __restrict__ lse) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < n_rows && lock[n] == 1) lse[n] = lnrho[(int64_t)khat[n] * npad + n];
+    if (n < n_rows && row_settled(lock, emask, npad, (K + 63) / 64, n)) lse[n] = lnrho[(int64_t)khat[n] * npad + n];
 }
 
 // Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-100) marks the pairs
@@ -906,7 +935,7 @@ __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __re
     const int k = (int)(e % K);
     bool exact = ((masks[(int64_t)(k >> 6) * npad + n] >> (k & 63)) & 1ull) != 0 || (rec.flags[n] & 1) != 0;
     // a settled row's pair (in the cache instead of the M-step's mask; refreshed by the caller before this read-out)
-    if (lock && (lock[n] == 1 || lock[n] == 3) && khat[n] == k) exact = true;
+    if (lock && (lock[n] == 1 || lock[n] >= 3) && khat[n] == k) exact = true;
     if (mode == 1) {
         out[e] = exact ? exp(lnrho[(int64_t)k * npad + n] - lse[n]) : 0.0;
         return;

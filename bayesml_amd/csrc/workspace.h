@@ -90,6 +90,7 @@ struct gmmvb_workspace {
     int prune = 1;
     int* lists = nullptr;      // [K][npad] sample lists (E-step candidates, then the M-step's active rows)
     bool active_lists = false; // the lists currently hold the active rows of the last E-step (scan + fill done)
+    bool blk_fresh = false;    // blk still holds the block COUNTS of masks (not yet scanned into bases)
     int* khat = nullptr;       // [npad]
     int* counts = nullptr;     // [K]
     int* blk = nullptr;        // [K][blocks of 256 rows] candidates per selection block -> block bases
@@ -104,15 +105,22 @@ struct gmmvb_workspace {
     float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
     int* dblk = nullptr;               // [K][blocks] their block counts
+    unsigned long long* mmask = nullptr;   // [ceil(K / 64)][npad] the M-step's lists: active pairs of the rows not in the cache
+    int* mblk = nullptr;               // [K][blocks] their block counts
     double* cache = nullptr;           // [stats_len] statistics of the settled rows
     double* spart = nullptr, *gpart = nullptr;   // [blocks] settled rows / listed pairs per selection block
     unsigned long long* rmask = nullptr;   // read-outs of settled rows: their (row, component) pairs ...
     int* rblk = nullptr;                   // ... and block counts (allocated by the first such read-out)
     bool lock_live = false;            // some rows may be settled: the list M-step must add the cache
-    bool delta_pending = false;        // an E-step marked rows 2 / 3 and no M-step has applied them yet
+    bool delta_pending = false;        // an E-step marked rows 2 / 3 / 4 and no M-step has applied them yet
+    bool mlists_done = false;          // the lists hold the M-step's own lists (mmask) of the last E-step
+    bool mlists_lost = false;          // ... did, until a read-out of settled rows used the buffers
+    bool skip_used = false;            // some pass since the cache was last emptied was allowed to settle rows
     bool lock_reset = false;           // the settled state belongs to something else now: drop it at the next E-step
     bool settled_fresh = false;        // read-outs: the settled rows' ln rho / lse were re-evaluated for the parameters in force
     double settle_margin = 30.0;       // nats of slack demanded before a row is settled (< 0: never settle)
+    double settle_gamma = 0.98;        // ... and only while the caller's drift summary (typical_gamma) is at least this
+    bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
     void* xp = nullptr;        // [max_rows][D] x in internal row order (storage dtype), allocated with the lists
     int* perm = nullptr, *iperm = nullptr, *perm_tmp = nullptr;   // [npad] each
