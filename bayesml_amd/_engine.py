@@ -48,6 +48,7 @@ SYMBOLS = {
     "gmmvb_kside_step": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_kside_drift": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "gmmvb_last_sparsity": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "gmmvb_last_work": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "gmmvb_comm_unique_id": (_int, [_vp]),
     "gmmvb_comm_create": (_int, [_vp, _int, _int, ctypes.POINTER(_vp)]),
     "gmmvb_comm_destroy": (_int, [_vp]),
@@ -306,6 +307,13 @@ class DataPass:
             _check(self.lib, self.lib.gmmvb_last_sparsity(self._ws, self._stream(), ctypes.byref(a), ctypes.byref(e)),
                    "gmmvb_last_sparsity")
         return float(a.value), float(e.value)
+
+    def work(self) -> dict:
+        """Pairs of the last E-step (gmmvb_last_work): active, evaluated exactly, accumulated by the list M-step, and the
+        rows the E-step did not evaluate at all (settled)."""
+        out = (ctypes.c_double * 4)()
+        _check(self.lib, self.lib.gmmvb_last_work(self._ws, out), "gmmvb_last_work")
+        return dict(active=float(out[0]), evaluated=float(out[1]), accumulated=float(out[2]), settled_rows=float(out[3]))
 
     def profile(self, on: bool = True):
         _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")

@@ -118,7 +118,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->slabs, (int64_t)ws->S_cap * K * slab_len(ws->T)},
         {&ws->xc, 0},
         {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K},
-        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->ctr, 6}, {&ws->drift, 4 * (int64_t)K}};
+        {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->ctr, 8}, {&ws->drift, 4 * (int64_t)K}};
     {
         const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
         if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
@@ -175,8 +175,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         return GMMVB_ENOMEM;
     }
     e = hipMemset(ws->pivot, 0, (size_t)D * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 6 * sizeof(double));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 6 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 8 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 8 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ctr_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         gmmvb_workspace_destroy(ws);
@@ -193,7 +193,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
-                     ws->lock, ws->dlock, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart,
+                     ws->lock, ws->dlock, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
                      ws->rmask, ws->rblk};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
@@ -408,6 +408,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMemset(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->spart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->gpart, (size_t)sel_blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->qpart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->epart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->opart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mpart, (size_t)sel_blocks * sizeof(double));
@@ -444,10 +445,11 @@ static int fetch_counters(gmmvb_workspace* ws) {
             ws->lag_eval = (double)ws->pend_rows * ws->K;
             ws->lag_over = 0.0;
             ws->lag_settled = 0.0;
-            ws->lag_listed = ws->lag_act;
+            ws->lag_listed = ws->lag_accum = ws->lag_act;
         } else {
             ws->lag_settled = ws->ctr_host[4];
-            ws->lag_listed = ws->ctr_host[5];                               // a bound pass / sweep also evaluated every row's (previous) best component
+            ws->lag_listed = ws->ctr_host[5];
+            ws->lag_accum = ws->ctr_host[6];                               // a bound pass / sweep also evaluated every row's (previous) best component
             ws->lag_eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? ws->pend_round0 : 0.0);
             ws->lag_over = ws->ctr_host[2];
             // rows whose best component changed: after a regrouping they no longer sit with their component's rows.
@@ -476,6 +478,19 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
     if (rc) return rc;
     *evaluated_pairs = ws->lag_mode == 0 ? (double)ws->e_rows * ws->K : ws->lag_eval;
     *active_pairs = (ws->sparse && ws->act_rows == ws->e_rows) ? ws->lag_act : -1.0;   // GMMVB_MSTEP_SPARSE=0: not counted
+    return GMMVB_OK;
+}
+
+int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
+    if (!ws || !out) return fail(GMMVB_EINVAL, "null argument");
+    if (ws->e_state != 1) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    int rc = fetch_counters(ws);
+    if (rc) return rc;
+    const bool counted = ws->sparse && ws->act_rows == ws->e_rows;
+    out[0] = counted ? ws->lag_act : -1.0;
+    out[1] = ws->lag_mode == 0 ? (double)ws->e_rows * ws->K : ws->lag_eval;
+    out[2] = counted ? ws->lag_accum : -1.0;
+    out[3] = ws->lag_mode == 0 ? 0.0 : ws->lag_settled;
     return GMMVB_OK;
 }
 
@@ -801,7 +816,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
                                ws->K, ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
             hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(1024), 0, st, ws->apart, nullptr, nullptr, nullptr, nullptr, nullptr,
-                               sel_grid, ws->ctr);
+                               nullptr, sel_grid, ws->ctr);
             // records for the next pass (one more sweep of the array, ~1 % of the dense kernel's time)
             if (can_prune && big)
                 hipLaunchKernelGGL(rec_build_kernel<false>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
@@ -911,9 +926,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
                            ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32,
                            settle ? ws->lock : nullptr, ws->dlock, skip_margin, settle ? ws->dmask : nullptr,
-                           settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(6), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, ws->spart,
-                           ws->gpart, sel_grid, ws->ctr);
+                           settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart, ws->qpart);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(7), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, ws->spart,
+                           ws->gpart, ws->qpart, sel_grid, ws->ctr);
         e = hipGetLastError();
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "rec_finish launch", e);
@@ -928,7 +943,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     // counters -> pinned host memory, behind an event (read by the next pass, or by gmmvb_last_sparsity)
     if (counted) {
-        e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 6 * sizeof(double), hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 8 * sizeof(double), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(ws->ctr_ev, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step counters", e);
         ws->ctr_pending = true;

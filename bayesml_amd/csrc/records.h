@@ -555,11 +555,12 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               float* __restrict__ dlock, double settle_margin /*< 0: rows never settle*/,
                                                               unsigned long long* __restrict__ dmask, int* __restrict__ dblk,
                                                               unsigned long long* __restrict__ mmask, int* __restrict__ mblk,
-                                                              double* __restrict__ spart, double* __restrict__ gpart) {
+                                                              double* __restrict__ spart, double* __restrict__ gpart,
+                                                              double* __restrict__ qpart /*pairs the M-step accumulates*/) {
     __shared__ int wcnt[4][256];
     __shared__ int dcnt[4][256];
     __shared__ int mcnt[4][256];
-    __shared__ int wact[4], wmov[4], wset[4], wlist[4];
+    __shared__ int wact[4], wmov[4], wset[4], wlist[4], wacc[4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
     for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = dcnt[wave][k] = mcnt[wave][k] = 0;
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     // Settling goes one step further: if every other component is at least settle_margin nats below the 2^-100 line the
     // row is also left out of the E-step's lists (masks); the next sweep then only checks its carried bounds.
     unsigned long long mm[4] = {mk[0], mk[1], mk[2], mk[3]};         // the M-step's lists
-    int in_lists = 0;
+    int in_lists = 0, m_pairs = 0;
     if (valid && lock != nullptr && fl != 4u) {
         const unsigned lk = lock[n];
         const bool single = row_arg >= 0 && active == 1;
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         for (int w = 0; w < W; ++w) {
             masks[(int64_t)w * npad + n] = mk[w];
             in_lists += __builtin_popcountll(mk[w]);
+            m_pairs += __builtin_popcountll(mm[w]) + __builtin_popcountll(dm[w]);
             if (dmask) {
                 dmask[(int64_t)w * npad + n] = dm[w];
                 mmask[(int64_t)w * npad + n] = mm[w];
@@ -834,12 +836,14 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         moved += __shfl_xor(moved, o);
         settled_i += __shfl_xor(settled_i, o);
         in_lists += __shfl_xor(in_lists, o);
+        m_pairs += __shfl_xor(m_pairs, o);
     }
     if ((tid & 63) == 0) {
         wact[wave] = active;
         wmov[wave] = moved;
         wset[wave] = settled_i;
         wlist[wave] = in_lists;
+        wacc[wave] = m_pairs;
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows) {
@@ -854,19 +858,21 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         mpart[blockIdx.x] = (double)(wmov[0] + wmov[1] + wmov[2] + wmov[3]);
         spart[blockIdx.x] = (double)(wset[0] + wset[1] + wset[2] + wset[3]);
         gpart[blockIdx.x] = (double)(wlist[0] + wlist[1] + wlist[2] + wlist[3]);
+        qpart[blockIdx.x] = (double)(wacc[0] + wacc[1] + wacc[2] + wacc[3]);
     }
 }
 
 // ctr[0] = sum apart (active pairs), ctr[1] = sum epart (exactly evaluated pairs), ctr[2] = sum opart (overflow rows),
 // ctr[3] = sum mpart (rows whose best component changed), ctr[4] = sum spart (settled rows), ctr[5] = sum gpart (pairs
-// in the M-step's lists); a null part leaves its counter as it is.  One workgroup per counter.
+// in the E-step's lists), ctr[6] = sum qpart (pairs the M-step accumulates); a null part leaves its counter as it is.
+// One workgroup per counter.
 __global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
                                                          const double* __restrict__ opart, const double* __restrict__ mpart,
                                                          const double* __restrict__ spart, const double* __restrict__ gpart,
-                                                         int blocks, double* __restrict__ ctr) {
+                                                         const double* __restrict__ qpart, int blocks, double* __restrict__ ctr) {
     __shared__ double part[16];
     const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : (blockIdx.x == 2 ? opart :
-                        (blockIdx.x == 3 ? mpart : (blockIdx.x == 4 ? spart : gpart))));
+                        (blockIdx.x == 3 ? mpart : (blockIdx.x == 4 ? spart : (blockIdx.x == 5 ? gpart : qpart)))));
     if (!src) return;
     double a = 0.0;                                   // (integer-valued addends below 2^53: any order is exact)
     for (int b = threadIdx.x; b < blocks; b += 1024) a += src[b];

@@ -62,8 +62,9 @@ struct gmmvb_workspace {
     // Written on the device at the end of every E-step and copied to pinned host memory behind an event; the NEXT
     // E-step / M-step reads whatever has arrived (policy decisions lag one pass, results never depend on them).
     // [4] settled rows (see below), [5] pairs in the M-step's lists.
-    double* ctr = nullptr;             // [6] device
-    double* ctr_host = nullptr;        // [6] pinned
+    // [6] pairs the M-step accumulates.
+    double* ctr = nullptr;             // [8] device
+    double* ctr_host = nullptr;        // [8] pinned
     hipEvent_t ctr_ev = nullptr;
     bool ctr_pending = false;          // a copy is in flight ...
     int pend_mode = 0;                 // ... of an E-step of this mode over pend_rows rows
@@ -71,7 +72,7 @@ struct gmmvb_workspace {
     double pend_round0 = 0.0;          // pairs that E-step evaluated before its counted selection round
     bool sweep_prev = false;           // the last sweep's first round used the previous pass's M-step lists
     bool lag_valid = false;            // lag_* = counters of the most recent E-step whose copy has arrived
-    double lag_act = 0.0, lag_eval = 0.0, lag_over = 0.0, lag_settled = 0.0, lag_listed = 0.0;
+    double lag_act = 0.0, lag_eval = 0.0, lag_over = 0.0, lag_settled = 0.0, lag_listed = 0.0, lag_accum = 0.0;
     int64_t lag_rows = 0;
     int lag_mode = 0;
     bool forget = false;               // gmmvb_forget: the next parameters are unrelated to the last E-step's
@@ -108,7 +109,7 @@ struct gmmvb_workspace {
     unsigned long long* mmask = nullptr;   // [ceil(K / 64)][npad] the M-step's lists: active pairs of the rows not in the cache
     int* mblk = nullptr;               // [K][blocks] their block counts
     double* cache = nullptr;           // [stats_len] statistics of the settled rows
-    double* spart = nullptr, *gpart = nullptr;   // [blocks] settled rows / listed pairs per selection block
+    double* spart = nullptr, *gpart = nullptr, *qpart = nullptr;   // [blocks] settled rows / listed pairs / M-step pairs per selection block
     unsigned long long* rmask = nullptr;   // read-outs of settled rows: their (row, component) pairs ...
     int* rblk = nullptr;                   // ... and block counts (allocated by the first such read-out)
     bool lock_live = false;            // some rows may be settled: the list M-step must add the cache

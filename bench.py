@@ -236,7 +236,8 @@ class Workload:
         return dict(estep_ms=round(em, 2), mstep_ms=round(mm, 2),
                     kernels=[p.strip().split(" ")[0] for p in self.eng.launch_info.split("|")],
                     active_components_per_sample=round(a / self.n, 2) if a >= 0 else None,
-                    evaluated_components_per_sample=round(e / self.n, 2))
+                    evaluated_components_per_sample=round(e / self.n, 2),
+                    accumulated_components_per_sample=round(self.eng.work()["accumulated"] / self.n, 2))
 
     def close(self):
         self.eng.close()
@@ -319,7 +320,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ker, launches, spars, spans = [], [], [], []
+    ker, launches, spars, spans, works = [], [], [], [], []
     counts0 = eng.pass_counts()
     fence()
     t0 = time.perf_counter()
@@ -329,6 +330,7 @@ def main():
         spans.append(eng.kernel_spans())
         launches.append(eng.launch_info)
         spars.append(eng.sparsity())
+        works.append(eng.work())
     fence()
     elapsed = time.perf_counter() - t0
     counts1 = eng.pass_counts()
@@ -351,7 +353,11 @@ def main():
         tiles = (D + 15) // 16
         fl_pair = 512 * tiles * (tiles + 1) // 2        # executed f64 MFMA flops per exactly evaluated (sample, component)
         ev = float(np.mean([e for _, e in spars]))      # pairs evaluated exactly per E-step
-        ac = float(np.mean([a for a, _ in spars]))      # active pairs (the M-step's, when it runs over lists)
+        ac = float(np.mean([a for a, _ in spars]))      # active pairs (r >= 2^-100)
+        # pairs the list M-step accumulates: active pairs minus the rows whose single component has r = 1.0 exactly and
+        # did not change (their addends sit in the workspace's cache), plus the rows entering / leaving that cache
+        acc = float(np.mean([wk["accumulated"] if wk["accumulated"] >= 0 else n_local * K for wk in works]))
+        settled = float(np.mean([wk["settled_rows"] for wk in works]))
         timed_counts = {k: counts1[k] - counts0[k] for k in counts1}
         m_sparse = timed_counts["mstep_list"] > 0
         # ---- per kernel group: mean HIP-event ms per step, algorithmic bytes per step (rows the group must read x D x s)
@@ -364,7 +370,7 @@ def main():
         alg = {"estep_main": n_local * row_bytes * (timed_counts["estep_dense"] + timed_counts["estep_bound"]
                                                     + timed_counts["estep_fell_back_dense"]) / steps,
                "estep_gather": ev * row_bytes if sparse_e else 0.0,
-               "mstep_main": (ac if m_sparse else n_local) * row_bytes}
+               "mstep_main": (acc if m_sparse else n_local) * row_bytes}
         for g, b in alg.items():
             if g in groups and groups[g]["ms"] > 0:
                 groups[g]["algorithmic_bytes"] = b
@@ -372,7 +378,7 @@ def main():
         if groups.get("estep_gather", {}).get("ms", 0) > 0:
             groups["estep_gather"]["executed_f64_tflops"] = fl_pair * ev / groups["estep_gather"]["ms"] / 1e9
         if "mstep_main" in groups:
-            groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (ac if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
+            groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (acc if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
         cand = [g for g in ("estep_main", "estep_gather", "mstep_main") if g in groups and "algorithmic_GBps" in groups[g]]
         dom = max(cand, key=lambda g: groups[g]["ms"])
         dom_kernel = {"estep_main": names[0], "estep_gather": "estep_gather_f64", "mstep_main": names[1]}[dom]
@@ -400,8 +406,10 @@ def main():
                 "step_hbm_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
                 "step_hbm_frac": step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                 "hbm_roofline_samples_per_s": PEAK_HBM_GBPS * 1e9 / row_bytes,
-                "f64_mfma_ceiling_samples_per_s": (PEAK_F64_MFMA_TFLOPS * 1e12 / (fl_pair * (ev + ac) / n_local)
-                                                   if (ev + ac) > 0 else None),
+                "f64_mfma_ceiling_samples_per_s": (PEAK_F64_MFMA_TFLOPS * 1e12 / (fl_pair * (ev + acc) / n_local)
+                                                   if (ev + acc) > 0 else None),
+                "pairs_per_sample": {"active": ac / n_local, "evaluated_exactly": ev / n_local,
+                                     "accumulated_by_mstep": acc / n_local, "settled_rows": settled / n_local},
                 "kernel_groups": groups,
                 "events_ms_per_step": sum(g["ms"] for g in groups.values()),
                 "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
@@ -446,7 +454,9 @@ def main():
             "per_step": {"estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
                          "estep_kernel": [kernel_name(l) for l in launches],
                          "active_components_per_sample": [round(a / n_local, 2) if a >= 0 else None for a, _ in spars],
-                         "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars]},
+                         "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars],
+                         "accumulated_components_per_sample": [round(wk["accumulated"] / n_local, 2) for wk in works],
+                         "settled_rows_per_sample": [round(wk["settled_rows"] / n_local, 3) for wk in works]},
         }
         print(json.dumps(out), flush=True)
     if use_dist:

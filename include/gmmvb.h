@@ -262,6 +262,11 @@ int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26], hos
  * besides gmmvb_profile_* that blocks; gmmvb_mstep blocks the same way right after a DENSE gmmvb_estep of N K >= 2^18,
  * to choose between its dense and its list form). */
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs);
+/* The same (blocking) with the work the pass left for the M-step.  out[0] active pairs (r >= 2^-100; -1: not counted),
+ * out[1] pairs the E-step evaluated exactly, out[2] pairs the list M-step accumulates (rows whose single component has
+ * r = 1.0 exactly keep their addend in a cache and are only touched when that changes; -1: not counted), out[3] rows the
+ * E-step did not evaluate at all (settled: their carried bounds prove that nothing changed). */
+int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[4], host*/);
 
 #ifdef __cplusplus
 }

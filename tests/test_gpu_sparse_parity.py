@@ -21,9 +21,15 @@ from oracle import gmm_vb_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS")
+ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_GAMMA",
+            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE")
 VARIANTS = {
     "default": {},
+    # rows with a single active component are settled (left out of the E-step on the strength of their carried bounds)
+    # whatever the drift, with 10 nats of slack instead of 30: the read-outs below need their values re-evaluated
+    "settle": {"GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10"},
+    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10"},
+    "nocache": {"GMMVB_MSTEP_CACHE": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
     "force_nocarry": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_CARRY_OFF": "1"},
     "dense": {"GMMVB_ESTEP_PRUNE": "0", "GMMVB_MSTEP_SPARSE": "0"},
@@ -82,6 +88,8 @@ def expect_kernels(counts, variant, min_carried=1, lists=True):
         assert counts["mstep_list"] >= 1, counts
     if variant == "force_nocarry":
         assert counts["estep_carried"] == counts["estep_sweep"] == 0, counts
+    elif variant in ("settle", "force_settle"):
+        assert counts["estep_sweep"] >= 2, counts
     else:       # carried over the parameter update: on per-row records, or (early in a fit) by a sweep of the dense array
         assert counts["estep_carried"] + counts["estep_sweep"] >= min_carried, counts
 
@@ -104,6 +112,8 @@ def test_small_fixture_forced_sparse_matches_reference(variant):
 
 
 LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n140000_f32.npz", "force_nocarry"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
+         ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
          ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "dense")]
 
@@ -138,6 +148,16 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+    if "overlap" not in name and variant in ("default", "settle", "nocache"):
+        # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
+        # again; settled rows are not even evaluated
+        wk = m._engine.work()
+        if variant == "nocache":
+            assert wk["accumulated"] == wk["active"] and wk["settled_rows"] == 0, wk
+        else:
+            assert 0 <= wk["accumulated"] < 0.7 * wk["active"], wk
+        if variant == "settle":
+            assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
     if variant == "default" and "overlap" not in name:
         # the workspace regrouped its internal row order by dominant component on the way: every
         # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless
@@ -163,7 +183,8 @@ def _oracle_post(q):
     return o
 
 
-def test_carried_bounds_are_upper_bounds_of_the_oracle():
+@pytest.mark.parametrize("variant", ["force", "force_settle"])
+def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
     bound of it lying at least 100 ln 2 below the row's best component; responsibilities and statistics equal the
@@ -174,9 +195,10 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle():
     x = orc.synth_gmm(K, D, N, np.float32)
     x64 = x.astype(np.float64)
     dev = torch.device("cuda", 0)
-    with env(VARIANTS["force"]):
+    with env(VARIANTS[variant]):
         m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
         eng, xd = m._open(x)
+    settled_seen = 0.0
     prior = m._prior_tensors(dev)
     q = m._init_subsampling(eng, xd, _kside.post_from_prior(prior), N)
     s = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
@@ -191,6 +213,7 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle():
         ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=(*hint, float((hint[0] - hint[1] / 30.0).min())))
         if eng.pass_counts()["estep_carried"] + eng.pass_counts()["estep_sweep"] == before:
             continue
+        settled_seen = max(settled_seen, eng.work()["settled_rows"])
         lb = eng.ln_rho().cpu().numpy()
         oq = _oracle_post(q)
         st = orc.data_pass(x64, oq)
@@ -205,3 +228,5 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle():
         assert rel_err(ns.cpu().numpy(), st.ns) < 1e-10 and rel_err(s.cpu().numpy(), st.s) < 1e-9
         checked += 1
     assert checked >= 3, eng.pass_counts()
+    if variant == "force_settle":       # rows that were not evaluated at all: read out exactly all the same
+        assert settled_seen > 0.1 * N, settled_seen
