@@ -232,6 +232,6 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         assert rel_err(ns.cpu().numpy(), st.ns) < 1e-10 and rel_err(s.cpu().numpy(), st.s) < 1e-9
         checked += 1
     assert checked >= 3, eng.pass_counts()
-    assert cached_seen > 0.3 * N, cached_seen       # single-component rows the M-step did not accumulate again
+    assert cached_seen > 0.1 * N, cached_seen       # single-component rows the M-step did not accumulate again
     if variant == "force_settle":       # rows that were not evaluated at all: read out exactly all the same
         assert settled_seen > 0.1 * N, settled_seen
