@@ -136,6 +136,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->settle_margin = std::atof(v);
         v = std::getenv("GMMVB_SETTLE_GAMMA");
         if (v) ws->settle_gamma = std::atof(v);
+        v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
+        ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
     }
@@ -193,7 +195,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
-                     ws->lock, ws->dlock, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
+                     ws->lock, ws->dlock, ws->rthr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
                      ws->rmask, ws->rblk};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
@@ -400,6 +402,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->lock, (size_t)np);
     if (e == hipSuccess) e = hipMemset(ws->lock, 0, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dlock, (size_t)np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rthr, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mmask, (size_t)words * np * sizeof(unsigned long long));
@@ -597,7 +600,8 @@ static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepArgs& a, con
 }
 
 // masks -> per-component lists -> chunk plan -> exact f64 evaluation of the listed pairs (all sized on the device)
-static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int is64, bool vec, int sel_grid, hipStream_t st) {
+static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int is64, bool vec, int sel_grid, hipStream_t st,
+                                   const float* thr = nullptr) {
     span_begin(ws, kSpanSelect, st);
     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, a.n_rows, ws->K, ws->blk,
@@ -608,7 +612,7 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     span_end(ws, st);
     if (e != hipSuccess) return e;
     span_begin(ws, kSpanGather, st);
-    e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan);
+    e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan, thr);
     span_end(ws, st);
     ++ws->passes[7];
     return e;
@@ -860,7 +864,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             hipLaunchKernelGGL(rec_build_kernel<true>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
                                ws->npad, n_rows, ws->K, ws->cvec, ws->khat, rec, ws->ub32);
             hipLaunchKernelGGL(rec_select_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
-                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart);
+                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart, ws->rthr);
             span_end(ws, st);
         } else if (mode == kSweep) {
             rpw = kSelRows;
@@ -890,7 +894,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr);
                 span_end(ws, st);
             } else {
                 span_begin(ws, kSpanSelect, st);
@@ -902,7 +906,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;
@@ -913,10 +917,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             ++ws->passes[2];
             span_begin(ws, kSpanSelect, st);
             hipLaunchKernelGGL(rec_select_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
-                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart);
+                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart, ws->rthr);
             span_end(ws, st);
         }
-        e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
+        // candidates: a pair whose first output blocks already put it below the row's threshold is not evaluated further
+        e = lists_and_gather(ws, a, is64, vec, sel_grid, st, ws->gather_exit ? ws->rthr : nullptr);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate evaluation", e);
         if (ws->prof) {
             (void)hipEventRecord(ws->ev[1], st);
@@ -926,7 +931,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
                            ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32,
                            settle ? ws->lock : nullptr, ws->dlock, skip_margin, settle ? ws->dmask : nullptr,
-                           settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart, ws->qpart);
+                           settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart, ws->qpart, ws->rthr);
         hipLaunchKernelGGL(sum_parts_kernel, dim3(7), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, ws->spart,
                            ws->gpart, ws->qpart, sel_grid, ws->ctr);
         e = hipGetLastError();

@@ -24,6 +24,7 @@
 //                   latency hidden a whole component block ahead); the default.
 //   estep_mfma_f64  no LDS: every wave streams the image from L2 straight into registers.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace gmmvb {
@@ -122,6 +123,82 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB
         }
         q = sum_groups(q);
         if (g == 0 && rows[nb] >= 0) lnrho_k[rows[nb]] = ck - 0.5 * q;
+    }
+}
+
+// The same with an early way out for candidates that turn out irrelevant: after the first J1 output blocks (J1 (J1 + 1) / 2
+// of the JB (JB + 1) / 2 tile pairs) the partial sum q_J1 <= q already bounds ln rho from above; if for EVERY row of the wave
+// tile  c_k - q_J1 / 2 < thr[row]  (the row's relevance threshold: its best exact value - 100 ln 2, written by the
+// selection kernels), the remaining blocks are skipped and the bound is stored instead of the value.  Whoever reads the
+// array treats a stored value below thr[row] as a bound (records.h, rec_finish_kernel).  Pairs that are evaluated in
+// full go through exactly the same operations as in estep_component.
+template <int NB, typename XT, int JB, int J1, int BOFF, typename ImgPtr>
+__device__ __forceinline__ void estep_component_exit(ImgPtr im, const XT (&xr)[NB][JB][4], double ck, int lane, int g,
+                                                     const int64_t (&rows)[NB], double* __restrict__ lnrho_k,
+                                                     const float* __restrict__ thr) {
+    static_assert(J1 >= 1 && J1 < JB, "the way out lies strictly inside the block loop");
+    constexpr int P = BOFF / 256;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    float th[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) th[nb] = rows[nb] >= 0 ? thr[rows[nb]] : __builtin_huge_valf();
+    d4 acc[JB][NB];
+#pragma unroll
+    for (int jt = 0; jt < JB; ++jt) {
+        const d2 b01 = *reinterpret_cast<const d2*>(im + P * 256 + (jt * 4 + g) * 4);
+        const d2 b23 = *reinterpret_cast<const d2*>(im + P * 256 + (jt * 4 + g) * 4 + 2);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[jt][nb] = d4{b01[0], b01[1], b23[0], b23[1]};
+    }
+    auto blocks = [&](auto lo, auto hi) {
+#pragma unroll
+        for (int jt = decltype(lo)::value; jt < decltype(hi)::value; ++jt) {
+#pragma unroll
+            for (int b = 0; b <= jt; ++b) {
+                const int p = pair_index(jt, b);
+                const d2 a01 = *reinterpret_cast<const d2*>(im + p * 256 + lane * 2);
+                const d2 a23 = *reinterpret_cast<const d2*>(im + p * 256 + 128 + lane * 2);
+                const double a[4] = {a01[0], a01[1], a23[0], a23[1]};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[jt][nb] = mfma_f64(a[s], (double)xr[nb][b][s], acc[jt][nb]);
+                }
+            }
+        }
+    };
+    blocks(std::integral_constant<int, 0>{}, std::integral_constant<int, J1>{});
+    double q[NB];
+    bool out = true;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        q[nb] = 0.0;
+#pragma unroll
+        for (int jt = 0; jt < J1; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[nb] = fma(acc[jt][nb][r], acc[jt][nb][r], q[nb]);
+        }
+        out = out && (ck - 0.5 * sum_groups(q[nb]) < (double)th[nb]);          // NaN: stays in
+    }
+    if (__all(out)) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const double qs = sum_groups(q[nb]);
+            if (g == 0 && rows[nb] >= 0) lnrho_k[rows[nb]] = ck - 0.5 * qs;
+        }
+        return;
+    }
+    blocks(std::integral_constant<int, J1>{}, std::integral_constant<int, JB>{});
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        double qq = q[nb];
+#pragma unroll
+        for (int jt = J1; jt < JB; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qq = fma(acc[jt][nb][r], acc[jt][nb][r], qq);
+        }
+        qq = sum_groups(qq);
+        if (g == 0 && rows[nb] >= 0) lnrho_k[rows[nb]] = ck - 0.5 * qq;
     }
 }
 
@@ -304,13 +381,15 @@ constexpr int kGatherTiles = 8;
 // plan[k] = index of component k's first chunk of kGatherTiles x 8 waves x 16 NB list entries, plan[K] = total
 // (gather_plan_kernel, records.h).  A fixed grid of persistent workgroups takes contiguous runs of chunks, restaging
 // the component image only when the component changes.
-template <int T, typename XT, bool VEC>
+// EXIT: candidates of a selection round - rows carry a relevance threshold thr[row], see estep_component_exit.
+template <int T, typename XT, bool VEC, bool EXIT>
 __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict__ x, int64_t ldx, int D,
                                                             const double* __restrict__ img, const double* __restrict__ cvec,
                                                             int K, const int* __restrict__ lists /*[K][cap]*/, int64_t cap,
                                                             const int* __restrict__ counts /*[K]*/,
                                                             const int* __restrict__ plan /*[K + 1]*/,
-                                                            double* __restrict__ lnrho, int64_t npad) {
+                                                            double* __restrict__ lnrho, int64_t npad,
+                                                            const float* __restrict__ thr) {
     constexpr int NW = 8;
     constexpr int NB = estep_nb_w<XT>(T, NW);
     constexpr int IMG = img_doubles(T);
@@ -357,7 +436,10 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
             }
             XT xr[NB][T][4];
             load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
-            estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
+            if constexpr (EXIT)
+                estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr);
+            else
+                estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
         }
     }
 }

@@ -30,7 +30,8 @@ hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream
 // exact f64 evaluation of listed pairs (device lists [K][cap], device counts), chunk plan on the device
 // (records.h: gather_plan_kernel), a fixed grid of persistent workgroups
 hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
-                                   const int* lists, int64_t cap, const int* counts_dev, const int* plan_dev);
+                                   const int* lists, int64_t cap, const int* counts_dev, const int* plan_dev,
+                                   const float* thr = nullptr /*[npad] relevance thresholds: early way out for irrelevant pairs*/);
 // int8-digit E-step (estep_i8.h): own parameter image (bytes per component), 256 rows per workgroup
 struct EstepI8Args {
     const void* x; int64_t ldx; int64_t n_rows; int D;

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
                                                               const double* __restrict__ c_new,
                                                               unsigned long long* __restrict__ masks, int64_t npad,
                                                               int* __restrict__ blk_cnt, double* __restrict__ epart,
-                                                              double* __restrict__ opart) {
+                                                              double* __restrict__ opart,
+                                                              float* __restrict__ rthr /*[npad] the row's relevance threshold*/) {
     __shared__ int wcnt[4][256];
     __shared__ double sg[256], sdl[256], sG[256], sc[256], sco[256];
     __shared__ int wsum[2][4];
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
         }
         rec.sel[n] = (unsigned char)sel;
         rec.flags[n] = (unsigned char)(over ? 1 : (extra > 0 ? 2 : 0));
+        rthr[n] = (over || !(thr > ninf)) ? -__builtin_huge_valf() : f32_down(thr);
         if (!IDENT) rec.exact[n] = 0;          // carried distances are one-sided until the pair is evaluated again
         for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
     }
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              int* __restrict__ blk_cnt, double* __restrict__ epart,
                                                              double* __restrict__ opart,
                                                              unsigned char* __restrict__ lock /*null: no settled rows*/,
-                                                             float* __restrict__ dlock) {
+                                                             float* __restrict__ dlock,
+                                                             float* __restrict__ rthr /*[npad] the row's relevance threshold*/) {
     __shared__ int wcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         const bool over = !by_bound && !(thr > ninf);          // NaN / -inf: nothing to compare with
         const float thr_f = by_bound ? thr_set : (over ? -__builtin_huge_valf() : f32_down(thr));   // over: every pair is a candidate
         if (over) fresh[0] = fresh[1] = fresh[2] = fresh[3] = 0ull;
+        rthr[n] = thr_f;                                       // (-inf: everything is evaluated in full)
         unsigned long long nocand[4] = {fresh[0], fresh[1], fresh[2], fresh[3]};
         if (by_bound) nocand[kset >> 6] |= 1ull << (kset & 63);
         unsigned s[kRecSlots + 1];
@@ -556,7 +560,8 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               unsigned long long* __restrict__ dmask, int* __restrict__ dblk,
                                                               unsigned long long* __restrict__ mmask, int* __restrict__ mblk,
                                                               double* __restrict__ spart, double* __restrict__ gpart,
-                                                              double* __restrict__ qpart /*pairs the M-step accumulates*/) {
+                                                              double* __restrict__ qpart /*pairs the M-step accumulates*/,
+                                                              const float* __restrict__ rthr /*[npad] relevance thresholds*/) {
     __shared__ int wcnt[4][256];
     __shared__ int dcnt[4][256];
     __shared__ int mcnt[4][256];
@@ -575,6 +580,9 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     // among the other components (+inf: unknown - the row is left alone)
     double row_l = 0.0, row_best = 0.0, row_second = __builtin_huge_val();
     int row_arg = -1;
+    // a stored value below the row's relevance threshold may be a bound (the gather's early way out, estep.h): it is
+    // irrelevant either way (2^-100 below the best), counts as evaluated, but is never flagged exact
+    const double thr_row = valid ? (double)rthr[n] : 0.0;
     if (valid && fl == 4u) {
         // settled row: nothing was evaluated, nothing changes (lse[n] and the ln rho entries are stale until a read-out
         // asks for them); it still counts as one active pair
@@ -611,7 +619,8 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                 if (x == mx && k < arg) arg = k;
                 ssum += exp(x - mx);
             }
-            rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], x)), (unsigned short)(k | kRecExactBit), f32_up(x));
+            rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], x)),
+                       (unsigned short)(k | (x < thr_row ? 0 : kRecExactBit)), f32_up(x));
         };
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
@@ -671,6 +680,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         }
     } else if (valid && fl == 0u) {
         unsigned live = (unsigned)rec.sel[n] | (unsigned)rec.exact[n];
+        unsigned bounds_only = 0;
         double v[kRecSlots];
         unsigned short kk[kRecSlots];
         double mx = -__builtin_huge_val();
@@ -685,6 +695,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
             v[j] = x;
             ub32[(int64_t)kk[j] * npad + n] = f32_up(x);
             rec.d[(int64_t)j * rec.npad + n] = f32_down(dist_of(cvec[kk[j]], x));
+            if (x < thr_row) bounds_only |= 1u << j;
             nan = nan || x != x;
             if (x > mx || (x == mx && (int)kk[j] < arg)) {          // first maximiser, like numpy.argmax
                 mx = x;
@@ -702,7 +713,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         }
         lse[n] = l;
         khat[n] = arg == 0x7fffffff ? 0 : arg;
-        rec.exact[n] = (unsigned char)live;
+        rec.exact[n] = (unsigned char)(live & ~bounds_only);
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
             if (!((live >> j) & 1u)) continue;

@@ -104,6 +104,7 @@ struct gmmvb_workspace {
     // through the rows that settle or come loose in a pass (the M-step's delta lists).
     unsigned char* lock = nullptr;     // [npad] 0 free, 1 settled, 2 came loose in this pass, 3 settled in this pass
     float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
+    float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 100 ln 2)
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
     int* dblk = nullptr;               // [K][blocks] their block counts
     unsigned long long* mmask = nullptr;   // [ceil(K / 64)][npad] the M-step's lists: active pairs of the rows not in the cache
@@ -122,6 +123,7 @@ struct gmmvb_workspace {
     double settle_margin = 30.0;       // nats of slack demanded before a row is settled (< 0: never settle)
     double settle_gamma = 0.98;        // ... and only while the caller's drift summary (typical_gamma) is at least this
     bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows
+    bool gather_exit = true;           // env GMMVB_GATHER_EXIT=0: no early way out in the candidate gather
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
     void* xp = nullptr;        // [max_rows][D] x in internal row order (storage dtype), allocated with the lists
     int* perm = nullptr, *iperm = nullptr, *perm_tmp = nullptr;   // [npad] each
