@@ -65,11 +65,21 @@ def main():
     if json_out:
         import json
         out = {}
+        # template variants of one kernel (e.g. the gather with and without the early way out) share an entry: the
+        # average is over all their launches
+        merged = defaultdict(lambda: defaultdict(list))
+        names = defaultdict(list)
         for name in rows:
-            c = {k: sum(v) / len(v) for k, v in rows[name].items()}
+            base = name.replace("gmmvb::", "").split("<")[0]
+            names[base].append(name)
+            for k, v in rows[name].items():
+                merged[base][k].extend(v)
+        for base in merged:
+            c = {k: sum(v) / len(v) for k, v in merged[base].items()}
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                out[name.replace("gmmvb::", "").split("<")[0]] = dict(
-                    kernel=name, grid_threads=grid[name], fetch_bytes_raw=c["FETCH_SIZE"] * 1024,
+                out[base] = dict(
+                    kernel=" + ".join(sorted(names[base])), grid_threads=max(grid[n] for n in names[base]),
+                    launches=len(merged[base]["FETCH_SIZE"]), fetch_bytes_raw=c["FETCH_SIZE"] * 1024,
                     fetch_bytes=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024, config=config,
                     note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, FETCH x2 (gfx950)")
         with open(json_out, "w") as f:
