@@ -136,6 +136,10 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->settle_margin = std::atof(v);
         v = std::getenv("GMMVB_SETTLE_GAMMA");
         if (v) ws->settle_gamma = std::atof(v);
+        v = std::getenv("GMMVB_SETTLE_I8");
+        ws->settle_i8 = !(v && std::strcmp(v, "0") == 0);
+        v = std::getenv("GMMVB_SETTLE_MARGIN_I8");
+        if (v) ws->settle_margin_i8 = std::atof(v);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_MSTEP_CACHE");
@@ -406,6 +410,8 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mmask, (size_t)words * np * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rmask, (size_t)words * np * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->rblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->cache, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double));
     if (e == hipSuccess) e = hipMemset(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double));
@@ -713,8 +719,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         settle = mode == kSweep && ws->cache_on && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
                  ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     }
-    // rows are settled (left out of the E-step as well) only while the parameters move little
-    const double skip_margin = (settle && ws->settle_margin >= 0.0 && ws->typical_gamma >= ws->settle_gamma) ? ws->settle_margin : -1.0;
+    // Rows are settled (left out of the E-step as well) when the next pass can re-evaluate their reference bound cheaply
+    // (three int8 digits, estep_i8_pairs) - or, without that, only while the parameters move little (the bound is then
+    // carried through Gamma and delta and erodes quickly otherwise).
+    const bool i8_ref = settle && ws->settle_i8 && ws->img_i8b != nullptr && ws->settle_margin_i8 >= 0.0;
+    const double skip_margin = !settle ? -1.0
+                               : (i8_ref ? ws->settle_margin_i8
+                                         : ((ws->settle_margin >= 0.0 && ws->typical_gamma >= ws->settle_gamma) ? ws->settle_margin : -1.0));
     ws->settled_fresh = false;
     if (std::getenv("GMMVB_DEBUG"))
         std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",
@@ -877,6 +888,28 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // workspace with their masks: evaluate them as they are (no list building); else the previous best
             // component of every row.
             if (prev_lists) {
+                if (i8_ref && ws->skip_used) {
+                    // the settled rows' reference: an upper bound of their distance to their one component under the new
+                    // parameters, from three int8 digits (their lists are built and used before the buffers take the
+                    // active pairs' lists)
+                    span_begin(ws, kSpanSelect, st);
+                    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->khat,
+                                       ws->npad, n_rows, ws->K, ws->rmask, ws->rblk);
+                    launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+                    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
+                                       ws->K, ws->rblk, ws->lists, ws->npad);
+                    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
+                                       estep_i8_pairs_per_chunk(), ws->plan);
+                    span_end(ws, st);
+                    span_begin(ws, kSpanEstepMain, st);
+                    EstepI8Args ab = a8;
+                    ab.img = ws->img_i8b;
+                    e = launch_estep_i8_pairs(is64, vec, 2 * ws->num_cu, st, ab, ws->lists, ws->npad, ws->counts, ws->plan,
+                                              ws->dlock);
+                    span_end(ws, st);
+                    if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row reference bounds", e);
+                    ws->active_lists = false;
+                }
                 span_begin(ws, kSpanSelect, st);
                 if (!ws->active_lists) {        // (the M-step's lists left out the rows in its cache)
                     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
@@ -894,7 +927,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, (i8_ref && ws->skip_used) ? 1 : 0);
                 span_end(ws, st);
             } else {
                 span_begin(ws, kSpanSelect, st);
@@ -906,7 +939,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, 0);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;

@@ -159,11 +159,9 @@ __global__ void pack_params_i8_kernel(const double* __restrict__ u, const double
 // c2 = 2^(en - 12 - 7 (ND - 1)), the weight of the last kept digit pair class (NaN when the sample holds a non-finite
 // value, so that its ln rho comes out NaN like the f64 path's); sn = 2^en.
 template <int ND, int T32, typename XT, bool VEC>
-__device__ __forceinline__ void load_x_digits(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
-                                              const double* __restrict__ pivot, int64_t n0, int c, int h,
-                                              i4v (&xd)[ND][T32], double& c2, double& sn) {
-    int64_t row = n0 + c;
-    if (row >= n_rows) row = n_rows - 1;          // clamp: padded samples are never stored
+__device__ __forceinline__ void load_x_digits_row(const XT* __restrict__ x, int64_t ldx, int D,
+                                                  const double* __restrict__ pivot, int64_t row, int h,
+                                                  i4v (&xd)[ND][T32], double& c2, double& sn) {
     const XT* xp = x + row * ldx + 16 * h;
     // 16 features of block `it` as centred doubles (zero past D); two passes over x (the second hits L1/L2) keep
     // the conversion's live registers at one block instead of the whole row
@@ -226,6 +224,15 @@ __device__ __forceinline__ void load_x_digits(const XT* __restrict__ x, int64_t 
 #pragma unroll
         for (int a = 0; a < ND; ++a) xd[a][it] = i4v{(int)w[a][0], (int)w[a][1], (int)w[a][2], (int)w[a][3]};
     }
+}
+
+template <int ND, int T32, typename XT, bool VEC>
+__device__ __forceinline__ void load_x_digits(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                              const double* __restrict__ pivot, int64_t n0, int c, int h,
+                                              i4v (&xd)[ND][T32], double& c2, double& sn) {
+    int64_t row = n0 + c;
+    if (row >= n_rows) row = n_rows - 1;          // clamp: padded samples are never stored
+    load_x_digits_row<ND, T32, XT, VEC>(x, ldx, D, pivot, row, h, xd, c2, sn);
 }
 
 // LDS reads whose completion is awaited by hand.  The compiler only ever emits s_waitcnt lgkmcnt(0) in this
@@ -375,10 +382,12 @@ __device__ __forceinline__ void i8_rows_bound(unsigned const_addr, const i16v (&
     if constexpr (GP + 1 < 4) i8_rows_bound<JT, GP + 1>(const_addr, acc, sb, m, y2, ya);
 }
 
-template <int ND, bool BOUND, int T32, bool REV, int O, typename QT>
+// TWO: also an UPPER bound of sum y_exact^2 in qu:  y_exact^2 <= (|y| (1 + 2^-20) + e)^2, e = beta_jt + 2^e_jt cef, i.e. per
+// block and lane  (1 + 2^-19) Y2 + 2 (1 + 2^-20) e A + 16 e^2  (16 rows per lane and block).
+template <int ND, bool BOUND, int T32, bool REV, int O, typename QT, bool TWO = false>
 __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned const_addr, i4v (&ua)[3],
                                                const i4v (&xd)[ND][T32], const i8_lane_consts& lc, const i4v& scales,
-                                               const i4v& scales2, QT& q) {
+                                               const i4v& scales2, QT& q, QT* qu = nullptr) {
     constexpr int JT = REV ? T32 - 1 - O : O;
     i16v acc[ND];
 #pragma unroll
@@ -392,12 +401,15 @@ __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned cons
         const float sj = sc.f[2 * (JT & 1)], beta = sc.f[2 * (JT & 1) + 1];
         float y2 = 0.0f, ya = 0.0f;
         i8_rows_bound<JT, 0>(const_addr, acc, sb, sj * lc.c2f, y2, ya);
-        q = __builtin_fmaf(-2.0f * ya, __builtin_fmaf(sj, lc.cef, beta), __builtin_fmaf(y2, 0.9999980926513671875f, q));
+        const float eb = __builtin_fmaf(sj, lc.cef, beta);
+        q = __builtin_fmaf(-2.0f * ya, eb, __builtin_fmaf(y2, 0.9999980926513671875f, q));
+        if constexpr (TWO)
+            *qu = __builtin_fmaf(16.001f * eb, eb, __builtin_fmaf(2.00001f * ya, eb, __builtin_fmaf(y2, 1.0000019073486328125f, *qu)));
     } else {
         i8_rows<ND, JT, 0>(const_addr, acc, sb, lc, q);
     }
     if constexpr (O + 1 < T32)
-        i8_blocks_from<ND, BOUND, T32, REV, O + 1>(frag_addr, const_addr, ua, xd, lc, scales, scales2, q);
+        i8_blocks_from<ND, BOUND, T32, REV, O + 1, QT, TWO>(frag_addr, const_addr, ua, xd, lc, scales, scales2, q, qu);
 }
 
 // One component for one wave tile; `im_lds` is the LDS byte address of the component's image.
@@ -515,6 +527,107 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
             __syncthreads();
         }
         if (khat && h == 0 && n0 + c < n_rows) khat[n0 + c] = arg;
+    }
+}
+
+// ---- two-sided bounds for listed (sample, component) pairs --------------------------------------------------------------
+// The settled rows of the pruned E-step (records.h) need, per pass, a LOWER bound of ln rho of their one active component
+// under the new parameters - an upper bound of || U_k (x_n - m_k) || - and nothing else; three digits on the int8 pipe give
+// it to about 1e-3 of the distance at an eighth of the f64 evaluation's cost.  Same images, digits and error terms as the
+// bound pass; the error term is added instead of subtracted.  Returns (lower, upper) bound of q = || U (x - m) ||^2.
+template <int T32, bool REV>
+__device__ __forceinline__ void estep_i8_two_sided(unsigned im_lds, const i4v (&xd)[kBoundDigits][T32],
+                                                   const i8_lane_consts& lc, int lane, int h, float& q_lo, float& q_hi) {
+    constexpr int ND = kBoundDigits;
+    using ord = i8_order<ND, T32, REV>;
+    constexpr int P = tri_pairs(T32);
+    const unsigned frag_addr = im_lds + lane * 16;
+    const unsigned const_addr = im_lds + P * ND * 1024 + h * 64;
+    float q = 0.0f, qu = 0.0f;
+    i4v scales = {0, 0, 0, 0}, scales2 = {0, 0, 0, 0};
+    lds_read16<0>(scales, im_lds + P * ND * 1024 + T32 * 128);
+    lds_read16<16>(scales2, im_lds + P * ND * 1024 + T32 * 128);
+    lds_wait<0>(scales, scales2);
+    i4v ua[3];
+    lds_read16<1024 * ord::layout_of(0)>(ua[0], frag_addr);
+    lds_read16<1024 * ord::layout_of(1)>(ua[1], frag_addr);
+    i8_blocks_from<ND, true, T32, REV, 0, float, true>(frag_addr, const_addr, ua, xd, lc, scales, scales2, q, &qu);
+    q += __shfl_xor(q, 32);
+    qu += __shfl_xor(qu, 32);
+    q_lo = (q < 0) ? 0 : q;
+    q_hi = qu;
+}
+
+constexpr int kI8PairTiles = 8;      // wave tiles (32 list entries each) per wave and chunk
+__host__ __device__ constexpr int i8_pairs_per_chunk() { return 8 * 32 * kI8PairTiles; }
+
+// plan[k] = component k's first chunk of i8_pairs_per_chunk() list entries, plan[K] = total (gather_plan_kernel); a fixed
+// grid of persistent workgroups takes contiguous runs of chunks and restages the 31-KB digit image only when the
+// component changes.  dist_up[row] <- an upper bound of the whitened distance of (row, its listed component); +inf / NaN
+// when the image or the sample admits no bound (the caller then treats the row as unproven).
+template <int T32, typename XT, bool VEC>
+__global__ __launch_bounds__(512) void estep_i8_pairs(const XT* __restrict__ x, int64_t ldx, int D,
+                                                      const unsigned char* __restrict__ img /*[K][IMGB], 3 digits*/,
+                                                      const double* __restrict__ pivot, int K,
+                                                      const int* __restrict__ lists /*[K][cap]*/, int64_t cap,
+                                                      const int* __restrict__ counts, const int* __restrict__ plan,
+                                                      float* __restrict__ dist_up) {
+    constexpr int ND = kBoundDigits, NW = 8;
+    constexpr int IMGB = i8_img_bytes(ND, T32);
+    constexpr int CHUNK = i8_pairs_per_chunk();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IMGB];
+    __shared__ int s_first[257];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    for (int k = threadIdx.x; k <= K; k += 512) s_first[k] = plan[k];
+    __syncthreads();
+    const int total = s_first[K];
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c0 = (int)blockIdx.x * per;
+    const int c1 = c0 + per < total ? c0 + per : total;
+    const unsigned im_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+    int k = 0, kcur = -1;
+    for (int ch = c0; ch < c1; ++ch) {
+        while (s_first[k + 1] <= ch) ++k;
+        if (k != kcur) {
+            __syncthreads();
+            const unsigned char* src = img + (int64_t)k * IMGB + lane * 16;
+            for (int piece = wave; piece < IMGB / 1024; piece += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                                 (__attribute__((address_space(3))) void*)(&smem[piece * 1024]), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            kcur = k;
+        }
+        const int count = counts[k];
+        const int64_t chunk0 = (int64_t)(ch - s_first[k]) * CHUNK;
+        const int* list = lists + (int64_t)k * cap;
+        for (int t = 0; t < kI8PairTiles; ++t) {
+            const int64_t e0 = chunk0 + ((int64_t)t * NW + wave) * 32;
+            if (e0 >= count) break;
+            const int64_t e = e0 + c;
+            const int64_t row = list[e < count ? e : count - 1];
+            i4v xd[ND][T32];
+            double c2, sn;
+            load_x_digits_row<ND, T32, XT, VEC>(x, ldx, D, pivot, row, h, xd, c2, sn);
+            i8_lane_consts lc;
+            lc.c[2] = c2;
+            lc.c[1] = c2 * 128.0;
+            lc.c[0] = c2 * 268435456.0;
+            int en = 0;
+            (void)frexp(sn, &en);
+            const bool ok = (c2 == c2) && en >= -44 && en <= 46;
+            lc.c2f = ok ? (float)c2 : 0.0f;
+            lc.cef = ok ? (float)(sn * i8_err(ND, T32) * 1.0001) : __builtin_huge_valf();
+            float q_lo, q_hi;
+            if (T32 > 1 && wave >= NW / 2)
+                estep_i8_two_sided<T32, true>(im_lds, xd, lc, lane, h, q_lo, q_hi);
+            else
+                estep_i8_two_sided<T32, false>(im_lds, xd, lc, lane, h, q_lo, q_hi);
+            // 2^-16 of q covers the f32 rounding of its 128 squares and additions; the square root one more ulp
+            if (h == 0 && e < count) dist_up[row] = __builtin_sqrtf(q_hi * 1.0000153f) * 1.0000003f;
+        }
     }
 }
 

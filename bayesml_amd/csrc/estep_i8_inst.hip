@@ -66,4 +66,32 @@ hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int tb, int grid, hipSt
     return hipErrorInvalidValue;
 }
 
+// two-sided bounds of listed pairs (the settled rows' reference values): all ceil(D / 32) blocks, three digits
+int estep_i8_pairs_per_chunk() { return i8_pairs_per_chunk(); }
+
+template <int T32, typename XT, bool VEC>
+static hipError_t go_pairs(int grid, hipStream_t st, const EstepI8Args& a, const int* lists, int64_t cap, const int* counts,
+                           const int* plan, float* dist_up) {
+    hipLaunchKernelGGL((estep_i8_pairs<T32, XT, VEC>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x), a.ldx, a.D,
+                       a.img, a.pivot, a.K, lists, cap, counts, plan, dist_up);
+    return hipGetLastError();
+}
+
+hipError_t launch_estep_i8_pairs(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const int* lists,
+                                 int64_t cap, const int* counts, const int* plan, float* dist_up) {
+    if (a.K > 256) return hipErrorInvalidValue;
+#define PC(T)                                                                                                         \
+    case T:                                                                                                           \
+        if (x_is_f64)                                                                                                 \
+            return vec ? go_pairs<T, double, true>(grid, st, a, lists, cap, counts, plan, dist_up)                    \
+                       : go_pairs<T, double, false>(grid, st, a, lists, cap, counts, plan, dist_up);                  \
+        return vec ? go_pairs<T, float, true>(grid, st, a, lists, cap, counts, plan, dist_up)                         \
+                   : go_pairs<T, float, false>(grid, st, a, lists, cap, counts, plan, dist_up);
+    switch (i8_blocks(a.D)) {
+        PC(1) PC(2) PC(3) PC(4)
+    }
+#undef PC
+    return hipErrorInvalidValue;
+}
+
 }  // namespace gmmvb

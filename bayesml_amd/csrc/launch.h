@@ -32,6 +32,12 @@ hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream
 hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
                                    const int* lists, int64_t cap, const int* counts_dev, const int* plan_dev,
                                    const float* thr = nullptr /*[npad] relevance thresholds: early way out for irrelevant pairs*/);
+// two-sided int8 bounds of listed pairs (estep_i8.h, estep_i8_pairs): a.img = the 3-digit image, dist_up[row] <- upper
+// bound of the whitened distance of (row, its listed component)
+struct EstepI8Args;
+int estep_i8_pairs_per_chunk();
+hipError_t launch_estep_i8_pairs(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const int* lists,
+                                 int64_t cap, const int* counts, const int* plan, float* dist_up);
 // int8-digit E-step (estep_i8.h): own parameter image (bytes per component), 256 rows per workgroup
 struct EstepI8Args {
     const void* x; int64_t ldx; int64_t n_rows; int D;

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              double* __restrict__ opart,
                                                              unsigned char* __restrict__ lock /*null: no settled rows*/,
                                                              float* __restrict__ dlock,
-                                                             float* __restrict__ rthr /*[npad] the row's relevance threshold*/) {
+                                                             float* __restrict__ rthr /*[npad] the row's relevance threshold*/,
+                                                             int fresh_ref /*dlock already holds bounds under the new parameters*/) {
     __shared__ int wcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
@@ -388,7 +389,9 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         float d_set = 0.0f, thr_set = 0.0f;
         if (by_bound) {
             kset = khat[n];
-            const float dn = fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
+            // the distance bound: evaluated for the new parameters on the int8 pipe (estep_i8_pairs), or the previous
+            // pass's carried through Gamma and delta
+            const float dn = fresh_ref ? dlock[n] : fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
             const float lb = sq[kset].y - dn * dn * 0.5000005f;
             d_set = dn;
             thr_set = (lb - fabsf(lb) * 2.4e-7f) - 69.5f;
