@@ -136,8 +136,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->settle_margin = std::atof(v);
         v = std::getenv("GMMVB_SETTLE_GAMMA");
         if (v) ws->settle_gamma = std::atof(v);
-        v = std::getenv("GMMVB_SETTLE_I8");
-        ws->settle_i8 = !(v && std::strcmp(v, "0") == 0);
+        v = std::getenv("GMMVB_SETTLE_I8");                        // "1": int8 reference bounds for settled rows (slower at C3)
+        ws->settle_i8 = v && std::strcmp(v, "1") == 0;
         v = std::getenv("GMMVB_SETTLE_MARGIN_I8");
         if (v) ws->settle_margin_i8 = std::atof(v);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
