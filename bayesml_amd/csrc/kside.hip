@@ -242,9 +242,9 @@ __device__ inline double digamma_pos(double x) {
     return r + log(x) - 0.5 / x - ser;
 }
 
-// deterministic block sum of NV values per thread (256 threads): wave shuffles, then the four wave results in order
-template <int NV>
-__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /*[4 * NV]*/) {
+// deterministic block sum of NV values per thread (NT threads): wave shuffles, then the wave results in a fixed tree
+template <int NV, int NT>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /*[NT / 64 * NV]*/) {
 #pragma unroll
     for (int q = 0; q < NV; ++q)
 #pragma unroll
@@ -255,10 +255,19 @@ __device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /*[4 * 
         for (int q = 0; q < NV; ++q) red[(threadIdx.x >> 6) * NV + q] = v[q];
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = (red[q] + red[NV + q]) + (red[2 * NV + q] + red[3 * NV + q]);
+    for (int q = 0; q < NV; ++q) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w += 4)
+            t += (red[w * NV + q] + red[(w + 1) * NV + q]) + (red[(w + 2) * NV + q] + red[(w + 3) * NV + q]);
+        v[q] = t;
+    }
 }
 
-__global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView pr, PostView q, PostView qn,
+// NT threads per component: 1024 for D > 32 (sixteen waves hide the LDS latency of the factorisation's short dependent
+// steps: 0.61 -> see DESIGN.md 5d), 256 below.
+template <int NT>
+__global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView pr, PostView q, PostView qn,
                                                          const double* __restrict__ stats, const double* __restrict__ pivot,
                                                          double* __restrict__ s_prev, double* __restrict__ ns_out,
                                                          double* __restrict__ x_bar_out, double* __restrict__ s_out,
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView
     double* dev0 = xbar + D;
     double* dq = dev0 + D;
     double* dm = dq + D;
-    double* red = dm + D;
+    double* red = dm + D;          // [NT / 64 * 4]
     const int tid = threadIdx.x, k = blockIdx.x;
     const int64_t vb = (int64_t)k * D, mb = (int64_t)k * D * D;
     const double LN_2PI = 1.8378770664093454835606594728112, LN_2 = 0.69314718055994530941723212145818,
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView
     const double safe = pos ? ns : 1.0;
     const double kap0 = pr.kappa[k], nu0 = pr.nu[k], al0 = pr.alpha[k];
     const double kapq = q.kappa[k], nuq = q.nu[k], alq = q.alpha[k], elpq = q.e_ln_pi[k], eldq = q.e_ln_lambda_det[k];
-    for (int i = tid; i < D; i += 256) {
+    for (int i = tid; i < D; i += NT) {
         const double ab = a[i] / safe;
         const double xb = pos ? pivot[i] + ab : 0.0;
         abar[i] = ab;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView
     const double kapn = kap0 + ns, nun = nu0 + ns, aln = al0 + ns;
     const double coef = kap0 * ns / kapn;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};          // tr(S nu W), dq' nu W dq, dm' nu W dm, tr(W0^-1 nu W)
-    for (int e = tid; e < D * D; e += 256) {
+    for (int e = tid; e < D * D; e += NT) {
         const int i = e / D, j = e - i * D;
         const double sij = pos ? B[e] / safe - abar[i] * abar[j] : s_prev[mb + e];
         s_out[mb + e] = sij;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView
         qn.w_inv[mb + e] = wn;
         mat[i * ld + j] = j <= i ? wn : 0.0;
     }
-    block_sum_n<4>(acc, red);
+    block_sum_n<4, NT>(acc, red);
     if (tid == 0) {
         double* pt = partials + (int64_t)k * kPartials;
         pt[0] = 0.5 * ns * (eldq - D / kapq - acc[0] - acc[1] - D * LN_2PI);                                   // p_x
@@ -330,35 +339,36 @@ __global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView
         qn.kappa[k] = kapn;
         qn.nu[k] = nun;
     }
-    for (int i = tid; i < D; i += 256) qn.m[vb + i] = (kap0 * pr.m[vb + i] + ns * xbar[i]) / kapn;
+    for (int i = tid; i < D; i += NT) qn.m[vb + i] = (kap0 * pr.m[vb + i] + ns * xbar[i]) / kapn;
     __syncthreads();
     // ---- Cholesky of W'^-1 in LDS (as in chol_inv_kernel)
-    const int ti = tid >> 4, tj = tid & 15;
+    constexpr int TG = NT == 1024 ? 32 : 16;                  // the trailing update runs on a TG x TG thread grid
+    const int ti = tid / TG, tj = tid % TG;
     for (int j = 0; j < D; ++j) {
         if (tid == 0) mat[j * ld + j] = sqrt(mat[j * ld + j]);
         __syncthreads();
         const double inv = 1.0 / mat[j * ld + j];
-        for (int i = j + 1 + tid; i < D; i += 256) mat[i * ld + j] *= inv;
+        for (int i = j + 1 + tid; i < D; i += NT) mat[i * ld + j] *= inv;
         __syncthreads();
-        for (int i = j + 1 + ti; i < D; i += 16) {
+        for (int i = j + 1 + ti; i < D; i += TG) {
             const double lij = mat[i * ld + j];
-            for (int c = j + 1 + tj; c <= i; c += 16) mat[i * ld + c] = fma(-lij, mat[c * ld + j], mat[i * ld + c]);
+            for (int c = j + 1 + tj; c <= i; c += TG) mat[i * ld + c] = fma(-lij, mat[c * ld + j], mat[i * ld + c]);
         }
         __syncthreads();
     }
     const double sq = sqrt(nun), isq = 1.0 / sq;
-    for (int e = tid; e < D * D; e += 256) {
+    for (int e = tid; e < D * D; e += NT) {
         const int i = e / D, j = e - i * D;
         qn.u_inv[mb + e] = mat[i * ld + j] * isq;             // u'^-1 = G / sqrt(nu')
     }
     // log det W'^-1 and the digamma / lgamma sums over d < D
     double f[3] = {0.0, 0.0, 0.0};
-    for (int d = tid; d < D; d += 256) {
+    for (int d = tid; d < D; d += NT) {
         f[0] += log(mat[d * ld + d]);
         f[1] += digamma_pos(0.5 * (nun - d));
         f[2] += lgamma(0.5 * (nun - d));
     }
-    block_sum_n<3>(f, red);
+    block_sum_n<3, NT>(f, red);
     const double logdet = 2.0 * f[0];
     const double eld = f[1] + D * LN_2 - logdet;
     if (tid == 0) {
@@ -371,30 +381,25 @@ __global__ __launch_bounds__(256) void kside_step_kernel(int K, int D, PriorView
         qn.c[k] = elp + 0.5 * (eld - D * LN_2PI - D / kapn);
     }
     __syncthreads();
-    // ---- in-place inverse of the factor
+    // ---- in-place inverse of the factor: column j from the columns right of it; SEG threads share a row's dot product
+    constexpr int SEG = NT / 128;                             // D <= 128 rows
+    const int rl = tid / SEG, seg = tid % SEG;
     for (int j = D - 1; j >= 0; --j) {
         const double xjj = 1.0 / mat[j * ld + j];
+        const int i = j + 1 + rl;
         double v = 0.0;
-        const int i = j + 1 + tid;
-        if (i < D) {
-            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
-            int p = j + 1;
-            for (; p + 3 <= i; p += 4) {
-                v = fma(mat[i * ld + p], mat[p * ld + j], v);
-                v1 = fma(mat[i * ld + p + 1], mat[(p + 1) * ld + j], v1);
-                v2 = fma(mat[i * ld + p + 2], mat[(p + 2) * ld + j], v2);
-                v3 = fma(mat[i * ld + p + 3], mat[(p + 3) * ld + j], v3);
-            }
-            for (; p <= i; ++p) v = fma(mat[i * ld + p], mat[p * ld + j], v);
-            v = -((v + v1) + (v2 + v3)) * xjj;
-        }
+        if (i < D)
+            for (int p = j + 1 + seg; p <= i; p += SEG) v = fma(mat[i * ld + p], mat[p * ld + j], v);
+#pragma unroll
+        for (int o = 1; o < SEG; o <<= 1) v += __shfl_xor(v, o);
+        v = -v * xjj;
         __syncthreads();
-        if (i < D) mat[i * ld + j] = v;
+        if (i < D && seg == 0) mat[i * ld + j] = v;
         if (tid == 0) mat[j * ld + j] = xjj;
         __syncthreads();
     }
     // u' = sqrt(nu') G^-1 and W' = G^-T G^-1 (upper triangle computed, mirrored: exactly symmetric)
-    for (int e = tid; e < D * D; e += 256) {
+    for (int e = tid; e < D * D; e += NT) {
         const int i = e / D, j = e - i * D;
         qn.u[mb + e] = mat[i * ld + j] * sq;
         if (i <= j) {
@@ -512,17 +517,23 @@ extern "C" int gmmvb_kside_step(int K, int D, const gmmvb_prior_view* prior, con
     std::memcpy(&qa, q, sizeof(qa));
     std::memcpy(&qb, q_next, sizeof(qb));
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = ((size_t)D * (D + 1) + 5 * (size_t)D + 32) * sizeof(double);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kside_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = ((size_t)D * (D + 1) + 5 * (size_t)D + 64) * sizeof(double);
+    const bool wide = D > 32;
+    static size_t lds_set[2] = {0, 0};
+    if (lds > lds_set[wide]) {
+        hipError_t e = hipFuncSetAttribute(wide ? (const void*)kside_step_kernel<1024> : (const void*)kside_step_kernel<256>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "hipFuncSetAttribute(kside_step_kernel)", e);
-        lds_set = lds;
+        lds_set[wide] = lds;
     }
     double* partials = scratch_dev;                       // [K][kPartials]
     double* enorm = scratch_dev + (size_t)K * kPartials;  // [K]
-    hipLaunchKernelGGL(kside_step_kernel, dim3(K), dim3(256), lds, st, K, D, pr, qa, qb, stats_dev, pivot_dev, s_prev_dev, ns_dev,
-                       x_bar_dev, s_dev, partials);
+    if (wide)
+        hipLaunchKernelGGL(kside_step_kernel<1024>, dim3(K), dim3(1024), lds, st, K, D, pr, qa, qb, stats_dev, pivot_dev, s_prev_dev,
+                           ns_dev, x_bar_dev, s_dev, partials);
+    else
+        hipLaunchKernelGGL(kside_step_kernel<256>, dim3(K), dim3(256), lds, st, K, D, pr, qa, qb, stats_dev, pivot_dev, s_prev_dev,
+                           ns_dev, x_bar_dev, s_dev, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "kside_step_kernel launch", e);
     if (want_drift) {
