@@ -121,11 +121,26 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
     double acc[8][8];
 
     if (dir == 0) {          // delta
+        // a wave per row: coalesced row reads, independent rows in flight (a thread per row walked its row with 128
+        // dependent strided loads)
+        const int lane = tid & 63, wv = tid >> 6;
+        double dmv[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int i = lane + 64 * hh;
+            dmv[hh] = i < D ? m_new[(int64_t)k * D + i] - m_old[(int64_t)k * D + i] : 0.0;
+        }
         double part = 0.0;
-        if (tid < D) {
+        for (int r = wv; r < D; r += 4) {
             double y = 0.0;
-            for (int i = 0; i < D; ++i) y = fma(u_new[base + (int64_t)tid * D + i], m_new[(int64_t)k * D + i] - m_old[(int64_t)k * D + i], y);
-            part = y * y;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int i = lane + 64 * hh;
+                if (i < D) y = fma(u_new[base + (int64_t)r * D + i], dmv[hh], y);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) y += __shfl_xor(y, o);
+            part += lane == 0 ? y * y : 0.0;
         }
         const double t = block_sum256(part, red);
         if (tid == 0) delta[k] = sqrt(t) * (1.0 + 1e-9);
@@ -141,15 +156,23 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
+    // (the rows of R are requested one step ahead and without branches - columns past D read column D - 1 and are
+    // zeroed when A is stored: a load waited for inside its own step costs a memory round trip per step, 128 of them)
+    int jc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) jc[b] = tx + 16 * b < D ? tx + 16 * b : D - 1;
+    double rn[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) rn[b] = R[jc[b]];
     for (int p = 0; p < D; ++p) {
         double lv[8], rv[8];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) lv[a] = sm[(ty + 16 * a) * kDriftLd + p];
+        for (int b = 0; b < 8; ++b) rv[b] = rn[b];
+        const int pn = p + 1 < D ? p + 1 : p;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int j = tx + 16 * b;
-            rv[b] = j < D ? R[(int64_t)p * D + j] : 0.0;
-        }
+        for (int b = 0; b < 8; ++b) rn[b] = R[(int64_t)pn * D + jc[b]];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) lv[a] = sm[(ty + 16 * a) * kDriftLd + p];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -161,7 +184,7 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int i = ty + 16 * a, j = tx + 16 * b;
-            sm[i * kDriftLd + j] = acc[a][b] - ((dir == 2 && i == j && i < D) ? 1.0 : 0.0);
+            sm[i * kDriftLd + j] = j < D ? acc[a][b] - ((dir == 2 && i == j && i < D) ? 1.0 : 0.0) : 0.0;
         }
     __syncthreads();
     // G = A^T A, then the squarings; every product is followed by its Frobenius norm
