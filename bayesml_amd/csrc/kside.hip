@@ -194,12 +194,23 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
+        // one wave per SIMD: the operands of step p + 1 are read from LDS while step p's 64 FMAs run
+        double ln[8], rn2[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) ln[a] = it == 0 ? sm[ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) rn2[b] = sm[tx + 16 * b];
         for (int p = 0; p < 128; ++p) {
             double lv[8], rv[8];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) lv[a] = it == 0 ? sm[p * kDriftLd + ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd + p];
+            for (int a = 0; a < 8; ++a) lv[a] = ln[a];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) rv[b] = sm[p * kDriftLd + tx + 16 * b];
+            for (int b = 0; b < 8; ++b) rv[b] = rn2[b];
+            const int pn = p + 1 < 128 ? p + 1 : p;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) ln[a] = it == 0 ? sm[pn * kDriftLd + ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd + pn];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) rn2[b] = sm[pn * kDriftLd + tx + 16 * b];
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
