@@ -544,7 +544,23 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->xc_src = x_dev;
     ws->xc_rows = n_rows;
     ws->xc_ldx = ldx;
+    ws->xc_stale = false;
     return GMMVB_OK;
+}
+
+// The centred copy in the workspace's internal row order (after a regrouping; see regroup_rows)
+static hipError_t recenter_rows(gmmvb_workspace* ws, int64_t n_rows, hipStream_t st) {
+    const int Dp = 16 * ws->T;
+    const int64_t pad_rows = round_up(n_rows, 64) + 64;
+    const unsigned cg = (unsigned)((pad_rows * Dp + 255) / 256);
+    if (ws->x_dtype == GMMVB_F64)
+        hipLaunchKernelGGL(center_rows_kernel<double>, dim3(cg), dim3(256), 0, st, (const double*)ws->xp, (int64_t)ws->D, n_rows,
+                           pad_rows, ws->D, Dp, ws->pivot, ws->xc);
+    else
+        hipLaunchKernelGGL(center_rows_kernel<float>, dim3(cg), dim3(256), 0, st, (const float*)ws->xp, (int64_t)ws->D, n_rows,
+                           pad_rows, ws->D, Dp, ws->pivot, ws->xc);
+    ws->xc_stale = false;
+    return hipGetLastError();
 }
 
 // Regroup the internal row order by the best component of the last E-step (aux_kernels.h): new permutation, permuted copy
@@ -569,17 +585,9 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     else
         hipLaunchKernelGGL(permute_rows_kernel<float>, dim3(pg), dim3(256), 0, st, (const float*)x_dev, ldx, n_rows, ws->D,
                            ws->perm, (float*)ws->xp);
-    if (ws->xc) {
-        const int Dp = 16 * ws->T;
-        const int64_t pad_rows = round_up(n_rows, 64) + 64;
-        const unsigned cg = (unsigned)((pad_rows * Dp + 255) / 256);
-        if (ws->x_dtype == GMMVB_F64)
-            hipLaunchKernelGGL(center_rows_kernel<double>, dim3(cg), dim3(256), 0, st, (const double*)ws->xp, (int64_t)ws->D, n_rows,
-                               pad_rows, ws->D, Dp, ws->pivot, ws->xc);
-        else
-            hipLaunchKernelGGL(center_rows_kernel<float>, dim3(cg), dim3(256), 0, st, (const float*)ws->xp, (int64_t)ws->D, n_rows,
-                               pad_rows, ws->D, Dp, ws->pivot, ws->xc);
-    }
+    // the centred f64 copy follows the internal order too, but it is only read by the dense M-step (and by the list
+    // M-step of f64 / ragged-D inputs): rebuilt there when needed (recenter_rows), not here - 4 ms and 10 GB at C3
+    ws->xc_stale = ws->xc != nullptr;
     ws->sorted = true;
     ++ws->sorts;
     return hipGetLastError();
@@ -1124,6 +1132,10 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             la0.D = ws->D;
             la0.pivot = ws->pivot;
         }
+        if (!la0.x32 && ws->xc_stale) {        // this list kernel reads the centred copy: bring it to the internal row order
+            e = recenter_rows(ws, n_rows, st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
+        }
         int64_t lgrid = (cap_chunks0 + kpw - 1) / kpw;
         {
             const int64_t most = (n_rows * (int64_t)ws->K + r_min0 - 1) / r_min0 + ws->K;      // no more chunks than this can exist
@@ -1196,6 +1208,10 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     } else {
         ++ws->passes[5];
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
+        if (pre && ws->xc_stale) {             // the dense kernel reads the centred copy: bring it to the internal row order
+            e = recenter_rows(ws, n_rows, st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
+        }
         span_begin(ws, kSpanMstepMain, st);
         e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
         span_end(ws, st);

@@ -135,6 +135,7 @@ struct gmmvb_workspace {
     double* xc = nullptr;      // [npad][16T] centred f64 copy of the sample matrix (M-step operand), optional
     const void* xc_src = nullptr;   // the x it was made from (null = not prepared)
     int64_t xc_rows = 0, xc_ldx = 0;
+    bool xc_stale = false;     // the rows were regrouped since xc was made: it is rebuilt from xp when a kernel needs it
     int64_t bytes = 0;
     bool have_params = false;
     int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly, 3 HMM gamma
