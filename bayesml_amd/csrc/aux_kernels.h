@@ -270,12 +270,12 @@ inline void launch_scan_counts(hipStream_t st, int* blk, int blocks, int K, int*
 
 // lock (delta lists of the cache of single-component rows, records.h rec_finish_kernel): a row that leaves its
 // component's cache (state 2, or 4 in the list of a component that is not its best any more) is listed with the sign
-// bit set; one that enters (state 3, or 4 in the list of its new best component khat) without.  State afterwards: 0 / 1.
+// bit set; one that enters (state 3, or 4 in the list of its new component lcomp) without.  State afterwards: 0 / 1.
 __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned long long* __restrict__ masks, int64_t npad,
                                                               int64_t n_rows, int K, const int* __restrict__ blk_base,
                                                               int* __restrict__ lists, int64_t cap,
                                                               unsigned char* __restrict__ lock = nullptr,
-                                                              const int* __restrict__ khat = nullptr) {
+                                                              const unsigned char* __restrict__ lcomp = nullptr) {
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
     }
     __syncthreads();
     const unsigned lk0 = (lock && valid) ? lock[n] : 0u;
-    const int kh0 = (lock && valid) ? khat[n] : 0;
+    const int kh0 = (lock && valid) ? (int)lcomp[n] : 0;
     if (lk0 >= 2u) lock[n] = lk0 == 2u ? 0 : 1;
     for (int w = 0; w < W; ++w) {
         const unsigned long long mk = valid ? masks[(int64_t)w * npad + n] : 0ull;

@@ -199,7 +199,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
-                     ws->lock, ws->dlock, ws->rthr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
+                     ws->lock, ws->lcomp, ws->dlock, ws->rthr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
                      ws->rmask, ws->rblk};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
@@ -405,6 +405,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->masks, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->lock, (size_t)np);
     if (e == hipSuccess) e = hipMemset(ws->lock, 0, (size_t)np);
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->lcomp, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dlock, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rthr, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
@@ -713,12 +714,18 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
     }
     ws->forget = false;
-    // Settled rows survive only from sweep to sweep over the same rows, with the M-step in between having applied the
-    // delta lists.  Anything else drops them; the rows then have no active pair on record, which only a pass that
-    // rebuilds everything (bound or dense) can digest.
+    // The cache of single-component rows (and the settled rows among them) survives every pruned pass over the same rows
+    // whose M-step applied the delta lists - all of them end in rec_finish_kernel.  A dense pass, a regrouping of the rows,
+    // new data or parameters unrelated to the last pass drop it; rows that were settled then have no active pair on
+    // record, which only a pass that rebuilds everything (bound or dense) can digest.
+    auto regroup_due = [&]() {
+        return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
+               ws->lag_act <= 4.0 * (double)n_rows && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
+               (!ws->sorted || ws->moved_since_sort > 0.05 * (double)n_rows);      // (again once 5 % of the rows have moved on)
+    };
     bool settle = false;
     if (ws->lock) {
-        const bool keep = mode == kSweep && same_rows && !ws->lock_reset && !ws->delta_pending;
+        const bool keep = mode != kDense && same_rows && !ws->lock_reset && !ws->delta_pending && !regroup_due();
         if (ws->lock_reset || (ws->lock_live && !keep)) {
             if (mode == kSweep || mode == kCarry) mode = kBound;
             (void)hipMemsetAsync(ws->lock, 0, (size_t)ws->npad, st);
@@ -728,7 +735,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
         ws->lock_reset = false;
         ws->delta_pending = false;
-        settle = mode == kSweep && ws->cache_on && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
+        settle = mode != kDense && ws->cache_on && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
                  ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     }
     // Rows are settled (left out of the E-step as well) when the next pass can re-evaluate their reference bound cheaply
@@ -795,9 +802,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // a bound pass rebuilds everything row-indexed anyway: the moment to regroup the internal row order by the best
     // component of the previous pass (once at most 4 components per row are active: later passes are list-driven)
     bool sorted_now = false;
-    if (mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
-        ws->lag_act <= 4.0 * (double)n_rows && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
-        (!ws->sorted || ws->moved_since_sort > 0.05 * (double)n_rows)) {     // (again once 5 % of the rows have moved on)
+    if (regroup_due()) {
         span_begin(ws, kSpanSelect, st);
         e = regroup_rows(ws, x_dev, ldx, n_rows, st);
         span_end(ws, st);
@@ -905,7 +910,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     // parameters, from three int8 digits (their lists are built and used before the buffers take the
                     // active pairs' lists)
                     span_begin(ws, kSpanSelect, st);
-                    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->khat,
+                    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->lcomp,
                                        ws->npad, n_rows, ws->K, ws->rmask, ws->rblk);
                     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
                     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
@@ -939,7 +944,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, (i8_ref && ws->skip_used) ? 1 : 0);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, (i8_ref && ws->skip_used) ? 1 : 0, ws->lcomp);
                 span_end(ws, st);
             } else {
                 span_begin(ws, kSpanSelect, st);
@@ -951,7 +956,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, 0);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, 0, ws->lcomp);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;
@@ -976,7 +981,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,
                            ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32,
                            settle ? ws->lock : nullptr, ws->dlock, skip_margin, settle ? ws->dmask : nullptr,
-                           settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart, ws->qpart, ws->rthr);
+                           settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart, ws->qpart, ws->rthr, ws->lcomp);
         hipLaunchKernelGGL(sum_parts_kernel, dim3(7), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, ws->spart,
                            ws->gpart, ws->qpart, sel_grid, ws->ctr);
         e = hipGetLastError();
@@ -1148,7 +1153,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             span_begin(ws, kSpanLists, st);
             launch_scan_counts(st, ws->dblk, nblk, ws->K, ws->counts, ws->scan_parts);
             hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->dmask, ws->npad, n_rows, ws->K,
-                               ws->dblk, ws->lists, ws->npad, ws->lock, ws->khat);
+                               ws->dblk, ws->lists, ws->npad, ws->lock, ws->lcomp);
             span_end(ws, st);
             MstepListArgs ld = la0;
             ld.direct_r = 3;
@@ -1267,7 +1272,7 @@ static int refresh_settled(gmmvb_workspace* ws, hipStream_t st) {
         a.ldx = ws->D;
         vec = ws->D % 16 == 0;
     }
-    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->khat, ws->npad, n_rows,
+    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->lcomp, ws->npad, n_rows,
                        ws->K, ws->rmask, ws->rblk);
     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows, ws->K, ws->rblk,
@@ -1276,7 +1281,7 @@ static int refresh_settled(gmmvb_workspace* ws, hipStream_t st) {
                        ws->plan);
     hipError_t e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row evaluation", e);
-    hipLaunchKernelGGL(settled_lse_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lock, ws->masks, ws->khat,
+    hipLaunchKernelGGL(settled_lse_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lock, ws->masks, ws->lcomp,
                        ws->lnrho, ws->npad, n_rows, ws->K, ws->lse);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row read-out", e);
@@ -1302,7 +1307,7 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
         const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
         hipLaunchKernelGGL(rec_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec,
                            ws->masks, ws->lnrho, ws->lse, ws->cvec, ws->npad, row0, n_rows, ws->K, mode, out,
-                           ws->sorted ? ws->iperm : nullptr, ws->lock_live ? ws->lock : nullptr, ws->khat);
+                           ws->sorted ? ws->iperm : nullptr, ws->lock_live ? ws->lock : nullptr, ws->lcomp);
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return fail(GMMVB_EHIP, "rec_readout launch", er);
         return GMMVB_OK;

@@ -338,7 +338,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              unsigned char* __restrict__ lock /*null: no settled rows*/,
                                                              float* __restrict__ dlock,
                                                              float* __restrict__ rthr /*[npad] the row's relevance threshold*/,
-                                                             int fresh_ref /*dlock already holds bounds under the new parameters*/) {
+                                                             int fresh_ref /*dlock already holds bounds under the new parameters*/,
+                                                             const unsigned char* __restrict__ lcomp /*[npad] component a cached row is in*/) {
     __shared__ int wcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         int kset = -1;
         float d_set = 0.0f, thr_set = 0.0f;
         if (by_bound) {
-            kset = khat[n];
+            kset = lcomp[n];
             // the distance bound: evaluated for the new parameters on the int8 pipe (estep_i8_pairs), or the previous
             // pass's carried through Gamma and delta
             const float dn = fresh_ref ? dlock[n] : fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               unsigned long long* __restrict__ mmask, int* __restrict__ mblk,
                                                               double* __restrict__ spart, double* __restrict__ gpart,
                                                               double* __restrict__ qpart /*pairs the M-step accumulates*/,
-                                                              const float* __restrict__ rthr /*[npad] relevance thresholds*/) {
+                                                              const float* __restrict__ rthr /*[npad] relevance thresholds*/,
+                                                              unsigned char* __restrict__ lcomp /*[npad] component a cached row is in*/) {
     __shared__ int wcnt[4][256];
     __shared__ int dcnt[4][256];
     __shared__ int mcnt[4][256];
@@ -808,8 +810,9 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         const unsigned lk = lock[n];
         const bool single = row_arg >= 0 && active == 1;
         if (lk == 1u) {
-            if (!(single && row_arg == khat_before)) {
-                dm[khat_before >> 6] |= 1ull << (khat_before & 63);
+            const int was = lcomp[n];                   // (khat may have been rewritten by a bound pass on the way here)
+            if (!(single && row_arg == was)) {
+                dm[was >> 6] |= 1ull << (was & 63);
                 if (single) dm[row_arg >> 6] |= 1ull << (row_arg & 63);
                 lock[n] = single ? 4 : 2;
             }
@@ -818,6 +821,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
             lock[n] = 3;
         }
         if (single) {
+            lcomp[n] = (unsigned char)row_arg;
             mm[row_arg >> 6] &= ~(1ull << (row_arg & 63));
             if (settle_margin >= 0.0 && row_second < row_l - k100Ln2 - settle_margin) {
                 dlock[n] = f32_up(dist_of(cvec[row_arg], row_best) * (1.0 + 1e-9));
@@ -914,7 +918,7 @@ __device__ __forceinline__ bool row_settled(const unsigned char* __restrict__ lo
 
 __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned char* __restrict__ lock,
                                                                 const unsigned long long* __restrict__ emask,
-                                                                const int* __restrict__ khat, int64_t npad, int64_t n_rows,
+                                                                const unsigned char* __restrict__ lcomp, int64_t npad, int64_t n_rows,
                                                                 int K, unsigned long long* __restrict__ masks,
                                                                 int* __restrict__ blk_cnt) {
     __shared__ int wcnt[4][256];
@@ -923,7 +927,7 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
     const int W = (K + 63) / 64;
     const int wave = threadIdx.x >> 6;
     for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
-    const int kh = (valid && row_settled(lock, emask, npad, W, n)) ? khat[n] : -1;
+    const int kh = (valid && row_settled(lock, emask, npad, W, n)) ? (int)lcomp[n] : -1;
     for (int w = 0; w < W; ++w) {
         const unsigned long long mk = (kh >= 0 && (kh >> 6) == w) ? 1ull << (kh & 63) : 0ull;
         if (valid) masks[(int64_t)w * npad + n] = mk;
@@ -935,10 +939,10 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
 }
 
 __global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const unsigned long long* __restrict__ emask,
-                                   const int* __restrict__ khat, const double* __restrict__ lnrho, int64_t npad,
+                                   const unsigned char* __restrict__ lcomp, const double* __restrict__ lnrho, int64_t npad,
                                    int64_t n_rows, int K, double* __restrict__ lse) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < n_rows && row_settled(lock, emask, npad, (K + 63) / 64, n)) lse[n] = lnrho[(int64_t)khat[n] * npad + n];
+    if (n < n_rows && row_settled(lock, emask, npad, (K + 63) / 64, n)) lse[n] = lnrho[(int64_t)lcomp[n] * npad + n];
 }
 
 // Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-100) marks the pairs
@@ -948,14 +952,14 @@ __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __re
                                    const double* __restrict__ lnrho, const double* __restrict__ lse,
                                    const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
                                    int mode, double* __restrict__ out, const int* __restrict__ iperm,
-                                   const unsigned char* __restrict__ lock, const int* __restrict__ khat) {
+                                   const unsigned char* __restrict__ lock, const unsigned char* __restrict__ lcomp) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rows * K) return;
     const int64_t n = iperm ? iperm[row0 + e / K] : row0 + e / K;
     const int k = (int)(e % K);
     bool exact = ((masks[(int64_t)(k >> 6) * npad + n] >> (k & 63)) & 1ull) != 0 || (rec.flags[n] & 1) != 0;
     // a settled row's pair (in the cache instead of the M-step's mask; refreshed by the caller before this read-out)
-    if (lock && (lock[n] == 1 || lock[n] >= 3) && khat[n] == k) exact = true;
+    if (lock && (lock[n] == 1 || lock[n] >= 3) && (int)lcomp[n] == k) exact = true;
     if (mode == 1) {
         out[e] = exact ? exp(lnrho[(int64_t)k * npad + n] - lse[n]) : 0.0;
         return;

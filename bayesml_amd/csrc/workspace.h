@@ -103,6 +103,7 @@ struct gmmvb_workspace {
     // evaluated (E) nor accumulated (M): its addend lives in `cache` (same layout as the statistics), which changes only
     // through the rows that settle or come loose in a pass (the M-step's delta lists).
     unsigned char* lock = nullptr;     // [npad] 0 free, 1 settled, 2 came loose in this pass, 3 settled in this pass
+    unsigned char* lcomp = nullptr;    // [npad] cached rows: the component whose cache holds the row (K <= 256)
     float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
     float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 100 ln 2)
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
