@@ -694,7 +694,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
-                if (gpp * spare * 2.5 >= bound_cost) carry = sweep = false;
+                double weight = 2.5;
+                if (const char* v = std::getenv("GMMVB_SPARE_WEIGHT")) weight = std::atof(v);
+                if (gpp * spare * weight >= bound_cost) carry = sweep = false;
                 // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
                 // (x4 - x8 observed): stop carrying well before they dominate
                 if (ws->lag_over > 0.02 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = sweep = false;
