@@ -234,6 +234,122 @@ __global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __
     }
 }
 
+// ---- two-level boundary pass (long sequences) -------------------------------------------------------------------------
+// With one level the chunk length has to balance the sequential pass over T / L chunk products against the L
+// dependent steps of a replay wave (L ~ sqrt(T): 2048 at T = 1e7, 4883 sequential products = 5.3 ms, and only 77
+// replay workgroups).  With two levels the chunks are short (256 steps: 39063 chunks, 610 replay workgroups), the
+// products of kHmmSuper consecutive chunks are multiplied up in parallel (H3a), the sequential pass runs over the 611
+// super-chunk products (H3 itself), and every super-chunk then fills in its own chunks' start / end vectors (H3b).
+constexpr int kHmmSuper = 64;
+
+// H3a: Q_s = P_{sG} P_{sG+1} ... (G = kHmmSuper chunks), rescaled to max 1 after every product.  One workgroup per s.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_super_products_kernel(const double* __restrict__ prod, int64_t n_chunks,
+                                                                 double* __restrict__ qprod /*[n_super][Kp][Kp]*/) {
+    constexpr int Kp = 16 * KT, E = (Kp * Kp + 255) / 256;
+    __shared__ double A[Kp * Kp], B[Kp * Kp];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * kHmmSuper;
+    const int64_t c1 = c0 + kHmmSuper < n_chunks ? c0 + kHmmSuper : n_chunks;
+    for (int e = tid; e < Kp * Kp; e += 256) A[e] = prod[c0 * Kp * Kp + e];
+    for (int64_t c = c0 + 1; c < c1; ++c) {
+        for (int e = tid; e < Kp * Kp; e += 256) B[e] = prod[c * Kp * Kp + e];
+        __syncthreads();
+        double out[E];
+        double m = 0.0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int e = tid + 256 * q;
+            double acc = 0.0;
+            if (e < Kp * Kp) {
+                const int i = e / Kp, j = e % Kp;
+                for (int p2 = 0; p2 < Kp; ++p2) acc = fma(A[i * Kp + p2], B[p2 * Kp + j], acc);
+            }
+            out[q] = acc;
+            m = fmax(m, acc);
+        }
+        m = max_wave(m);
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();                                   // (also: every read of A and B is done)
+        m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        const double sc = m > 0.0 ? 1.0 / m : 1.0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int e = tid + 256 * q;
+            if (e < Kp * Kp) A[e] = out[q] * sc;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int e = tid; e < Kp * Kp; e += 256) qprod[(int64_t)blockIdx.x * Kp * Kp + e] = A[e];
+}
+
+// H3b: from the super-chunk boundary vectors (H3 run on the Q_s) to every chunk's: wave 0 forward, wave 1 backward, the
+// loops of H3 over the chunks of one super-chunk.  fstart_s[s] = alpha at the start of super-chunk s, bend_s[s] = beta~ at
+// the end of its last chunk.
+template <int KT>
+__global__ __launch_bounds__(128) void hmm_boundary_fill_kernel(const double* __restrict__ prod, int64_t n_chunks,
+                                                                const double* __restrict__ fstart_s,
+                                                                const double* __restrict__ bend_s,
+                                                                double* __restrict__ fstart, double* __restrict__ bend) {
+    constexpr int Kp = 16 * KT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ln = lane < Kp ? lane : 0;
+    const int64_t s = blockIdx.x;
+    const int64_t c0 = s * kHmmSuper;
+    const int64_t c1 = c0 + kHmmSuper < n_chunks ? c0 + kHmmSuper : n_chunks;
+    double cur[Kp], nxt[Kp];
+    if (wave == 0) {
+        double v = lane < Kp ? fstart_s[s * Kp + lane] : 0.0;
+        if (lane < Kp) fstart[c0 * Kp + lane] = v;
+        if (c0 + 1 < c1) {
+#pragma unroll
+            for (int i = 0; i < Kp; ++i) nxt[i] = prod[c0 * Kp * Kp + i * Kp + ln];
+        }
+        for (int64_t c = c0; c + 1 < c1; ++c) {
+#pragma unroll
+            for (int i = 0; i < Kp; ++i) cur[i] = nxt[i];
+            if (c + 2 < c1) {
+                const double* P = prod + (c + 1) * Kp * Kp;
+#pragma unroll
+                for (int i = 0; i < Kp; ++i) nxt[i] = P[i * Kp + ln];
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < Kp; ++i) acc = fma(__shfl(v, i), cur[i], acc);
+            if (lane >= Kp) acc = 0.0;
+            const double tot = sum_wave(acc);
+            v = tot > 0.0 ? acc / tot : 0.0;
+            if (lane < Kp) fstart[(c + 1) * Kp + lane] = v;
+        }
+    } else {
+        double v = lane < Kp ? bend_s[s * Kp + lane] : 0.0;
+        if (lane < Kp) bend[(c1 - 1) * Kp + lane] = v;
+        if (c1 - 1 > c0) {
+            const double* P = prod + (c1 - 1) * Kp * Kp;
+#pragma unroll
+            for (int jj = 0; jj < Kp; ++jj) nxt[jj] = P[ln * Kp + jj];
+        }
+        for (int64_t c = c1 - 1; c > c0; --c) {
+#pragma unroll
+            for (int jj = 0; jj < Kp; ++jj) cur[jj] = nxt[jj];
+            if (c - 1 > c0) {
+                const double* P = prod + (c - 1) * Kp * Kp;
+#pragma unroll
+                for (int jj = 0; jj < Kp; ++jj) nxt[jj] = P[ln * Kp + jj];
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < Kp; ++jj) acc = fma(cur[jj], __shfl(v, jj), acc);
+            if (lane >= Kp) acc = 0.0;
+            const double tot = sum_wave(acc);
+            v = tot > 0.0 ? acc / tot : 0.0;
+            if (lane < Kp) bend[(c - 1) * Kp + lane] = v;
+        }
+    }
+}
+
 // H4: forward replay.  One wave = 16 chunks (MFMA columns).  alpha_tm / rho_tm in lane order.
 template <int KT>
 __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* __restrict__ rho_tm,

@@ -7,6 +7,8 @@
 
 #include "hmm.h"
 
+#include <cstdlib>
+
 using namespace gmmvb;
 
 struct gmmvb_hmm_state {
@@ -22,6 +24,8 @@ struct gmmvb_hmm_state {
     double* prod = nullptr;       // [max_chunks][Kp][Kp]
     double* fstart = nullptr;     // [max_chunks][Kp]
     double* bend = nullptr;       // [max_chunks][Kp]
+    double* qprod = nullptr;      // [max_chunks / kHmmSuper + 2][Kp][Kp] super-chunk products (two-level boundary pass)
+    double* fstart_s = nullptr, *bend_s = nullptr;   // [max_chunks / kHmmSuper + 2][Kp] their boundary vectors
     double* xi_slabs = nullptr;   // [xi_waves][Kp][Kp]
     double* lnc_partial = nullptr;   // [kLncBlocks]
     unsigned char* phi = nullptr; // [npad][Kp] Viterbi back-pointers (allocated on first use by hmmvb_enable)
@@ -33,7 +37,8 @@ namespace gmmvb {
 void hmm_state_destroy(gmmvb_hmm_state* h) {
     if (!h) return;
     double* bufs[] = {h->rho_tm, h->alpha_tm, h->gamma_tm, h->w_tm, h->gamma_cm, h->mx,
-                      h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs, h->lnc_partial};
+                      h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs, h->lnc_partial,
+                      h->qprod,  h->fstart_s, h->bend_s};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (h->phi) (void)hipFree(h->phi);
@@ -49,7 +54,9 @@ constexpr int kLncBlocks = 1024;
 
 // chunk length: balances the sequential boundary scan (T/L steps of ~1.5 us) against the replay depth
 // (L steps of ~4 us forward+backward): L ~ sqrt(T * 1.5 / 4), a power of two in [16, 4096]
+// Long sequences (more than 2^18 steps): chunks of 256 steps and a two-level boundary pass (hmm.h, H3a / H3b).
 int64_t chunk_len(int64_t T) {
+    if (T > (int64_t(1) << 18) && std::getenv("HMMVB_ONE_LEVEL") == nullptr) return 256;
     int64_t L = 16;
     while (L < 4096 && 8 * L * L < 3 * T) L *= 2;
     return L;
@@ -66,8 +73,18 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     if (n_chunks > 0)
         hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
                            h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod);
-    hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K,
-                       n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+    const bool two_level = T > (int64_t(1) << 18) && L == 256 && n_chunks > 2 * kHmmSuper;
+    if (two_level) {
+        const int64_t n_super = (n_chunks + kHmmSuper - 1) / kHmmSuper;
+        hipLaunchKernelGGL((hmm_super_products_kernel<KT>), dim3((unsigned)n_super), dim3(256), 0, st, h->prod, n_chunks, h->qprod);
+        hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->qprod, K, n_super,
+                           h->fstart_s, h->bend_s, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+        hipLaunchKernelGGL((hmm_boundary_fill_kernel<KT>), dim3((unsigned)n_super), dim3(128), 0, st, h->prod, n_chunks,
+                           h->fstart_s, h->bend_s, h->fstart, h->bend);
+    } else {
+        hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K,
+                           n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+    }
     if (n_chunks > 0) {
         const unsigned grid = (unsigned)((n_chunks + 63) / 64);      // 16 chunks per wave, 4 waves per block
         hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
@@ -117,7 +134,9 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         {&h->gamma_cm, (int64_t)ws->K * h->npad}, {&h->mx, h->npad}, {&h->cprime, h->npad},
         {&h->prod, h->max_chunks * h->Kp * h->Kp}, {&h->fstart, h->max_chunks * h->Kp},
         {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, (h->xi_waves + 4) * h->Kp * h->Kp},
-        {&h->lnc_partial, kLncBlocks}};
+        {&h->lnc_partial, kLncBlocks},
+        {&h->qprod, (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp}, {&h->fstart_s, (h->max_chunks / kHmmSuper + 2) * h->Kp},
+        {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}};
     for (auto& b : bufs) {
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
         if (e != hipSuccess) {

@@ -88,9 +88,11 @@ def test_forward_backward_matches_reference(name):
 
 @pytest.mark.parametrize("K,D,T,dtype", [(3, 2, 1, np.float64), (5, 3, 2, np.float64), (7, 4, 17, np.float32),
                                          (16, 8, 1000, np.float64), (20, 5, 3001, np.float32),
-                                         (33, 6, 777, np.float64), (64, 4, 5000, np.float32), (2, 1, 40000, np.float64)])
+                                         (33, 6, 777, np.float64), (64, 4, 5000, np.float32), (2, 1, 40000, np.float64),
+                                         (8, 4, 300001, np.float32), (33, 3, 270000, np.float64)])
 def test_ragged_shapes_against_oracle(K, D, T, dtype):
-    """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths; random posterior."""
+    """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths - and, past 2^18 steps, the
+    two-level boundary pass (chunks of 256 steps, super-chunk products); random posterior."""
     rng = np.random.default_rng(100 * K + D)
     x, _ = orc.synth_hmm(max(2, K // 2), D, T, dtype, seed=K + T, stay=0.8)
     p = orc.HmmPrior.default(K, D)
