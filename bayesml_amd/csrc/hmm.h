@@ -557,25 +557,34 @@ __global__ __launch_bounds__(256) void hmm_lnc_partial_kernel(const double* __re
 }
 
 // ms[i][j] = a_tilde[i][j] * sum_w slabs[w][pos(i)][pos(j)];  also sum_t (ln c'_t + mx_t), gamma_first/last
-__global__ void hmm_finish_kernel(const double* __restrict__ slabs, int64_t n_waves, const double* __restrict__ a_tilde,
-                                  int K, int Kp, const double* __restrict__ lnc_partial, int n_partial,
-                                  int64_t T, const double* __restrict__ gamma_tm,
-                                  double* __restrict__ out /*[K*K | K | K | 1]*/) {
-    const int tid = threadIdx.x;
-    for (int e = tid; e < K * K; e += blockDim.x) {
+// Entry e of ms = a~ o (sum of the xi slabs): 32 lanes per entry, eight entries per workgroup; fixed summation order.
+__global__ __launch_bounds__(256) void hmm_finish_kernel(const double* __restrict__ slabs, int64_t n_waves,
+                                                         const double* __restrict__ a_tilde, int K, int Kp,
+                                                         const double* __restrict__ lnc_partial, int n_partial, int64_t T,
+                                                         const double* __restrict__ gamma_tm,
+                                                         double* __restrict__ out /*[K*K | K | K | 1]*/) {
+    const int tid = threadIdx.x, sub = tid & 31;
+    const int e = (int)blockIdx.x * 8 + (tid >> 5);
+    double s = 0.0;
+    if (e < K * K) {
         const int i = e / K, j = e - i * K;
-        double s = 0.0;
-        for (int64_t w = 0; w < n_waves; ++w) s += slabs[w * Kp * Kp + hmm_pos(i) * Kp + hmm_pos(j)];
-        out[e] = a_tilde[e] * s;
+        for (int64_t w = sub; w < n_waves; w += 32) s += slabs[w * Kp * Kp + hmm_pos(i) * Kp + hmm_pos(j)];
     }
-    for (int k = tid; k < K; k += blockDim.x) {
-        out[K * K + k] = gamma_tm[hmm_pos(k)];
-        out[K * K + K + k] = gamma_tm[(T - 1) * Kp + hmm_pos(k)];
-    }
-    if (tid == 0) {
-        double s = 0.0;
-        for (int b = 0; b < n_partial; ++b) s += lnc_partial[b];
-        out[K * K + 2 * K] = s;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (e < K * K && sub == 0) out[e] = a_tilde[e] * s;
+    if (blockIdx.x == 0) {
+        for (int k = tid; k < K; k += blockDim.x) {
+            out[K * K + k] = gamma_tm[hmm_pos(k)];
+            out[K * K + K + k] = gamma_tm[(T - 1) * Kp + hmm_pos(k)];
+        }
+        double p = 0.0;
+        for (int b = tid; b < n_partial; b += 256) p += lnc_partial[b];
+        __shared__ double red[4];
+        p = sum_wave(p);
+        if ((tid & 63) == 0) red[tid >> 6] = p;
+        __syncthreads();
+        if (tid == 0) out[K * K + 2 * K] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 

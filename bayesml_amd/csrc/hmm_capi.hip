@@ -103,7 +103,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     const int64_t n_slabs = n_waves > 0 ? ((n_waves + 3) / 4) * 4 : 0;
     const int n_part = (int)std::min<int64_t>(kLncBlocks, (T + 255) / 256);
     hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
-    hipLaunchKernelGGL(hmm_finish_kernel, dim3(1), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
+    hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
                        h->lnc_partial, n_part, T, h->gamma_tm, out);
     hipLaunchKernelGGL(hmm_gamma_to_cm_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0,
                        st, h->gamma_tm, T, K, Kp, ws->npad, h->gamma_cm);
