@@ -68,8 +68,9 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     const int K = h->K, Kp = h->Kp;
     const int64_t L = chunk_len(T);
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
-    hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ws->lnrho, ws->npad, T, K,
-                       Kp, h->rho_tm, h->mx);
+    hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
+                       ((size_t)Kp * (kPrepSteps + 1) + kPrepSteps) * sizeof(double), st, ws->lnrho, ws->npad, T, K, Kp, h->rho_tm,
+                       h->mx);
     if (n_chunks > 0)
         hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
                            h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod);
