@@ -237,3 +237,62 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     assert cached_seen > 0.1 * N, cached_seen       # single-component rows the M-step did not accumulate again
     if variant == "force_settle":       # rows that were not evaluated at all: read out exactly all the same
         assert settled_seen > 0.1 * N, settled_seen
+
+
+@pytest.mark.parametrize("variant", ["force", "force_settle"])
+def test_cache_survives_unusual_call_orders(variant):
+    """The cache of single-component rows is internal state of the workspace: whatever order the entry points are
+    called in - an M-step twice, an E-step twice without an M-step, read-outs between the two - the statistics and
+    the responsibilities stay the oracle's."""
+    from bayesml_amd import _kside
+    from bayesml_amd import gaussianmixture as gm
+    K, D, N = 24, 64, 24000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    x64 = x.astype(np.float64)
+    dev = torch.device("cuda", 0)
+    with env(VARIANTS[variant]):
+        m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
+        eng, xd = m._open(x)
+    prior = m._prior_tensors(dev)
+    q = m._init_subsampling(eng, xd, _kside.post_from_prior(prior), N)
+    s = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
+    ns, x_bar, s, _h = m._pass(eng, xd, q, s)
+
+    def check(ns, s, q):
+        st = orc.data_pass(x64, _oracle_post(q))
+        assert rel_err(ns.cpu().numpy(), st.ns) < 1e-10 and rel_err(s.cpu().numpy(), st.s) < 1e-9
+        return st
+
+    cached = 0.0
+    for it in range(16):
+        q_new = _kside.update_q(prior, ns, x_bar, s)
+        hint = m._drift_hint(eng, xd, q, q_new)
+        q = q_new
+        full = (*hint, float((hint[0] - hint[1] / 30.0).min()))
+        kind = it % 4
+        if kind == 0:           # the ordinary iteration
+            ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=full)
+        elif kind == 1:         # M-step twice on one E-step
+            ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=full)
+            ns2, _xb, s2, _h2 = m._pass(eng, xd, q, s, estep=False)
+            assert torch.equal(ns, ns2) and torch.equal(s, s2)
+        elif kind == 2:         # E-step twice (the first one's M-step never runs), read-outs before the M-step
+            m._give_params(eng, q, full)
+            eng.estep(xd)
+            eng.estep(xd)
+            r = eng.responsibilities().cpu().numpy()
+            ns, x_bar, s, _h = m._pass(eng, xd, q, s, estep=False)
+            st = check(ns, s, q)
+            assert np.max(np.abs(r - st.r)) < 1e-9
+        else:                   # read-outs after the M-step, then the next iteration carries on
+            ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=full)
+            st = check(ns, s, q)
+            assert np.max(np.abs(eng.responsibilities().cpu().numpy() - st.r)) < 1e-9
+            lb = eng.ln_rho().cpu().numpy()
+            same = np.abs(st.ln_rho - lb) <= 1e-8 * np.maximum(1.0, np.abs(st.ln_rho))
+            assert np.all(lb[~same] >= st.ln_rho[~same])
+        check(ns, s, q)
+        wk = eng.work()
+        if wk["accumulated"] >= 0:
+            cached = max(cached, wk["active"] - wk["accumulated"])
+    assert cached > 0.1 * N, cached
