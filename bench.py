@@ -418,7 +418,9 @@ def main():
                 "note": "achieved = algorithmic bytes of the dominant kernel group per step (rows it must read x D x s, "
                         "SURVEY 8d) / its HIP-event time per step; frac <= 1 by construction.  step_hbm_frac = value / "
                         "hbm_roofline_samples_per_s.  f64_mfma_ceiling = the rate at which the f64 matrix pipe alone could "
-                        "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M)"}
+                        "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M).  "
+                        "executed_f64_tflops of estep_gather counts every evaluated pair as a full evaluation: pairs that "
+                        "take the gather's early way out (DESIGN.md 5c) do 10 of the 36 tile pairs, so it is an upper bound"}
         if args.dense or not sparse_e:
             # the dense kernels are MFMA-bound: executed flops against the f64 MFMA peak
             ex = fl_pair * n_local * K

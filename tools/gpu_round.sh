@@ -26,6 +26,9 @@ for stage in "$@"; do
     hmm) timeout 900 python tools/bench_hmm.py > $OUT/${TAG}_hmm_bench_line.json 2> $OUT/${TAG}_hmm.err; tail -c 400 $OUT/${TAG}_hmm.err; head -c 800 $OUT/${TAG}_hmm_bench_line.json; echo ;;
     full) timeout 900 python tools/full_run.py > $OUT/${TAG}_full_run.json 2> $OUT/${TAG}_full.err; tail -c 400 $OUT/${TAG}_full.err; head -c 800 $OUT/${TAG}_full_run.json; echo ;;
     small) timeout 600 python tools/bench_small.py > $OUT/${TAG}_small.json 2> $OUT/${TAG}_small.err; tail -c 300 $OUT/${TAG}_small.err; head -c 900 $OUT/${TAG}_small.json; echo ;;
+    dist) timeout 900 python bench.py --force-dist --no-cpu --no-legs --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_force_dist_torch.json 2> $OUT/${TAG}_dist_torch.err; head -c 400 $OUT/${TAG}_bench_line_force_dist_torch.json; echo
+          timeout 900 python bench.py --force-dist --native-allreduce --no-cpu --no-legs --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_force_dist_native.json 2> $OUT/${TAG}_dist_native.err; head -c 400 $OUT/${TAG}_bench_line_force_dist_native.json; echo ;;
+    hmmtrace) bash tools/trace_hmm.sh $TAG ;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
     *) echo "unknown stage $stage" ;;
   esac
