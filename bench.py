@@ -324,8 +324,11 @@ def main():
     counts0 = eng.pass_counts()
     fence()
     t0 = time.perf_counter()
+    walls = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         vl = w.step()
+        walls.append((time.perf_counter() - ts) * 1e3)
         ker.append(eng.last_kernel_ms())        # events already complete: step() ended with a host sync
         spans.append(eng.kernel_spans())
         launches.append(eng.launch_info)
@@ -453,7 +456,8 @@ def main():
             "roofline": roof, "dense": dense_leg, "hard_workload": hard,
             "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,
             "launch": last_launch, "warmup_steps": warm,
-            "per_step": {"estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
+            "per_step": {"wall_ms": [round(v, 2) for v in walls],
+                         "estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
                          "estep_kernel": [kernel_name(l) for l in launches],
                          "active_components_per_sample": [round(a / n_local, 2) if a >= 0 else None for a, _ in spars],
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars],
