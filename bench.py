@@ -34,6 +34,7 @@ algorithmic bytes of the dominant kernel group per launch (rows it has to read x
 time; ``step_hbm_frac`` = the whole step's N D s bytes / step time / 8 TB/s (= value / HBM-roofline samples/s).
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -324,6 +325,11 @@ def main():
 
     ker, launches, spars, spans, works = [], [], [], [], []
     counts0 = eng.pass_counts()
+    # A full collection of Python's garbage collector inside the timed steps is a 40-70 ms host stall once
+    # torch.distributed has been imported and initialised (measured: always the same step, profiles/r2_experiments.md):
+    # collect now and move what is alive to the permanent generation.
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
     walls = []
