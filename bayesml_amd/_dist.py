@@ -15,14 +15,17 @@ import torch.distributed as dist
 class RowShard:
     """Describes which rows of the global sample matrix this process holds."""
 
-    def __init__(self, group=None, native: bool = False):
-        """``native=True``: the per-iteration all-reduce of the statistics block goes through the library's own RCCL
+    def __init__(self, group=None, native: bool = False, always: bool = False):
+        """``always=True``: issue the collective even in a group of one rank (bench.py --force-dist exercises the RCCL
+        path that way).
+        ``native=True``: the per-iteration all-reduce of the statistics block goes through the library's own RCCL
         communicator (C ABI ``gmmvb_allreduce_stats``, bootstrapped over the process group) instead of
         ``torch.distributed.all_reduce``; everything else (row counts, sub-sample moments) stays on the group."""
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
         self.group = group
         self.native = native
+        self.always = always
         self._rccl = None
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -48,7 +51,7 @@ class RowShard:
                 from ._engine import RcclComm
                 self._rccl = RcclComm(self.rank, self.world, t.device)
             return self._rccl.all_reduce_(t)
-        if self.world > 1:
+        if self.world > 1 or self.always:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 

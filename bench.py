@@ -278,7 +278,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
-        comm = RowShard(native=args.native_allreduce)
+        comm = RowShard(native=args.native_allreduce, always=args.force_dist)
         # every rank contributes 1: proves the RCCL group really spans `world` processes
         one = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(one)
