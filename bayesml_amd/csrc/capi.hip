@@ -1222,7 +1222,14 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
         }
         span_begin(ws, kSpanMstepMain, st);
-        e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
+        if (ws->T == 1 && pre && std::getenv("GMMVB_MSTEP_SMALL_OFF") == nullptr) {
+            // one feature tile: a wave walks the rows once for eight components (mstep.h, mstep_small_f64)
+            const int KGW = (ws->K + mstep_small_components_per_wg() - 1) / mstep_small_components_per_wg();
+            grid = 8 * ((S + 7) / 8) * KGW;
+            e = launch_mstep_small((int)grid, st, a, KGW, &name);
+        } else {
+            e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
+        }
         span_end(ws, st);
     }
     if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);

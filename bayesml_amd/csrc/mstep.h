@@ -259,6 +259,92 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
     }
 }
 
+// ---- one feature tile (D <= 16): many components per wave ----------------------------------------------------------
+// With T = 1 a component's whole second moment is ONE 16 x 16 accumulator tile, and a step of mstep_body is a row load,
+// a shuffle, two multiplies and one MFMA: the kernel above spends its time issuing the loop, re-reading the rows once per
+// component group (HMM config 5, K = 32, D = 16: 8.3 ms for 1 ms of MFMA work).  Here a wave keeps CW components'
+// tiles and walks the rows ONCE for all of them; the four waves of a workgroup take 4 CW consecutive components over the
+// same rows.  Same operations per component in the same order as mstep_body<1, ...> (bit-identical slabs), same slab
+// layout, same reduce.  Rows come from the centred f64 copy ([npad + 64][16], zero padded).
+template <int CW>
+__global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict__ xc, int64_t n_rows,
+                                                       const double* __restrict__ lnrho, const double* __restrict__ lse,
+                                                       const double* __restrict__ aux, int64_t npad, int K, int KGW, int S,
+                                                       int64_t rows_per_split, int direct_r,
+                                                       double* __restrict__ slabs /*[S][K][slab_len(1)]*/) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int kgw = j % KGW;
+    const int split = (j / KGW) * 8 + xcd;
+    if (split >= S) return;
+    const int k0 = (kgw * 4 + wave) * CW;
+    if (k0 >= K) return;
+    const int64_t lo = (int64_t)split * rows_per_split;
+    int64_t hi = lo + rows_per_split;
+    if (hi > n_rows) hi = n_rows;
+    d4 acc[CW];
+    double asum[CW], nsum[CW], hsum[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+        asum[c] = nsum[c] = hsum[c] = 0.0;
+    }
+    double xn = xc[(lo + g) * 16 + i];
+    for (int64_t c0 = lo; c0 < hi; c0 += 64) {
+        const int64_t nl = c0 + lane;
+        double r_l[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const int k = k0 + c;
+            double r = 0.0;
+            if (k < K && nl < hi) {
+                const double v = lnrho[(int64_t)k * npad + nl];
+                if (direct_r == 2) {                 // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
+                    r = v;
+                    if (v > 0.0) hsum[c] = fma(v, aux[(int64_t)k * npad + nl], hsum[c]);
+                } else if (direct_r) {
+                    r = v;
+                    if (v > 0.0) hsum[c] = fma(v, log(v), hsum[c]);
+                } else {
+                    const double t = v - lse[nl];
+                    r = exp(t);
+                    hsum[c] = fma(r, t, hsum[c]);
+                }
+                nsum[c] += r;
+            }
+            r_l[c] = r;
+        }
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {
+            const double xq = xn;
+            xn = xc[(c0 + 4 * (st + 1) + g) * 16 + i];          // (zero rows up to npad + 64: no clamp)
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const double ra = __shfl(r_l[c], 4 * st + g) * xq;
+                asum[c] += ra;
+                acc[c] = mfma_f64(ra, xq, acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const int k = k0 + c;
+        if (k >= K) break;
+        double* out = slabs + ((int64_t)split * K + k) * slab_len(1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r * 64 + lane] = acc[c][r];
+        const double a = sum_groups(asum[c]);
+        if (g == 0) out[256 + i] = a;
+        const double n = sum_wave(nsum[c]), h = sum_wave(hsum[c]);
+        if (lane == 0) {
+            out[256 + 16 + 0] = n;
+            out[256 + 16 + 1] = h;
+        }
+    }
+}
+
 // ---- sparse responsibilities ---------------------------------------------------------------------------------
 // After the first VB iterations most responsibilities are negligible: a sample belongs to a handful of the K
 // components.  A term with r_nk < 2^-100 max_n r_nk cannot change any of component k's f64 sums (there are fewer

@@ -15,6 +15,15 @@ static hipError_t go(int grid, hipStream_t st, const MstepArgs& a) {
     return hipGetLastError();
 }
 
+// one feature tile, rows from the centred copy: eight components per wave (mstep_small_f64)
+int mstep_small_components_per_wg() { return 4 * 8; }
+hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const char** name) {
+    *name = "mstep_small_f64<T=1,8 components per wave,centred-f64>";
+    hipLaunchKernelGGL((mstep_small_f64<8>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(a.x), a.n_rows, a.lnrho,
+                       a.lse, a.aux, a.npad, a.K, KGW, a.S, a.rows_per_split, a.direct_r, a.slabs);
+    return hipGetLastError();
+}
+
 int mstep_components_per_wg(int T, bool pre) { return mstep_waves(T, pre) / mstep_ws(T); }
 int mstep_threads(int T, bool pre) { return 64 * mstep_waves(T, pre); }
 
