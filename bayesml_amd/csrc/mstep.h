@@ -320,15 +320,9 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
         for (int st = 0; st < 16; ++st) {
             const double xq = xn;
             xn = xc[(c0 + 4 * (st + 1) + g) * 16 + i];          // (zero rows up to npad + 64: no clamp)
-            const int64_t row = c0 + 4 * st + g;
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
-                // the sample's weight: read again (the batch's 512 bytes per component are in L1) when it is stored as
-                // such, shuffled out of the lane that formed it otherwise
-                double rr;
-                if (direct_r) rr = (k0 + c < K && row < hi) ? lnrho[(int64_t)(k0 + c) * npad + row] : 0.0;
-                else rr = __shfl(r_l[c], 4 * st + g);
-                const double ra = rr * xq;
+                const double ra = __shfl(r_l[c], 4 * st + g) * xq;
                 asum[c] += ra;
                 acc[c] = mfma_f64(ra, xq, acc[c]);
             }
