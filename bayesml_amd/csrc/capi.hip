@@ -86,7 +86,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     }
     // row splits of the dense M-step: ~4 workgroups per CU; with a single feature tile a step is a row load and one
     // MFMA - latency, not arithmetic - so many more, shorter, splits (HMM config 5)
-    ws->S_cap = (int)round_up(((int64_t)(ws->T == 1 ? 64 : 4) * ws->num_cu + ws->KG - 1) / ws->KG, 8);
+    ws->S_cap = (int)round_up(((int64_t)(ws->T == 1 ? 16 : 4) * ws->num_cu + ws->KG - 1) / ws->KG, 8);
     if (ws->S_cap < 8) ws->S_cap = 8;
     {
         // Cap on the rows of one M-step split: 16 MB of centred rows (16384 rows at D = 128).  All component groups
