@@ -291,17 +291,9 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
         acc[c] = d4{0.0, 0.0, 0.0, 0.0};
         asum[c] = nsum[c] = hsum[c] = 0.0;
     }
-    // the 16 steps' rows of a batch are requested a whole batch ahead (a step is ~300 cycles of issue: one step of
-    // lead does not cover a memory round trip)
-    double xb[16];
-#pragma unroll
-    for (int st = 0; st < 16; ++st) xb[st] = xc[(lo + 4 * st + g) * 16 + i];
+    double xn = xc[(lo + g) * 16 + i];
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         const int64_t nl = c0 + lane;
-        double xnext[16];
-        const bool more = c0 + 64 < hi;
-#pragma unroll
-        for (int st = 0; st < 16; ++st) xnext[st] = more ? xc[(c0 + 64 + 4 * st + g) * 16 + i] : 0.0;
         double r_l[CW];
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
@@ -324,9 +316,10 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
             }
             r_l[c] = r;
         }
-#pragma unroll
+#pragma unroll 4
         for (int st = 0; st < 16; ++st) {
-            const double xq = xb[st];
+            const double xq = xn;
+            xn = xc[(c0 + 4 * (st + 1) + g) * 16 + i];          // (zero rows up to npad + 64: no clamp)
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const double ra = __shfl(r_l[c], 4 * st + g) * xq;
@@ -334,8 +327,6 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
                 acc[c] = mfma_f64(ra, xq, acc[c]);
             }
         }
-#pragma unroll
-        for (int st = 0; st < 16; ++st) xb[st] = xnext[st];
     }
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
