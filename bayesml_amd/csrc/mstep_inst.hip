@@ -17,10 +17,10 @@ static hipError_t go(int grid, hipStream_t st, const MstepArgs& a) {
     return hipGetLastError();
 }
 
-// one feature tile, rows from the centred copy: CW components per wave (mstep_small_f64); env GMMVB_MSTEP_SMALL_CW = 4 | 8
+// one feature tile, rows from the centred copy: CW components per wave (mstep_small_f64); env GMMVB_MSTEP_SMALL_CW = 4 (default 8: 5.1 against 5.4 ms at HMM config 5)
 static int small_cw() {
     const char* v = std::getenv("GMMVB_MSTEP_SMALL_CW");
-    return (v && std::atoi(v) == 8) ? 8 : 4;
+    return (v && std::atoi(v) == 4) ? 4 : 8;
 }
 int mstep_small_components_per_wg() { return 4 * small_cw(); }
 hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const char** name) {
