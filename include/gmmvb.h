@@ -94,7 +94,12 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
 int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_t n_rows, void* stream);
 
 /* M-step statistics for the responsibilities currently in the workspace (replaces
- * _gaussianmixture.py:725-732 and the N-sized term of :704).  stats_dev: gmmvb_stats_len doubles. */
+ * _gaussianmixture.py:725-732 and the N-sized term of :704).  stats_dev: gmmvb_stats_len doubles.
+ * After a pruned E-step the sums run over per-component lists, and rows with a single active component (r = 1.0 exactly:
+ * their addend does not depend on the parameters) are kept in a cache inside the workspace that only changes through the
+ * rows entering or leaving it; the result is the same sum.  The cache follows the E-step / M-step alternation of one
+ * sample matrix: any other call order is legal (a second gmmvb_mstep returns the same block, an E-step without an M-step
+ * drops the cache) but a pass's first gmmvb_mstep must see the (x_dev, ldx, n_rows) of its gmmvb_estep. */
 int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, double* stats_dev,
                 void* stream);
 
