@@ -22,14 +22,17 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_GAMMA",
-            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE")
+            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE", "GMMVB_SETTLE_I8", "GMMVB_SETTLE_MARGIN_I8", "GMMVB_GATHER_EXIT")
 VARIANTS = {
     "default": {},
     # rows with a single active component are settled (left out of the E-step on the strength of their carried bounds)
     # whatever the drift, with 10 nats of slack instead of 30: the read-outs below need their values re-evaluated
     "settle": {"GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10"},
     "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10"},
+    # ... with their reference bound re-evaluated every pass on the int8 pipe (estep_i8_pairs) instead of carried
+    "force_settle_i8": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_I8": "1", "GMMVB_SETTLE_MARGIN_I8": "0"},
     "nocache": {"GMMVB_MSTEP_CACHE": "0"},
+    "noexit": {"GMMVB_GATHER_EXIT": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
     "force_nocarry": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_CARRY_OFF": "1"},
     "dense": {"GMMVB_ESTEP_PRUNE": "0", "GMMVB_MSTEP_SPARSE": "0"},
@@ -88,7 +91,7 @@ def expect_kernels(counts, variant, min_carried=1, lists=True):
         assert counts["mstep_list"] >= 1, counts
     if variant == "force_nocarry":
         assert counts["estep_carried"] == counts["estep_sweep"] == 0, counts
-    elif variant in ("settle", "force_settle"):
+    elif variant in ("settle", "force_settle", "force_settle_i8"):
         assert counts["estep_sweep"] >= 2, counts
     else:       # carried over the parameter update: on per-row records, or (early in a fit) by a sweep of the dense array
         assert counts["estep_carried"] + counts["estep_sweep"] >= min_carried, counts
@@ -113,6 +116,7 @@ def test_small_fixture_forced_sparse_matches_reference(variant):
 
 LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n140000_f32.npz", "force_nocarry"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
          ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "dense")]
@@ -148,7 +152,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if "overlap" not in name and variant in ("default", "settle", "nocache"):
+    if "overlap" not in name and variant in ("default", "settle", "nocache", "noexit"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -186,7 +190,7 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_i8"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
@@ -235,11 +239,11 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         checked += 1
     assert checked >= 3, eng.pass_counts()
     assert cached_seen > 0.1 * N, cached_seen       # single-component rows the M-step did not accumulate again
-    if variant == "force_settle":       # rows that were not evaluated at all: read out exactly all the same
+    if variant in ("force_settle", "force_settle_i8"):       # rows that were not evaluated at all: read out exactly all the same
         assert settled_seen > 0.1 * N, settled_seen
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_i8"])
 def test_cache_survives_unusual_call_orders(variant):
     """The cache of single-component rows is internal state of the workspace: whatever order the entry points are
     called in - an M-step twice, an E-step twice without an M-step, read-outs between the two - the statistics and
