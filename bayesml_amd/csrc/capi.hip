@@ -1267,12 +1267,7 @@ static int refresh_settled(gmmvb_workspace* ws, hipStream_t st) {
     if (!ws->params_used) return fail(GMMVB_ESTATE, "the parameters changed after the E-step whose settled rows are read");
     const int64_t n_rows = ws->e_rows;
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
-    const int words = (ws->K + 63) / 64;
-    if (!ws->rmask) {
-        hipError_t em = hipMalloc((void**)&ws->rmask, (size_t)words * ws->npad * sizeof(unsigned long long));
-        if (em == hipSuccess) em = hipMalloc((void**)&ws->rblk, (size_t)((ws->npad + kSelRows - 1) / kSelRows) * ws->K * sizeof(int));
-        if (em != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (settled-row read-out)", em);
-    }
+    if (!ws->rmask || !ws->rblk) return fail(GMMVB_ESTATE, "the list buffers of the pruned E-step are not allocated");
     const int is64 = ws->x_dtype == GMMVB_F64;
     bool vec = false;
     int rc = check_x(ws, ws->bounds_x, ws->bounds_ldx, n_rows, &vec);
