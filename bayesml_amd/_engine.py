@@ -311,9 +311,10 @@ class DataPass:
     def work(self) -> dict:
         """Pairs of the last E-step (gmmvb_last_work): active, evaluated exactly, accumulated by the list M-step, and the
         rows the E-step did not evaluate at all (settled)."""
-        out = (ctypes.c_double * 4)()
+        out = (ctypes.c_double * 5)()
         _check(self.lib, self.lib.gmmvb_last_work(self._ws, out), "gmmvb_last_work")
-        return dict(active=float(out[0]), evaluated=float(out[1]), accumulated=float(out[2]), settled_rows=float(out[3]))
+        return dict(active=float(out[0]), evaluated=float(out[1]), accumulated=float(out[2]), settled_rows=float(out[3]),
+                    early_exits=float(out[4]))
 
     def profile(self, on: bool = True):
         _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")

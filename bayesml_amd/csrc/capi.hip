@@ -201,11 +201,12 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
-                     ws->lock, ws->lcomp, ws->dlock, ws->rthr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
+                     ws->lock, ws->lcomp, ws->dlock, ws->rthr, ws->exit_ctr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
                      ws->rmask, ws->rblk};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
+    if (ws->exit_host) (void)hipHostFree(ws->exit_host);
     if (ws->ctr_ev) (void)hipEventDestroy(ws->ctr_ev);
     for (int* p : ibufs)
         if (p) (void)hipFree(p);
@@ -410,6 +411,10 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->lcomp, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dlock, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rthr, (size_t)np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->exit_ctr, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ws->exit_ctr, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->exit_host, sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) *ws->exit_host = 0;
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mmask, (size_t)words * np * sizeof(unsigned long long));
@@ -458,7 +463,9 @@ static int fetch_counters(gmmvb_workspace* ws) {
             ws->lag_over = 0.0;
             ws->lag_settled = 0.0;
             ws->lag_listed = ws->lag_accum = ws->lag_act;
+            ws->lag_exits = 0.0;
         } else {
+            ws->lag_exits = (ws->exit_host && ws->gather_exit) ? (double)*ws->exit_host : 0.0;
             ws->lag_settled = ws->ctr_host[4];
             ws->lag_listed = ws->ctr_host[5];
             ws->lag_accum = ws->ctr_host[6];                               // a bound pass / sweep also evaluated every row's (previous) best component
@@ -503,6 +510,7 @@ int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
     out[1] = ws->lag_mode == 0 ? (double)ws->e_rows * ws->K : ws->lag_eval;
     out[2] = counted ? ws->lag_accum : -1.0;
     out[3] = ws->lag_mode == 0 ? 0.0 : ws->lag_settled;
+    out[4] = ws->lag_mode == 0 ? 0.0 : ws->lag_exits;
     return GMMVB_OK;
 }
 
@@ -619,6 +627,7 @@ static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepArgs& a, con
 // masks -> per-component lists -> chunk plan -> exact f64 evaluation of the listed pairs (all sized on the device)
 static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int is64, bool vec, int sel_grid, hipStream_t st,
                                    const float* thr = nullptr) {
+    if (thr) (void)hipMemsetAsync(ws->exit_ctr, 0, sizeof(unsigned long long), st);
     span_begin(ws, kSpanSelect, st);
     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, a.n_rows, ws->K, ws->blk,
@@ -629,7 +638,8 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     span_end(ws, st);
     if (e != hipSuccess) return e;
     span_begin(ws, kSpanGather, st);
-    e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan, thr);
+    e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan, thr,
+                                thr ? ws->exit_ctr : nullptr);
     span_end(ws, st);
     ++ws->passes[7];
     return e;
@@ -1003,6 +1013,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // counters -> pinned host memory, behind an event (read by the next pass, or by gmmvb_last_sparsity)
     if (counted) {
         e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 8 * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && ws->exit_ctr && mode != kDense)
+            e = hipMemcpyAsync(ws->exit_host, ws->exit_ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(ws->ctr_ev, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step counters", e);
         ws->ctr_pending = true;

@@ -133,7 +133,7 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB
 // array treats a stored value below thr[row] as a bound (records.h, rec_finish_kernel).  Pairs that are evaluated in
 // full go through exactly the same operations as in estep_component.
 template <int NB, typename XT, int JB, int J1, int BOFF, typename ImgPtr>
-__device__ __forceinline__ void estep_component_exit(ImgPtr im, const XT (&xr)[NB][JB][4], double ck, int lane, int g,
+__device__ __forceinline__ bool estep_component_exit(ImgPtr im, const XT (&xr)[NB][JB][4], double ck, int lane, int g,
                                                      const int64_t (&rows)[NB], double* __restrict__ lnrho_k,
                                                      const float* __restrict__ thr) {
     static_assert(J1 >= 1 && J1 < JB, "the way out lies strictly inside the block loop");
@@ -186,7 +186,7 @@ __device__ __forceinline__ void estep_component_exit(ImgPtr im, const XT (&xr)[N
             const double qs = sum_groups(q[nb]);
             if (g == 0 && rows[nb] >= 0) lnrho_k[rows[nb]] = ck - 0.5 * qs;
         }
-        return;
+        return true;                   // (the whole wave tile took the way out)
     }
     blocks(std::integral_constant<int, J1>{}, std::integral_constant<int, JB>{});
 #pragma unroll
@@ -200,6 +200,7 @@ __device__ __forceinline__ void estep_component_exit(ImgPtr im, const XT (&xr)[N
         qq = sum_groups(qq);
         if (g == 0 && rows[nb] >= 0) lnrho_k[rows[nb]] = ck - 0.5 * qq;
     }
+    return false;
 }
 
 // ---- variant without LDS -------------------------------------------------------------------
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
                                                             const int* __restrict__ counts /*[K]*/,
                                                             const int* __restrict__ plan /*[K + 1]*/,
                                                             double* __restrict__ lnrho, int64_t npad,
-                                                            const float* __restrict__ thr) {
+                                                            const float* __restrict__ thr,
+                                                            unsigned long long* __restrict__ exits /*pairs that took the way out*/) {
     constexpr int NW = 8;
     constexpr int NB = estep_nb_w<XT>(T, NW);
     constexpr int IMG = img_doubles(T);
@@ -436,9 +438,13 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
             }
             XT xr[NB][T][4];
             load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
-            if constexpr (EXIT)
-                estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr);
-            else
+            if constexpr (EXIT) {
+                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr) &&
+                    lane == 0) {
+                    const int64_t left = count - e0;           // (statistics only: an integer counter, order-free)
+                    atomicAdd(exits, (unsigned long long)(left < 16 * NB ? left : 16 * NB));
+                }
+            } else
                 estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
         }
     }

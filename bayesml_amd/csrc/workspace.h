@@ -106,6 +106,9 @@ struct gmmvb_workspace {
     unsigned char* lcomp = nullptr;    // [npad] cached rows: the component whose cache holds the row (K <= 256)
     float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
     float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 100 ln 2)
+    unsigned long long* exit_ctr = nullptr;    // [1] device: candidate pairs of the pass that took the gather's early way out
+    unsigned long long* exit_host = nullptr;   // [1] pinned mirror (copied with the other counters)
+    double lag_exits = 0.0;
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
     int* dblk = nullptr;               // [K][blocks] their block counts
     unsigned long long* mmask = nullptr;   // [ceil(K / 64)][npad] the M-step's lists: active pairs of the rows not in the cache

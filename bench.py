@@ -369,6 +369,7 @@ def main():
         # did not change (their addends sit in the workspace's cache), plus the rows entering / leaving that cache
         acc = float(np.mean([wk["accumulated"] if wk["accumulated"] >= 0 else n_local * K for wk in works]))
         settled = float(np.mean([wk["settled_rows"] for wk in works]))
+        exits = float(np.mean([wk["early_exits"] for wk in works]))      # candidates that stopped after T/2 output blocks
         timed_counts = {k: counts1[k] - counts0[k] for k in counts1}
         m_sparse = timed_counts["mstep_list"] > 0
         # ---- per kernel group: mean HIP-event ms per step, algorithmic bytes per step (rows the group must read x D x s)
@@ -387,7 +388,9 @@ def main():
                 groups[g]["algorithmic_bytes"] = b
                 groups[g]["algorithmic_GBps"] = b / (groups[g]["ms"] * 1e-3) / 1e9
         if groups.get("estep_gather", {}).get("ms", 0) > 0:
-            groups["estep_gather"]["executed_f64_tflops"] = fl_pair * ev / groups["estep_gather"]["ms"] / 1e9
+            half = (tiles // 2) * (tiles // 2 + 1) // 2            # tile pairs of the first T/2 output blocks
+            done = ev - exits * (1.0 - half / (tiles * (tiles + 1) // 2)) if tiles >= 2 else ev
+            groups["estep_gather"]["executed_f64_tflops"] = fl_pair * done / groups["estep_gather"]["ms"] / 1e9
         if "mstep_main" in groups:
             groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (acc if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
         cand = [g for g in ("estep_main", "estep_gather", "mstep_main") if g in groups and "algorithmic_GBps" in groups[g]]
@@ -420,7 +423,8 @@ def main():
                 "f64_mfma_ceiling_samples_per_s": (PEAK_F64_MFMA_TFLOPS * 1e12 / (fl_pair * (ev + acc) / n_local)
                                                    if (ev + acc) > 0 else None),
                 "pairs_per_sample": {"active": ac / n_local, "evaluated_exactly": ev / n_local,
-                                     "accumulated_by_mstep": acc / n_local, "settled_rows": settled / n_local},
+                                     "accumulated_by_mstep": acc / n_local, "settled_rows": settled / n_local,
+                                     "early_exits": exits / n_local},
                 "kernel_groups": groups,
                 "events_ms_per_step": sum(g["ms"] for g in groups.values()),
                 "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
@@ -430,8 +434,8 @@ def main():
                         "SURVEY 8d) / its HIP-event time per step; frac <= 1 by construction.  step_hbm_frac = value / "
                         "hbm_roofline_samples_per_s.  f64_mfma_ceiling = the rate at which the f64 matrix pipe alone could "
                         "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M).  "
-                        "executed_f64_tflops of estep_gather counts every evaluated pair as a full evaluation: pairs that "
-                        "take the gather's early way out (DESIGN.md 5c) do 10 of the 36 tile pairs, so it is an upper bound"}
+                        "executed_f64_tflops of estep_gather charges the pairs that take the gather's early way out "
+                        "(DESIGN.md 5c; pairs_per_sample.early_exits) with the tile pairs they really do"}
         if args.dense or not sparse_e:
             # the dense kernels are MFMA-bound: executed flops against the f64 MFMA peak
             ex = fl_pair * n_local * K

@@ -270,8 +270,10 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
 /* The same (blocking) with the work the pass left for the M-step.  out[0] active pairs (r >= 2^-100; -1: not counted),
  * out[1] pairs the E-step evaluated exactly, out[2] pairs the list M-step accumulates (rows whose single component has
  * r = 1.0 exactly keep their addend in a cache and are only touched when that changes; -1: not counted), out[3] rows the
- * E-step did not evaluate at all (settled: their carried bounds prove that nothing changed). */
-int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[4], host*/);
+ * E-step did not evaluate at all (settled: their carried bounds prove that nothing changed), out[4] of the pairs in
+ * out[1], those whose evaluation stopped after half of the output blocks because the partial sum already put them below
+ * the row's relevance threshold (they cost 10 of the 36 tile pairs at D = 128). */
+int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[5], host*/);
 
 #ifdef __cplusplus
 }
