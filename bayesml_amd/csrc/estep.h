@@ -408,6 +408,7 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
     const int c0 = (int)blockIdx.x * per;
     const int c1 = c0 + per < total ? c0 + per : total;
     int k = 0, kcur = -1;
+    unsigned long long my_exits = 0;                     // pairs of this wave that took the early way out (statistics)
     for (int c = c0; c < c1; ++c) {
         while (s_first[k + 1] <= c) ++k;                 // component of chunk c (empty components are skipped)
         if (k != kcur) {
@@ -439,15 +440,16 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
             XT xr[NB][T][4];
             load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
             if constexpr (EXIT) {
-                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr) &&
-                    lane == 0) {
-                    const int64_t left = count - e0;           // (statistics only: an integer counter, order-free)
-                    atomicAdd(exits, (unsigned long long)(left < 16 * NB ? left : 16 * NB));
+                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr)) {
+                    const int64_t left = count - e0;
+                    my_exits += (unsigned long long)(left < 16 * NB ? left : 16 * NB);
                 }
             } else
                 estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
         }
     }
+    // one atomic per wave (an integer counter: order-free; one per exit would serialise 5e5 of them on one address)
+    if (EXIT && lane == 0 && my_exits != 0ull) atomicAdd(exits, my_exits);
 }
 
 }  // namespace gmmvb
