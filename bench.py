@@ -284,8 +284,6 @@ def main():
         dist.all_reduce(one)
         rccl_ranks = int(one.item())
         assert rccl_ranks == world
-        if os.environ.get("BENCH_DIST_SETTLE_S"):          # experiment: let the process group's start-up work finish
-            time.sleep(float(os.environ["BENCH_DIST_SETTLE_S"]))
 
     cfg = CONFIGS[args.config]
     K = args.classes or cfg["classes"]
