@@ -144,6 +144,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->settle_margin_i8 = std::atof(v);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
+        v = std::getenv("GMMVB_EXIT_MARGIN");                      // nats the partial bound must lie below the threshold
+        if (v) ws->exit_margin = (float)std::atof(v);
         v = std::getenv("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
     }
@@ -639,7 +641,7 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     if (e != hipSuccess) return e;
     span_begin(ws, kSpanGather, st);
     e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan, thr,
-                                thr ? ws->exit_ctr : nullptr);
+                                thr ? ws->exit_ctr : nullptr, ws->exit_margin);
     span_end(ws, st);
     ++ws->passes[7];
     return e;

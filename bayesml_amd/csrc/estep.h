@@ -135,13 +135,13 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB
 template <int NB, typename XT, int JB, int J1, int BOFF, typename ImgPtr>
 __device__ __forceinline__ bool estep_component_exit(ImgPtr im, const XT (&xr)[NB][JB][4], double ck, int lane, int g,
                                                      const int64_t (&rows)[NB], double* __restrict__ lnrho_k,
-                                                     const float* __restrict__ thr) {
+                                                     const float* __restrict__ thr, float margin) {
     static_assert(J1 >= 1 && J1 < JB, "the way out lies strictly inside the block loop");
     constexpr int P = BOFF / 256;
     typedef double d2 __attribute__((ext_vector_type(2)));
     float th[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) th[nb] = rows[nb] >= 0 ? thr[rows[nb]] : __builtin_huge_valf();
+    for (int nb = 0; nb < NB; ++nb) th[nb] = rows[nb] >= 0 ? thr[rows[nb]] - margin : __builtin_huge_valf();
     d4 acc[JB][NB];
 #pragma unroll
     for (int jt = 0; jt < JB; ++jt) {
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
                                                             const int* __restrict__ plan /*[K + 1]*/,
                                                             double* __restrict__ lnrho, int64_t npad,
                                                             const float* __restrict__ thr,
-                                                            unsigned long long* __restrict__ exits /*pairs that took the way out*/) {
+                                                            unsigned long long* __restrict__ exits /*pairs that took the way out*/,
+                                                            float exit_margin /*nats the partial bound must lie below thr*/) {
     constexpr int NW = 8;
     constexpr int NB = estep_nb_w<XT>(T, NW);
     constexpr int IMG = img_doubles(T);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
             XT xr[NB][T][4];
             load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
             if constexpr (EXIT) {
-                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr)) {
+                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr, exit_margin)) {
                     const int64_t left = count - e0;
                     my_exits += (unsigned long long)(left < 16 * NB ? left : 16 * NB);
                 }
