@@ -138,6 +138,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->settle_margin = std::atof(v);
         v = std::getenv("GMMVB_SETTLE_GAMMA");
         if (v) ws->settle_gamma = std::atof(v);
+        v = std::getenv("GMMVB_SETTLE_SPARE");
+        if (v) ws->settle_spare = std::atof(v);
         v = std::getenv("GMMVB_SETTLE_I8");                        // "1": int8 reference bounds for settled rows (slower at C3)
         ws->settle_i8 = v && std::strcmp(v, "1") == 0;
         v = std::getenv("GMMVB_SETTLE_MARGIN_I8");
@@ -758,9 +760,21 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // (three int8 digits, estep_i8_pairs) - or, without that, only while the parameters move little (the bound is then
     // carried through Gamma and delta and erodes quickly otherwise).
     const bool i8_ref = settle && ws->settle_i8 && ws->img_i8b != nullptr && ws->settle_margin_i8 >= 0.0;
+    // (measured at C3, profiles/r2_experiments.md: settling while the components still move by per cents makes the rows
+    // come loose in masses against weak thresholds - 14.1 instead of 12.9 ms per step over iterations 6-25 - whereas from
+    // iteration ~15 on it takes the E-step from 5.2 to 3.7 ms: hence a gate with hysteresis on the drift summary and on
+    // the spare candidates of the last sweep)
+    if (mode != kSweep) {
+        ws->settle_on = false;
+    } else if (!ws->settle_on) {
+        ws->settle_on = ws->typical_gamma >= ws->settle_gamma && known && ws->lag_mode == kSweep &&
+                        std::max(0.0, ws->lag_eval - (ws->lag_act - ws->lag_settled)) <= ws->settle_spare * (double)n_rows;
+    } else if (ws->typical_gamma > 0.0 && ws->typical_gamma < ws->settle_gamma - 0.05) {
+        ws->settle_on = false;
+    }
     const double skip_margin = !settle ? -1.0
                                : (i8_ref ? ws->settle_margin_i8
-                                         : ((ws->settle_margin >= 0.0 && ws->typical_gamma >= ws->settle_gamma) ? ws->settle_margin : -1.0));
+                                         : ((ws->settle_margin >= 0.0 && ws->settle_on) ? ws->settle_margin : -1.0));
     ws->settled_fresh = false;
     if (std::getenv("GMMVB_DEBUG"))
         std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",

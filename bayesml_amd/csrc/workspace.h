@@ -124,8 +124,11 @@ struct gmmvb_workspace {
     bool skip_used = false;            // some pass since the cache was last emptied was allowed to settle rows
     bool lock_reset = false;           // the settled state belongs to something else now: drop it at the next E-step
     bool settled_fresh = false;        // read-outs: the settled rows' ln rho / lse were re-evaluated for the parameters in force
-    double settle_margin = 30.0;       // nats of slack demanded before a row is settled (< 0: never settle)
-    double settle_gamma = 0.98;        // ... and only while the caller's drift summary (typical_gamma) is at least this
+    double settle_margin = 5.0;        // nats of slack demanded before a row is settled (< 0: never settle)
+    double settle_gamma = 0.85;        // settling starts when the caller's drift summary (typical_gamma) reaches this ...
+    double settle_spare = 0.6;         // ... and the last sweep left at most this many spare candidates per row;
+    bool settle_on = false;            // it then stays on until the summary falls below settle_gamma - 0.05 or a pass
+                                       // other than a sweep comes (the regime where carried reference bounds hold)
     bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows
     bool gather_exit = true;           // env GMMVB_GATHER_EXIT=0: no early way out in the candidate gather
     float exit_margin = 0.0f;          // env GMMVB_EXIT_MARGIN: nats a partial bound must lie below the row's threshold
