@@ -126,7 +126,7 @@ struct gmmvb_workspace {
     bool settled_fresh = false;        // read-outs: the settled rows' ln rho / lse were re-evaluated for the parameters in force
     double settle_margin = 5.0;        // nats of slack demanded before a row is settled (< 0: never settle)
     double settle_gamma = 0.85;        // settling starts when the caller's drift summary (typical_gamma) reaches this ...
-    double settle_spare = 0.6;         // ... and the last sweep left at most this many spare candidates per row;
+    double settle_spare = 1.0;         // ... and the last sweep left at most this many spare candidates per row;
     bool settle_on = false;            // it then stays on until the summary falls below settle_gamma - 0.05 or a pass
                                        // other than a sweep comes (the regime where carried reference bounds hold)
     bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows

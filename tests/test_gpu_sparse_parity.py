@@ -22,13 +22,16 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_GAMMA",
-            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE", "GMMVB_SETTLE_I8", "GMMVB_SETTLE_MARGIN_I8", "GMMVB_GATHER_EXIT")
+            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE", "GMMVB_SETTLE_I8", "GMMVB_SETTLE_MARGIN_I8", "GMMVB_GATHER_EXIT",
+            "GMMVB_SETTLE_SPARE")
 VARIANTS = {
     "default": {},
     # rows with a single active component are settled (left out of the E-step on the strength of their carried bounds)
-    # whatever the drift, with 10 nats of slack instead of 30: the read-outs below need their values re-evaluated
-    "settle": {"GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10"},
-    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10"},
+    # whatever the drift and the spare candidates of the last sweep, with 10 nats of slack: the read-outs below need
+    # their values re-evaluated
+    "settle": {"GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
+    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10",
+                     "GMMVB_SETTLE_SPARE": "1000"},
     # ... with their reference bound re-evaluated every pass on the int8 pipe (estep_i8_pairs) instead of carried
     "force_settle_i8": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_I8": "1", "GMMVB_SETTLE_MARGIN_I8": "0"},
     "nocache": {"GMMVB_MSTEP_CACHE": "0"},
