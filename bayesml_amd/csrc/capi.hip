@@ -974,7 +974,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, (i8_ref && ws->skip_used) ? 1 : 0, ws->lcomp);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, (i8_ref && ws->skip_used) ? 1 : 0, ws->lcomp,
+                                   std::getenv("GMMVB_LOOSE_EXIT") == nullptr ? 1 : 0);
                 span_end(ws, st);
             } else {
                 span_begin(ws, kSpanSelect, st);
@@ -986,7 +987,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, 0, ws->lcomp);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, 0, ws->lcomp, 0);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;

@@ -339,7 +339,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              float* __restrict__ dlock,
                                                              float* __restrict__ rthr /*[npad] the row's relevance threshold*/,
                                                              int fresh_ref /*dlock already holds bounds under the new parameters*/,
-                                                             const unsigned char* __restrict__ lcomp /*[npad] component a cached row is in*/) {
+                                                             const unsigned char* __restrict__ lcomp /*[npad] component a cached row is in*/,
+                                                             int full_when_loose) {
     __shared__ int wcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
@@ -453,8 +454,14 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         bool stays = false;
         if (by_bound) {
             stays = (mk[0] | mk[1] | mk[2] | mk[3]) == 0ull;
-            if (stays) dlock[n] = d_set;
-            else mk[kset >> 6] |= 1ull << (kset & 63);         // loose: its component and the candidates are evaluated
+            if (stays) {
+                dlock[n] = d_set;
+            } else {
+                mk[kset >> 6] |= 1ull << (kset & 63);          // loose: its component and the candidates are evaluated -
+                // in full: a candidate that left the gather early would keep a loose bound, erode back to the threshold
+                // within a pass or two and bring the row loose again; its exact value keeps the row settled for longer
+                if (full_when_loose) rthr[n] = -__builtin_huge_valf();
+            }
         }
         // the exact pairs: their values replace the carried bounds, and they compete for slots by value (the single
         // reference pair of the !PREV form always gets one)
