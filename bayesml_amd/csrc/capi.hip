@@ -703,6 +703,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                     ws->xc_ldx == ldx;
             bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && (ws->sweeps < 24 || may_settle);
             if (sweep && may_settle) carry = false;
+            if (std::getenv("GMMVB_ESTEP_RECORDS") != nullptr) {      // tests: the record pass whatever the drift summary
+                carry = hinted && ws->rec_valid;
+                sweep = false;
+            }
             if ((carry || sweep) && known && ws->lag_mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow

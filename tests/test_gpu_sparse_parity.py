@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_GAMMA",
             "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE", "GMMVB_SETTLE_I8", "GMMVB_SETTLE_MARGIN_I8", "GMMVB_GATHER_EXIT",
-            "GMMVB_SETTLE_SPARE")
+            "GMMVB_SETTLE_SPARE", "GMMVB_ESTEP_RECORDS")
 VARIANTS = {
     "default": {},
     # rows with a single active component are settled (left out of the E-step on the strength of their carried bounds)
@@ -34,6 +34,8 @@ VARIANTS = {
                      "GMMVB_SETTLE_SPARE": "1000"},
     # ... with their reference bound re-evaluated every pass on the int8 pipe (estep_i8_pairs) instead of carried
     "force_settle_i8": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_I8": "1", "GMMVB_SETTLE_MARGIN_I8": "0"},
+    # the pass on 55-byte records (one rest bound per row) instead of the sweep of per-pair bounds
+    "force_records": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_RECORDS": "1"},
     "nocache": {"GMMVB_MSTEP_CACHE": "0"},
     "noexit": {"GMMVB_GATHER_EXIT": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
@@ -193,7 +195,7 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_i8"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_i8", "force_records"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
@@ -225,7 +227,9 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
             continue
         wk = eng.work()
         settled_seen = max(settled_seen, wk["settled_rows"])
-        if eng.launch_info.startswith("estep_sweep") and it >= 6:
+        if variant == "force_records":
+            assert eng.launch_info.startswith("estep_carried"), eng.launch_info
+        if it >= 6 and wk["accumulated"] >= 0:
             cached_seen = max(cached_seen, wk["active"] - wk["accumulated"])
         lb = eng.ln_rho().cpu().numpy()
         oq = _oracle_post(q)
