@@ -144,6 +144,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         ws->settle_i8 = v && std::strcmp(v, "1") == 0;
         v = std::getenv("GMMVB_SETTLE_MARGIN_I8");
         if (v) ws->settle_margin_i8 = std::atof(v);
+        ws->prefer_records = std::getenv("GMMVB_ESTEP_RECORDS") != nullptr;
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_EXIT_MARGIN");                      // nats the partial bound must lie below the threshold
@@ -703,7 +704,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                     ws->xc_ldx == ldx;
             bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && (ws->sweeps < 24 || may_settle);
             if (sweep && may_settle) carry = false;
-            if (std::getenv("GMMVB_ESTEP_RECORDS") != nullptr) {      // tests: the record pass whatever the drift summary
+            if (ws->prefer_records) {                                 // tests: the record pass whatever the drift summary
                 carry = hinted && ws->rec_valid;
                 sweep = false;
             }

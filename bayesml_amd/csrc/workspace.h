@@ -131,6 +131,7 @@ struct gmmvb_workspace {
                                        // other than a sweep comes (the regime where carried reference bounds hold)
     bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows
     bool gather_exit = true;           // env GMMVB_GATHER_EXIT=0: no early way out in the candidate gather
+    bool prefer_records = false;       // env GMMVB_ESTEP_RECORDS: carried passes on records, never sweeps (tests)
     float exit_margin = 0.0f;          // env GMMVB_EXIT_MARGIN: nats a partial bound must lie below the row's threshold
     bool settle_i8 = false;            // env GMMVB_SETTLE_I8=1: settled rows' reference bounds are re-evaluated on the int8 pipe every pass instead of carried
     double settle_margin_i8 = 5.0;     // nats of slack for settling when the reference is re-evaluated every pass
