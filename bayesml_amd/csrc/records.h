@@ -25,6 +25,15 @@
 // Nothing here needs the host: lists, gather grid and statistics are sized on the device, so an E-step is a fixed
 // sequence of launches without a synchronisation.  The dense [K][npad] ln rho array stays the exchange buffer for
 // exact values (gather kernel -> rec_finish_kernel / M-step / read-outs); only listed entries of it are touched.
+//
+// Beside the records the sweep form of the pass (rec_sweep_kernel) keeps one f32 upper bound per PAIR (ub, [K][npad]),
+// and rec_finish_kernel keeps three more things per row (workspace.h):
+//   rthr    the relevance threshold of the pass (best exact value - 100 ln 2): the candidate gather may stop a pair whose
+//           partial sum already lies below it, and a stored value below it is treated as a bound, never flagged exact;
+//   lock / lcomp   whether the row's addend sits in the M-step's cache of single-component rows (r = 1.0 exactly), and for
+//           which component; the pass's changes leave through the delta masks (dmask), the M-step's own lists are mmask;
+//   dlock   for a settled row (cached AND left out of the E-step's lists) the upper bound of its distance to that
+//           component, from which the next sweep takes the row's reference value instead of an exact evaluation.
 #pragma once
 #include "aux_kernels.h"
 
