@@ -151,6 +151,20 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->exit_margin = (float)std::atof(v);
         v = std::getenv("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
+        ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
+        ws->opt_debug = std::getenv("GMMVB_DEBUG") != nullptr;
+        v = std::getenv("GMMVB_ESTEP_BOUND_BLOCKS");
+        ws->opt_bound_blocks = v ? std::atoi(v) : 0;
+        v = std::getenv("GMMVB_SPARE_WEIGHT");
+        if (v) ws->opt_spare_weight = std::atof(v);
+        ws->opt_loose_exit = std::getenv("GMMVB_LOOSE_EXIT") != nullptr;
+        v = std::getenv("GMMVB_MSTEP_CHUNK");
+        if (v) ws->opt_mstep_chunk = std::max(64, std::atoi(v) / 64 * 64);
+        ws->opt_list_xc = std::getenv("GMMVB_MSTEP_LIST_XC") != nullptr;
+        ws->opt_small_off = std::getenv("GMMVB_MSTEP_SMALL_OFF") != nullptr;
+        v = std::getenv("GMMVB_MSTEP_SMALL_CW");
+        ws->opt_small_cw = (v && std::atoi(v) == 4) ? 4 : 8;
+        ws->opt_one_level = std::getenv("HMMVB_ONE_LEVEL") != nullptr;
     }
     {
         const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0 && ws->bound_i8;
@@ -307,7 +321,7 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
 
 int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows) {
     if (!ws || ws->prune == 0 || ws->estep_variant != kEstepLds8 || ws->hmm != nullptr || !ws->rec_k) return 0;
-    if (std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr) return 0;
+    if (ws->opt_carry_off) return 0;
     return (ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23)) ? 1 : 0;
 }
 
@@ -684,7 +698,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (!sparse_ok && known && !ws->forget) sparse_ok = ws->lag_act <= 0.5 * pairs;
         if (sparse_ok) {
             mode = kBound;
-            const bool hinted = same_rows && ws->have_drift && std::getenv("GMMVB_ESTEP_CARRY_OFF") == nullptr;
+            const bool hinted = same_rows && ws->have_drift && !ws->opt_carry_off;
             // Two ways of carrying the previous pass over the parameter update (gmmvb_set_drift):
             //   records (records.h)  55 bytes per row, ONE bound for all components without a slot: it erodes at the pace
             //                        of the fastest-moving component (a 300-sample component with gamma 0.95 costs every
@@ -715,9 +729,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
-                double weight = 2.5;
-                if (const char* v = std::getenv("GMMVB_SPARE_WEIGHT")) weight = std::atof(v);
-                if (gpp * spare * weight >= bound_cost) carry = sweep = false;
+                if (gpp * spare * ws->opt_spare_weight >= bound_cost) carry = sweep = false;
                 // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
                 // (x4 - x8 observed): stop carrying well before they dominate
                 if (ws->lag_over > 0.02 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = sweep = false;
@@ -781,7 +793,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                : (i8_ref ? ws->settle_margin_i8
                                          : ((ws->settle_margin >= 0.0 && ws->settle_on) ? ws->settle_margin : -1.0));
     ws->settled_fresh = false;
-    if (std::getenv("GMMVB_DEBUG"))
+    if (ws->opt_debug)
         std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",
                      mode, (int)known, ws->lag_mode, ws->lag_act / n_rows, ws->lag_eval / n_rows, ws->lag_over / n_rows,
                      ws->lag_settled / n_rows, ws->lag_listed / n_rows, ws->typical_gamma, (int)ws->rec_valid,
@@ -793,10 +805,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // bound passes; look one level down when the current one leaves hardly any spare candidates or one level up
         // when more than half of its candidates are spare, if that level is unknown.
         const int t32 = (ws->D + 31) / 32;
-        const char* pin = std::getenv("GMMVB_ESTEP_BOUND_BLOCKS");      // pins the level (1 .. ceil(D/32))
+        const int pin = ws->opt_bound_blocks;                          // pins the level (1 .. ceil(D/32))
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
-        if (pin && std::atoi(pin) >= 1 && std::atoi(pin) <= t32) {
-            ws->bound_tb = std::atoi(pin);
+        if (pin >= 1 && pin <= t32) {
+            ws->bound_tb = pin;
         } else if (known && ws->lag_mode == kBound) {
             const int cur = ws->bound_tb;
             ws->tb_cand[cur] = ws->lag_eval / pairs;
@@ -980,7 +992,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
                                    settle ? ws->lock : nullptr, ws->dlock, ws->rthr, (i8_ref && ws->skip_used) ? 1 : 0, ws->lcomp,
-                                   std::getenv("GMMVB_LOOSE_EXIT") == nullptr ? 1 : 0);
+                                   ws->opt_loose_exit ? 0 : 1);
                 span_end(ws, st);
             } else {
                 span_begin(ws, kSpanSelect, st);
@@ -1157,13 +1169,12 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
         const int cap_chunks0 = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
-        int r_min0 = 1024;
-        if (const char* v = std::getenv("GMMVB_MSTEP_CHUNK")) r_min0 = std::max(64, atoi(v) / 64 * 64);
+        const int r_min0 = ws->opt_mstep_chunk;
         MstepListArgs la0{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks0, r_min0,
                           ws->npad, ws->K, ws->slabs};
         // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
         if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8) &&
-            std::getenv("GMMVB_MSTEP_LIST_XC") == nullptr) {
+            !ws->opt_list_xc) {
             if (ws->sorted) {
                 la0.x32 = (const float*)ws->xp;
                 la0.ldx = ws->D;
@@ -1256,11 +1267,12 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
         }
         span_begin(ws, kSpanMstepMain, st);
-        if (ws->T == 1 && pre && std::getenv("GMMVB_MSTEP_SMALL_OFF") == nullptr) {
+        if (ws->T == 1 && pre && !ws->opt_small_off) {
             // one feature tile: a wave walks the rows once for eight components (mstep.h, mstep_small_f64)
-            const int KGW = (ws->K + mstep_small_components_per_wg() - 1) / mstep_small_components_per_wg();
+            const int per_wg = 4 * ws->opt_small_cw;
+            const int KGW = (ws->K + per_wg - 1) / per_wg;
             grid = 8 * ((S + 7) / 8) * KGW;
-            e = launch_mstep_small((int)grid, st, a, KGW, &name);
+            e = launch_mstep_small((int)grid, st, a, KGW, ws->opt_small_cw, &name);
         } else {
             e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
         }

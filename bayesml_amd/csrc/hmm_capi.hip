@@ -55,8 +55,8 @@ constexpr int kLncBlocks = 1024;
 // chunk length: balances the sequential boundary scan (T/L steps of ~1.5 us) against the replay depth
 // (L steps of ~4 us forward+backward): L ~ sqrt(T * 1.5 / 4), a power of two in [16, 4096]
 // Long sequences (more than 2^18 steps): chunks of 256 steps and a two-level boundary pass (hmm.h, H3a / H3b).
-int64_t chunk_len(int64_t T) {
-    if (T > (int64_t(1) << 18) && std::getenv("HMMVB_ONE_LEVEL") == nullptr) return 256;
+int64_t chunk_len(int64_t T, bool one_level) {
+    if (T > (int64_t(1) << 18) && !one_level) return 256;
     int64_t L = 16;
     while (L < 4096 && 8 * L * L < 3 * T) L *= 2;
     return L;
@@ -66,7 +66,7 @@ template <int KT>
 hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
                double* out, hipStream_t st) {
     const int K = h->K, Kp = h->Kp;
-    const int64_t L = chunk_len(T);
+    const int64_t L = chunk_len(T, ws->opt_one_level);
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
     hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
                        ((size_t)Kp * (kPrepSteps + 1) + kPrepSteps) * sizeof(double), st, ws->lnrho, ws->npad, T, K, Kp, h->rho_tm,

@@ -67,8 +67,7 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
                         const char** name);
 
 // sparse-responsibility M-step over the centred copy and per-component lists of active rows (mstep.h)
-int mstep_small_components_per_wg();
-hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const char** name);
+hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, int cw, const char** name);
 
 struct MstepListArgs {
     const double* xc; const double* lnrho; const double* lse;

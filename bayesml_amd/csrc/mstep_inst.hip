@@ -17,14 +17,10 @@ static hipError_t go(int grid, hipStream_t st, const MstepArgs& a) {
     return hipGetLastError();
 }
 
-// one feature tile, rows from the centred copy: CW components per wave (mstep_small_f64); env GMMVB_MSTEP_SMALL_CW = 4 (default 8: 5.1 against 5.4 ms at HMM config 5)
-static int small_cw() {
-    const char* v = std::getenv("GMMVB_MSTEP_SMALL_CW");
-    return (v && std::atoi(v) == 4) ? 4 : 8;
-}
-int mstep_small_components_per_wg() { return 4 * small_cw(); }
-hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const char** name) {
-    if (small_cw() == 8) {
+// one feature tile, rows from the centred copy: cw = 4 | 8 components per wave (mstep_small_f64; 5.4 against 5.1 ms at HMM
+// config 5)
+hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, int cw, const char** name) {
+    if (cw == 8) {
         *name = "mstep_small_f64<T=1,8 components per wave,centred-f64>";
         hipLaunchKernelGGL((mstep_small_f64<8>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(a.x), a.n_rows, a.lnrho,
                            a.lse, a.aux, a.npad, a.K, KGW, a.S, a.rows_per_split, a.direct_r, a.slabs);

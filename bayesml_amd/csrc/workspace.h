@@ -132,6 +132,17 @@ struct gmmvb_workspace {
     bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows
     bool gather_exit = true;           // env GMMVB_GATHER_EXIT=0: no early way out in the candidate gather
     bool prefer_records = false;       // env GMMVB_ESTEP_RECORDS: carried passes on records, never sweeps (tests)
+    // further switches, all read ONCE when the workspace is created (no getenv on the per-iteration path)
+    bool opt_carry_off = false;        // GMMVB_ESTEP_CARRY_OFF: ignore gmmvb_set_drift
+    bool opt_debug = false;            // GMMVB_DEBUG: one line per E-step on stderr
+    int opt_bound_blocks = 0;          // GMMVB_ESTEP_BOUND_BLOCKS: pinned level of the int8 bound pass (0: cost model)
+    double opt_spare_weight = 2.5;     // GMMVB_SPARE_WEIGHT: weight of spare candidates against a fresh bound pass
+    bool opt_loose_exit = false;       // GMMVB_LOOSE_EXIT: rows that come loose may use the gather's early way out
+    int opt_mstep_chunk = 1024;        // GMMVB_MSTEP_CHUNK: list entries per list M-step chunk
+    bool opt_list_xc = false;          // GMMVB_MSTEP_LIST_XC: the list M-step reads the centred copy, not the f32 rows
+    bool opt_small_off = false;        // GMMVB_MSTEP_SMALL_OFF: no mstep_small_f64 at one feature tile
+    int opt_small_cw = 8;              // GMMVB_MSTEP_SMALL_CW: its components per wave (4 | 8)
+    bool opt_one_level = false;        // HMMVB_ONE_LEVEL: one-level boundary pass whatever the sequence length
     float exit_margin = 0.0f;          // env GMMVB_EXIT_MARGIN: nats a partial bound must lie below the row's threshold
     bool settle_i8 = false;            // env GMMVB_SETTLE_I8=1: settled rows' reference bounds are re-evaluated on the int8 pipe every pass instead of carried
     double settle_margin_i8 = 5.0;     // nats of slack for settling when the reference is re-evaluated every pass
