@@ -165,6 +165,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         v = std::getenv("GMMVB_MSTEP_SMALL_CW");
         ws->opt_small_cw = (v && std::atoi(v) == 4) ? 4 : 8;
         ws->opt_one_level = std::getenv("HMMVB_ONE_LEVEL") != nullptr;
+        v = std::getenv("GMMVB_REGROUP_MOVED");
+        if (v) ws->opt_regroup_moved = std::atof(v);
     }
     {
         const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0 && ws->bound_i8;
@@ -756,7 +758,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     auto regroup_due = [&]() {
         return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
                ws->lag_act <= 4.0 * (double)n_rows && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
-               (!ws->sorted || ws->moved_since_sort > 0.05 * (double)n_rows);      // (again once 5 % of the rows have moved on)
+               (!ws->sorted || ws->moved_since_sort > ws->opt_regroup_moved * (double)n_rows);      // (again once that share of the rows has moved on)
     };
     bool settle = false;
     if (ws->lock) {
