@@ -153,8 +153,6 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_EXIT_MARGIN");                      // nats the partial bound must lie below the threshold
         if (v) ws->exit_margin = (float)std::atof(v);
-        v = std::getenv("GMMVB_EXIT_MARGIN0");                     // nats at the first (quarter-way) exit; negative: none
-        if (v) ws->exit_margin0 = (float)std::atof(v);
         v = std::getenv("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
         ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
@@ -666,7 +664,7 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     if (e != hipSuccess) return e;
     span_begin(ws, kSpanGather, st);
     e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan, thr,
-                                thr ? ws->exit_ctr : nullptr, ws->exit_margin, ws->exit_margin0);
+                                thr ? ws->exit_ctr : nullptr, ws->exit_margin);
     span_end(ws, st);
     ++ws->passes[7];
     return e;

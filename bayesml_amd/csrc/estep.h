@@ -135,9 +135,8 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB
 template <int NB, typename XT, int JB, int J1, int BOFF, typename ImgPtr>
 __device__ __forceinline__ bool estep_component_exit(ImgPtr im, const XT (&xr)[NB][JB][4], double ck, int lane, int g,
                                                      const int64_t (&rows)[NB], double* __restrict__ lnrho_k,
-                                                     const float* __restrict__ thr, float margin, float margin0) {
+                                                     const float* __restrict__ thr, float margin) {
     static_assert(J1 >= 1 && J1 < JB, "the way out lies strictly inside the block loop");
-    constexpr int J0 = J1 / 2;          // a first, earlier way out for the hopeless: margin0 nats below the threshold
     constexpr int P = BOFF / 256;
     typedef double d2 __attribute__((ext_vector_type(2)));
     float th[NB];
@@ -168,38 +167,14 @@ __device__ __forceinline__ bool estep_component_exit(ImgPtr im, const XT (&xr)[N
             }
         }
     };
+    blocks(std::integral_constant<int, 0>{}, std::integral_constant<int, J1>{});
     double q[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) q[nb] = 0.0;
-    if constexpr (J0 >= 1) {
-        // after a quarter of the output blocks (3 of 36 tile pairs at D = 128) a pair that is already margin0 nats below
-        // the threshold leaves with that bound: loose, but far enough down to stay out for several passes
-        blocks(std::integral_constant<int, 0>{}, std::integral_constant<int, J0>{});
-        bool out0 = margin0 >= 0.0f;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-            for (int jt = 0; jt < J0; ++jt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) q[nb] = fma(acc[jt][nb][r], acc[jt][nb][r], q[nb]);
-            }
-            out0 = out0 && (ck - 0.5 * sum_groups(q[nb]) < (double)th[nb] - (double)margin0);
-        }
-        if (__all(out0)) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const double qs = sum_groups(q[nb]);
-                if (g == 0 && rows[nb] >= 0) lnrho_k[rows[nb]] = ck - 0.5 * qs;
-            }
-            return true;
-        }
-    }
-    blocks(std::integral_constant<int, J0>{}, std::integral_constant<int, J1>{});
     bool out = true;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
+        q[nb] = 0.0;
 #pragma unroll
-        for (int jt = J0; jt < J1; ++jt) {
+        for (int jt = 0; jt < J1; ++jt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) q[nb] = fma(acc[jt][nb][r], acc[jt][nb][r], q[nb]);
         }
@@ -417,8 +392,7 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
                                                             double* __restrict__ lnrho, int64_t npad,
                                                             const float* __restrict__ thr,
                                                             unsigned long long* __restrict__ exits /*pairs that took the way out*/,
-                                                            float exit_margin /*nats the partial bound must lie below thr*/,
-                                                            float exit_margin0 /*... at the first way out (< 0: none)*/) {
+                                                            float exit_margin /*nats the partial bound must lie below thr*/) {
     constexpr int NW = 8;
     constexpr int NB = estep_nb_w<XT>(T, NW);
     constexpr int IMG = img_doubles(T);
@@ -467,8 +441,7 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
             XT xr[NB][T][4];
             load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
             if constexpr (EXIT) {
-                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr, exit_margin,
-                                                                               exit_margin0)) {
+                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr, exit_margin)) {
                     const int64_t left = count - e0;
                     my_exits += (unsigned long long)(left < 16 * NB ? left : 16 * NB);
                 }

@@ -80,27 +80,27 @@ hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream
 
 template <int T, typename XT, bool VEC>
 static hipError_t go_gather_dev(int grid, hipStream_t st, const EstepArgs& a, const int* lists, int64_t cap,
-                                const int* counts, const int* plan, const float* thr, unsigned long long* exits, float margin, float margin0) {
+                                const int* counts, const int* plan, const float* thr, unsigned long long* exits, float margin) {
     if (thr)
         hipLaunchKernelGGL((estep_gather_dev_f64<T, XT, VEC, true>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x),
-                           a.ldx, a.D, a.img, a.cvec, a.K, lists, cap, counts, plan, a.lnrho, a.npad, thr, exits, margin, margin0);
+                           a.ldx, a.D, a.img, a.cvec, a.K, lists, cap, counts, plan, a.lnrho, a.npad, thr, exits, margin);
     else
         hipLaunchKernelGGL((estep_gather_dev_f64<T, XT, VEC, false>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x),
-                           a.ldx, a.D, a.img, a.cvec, a.K, lists, cap, counts, plan, a.lnrho, a.npad, thr, exits, margin, margin0);
+                           a.ldx, a.D, a.img, a.cvec, a.K, lists, cap, counts, plan, a.lnrho, a.npad, thr, exits, margin);
     return hipGetLastError();
 }
 
 #define GDCASE(TT)                                                                                                           \
     case TT:                                                                                                                 \
         if (x_is_f64)                                                                                                        \
-            return vec ? go_gather_dev<TT, double, true>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin, margin0)                      \
-                       : go_gather_dev<TT, double, false>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin, margin0);                    \
-        return vec ? go_gather_dev<TT, float, true>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin, margin0)                           \
-                   : go_gather_dev<TT, float, false>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin, margin0);
+            return vec ? go_gather_dev<TT, double, true>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin)                      \
+                       : go_gather_dev<TT, double, false>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin);                    \
+        return vec ? go_gather_dev<TT, float, true>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin)                           \
+                   : go_gather_dev<TT, float, false>(grid, st, a, lists, cap, counts_dev, plan_dev, thr, exits, margin);
 
 hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
                                    const int* lists, int64_t cap, const int* counts_dev, const int* plan_dev,
-                                   const float* thr, unsigned long long* exits, float margin, float margin0) {
+                                   const float* thr, unsigned long long* exits, float margin) {
     if (a.K > 256) return hipErrorInvalidValue;
     switch (T) {
         GDCASE(4) GDCASE(5) GDCASE(6) GDCASE(7) GDCASE(8)

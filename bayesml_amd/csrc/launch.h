@@ -33,8 +33,7 @@ hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipS
                                    const int* lists, int64_t cap, const int* counts_dev, const int* plan_dev,
                                    const float* thr = nullptr /*[npad] relevance thresholds: early way out for irrelevant pairs*/,
                                    unsigned long long* exits = nullptr /*with thr: counter of the pairs that took it*/,
-                                   float margin = 0.0f /*nats below thr a partial bound has to lie to take it*/,
-                                   float margin0 = -1.0f /*the same at the first, earlier way out (< 0: none)*/);
+                                   float margin = 0.0f /*nats below thr a partial bound has to lie to take it*/);
 // two-sided int8 bounds of listed pairs (estep_i8.h, estep_i8_pairs): a.img = the 3-digit image, dist_up[row] <- upper
 // bound of the whitened distance of (row, its listed component)
 struct EstepI8Args;

@@ -145,7 +145,6 @@ struct gmmvb_workspace {
     bool opt_one_level = false;        // HMMVB_ONE_LEVEL: one-level boundary pass whatever the sequence length
     double opt_regroup_moved = 0.05;   // GMMVB_REGROUP_MOVED: share of rows that changed their best component before the rows are regrouped again
     float exit_margin = 0.0f;          // env GMMVB_EXIT_MARGIN: nats a partial bound must lie below the row's threshold
-    float exit_margin0 = -1.0f;        // env GMMVB_EXIT_MARGIN0: the same at the quarter-way exit (< 0: that exit is not taken)
     bool settle_i8 = false;            // env GMMVB_SETTLE_I8=1: settled rows' reference bounds are re-evaluated on the int8 pipe every pass instead of carried
     double settle_margin_i8 = 5.0;     // nats of slack for settling when the reference is re-evaluated every pass
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
