@@ -33,6 +33,7 @@ SYMBOLS = {
     "gmmvb_forget": (_int, [_vp]),
     "gmmvb_regroup_count": (_i64, [_vp]),
     "gmmvb_debug_record": (_int, [_vp, _i64, ctypes.POINTER(ctypes.c_double)]),
+    "gmmvb_debug_proof": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
     "gmmvb_wants_drift": (_int, [_vp, _i64]),
     "gmmvb_prepare_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gmmvb_estep": (_int, [_vp, _vp, _i64, _i64, _vp]),
@@ -310,11 +311,11 @@ class DataPass:
 
     def work(self) -> dict:
         """Pairs of the last E-step (gmmvb_last_work): active, evaluated exactly, accumulated by the list M-step, and the
-        rows the E-step did not evaluate at all (settled)."""
-        out = (ctypes.c_double * 5)()
+        rows the E-step did not evaluate at all (settled), pairs of the int8 proof round."""
+        out = (ctypes.c_double * 8)()
         _check(self.lib, self.lib.gmmvb_last_work(self._ws, out), "gmmvb_last_work")
         return dict(active=float(out[0]), evaluated=float(out[1]), accumulated=float(out[2]), settled_rows=float(out[3]),
-                    early_exits=float(out[4]))
+                    early_exits=float(out[4]), proof_pairs=float(out[5]))
 
     def profile(self, on: bool = True):
         _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")
@@ -383,6 +384,15 @@ class DataPass:
         v = list(out)
         return dict(k=[int(x) for x in v[:8]], d=[round(x, 3) for x in v[8:16]], B=v[16], exact=int(v[17]), sel=int(v[18]),
                     flags=int(v[19]), khat=int(v[20]), lse=v[21], masks=[int(x) for x in v[22:26]])
+
+    def debug_proof(self, k: int, n_rows: int):
+        """(upper f32, lower f64) bounds of ln rho_nk for every prepared row from the proof round's int8 kernel."""
+        ub = torch.empty(n_rows, dtype=torch.float32, device=self.device)
+        lb = torch.empty(n_rows, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_debug_proof(self._ws, int(k), int(n_rows), ub.data_ptr(), lb.data_ptr(),
+                                                        self._stream()), "gmmvb_debug_proof")
+        return ub, lb
 
     def forget(self):
         """The next parameters are unrelated to the last E-step's (a new restart): see gmmvb_forget."""

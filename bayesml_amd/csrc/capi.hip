@@ -44,9 +44,9 @@ static int ensure_lists(gmmvb_workspace* ws);
 
 // profiling spans (gmmvb_profile_spans): HIP events on the launch stream around groups of kernels
 enum { kSpanEstepMain = 0, kSpanSelect = 1, kSpanGather = 2, kSpanLse = 3, kSpanLists = 4, kSpanMstepMain = 5,
-       kSpanReduce = 6, kSpanSlots = 8 };
+       kSpanReduce = 6, kSpanProof = 7, kSpanSlots = 8 };
 static const char* const kSpanNames[kSpanSlots] = {"estep_main", "estep_select", "estep_gather", "estep_lse_mask",
-                                                   "mstep_lists", "mstep_main", "mstep_reduce", ""};
+                                                   "mstep_lists", "mstep_main", "mstep_reduce", "estep_proof"};
 static void span_begin(gmmvb_workspace* ws, int slot, hipStream_t st) {
     if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans) return;
     ws->span_slot[ws->n_spans] = slot;
@@ -144,10 +144,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->settle_gamma = std::atof(v);
         v = std::getenv("GMMVB_SETTLE_SPARE");
         if (v) ws->settle_spare = std::atof(v);
-        v = std::getenv("GMMVB_SETTLE_I8");                        // "1": int8 reference bounds for settled rows (slower at C3)
-        ws->settle_i8 = v && std::strcmp(v, "1") == 0;
-        v = std::getenv("GMMVB_SETTLE_MARGIN_I8");
-        if (v) ws->settle_margin_i8 = std::atof(v);
+        v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round for settled rows
+        ws->opt_proof = !(v && std::strcmp(v, "0") == 0);
         ws->prefer_records = std::getenv("GMMVB_ESTEP_RECORDS") != nullptr;
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
@@ -161,7 +159,6 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         ws->opt_bound_blocks = v ? std::atoi(v) : 0;
         v = std::getenv("GMMVB_SPARE_WEIGHT");
         if (v) ws->opt_spare_weight = std::atof(v);
-        ws->opt_loose_exit = std::getenv("GMMVB_LOOSE_EXIT") != nullptr;
         v = std::getenv("GMMVB_MSTEP_CHUNK");
         if (v) ws->opt_mstep_chunk = std::max(64, std::atoi(v) / 64 * 64);
         ws->opt_list_xc = std::getenv("GMMVB_MSTEP_LIST_XC") != nullptr;
@@ -227,7 +224,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
                      ws->lock, ws->lcomp, ws->dlock, ws->rthr, ws->exit_ctr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
-                     ws->rmask, ws->rblk};
+                     ws->rmask, ws->rblk, ws->xq, ws->xqe, ws->ppart};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -318,6 +315,8 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(pivot)", e);
     ws->xc_src = nullptr;      // the centred copy (if any) is stale now
+    ws->xq_src = nullptr;      // ... and so are the digit planes
+    ++ws->pivot_gen;
     if (ws->lock_live) {               // the settled rows belonged to the previous state of affairs
         ws->lock_live = false;
         ws->lock_reset = true;
@@ -385,6 +384,44 @@ int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26] host
 
 int64_t gmmvb_regroup_count(const gmmvb_workspace* ws) { return ws ? ws->sorts : -1; }
 
+// test / diagnostic: the proof round's kernel over (row, k) for EVERY row of the prepared matrix
+namespace {
+__global__ void debug_all_rows_kernel(int* __restrict__ list, int* __restrict__ counts, int K, int k, int64_t n_rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) list[i] = (int)i;
+    if (i < K) counts[i] = (int)(i == k ? n_rows : 0);
+}
+}  // namespace
+
+int gmmvb_debug_proof(gmmvb_workspace* ws, int k, int64_t n_rows, float* ub_dev, double* lb_dev, void* stream) {
+    if (!ws || !ub_dev || !lb_dev || k < 0 || k >= ws->K) return fail(GMMVB_EINVAL, "bad argument");
+    if (!ws->xq || !ws->img_i8b || ws->xq_src == nullptr || ws->xq_rows != n_rows || ws->xq_gen != ws->img_gen || !ws->have_params)
+        return fail(GMMVB_ESTATE, "no digit planes for these rows: gmmvb_set_pivot, gmmvb_prepare_rows, gmmvb_set_params first");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((std::max<int64_t>(n_rows, ws->K) + 255) / 256);
+    hipLaunchKernelGGL(debug_all_rows_kernel, dim3(grid), dim3(256), 0, st, ws->lists + (int64_t)k * ws->npad, ws->counts, ws->K, k,
+                       n_rows);
+    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K, estep_i8_pairs_per_chunk(), ws->plan);
+    hipError_t e = launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists, ws->npad,
+                                         ws->counts, ws->plan, ws->ub32, ws->lnrho, ws->npad);
+    if (e == hipSuccess) e = hipMemcpyAsync(ub_dev, ws->ub32 + (int64_t)k * ws->npad, (size_t)n_rows * sizeof(float),
+                                            hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(lb_dev, ws->lnrho + (int64_t)k * ws->npad, (size_t)n_rows * sizeof(double),
+                                            hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "proof kernel (diagnostic)", e);
+    // whatever the workspace held of an E-step is gone
+    ws->e_state = 0;
+    ws->bounds_rows = 0;
+    ws->rec_valid = ws->dense_valid = ws->rec_live = false;
+    ws->active_lists = ws->blk_fresh = false;
+    ws->lag_valid = false;
+    if (ws->lock_live) {
+        ws->lock_live = false;
+        ws->lock_reset = true;
+    }
+    return GMMVB_OK;
+}
+
 int gmmvb_forget(gmmvb_workspace* ws) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     ws->forget = true;
@@ -412,6 +449,7 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
         if (e == hipSuccess && ws->img_i8) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8, 0, st);
         if (e == hipSuccess && ws->img_i8b) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8b, 1, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_i8_kernel", e);
+        ws->img_gen = ws->pivot_gen;
     }
     ws->have_params = true;
     ws->params_used = false;
@@ -454,6 +492,14 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->epart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->opart, (size_t)sel_blocks * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mpart, (size_t)sel_blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->ppart, (size_t)sel_blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(ws->ppart, 0, (size_t)sel_blocks * sizeof(double));
+    if (ws->prune != 0 && ws->img_i8b && ws->opt_proof && ws->cache_on) {
+        const int64_t rb = estep_i8_digit_row_bytes(ws->D);
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->xq, (size_t)(np * rb));
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->xqe, (size_t)np);
+        if (e == hipSuccess) ws->bytes += np * (rb + 1);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_k, (size_t)kRecSlots * np * sizeof(unsigned short));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_d, (size_t)kRecSlots * np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_B, (size_t)np * sizeof(float));
@@ -489,7 +535,9 @@ static int fetch_counters(gmmvb_workspace* ws) {
             ws->lag_settled = 0.0;
             ws->lag_listed = ws->lag_accum = ws->lag_act;
             ws->lag_exits = 0.0;
+            ws->lag_proof = 0.0;
         } else {
+            ws->lag_proof = ws->ctr_host[7];
             ws->lag_exits = (ws->exit_host && ws->gather_exit) ? (double)*ws->exit_host : 0.0;
             ws->lag_settled = ws->ctr_host[4];
             ws->lag_listed = ws->ctr_host[5];
@@ -536,6 +584,8 @@ int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
     out[2] = counted ? ws->lag_accum : -1.0;
     out[3] = ws->lag_mode == 0 ? 0.0 : ws->lag_settled;
     out[4] = ws->lag_mode == 0 ? 0.0 : ws->lag_exits;
+    out[5] = ws->lag_mode == 0 ? 0.0 : ws->lag_proof;
+    out[6] = out[7] = 0.0;
     return GMMVB_OK;
 }
 
@@ -581,6 +631,14 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->xc_rows = n_rows;
     ws->xc_ldx = ldx;
     ws->xc_stale = false;
+    if (ws->xq) {              // the int8 digit planes of the proof round, about the same pivot
+        e = launch_x_digits(x_dev, ws->x_dtype == GMMVB_F64, ldx, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "x_digits launch", e);
+        ws->xq_src = x_dev;
+        ws->xq_rows = n_rows;
+        ws->xq_ldx = ldx;
+        ws->xq_gen = ws->pivot_gen;
+    }
     return GMMVB_OK;
 }
 
@@ -624,6 +682,11 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     // the centred f64 copy follows the internal order too, but it is only read by the dense M-step (and by the list
     // M-step of f64 / ragged-D inputs): rebuilt there when needed (recenter_rows), not here - 4 ms and 10 GB at C3
     ws->xc_stale = ws->xc != nullptr;
+    if (ws->xq && ws->xq_src == x_dev) {       // the digit planes follow the internal order (3 ms at C3, once or twice per fit)
+        hipError_t eq = launch_x_digits(ws->xp, ws->x_dtype == GMMVB_F64, ws->D, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st);
+        if (eq != hipSuccess) return eq;
+        ws->xq_gen = ws->pivot_gen;
+    }
     ws->sorted = true;
     ++ws->sorts;
     return hipGetLastError();
@@ -731,7 +794,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if ((carry || sweep) && known && ws->lag_mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
-                const double spare = std::max(0.0, ws->lag_eval - (ws->lag_act - ws->lag_settled)) / pairs;
+                // (a pair of the proof round costs about a fifth of an exact evaluation)
+                const double spare = (std::max(0.0, ws->lag_eval - (ws->lag_act - ws->lag_settled)) + 0.2 * ws->lag_proof) / pairs;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
@@ -779,14 +843,15 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         settle = mode != kDense && ws->cache_on && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
                  ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     }
-    // Rows are settled (left out of the E-step as well) when the next pass can re-evaluate their reference bound cheaply
-    // (three int8 digits, estep_i8_pairs) - or, without that, only while the parameters move little (the bound is then
-    // carried through Gamma and delta and erodes quickly otherwise).
-    const bool i8_ref = settle && ws->settle_i8 && ws->img_i8b != nullptr && ws->settle_margin_i8 >= 0.0;
-    // (measured at C3, profiles/r2_experiments.md: settling while the components still move by per cents makes the rows
-    // come loose in masses against weak thresholds - 14.1 instead of 12.9 ms per step over iterations 6-25 - whereas from
-    // iteration ~15 on it takes the E-step from 5.2 to 3.7 ms: hence a gate with hysteresis on the drift summary and on
-    // the spare candidates of the last sweep)
+    // Rows with a single active component are settled (left out of the E-step as well as of the M-step).  With the proof
+    // round available - the int8 digit planes of this matrix are in the workspace, about the pivot the component images
+    // were packed for - a settled row whose carried bounds no longer prove it costs a few int8 pairs, so rows settle in
+    // every pruned pass.  Without it a row that comes loose costs exact evaluations, and settling while the components
+    // still move by per cents makes rows come loose in masses (measured at C3, profiles/r2_experiments.md: 14.1 instead of
+    // 12.9 ms per step over iterations 6-25): hence the gate with hysteresis on the drift summary and on the spare
+    // candidates of the last sweep.
+    const bool proof_capable = settle && ws->opt_proof && ws->xq != nullptr && ws->img_i8b != nullptr && ws->xq_src == x_dev &&
+                               ws->xq_rows == n_rows && ws->xq_ldx == ldx && ws->xq_gen == ws->img_gen;
     if (mode != kSweep) {
         ws->settle_on = false;
     } else if (!ws->settle_on) {
@@ -795,9 +860,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     } else if (ws->typical_gamma > 0.0 && ws->typical_gamma < ws->settle_gamma - 0.05) {
         ws->settle_on = false;
     }
-    const double skip_margin = !settle ? -1.0
-                               : (i8_ref ? ws->settle_margin_i8
-                                         : ((ws->settle_margin >= 0.0 && ws->settle_on) ? ws->settle_margin : -1.0));
+    const double skip_margin = (settle && ws->settle_margin >= 0.0 && (proof_capable || ws->settle_on)) ? ws->settle_margin : -1.0;
     ws->settled_fresh = false;
     if (ws->opt_debug)
         std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",
@@ -870,7 +933,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
     const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
-    bool counted = false;
+    bool counted = false, proof_ran = false;
     if (mode == kDense) {
         rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
         grid = (n_rows + rpw - 1) / rpw;
@@ -901,7 +964,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             hipLaunchKernelGGL(lse_mask_kernel, dim3((unsigned)sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
                                ws->K, ws->thr, ws->lse, ws->masks, ws->blk, ws->apart, ws->khat);
             hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(1024), 0, st, ws->apart, nullptr, nullptr, nullptr, nullptr, nullptr,
-                               nullptr, sel_grid, ws->ctr);
+                               nullptr, nullptr, sel_grid, ws->ctr);
             // records for the next pass (one more sweep of the array, ~1 % of the dense kernel's time)
             if (can_prune && big)
                 hipLaunchKernelGGL(rec_build_kernel<false>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
@@ -958,28 +1021,6 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // workspace with their masks: evaluate them as they are (no list building); else the previous best
             // component of every row.
             if (prev_lists) {
-                if (i8_ref && ws->skip_used) {
-                    // the settled rows' reference: an upper bound of their distance to their one component under the new
-                    // parameters, from three int8 digits (their lists are built and used before the buffers take the
-                    // active pairs' lists)
-                    span_begin(ws, kSpanSelect, st);
-                    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->lcomp,
-                                       ws->npad, n_rows, ws->K, ws->rmask, ws->rblk);
-                    launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
-                    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
-                                       ws->K, ws->rblk, ws->lists, ws->npad);
-                    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
-                                       estep_i8_pairs_per_chunk(), ws->plan);
-                    span_end(ws, st);
-                    span_begin(ws, kSpanEstepMain, st);
-                    EstepI8Args ab = a8;
-                    ab.img = ws->img_i8b;
-                    e = launch_estep_i8_pairs(is64, vec, 2 * ws->num_cu, st, ab, ws->lists, ws->npad, ws->counts, ws->plan,
-                                              ws->dlock);
-                    span_end(ws, st);
-                    if (e != hipSuccess) return fail(GMMVB_EHIP, "settled-row reference bounds", e);
-                    ws->active_lists = false;
-                }
                 span_begin(ws, kSpanSelect, st);
                 if (!ws->active_lists) {        // (the M-step's lists left out the rows in its cache)
                     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
@@ -995,10 +1036,32 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 ++ws->passes[7];
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step active-pair evaluation", e);
                 span_begin(ws, kSpanSelect, st);
+                const bool proof = proof_capable && ws->skip_used;       // (some rows may be settled)
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, (i8_ref && ws->skip_used) ? 1 : 0, ws->lcomp,
-                                   ws->opt_loose_exit ? 0 : 1);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
+                                   ws->rblk);
+                if (proof) {
+                    // proof round: settled rows whose carried bounds left candidates - their component and the candidates
+                    // get two-sided bounds from three int8 digits; rows that are proven stay settled, the others join
+                    // the pass's lists (records.h)
+                    launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+                    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
+                                       ws->K, ws->rblk, ws->lists, ws->npad);
+                    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
+                                       estep_i8_pairs_per_chunk(), ws->plan);
+                    span_end(ws, st);
+                    span_begin(ws, kSpanProof, st);
+                    e = launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists,
+                                              ws->npad, ws->counts, ws->plan, ws->ub32, ws->lnrho, ws->npad);
+                    span_end(ws, st);
+                    if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round", e);
+                    span_begin(ws, kSpanSelect, st);
+                    hipLaunchKernelGGL(rec_proof_decide_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->rmask, ws->masks,
+                                       ws->npad, n_rows, ws->K, ws->cvec, ws->ub32, ws->lnrho, ws->lcomp, ws->dlock, ws->rthr,
+                                       ws->blk, ws->epart, ws->ppart);
+                    proof_ran = true;
+                }
                 span_end(ws, st);
             } else {
                 span_begin(ws, kSpanSelect, st);
@@ -1010,7 +1073,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, 0, ws->lcomp, 0);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, nullptr, nullptr);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;
@@ -1036,8 +1099,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                            ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32,
                            settle ? ws->lock : nullptr, ws->dlock, skip_margin, settle ? ws->dmask : nullptr,
                            settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart, ws->qpart, ws->rthr, ws->lcomp);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(7), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart, ws->spart,
-                           ws->gpart, ws->qpart, sel_grid, ws->ctr);
+        if (!proof_ran) (void)hipMemsetAsync(ws->ctr + 7, 0, sizeof(double), st);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(proof_ran ? 8 : 7), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart,
+                           ws->spart, ws->gpart, ws->qpart, ws->ppart, sel_grid, ws->ctr);
         e = hipGetLastError();
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "rec_finish launch", e);

@@ -530,11 +530,75 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
     }
 }
 
-// ---- two-sided bounds for listed (sample, component) pairs --------------------------------------------------------------
-// The settled rows of the pruned E-step (records.h) need, per pass, a LOWER bound of ln rho of their one active component
-// under the new parameters - an upper bound of || U_k (x_n - m_k) || - and nothing else; three digits on the int8 pipe give
-// it to about 1e-3 of the distance at an eighth of the f64 evaluation's cost.  Same images, digits and error terms as the
-// bound pass; the error term is added instead of subtracted.  Returns (lower, upper) bound of q = || U (x - m) ||^2.
+// ---- sample digits kept in HBM ---------------------------------------------------------------------------------------------
+// The list-driven kernels below evaluate ONE component per sample, so the f64 digit extraction of load_x_digits_row
+// (3400 vector instructions per 32-sample tile) is not amortised over K components as in estep_i8: measured in round 2,
+// it made a 3-digit pair as slow as its f64 evaluation.  The three digit planes of every row are therefore made once per
+// sample matrix (and per regrouping of the rows) and kept next to x:
+//   xq [row][a = 0..2][32 T32] int8   digit a of feature f of (x - pivot) 2^(6 - en), the bytes load_x_digits_row<3> forms
+//   xqe[row]                   int8   en, the exponent of the row's largest |x - pivot| (kNoDigits: non-finite row, or
+//                                     an exponent outside the range in which the f32 epilogue is exact - no bound)
+// 3 bytes per feature instead of 4: a pair costs 96 T32 bytes of HBM traffic and no vector arithmetic before its MFMAs.
+constexpr signed char kNoDigits = 127;
+__host__ __device__ constexpr int64_t i8_digit_row_bytes(int t32) { return (int64_t)kBoundDigits * 32 * t32; }
+
+// 8 threads per row, thread g owns features 16 g .. 16 g + 15 (g < 2 T32); 32 rows per 256-thread block.
+template <typename XT>
+__global__ __launch_bounds__(256) void x_digits_kernel(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D, int T32,
+                                                       const double* __restrict__ pivot, unsigned char* __restrict__ xq,
+                                                       signed char* __restrict__ xqe) {
+    constexpr int ND = kBoundDigits;
+    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int g = threadIdx.x & 7;
+    const bool in_row = row < n_rows;
+    const bool has = in_row && g < 2 * T32;
+    double v[16];
+    double mx = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int f = 16 * g + e;
+        v[e] = (has && f < D) ? (double)x[row * ldx + f] - pivot[f] : 0.0;
+        const double a = fabs(v[e]);
+        bad |= !(a <= 1.7976931348623157e308);
+        mx = fmax(mx, a);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        mx = fmax(mx, __shfl_xor(mx, o));
+        bad |= (bool)__shfl_xor((int)bad, o);
+    }
+    int en = 0;
+    if (mx > 0.0) (void)frexp(mx, &en);
+    const bool ok = !bad && en >= -44 && en <= 46;          // the range in which estep_i8's f32 epilogue stays exact
+    const double scale = ok ? ldexp(1.0, 6 - en) : 0.0;
+    unsigned w[ND][4];
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[a][q] = 0u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        int d[ND];
+        digits_of<ND>(v[e] * scale, d);
+#pragma unroll
+        for (int a = 0; a < ND; ++a) w[a][e >> 2] |= (unsigned)(d[a] & 0xff) << (8 * (e & 3));
+    }
+    if (has) {
+        unsigned char* dst = xq + row * i8_digit_row_bytes(T32) + 16 * g;
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+            *reinterpret_cast<i4v*>(dst + a * 32 * T32) = i4v{(int)w[a][0], (int)w[a][1], (int)w[a][2], (int)w[a][3]};
+    }
+    if (in_row && g == 0) xqe[row] = ok ? (signed char)en : kNoDigits;
+}
+
+// ---- two-sided bounds for listed (sample, component) pairs: the proof round of the pruned E-step ---------------------------
+// A row with a single active component has r = 1.0 exactly whatever the value of its ln rho (records.h, "settled rows"):
+// all the E-step owes such a row is the PROOF that it still has one - a lower bound of its component's ln rho and upper
+// bounds of the components whose carried bound no longer clears it.  Three digits on the int8 pipe give both to about
+// 1e-5 relative (same images, digits and error terms as the bound pass; the error term is added for the lower bound).
+// Returns (lower, upper) bound of q = || U (x - m) ||^2.
 template <int T32, bool REV>
 __device__ __forceinline__ void estep_i8_two_sided(unsigned im_lds, const i4v (&xd)[kBoundDigits][T32],
                                                    const i8_lane_consts& lc, int lane, int h, float& q_lo, float& q_hi) {
@@ -563,18 +627,22 @@ __host__ __device__ constexpr int i8_pairs_per_chunk() { return 8 * 32 * kI8Pair
 
 // plan[k] = component k's first chunk of i8_pairs_per_chunk() list entries, plan[K] = total (gather_plan_kernel); a fixed
 // grid of persistent workgroups takes contiguous runs of chunks and restages the 31-KB digit image only when the
-// component changes.  dist_up[row] <- an upper bound of the whitened distance of (row, its listed component); +inf / NaN
-// when the image or the sample admits no bound (the caller then treats the row as unproven).
-template <int T32, typename XT, bool VEC>
-__global__ __launch_bounds__(512) void estep_i8_pairs(const XT* __restrict__ x, int64_t ldx, int D,
+// component changes.  For every listed pair (row, k):
+//   ub[k][row] <- an upper bound of ln rho_{row,k}, rounded up to f32 (the array the sweeps carry, records.h);
+//   lb[k][row] <- a lower bound of it (f64; -inf when the image or the sample admits no bound - the caller then
+//                 treats the row as unproven and evaluates it exactly).
+template <int T32>
+__global__ __launch_bounds__(512) void estep_i8_proof(const unsigned char* __restrict__ xq, const signed char* __restrict__ xqe,
                                                       const unsigned char* __restrict__ img /*[K][IMGB], 3 digits*/,
-                                                      const double* __restrict__ pivot, int K,
+                                                      const double* __restrict__ cvec, int K,
                                                       const int* __restrict__ lists /*[K][cap]*/, int64_t cap,
                                                       const int* __restrict__ counts, const int* __restrict__ plan,
-                                                      float* __restrict__ dist_up) {
+                                                      float* __restrict__ ub /*[K][npad]*/, double* __restrict__ lb /*[K][npad]*/,
+                                                      int64_t npad) {
     constexpr int ND = kBoundDigits, NW = 8;
     constexpr int IMGB = i8_img_bytes(ND, T32);
     constexpr int CHUNK = i8_pairs_per_chunk();
+    constexpr int64_t RS = i8_digit_row_bytes(T32);
     __shared__ __attribute__((aligned(16))) unsigned char smem[IMGB];
     __shared__ int s_first[257];
     const int lane = threadIdx.x & 63;
@@ -603,30 +671,51 @@ __global__ __launch_bounds__(512) void estep_i8_pairs(const XT* __restrict__ x, 
         const int count = counts[k];
         const int64_t chunk0 = (int64_t)(ch - s_first[k]) * CHUNK;
         const int* list = lists + (int64_t)k * cap;
-        for (int t = 0; t < kI8PairTiles; ++t) {
-            const int64_t e0 = chunk0 + ((int64_t)t * NW + wave) * 32;
-            if (e0 >= count) break;
-            const int64_t e = e0 + c;
-            const int64_t row = list[e < count ? e : count - 1];
-            i4v xd[ND][T32];
-            double c2, sn;
-            load_x_digits_row<ND, T32, XT, VEC>(x, ldx, D, pivot, row, h, xd, c2, sn);
+        const double ck = cvec[k];
+        // tiles of this wave in the chunk: t = 0 .. nt - 1 at list entries chunk0 + (t NW + wave) 32; the digits of tile
+        // t + 1 are requested before tile t is computed (two register sets, the loop is unrolled by two)
+        int nt = 0;
+        while (nt < kI8PairTiles && chunk0 + ((int64_t)nt * NW + wave) * 32 < count) ++nt;
+        auto request = [&](int t, i4v (&xd)[ND][T32], int64_t& row, int& en) {
+            const int64_t e = chunk0 + ((int64_t)t * NW + wave) * 32 + c;
+            row = list[e < count ? e : count - 1];
+            const unsigned char* src = xq + row * RS + 16 * h;
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+#pragma unroll
+                for (int it = 0; it < T32; ++it) xd[a][it] = *reinterpret_cast<const i4v*>(src + a * 32 * T32 + 32 * it);
+            en = xqe[row];
+        };
+        auto evaluate = [&](int t, const i4v (&xd)[ND][T32], int64_t row, int en) {
+            const bool ok = en != kNoDigits;
             i8_lane_consts lc;
-            lc.c[2] = c2;
-            lc.c[1] = c2 * 128.0;
-            lc.c[0] = c2 * 268435456.0;
-            int en = 0;
-            (void)frexp(sn, &en);
-            const bool ok = (c2 == c2) && en >= -44 && en <= 46;
-            lc.c2f = ok ? (float)c2 : 0.0f;
-            lc.cef = ok ? (float)(sn * i8_err(ND, T32) * 1.0001) : __builtin_huge_valf();
+            lc.c[0] = lc.c[1] = lc.c[2] = 0.0;        // (the f64 weights belong to the six-digit epilogue)
+            lc.c2f = ok ? (float)ldexp(1.0, en - 12 - 7 * (ND - 1)) : 0.0f;
+            lc.cef = ok ? (float)(ldexp(1.0, en) * i8_err(ND, T32) * 1.0001) : __builtin_huge_valf();
             float q_lo, q_hi;
             if (T32 > 1 && wave >= NW / 2)
                 estep_i8_two_sided<T32, true>(im_lds, xd, lc, lane, h, q_lo, q_hi);
             else
                 estep_i8_two_sided<T32, false>(im_lds, xd, lc, lane, h, q_lo, q_hi);
-            // 2^-16 of q covers the f32 rounding of its 128 squares and additions; the square root one more ulp
-            if (h == 0 && e < count) dist_up[row] = __builtin_sqrtf(q_hi * 1.0000153f) * 1.0000003f;
+            const int64_t e = chunk0 + ((int64_t)t * NW + wave) * 32 + c;
+            if (h == 0 && e < count) {
+                // 2^-16 of q covers the f32 rounding of its 32 T32 squares and additions (as in estep_i8_component)
+                const double up = fma(-0.5 * (double)q_lo, 1.0 - 1.52587890625e-05, ck + 1e-12 * fabs(ck));
+                const double lo = fma(-0.5 * (double)q_hi, 1.0 + 1.52587890625e-05, ck - 1e-12 * fabs(ck));
+                ub[(int64_t)k * npad + row] = __double2float_ru(up);
+                lb[(int64_t)k * npad + row] = (lo == lo) ? lo : -__builtin_huge_val();
+            }
+        };
+        i4v xa[ND][T32], xb[ND][T32];
+        int64_t ra = 0, rb = 0;
+        int ea = 0, eb = 0;
+        if (nt > 0) request(0, xa, ra, ea);
+        for (int t = 0; t < nt; t += 2) {
+            if (t + 1 < nt) request(t + 1, xb, rb, eb);
+            evaluate(t, xa, ra, ea);
+            if (t + 1 >= nt) break;
+            if (t + 2 < nt) request(t + 2, xa, ra, ea);
+            evaluate(t + 1, xb, rb, eb);
         }
     }
 }

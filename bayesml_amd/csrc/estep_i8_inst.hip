@@ -66,28 +66,35 @@ hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int tb, int grid, hipSt
     return hipErrorInvalidValue;
 }
 
-// two-sided bounds of listed pairs (the settled rows' reference values): all ceil(D / 32) blocks, three digits
-int estep_i8_pairs_per_chunk() { return i8_pairs_per_chunk(); }
+// sample digits in HBM; two-sided bounds of listed pairs over them (the proof round): all ceil(D / 32) blocks, three digits
+int64_t estep_i8_digit_row_bytes(int D) { return i8_digit_row_bytes(i8_blocks(D)); }
 
-template <int T32, typename XT, bool VEC>
-static hipError_t go_pairs(int grid, hipStream_t st, const EstepI8Args& a, const int* lists, int64_t cap, const int* counts,
-                           const int* plan, float* dist_up) {
-    hipLaunchKernelGGL((estep_i8_pairs<T32, XT, VEC>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x), a.ldx, a.D,
-                       a.img, a.pivot, a.K, lists, cap, counts, plan, dist_up);
+hipError_t launch_x_digits(const void* x, int x_is_f64, int64_t ldx, int64_t n_rows, int D, const double* pivot,
+                           unsigned char* xq, signed char* xqe, hipStream_t st) {
+    const int t32 = i8_blocks(D);
+    if (t32 < 1 || t32 > 4) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n_rows + 31) / 32);
+    if (x_is_f64)
+        hipLaunchKernelGGL(x_digits_kernel<double>, dim3(grid), dim3(256), 0, st, static_cast<const double*>(x), ldx, n_rows, D,
+                           t32, pivot, xq, xqe);
+    else
+        hipLaunchKernelGGL(x_digits_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x), ldx, n_rows, D,
+                           t32, pivot, xq, xqe);
     return hipGetLastError();
 }
 
-hipError_t launch_estep_i8_pairs(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const int* lists,
-                                 int64_t cap, const int* counts, const int* plan, float* dist_up) {
-    if (a.K > 256) return hipErrorInvalidValue;
-#define PC(T)                                                                                                         \
-    case T:                                                                                                           \
-        if (x_is_f64)                                                                                                 \
-            return vec ? go_pairs<T, double, true>(grid, st, a, lists, cap, counts, plan, dist_up)                    \
-                       : go_pairs<T, double, false>(grid, st, a, lists, cap, counts, plan, dist_up);                  \
-        return vec ? go_pairs<T, float, true>(grid, st, a, lists, cap, counts, plan, dist_up)                         \
-                   : go_pairs<T, float, false>(grid, st, a, lists, cap, counts, plan, dist_up);
-    switch (i8_blocks(a.D)) {
+int estep_i8_pairs_per_chunk() { return i8_pairs_per_chunk(); }
+
+hipError_t launch_estep_i8_proof(int D, int grid, hipStream_t st, const unsigned char* xq, const signed char* xqe,
+                                 const unsigned char* img, const double* cvec, int K, const int* lists, int64_t cap,
+                                 const int* counts, const int* plan, float* ub, double* lb, int64_t npad) {
+    if (K > 256) return hipErrorInvalidValue;
+#define PC(T)                                                                                                              \
+    case T:                                                                                                                \
+        hipLaunchKernelGGL((estep_i8_proof<T>), dim3(grid), dim3(512), 0, st, xq, xqe, img, cvec, K, lists, cap, counts,   \
+                           plan, ub, lb, npad);                                                                            \
+        return hipGetLastError();
+    switch (i8_blocks(D)) {
         PC(1) PC(2) PC(3) PC(4)
     }
 #undef PC

@@ -34,12 +34,15 @@ hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipS
                                    const float* thr = nullptr /*[npad] relevance thresholds: early way out for irrelevant pairs*/,
                                    unsigned long long* exits = nullptr /*with thr: counter of the pairs that took it*/,
                                    float margin = 0.0f /*nats below thr a partial bound has to lie to take it*/);
-// two-sided int8 bounds of listed pairs (estep_i8.h, estep_i8_pairs): a.img = the 3-digit image, dist_up[row] <- upper
-// bound of the whitened distance of (row, its listed component)
-struct EstepI8Args;
+// sample digits kept in HBM and the proof round over them (estep_i8.h: x_digits_kernel, estep_i8_proof)
+int64_t estep_i8_digit_row_bytes(int D);
+hipError_t launch_x_digits(const void* x, int x_is_f64, int64_t ldx, int64_t n_rows, int D, const double* pivot,
+                           unsigned char* xq, signed char* xqe, hipStream_t st);
 int estep_i8_pairs_per_chunk();
-hipError_t launch_estep_i8_pairs(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepI8Args& a, const int* lists,
-                                 int64_t cap, const int* counts, const int* plan, float* dist_up);
+// img = the 3-digit images; for every listed pair ub[k][row] <- upper bound (f32, rounded up), lb[k][row] <- lower bound of ln rho
+hipError_t launch_estep_i8_proof(int D, int grid, hipStream_t st, const unsigned char* xq, const signed char* xqe,
+                                 const unsigned char* img, const double* cvec, int K, const int* lists, int64_t cap,
+                                 const int* counts, const int* plan, float* ub, double* lb, int64_t npad);
 // int8-digit E-step (estep_i8.h): own parameter image (bytes per component), 256 rows per workgroup
 struct EstepI8Args {
     const void* x; int64_t ldx; int64_t n_rows; int D;

@@ -347,17 +347,18 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              unsigned char* __restrict__ lock /*null: no settled rows*/,
                                                              float* __restrict__ dlock,
                                                              float* __restrict__ rthr /*[npad] the row's relevance threshold*/,
-                                                             int fresh_ref /*dlock already holds bounds under the new parameters*/,
                                                              const unsigned char* __restrict__ lcomp /*[npad] component a cached row is in*/,
-                                                             int full_when_loose) {
+                                                             unsigned long long* __restrict__ pmask /*null: no proof round*/,
+                                                             int* __restrict__ pblk) {
     __shared__ int wcnt[4][256];
+    __shared__ int pcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
     __shared__ double sc[256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
-    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = pcnt[wave][k] = 0;
     for (int k = tid; k < K; k += kSelRows) {
         const double g = drift[k] * (1.0 - 1e-6);
         sp[k] = make_float4(g > 0.0 ? f32_down(g) : 0.0f, f32_up(drift[K + k]), f32_up(c_new[k]), f32_down(drift[2 * K + k]));
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
     const bool valid = n < n_rows;
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long pm[4] = {0ull, 0ull, 0ull, 0ull};        // pairs of the proof round (a settled row with candidates)
     int listed = 0, over_i = 0;
     if (valid) {
         const double ninf = -__builtin_huge_val();
@@ -400,9 +402,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         float d_set = 0.0f, thr_set = 0.0f;
         if (by_bound) {
             kset = lcomp[n];
-            // the distance bound: evaluated for the new parameters on the int8 pipe (estep_i8_pairs), or the previous
-            // pass's carried through Gamma and delta
-            const float dn = fresh_ref ? dlock[n] : fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
+            // the distance bound: the previous pass's carried through Gamma and delta
+            const float dn = fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
             const float lb = sq[kset].y - dn * dn * 0.5000005f;
             d_set = dn;
             thr_set = (lb - fabsf(lb) * 2.4e-7f) - 69.5f;
@@ -460,16 +461,28 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             else if (w == 2) mk[2] = mw;
             else mk[3] = mw;
         }
-        bool stays = false;
+        bool stays = false, proof_row = false;
         if (by_bound) {
             stays = (mk[0] | mk[1] | mk[2] | mk[3]) == 0ull;
             if (stays) {
                 dlock[n] = d_set;
+            } else if (pmask != nullptr) {
+                // Proof round: the row's component and the candidates get fresh two-sided bounds from three int8 digits
+                // (estep_i8_proof) before anything is evaluated in f64; rec_proof_decide_kernel then either keeps the row
+                // settled or hands it - with the candidates that survived - to the exact gather.  Until then the row has
+                // no pair in the pass's lists, and its record holds carried bounds only (no slot selected).
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    pm[w] = mk[w];
+                    mk[w] = 0ull;
+                }
+                pm[kset >> 6] |= 1ull << (kset & 63);
+                proof_row = true;
             } else {
                 mk[kset >> 6] |= 1ull << (kset & 63);          // loose: its component and the candidates are evaluated -
                 // in full: a candidate that left the gather early would keep a loose bound, erode back to the threshold
                 // within a pass or two and bring the row loose again; its exact value keeps the row settled for longer
-                if (full_when_loose) rthr[n] = -__builtin_huge_valf();
+                rthr[n] = -__builtin_huge_valf();
             }
         }
         // the exact pairs: their values replace the carried bounds, and they compete for slots by value (the single
@@ -531,11 +544,17 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         rec.B[n] = rest;
         rec.exact[n] = (unsigned char)(over ? 0 : ex);
         rec.sel[n] = (unsigned char)(over ? 0 : sel);
-        rec.flags[n] = (unsigned char)(stays ? 4 : (over ? 1 : (listed > in_slots ? 2 : 0)));
+        rec.flags[n] = (unsigned char)(stays ? 4 : (proof_row ? 8 : (over ? 1 : (listed > in_slots ? 2 : 0))));
         over_i = over ? 1 : 0;
-        for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
+        for (int w = 0; w < W; ++w) {
+            masks[(int64_t)w * npad + n] = mk[w];
+            if (pmask) pmask[(int64_t)w * npad + n] = pm[w];
+        }
     }
-    for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+    for (int w = 0; w < W; ++w) {
+        count_word(mk[w], w, wave, wcnt);
+        if (pmask) count_word(pm[w], w, wave, pcnt);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         listed += __shfl_xor(listed, o);
@@ -546,11 +565,108 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         wsum[1][wave] = over_i;
     }
     __syncthreads();
+    for (int k = tid; k < K; k += kSelRows) {
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        if (pmask) pblk[(int64_t)k * gridDim.x + blockIdx.x] = pcnt[0][k] + pcnt[1][k] + pcnt[2][k] + pcnt[3][k];
+    }
+    if (tid == 0) {
+        epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
+        opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
+    }
+}
+
+// After the proof round (estep_i8_proof over the pairs of pmask): every row the sweep flagged 8 has a lower bound of its
+// component's ln rho in lb[kset][n] and fresh upper bounds of its candidates in ub32.  A candidate whose bound lies below
+// lb - 100 ln 2 is irrelevant (r < 2^-100 against the row's log-normaliser >= lb): if all are, the row stays settled - its
+// responsibility is 1.0 to the last bit whatever the exact values (flag 4, new distance bound in dlock); otherwise the row
+// comes loose: its component and the surviving candidates join the pass's lists for the exact gather, slots that hold
+// one of them are marked selected (rec_finish_kernel finds the evaluated pairs through the slots and the mask), and the
+// row is evaluated in full (threshold -inf).  The kernel visits every row: it also recounts the pass's candidate masks
+// per block (blk_cnt, epart) now that rows have joined, and counts the proof round's pairs (ppart).
+__global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays rec, const unsigned long long* __restrict__ pmask,
+                                                                    unsigned long long* __restrict__ masks, int64_t npad,
+                                                                    int64_t n_rows, int K, const double* __restrict__ cvec,
+                                                                    const float* __restrict__ ub32, const double* __restrict__ lb,
+                                                                    const unsigned char* __restrict__ lcomp,
+                                                                    float* __restrict__ dlock, float* __restrict__ rthr,
+                                                                    int* __restrict__ blk_cnt, double* __restrict__ epart,
+                                                                    double* __restrict__ ppart) {
+    __shared__ int wcnt[4][256];
+    __shared__ int wsum[2][4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int W = (K + 63) / 64;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
+    const bool valid = n < n_rows;
+    unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+    int listed = 0, proved = 0;
+    if (valid) {
+        for (int w = 0; w < W; ++w) mk[w] = masks[(int64_t)w * npad + n];
+        if (rec.flags[n] == 8u) {
+            const int kset = lcomp[n];
+            const double l = lb[(int64_t)kset * npad + n];
+            const double thr = l - k100Ln2;                              // -inf when the proof kernel had no bound
+            unsigned long long kept[4] = {0ull, 0ull, 0ull, 0ull};
+            bool any = false;
+            for (int w = 0; w < W; ++w) {
+                unsigned long long m = pmask[(int64_t)w * npad + n];
+                proved += __builtin_popcountll(m);
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int k = 64 * w + b;
+                    if (k == kset) continue;
+                    const double u = (double)ub32[(int64_t)k * npad + n];
+                    if (!(u < thr)) {                                        // also NaN
+                        kept[w] |= 1ull << b;
+                        any = true;
+                    }
+                }
+            }
+            if (!any && l > -__builtin_huge_val()) {
+                rec.flags[n] = 4;
+                dlock[n] = f32_up(dist_of(cvec[kset], l) * (1.0 + 1e-9));
+            } else {
+                kept[kset >> 6] |= 1ull << (kset & 63);
+                unsigned sel = 0;
+                int in_slots = 0, total = 0;
+#pragma unroll
+                for (int j = 0; j < kRecSlots; ++j) {
+                    const unsigned short k = rec.k[(int64_t)j * rec.npad + n];
+                    if (k != kRecEmpty && ((kept[k >> 6] >> (k & 63)) & 1ull)) {
+                        sel |= 1u << j;
+                        ++in_slots;
+                    }
+                }
+                for (int w = 0; w < W; ++w) {
+                    mk[w] = kept[w];
+                    total += __builtin_popcountll(kept[w]);
+                    masks[(int64_t)w * npad + n] = kept[w];
+                }
+                rec.sel[n] = (unsigned char)sel;
+                rec.exact[n] = 0;
+                rec.flags[n] = (unsigned char)(total > in_slots ? 2 : 0);
+                rthr[n] = -__builtin_huge_valf();
+            }
+        }
+        for (int w = 0; w < W; ++w) listed += __builtin_popcountll(mk[w]);
+    }
+    for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        listed += __shfl_xor(listed, o);
+        proved += __shfl_xor(proved, o);
+    }
+    if ((tid & 63) == 0) {
+        wsum[0][wave] = listed;
+        wsum[1][wave] = proved;
+    }
+    __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
         blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
-        opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
+        ppart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
     }
 }
 
@@ -898,15 +1014,18 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
 
 // ctr[0] = sum apart (active pairs), ctr[1] = sum epart (exactly evaluated pairs), ctr[2] = sum opart (overflow rows),
 // ctr[3] = sum mpart (rows whose best component changed), ctr[4] = sum spart (settled rows), ctr[5] = sum gpart (pairs
-// in the E-step's lists), ctr[6] = sum qpart (pairs the M-step accumulates); a null part leaves its counter as it is.
+// in the E-step's lists), ctr[6] = sum qpart (pairs the M-step accumulates), ctr[7] = sum ppart (pairs of the proof round);
+// a null part leaves its counter as it is.
 // One workgroup per counter.
 __global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
                                                          const double* __restrict__ opart, const double* __restrict__ mpart,
                                                          const double* __restrict__ spart, const double* __restrict__ gpart,
-                                                         const double* __restrict__ qpart, int blocks, double* __restrict__ ctr) {
+                                                         const double* __restrict__ qpart, const double* __restrict__ ppart,
+                                                         int blocks, double* __restrict__ ctr) {
     __shared__ double part[16];
     const double* src = blockIdx.x == 0 ? apart : (blockIdx.x == 1 ? epart : (blockIdx.x == 2 ? opart :
-                        (blockIdx.x == 3 ? mpart : (blockIdx.x == 4 ? spart : (blockIdx.x == 5 ? gpart : qpart)))));
+                        (blockIdx.x == 3 ? mpart : (blockIdx.x == 4 ? spart : (blockIdx.x == 5 ? gpart :
+                        (blockIdx.x == 6 ? qpart : ppart))))));
     if (!src) return;
     double a = 0.0;                                   // (integer-valued addends below 2^53: any order is exact)
     for (int b = threadIdx.x; b < blocks; b += 1024) a += src[b];

@@ -62,7 +62,7 @@ struct gmmvb_workspace {
     // Written on the device at the end of every E-step and copied to pinned host memory behind an event; the NEXT
     // E-step / M-step reads whatever has arrived (policy decisions lag one pass, results never depend on them).
     // [4] settled rows (see below), [5] pairs in the M-step's lists.
-    // [6] pairs the M-step accumulates.
+    // [6] pairs the M-step accumulates, [7] pairs of the proof round (int8 two-sided bounds instead of f64 values).
     double* ctr = nullptr;             // [8] device
     double* ctr_host = nullptr;        // [8] pinned
     hipEvent_t ctr_ev = nullptr;
@@ -137,7 +137,6 @@ struct gmmvb_workspace {
     bool opt_debug = false;            // GMMVB_DEBUG: one line per E-step on stderr
     int opt_bound_blocks = 0;          // GMMVB_ESTEP_BOUND_BLOCKS: pinned level of the int8 bound pass (0: cost model)
     double opt_spare_weight = 2.5;     // GMMVB_SPARE_WEIGHT: weight of spare candidates against a fresh bound pass
-    bool opt_loose_exit = false;       // GMMVB_LOOSE_EXIT: rows that come loose may use the gather's early way out
     int opt_mstep_chunk = 1024;        // GMMVB_MSTEP_CHUNK: list entries per list M-step chunk
     bool opt_list_xc = false;          // GMMVB_MSTEP_LIST_XC: the list M-step reads the centred copy, not the f32 rows
     bool opt_small_off = false;        // GMMVB_MSTEP_SMALL_OFF: no mstep_small_f64 at one feature tile
@@ -145,8 +144,17 @@ struct gmmvb_workspace {
     bool opt_one_level = false;        // HMMVB_ONE_LEVEL: one-level boundary pass whatever the sequence length
     double opt_regroup_moved = 0.05;   // GMMVB_REGROUP_MOVED: share of rows that changed their best component before the rows are regrouped again
     float exit_margin = 0.0f;          // env GMMVB_EXIT_MARGIN: nats a partial bound must lie below the row's threshold
-    bool settle_i8 = false;            // env GMMVB_SETTLE_I8=1: settled rows' reference bounds are re-evaluated on the int8 pipe every pass instead of carried
-    double settle_margin_i8 = 5.0;     // nats of slack for settling when the reference is re-evaluated every pass
+    // Proof round (estep_i8.h, records.h): the three int8 digit planes of every row, in the internal row order, made with
+    // the centred copy (gmmvb_prepare_rows) and again when the rows are regrouped.  Valid for the matrix xq_src while the
+    // pivot they are centred on is the one the component images were packed for (xq_gen == img_gen).
+    unsigned char* xq = nullptr;       // [npad][3][32 ceil(D / 32)]
+    signed char* xqe = nullptr;        // [npad] exponent of the row's largest |x - pivot| (127: no digits)
+    const void* xq_src = nullptr;
+    int64_t xq_rows = 0, xq_ldx = 0;
+    int pivot_gen = 0, xq_gen = -1, img_gen = -2;
+    bool opt_proof = true;             // env GMMVB_PROOF=0: settled rows with candidates go straight to the f64 gather
+    double* ppart = nullptr;           // [blocks] pairs of the proof round per selection block
+    double lag_proof = 0.0;
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
     void* xp = nullptr;        // [max_rows][D] x in internal row order (storage dtype), allocated with the lists
     int* perm = nullptr, *iperm = nullptr, *perm_tmp = nullptr;   // [npad] each

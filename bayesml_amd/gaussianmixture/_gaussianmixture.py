@@ -156,32 +156,18 @@ class GenModel(base.Generative):
             x[n] = self.rng.multivariate_normal(mean=self.mu_vecs[k], cov=cov[k])
         return x, z
 
-    def _gen_sample_device(self, n, dev, dtype, chunk=1 << 22):
-        """z ~ Categorical(pi_vec), x = mu_z + L_z^-T eps with Lambda_z = L_z L_z^T, chunked over the rows."""
+    def _gen_sample_device(self, n, dev, dtype):
+        """z ~ Categorical(pi_vec), x = mu_z + eps L_z^-T with Lambda_z = L_z L_z^T (``bayesml_amd._sample``)."""
+        from .. import _sample
         gen = torch.Generator(device=dev).manual_seed(int(self.rng.integers(0, 2 ** 63 - 1)))
         pi = torch.as_tensor(self.pi_vec, dtype=torch.float64, device=dev)
         mu = torch.as_tensor(self.mu_vecs, dtype=torch.float64, device=dev)
-        chol = torch.linalg.cholesky(torch.as_tensor(self.lambda_mats, dtype=torch.float64, device=dev))
-        eye = torch.eye(self.c_degree, dtype=torch.float64, device=dev).expand_as(chol)
-        a = torch.linalg.solve_triangular(chol, eye, upper=False)          # a^T a = Lambda^-1: x = mu + eps a
-        x = torch.empty((n, self.c_degree), dtype=dtype, device=dev)
+        a = _sample.emission_factors(torch.as_tensor(self.lambda_mats, dtype=torch.float64, device=dev))
         z = torch.empty(n, dtype=torch.int64, device=dev)
-        for lo in range(0, n, chunk):
-            hi = min(n, lo + chunk)
-            zc = torch.multinomial(pi, hi - lo, replacement=True, generator=gen)
-            eps = torch.randn(hi - lo, self.c_degree, dtype=torch.float64, device=dev, generator=gen)
-            order = torch.argsort(zc)
-            counts = torch.bincount(zc, minlength=self.c_num_classes).tolist()
-            out = torch.empty_like(eps)
-            start = 0
-            for k, c in enumerate(counts):
-                if c:
-                    idx = order[start:start + c]
-                    out[idx] = mu[k] + eps[idx] @ a[k]
-                    start += c
-            x[lo:hi] = out.to(dtype)
-            z[lo:hi] = zc
-        return x, z
+        for lo in range(0, n, 1 << 22):
+            hi = min(n, lo + (1 << 22))
+            z[lo:hi] = torch.multinomial(pi, hi - lo, replacement=True, generator=gen)
+        return _sample.draw_emissions(z, mu, a, gen, dtype), z
 
     def save_sample(self, filename, sample_size):
         """``numpy.savez_compressed(filename, x=x, z=z)`` (ref:266-284)."""

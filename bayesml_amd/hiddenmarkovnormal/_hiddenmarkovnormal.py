@@ -134,9 +134,21 @@ class GenModel(base.Generative):
                 mean=self.h_m_vecs[k], cov=np.linalg.inv(self.h_kappas[k] * self.lambda_mats[k]))
         return self
 
-    def gen_sample(self, sample_length):
-        """(x [T, D], one-hot z [T, K]) with the reference's per-step draws (ref:344-358)."""
+    def gen_sample(self, sample_length, *, device=None, dtype=torch.float64):
+        """(x [T, D], one-hot z [T, K]) with the reference's per-step draws (ref:344-358).
+
+        Extension: with ``device`` (e.g. ``"cuda"``) the sequence is drawn ON that device - the Markov chain as a
+        chunk-parallel composition of per-step state maps, the emissions in one batched pass (``bayesml_amd._sample``) -
+        and returned as torch tensors ``(x [T, D] of ``dtype``, z [T] int64 state indices)``; the reference's loop takes
+        2.4 s per 2e4 steps.  Seeded from ``self.rng`` (reproducible per ``seed``), not the reference's stream."""
         _check.pos_int(sample_length, "sample_length", DataFormatError)
+        if device is not None:
+            from .. import _sample
+            dev = torch.device(device)
+            gen = torch.Generator(device=dev).manual_seed(int(self.rng.integers(0, 2 ** 63 - 1)))
+            t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)      # noqa: E731
+            z = _sample.markov_chain(t(self.pi_vec), t(self.a_mat), int(sample_length), gen)
+            return _sample.draw_emissions(z, t(self.mu_vecs), _sample.emission_factors(t(self.lambda_mats)), gen, dtype), z
         K = self.c_num_classes
         z = np.zeros([sample_length, K], dtype=int)
         x = np.empty([sample_length, self.c_degree])

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GMMVB_ABI_VERSION 2
+#define GMMVB_ABI_VERSION 3
 
 enum gmmvb_status {
     GMMVB_OK = 0,
@@ -174,7 +174,7 @@ int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms)
 /* Finer view of the same profile: HIP-event time (ms, summed over the launches of a group) and number of launch
  * groups per slot for the last gmmvb_estep + gmmvb_mstep; gmmvb_profile_span_name(slot) names the slots
  * ("estep_main" = dense / bound kernel, "estep_select", "estep_gather", "estep_lse_mask", "mstep_lists",
- * "mstep_main" = dense / list kernel, "mstep_reduce"; "" = unused).  Waits for the last recorded event. */
+ * "mstep_main" = dense / list kernel, "mstep_reduce", "estep_proof" = the int8 proof round).  Waits for the last recorded event. */
 int gmmvb_profile_spans(gmmvb_workspace* ws, float* ms /*[8]*/, int* launches /*[8]*/);
 const char* gmmvb_profile_span_name(int slot);
 
@@ -260,6 +260,13 @@ int64_t gmmvb_regroup_count(const gmmvb_workspace* ws);
  * component [20], lse [21], the row's mask words [22..25]. */
 int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26], host*/);
 
+/* test / diagnostic: the proof round's kernel (csrc/estep_i8.h, estep_i8_proof: three int8 digits per operand, exact int32
+ * accumulation, rigorous error term) for component k and EVERY row of the matrix last given to gmmvb_prepare_rows, in the
+ * caller's row order if the rows have not been regrouped: ub_dev[n] >= ln rho_nk >= lb_dev[n] under the parameters of
+ * the last gmmvb_set_params.  Discards the workspace's E-step state. */
+int gmmvb_debug_proof(gmmvb_workspace* ws, int k, int64_t n_rows, float* ub_dev /*[n_rows]*/, double* lb_dev /*[n_rows]*/,
+                      void* stream);
+
 /* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
  * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
  * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  *active_pairs = -1 when the
@@ -272,8 +279,11 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
  * r = 1.0 exactly keep their addend in a cache and are only touched when that changes; -1: not counted), out[3] rows the
  * E-step did not evaluate at all (settled: their carried bounds prove that nothing changed), out[4] of the pairs in
  * out[1], those whose evaluation stopped after half of the output blocks because the partial sum already put them below
- * the row's relevance threshold (they cost 10 of the 36 tile pairs at D = 128). */
-int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[5], host*/);
+ * the row's relevance threshold (they cost 10 of the 36 tile pairs at D = 128), out[5] pairs of the proof round: settled
+ * rows whose carried bounds left candidates get two-sided bounds of their component and of the candidates from three int8
+ * digits (about a fifth of an exact evaluation's cost) - rows that are proven to keep a single active component are not
+ * evaluated at all (their responsibility is 1.0 to the last bit whatever the value); out[6], out[7] reserved (0). */
+int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[8], host*/);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,11 @@
       run-to-run determinism, linearity over row shards (two halves add up to the whole to 1e-12),
       the centred second moments are shift-consistent (trace identity against a direct torch reduction).
   C5  HMM K=32, D=16, T=1e7:  sum ns = T, sum ms = T - 1 (every xi_t sums to one), rows of gamma sum to one.
+  C3 / C4 through the SPARSE path the benchmark times (bound pass -> sweeps of carried bounds -> settled rows and their
+      int8 proof round -> cache of single-component rows -> regrouped rows -> list M-step), driven exactly like
+      update_posterior's loop: after >= 10 hinted iterations the statistics block of the last (carried) pass must equal,
+      to rounding, what the DENSE kernels give for the same parameters on the same rows; sum ns = N; the counters show
+      that every one of those mechanisms really ran.
 """
 import numpy as np
 import pytest
@@ -108,3 +113,60 @@ def test_hmm_c5_full_size_properties():
     assert float((ms.sum(dim=1) - (ns - gl)).abs().max()) < 1e-6
     assert float((ms.sum(dim=0) - (ns - g0)).abs().max()) < 1e-6
     eng.close()
+
+
+def _sparse_vs_dense(K, D, N, iters, tol):
+    """bench.py's workload at full size: `iters` VB iterations as update_posterior runs them, then the last pass's
+    statistics against a dense data pass on the same parameters."""
+    import bench
+    from bayesml_amd._engine import DataPass
+    dev = torch.device("cuda", 0)
+    x = bench.device_rows(K, D, N, torch.float32, dev, bench.SEED + 1, 2.0)
+    w = bench.Workload(K, D, x, dev, None)
+    seen = dict(settled=0.0, proof=0.0, cached=0.0)
+    for _ in range(iters):
+        w.step()
+        wk = w.eng.work()
+        seen["settled"] = max(seen["settled"], wk["settled_rows"])
+        seen["proof"] = max(seen["proof"], wk["proof_pairs"])
+        if wk["accumulated"] >= 0:
+            seen["cached"] = max(seen["cached"], wk["active"] - wk["accumulated"])
+    counts = w.eng.pass_counts()
+    assert w.eng.launch_info.startswith("estep_sweep"), w.eng.launch_info          # the compared pass lived on carried bounds
+    assert counts["estep_bound"] >= 1 and counts["estep_sweep"] >= 4 and counts["mstep_list"] >= 5, counts
+    assert counts["estep_gather"] >= 8 and w.eng.regroup_count >= 1, counts
+    assert seen["cached"] > 0.3 * N and seen["settled"] > 0.1 * N and seen["proof"] > 0, seen
+    wk = w.eng.work()
+    assert wk["evaluated"] < 0.1 * N * K and 0.99 * N <= wk["active"] < 3.0 * N, wk
+    sparse = w.ks.stats.clone()
+    q = w.q
+    ns = sparse[:K]
+    assert abs(float(ns.sum()) - N) < 1e-6
+    with bench.env_vars(GMMVB_ESTEP_PRUNE="0", GMMVB_MSTEP_SPARSE="0"):       # switches are read at workspace creation
+        ref = DataPass(K, D, x.dtype, N, dev)
+    ref.set_pivot(w.eng.pivot)
+    ref.prepare_rows(w.xd)
+    ref.set_params(q.c, q.m, q.u)
+    dense = ref.estep_mstep(w.xd)
+    assert ref.pass_counts()["estep_dense"] == 1 and ref.pass_counts()["mstep_dense"] == 1
+    for name, a_, b_ in zip(("ns", "h", "a", "B"), w.eng.split_stats(sparse), ref.split_stats(dense)):
+        rel = float((a_ - b_).abs().max() / b_.abs().max())
+        assert rel < tol, (name, rel)
+    # hard assignments of the sparse pass (settled rows included, in the caller's row order) against the dense pass's
+    zs = w.eng.argmax(0, 1 << 16).cpu()
+    zd = ref.argmax(0, 1 << 16).cpu()
+    assert torch.equal(zs, zd)
+    rs = w.eng.responsibilities(N - 4096, 4096)
+    rd = ref.responsibilities(N - 4096, 4096)
+    assert float((rs - rd).abs().max()) < 1e-9
+    ref.close()
+    w.close()
+
+
+def test_gmm_c3_full_size_sparse():
+    _sparse_vs_dense(64, 128, 10_000_000, iters=12, tol=1e-12)
+
+
+def test_gmm_c4_shard_full_size_sparse():
+    """One GPU's shard of config 4: K=256, D=64, 1.25e7 rows (N = 1e8 over 8 GPUs)."""
+    _sparse_vs_dense(256, 64, 12_500_000, iters=14, tol=1e-12)

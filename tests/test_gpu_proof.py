@@ -1,0 +1,89 @@
+"""The proof round's kernel (csrc/estep_i8.h: x_digits_kernel + estep_i8_proof) against the ORACLE: for every row and a
+given component the two values it returns must enclose the oracle's ln rho (reference ``_gaussianmixture.py:773-781``)
+- that is all the pruned E-step relies on when it keeps a settled row out of the exact evaluation - and they must be
+tight enough to be of use (a few 1e-5 of the whitened distance)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gmm_vb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _posterior(K, D, x64, seed=0, iters=2):
+    p = orc.Prior.default(K, D)
+    q = orc.Posterior.from_prior(p)
+    orc.init_subsampling(x64, q, np.random.default_rng(seed))
+    st = orc.data_pass(x64, q)
+    for _ in range(iters):
+        orc.update_q_mu_lambda(p, q, st)
+        orc.update_q_pi(p, q, st)
+        st = orc.data_pass(x64, q, st.s)
+    return q, st
+
+
+def _engine(K, D, x, q, dev, pivot_rows=None):
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
+    qd = _kside.features(_kside.PostT(t(q.alpha), t(q.m), t(q.kappa), t(q.nu), t(q.w_inv)))
+    xd = torch.from_numpy(x).to(dev)
+    eng = DataPass(K, D, xd.dtype, x.shape[0], dev)
+    src = xd[:1024] if pivot_rows is None else torch.from_numpy(pivot_rows).to(dev)
+    eng.set_pivot(src.to(torch.float64).mean(dim=0))
+    eng.prepare_rows(xd)
+    eng.set_params(qd.c, qd.m, qd.u)
+    return eng, xd
+
+
+@pytest.mark.parametrize("K,D,N,dtype", [(8, 128, 6000, np.float32), (12, 80, 5000, np.float32), (6, 64, 4097, np.float64),
+                                         (5, 49, 3000, np.float32)])
+def test_proof_bounds_enclose_the_oracle(K, D, N, dtype):
+    x = orc.synth_gmm(K, D, N, dtype)
+    x64 = x.astype(np.float64)
+    q, st = _posterior(K, D, x64)
+    dev = torch.device("cuda", 0)
+    eng, _xd = _engine(K, D, x, q, dev)
+    for k in range(K):
+        ub, lb = eng.debug_proof(k, N)
+        ub, lb = ub.cpu().numpy().astype(np.float64), lb.cpu().numpy()
+        exact = st.ln_rho[:, k]
+        assert np.all(lb <= exact), (k, float(np.max(lb - exact)))
+        assert np.all(ub >= exact), (k, float(np.max(exact - ub)))
+        # tightness: both within 1e-4 of the quadratic form (+ f32 rounding of the upper bound)
+        quad = np.abs(exact) + 1.0
+        assert np.max((ub - lb) / quad) < 3e-4, (k, float(np.max((ub - lb) / quad)))
+    eng.close()
+
+
+def test_proof_bounds_on_awkward_rows():
+    """Rows the digits cannot represent (non-finite, huge) must come back without a bound: lower = -inf, upper >= the
+    trivial bound's truth; ordinary rows next to them are unaffected.  An ill-conditioned component keeps valid bounds."""
+    K, D, N = 4, 128, 2048
+    x = orc.synth_gmm(K, D, N, np.float32)
+    x[5, 7] = np.inf
+    x[9, 100] = np.nan
+    x[11, :] = 0.0
+    x[13, 3] = 3e30
+    x64 = x.astype(np.float64)
+    good = np.ones(N, dtype=bool)
+    good[[5, 9, 13]] = False
+    q, _st = _posterior(K, D, x64[good])
+    q.w[1] *= 1e6                      # E[Lambda_1] scaled by 1e6 (a narrow component): distances of 1e3 per coordinate
+    q.w_inv[1] /= 1e6
+    q.refresh_pi()
+    q.refresh_lambda()
+    with np.errstate(all="ignore"):
+        st = orc.data_pass(np.where(np.isfinite(x64), x64, 0.0), q)
+    dev = torch.device("cuda", 0)
+    eng, _xd = _engine(K, D, x, q, dev, pivot_rows=x[good][:1024])
+    for k in range(K):
+        ub, lb = eng.debug_proof(k, N)
+        ub, lb = ub.cpu().numpy().astype(np.float64), lb.cpu().numpy()
+        exact = st.ln_rho[:, k]
+        assert np.all(lb[good] <= exact[good]) and np.all(ub[good] >= exact[good]), k
+        for bad in (5, 9, 13):
+            assert lb[bad] == -np.inf, (k, bad, lb[bad])
+            assert not (ub[bad] < lb[bad])
+    eng.close()

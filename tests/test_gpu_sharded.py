@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import rel_err
+from conftest import load_golden, mat_functionals, rel_err
 from oracle import gmm_vb_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -88,3 +88,109 @@ def test_c_abi_comm_argument_errors():
     assert lib.gmmvb_comm_create(None, 1, 0, ctypes.byref(h)) == 1
     assert lib.gmmvb_allreduce_stats(None, None, 0, None) == 1
     assert lib.gmmvb_comm_destroy(None) == 0
+
+
+# ---- sharded AND sparse, with the two ranks on different pass policies ------------------------------------------------
+def _sparse_worker(rank, world, port, out_dir):
+    """Half of the reference fixture K=64, D=128, N=140000 per rank, pruning forced (a half is below the default policy's
+    size threshold); rank 1 additionally ignores the drift hint, so it runs a fresh bound pass where rank 0 carries."""
+    import json
+    os.environ["GMMVB_ESTEP_PRUNE"] = "force"
+    if rank == 1:
+        os.environ["GMMVB_ESTEP_CARRY_OFF"] = "1"
+    from bayesml_amd import RowShard
+    from bayesml_amd import gaussianmixture as gm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden("gmm_f3_k64_d128_n140000_f32.npz")
+    Kk, Dd, Nn = int(g["K"]), int(g["D"]), int(g["N"])
+    x = orc.synth_gmm(int(g["K_data"]), Dd, Nn, np.float32, spread=float(g["spread"]))
+    half = Nn // 2 + 333
+    lo, hi = (0, half) if rank == 0 else (half, Nn)
+    m = gm.LearnModel(Kk, Dd, seed=int(g["seed"]), comm=RowShard(), device="cuda:0", verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.update_posterior(x[lo:hi], **json.loads(str(g["kw"])))
+    counts = m._engine.pass_counts()
+    np.savez(os.path.join(out_dir, f"sparse_rank{rank}.npz"), vl=m.vl, ns=m.ns, x_bar=m.x_bar_vecs,
+             w_inv=m.hn_w_mats_inv, s=m.s_mats, counts=json.dumps(counts), **m.get_hn_params())
+    dist.destroy_process_group()
+
+
+def test_two_sparse_ranks_with_different_policies_match_the_reference(tmp_path):
+    import json
+    mp.spawn(_sparse_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g = load_golden("gmm_f3_k64_d128_n140000_f32.npz")
+    res = [dict(np.load(os.path.join(str(tmp_path), f"sparse_rank{r}.npz"))) for r in range(2)]
+    c0, c1 = (json.loads(str(r["counts"])) for r in res)
+    assert c0["estep_bound"] >= 1 and c0["estep_sweep"] + c0["estep_carried"] >= 3 and c0["mstep_list"] >= 3, c0
+    assert c1["estep_sweep"] == c1["estep_carried"] == 0 and c1["estep_bound"] > c0["estep_bound"], (c0, c1)
+    for r in res:
+        for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus"):
+            assert rel_err(r[key], g[key]) < 1e-6, key
+        for key, got in (("hn_w_mats", r["hn_w_mats"]), ("hn_w_mats_inv", r["w_inv"])):
+            for fn, val in mat_functionals(got).items():
+                ref = g[f"{key}_{fn}"]
+                if fn == "logabsdet":
+                    assert np.max(np.abs(val - ref)) < 1e-6 * max(1.0, float(np.max(np.abs(ref)))), (key, fn)
+                else:
+                    assert rel_err(val, ref) < 1e-6, (key, fn)
+        assert rel_err(r["ns"], g["ns"]) < 1e-6 and rel_err(r["x_bar"], g["x_bar_vecs"]) < 1e-6
+        assert abs(float(r["vl"]) - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+    for key in ("hn_m_vecs", "hn_w_mats", "ns"):          # both ranks hold the same posterior, bit for bit
+        assert np.array_equal(res[0][key], res[1][key]), key
+
+
+# ---- restart-level parallelism on the real engine ---------------------------------------------------------------------
+def _restart_worker(rank, world, port, out_dir):
+    import io
+    from contextlib import redirect_stdout
+    from bayesml_amd import RestartShard
+    from bayesml_amd import gaussianmixture as gm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = load_golden("gmm_c1_sample.npz")["x"]
+    m = gm.LearnModel(3, 2, seed=0, comm=RestartShard(), device="cuda:0")
+    with redirect_stdout(io.StringIO()) as buf, warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.update_posterior(x)
+    np.savez(os.path.join(out_dir, f"restart_rank{rank}.npz"), vl=m.vl, ns=m.ns, stdout=buf.getvalue(), warned=len(w) > 0,
+             **m.get_hn_params())
+    dist.destroy_process_group()
+
+
+def test_restarts_over_two_ranks_on_the_real_engine(tmp_path):
+    """comm = RestartShard (reference loop ``_gaussianmixture.py:847-883``) with the HIP engine: restart i
+    runs on rank i mod 2; winner, lower-bound trace and posterior are those of the single-process GPU run, bit for bit,
+    and the reference's (fixture gmm_f3_c1_subsampling.npz)."""
+    import io
+    from contextlib import redirect_stdout
+    from bayesml_amd import gaussianmixture as gm
+    mp.spawn(_restart_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g = load_golden("gmm_f3_c1_subsampling.npz")
+    x = load_golden("gmm_c1_sample.npz")["x"]
+    one = gm.LearnModel(3, 2, seed=0, device="cuda:0")
+    with redirect_stdout(io.StringIO()) as buf, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one.update_posterior(x)
+    text = buf.getvalue()
+    ranks = [dict(np.load(os.path.join(str(tmp_path), f"restart_rank{r}.npz"))) for r in range(2)]
+    for r, res in enumerate(ranks):
+        for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+            assert np.array_equal(res[key], one.get_hn_params()[key]), (r, key)
+            assert rel_err(res[key], g[key]) < 1e-7, (r, key)
+        assert float(res["vl"]) == one.vl
+        assert bool(res["warned"]) == bool(g["result_warning"])
+    assert str(ranks[0]["stdout"]) == text and str(ranks[1]["stdout"]) == ""
+    stars = [ln.endswith("*") for ln in text.split("\n") if ln.strip()]
+    assert max(i for i, s in enumerate(stars) if s) == int(g["winner"])
+    lines = [ln for ln in text.split("\n") if ln.strip()]
+    tr = g["vl_trace"]
+    for i, ln in enumerate(lines):
+        vals = [float(seg.split("VL: ")[1].split(" ")[0].rstrip("*").replace("(converged)", "")) for seg in ln.split("\r") if seg]
+        ref = tr[i][~np.isnan(tr[i])]
+        assert len(vals) == len(ref) and np.allclose(vals, ref, rtol=1e-9, atol=0), i

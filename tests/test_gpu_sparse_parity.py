@@ -22,18 +22,22 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_GAMMA",
-            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE", "GMMVB_SETTLE_I8", "GMMVB_SETTLE_MARGIN_I8", "GMMVB_GATHER_EXIT",
+            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT",
             "GMMVB_SETTLE_SPARE", "GMMVB_ESTEP_RECORDS")
 VARIANTS = {
     "default": {},
-    # rows with a single active component are settled (left out of the E-step on the strength of their carried bounds)
-    # whatever the drift and the spare candidates of the last sweep, with 10 nats of slack: the read-outs below need
-    # their values re-evaluated
-    "settle": {"GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
-    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10",
-                     "GMMVB_SETTLE_SPARE": "1000"},
-    # ... with their reference bound re-evaluated every pass on the int8 pipe (estep_i8_pairs) instead of carried
-    "force_settle_i8": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_I8": "1", "GMMVB_SETTLE_MARGIN_I8": "0"},
+    # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, with 5 nats
+    # of slack; a settled row whose carried bounds leave candidates goes through the int8 proof round (estep_i8_proof).
+    # "settle": no slack at all, so that most settled rows have candidates in the next pass and the proof round decides;
+    # the read-outs below need the settled rows' values re-evaluated
+    "settle": {"GMMVB_SETTLE_MARGIN": "0"},
+    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_MARGIN": "0"},
+    # ... without the proof round: rows settle on the strength of their carried bounds only (whatever the drift and the
+    # spare candidates of the last sweep, 10 nats of slack) and come loose into the exact gather
+    "settle_noproof": {"GMMVB_PROOF": "0", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
+    "force_settle_noproof": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "0", "GMMVB_SETTLE_GAMMA": "0",
+                             "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
+    "nosettle": {"GMMVB_SETTLE_MARGIN": "-1"},
     # the pass on 55-byte records (one rest bound per row) instead of the sweep of per-pair bounds
     "force_records": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_RECORDS": "1"},
     "nocache": {"GMMVB_MSTEP_CACHE": "0"},
@@ -96,7 +100,7 @@ def expect_kernels(counts, variant, min_carried=1, lists=True):
         assert counts["mstep_list"] >= 1, counts
     if variant == "force_nocarry":
         assert counts["estep_carried"] == counts["estep_sweep"] == 0, counts
-    elif variant in ("settle", "force_settle", "force_settle_i8"):
+    elif variant in ("settle", "force_settle", "settle_noproof", "force_settle_noproof"):
         assert counts["estep_sweep"] >= 2, counts
     else:       # carried over the parameter update: on per-row records, or (early in a fit) by a sweep of the dense array
         assert counts["estep_carried"] + counts["estep_sweep"] >= min_carried, counts
@@ -120,7 +124,8 @@ def test_small_fixture_forced_sparse_matches_reference(variant):
 
 
 LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n140000_f32.npz", "force_nocarry"),
-         ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "settle_noproof"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "nosettle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
@@ -157,7 +162,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if "overlap" not in name and variant in ("default", "settle", "nocache", "noexit"):
+    if "overlap" not in name and variant in ("default", "settle", "settle_noproof", "nosettle", "nocache", "noexit"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -168,8 +173,12 @@ def test_large_fixture_matches_reference(name, variant):
             assert 0 <= wk["accumulated"] <= wk["active"], wk
             if swept:
                 assert wk["accumulated"] < 0.7 * wk["active"], wk
-        if variant == "settle" and swept:
+        if variant in ("settle", "settle_noproof") and swept:
             assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
+        if variant == "nosettle":
+            assert wk["settled_rows"] == 0 and wk["proof_pairs"] == 0, wk
+        if variant == "settle_noproof":
+            assert wk["proof_pairs"] == 0, wk
     if variant == "default" and "overlap" not in name:
         # the workspace regrouped its internal row order by dominant component on the way: every
         # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless
@@ -195,7 +204,7 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_i8", "force_records"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_noproof", "force_records"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
@@ -210,7 +219,7 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     with env(VARIANTS[variant]):
         m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
         eng, xd = m._open(x)
-    settled_seen = cached_seen = 0.0
+    settled_seen = cached_seen = proof_seen = 0.0
     prior = m._prior_tensors(dev)
     q = m._init_subsampling(eng, xd, _kside.post_from_prior(prior), N)
     s = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
@@ -227,6 +236,7 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
             continue
         wk = eng.work()
         settled_seen = max(settled_seen, wk["settled_rows"])
+        proof_seen = max(proof_seen, wk["proof_pairs"])
         if variant == "force_records":
             assert eng.launch_info.startswith("estep_carried"), eng.launch_info
         if it >= 6 and wk["accumulated"] >= 0:
@@ -246,11 +256,15 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         checked += 1
     assert checked >= 3, eng.pass_counts()
     assert cached_seen > 0.1 * N, cached_seen       # single-component rows the M-step did not accumulate again
-    if variant in ("force_settle", "force_settle_i8"):       # rows that were not evaluated at all: read out exactly all the same
+    if variant in ("force_settle", "force_settle_noproof"):  # rows that were not evaluated at all: read out exactly all the same
         assert settled_seen > 0.1 * N, settled_seen
+    if variant == "force_settle":                            # ... many of them on the strength of the int8 proof round
+        assert proof_seen > 0.01 * N, proof_seen
+    if variant == "force_settle_noproof":
+        assert proof_seen == 0
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_i8"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_noproof"])
 def test_cache_survives_unusual_call_orders(variant):
     """The cache of single-component rows is internal state of the workspace: whatever order the entry points are
     called in - an M-step twice, an E-step twice without an M-step, read-outs between the two - the statistics and
