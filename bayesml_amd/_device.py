@@ -53,6 +53,8 @@ class DeviceModel:
                 eng = DataPass(K, D, xd.dtype, xd.shape[0], dev)
         self._engine, self._x_dev, self._r_cache = eng, xd, None
         self._comm.bind_rows(xd.shape[0], xd.device)
+        if hasattr(eng, "set_shard") and not getattr(self._comm, "restart_parallel", False):
+            eng.set_shard(self._comm.global_rows, self._comm.world)      # row shards decide their pass policy together
         # expansion point of the second moments: mean of the leading rows (any fixed point near the data works)
         head = xd[: min(xd.shape[0], 4096)].to(torch.float64)
         cnt = torch.tensor([float(head.shape[0])], dtype=torch.float64, device=xd.device)

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgmmvb.so")
 
 GMMVB_F32, GMMVB_F64 = 0, 1
+POLICY_LEN = 16           # include/gmmvb.h: GMMVB_POLICY_LEN
 _STATUS = {0: "GMMVB_OK", 1: "GMMVB_EINVAL", 2: "GMMVB_EUNSUPPORTED", 3: "GMMVB_EHIP", 4: "GMMVB_ENOMEM",
            5: "GMMVB_ESTATE"}
 
@@ -54,6 +55,9 @@ SYMBOLS = {
     "gmmvb_comm_create": (_int, [_vp, _int, _int, ctypes.POINTER(_vp)]),
     "gmmvb_comm_destroy": (_int, [_vp]),
     "gmmvb_allreduce_stats": (_int, [_vp, _vp, _i64, _vp]),
+    "gmmvb_set_shard": (_int, [_vp, _i64, _int]),
+    "gmmvb_policy_export": (_int, [_vp, _vp, _vp]),
+    "gmmvb_policy_import": (_int, [_vp, _vp, _vp]),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
     "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -360,6 +364,19 @@ class DataPass:
             _check(self.lib, self.lib.gmmvb_set_params(self._ws, c.data_ptr(), m.data_ptr(), u.data_ptr(),
                                                        self._stream()), "gmmvb_set_params")
         self._keep = [c, m, u]
+
+    def set_shard(self, global_rows: int, n_ranks: int):
+        """This workspace holds one shard of a row-sharded job: pass-policy decisions use job-wide numbers only
+        (gmmvb_set_shard), fed by policy_export / all-reduce / policy_import around the iteration's collective."""
+        _check(self.lib, self.lib.gmmvb_set_shard(self._ws, int(global_rows), int(n_ranks)), "gmmvb_set_shard")
+
+    def policy_export(self, tail: torch.Tensor):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_policy_export(self._ws, tail.data_ptr(), self._stream()), "gmmvb_policy_export")
+
+    def policy_import(self, tail: torch.Tensor):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.gmmvb_policy_import(self._ws, tail.data_ptr(), self._stream()), "gmmvb_policy_import")
 
     def wants_drift(self, n_rows: int) -> bool:
         return bool(self.lib.gmmvb_wants_drift(self._ws, int(n_rows)))

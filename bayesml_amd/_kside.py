@@ -388,7 +388,11 @@ class KStepper:
         dev = prior.m.device
         self.prior, self.pivot, self.K, self.D = prior, pivot, K, D
         self.want_drift = want_drift
-        self.stats = torch.zeros(stats_len, dtype=torch.float64, device=dev)      # the data pass writes here
+        # the data pass writes `stats`; behind it, in the same allocation, the engine's policy counters of a row-sharded
+        # job (include/gmmvb.h: GMMVB_POLICY_LEN): one all-reduce of `stats_and_tail` carries both
+        self.stats_and_tail = torch.zeros(stats_len + 16, dtype=torch.float64, device=dev)
+        self.stats = self.stats_and_tail[:stats_len]
+        self.tail = self.stats_and_tail[stats_len:]
         self.s_prev = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
         self.q = _clone_post(post_from_prior(prior))
         self.q_next = _clone_post(self.q)

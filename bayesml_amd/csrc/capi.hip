@@ -228,6 +228,8 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
+    if (ws->pol_host) (void)hipHostFree(ws->pol_host);
+    if (ws->pol_ev) (void)hipEventDestroy(ws->pol_ev);
     if (ws->exit_host) (void)hipHostFree(ws->exit_host);
     if (ws->ctr_ev) (void)hipEventDestroy(ws->ctr_ev);
     for (int* p : ibufs)
@@ -327,6 +329,7 @@ int gmmvb_set_pivot(gmmvb_workspace* ws, const double* pivot_dev, void* stream) 
 int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows) {
     if (!ws || ws->prune == 0 || ws->estep_variant != kEstepLds8 || ws->hmm != nullptr || !ws->rec_k) return 0;
     if (ws->opt_carry_off) return 0;
+    if (ws->sharded) n_rows = ws->shard_rows / ws->shard_ranks;        // the same answer on every rank
     return (ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23)) ? 1 : 0;
 }
 
@@ -414,7 +417,7 @@ int gmmvb_debug_proof(gmmvb_workspace* ws, int k, int64_t n_rows, float* ub_dev,
     ws->bounds_rows = 0;
     ws->rec_valid = ws->dense_valid = ws->rec_live = false;
     ws->active_lists = ws->blk_fresh = false;
-    ws->lag_valid = false;
+    ws->lag.valid = false;
     if (ws->lock_live) {
         ws->lock_live = false;
         ws->lock_reset = true;
@@ -528,29 +531,31 @@ static int fetch_counters(gmmvb_workspace* ws) {
     if (ws->ctr_pending) {
         hipError_t e = hipEventSynchronize(ws->ctr_ev);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "waiting for the E-step counters", e);
-        ws->lag_act = ws->ctr_host[0];
+        ws->lag.act = ws->ctr_host[0];
         if (ws->pend_mode == 0) {              // dense pass: every pair evaluated, no records involved
-            ws->lag_eval = (double)ws->pend_rows * ws->K;
-            ws->lag_over = 0.0;
-            ws->lag_settled = 0.0;
-            ws->lag_listed = ws->lag_accum = ws->lag_act;
-            ws->lag_exits = 0.0;
-            ws->lag_proof = 0.0;
+            ws->lag.eval = (double)ws->pend_rows * ws->K;
+            ws->lag.over = 0.0;
+            ws->lag.settled = 0.0;
+            ws->lag.listed = ws->lag.accum = ws->lag.act;
+            ws->lag.exits = 0.0;
+            ws->lag.proof = 0.0;
+            ws->lag.moved = 0.0;
         } else {
-            ws->lag_proof = ws->ctr_host[7];
-            ws->lag_exits = (ws->exit_host && ws->gather_exit) ? (double)*ws->exit_host : 0.0;
-            ws->lag_settled = ws->ctr_host[4];
-            ws->lag_listed = ws->ctr_host[5];
-            ws->lag_accum = ws->ctr_host[6];                               // a bound pass / sweep also evaluated every row's (previous) best component
-            ws->lag_eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? ws->pend_round0 : 0.0);
-            ws->lag_over = ws->ctr_host[2];
+            ws->lag.proof = ws->ctr_host[7];
+            ws->lag.exits = (ws->exit_host && ws->gather_exit) ? (double)*ws->exit_host : 0.0;
+            ws->lag.settled = ws->ctr_host[4];
+            ws->lag.listed = ws->ctr_host[5];
+            ws->lag.accum = ws->ctr_host[6];                               // a bound pass / sweep also evaluated every row's (previous) best component
+            ws->lag.eval = ws->ctr_host[1] + ((ws->pend_mode == 1 || ws->pend_mode == 3) ? ws->pend_round0 : 0.0);
+            ws->lag.over = ws->ctr_host[2];
             // rows whose best component changed: after a regrouping they no longer sit with their component's rows.
             // (the first pass after a regrouping compares with the bound kernel's guess, not with a previous best)
-            if (ws->sorted && !ws->pend_first_sorted) ws->moved_since_sort += ws->ctr_host[3];
+            ws->lag.moved = ws->ctr_host[3];
+            if (!ws->sharded && ws->sorted && !ws->pend_first_sorted) ws->moved_since_sort += ws->lag.moved;
         }
-        ws->lag_rows = ws->pend_rows;
-        ws->lag_mode = ws->pend_mode;
-        ws->lag_valid = true;
+        ws->lag.rows = (double)ws->pend_rows;
+        ws->lag.mode = ws->pend_mode;
+        ws->lag.valid = true;
         ws->ctr_pending = false;
     }
     return GMMVB_OK;
@@ -562,14 +567,106 @@ static void poll_counters(gmmvb_workspace* ws) {
     if (ws->ctr_pending && hipEventQuery(ws->ctr_ev) == hipSuccess) (void)fetch_counters(ws);
 }
 
+// ---- row-sharded jobs: one policy for all ranks ------------------------------------------------------------------------
+// The choice of pass (dense / bound / sweep / records, regrouping, bound level, settling) is driven by counters of the
+// previous pass.  With the rows sharded over ranks each rank would see its own counters and the ranks would drift apart:
+// a 40-ms bound pass on one rank while the others sweep in 8 ms stalls everybody at the iteration's all-reduce.  So the
+// counters travel with the statistics block: gmmvb_policy_export writes them (GMMVB_POLICY_LEN doubles) where the caller's
+// all-reduce picks them up, gmmvb_policy_import hands the sums back, and a sharded workspace (gmmvb_set_shard) decides
+// from those sums only - every rank the same way.
+namespace {
+__global__ void policy_export_kernel(const double* __restrict__ ctr, const unsigned long long* __restrict__ exits, int mode,
+                                     double rows, int K, double round0, int counted, int use_exits, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool dense = mode == 0;
+    const double act = counted ? ctr[0] : 0.0;
+    out[0] = act;
+    out[1] = dense ? rows * K : ctr[1] + ((mode == 1 || mode == 3) ? round0 : 0.0);
+    out[2] = dense ? 0.0 : ctr[2];
+    out[3] = dense ? 0.0 : ctr[3];
+    out[4] = dense ? 0.0 : ctr[4];
+    out[5] = dense ? act : ctr[5];
+    out[6] = dense ? act : ctr[6];
+    out[7] = dense ? 0.0 : ctr[7];
+    out[8] = (dense || !use_exits || !exits) ? 0.0 : (double)*exits;
+    out[9] = rows;
+    out[10] = 1.0;                      // ranks
+    out[11] = counted ? 1.0 : 0.0;      // ranks whose pass counted its pairs
+    for (int i = 12; i < GMMVB_POLICY_LEN; ++i) out[i] = 0.0;
+}
+}  // namespace
+
+int gmmvb_set_shard(gmmvb_workspace* ws, int64_t global_rows, int n_ranks) {
+    if (!ws || global_rows < 1 || n_ranks < 1) return fail(GMMVB_EINVAL, "bad argument");
+    ws->sharded = n_ranks > 1;
+    ws->shard_rows = global_rows;
+    ws->shard_ranks = n_ranks;
+    ws->pol.valid = false;
+    if (ws->sharded && !ws->pol_host) {
+        hipError_t e = hipHostMalloc((void**)&ws->pol_host, GMMVB_POLICY_LEN * sizeof(double), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->pol_ev, hipEventDisableTiming);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "policy buffers", e);
+    }
+    return GMMVB_OK;
+}
+
+int gmmvb_policy_export(gmmvb_workspace* ws, double* out_dev, void* stream) {
+    if (!ws || !out_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (ws->e_state != 1) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    hipLaunchKernelGGL(policy_export_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws->ctr, ws->exit_ctr, ws->prev_pass,
+                       (double)ws->e_rows, ws->K, ws->pend_round0, ws->exp_counted ? 1 : 0, ws->gather_exit ? 1 : 0, out_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "policy export", e);
+    return GMMVB_OK;
+}
+
+int gmmvb_policy_import(gmmvb_workspace* ws, const double* in_dev, void* stream) {
+    if (!ws || !in_dev) return fail(GMMVB_EINVAL, "null argument");
+    if (!ws->sharded) return GMMVB_OK;          // a single process decides from its own counters
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(ws->pol_host, in_dev, GMMVB_POLICY_LEN * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(ws->pol_ev, st);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "policy import", e);
+    ws->pol_pending = true;
+    ws->pol_mode = ws->prev_pass;
+    ws->pol_first_sorted = ws->pend_first_sorted;
+    return GMMVB_OK;
+}
+
+// The imported counters, waited for: the copy was enqueued before the caller's per-iteration host sync, so this returns
+// at once - and every rank must see them (a rank that decided without them would part ways with the others).
+static int take_policy(gmmvb_workspace* ws) {
+    if (!ws->pol_pending) return GMMVB_OK;
+    hipError_t e = hipEventSynchronize(ws->pol_ev);
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "waiting for the imported counters", e);
+    const double* h = ws->pol_host;
+    gmmvb_pass_counters& p = ws->pol;
+    p.act = h[0];
+    p.eval = h[1];
+    p.over = h[2];
+    p.moved = h[3];
+    p.settled = h[4];
+    p.listed = h[5];
+    p.accum = h[6];
+    p.proof = h[7];
+    p.exits = h[8];
+    p.rows = h[9];
+    p.ranks = h[10];
+    p.mode = ws->pol_mode;
+    p.valid = h[10] >= 1.0 && h[11] == h[10];
+    if (p.valid && ws->sorted && !ws->pol_first_sorted) ws->moved_since_sort += p.moved;
+    ws->pol_pending = false;
+    return GMMVB_OK;
+}
+
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs) {
     (void)stream;
     if (!ws || !active_pairs || !evaluated_pairs) return fail(GMMVB_EINVAL, "null argument");
     if (ws->e_state != 1) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     int rc = fetch_counters(ws);
     if (rc) return rc;
-    *evaluated_pairs = ws->lag_mode == 0 ? (double)ws->e_rows * ws->K : ws->lag_eval;
-    *active_pairs = (ws->sparse && ws->act_rows == ws->e_rows) ? ws->lag_act : -1.0;   // GMMVB_MSTEP_SPARSE=0: not counted
+    *evaluated_pairs = ws->lag.mode == 0 ? (double)ws->e_rows * ws->K : ws->lag.eval;
+    *active_pairs = (ws->sparse && ws->act_rows == ws->e_rows) ? ws->lag.act : -1.0;   // GMMVB_MSTEP_SPARSE=0: not counted
     return GMMVB_OK;
 }
 
@@ -579,12 +676,12 @@ int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
     int rc = fetch_counters(ws);
     if (rc) return rc;
     const bool counted = ws->sparse && ws->act_rows == ws->e_rows;
-    out[0] = counted ? ws->lag_act : -1.0;
-    out[1] = ws->lag_mode == 0 ? (double)ws->e_rows * ws->K : ws->lag_eval;
-    out[2] = counted ? ws->lag_accum : -1.0;
-    out[3] = ws->lag_mode == 0 ? 0.0 : ws->lag_settled;
-    out[4] = ws->lag_mode == 0 ? 0.0 : ws->lag_exits;
-    out[5] = ws->lag_mode == 0 ? 0.0 : ws->lag_proof;
+    out[0] = counted ? ws->lag.act : -1.0;
+    out[1] = ws->lag.mode == 0 ? (double)ws->e_rows * ws->K : ws->lag.eval;
+    out[2] = counted ? ws->lag.accum : -1.0;
+    out[3] = ws->lag.mode == 0 ? 0.0 : ws->lag.settled;
+    out[4] = ws->lag.mode == 0 ? 0.0 : ws->lag.exits;
+    out[5] = ws->lag.mode == 0 ? 0.0 : ws->lag.proof;
     out[6] = out[7] = 0.0;
     return GMMVB_OK;
 }
@@ -612,7 +709,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->sorted = false;                // ... and the internal row order is the caller's again
     ws->rec_valid = false;
     ws->dense_valid = false;
-    ws->lag_valid = false;
+    ws->lag.valid = false;
     if (!ws->xc) return GMMVB_OK;      // disabled: the M-step reads x directly
     const int Dp = 16 * ws->T;
     const int64_t pad_rows = round_up(n_rows, 64) + 64;
@@ -751,20 +848,31 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // ---- which kind of pass?  Decided from what the host knows WITHOUT waiting for the device: the counters of the
     // last E-step whose copy has arrived (they lag by one pass when the caller never synchronises; results do not
     // depend on the choice, only the time does).
+    // A shard of a row-sharded job (gmmvb_set_shard) decides from the counters summed over all ranks and from the
+    // job's size - nothing below differs between ranks, so neither do the decisions.
+    if (ws->sharded) {
+        rc = take_policy(ws);
+        if (rc) return rc;
+    }
     poll_counters(ws);
     enum { kDense = 0, kBound = 1, kCarry = 2, kSweep = 3 };
     int mode = kDense;
+    const gmmvb_pass_counters& L = ws->sharded ? ws->pol : ws->lag;
     const bool can_prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr && ws->rec_k != nullptr;
-    const bool big = ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23);
+    const int64_t size_rows = ws->sharded ? ws->shard_rows / ws->shard_ranks : n_rows;
+    const bool big = ws->prune == 2 || size_rows * (int64_t)ws->K >= (int64_t(1) << 23);
     const bool same_rows = ws->bounds_rows == n_rows && ws->bounds_x == x_dev && ws->bounds_ldx == ldx;
-    const bool known = ws->lag_valid && ws->lag_rows == n_rows && !ws->ctr_pending;     // counters of the previous pass
+    // counters of the previous pass, over rows_l rows (this rank's, or the job's)
+    const bool known = L.valid && (ws->sharded || (L.rows == (double)n_rows && !ws->ctr_pending));
+    const double rows_l = known ? L.rows : (double)n_rows;
+    const double pairs_l = rows_l * ws->K;
     // the previous pass's M-step left its per-component lists of active rows (and their masks) in the workspace
     // (or the masks and block counts they are built from)
     const bool prev_lists = (ws->active_lists || ws->blk_fresh) && ws->e_state == 1 && ws->act_rows == n_rows && same_rows;
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
         bool sparse_ok = ws->prune == 2;
-        if (!sparse_ok && known && !ws->forget) sparse_ok = ws->lag_act <= 0.5 * pairs;
+        if (!sparse_ok && known && !ws->forget) sparse_ok = L.act <= 0.5 * pairs_l;
         if (sparse_ok) {
             mode = kBound;
             const bool hinted = same_rows && ws->have_drift && !ws->opt_carry_off;
@@ -791,28 +899,28 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 carry = hinted && ws->rec_valid;
                 sweep = false;
             }
-            if ((carry || sweep) && known && ws->lag_mode != kDense) {
+            if ((carry || sweep) && known && L.mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
                 // (a pair of the proof round costs about a fifth of an exact evaluation)
-                const double spare = (std::max(0.0, ws->lag_eval - (ws->lag_act - ws->lag_settled)) + 0.2 * ws->lag_proof) / pairs;
+                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + 0.2 * L.proof) / pairs_l;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
                 if (gpp * spare * ws->opt_spare_weight >= bound_cost) carry = sweep = false;
                 // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
                 // (x4 - x8 observed): stop carrying well before they dominate
-                if (ws->lag_over > 0.02 * (double)n_rows || ws->lag_eval > 0.35 * pairs) carry = sweep = false;
+                if (L.over > 0.02 * rows_l || L.eval > 0.35 * pairs_l) carry = sweep = false;
             }
-            if ((carry || sweep) && known && ws->lag_mode == kDense && ws->lag_act > 0.1 * pairs) carry = sweep = false;
+            if ((carry || sweep) && known && L.mode == kDense && L.act > 0.1 * pairs_l) carry = sweep = false;
             // straight from a dense pass the parameters usually still jump (second or third iteration of a restart): the
             // sweep's per-pair bounds are exact values then, but carried over such an update most of them end up
             // candidates (measured at C4: 118 of 256 per row, 171 ms) - a bound pass is the safe first pruned pass
-            if (sweep && known && ws->lag_mode == kDense && tg > 0.0 && tg < 0.85) sweep = false;
+            if (sweep && known && L.mode == kDense && tg > 0.0 && tg < 0.85) sweep = false;
             if (carry) mode = kCarry;
             else if (sweep) mode = kSweep;
             // a bound pass that left most pairs candidates (the parameters jumped): back to the dense kernel
-            if (mode == kBound && ws->prune != 2 && known && ws->lag_mode == kBound && ws->lag_eval > 0.6 * pairs) {
+            if (mode == kBound && ws->prune != 2 && known && L.mode == kBound && L.eval > 0.6 * pairs_l) {
                 mode = kDense;
                 ++ws->passes[3];
             }
@@ -825,8 +933,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // record, which only a pass that rebuilds everything (bound or dense) can digest.
     auto regroup_due = [&]() {
         return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
-               ws->lag_act <= 4.0 * (double)n_rows && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
-               (!ws->sorted || ws->moved_since_sort > ws->opt_regroup_moved * (double)n_rows);      // (again once that share of the rows has moved on)
+               L.act <= 4.0 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
+               (!ws->sorted || ws->moved_since_sort > ws->opt_regroup_moved * rows_l);      // (again once that share of the rows has moved on)
     };
     bool settle = false;
     if (ws->lock) {
@@ -855,8 +963,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (mode != kSweep) {
         ws->settle_on = false;
     } else if (!ws->settle_on) {
-        ws->settle_on = ws->typical_gamma >= ws->settle_gamma && known && ws->lag_mode == kSweep &&
-                        std::max(0.0, ws->lag_eval - (ws->lag_act - ws->lag_settled)) <= ws->settle_spare * (double)n_rows;
+        ws->settle_on = ws->typical_gamma >= ws->settle_gamma && known && L.mode == kSweep &&
+                        std::max(0.0, L.eval - (L.act - L.settled)) <= ws->settle_spare * rows_l;
     } else if (ws->typical_gamma > 0.0 && ws->typical_gamma < ws->settle_gamma - 0.05) {
         ws->settle_on = false;
     }
@@ -864,8 +972,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->settled_fresh = false;
     if (ws->opt_debug)
         std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",
-                     mode, (int)known, ws->lag_mode, ws->lag_act / n_rows, ws->lag_eval / n_rows, ws->lag_over / n_rows,
-                     ws->lag_settled / n_rows, ws->lag_listed / n_rows, ws->typical_gamma, (int)ws->rec_valid,
+                     mode, (int)known, L.mode, L.act / rows_l, L.eval / rows_l, L.over / rows_l,
+                     L.settled / rows_l, L.listed / rows_l, ws->typical_gamma, (int)ws->rec_valid,
                      (int)ws->have_drift, (int)settle);
     if (mode == kBound && ws->img_i8b) {
         // How many output blocks the bound pass evaluates.  Cost model per (sample, component) pair, in units of
@@ -878,10 +986,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
         if (pin >= 1 && pin <= t32) {
             ws->bound_tb = pin;
-        } else if (known && ws->lag_mode == kBound) {
+        } else if (known && L.mode == kBound) {
             const int cur = ws->bound_tb;
-            ws->tb_cand[cur] = ws->lag_eval / pairs;
-            ws->tb_act[cur] = ws->lag_act / pairs;
+            ws->tb_cand[cur] = L.eval / pairs_l;
+            ws->tb_act[cur] = L.act / pairs_l;
             ws->tb_seen[cur] = 0;
             for (int l = 1; l <= t32; ++l)
                 if (l != cur && (++ws->tb_seen[l] > 32 || ws->tb_act[l] > 1.5 * ws->tb_act[cur] ||
@@ -1036,7 +1144,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 ++ws->passes[7];
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step active-pair evaluation", e);
                 span_begin(ws, kSpanSelect, st);
-                const bool proof = proof_capable && ws->skip_used;       // (some rows may be settled)
+                const bool proof = proof_capable;
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
                                    settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
@@ -1127,13 +1235,17 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // pairs evaluated before the counted selection: every row's best component, or (sweep over the previous
         // pass's lists) the previous pass's active pairs
         ws->pend_first_sorted = sorted_now;
-        ws->pend_round0 = (mode == kSweep && ws->sweep_prev && known) ? ws->lag_listed : (double)n_rows;
+        // (this rank's own numbers: what its kernels did)
+        const bool own = ws->lag.valid && ws->lag.rows == (double)n_rows && !ws->ctr_pending;
+        ws->pend_round0 = (mode == kSweep && ws->sweep_prev && own) ? ws->lag.listed : (double)n_rows;
         ws->act_rows = n_rows;
     } else {
         ws->ctr_pending = false;
-        ws->lag_valid = false;
+        ws->lag.valid = false;
         ws->act_rows = 0;              // nothing counted: dense M-step, no pruning decision from this pass
     }
+    ws->exp_counted = counted;
+    ws->pol.valid = false;             // (a sharded job imports this pass's sums before the next E-step)
     ws->act_host = -1.0;
     ws->active_lists = false;
     ws->mlists_done = ws->mlists_lost = false;
@@ -1221,13 +1333,15 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const double pairs = (double)n_rows * ws->K;
         if (ws->rec_live) {
             // a pass on records is sparse by construction; the last counters that have arrived can still veto
+            // (not in a sharded job: its ranks would have to agree, and the previous pass's sums are spent by now)
             poll_counters(ws);
-            if (ws->lag_valid && ws->lag_rows == n_rows && ws->lag_act > 0.35 * pairs && !ws->lock_live) sparse = false;
+            if (!ws->sharded && ws->lag.valid && ws->lag.rows == (double)n_rows && ws->lag.act > 0.35 * pairs && !ws->lock_live)
+                sparse = false;
         } else {
             // after a dense E-step the host has been waiting for that kernel anyway: read this pass's own count
             rc = fetch_counters(ws);
             if (rc) return rc;
-            sparse = ws->lag_valid && ws->lag_act <= 0.35 * pairs;
+            sparse = ws->lag.valid && ws->lag.act <= 0.35 * pairs;
         }
     }
     if (sparse && ws->K > 256) sparse = false;

@@ -461,7 +461,17 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             else if (w == 2) mk[2] = mw;
             else mk[3] = mw;
         }
-        bool stays = false, proof_row = false;
+        bool stays = false, proof_row = false, proof_cand = false;
+        if (pmask != nullptr && !by_bound && !over && (mk[0] | mk[1] | mk[2] | mk[3]) != 0ull) {
+            // a row with an exact reference: its candidates (carried bounds that no longer clear the threshold) get fresh
+            // int8 bounds first; only those that still do not clear it are evaluated exactly (rec_proof_decide_kernel)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                pm[w] = mk[w];
+                mk[w] = 0ull;
+            }
+            proof_cand = true;
+        }
         if (by_bound) {
             stays = (mk[0] | mk[1] | mk[2] | mk[3]) == 0ull;
             if (stays) {
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         rec.B[n] = rest;
         rec.exact[n] = (unsigned char)(over ? 0 : ex);
         rec.sel[n] = (unsigned char)(over ? 0 : sel);
-        rec.flags[n] = (unsigned char)(stays ? 4 : (proof_row ? 8 : (over ? 1 : (listed > in_slots ? 2 : 0))));
+        rec.flags[n] = (unsigned char)(stays ? 4 : (proof_row ? 8 : (over ? 1 : ((listed > in_slots ? 2 : 0) | (proof_cand ? 16 : 0)))));
         over_i = over ? 1 : 0;
         for (int w = 0; w < W; ++w) {
             masks[(int64_t)w * npad + n] = mk[w];
@@ -602,7 +612,41 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
     int listed = 0, proved = 0;
     if (valid) {
         for (int w = 0; w < W; ++w) mk[w] = masks[(int64_t)w * npad + n];
-        if (rec.flags[n] == 8u) {
+        const unsigned fl0 = rec.flags[n];
+        if (fl0 & 16u) {
+            // candidates of a row whose reference is exact (rthr = its best exact value - 100 ln 2): those whose fresh bound
+            // clears the threshold are done with; the others join the pass's lists (and may still leave the exact gather early)
+            const double thr = (double)rthr[n];
+            unsigned sel = rec.sel[n];
+            int in_slots = __builtin_popcount(sel), total = 0;
+            unsigned long long kept[4] = {0ull, 0ull, 0ull, 0ull};
+            for (int w = 0; w < W; ++w) {
+                unsigned long long m = pmask[(int64_t)w * npad + n];
+                proved += __builtin_popcountll(m);
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const double u = (double)ub32[(int64_t)(64 * w + b) * npad + n];
+                    if (!(u < thr)) kept[w] |= 1ull << b;                    // also NaN
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kRecSlots; ++j) {
+                const unsigned short k = rec.k[(int64_t)j * rec.npad + n];
+                if (k != kRecEmpty && ((kept[k >> 6] >> (k & 63)) & 1ull) && !((sel >> j) & 1u)) {
+                    sel |= 1u << j;
+                    ++in_slots;
+                }
+            }
+            for (int w = 0; w < W; ++w) {
+                mk[w] |= kept[w];
+                total += __builtin_popcountll(mk[w]);
+                masks[(int64_t)w * npad + n] = mk[w];
+            }
+            rec.sel[n] = (unsigned char)sel;
+            rec.flags[n] = (unsigned char)(total > in_slots ? 2 : 0);
+        }
+        if (fl0 == 8u) {
             const int kset = lcomp[n];
             const double l = lb[(int64_t)kset * npad + n];
             const double thr = l - k100Ln2;                              // -inf when the proof kernel had no bound

@@ -7,6 +7,15 @@
 
 struct gmmvb_hmm_state;      // HMM forward-backward buffers (hmm_capi.hip), allocated by hmmvb_enable
 
+// What an E-step leaves for the policy of the next one (and for gmmvb_last_work)
+struct gmmvb_pass_counters {
+    bool valid = false;
+    double act = 0.0, eval = 0.0, over = 0.0, settled = 0.0, listed = 0.0, accum = 0.0, proof = 0.0, exits = 0.0, moved = 0.0;
+    double rows = 0.0;           // rows the counters were taken over
+    double ranks = 1.0;          // ranks they were summed over
+    int mode = 0;                // kind of the pass: 0 dense, 1 bound pass, 2 carried records, 3 sweep
+};
+
 struct gmmvb_workspace {
     int K = 0, D = 0, T = 0, x_dtype = 0;
     int64_t max_rows = 0, npad = 0;
@@ -71,10 +80,20 @@ struct gmmvb_workspace {
     int64_t pend_rows = 0;
     double pend_round0 = 0.0;          // pairs that E-step evaluated before its counted selection round
     bool sweep_prev = false;           // the last sweep's first round used the previous pass's M-step lists
-    bool lag_valid = false;            // lag_* = counters of the most recent E-step whose copy has arrived
-    double lag_act = 0.0, lag_eval = 0.0, lag_over = 0.0, lag_settled = 0.0, lag_listed = 0.0, lag_accum = 0.0;
-    int64_t lag_rows = 0;
-    int lag_mode = 0;
+    // lag = counters of this rank's most recent E-step whose copy has arrived: what gmmvb_last_work reports, and the
+    // policy's input in a single process.  pol = the same summed over the ranks of a row-sharded job
+    // (gmmvb_policy_export / all-reduce / gmmvb_policy_import): once gmmvb_set_shard has been called the policy reads
+    // nothing else that differs between ranks, so every rank takes the same decisions.
+    gmmvb_pass_counters lag, pol;
+    bool sharded = false;              // gmmvb_set_shard: this workspace holds one shard of shard_rows rows over shard_ranks ranks
+    int64_t shard_rows = 0;
+    int shard_ranks = 1;
+    double* pol_host = nullptr;        // [GMMVB_POLICY_LEN] pinned: the imported (summed) counters
+    hipEvent_t pol_ev = nullptr;
+    bool pol_pending = false;          // an import is in flight ...
+    int pol_mode = 0;                  // ... of a pass of this mode
+    bool pol_first_sorted = false;
+    bool exp_counted = false;          // the last E-step counted its pairs (what gmmvb_policy_export may hand out)
     bool forget = false;               // gmmvb_forget: the next parameters are unrelated to the last E-step's
     double spare_last = -1.0;          // spare candidates per pair of the last pruned pass (diagnostics)
     double* cvec = nullptr;    // [K]
@@ -108,7 +127,6 @@ struct gmmvb_workspace {
     float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 100 ln 2)
     unsigned long long* exit_ctr = nullptr;    // [1] device: candidate pairs of the pass that took the gather's early way out
     unsigned long long* exit_host = nullptr;   // [1] pinned mirror (copied with the other counters)
-    double lag_exits = 0.0;
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
     int* dblk = nullptr;               // [K][blocks] their block counts
     unsigned long long* mmask = nullptr;   // [ceil(K / 64)][npad] the M-step's lists: active pairs of the rows not in the cache
@@ -124,7 +142,7 @@ struct gmmvb_workspace {
     bool skip_used = false;            // some pass since the cache was last emptied was allowed to settle rows
     bool lock_reset = false;           // the settled state belongs to something else now: drop it at the next E-step
     bool settled_fresh = false;        // read-outs: the settled rows' ln rho / lse were re-evaluated for the parameters in force
-    double settle_margin = 5.0;        // nats of slack demanded before a row is settled (< 0: never settle)
+    double settle_margin = 0.0;        // nats of slack demanded before a row is settled (< 0: never settle)
     double settle_gamma = 0.85;        // settling starts when the caller's drift summary (typical_gamma) reaches this ...
     double settle_spare = 1.0;         // ... and the last sweep left at most this many spare candidates per row;
     bool settle_on = false;            // it then stays on until the summary falls below settle_gamma - 0.05 or a pass
@@ -154,7 +172,6 @@ struct gmmvb_workspace {
     int pivot_gen = 0, xq_gen = -1, img_gen = -2;
     bool opt_proof = true;             // env GMMVB_PROOF=0: settled rows with candidates go straight to the f64 gather
     double* ppart = nullptr;           // [blocks] pairs of the proof round per selection block
-    double lag_proof = 0.0;
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
     void* xp = nullptr;        // [max_rows][D] x in internal row order (storage dtype), allocated with the lists
     int* perm = nullptr, *iperm = nullptr, *perm_tmp = nullptr;   // [npad] each

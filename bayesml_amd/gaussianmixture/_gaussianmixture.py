@@ -335,7 +335,15 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             eng.estep_mstep(xd, out=ks.stats)
         else:
             eng.mstep(xd, out=ks.stats)
-        self._comm.all_reduce_(ks.stats)
+        if estep and getattr(self._comm, "world", 1) > 1 and hasattr(eng, "policy_export") and not getattr(
+                self._comm, "restart_parallel", False):
+            # row shards: the engine's pass-policy counters ride behind the statistics block, so that every rank's
+            # next E-step decides from the same job-wide numbers - still ONE collective per iteration
+            eng.policy_export(ks.tail)
+            self._comm.all_reduce_(ks.stats_and_tail)
+            eng.policy_import(ks.tail)
+        else:
+            self._comm.all_reduce_(ks.stats)
 
     def _give_params(self, eng, q, hint=None):
         """Hand a posterior's E-step parameters to the engine; ``hint`` = (gamma, delta, big_gamma, mean gamma) of the update

@@ -80,11 +80,30 @@ def parse_args():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs this process could use, WITHOUT touching the HIP runtime (the parent of the rank processes must never
+    initialise a GPU, and on ROCm even torch.cuda.device_count() may): the *_VISIBLE_DEVICES lists if set, else the KFD
+    topology's nodes that have SIMDs.  None if neither is available."""
+    for key in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(key)
+        if v is not None and v.strip():
+            return len([t for t in v.split(",") if t.strip()])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except OSError:
+        return None
+
+
 def launch_ranks(n):
     """Start n rank processes of this script (rank r on GPU r).  The parent never initialises a GPU."""
-    import torch
-    have = torch.cuda.device_count()          # counting devices does not initialise the runtime
-    if have < n:
+    have = visible_gpus()
+    if have is not None and have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -343,7 +362,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     counts1 = eng.pass_counts()
+    policy_same = None
     if use_dist:
+        # every rank's sequence of E-step kinds over the timed steps: one policy for all ranks (gmmvb_set_shard) means
+        # they are identical
+        seqs = [None] * world
+        dist.all_gather_object(seqs, [kernel_name(l) for l in launches])
+        policy_same = all(q == seqs[0] for q in seqs)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -422,7 +447,8 @@ def main():
                                                    if (ev + acc) > 0 else None),
                 "pairs_per_sample": {"active": ac / n_local, "evaluated_exactly": ev / n_local,
                                      "accumulated_by_mstep": acc / n_local, "settled_rows": settled / n_local,
-                                     "early_exits": exits / n_local},
+                                     "early_exits": exits / n_local,
+                                     "proof_round_int8": float(np.mean([wk.get("proof_pairs", 0.0) for wk in works])) / n_local},
                 "kernel_groups": groups,
                 "events_ms_per_step": sum(g["ms"] for g in groups.values()),
                 "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
@@ -454,6 +480,7 @@ def main():
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
             "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "estep_kinds_identical_across_ranks": policy_same,
             "allreduce": (("gmmvb_allreduce_stats (C ABI, RCCL)" if args.native_allreduce else "torch.distributed nccl (RCCL)")
                           if use_dist else None),
             "steps": steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
@@ -472,7 +499,8 @@ def main():
                          "active_components_per_sample": [round(a / n_local, 2) if a >= 0 else None for a, _ in spars],
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars],
                          "accumulated_components_per_sample": [round(wk["accumulated"] / n_local, 2) for wk in works],
-                         "settled_rows_per_sample": [round(wk["settled_rows"] / n_local, 3) for wk in works]},
+                         "settled_rows_per_sample": [round(wk["settled_rows"] / n_local, 3) for wk in works],
+                         "proof_pairs_per_sample": [round(wk.get("proof_pairs", 0.0) / n_local, 3) for wk in works]},
         }
         print(json.dumps(out), flush=True)
     if use_dist:

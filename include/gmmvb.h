@@ -129,6 +129,23 @@ int gmmvb_comm_create(const unsigned char* id /*[128]*/, int n_ranks, int rank, 
 int gmmvb_comm_destroy(gmmvb_comm* comm);
 int gmmvb_allreduce_stats(gmmvb_comm* comm, double* stats_dev, int64_t len, void* stream);
 
+/* One pass policy for all ranks.  Inside gmmvb_estep the library chooses between its dense kernel, a fresh bound pass
+ * and carrying the previous pass's bounds from counters of the previous pass (how many pairs were active, evaluated,
+ * ...).  Ranks deciding from their own shards' counters would part ways, and with one all-reduce per iteration the
+ * slowest choice sets the step time for everybody.  A sharded workspace therefore decides from JOB-WIDE numbers only:
+ *   once:       gmmvb_set_shard(ws, rows of the whole job, n_ranks)
+ *   per pass:   gmmvb_estep_mstep(...); gmmvb_policy_export(ws, tail_dev, stream);
+ *               all-reduce(sum) of [statistics block | tail] - the tail is GMMVB_POLICY_LEN doubles, e.g. kept right
+ *               behind the statistics block so that the iteration still has ONE collective;
+ *               gmmvb_policy_import(ws, tail_dev, stream)     (enqueues a copy to pinned host memory; the next
+ *               gmmvb_estep waits for it, which costs nothing after the caller's per-iteration synchronisation).
+ * Results never depend on any of this - only which kernels run.  gmmvb_last_work keeps reporting the rank's own numbers.
+ * (The M-step's choice between its dense and its list form right after a DENSE E-step still uses the rank's own count.) */
+#define GMMVB_POLICY_LEN 16
+int gmmvb_set_shard(gmmvb_workspace* ws, int64_t global_rows, int n_ranks);
+int gmmvb_policy_export(gmmvb_workspace* ws, double* out_dev /*[GMMVB_POLICY_LEN]*/, void* stream);
+int gmmvb_policy_import(gmmvb_workspace* ws, const double* summed_dev /*[GMMVB_POLICY_LEN]*/, void* stream);
+
 /* ---- Gaussian-emission HMM (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py) -------------------------
  * The emission term is the GMM E-step without E[ln pi]: call gmmvb_set_params with
  *   c[k] = (E[ln det Lambda_k] - D ln 2pi - D/kappa_k)/2     (_calc_rho, :988-996)

@@ -1,7 +1,7 @@
 """The proof round's kernel (csrc/estep_i8.h: x_digits_kernel + estep_i8_proof) against the ORACLE: for every row and a
 given component the two values it returns must enclose the oracle's ln rho (reference ``_gaussianmixture.py:773-781``)
 - that is all the pruned E-step relies on when it keeps a settled row out of the exact evaluation - and they must be
-tight enough to be of use (a few 1e-5 of the whitened distance)."""
+tight enough to be of use (a nat or two at the benchmark's shape, against the 69-nat margin they decide)."""
 import numpy as np
 import pytest
 import torch
@@ -51,9 +51,11 @@ def test_proof_bounds_enclose_the_oracle(K, D, N, dtype):
         exact = st.ln_rho[:, k]
         assert np.all(lb <= exact), (k, float(np.max(lb - exact)))
         assert np.all(ub >= exact), (k, float(np.max(exact - ub)))
-        # tightness: both within 1e-4 of the quadratic form (+ f32 rounding of the upper bound)
+        # tightness: the rigorous error term assumes that all 32 ceil(D/32) truncation errors of a row of y line up - about
+        # a nat on || y ||^2 / 2 ~ 100 at this shape; the values themselves are far closer (1e-5)
         quad = np.abs(exact) + 1.0
-        assert np.max((ub - lb) / quad) < 3e-4, (k, float(np.max((ub - lb) / quad)))
+        assert np.max((ub - lb) / quad) < 3e-2, (k, float(np.max((ub - lb) / quad)))
+        assert np.median(np.abs(0.5 * (ub + lb) - exact) / quad) < 1e-3
     eng.close()
 
 

@@ -26,12 +26,12 @@ ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", 
             "GMMVB_SETTLE_SPARE", "GMMVB_ESTEP_RECORDS")
 VARIANTS = {
     "default": {},
-    # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, with 5 nats
-    # of slack; a settled row whose carried bounds leave candidates goes through the int8 proof round (estep_i8_proof).
-    # "settle": no slack at all, so that most settled rows have candidates in the next pass and the proof round decides;
-    # the read-outs below need the settled rows' values re-evaluated
-    "settle": {"GMMVB_SETTLE_MARGIN": "0"},
-    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_MARGIN": "0"},
+    # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, without
+    # slack - a settled row whose carried bounds leave candidates goes through the int8 proof round (estep_i8_proof), as do
+    # the candidates of every other row before anything is evaluated in f64.  "settle": 5 nats of slack (fewer rows settle,
+    # fewer come back); the read-outs below need the settled rows' values re-evaluated
+    "settle": {"GMMVB_SETTLE_MARGIN": "5"},
+    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_MARGIN": "5"},
     # ... without the proof round: rows settle on the strength of their carried bounds only (whatever the drift and the
     # spare candidates of the last sweep, 10 nats of slack) and come loose into the exact gather
     "settle_noproof": {"GMMVB_PROOF": "0", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
