@@ -32,7 +32,7 @@ class DeviceModel:
             eng = self._data_pass_factory(K, D, x)
             xd = eng.adopt(x)
         else:
-            from ._engine import DataPass, EngineUnavailableError
+            from ._engine import DataPass, EngineUnavailableError, open_data_pass
             if not torch.cuda.is_available():
                 raise EngineUnavailableError(
                     f"bayesml_amd {type(self).__module__}.LearnModel needs an MI355X: the data pass has no CPU fallback")
@@ -50,7 +50,10 @@ class DeviceModel:
                     or eng.device != dev or getattr(eng, "_ws", None) is None):
                 if eng is not None:
                     eng.close()
-                eng = DataPass(K, D, xd.dtype, xd.shape[0], dev)
+                # (a matrix whose per-pair workspace does not fit the GPU goes through it in row tiles; the HMM's time axis
+                # does not tile)
+                tiling = getattr(self, "_row_tiling", False)
+                eng = open_data_pass(K, D, xd.dtype, xd.shape[0], dev) if tiling else DataPass(K, D, xd.dtype, xd.shape[0], dev)
         self._engine, self._x_dev, self._r_cache = eng, xd, None
         self._comm.bind_rows(xd.shape[0], xd.device)
         if hasattr(eng, "set_shard") and not getattr(self._comm, "restart_parallel", False):

@@ -533,3 +533,234 @@ class DataPass:
 
     def argmax(self, row0=0, n=None) -> torch.Tensor:
         return self._readout(self.lib.gmmvb_argmax, "gmmvb_argmax", row0, n, dtype=torch.int32, cols=1)
+
+
+class TiledDataPass:
+    """The same surface as ``DataPass`` for a sample matrix whose per-pair workspace does not fit the GPU (the workspace
+    keeps 16 bytes per (row, component) pair: K = 256, N = 1e8 would need 410 GB next to the 25.6 GB matrix - the reference
+    has no such coupling, it allocates its [N, K] arrays on the host).
+
+    The rows are cut into tiles of ``tile_rows`` rows that go through ONE workspace, one after the other, in every data pass;
+    the statistics blocks add up (they are linear in the rows, like over row shards).  Nothing per-pair survives from one
+    tile to the next, so a tile's E-step cannot carry bounds from the previous iteration: it is the dense kernel while the
+    responsibilities are dense and a fresh int8 bound pass afterwards (the tiles share the pass policy through the same
+    job-wide counters as the ranks of a sharded job, gmmvb_set_shard).  Read-outs re-run the E-step of the tiles they touch."""
+
+    def __init__(self, K, D, x_dtype, n_rows, device, tile_rows):
+        self.K, self.D, self.x_dtype, self.max_rows = int(K), int(D), x_dtype, int(n_rows)
+        self.tile_rows = int(min(tile_rows, n_rows))
+        self.n_tiles = (self.max_rows + self.tile_rows - 1) // self.tile_rows
+        self.inner = DataPass(K, D, x_dtype, self.tile_rows, device)
+        self.device, self.lib, self.stats_len = self.inner.device, self.inner.lib, self.inner.stats_len
+        self._tmp = torch.zeros(self.stats_len, dtype=torch.float64, device=self.device)
+        self._tail_tmp = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
+        self._tail_acc = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
+        self._tail_in = None           # job-wide counters of the previous pass (summed over tiles, and over ranks by the caller)
+        self._ranks = 1
+        self._global_rows = self.max_rows
+        self._x = self._r = None
+        self._params = None
+        self._held = None              # tile whose E-step the inner workspace currently holds
+        self._infos, self._work, self._spars, self._ms = [], None, None, (0.0, 0.0)
+        self.rows = 0
+        self.inner.set_shard(self._global_rows, self.n_tiles)
+
+    # -- plumbing shared with DataPass
+    _ws = property(lambda self: self.inner._ws)
+    PASS_NAMES = DataPass.PASS_NAMES
+
+    def close(self):
+        self.inner.close()
+
+    def _tile(self, t):
+        lo = t * self.tile_rows
+        return lo, min(self.max_rows, lo + self.tile_rows)
+
+    @property
+    def workspace_bytes(self):
+        return self.inner.workspace_bytes
+
+    @property
+    def launch_info(self):
+        return f"{self.n_tiles} tiles x {self.tile_rows} rows: " + (self._infos[0] if self._infos else "")
+
+    @property
+    def regroup_count(self):
+        return self.inner.regroup_count
+
+    def pass_counts(self):
+        return self.inner.pass_counts()
+
+    def profile(self, on=True):
+        self.inner.profile(on)
+
+    def last_kernel_ms(self):
+        return self._ms
+
+    def kernel_spans(self):
+        return {}
+
+    def sparsity(self):
+        return self._spars if self._spars is not None else (-1.0, 0.0)
+
+    def work(self):
+        return self._work if self._work is not None else dict(active=-1.0, evaluated=0.0, accumulated=-1.0, settled_rows=0.0,
+                                                              early_exits=0.0, proof_pairs=0.0)
+
+    def split_stats(self, stats):
+        return self.inner.split_stats(stats)
+
+    # -- state
+    def set_pivot(self, pivot):
+        self.inner.set_pivot(pivot)
+        self.pivot = self.inner.pivot
+
+    def prepare_rows(self, x):
+        self._x, self._held = x, None          # tiles are prepared when they are processed
+
+    def set_params(self, c, m, u):
+        self.inner.set_params(c, m, u)
+        self._params = (c, m, u)
+        self._held = None
+
+    def wants_drift(self, n_rows):
+        return False                           # nothing to carry: a tile's bounds do not survive the other tiles
+
+    def set_drift(self, *a, **k):
+        pass
+
+    def forget(self):
+        self.inner.forget()
+        self._tail_in = None
+
+    def set_shard(self, global_rows, n_ranks):
+        self._global_rows, self._ranks = int(global_rows), int(n_ranks)
+        self.inner.set_shard(self._global_rows, self._ranks * self.n_tiles)
+
+    def policy_export(self, tail):
+        tail.copy_(self._tail_acc)
+
+    def policy_import(self, tail):
+        self._tail_in = tail.clone()
+
+    def load_responsibilities(self, r):
+        self._r = torch.as_tensor(r, dtype=torch.float64, device=self.device)
+        self.rows = self._r.shape[0]
+        self._held = None
+
+    # -- the data pass
+    def _run(self, x, out, estep):
+        if x.shape[0] != self.max_rows and x.shape[0] > self.max_rows:
+            raise ValueError("more rows than the tiled workspace was created for")
+        stats = self.inner._stats_out(out)
+        stats.zero_()
+        if estep:
+            self._r = None
+        self._tail_acc.zero_()
+        self._infos, act, ev, acc, e_ms, m_ms = [], 0.0, 0.0, 0.0, 0.0, 0.0
+        counted = True
+        n = x.shape[0]
+        for t in range((n + self.tile_rows - 1) // self.tile_rows):
+            lo, hi = t * self.tile_rows, min(n, (t + 1) * self.tile_rows)
+            xt = x[lo:hi]
+            self.inner.prepare_rows(xt)
+            if estep:
+                if self._tail_in is not None:
+                    self.inner.policy_import(self._tail_in)
+                self.inner.estep_mstep(xt, out=self._tmp)
+                self.inner.policy_export(self._tail_tmp)
+                self._tail_acc += self._tail_tmp
+            else:
+                self.inner.load_responsibilities(self._r[lo:hi])
+                self.inner.mstep(xt, out=self._tmp)
+            stats += self._tmp
+            self._infos.append(self.inner.launch_info)
+            if estep:
+                a, e = self.inner.sparsity()
+                wk = self.inner.work()
+                counted = counted and a >= 0
+                act, ev, acc = act + max(a, 0.0), ev + e, acc + max(wk["accumulated"], 0.0)
+                if self.inner.lib.gmmvb_profile_last_ms is not None and getattr(self, "_prof", False):
+                    k = self.inner.last_kernel_ms()
+                    e_ms, m_ms = e_ms + k[0], m_ms + k[1]
+        if estep:
+            if self._tail_in is None or self._ranks == 1:
+                self._tail_in = self._tail_acc.clone()      # a single process: the tiles' sums are the job's
+            self._spars = (act if counted else -1.0, ev)
+            self._work = dict(active=act if counted else -1.0, evaluated=ev, accumulated=acc if counted else -1.0,
+                              settled_rows=0.0, early_exits=0.0, proof_pairs=0.0)
+            self._ms = (e_ms, m_ms)
+            self._held = (n + self.tile_rows - 1) // self.tile_rows - 1
+            self.rows = n
+        return stats
+
+    def profile(self, on=True):          # noqa: F811
+        self._prof = bool(on)
+        self.inner.profile(on)
+
+    def estep_mstep(self, x, out=None):
+        self._x = x
+        return self._run(x, out, True)
+
+    def mstep(self, x, out=None):
+        self._x = x
+        if self._r is not None and self._held is None:
+            return self._run(x, out, False)
+        return self._run(x, out, True)             # statistics of the E-step under the parameters in force
+
+    def estep(self, x):
+        self._x, self.rows, self._held = x, x.shape[0], None
+
+    # -- read-outs: rows [row0, row0 + n) in the caller's order, tile by tile
+    def _readout(self, what, row0, n, dtype, cols):
+        n = self.rows - row0 if n is None else n
+        out = torch.empty((n, self.K) if cols else (n,), dtype=dtype, device=self.device)
+        pos = row0
+        while pos < row0 + n:
+            t = pos // self.tile_rows
+            lo, hi = self._tile(t)
+            hi = min(hi, self.rows)
+            if self._held != t:
+                xt = self._x[lo:hi]
+                self.inner.prepare_rows(xt)
+                if self._r is not None and self._params is None:
+                    self.inner.load_responsibilities(self._r[lo:hi])
+                else:
+                    self.inner.estep(xt)
+                self._held = t
+            take = min(hi, row0 + n) - pos
+            out[pos - row0: pos - row0 + take] = getattr(self.inner, what)(pos - lo, take)
+            pos += take
+        return out
+
+    def responsibilities(self, row0=0, n=None):
+        return self._readout("responsibilities", row0, n, torch.float64, True)
+
+    def ln_rho(self, row0=0, n=None):
+        return self._readout("ln_rho", row0, n, torch.float64, True)
+
+    def argmax(self, row0=0, n=None):
+        return self._readout("argmax", row0, n, torch.int32, False)
+
+
+def open_data_pass(K, D, x_dtype, n_rows, device, tile_rows=None):
+    """A DataPass for all rows if its workspace fits the GPU, else a TiledDataPass (halving the tile until it does).
+    ``tile_rows`` (or BAYESML_AMD_TILE_ROWS in the environment) forces tiles of that many rows."""
+    forced = tile_rows or int(os.environ.get("BAYESML_AMD_TILE_ROWS", "0"))
+    if forced and forced < n_rows:
+        return TiledDataPass(K, D, x_dtype, n_rows, device, forced)
+    try:
+        return DataPass(K, D, x_dtype, n_rows, device)
+    except EngineError as e:
+        if "GMMVB_ENOMEM" not in str(e):
+            raise
+    rows = (n_rows + 1) // 2
+    while rows >= 1 << 16:
+        torch.cuda.empty_cache()
+        try:
+            return TiledDataPass(K, D, x_dtype, n_rows, device, (rows + 63) // 64 * 64)
+        except EngineError as e:
+            if "GMMVB_ENOMEM" not in str(e):
+                raise
+        rows = (rows + 1) // 2
+    raise EngineError(f"no workspace fits the GPU even for tiles of {rows * 2} rows (K={K}, D={D})")

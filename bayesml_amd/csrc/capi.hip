@@ -144,8 +144,9 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v) ws->settle_gamma = std::atof(v);
         v = std::getenv("GMMVB_SETTLE_SPARE");
         if (v) ws->settle_spare = std::atof(v);
-        v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round for settled rows
-        ws->opt_proof = !(v && std::strcmp(v, "0") == 0);
+        v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round for settled rows; "all": every
+        ws->opt_proof = !(v && std::strcmp(v, "0") == 0);          // spare candidate goes through it first (experiment)
+        ws->opt_proof_all = v && std::strcmp(v, "all") == 0;
         ws->prefer_records = std::getenv("GMMVB_ESTEP_RECORDS") != nullptr;
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
@@ -864,6 +865,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool same_rows = ws->bounds_rows == n_rows && ws->bounds_x == x_dev && ws->bounds_ldx == ldx;
     // counters of the previous pass, over rows_l rows (this rank's, or the job's)
     const bool known = L.valid && (ws->sharded || (L.rows == (double)n_rows && !ws->ctr_pending));
+    // (this rank's own numbers of the previous pass: what its kernels did)
+    const bool own_known = ws->lag.valid && ws->lag.rows == (double)n_rows && !ws->ctr_pending;
     const double rows_l = known ? L.rows : (double)n_rows;
     const double pairs_l = rows_l * ws->K;
     // the previous pass's M-step left its per-component lists of active rows (and their masks) in the workspace
@@ -902,8 +905,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if ((carry || sweep) && known && L.mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
-                // (a pair of the proof round costs about a fifth of an exact evaluation)
-                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + 0.2 * L.proof) / pairs_l;
+                // (a pair of the proof round costs about a third of an exact evaluation)
+                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + 0.33 * L.proof) / pairs_l;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
@@ -931,6 +934,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // whose M-step applied the delta lists - all of them end in rec_finish_kernel.  A dense pass, a regrouping of the rows,
     // new data or parameters unrelated to the last pass drop it; rows that were settled then have no active pair on
     // record, which only a pass that rebuilds everything (bound or dense) can digest.
+    // The rows are regrouped by dominant component at a bound pass (which rebuilds everything row-indexed anyway).  With
+    // the proof round bound passes have become rare: the first time the responsibilities are sparse enough for the grouping
+    // to pay (at most 4 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
+    // kernels over ungrouped rows are 15-40 % slower for the rest of the fit.
+    if ((mode == kSweep || mode == kCarry) && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
+        ws->e_state == 1 && known && L.act <= 4.0 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx)
+        mode = kBound;
     auto regroup_due = [&]() {
         return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
                L.act <= 4.0 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
@@ -1144,11 +1154,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 ++ws->passes[7];
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step active-pair evaluation", e);
                 span_begin(ws, kSpanSelect, st);
-                const bool proof = proof_capable;
+                const bool proof = proof_capable && (ws->skip_used || ws->opt_proof_all);       // (some rows may be settled)
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
                                    settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
-                                   ws->rblk);
+                                   ws->rblk, ws->opt_proof_all ? 1 : 0);
                 if (proof) {
                     // proof round: settled rows whose carried bounds left candidates - their component and the candidates
                     // get two-sided bounds from three int8 digits; rows that are proven stay settled, the others join
@@ -1181,7 +1191,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, nullptr, nullptr);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, nullptr, nullptr, 0);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;
@@ -1235,9 +1245,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // pairs evaluated before the counted selection: every row's best component, or (sweep over the previous
         // pass's lists) the previous pass's active pairs
         ws->pend_first_sorted = sorted_now;
-        // (this rank's own numbers: what its kernels did)
-        const bool own = ws->lag.valid && ws->lag.rows == (double)n_rows && !ws->ctr_pending;
-        ws->pend_round0 = (mode == kSweep && ws->sweep_prev && own) ? ws->lag.listed : (double)n_rows;
+        ws->pend_round0 = (mode == kSweep && ws->sweep_prev && own_known) ? ws->lag.listed : (double)n_rows;
         ws->act_rows = n_rows;
     } else {
         ws->ctr_pending = false;

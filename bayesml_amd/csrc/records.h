@@ -349,7 +349,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              float* __restrict__ rthr /*[npad] the row's relevance threshold*/,
                                                              const unsigned char* __restrict__ lcomp /*[npad] component a cached row is in*/,
                                                              unsigned long long* __restrict__ pmask /*null: no proof round*/,
-                                                             int* __restrict__ pblk) {
+                                                             int* __restrict__ pblk,
+                                                             int proof_all /*candidates of rows with an exact reference too*/) {
     __shared__ int wcnt[4][256];
     __shared__ int pcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             else mk[3] = mw;
         }
         bool stays = false, proof_row = false, proof_cand = false;
-        if (pmask != nullptr && !by_bound && !over && (mk[0] | mk[1] | mk[2] | mk[3]) != 0ull) {
+        if (pmask != nullptr && proof_all && !by_bound && !over && (mk[0] | mk[1] | mk[2] | mk[3]) != 0ull) {
             // a row with an exact reference: its candidates (carried bounds that no longer clear the threshold) get fresh
             // int8 bounds first; only those that still do not clear it are evaluated exactly (rec_proof_decide_kernel)
 #pragma unroll
@@ -633,9 +634,13 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
 #pragma unroll
             for (int j = 0; j < kRecSlots; ++j) {
                 const unsigned short k = rec.k[(int64_t)j * rec.npad + n];
-                if (k != kRecEmpty && ((kept[k >> 6] >> (k & 63)) & 1ull) && !((sel >> j) & 1u)) {
+                if (k == kRecEmpty) continue;
+                if (((kept[k >> 6] >> (k & 63)) & 1ull) && !((sel >> j) & 1u)) {
                     sel |= 1u << j;
                     ++in_slots;
+                } else if ((pmask[(int64_t)(k >> 6) * npad + n] >> (k & 63)) & 1ull) {
+                    // done with by its fresh bound: the slot takes it over (tighter than the carried one)
+                    rec.d[(int64_t)j * rec.npad + n] = dist_lower_f32(cvec[k], (double)ub32[(int64_t)k * npad + n]);
                 }
             }
             for (int w = 0; w < W; ++w) {

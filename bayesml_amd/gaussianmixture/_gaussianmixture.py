@@ -195,7 +195,12 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
       comm     a ``bayesml_amd.RowShard``: ``x`` given to ``update_posterior`` is then this rank's
                block of rows of the global sample matrix (one process per GPU)
       verbose  False silences the per-iteration progress line
+
+    A sample matrix whose per-pair workspace does not fit the GPU (K N of the order of 2e10) is processed in row tiles
+    through one workspace (``_engine.TiledDataPass``); the reference keeps its [N, K] arrays on the host instead.
     """
+
+    _row_tiling = True
 
     def __init__(self, c_num_classes, c_degree, h0_alpha_vec=None, h0_m_vecs=None, h0_kappas=None,
                  h0_nus=None, h0_w_mats=None, seed=None, *, device=None, comm=None, verbose=True):

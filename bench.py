@@ -417,9 +417,13 @@ def main():
         if "mstep_main" in groups:
             groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (acc if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
         cand = [g for g in ("estep_main", "estep_gather", "mstep_main") if g in groups and "algorithmic_GBps" in groups[g]]
-        dom = max(cand, key=lambda g: groups[g]["ms"])
-        dom_kernel = {"estep_main": names[0], "estep_gather": "estep_gather_f64", "mstep_main": names[1]}[dom]
-        ach = groups[dom]["algorithmic_GBps"]
+        if cand:
+            dom = max(cand, key=lambda g: groups[g]["ms"])
+            dom_kernel = {"estep_main": names[0], "estep_gather": "estep_gather_f64", "mstep_main": names[-1]}[dom]
+            ach = groups[dom]["algorithmic_GBps"]
+        else:       # a row-tiled run (the workspace does not fit: _engine.TiledDataPass) keeps no per-group events
+            dom, dom_kernel = None, "tiled data pass (whole step)"
+            ach = n_local * row_bytes / (step_ms * 1e-3) / 1e9
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so they come
         # from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py), and only when that
         # file was made for the kernel that actually ran here
@@ -430,7 +434,7 @@ def main():
             ran = (dom_kernel == "estep_gather_f64" and timed_counts["estep_gather"] > 0) or any(dom_kernel in l for l in launches)
             if pm and pm.get("config") == f"K{K} D{D} N{n_local} {dt}" and ran:
                 # per step like `achieved`: the counters' average per launch x this run's launches of the group per step
-                per_step = groups[dom]["launch_groups_per_step"]
+                per_step = groups[dom]["launch_groups_per_step"] if dom else 1.0
                 traffic = (pm["fetch_bytes"] + pm["write_bytes"]) * per_step
                 traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, average per launch x {per_step:.2f} launches per "
                                "step): " + pm["note"])
@@ -460,7 +464,7 @@ def main():
                         "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M).  "
                         "executed_f64_tflops of estep_gather charges the pairs that take the gather's early way out "
                         "(DESIGN.md 5c; pairs_per_sample.early_exits) with the tile pairs they really do"}
-        if args.dense or not sparse_e:
+        if (args.dense or not sparse_e) and dom:
             # the dense kernels are MFMA-bound: executed flops against the f64 MFMA peak
             ex = fl_pair * n_local * K
             roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_F64_MFMA_TFLOPS,

@@ -31,7 +31,9 @@ VARIANTS = {
     # the candidates of every other row before anything is evaluated in f64.  "settle": 5 nats of slack (fewer rows settle,
     # fewer come back); the read-outs below need the settled rows' values re-evaluated
     "settle": {"GMMVB_SETTLE_MARGIN": "5"},
-    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_MARGIN": "5"},
+    "force_settle": {"GMMVB_ESTEP_PRUNE": "force"},
+    # every spare candidate through the proof round first (experiment switch)
+    "force_proof_all": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "all"},
     # ... without the proof round: rows settle on the strength of their carried bounds only (whatever the drift and the
     # spare candidates of the last sweep, 10 nats of slack) and come loose into the exact gather
     "settle_noproof": {"GMMVB_PROOF": "0", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
@@ -100,7 +102,7 @@ def expect_kernels(counts, variant, min_carried=1, lists=True):
         assert counts["mstep_list"] >= 1, counts
     if variant == "force_nocarry":
         assert counts["estep_carried"] == counts["estep_sweep"] == 0, counts
-    elif variant in ("settle", "force_settle", "settle_noproof", "force_settle_noproof"):
+    elif variant in ("settle", "force_settle", "settle_noproof", "force_settle_noproof", "force_proof_all"):
         assert counts["estep_sweep"] >= 2, counts
     else:       # carried over the parameter update: on per-row records, or (early in a fit) by a sweep of the dense array
         assert counts["estep_carried"] + counts["estep_sweep"] >= min_carried, counts
@@ -204,7 +206,7 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_noproof", "force_records"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_noproof", "force_records", "force_proof_all"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper

@@ -1,0 +1,66 @@
+"""Row-tiled data pass (``_engine.TiledDataPass``): a sample matrix whose per-pair workspace would not fit the GPU goes
+through ONE workspace in row tiles; statistics, posterior and read-outs must equal the untiled run's (the reference has no
+such limit: it keeps its [N, K] arrays on the host, ``_gaussianmixture.py:835-836``)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import gmm_vb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit(x, K, D, tile, init_type, force):
+    from bayesml_amd import gaussianmixture as gm
+    old = {k: os.environ.get(k) for k in ("BAYESML_AMD_TILE_ROWS", "GMMVB_ESTEP_PRUNE")}
+    try:
+        os.environ.pop("BAYESML_AMD_TILE_ROWS", None)
+        os.environ.pop("GMMVB_ESTEP_PRUNE", None)
+        if tile:
+            os.environ["BAYESML_AMD_TILE_ROWS"] = str(tile)
+        if force:
+            os.environ["GMMVB_ESTEP_PRUNE"] = "force"
+        m = gm.LearnModel(K, D, seed=0, device="cuda:0", verbose=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.update_posterior(x, max_itr=8, num_init=2, tolerance=0.0, init_type=init_type)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    return m
+
+
+@pytest.mark.parametrize("init_type,force", [("subsampling", False), ("subsampling", True), ("random_responsibility", False)])
+def test_tiled_run_equals_untiled(init_type, force):
+    from bayesml_amd._engine import DataPass, TiledDataPass
+    K, D, N = 12, 64, 100_000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    one = _fit(x, K, D, 0, init_type, force)
+    til = _fit(x, K, D, 30016, init_type, force)
+    assert isinstance(one._engine, DataPass) and isinstance(til._engine, TiledDataPass)
+    assert til._engine.n_tiles == 4
+    if force:
+        c = til._engine.pass_counts()
+        assert c["estep_bound"] >= 4 and c["estep_sweep"] == 0, c           # tiles cannot carry bounds: fresh bound passes
+    for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+        assert rel_err(til.get_hn_params()[key], one.get_hn_params()[key]) < 1e-9, key
+    assert abs(til.vl - one.vl) < 1e-10 * abs(one.vl)
+    assert rel_err(til.ns, one.ns) < 1e-10 and rel_err(til.s_mats, one.s_mats) < 1e-9
+    assert np.max(np.abs(til.r_vecs - one.r_vecs)) < 1e-9                    # read-outs across the tiles
+    z1 = one.estimate_latent_vars(x[40_000:70_000])
+    z2 = til.estimate_latent_vars(x[40_000:70_000])
+    assert np.array_equal(z1, z2)
+    # and the oracle's posterior (8 iterations, 2 restarts) for the subsampling start
+    if init_type == "subsampling" and not force:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = orc.update_posterior(x.astype(np.float64), orc.Prior.default(K, D),
+                                       orc.Posterior.from_prior(orc.Prior.default(K, D)), np.random.default_rng(0),
+                                       max_itr=8, num_init=2, tolerance=0.0)
+        assert rel_err(til.hn_m_vecs, ref.posterior.m) < 1e-7 and rel_err(til.hn_w_mats, ref.posterior.w) < 1e-7
