@@ -46,14 +46,21 @@ class RowShard:
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         """In-place sum over ranks of a contiguous f64 tensor (the per-iteration collective)."""
+        if not (self.world > 1 or self.always):
+            return t
         if self.native and t.is_cuda:
             if self._rccl is None:
                 from ._engine import RcclComm
-                self._rccl = RcclComm(self.rank, self.world, t.device)
+                self._rccl = RcclComm(self.rank, self.world, t.device, group=self.group)
             return self._rccl.all_reduce_(t)
-        if self.world > 1 or self.always:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def close(self):
+        """Release the library's RCCL communicator (``native=True``); the process group is the caller's."""
+        if self._rccl is not None:
+            self._rccl.close()
+            self._rccl = None
 
     def local_indices(self, global_idx: torch.Tensor) -> torch.Tensor:
         """Rows of a global index list that this rank owns, as local row numbers."""
@@ -66,7 +73,12 @@ class RestartShard:
     process holds ALL rows; restart i of ``update_posterior`` runs on rank i mod world (each rank still draws every
     restart's random numbers, so the streams - and the result - are those of a single process), the winner is chosen
     with the reference's rule over the gathered lower bounds and its posterior is broadcast from its owner.
-    No collective inside a VB iteration."""
+    No collective inside a VB iteration.
+
+    One deviation from a single process: the reference keeps ``s_mats[k]`` of a component with ``ns[k] == 0`` from the
+    previous pass - across restarts too (``_gaussianmixture.py:729``, "stale" S).  Here every rank only sees the chain of
+    its own restarts, so for an EXACTLY empty component ``s_mats[k]`` (an attribute, not part of the posterior) can differ
+    from the single-process value and between ranks."""
 
     restart_parallel = True
     row_offset = 0
@@ -98,8 +110,10 @@ class RestartShard:
         return out
 
     def broadcast_(self, tensors, src: int):
+        """``src`` is a rank of ``self.group``; torch.distributed wants the global rank."""
+        gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
         for t in tensors:
-            dist.broadcast(t, src=src, group=self.group)
+            dist.broadcast(t, src=gsrc, group=self.group)
 
 
 class SingleProcess:

@@ -138,7 +138,8 @@ class RcclComm:
     current torch stream.  ``bootstrap`` hands rank 0's 128-byte id to the other ranks; by default it is a
     ``torch.distributed`` broadcast over the default process group (any backend)."""
 
-    def __init__(self, rank: int, world: int, device, bootstrap=None):
+    def __init__(self, rank: int, world: int, device, bootstrap=None, group=None):
+        """``rank`` / ``world`` are the ranks of ``group`` (default: the whole job); the id travels over that group."""
         self.lib = load_library()
         self.device = torch.device(device)
         buf = (ctypes.c_ubyte * 128)()
@@ -147,9 +148,10 @@ class RcclComm:
         if bootstrap is None:
             import torch.distributed as dist
             t = torch.tensor(list(buf), dtype=torch.uint8)
-            if dist.get_backend() == "nccl":
+            if dist.get_backend(group) == "nccl":
                 t = t.to(self.device)
-            dist.broadcast(t, src=0)
+            # (broadcast takes the GLOBAL rank of the source: rank 0 of the group)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             raw = bytes(t.cpu().tolist())
         else:
             raw = bootstrap(bytes(buf))
@@ -172,6 +174,12 @@ class RcclComm:
             torch.cuda.synchronize(self.device)
             self.lib.gmmvb_comm_destroy(self._comm)
             self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def kside_factor(w_inv: torch.Tensor):
@@ -552,9 +560,13 @@ class TiledDataPass:
         self.n_tiles = (self.max_rows + self.tile_rows - 1) // self.tile_rows
         self.inner = DataPass(K, D, x_dtype, self.tile_rows, device)
         self.device, self.lib, self.stats_len = self.inner.device, self.inner.lib, self.inner.stats_len
-        self._tmp = torch.zeros(self.stats_len, dtype=torch.float64, device=self.device)
-        self._tail_tmp = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
-        self._tail_acc = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
+        try:
+            self._tmp = torch.zeros(self.stats_len, dtype=torch.float64, device=self.device)
+            self._tail_tmp = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
+            self._tail_acc = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
+        except torch.OutOfMemoryError:
+            self.inner.close()
+            raise
         self._tail_in = None           # job-wide counters of the previous pass (summed over tiles, and over ranks by the caller)
         self._ranks = 1
         self._global_rows = self.max_rows
@@ -744,23 +756,36 @@ class TiledDataPass:
 
 
 def open_data_pass(K, D, x_dtype, n_rows, device, tile_rows=None):
-    """A DataPass for all rows if its workspace fits the GPU, else a TiledDataPass (halving the tile until it does).
-    ``tile_rows`` (or BAYESML_AMD_TILE_ROWS in the environment) forces tiles of that many rows."""
+    """A DataPass for all rows if its workspace fits the GPU - leaving room for the K-sized state and the caller's
+    temporaries -, else a TiledDataPass (halving the tile until it does).  ``tile_rows`` (or BAYESML_AMD_TILE_ROWS in the
+    environment) forces tiles of that many rows."""
     forced = tile_rows or int(os.environ.get("BAYESML_AMD_TILE_ROWS", "0"))
     if forced and forced < n_rows:
         return TiledDataPass(K, D, x_dtype, n_rows, device, forced)
-    try:
-        return DataPass(K, D, x_dtype, n_rows, device)
-    except EngineError as e:
-        if "GMMVB_ENOMEM" not in str(e):
-            raise
-    rows = (n_rows + 1) // 2
-    while rows >= 1 << 16:
-        torch.cuda.empty_cache()
+    dev = torch.device(device)
+
+    def fits(make):
         try:
-            return TiledDataPass(K, D, x_dtype, n_rows, device, (rows + 63) // 64 * 64)
+            eng = make()
         except EngineError as e:
             if "GMMVB_ENOMEM" not in str(e):
                 raise
+            return None
+        except torch.OutOfMemoryError:
+            return None
+        free, total = torch.cuda.mem_get_info(dev)
+        if free < max(4 << 30, total // 16):          # no room left to work in
+            eng.close()
+            torch.cuda.empty_cache()
+            return None
+        return eng
+
+    eng = fits(lambda: DataPass(K, D, x_dtype, n_rows, dev))
+    rows = (n_rows + 1) // 2
+    while eng is None and rows >= 1 << 16:
+        torch.cuda.empty_cache()
+        eng = fits(lambda: TiledDataPass(K, D, x_dtype, n_rows, dev, (rows + 63) // 64 * 64))
         rows = (rows + 1) // 2
-    raise EngineError(f"no workspace fits the GPU even for tiles of {rows * 2} rows (K={K}, D={D})")
+    if eng is None:
+        raise EngineError(f"no workspace fits the GPU even for tiles of {rows * 2} rows (K={K}, D={D})")
+    return eng

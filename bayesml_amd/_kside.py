@@ -478,7 +478,9 @@ class KStepper:
 
     def hint(self, gmean):
         """The drift hint of q -> q_next for DataPass.set_drift, or None when the engine cannot use one."""
-        return (self.gamma, self.delta, self.big_gamma, gmean) if self.want_drift else None
+        # (the engine reads a summary <= 0 as "unknown"; a summary that IS that bad - delta > 30 gamma for some component -
+        # must say "bound afresh" instead, which any value below 0.5 does)
+        return (self.gamma, self.delta, self.big_gamma, max(float(gmean), 1e-6)) if self.want_drift else None
 
     def advance(self):
         """q <- q_next (after the engine has been given q_next's parameters)."""

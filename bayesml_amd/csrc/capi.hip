@@ -92,14 +92,10 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         // Cap on the rows of one M-step split: 16 MB of centred rows (16384 rows at D = 128).  All component groups
         // of a split stream the same rows; short splits keep those workgroups within an L2's reach of each other
         // (measured at C3: fetch 96 GB -> 16-21 GB ~ the algorithmic 15.4 GB, kernel 175.6 -> 171.5 ms) at the
-        // price of more slabs (+0.7 ms reduce).  env GMMVB_MSTEP_SPLIT_ROWS overrides; 0 disables the cap.
-        const char* v = std::getenv("GMMVB_MSTEP_SPLIT_ROWS");
+        // price of more slabs (+0.7 ms reduce).
         ws->split_rows = round_up(std::max<int64_t>(64, (16 << 20) / (16 * ws->T * 8)), 64);
-        if (v) ws->split_rows = std::atoll(v) > 0 ? round_up(std::max<int64_t>(64, std::atoll(v)), 64) : 0;
-        if (ws->split_rows) {
-            const int64_t need = round_up((max_rows + ws->split_rows - 1) / ws->split_rows, 8);
-            if (need > ws->S_cap) ws->S_cap = (int)need;
-        }
+        const int64_t need = round_up((max_rows + ws->split_rows - 1) / ws->split_rows, 8);
+        if (need > ws->S_cap) ws->S_cap = (int)need;
     }
     ws->img_len = estep_image_doubles(ws->T);
     {
@@ -113,10 +109,6 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (v && std::strcmp(v, "lds4") == 0) ws->estep_variant = kEstepLds;
         if (v && std::strcmp(v, "i8") == 0) ws->estep_variant = kEstepI8;
     }
-    {
-        const char* v = std::getenv("GMMVB_ESTEP_BOUND");
-        ws->bound_i8 = !(v && std::strcmp(v, "f64") == 0);
-    }
     struct { double** p; int64_t n; } bufs[] = {
         {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},
         {&ws->img, (int64_t)K * ws->img_len},
@@ -125,14 +117,18 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         {&ws->xc, 0},
         {&ws->dpart, ((ws->npad + kLseRows - 1) / kLseRows) * K}, {&ws->thr, K},
         {&ws->apart, (ws->npad + kSelRows - 1) / kSelRows}, {&ws->ctr, 8}, {&ws->drift, 4 * (int64_t)K}};
-    {
-        const char* v = std::getenv("GMMVB_MSTEP_PRECENTER");      // "0" = never make the centred copy
-        if (!(v && std::strcmp(v, "0") == 0)) bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;
-    }
+    bufs[6].n = (ws->npad + 64) * 16 * (int64_t)ws->T;            // the centred copy
     {
         const char* v = std::getenv("GMMVB_MSTEP_SPARSE");         // "0" = always the dense M-step
         ws->sparse = !(v && std::strcmp(v, "0") == 0);
         if (max_rows > 2000000000) ws->sparse = false;             // the sample lists hold 32-bit row numbers
+        if (K == 1) {
+            // one component: r = 1 for every row, nothing to prune, list or cache - and the one-pass moment computation of
+            // multivariate_normal.LearnModel (K = 1, unit responsibilities) should not pay for a centred copy it never
+            // builds: the M-step reads x directly
+            ws->sparse = false;
+            bufs[6].n = 0;
+        }
         v = std::getenv("GMMVB_SORT_ROWS");
         ws->sort_rows = !(v && std::strcmp(v, "0") == 0) && (int64_t)max_rows <= 2000000000;
         v = std::getenv("GMMVB_ESTEP_PRUNE");
@@ -140,38 +136,22 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;
         v = std::getenv("GMMVB_SETTLE_MARGIN");                    // nats; negative = never settle rows
         if (v) ws->settle_margin = std::atof(v);
-        v = std::getenv("GMMVB_SETTLE_GAMMA");
-        if (v) ws->settle_gamma = std::atof(v);
-        v = std::getenv("GMMVB_SETTLE_SPARE");
-        if (v) ws->settle_spare = std::atof(v);
-        v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round for settled rows; "all": every
-        ws->opt_proof = !(v && std::strcmp(v, "0") == 0);          // spare candidate goes through it first (experiment)
+        v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round (rows then never settle);
+        ws->opt_proof = !(v && std::strcmp(v, "0") == 0);          // "all": every spare candidate goes through it first
         ws->opt_proof_all = v && std::strcmp(v, "all") == 0;
-        ws->prefer_records = std::getenv("GMMVB_ESTEP_RECORDS") != nullptr;
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
-        v = std::getenv("GMMVB_EXIT_MARGIN");                      // nats the partial bound must lie below the threshold
-        if (v) ws->exit_margin = (float)std::atof(v);
         v = std::getenv("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
         ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
         ws->opt_debug = std::getenv("GMMVB_DEBUG") != nullptr;
-        v = std::getenv("GMMVB_ESTEP_BOUND_BLOCKS");
-        ws->opt_bound_blocks = v ? std::atoi(v) : 0;
-        v = std::getenv("GMMVB_SPARE_WEIGHT");
-        if (v) ws->opt_spare_weight = std::atof(v);
-        v = std::getenv("GMMVB_MSTEP_CHUNK");
-        if (v) ws->opt_mstep_chunk = std::max(64, std::atoi(v) / 64 * 64);
-        ws->opt_list_xc = std::getenv("GMMVB_MSTEP_LIST_XC") != nullptr;
-        ws->opt_small_off = std::getenv("GMMVB_MSTEP_SMALL_OFF") != nullptr;
-        v = std::getenv("GMMVB_MSTEP_SMALL_CW");
-        ws->opt_small_cw = (v && std::atoi(v) == 4) ? 4 : 8;
-        ws->opt_one_level = std::getenv("HMMVB_ONE_LEVEL") != nullptr;
-        v = std::getenv("GMMVB_REGROUP_MOVED");
-        if (v) ws->opt_regroup_moved = std::atof(v);
+        v = std::getenv("GMMVB_X_TB");                             // experiment: pins the bound pass's output blocks
+        ws->opt_tb_pin = v ? std::atoi(v) : 0;
+        v = std::getenv("GMMVB_X_REGROUP_ACT");                    // experiment: active pairs per row at which a regrouping is forced
+        if (v) ws->opt_regroup_act = std::atof(v);
     }
     {
-        const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0 && ws->bound_i8;
+        const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0;
         hipError_t e8 = hipSuccess;
         if (full) {
             ws->img_i8_len = estep_i8_image_bytes(D, 0);
@@ -521,8 +501,11 @@ static int ensure_lists(gmmvb_workspace* ws) {
         if (e == hipSuccess) ws->bytes += (int64_t)ws->max_rows * ws->D * (int64_t)esz + 3 * np * (int64_t)sizeof(int);
     }
     if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (sample lists / records)", e);
-    ws->bytes += ((int64_t)ws->K * np + np + 2 * ws->K + 1 + sel_blocks * ws->K) * (int64_t)sizeof(int) + words * np * 8 +
-                 2 * sel_blocks * 8 + np * (kRecSlots * 6 + 4 + 3);
+    // lists, khat, counts, plans, four sets of block counts and their scan parts; four sets of masks; lock / lcomp / dlock /
+    // rthr; the cache; eight per-block counters; the records
+    ws->bytes += ((int64_t)ws->K * np + np + 4 * ws->K + 3 + 4 * sel_blocks * ws->K + (int64_t)ws->K * kScanParts) * (int64_t)sizeof(int) +
+                 4 * words * np * 8 + np * (1 + 1 + 4 + 4) + gmmvb_stats_len(ws->K, ws->D) * 8 + 8 * sel_blocks * 8 +
+                 np * (kRecSlots * 6 + 4 + 3);
     return GMMVB_OK;
 }
 
@@ -790,24 +773,18 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     return hipGetLastError();
 }
 
-// bound pass of the pruned E-step: an upper bound of ln rho for every pair (int8 digits, or leading f64 blocks) and khat
-static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepArgs& a, const EstepI8Args& a8, int is64, bool vec,
-                                    hipStream_t st, const char** name, int* rpw_out, int64_t* grid_out) {
-    const int rpw = ws->img_i8b ? estep_i8_rows_per_wg() : estep_bound_rows_per_wg(ws->T, is64);
-    int64_t grid = (a.n_rows + rpw - 1) / rpw;
+// bound pass of the pruned E-step: an upper bound of ln rho for every pair (three int8 digits) and the best of them, khat
+static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepI8Args& a8, int is64, bool vec, hipStream_t st,
+                                    const char** name, int* rpw_out, int64_t* grid_out) {
+    const int rpw = estep_i8_rows_per_wg();
+    int64_t grid = (a8.n_rows + rpw - 1) / rpw;
     if (grid > (1 << 20)) grid = 1 << 20;
     *rpw_out = rpw;
     *grid_out = grid;
-    hipError_t e;
-    if (ws->img_i8b) {
-        EstepI8Args ab = a8;
-        ab.img = ws->img_i8b;
-        ab.khat = ws->khat;             // the bound kernel also finds every row's best component
-        e = launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, name);
-    } else {
-        e = launch_estep_bound(ws->T, is64, vec, (int)grid, st, a, name);
-    }
-    return e;
+    EstepI8Args ab = a8;
+    ab.img = ws->img_i8b;
+    ab.khat = ws->khat;
+    return launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, name);
 }
 
 // masks -> per-component lists -> chunk plan -> exact f64 evaluation of the listed pairs (all sized on the device)
@@ -825,7 +802,7 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     if (e != hipSuccess) return e;
     span_begin(ws, kSpanGather, st);
     e = launch_estep_gather_dev(ws->T, is64, vec, 2 * ws->num_cu, st, a, ws->lists, ws->npad, ws->counts, ws->plan, thr,
-                                thr ? ws->exit_ctr : nullptr, ws->exit_margin);
+                                thr ? ws->exit_ctr : nullptr, 0.0f);
     span_end(ws, st);
     ++ws->passes[7];
     return e;
@@ -856,7 +833,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (rc) return rc;
     }
     poll_counters(ws);
-    enum { kDense = 0, kBound = 1, kCarry = 2, kSweep = 3 };
+    enum { kDense = 0, kBound = 1, kSweep = 3 };      // (2 was the pass on per-row records, gone in round 3)
     int mode = kDense;
     const gmmvb_pass_counters& L = ws->sharded ? ws->pol : ws->lag;
     const bool can_prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr && ws->rec_k != nullptr;
@@ -879,29 +856,16 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (sparse_ok) {
             mode = kBound;
             const bool hinted = same_rows && ws->have_drift && !ws->opt_carry_off;
-            // Two ways of carrying the previous pass over the parameter update (gmmvb_set_drift):
-            //   records (records.h)  55 bytes per row, ONE bound for all components without a slot: it erodes at the pace
-            //                        of the fastest-moving component (a 300-sample component with gamma 0.95 costs every
-            //                        row ~40 nats per pass), so it is used once even the slowest gamma is >= 0.985;
-            //   dense sweep          every entry of the ln rho array carried with its own component's drift: one sweep
-            //                        of the array (2.5 ms at C3) + the previous best evaluated first, robust while
-            //                        components still move by per cents.
+            // Carrying the previous pass over the parameter update (gmmvb_set_drift): a sweep of the f32 per-pair bound
+            // array, every entry with its own component's drift (1.5 ms at C3), after the previous pass's active pairs have
+            // been evaluated under the new parameters.  (Round 2 also had a pass on 55-byte per-row records with ONE rest
+            // bound per row; it eroded at the pace of the fastest-moving component and the default policy never chose it.)
             // typical_gamma is the caller's pessimistic summary min_k (gamma_k - delta_k / 30) (0.3, 0.6, 0.7, 0.8 in
-            // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th).
+            // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th): below 0.5 the bounds are
+            // made afresh.
             const double tg = ws->typical_gamma;
-            bool carry = hinted && ws->rec_valid && !(tg > 0.0 && tg < 0.985);
-            // (the sweep's bounds erode by each component's own gamma: the spare-candidate rule below ends a run of
-            // sweeps when a fresh bound pass has become cheaper; 24 in a row at most)
-            // (settled rows, workspace.h, live on sweeps: no cap and no switch to records while there are any - their
-            // carried bounds are refreshed whenever a row comes loose)
-            const bool may_settle = ws->cache_on && ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
-                                    ws->xc_ldx == ldx;
-            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5) && (ws->sweeps < 24 || may_settle);
-            if (sweep && may_settle) carry = false;
-            if (ws->prefer_records) {                                 // tests: the record pass whatever the drift summary
-                carry = hinted && ws->rec_valid;
-                sweep = false;
-            }
+            const bool carry = false;
+            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5);
             if ((carry || sweep) && known && L.mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
@@ -910,18 +874,17 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
-                if (gpp * spare * ws->opt_spare_weight >= bound_cost) carry = sweep = false;
+                if (gpp * spare * 2.5 >= bound_cost) sweep = false;
                 // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
                 // (x4 - x8 observed): stop carrying well before they dominate
-                if (L.over > 0.02 * rows_l || L.eval > 0.35 * pairs_l) carry = sweep = false;
+                if (L.over > 0.02 * rows_l || L.eval > 0.35 * pairs_l) sweep = false;
             }
-            if ((carry || sweep) && known && L.mode == kDense && L.act > 0.1 * pairs_l) carry = sweep = false;
+            if (sweep && known && L.mode == kDense && L.act > 0.1 * pairs_l) sweep = false;
             // straight from a dense pass the parameters usually still jump (second or third iteration of a restart): the
             // sweep's per-pair bounds are exact values then, but carried over such an update most of them end up
             // candidates (measured at C4: 118 of 256 per row, 171 ms) - a bound pass is the safe first pruned pass
             if (sweep && known && L.mode == kDense && tg > 0.0 && tg < 0.85) sweep = false;
-            if (carry) mode = kCarry;
-            else if (sweep) mode = kSweep;
+            if (sweep) mode = kSweep;
             // a bound pass that left most pairs candidates (the parameters jumped): back to the dense kernel
             if (mode == kBound && ws->prune != 2 && known && L.mode == kBound && L.eval > 0.6 * pairs_l) {
                 mode = kDense;
@@ -938,19 +901,20 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // the proof round bound passes have become rare: the first time the responsibilities are sparse enough for the grouping
     // to pay (at most 4 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
     // kernels over ungrouped rows are 15-40 % slower for the rest of the fit.
-    if ((mode == kSweep || mode == kCarry) && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
-        ws->e_state == 1 && known && L.act <= 4.0 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx)
+    if (mode == kSweep && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
+        ws->e_state == 1 && known && L.act <= ws->opt_regroup_act * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
+        ws->xc_ldx == ldx)
         mode = kBound;
     auto regroup_due = [&]() {
         return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
                L.act <= 4.0 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
-               (!ws->sorted || ws->moved_since_sort > ws->opt_regroup_moved * rows_l);      // (again once that share of the rows has moved on)
+               (!ws->sorted || ws->moved_since_sort > 0.05 * rows_l);      // (again once that share of the rows has moved on)
     };
     bool settle = false;
     if (ws->lock) {
         const bool keep = mode != kDense && same_rows && !ws->lock_reset && !ws->delta_pending && !regroup_due();
         if (ws->lock_reset || (ws->lock_live && !keep)) {
-            if (mode == kSweep || mode == kCarry) mode = kBound;
+            if (mode == kSweep) mode = kBound;
             (void)hipMemsetAsync(ws->lock, 0, (size_t)ws->npad, st);
             (void)hipMemsetAsync(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double), st);
             ws->lock_live = false;
@@ -961,24 +925,14 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         settle = mode != kDense && ws->cache_on && ws->sparse && ws->masks && ws->xc && ws->xc_src == x_dev &&
                  ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     }
-    // Rows with a single active component are settled (left out of the E-step as well as of the M-step).  With the proof
-    // round available - the int8 digit planes of this matrix are in the workspace, about the pivot the component images
-    // were packed for - a settled row whose carried bounds no longer prove it costs a few int8 pairs, so rows settle in
-    // every pruned pass.  Without it a row that comes loose costs exact evaluations, and settling while the components
-    // still move by per cents makes rows come loose in masses (measured at C3, profiles/r2_experiments.md: 14.1 instead of
-    // 12.9 ms per step over iterations 6-25): hence the gate with hysteresis on the drift summary and on the spare
-    // candidates of the last sweep.
+    // Rows with a single active component are settled (left out of the E-step as well as of the M-step) in every pruned
+    // pass, provided the proof round is available - the int8 digit planes of this matrix are in the workspace, about the
+    // pivot the component images were packed for: a settled row whose carried bounds no longer prove it then costs a few
+    // int8 pairs.  (Without it such a row costs exact evaluations, and settling while the components still move by per
+    // cents made rows come loose in masses - round 2 needed a gate with hysteresis on the drift, profiles/r2_experiments.md.)
     const bool proof_capable = settle && ws->opt_proof && ws->xq != nullptr && ws->img_i8b != nullptr && ws->xq_src == x_dev &&
                                ws->xq_rows == n_rows && ws->xq_ldx == ldx && ws->xq_gen == ws->img_gen;
-    if (mode != kSweep) {
-        ws->settle_on = false;
-    } else if (!ws->settle_on) {
-        ws->settle_on = ws->typical_gamma >= ws->settle_gamma && known && L.mode == kSweep &&
-                        std::max(0.0, L.eval - (L.act - L.settled)) <= ws->settle_spare * rows_l;
-    } else if (ws->typical_gamma > 0.0 && ws->typical_gamma < ws->settle_gamma - 0.05) {
-        ws->settle_on = false;
-    }
-    const double skip_margin = (settle && ws->settle_margin >= 0.0 && (proof_capable || ws->settle_on)) ? ws->settle_margin : -1.0;
+    const double skip_margin = (proof_capable && ws->settle_margin >= 0.0) ? ws->settle_margin : -1.0;
     ws->settled_fresh = false;
     if (ws->opt_debug)
         std::fprintf(stderr, "[gmmvb] estep: mode=%d known=%d lag(mode=%d act=%.3g eval=%.3g over=%.3g settled=%.3g listed=%.3g) gamma=%.3f rec_valid=%d drift=%d settle=%d\n",
@@ -992,10 +946,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // bound passes; look one level down when the current one leaves hardly any spare candidates or one level up
         // when more than half of its candidates are spare, if that level is unknown.
         const int t32 = (ws->D + 31) / 32;
-        const int pin = ws->opt_bound_blocks;                          // pins the level (1 .. ceil(D/32))
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
-        if (pin >= 1 && pin <= t32) {
-            ws->bound_tb = pin;
+        if (ws->opt_tb_pin >= 1 && ws->opt_tb_pin <= t32) {
+            ws->bound_tb = ws->opt_tb_pin;
         } else if (known && L.mode == kBound) {
             const int cur = ws->bound_tb;
             ws->tb_cand[cur] = L.eval / pairs_l;
@@ -1106,18 +1059,14 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (rc) return rc;
         if (mode == kBound) {
             span_begin(ws, kSpanEstepMain, st);
-            e = launch_bound_pass(ws, a, a8, is64, vec, st, &name, &rpw, &grid);
+            e = launch_bound_pass(ws, a8, is64, vec, st, &name, &rpw, &grid);
             span_end(ws, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
             ++ws->passes[1];
             // the best component of every row, exactly
             span_begin(ws, kSpanSelect, st);
-            if (ws->img_i8b)
-                hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
-                                   ws->K, ws->khat, ws->masks, ws->blk);
-            else
-                hipLaunchKernelGGL(select_mask_kernel<0>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
-                                   ws->K, ws->khat, ws->masks, ws->blk);
+            hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                               ws->K, ws->khat, ws->masks, ws->blk);
             span_end(ws, st);
             e = lists_and_gather(ws, a, is64, vec, sel_grid, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step best-component evaluation", e);
@@ -1125,8 +1074,28 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             span_begin(ws, kSpanSelect, st);
             hipLaunchKernelGGL(rec_build_kernel<true>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->lnrho,
                                ws->npad, n_rows, ws->K, ws->cvec, ws->khat, rec, ws->ub32);
-            hipLaunchKernelGGL(rec_select_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
-                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart, ws->rthr);
+            hipLaunchKernelGGL(rec_select_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->cvec, ws->masks,
+                               ws->npad, ws->blk, ws->epart, ws->opart, ws->rthr);
+            if (proof_capable) {
+                // the candidates' bounds come from the bound pass's leading output blocks only: three int8 digits over ALL
+                // blocks first (a third of an exact evaluation's cost), and only what still does not clear the threshold
+                // goes to the exact gather
+                launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+                hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
+                                   ws->blk, ws->lists, ws->npad);
+                hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K, estep_i8_pairs_per_chunk(),
+                                   ws->plan);
+                span_end(ws, st);
+                span_begin(ws, kSpanProof, st);
+                e = launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists,
+                                          ws->npad, ws->counts, ws->plan, ws->ub32, ws->lnrho, ws->npad);
+                span_end(ws, st);
+                if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round (bound pass)", e);
+                span_begin(ws, kSpanSelect, st);
+                hipLaunchKernelGGL(rec_prune_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->masks, ws->npad, n_rows, ws->K,
+                                   ws->cvec, ws->ub32, ws->rthr, ws->blk, ws->epart, ws->ppart);
+                proof_ran = true;
+            }
             span_end(ws, st);
         } else if (mode == kSweep) {
             rpw = kSelRows;
@@ -1195,15 +1164,6 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;
-        } else {
-            rpw = kSelRows;
-            grid = sel_grid;
-            name = "estep_carried_bounds";
-            ++ws->passes[2];
-            span_begin(ws, kSpanSelect, st);
-            hipLaunchKernelGGL(rec_select_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->drift,
-                               ws->cvec, ws->masks, ws->npad, ws->blk, ws->epart, ws->opart, ws->rthr);
-            span_end(ws, st);
         }
         // candidates: a pair whose first output blocks already put it below the row's threshold is not evaluated further
         e = lists_and_gather(ws, a, is64, vec, sel_grid, st, ws->gather_exit ? ws->rthr : nullptr);
@@ -1269,7 +1229,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->prev_pass = mode;
     // the f32 bound array holds a value or bound under the parameters in force for EVERY pair after a dense pass, a
     // bound pass or a sweep; a pass on records only refreshes the evaluated entries
-    ws->dense_valid = mode != kCarry;
+    ws->dense_valid = true;
     if (mode == kDense || mode == kBound) ws->sweeps = 0;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
                   (i8 || mode != kDense) ? 512 : estep_threads(ws->estep_variant), rpw);
@@ -1361,12 +1321,11 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
         if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
         const int cap_chunks0 = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
-        const int r_min0 = ws->opt_mstep_chunk;
+        const int r_min0 = 1024;           // list entries per chunk (2048: +4 %, 4096: +19 % on the list M-step, round 2)
         MstepListArgs la0{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks0, r_min0,
                           ws->npad, ws->K, ws->slabs};
         // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
-        if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8) &&
-            !ws->opt_list_xc) {
+        if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8)) {
             if (ws->sorted) {
                 la0.x32 = (const float*)ws->xp;
                 la0.ldx = ws->D;
@@ -1459,12 +1418,13 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
         }
         span_begin(ws, kSpanMstepMain, st);
-        if (ws->T == 1 && pre && !ws->opt_small_off) {
+        if (ws->T == 1 && pre) {
             // one feature tile: a wave walks the rows once for eight components (mstep.h, mstep_small_f64)
-            const int per_wg = 4 * ws->opt_small_cw;
+            constexpr int kSmallCw = 8;
+            const int per_wg = 4 * kSmallCw;
             const int KGW = (ws->K + per_wg - 1) / per_wg;
             grid = 8 * ((S + 7) / 8) * KGW;
-            e = launch_mstep_small((int)grid, st, a, KGW, ws->opt_small_cw, &name);
+            e = launch_mstep_small((int)grid, st, a, KGW, kSmallCw, &name);
         } else {
             e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
         }

@@ -293,87 +293,12 @@ __global__ __launch_bounds__(64 * NW) void estep_lds_f64(const XT* __restrict__ 
 }
 
 // ---- pruned E-step -----------------------------------------------------------------------------------------------
-// Once the responsibilities are sparse, almost every (sample, component) pair only has to be shown irrelevant:
-//   1. estep_bound_f64: the first JB output blocks of y for ALL pairs -> u_nk = c_k - q_JB / 2 >= ln rho_nk
-//      (tri_pairs(JB) of the tri_pairs(T) tile pairs: 6 of 36 at D = 128, JB = 3), written to the ln rho array;
-//   2. select_best_kernel: khat_n = argmax_k u_nk, samples appended to per-component lists;
-//      estep_gather_f64 evaluates those pairs exactly (component fixed per workgroup, sample rows gathered);
-//   3. select_near_kernel: every k with u_nk >= ln rho_{n,khat} - 100 ln 2 joins the lists, evaluated exactly too.
-// Every other pair keeps its upper bound, which proves r_nk < 2^-100: it changes neither lse_n nor (mstep.h) any
-// statistic beyond the last bit.  The results of the exact pairs do not depend on list order (one MFMA column per
-// sample); the lists are filled without atomics, in a fixed order (aux_kernels.h).  Which pairs are candidates is
-// decided per row from the records of records.h.
-template <int JB>
-__host__ __device__ constexpr int bound_img_doubles() { return tri_pairs(JB) * 256 + 128; }
-template <int JB>
-__host__ __device__ constexpr int bound_kb() {
-    const int kb = (64 * 1024) / (bound_img_doubles<JB>() * 8);
-    return kb < 1 ? 1 : (kb > 16 ? 16 : kb);
-}
-template <typename XT>
-__host__ __device__ constexpr int bound_nb(int jb) {      // accumulators 8 JB NB, x registers JB NB 4 (x sizeof/4)
-    const int cap = (sizeof(XT) == 4 ? 12 : 8) / jb;
-    return cap < 1 ? 1 : (cap > 4 ? 4 : cap);
-}
-
-template <int T, int JB, typename XT, bool VEC>
-__global__ __launch_bounds__(512) void estep_bound_f64(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
-                                                       const double* __restrict__ img /*[K][img_doubles(T)]*/,
-                                                       const double* __restrict__ cvec, int K,
-                                                       double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
-    constexpr int NW = 8;
-    constexpr int NB = bound_nb<XT>(JB);
-    constexpr int IMG = img_doubles(T);
-    constexpr int IMJ = bound_img_doubles<JB>();
-    constexpr int PJ = tri_pairs(JB);
-    constexpr int KB = bound_kb<JB>();
-    __shared__ __attribute__((aligned(16))) double smem[2][KB * IMJ];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 15, g = lane >> 4;
-    const int64_t rows_per_wg = NW * 16 * NB;
-    const int64_t n_wg_tiles = (n_rows + rows_per_wg - 1) / rows_per_wg;
-    const int n_blocks = (K + KB - 1) / KB;
-
-    // per component: the first 2 PJ 1-KB pieces of the image (its first PJ tile pairs) and the bias piece
-    auto stage = [&](int kb, int buf) {
-        const int k0 = kb * KB;
-        const int kcount = (K - k0 < KB) ? (K - k0) : KB;
-        const int pieces = kcount * (2 * PJ + 1);
-        for (int piece = wave; piece < pieces; piece += NW) {
-            const int kk = piece / (2 * PJ + 1), q = piece - kk * (2 * PJ + 1);
-            const double* src = img + (int64_t)(k0 + kk) * IMG + (q < 2 * PJ ? q * 128 : tri_pairs(T) * 256) + lane * 2;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(&smem[buf][kk * IMJ + q * 128]),
-                                             16, 0, 0);
-        }
-    };
-
-    for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
-        const int64_t n0 = wt * rows_per_wg + (int64_t)wave * 16 * NB;
-        int64_t ld[NB], stv[NB];
-        tile_rows<NB>(n0, n, n_rows, ld, stv);
-        XT xr[NB][JB][4];
-        load_x_tile<JB, NB, XT, VEC>(x, ldx, D, ld, g, xr);
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kb = 0; kb < n_blocks; ++kb) {
-            if (kb + 1 < n_blocks) stage(kb + 1, (kb + 1) & 1);
-            const double* buf = smem[kb & 1];
-            const int k0 = kb * KB;
-#pragma unroll 1
-            for (int kk = 0; kk < KB; ++kk) {
-                const int k = k0 + kk;
-                if (k >= K) break;
-                estep_component<NB, XT, JB, PJ * 256>(buf + kk * IMJ, xr, cvec[k], lane, g, stv, lnrho + (int64_t)k * npad);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-}
-
+// Once the responsibilities are sparse, almost every (sample, component) pair only has to be shown irrelevant
+// (r_nk < 2^-100: it changes neither lse_n nor, mstep.h, any statistic beyond the last bit).  The bounds that show it come
+// from the int8 matrix pipe (estep_i8.h: a bound pass over all pairs, the proof round over listed pairs) and are carried
+// from pass to pass (records.h); what cannot be shown irrelevant is evaluated exactly by the gather kernel below
+// (component fixed per workgroup, sample rows gathered through per-component lists).  The results of the exact pairs do not
+// depend on list order (one MFMA column per sample); the lists are filled without atomics, in a fixed order (aux_kernels.h).
 // Exact ln rho for listed (sample, component) pairs: a component's image is staged once and kept while a workgroup works
 // through that component's list, 8 waves x 16 NB x kGatherTiles entries per chunk.
 constexpr int kGatherTiles = 8;

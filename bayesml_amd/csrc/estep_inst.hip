@@ -49,33 +49,10 @@ hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hi
 }
 
 // ---- pruned E-step -------------------------------------------------------------------------------------------
+// feature tiles from which the pruned E-step is built (D >= 49): the gather kernel is instantiated for T = 4 .. 8
 int estep_bound_blocks(int T) { return T >= 6 ? 3 : (T >= 4 ? 2 : 0); }
-int estep_bound_rows_per_wg(int T, int x_is_f64) {
-    const int jb = estep_bound_blocks(T);
-    return jb ? 8 * 16 * (x_is_f64 ? bound_nb<double>(jb) : bound_nb<float>(jb)) : 0;
-}
 int estep_gather_rows_per_wg(int T, int x_is_f64) {
     return 8 * 16 * (x_is_f64 ? estep_nb_w<double>(T, 8) : estep_nb_w<float>(T, 8)) * kGatherTiles;
-}
-
-template <int T, int JB, typename XT, bool VEC>
-static hipError_t go_bound(int grid, hipStream_t st, const EstepArgs& a) {
-    hipLaunchKernelGGL((estep_bound_f64<T, JB, XT, VEC>), dim3(grid), dim3(512), 0, st, static_cast<const XT*>(a.x), a.ldx,
-                       a.n_rows, a.D, a.img, a.cvec, a.K, a.lnrho, a.npad);
-    return hipGetLastError();
-}
-#define BCASE(TT, JB)                                                                                              \
-    case TT:                                                                                                       \
-        *name = "estep_bound_f64<T=" #TT ",blocks=" #JB ">";                                                       \
-        if (x_is_f64) return vec ? go_bound<TT, JB, double, true>(grid, st, a) : go_bound<TT, JB, double, false>(grid, st, a); \
-        return vec ? go_bound<TT, JB, float, true>(grid, st, a) : go_bound<TT, JB, float, false>(grid, st, a);
-
-hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
-                              const char** name) {
-    switch (T) {
-        BCASE(4, 2) BCASE(5, 2) BCASE(6, 3) BCASE(7, 3) BCASE(8, 3)
-    }
-    return hipErrorInvalidValue;
 }
 
 template <int T, typename XT, bool VEC>

@@ -66,7 +66,7 @@ template <int KT>
 hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
                double* out, hipStream_t st) {
     const int K = h->K, Kp = h->Kp;
-    const int64_t L = chunk_len(T, ws->opt_one_level);
+    const int64_t L = chunk_len(T, false);
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
     hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
                        ((size_t)Kp * (kPrepSteps + 1) + kPrepSteps) * sizeof(double), st, ws->lnrho, ws->npad, T, K, Kp, h->rho_tm,

@@ -8,6 +8,8 @@
 #include "workspace.h"
 
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace gmmvb {
 
@@ -491,18 +493,44 @@ __global__ void drift_combine_kernel(int K, double* __restrict__ gamma, double* 
 
 using namespace gmmvb;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): remembered per device ordinal, under a
+// lock (a process may drive several GPUs, or create models from several threads)
+namespace {
+struct LdsAttr {
+    const void* fn;
+    int dev;
+    size_t bytes;
+};
+std::mutex g_lds_mu;
+std::vector<LdsAttr> g_lds_set;
+
+hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_lds_mu);
+    for (LdsAttr& a : g_lds_set) {
+        if (a.fn != fn || a.dev != dev) continue;
+        if (a.bytes >= bytes) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) a.bytes = bytes;
+        return e;
+    }
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) g_lds_set.push_back({fn, dev, bytes});
+    return e;
+}
+}  // namespace
+
 extern "C" int gmmvb_kside_factor(int K, int D, const double* w_inv_dev, double* g_dev, double* g_inv_dev,
                                   double* logdet_dev, void* stream) {
     if (K < 1 || D < 1) return fail(GMMVB_EINVAL, "K and D must be positive");
     if (D > 128) return fail(GMMVB_EUNSUPPORTED, "gmmvb_kside_factor: D > 128 (the factor is kept in LDS)");
     if (!w_inv_dev || !g_dev || !g_inv_dev || !logdet_dev) return fail(GMMVB_EINVAL, "null argument");
     const size_t lds = (size_t)D * (D + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           128 * 129 * (int)sizeof(double));
+    {
+        hipError_t e = ensure_dynamic_lds((const void*)chol_inv_kernel, (size_t)128 * 129 * sizeof(double));
         if (e != hipSuccess) return fail(GMMVB_EHIP, "hipFuncSetAttribute(chol_inv_kernel)", e);
-        attr_set = true;
     }
     hipLaunchKernelGGL(chol_inv_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, w_inv_dev, D, g_dev, g_inv_dev,
                        logdet_dev);
@@ -521,11 +549,9 @@ extern "C" int gmmvb_kside_drift(int K, int D, const double* u_old_dev, const do
         !big_gamma_dev || !enorm_dev)
         return fail(GMMVB_EINVAL, "null argument");
     const size_t lds = (size_t)128 * kDriftLd * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)drift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds((const void*)drift_kernel, lds);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "hipFuncSetAttribute(drift_kernel)", e);
-        attr_set = true;
     }
     hipLaunchKernelGGL(drift_kernel, dim3(K, 3), dim3(256), lds, (hipStream_t)stream, u_old_dev, uinv_old_dev, m_old_dev,
                        u_new_dev, uinv_new_dev, m_new_dev, D, squarings, squarings_big, gamma_dev, delta_dev, big_gamma_dev,
@@ -553,12 +579,9 @@ extern "C" int gmmvb_kside_step(int K, int D, const gmmvb_prior_view* prior, con
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = ((size_t)D * (D + 1) + 5 * (size_t)D + 64) * sizeof(double);
     const bool wide = D > 32;
-    static size_t lds_set[2] = {0, 0};
-    if (lds > lds_set[wide]) {
-        hipError_t e = hipFuncSetAttribute(wide ? (const void*)kside_step_kernel<1024> : (const void*)kside_step_kernel<256>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(wide ? (const void*)kside_step_kernel<1024> : (const void*)kside_step_kernel<256>, lds);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "hipFuncSetAttribute(kside_step_kernel)", e);
-        lds_set[wide] = lds;
     }
     double* partials = scratch_dev;                       // [K][kPartials]
     double* enorm = scratch_dev + (size_t)K * kPartials;  // [K]

@@ -21,12 +21,9 @@ enum EstepVariant { kEstepLds = 0, kEstepDirect = 1, kEstepLds8 = 2, kEstepI8 = 
 int estep_rows_per_wg(int variant, int T, int x_is_f64);
 int estep_threads(int variant);
 int estep_image_doubles(int T);
-// pruned E-step (estep.h): bound kernel over all pairs, exact kernel over per-component sample lists
-int estep_bound_blocks(int T);                    // JB, 0 = the pruned path is not built for this T
-int estep_bound_rows_per_wg(int T, int x_is_f64);
+// pruned E-step (estep.h): exact kernel over per-component sample lists; the bounds come from estep_i8.h
+int estep_bound_blocks(int T);                    // 0 = the pruned path is not built for this T (D < 49)
 int estep_gather_rows_per_wg(int T, int x_is_f64);
-hipError_t launch_estep_bound(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,
-                              const char** name);
 // exact f64 evaluation of listed pairs (device lists [K][cap], device counts), chunk plan on the device
 // (records.h: gather_plan_kernel), a fixed grid of persistent workgroups
 hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a,

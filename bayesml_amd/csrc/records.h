@@ -163,32 +163,26 @@ __device__ __forceinline__ void count_word(unsigned long long mk, int w, int wav
     }
 }
 
-// Carry the records over a parameter update and select this pass's candidates (header comment).
-// drift = [gamma K | delta K | c of the last E-step K | Gamma K]; IDENT: no update happened (the records were just built
-// from a bound pass): gamma = Gamma = 1, delta = 0, c_old = c_new, and exact slots are already evaluated (never listed again).
-// Outputs: masks (candidate components per row, all K for overflow rows), per-block counts for scan_counts /
-// fill_lists, epart[block] = listed pairs, opart[block] = overflow rows.
-template <bool IDENT>
+// After a bound pass: select the candidates from the records rec_build_kernel<true> has just made (no parameter update in
+// between: every slot's bound is what the bound pass computed, the one exact slot - the row's best component - gives the
+// threshold best - 100 ln 2).  Slots whose bound clears the threshold are done with; the others are listed, and so is
+// every component WITHOUT a slot if the rest bound B does not clear it ("refreshed row": B becomes the largest bound among
+// the components not listed; more than 24 such components, or no exact slot: all K pairs are evaluated, "overflow row").
+// Outputs: masks (candidate components per row), per-block counts for scan_counts / fill_lists, epart[block] = listed
+// pairs, opart[block] = overflow rows.
 __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int64_t n_rows, int K,
-                                                              const double* __restrict__ drift,
-                                                              const double* __restrict__ c_new,
+                                                              const double* __restrict__ cvec,
                                                               unsigned long long* __restrict__ masks, int64_t npad,
                                                               int* __restrict__ blk_cnt, double* __restrict__ epart,
                                                               double* __restrict__ opart,
                                                               float* __restrict__ rthr /*[npad] the row's relevance threshold*/) {
     __shared__ int wcnt[4][256];
-    __shared__ double sg[256], sdl[256], sG[256], sc[256], sco[256];
+    __shared__ double sc[256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
     for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
-    for (int k = tid; k < K; k += kSelRows) {
-        sg[k] = IDENT ? 1.0 : drift[k];
-        sdl[k] = IDENT ? 0.0 : drift[K + k];
-        sG[k] = IDENT ? 1.0 : drift[3 * K + k];
-        sc[k] = c_new[k];
-        sco[k] = IDENT ? c_new[k] : drift[2 * K + k];
-    }
+    for (int k = tid; k < K; k += kSelRows) sc[k] = cvec[k];
     __syncthreads();
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
     const bool valid = n < n_rows;
@@ -207,14 +201,11 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
             ub[j] = ninf;
             if (k == kRecEmpty) continue;
             const double d = (double)rec.d[(int64_t)j * rec.npad + n];
-            double y = sg[k] * d * (1.0 - 1e-12) - sdl[k];
-            y = y > 0.0 ? y : 0.0;                                   // also NaN -> 0: the trivial bound c'
-            const float yf = f32_down(y);
+            const float yf = f32_down(d * (1.0 - 1e-12));                // NaN -> the trivial bound c
             const double c = sc[k];
             ub[j] = c - 0.5 * (double)yf * (double)yf * (1.0 - 1e-12) + 1e-12 * fabs(c);
-            if (!IDENT) rec.d[(int64_t)j * rec.npad + n] = yf;
             if ((ex >> j) & 1u) {
-                const double du = sG[k] * d * (1.0 + 2.4e-7) * (1.0 + 1e-12) + sdl[k];
+                const double du = d * (1.0 + 2.4e-7) * (1.0 + 1e-12);
                 const double l = c - 0.5 * du * du * (1.0 + 1e-12) - 1e-12 * fabs(c);
                 lb = l > lb ? l : lb;                                // NaN never raises the threshold
             }
@@ -223,41 +214,29 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
         unsigned sel = 0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
-            if (kk[j] == kRecEmpty) continue;
-            if (IDENT && ((ex >> j) & 1u)) continue;                 // already exact under these parameters
+            if (kk[j] == kRecEmpty || ((ex >> j) & 1u)) continue;        // (exact slots are evaluated already)
             if (!(ub[j] < thr)) {
                 sel |= 1u << j;
                 mk[kk[j] >> 6] |= 1ull << (kk[j] & 63);
                 ++listed;
             }
         }
-        // every component without a slot: from ln rho_k <= B under the old parameters to a bound under the new ones;
-        // those whose bound is not good enough are listed too, the others define the new B
+        // every component without a slot is bounded by B: if B does not clear the threshold they are all listed
+        // (B = -inf afterwards: nothing is left without a slot or a listing)
         const double B = (double)rec.B[n];
         bool over = !(lb > ninf);                                    // no exact slot: nothing to compare with
         int extra = 0;
-        if (!over && (B > ninf || B != B)) {
+        if (!over && (B > ninf || B != B) && !(B < thr)) {
             unsigned long long inslot[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
             for (int j = 0; j < kRecSlots; ++j)
                 if (kk[j] != kRecEmpty) inslot[kk[j] >> 6] |= 1ull << (kk[j] & 63);
-            double keep = ninf;
             for (int k = 0; k < K; ++k) {
                 if ((inslot[k >> 6] >> (k & 63)) & 1ull) continue;
-                const double q = 2.0 * (sco[k] - B);
-                const double r = q > 0.0 ? sqrt(q) : 0.0;                    // also NaN -> 0
-                double y = sg[k] * r * (1.0 - 1e-12) - sdl[k];
-                y = y > 0.0 ? y : 0.0;
-                const double c = sc[k];
-                const double f = c - 0.5 * y * y * (1.0 - 1e-12) + 1e-12 * fabs(c);
-                if (f < thr) {
-                    keep = f > keep ? f : keep;
-                } else {                                                     // also NaN
-                    mk[k >> 6] |= 1ull << (k & 63);
-                    ++extra;
-                }
+                mk[k >> 6] |= 1ull << (k & 63);
+                ++extra;
             }
-            rec.B[n] = f32_up(keep);
+            rec.B[n] = -__builtin_huge_valf();
             over = extra > 24;
         }
         listed += extra;
@@ -270,7 +249,6 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
         rec.sel[n] = (unsigned char)sel;
         rec.flags[n] = (unsigned char)(over ? 1 : (extra > 0 ? 2 : 0));
         rthr[n] = (over || !(thr > ninf)) ? -__builtin_huge_valf() : f32_down(thr);
-        if (!IDENT) rec.exact[n] = 0;          // carried distances are one-sided until the pair is evaluated again
         for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
     }
     for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
@@ -696,6 +674,93 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
                 rec.exact[n] = 0;
                 rec.flags[n] = (unsigned char)(total > in_slots ? 2 : 0);
                 rthr[n] = -__builtin_huge_valf();
+            }
+        }
+        for (int w = 0; w < W; ++w) listed += __builtin_popcountll(mk[w]);
+    }
+    for (int w = 0; w < W; ++w) count_word(mk[w], w, wave, wcnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        listed += __shfl_xor(listed, o);
+        proved += __shfl_xor(proved, o);
+    }
+    if ((tid & 63) == 0) {
+        wsum[0][wave] = listed;
+        wsum[1][wave] = proved;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += kSelRows)
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    if (tid == 0) {
+        epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
+        ppart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
+    }
+}
+
+// Bound pass with a proof round: the candidates rec_select_kernel has listed carry bounds from the bound pass's leading
+// output blocks only; estep_i8_proof has given each of them a bound from ALL blocks (ub32).  Those that now clear the row's
+// threshold (its best component's exact value - 100 ln 2) are done with: taken off the pass's lists; a slot keeps the fresh
+// bound, a component without a slot rejoins the rest bound B.  Overflow rows are left alone.  Recounts the lists per block.
+__global__ __launch_bounds__(kSelRows) void rec_prune_kernel(RecArrays rec, unsigned long long* __restrict__ masks, int64_t npad,
+                                                             int64_t n_rows, int K, const double* __restrict__ cvec,
+                                                             const float* __restrict__ ub32, const float* __restrict__ rthr,
+                                                             int* __restrict__ blk_cnt, double* __restrict__ epart,
+                                                             double* __restrict__ ppart) {
+    __shared__ int wcnt[4][256];
+    __shared__ int wsum[2][4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int W = (K + 63) / 64;
+    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = 0;
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
+    const bool valid = n < n_rows;
+    unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+    int listed = 0, proved = 0;
+    if (valid) {
+        for (int w = 0; w < W; ++w) mk[w] = masks[(int64_t)w * npad + n];
+        const unsigned fl = rec.flags[n];
+        if (fl != 1u && (mk[0] | mk[1] | mk[2] | mk[3]) != 0ull) {
+            const double thr = (double)rthr[n];
+            unsigned long long inslot[4] = {0ull, 0ull, 0ull, 0ull};
+            unsigned sel = rec.sel[n];
+            float rest = rec.B[n];
+            bool changed = false;
+#pragma unroll
+            for (int j = 0; j < kRecSlots; ++j) {
+                const unsigned short k = rec.k[(int64_t)j * rec.npad + n];
+                if (k == kRecEmpty) continue;
+                inslot[k >> 6] |= 1ull << (k & 63);
+                if (!((sel >> j) & 1u)) continue;
+                const float u = ub32[(int64_t)k * npad + n];
+                if ((double)u < thr) {                                    // done with: the slot keeps the fresh bound
+                    sel &= ~(1u << j);
+                    mk[k >> 6] &= ~(1ull << (k & 63));
+                    rec.d[(int64_t)j * rec.npad + n] = dist_lower_f32(cvec[k], (double)u);
+                    changed = true;
+                }
+                ++proved;
+            }
+            int extra = 0;
+            for (int w = 0; w < W; ++w) {
+                unsigned long long m = mk[w] & ~inslot[w];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float u = ub32[(int64_t)(64 * w + b) * npad + n];
+                    ++proved;
+                    if ((double)u < thr) {                                // rejoins the components the rest bound speaks for
+                        mk[w] &= ~(1ull << b);
+                        rest = (u > rest) ? u : rest;
+                        changed = true;
+                    } else {
+                        ++extra;
+                    }
+                }
+            }
+            if (changed) {
+                for (int w = 0; w < W; ++w) masks[(int64_t)w * npad + n] = mk[w];
+                rec.sel[n] = (unsigned char)sel;
+                rec.B[n] = rest;
+                rec.flags[n] = (unsigned char)(extra > 0 ? 2 : 0);
             }
         }
         for (int w = 0; w < W; ++w) listed += __builtin_popcountll(mk[w]);

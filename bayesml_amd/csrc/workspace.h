@@ -20,7 +20,7 @@ struct gmmvb_workspace {
     int K = 0, D = 0, T = 0, x_dtype = 0;
     int64_t max_rows = 0, npad = 0;
     int num_cu = 0, KG = 0, S_cap = 0;
-    int64_t split_rows = 0;    // optional cap on rows per M-step split (0 = ~4 workgroups per CU)
+    int64_t split_rows = 0;    // cap on rows per M-step split
     double* lnrho = nullptr;   // [K][npad]
     double* lse = nullptr;     // [npad]
     double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
@@ -31,7 +31,6 @@ struct gmmvb_workspace {
     double* pivot_i8 = nullptr;        // [D] the pivot those images (and the sample digits) are centred on
     unsigned char* img_i8b = nullptr;  // [K][img_i8b_len] 3-digit images of the pruned E-step's bound pass
     int img_i8b_len = 0;
-    bool bound_i8 = true;              // env GMMVB_ESTEP_BOUND=f64: bound pass = leading blocks in f64 instead
     // output blocks the int8 bound pass evaluates (fewer blocks: cheaper pass, looser bound, more candidates for the
     // exact pass).  tb_cand[L] = candidates per pair the last pass at level L left, tb_seen[L] = pruned E-steps since
     // (levels not seen for 32 passes count as unknown); gmmvb_estep picks the level with the lowest modelled cost
@@ -143,25 +142,11 @@ struct gmmvb_workspace {
     bool lock_reset = false;           // the settled state belongs to something else now: drop it at the next E-step
     bool settled_fresh = false;        // read-outs: the settled rows' ln rho / lse were re-evaluated for the parameters in force
     double settle_margin = 0.0;        // nats of slack demanded before a row is settled (< 0: never settle)
-    double settle_gamma = 0.85;        // settling starts when the caller's drift summary (typical_gamma) reaches this ...
-    double settle_spare = 1.0;         // ... and the last sweep left at most this many spare candidates per row;
-    bool settle_on = false;            // it then stays on until the summary falls below settle_gamma - 0.05 or a pass
-                                       // other than a sweep comes (the regime where carried reference bounds hold)
     bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows
     bool gather_exit = true;           // env GMMVB_GATHER_EXIT=0: no early way out in the candidate gather
-    bool prefer_records = false;       // env GMMVB_ESTEP_RECORDS: carried passes on records, never sweeps (tests)
     // further switches, all read ONCE when the workspace is created (no getenv on the per-iteration path)
     bool opt_carry_off = false;        // GMMVB_ESTEP_CARRY_OFF: ignore gmmvb_set_drift
     bool opt_debug = false;            // GMMVB_DEBUG: one line per E-step on stderr
-    int opt_bound_blocks = 0;          // GMMVB_ESTEP_BOUND_BLOCKS: pinned level of the int8 bound pass (0: cost model)
-    double opt_spare_weight = 2.5;     // GMMVB_SPARE_WEIGHT: weight of spare candidates against a fresh bound pass
-    int opt_mstep_chunk = 1024;        // GMMVB_MSTEP_CHUNK: list entries per list M-step chunk
-    bool opt_list_xc = false;          // GMMVB_MSTEP_LIST_XC: the list M-step reads the centred copy, not the f32 rows
-    bool opt_small_off = false;        // GMMVB_MSTEP_SMALL_OFF: no mstep_small_f64 at one feature tile
-    int opt_small_cw = 8;              // GMMVB_MSTEP_SMALL_CW: its components per wave (4 | 8)
-    bool opt_one_level = false;        // HMMVB_ONE_LEVEL: one-level boundary pass whatever the sequence length
-    double opt_regroup_moved = 0.05;   // GMMVB_REGROUP_MOVED: share of rows that changed their best component before the rows are regrouped again
-    float exit_margin = 0.0f;          // env GMMVB_EXIT_MARGIN: nats a partial bound must lie below the row's threshold
     // Proof round (estep_i8.h, records.h): the three int8 digit planes of every row, in the internal row order, made with
     // the centred copy (gmmvb_prepare_rows) and again when the rows are regrouped.  Valid for the matrix xq_src while the
     // pivot they are centred on is the one the component images were packed for (xq_gen == img_gen).
@@ -171,6 +156,8 @@ struct gmmvb_workspace {
     int64_t xq_rows = 0, xq_ldx = 0;
     int pivot_gen = 0, xq_gen = -1, img_gen = -2;
     bool opt_proof = true;             // env GMMVB_PROOF=0: settled rows with candidates go straight to the f64 gather
+    int opt_tb_pin = 0;                // (experiment switch GMMVB_X_TB)
+    double opt_regroup_act = 2.5;      // (experiment switch GMMVB_X_REGROUP_ACT)
     bool opt_proof_all = false;        // env GMMVB_PROOF=all: the candidates of every other row go through the proof round too
     double* ppart = nullptr;           // [blocks] pairs of the proof round per selection block
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]

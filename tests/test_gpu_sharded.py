@@ -129,11 +129,11 @@ def test_two_sparse_ranks_match_the_reference(tmp_path, divergent):
     g = load_golden("gmm_f3_k64_d128_n140000_f32.npz")
     res = [dict(np.load(os.path.join(str(tmp_path), f"sparse_rank{r}.npz"))) for r in range(2)]
     c0, c1 = (json.loads(str(r["counts"])) for r in res)
-    assert c0["estep_bound"] >= 1 and c0["estep_sweep"] + c0["estep_carried"] >= 3 and c0["mstep_list"] >= 3, c0
+    assert c0["estep_bound"] >= 1 and c0["estep_sweep"] >= 3 and c0["mstep_list"] >= 3, c0
     if divergent:
-        assert c1["estep_sweep"] == c1["estep_carried"] == 0 and c1["estep_bound"] > c0["estep_bound"], (c0, c1)
+        assert c1["estep_sweep"] == 0 and c1["estep_bound"] > c0["estep_bound"], (c0, c1)
     else:           # one policy for both ranks: the same kind of E-step in every pass
-        for key in ("estep_dense", "estep_bound", "estep_carried", "estep_fell_back_dense", "estep_sweep"):
+        for key in ("estep_dense", "estep_bound", "estep_fell_back_dense", "estep_sweep"):
             assert c0[key] == c1[key], (key, c0, c1)
     for r in res:
         for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus"):

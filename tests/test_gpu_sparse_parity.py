@@ -21,9 +21,8 @@ from oracle import gmm_vb_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_GAMMA",
-            "GMMVB_SETTLE_MARGIN", "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT",
-            "GMMVB_SETTLE_SPARE", "GMMVB_ESTEP_RECORDS")
+ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_MARGIN",
+            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT")
 VARIANTS = {
     "default": {},
     # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, without
@@ -31,17 +30,13 @@ VARIANTS = {
     # the candidates of every other row before anything is evaluated in f64.  "settle": 5 nats of slack (fewer rows settle,
     # fewer come back); the read-outs below need the settled rows' values re-evaluated
     "settle": {"GMMVB_SETTLE_MARGIN": "5"},
-    "force_settle": {"GMMVB_ESTEP_PRUNE": "force"},
+    "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_MARGIN": "3"},
+    "force_noproof": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "0"},
     # every spare candidate through the proof round first (experiment switch)
     "force_proof_all": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "all"},
-    # ... without the proof round: rows settle on the strength of their carried bounds only (whatever the drift and the
-    # spare candidates of the last sweep, 10 nats of slack) and come loose into the exact gather
-    "settle_noproof": {"GMMVB_PROOF": "0", "GMMVB_SETTLE_GAMMA": "0", "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
-    "force_settle_noproof": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "0", "GMMVB_SETTLE_GAMMA": "0",
-                             "GMMVB_SETTLE_MARGIN": "10", "GMMVB_SETTLE_SPARE": "1000"},
+    # ... without the proof round rows never settle (a settled row that came loose would cost exact evaluations)
+    "noproof": {"GMMVB_PROOF": "0"},
     "nosettle": {"GMMVB_SETTLE_MARGIN": "-1"},
-    # the pass on 55-byte records (one rest bound per row) instead of the sweep of per-pair bounds
-    "force_records": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_RECORDS": "1"},
     "nocache": {"GMMVB_MSTEP_CACHE": "0"},
     "noexit": {"GMMVB_GATHER_EXIT": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
@@ -102,10 +97,10 @@ def expect_kernels(counts, variant, min_carried=1, lists=True):
         assert counts["mstep_list"] >= 1, counts
     if variant == "force_nocarry":
         assert counts["estep_carried"] == counts["estep_sweep"] == 0, counts
-    elif variant in ("settle", "force_settle", "settle_noproof", "force_settle_noproof", "force_proof_all"):
+    elif variant in ("settle", "force_settle", "force_proof_all"):
         assert counts["estep_sweep"] >= 2, counts
-    else:       # carried over the parameter update: on per-row records, or (early in a fit) by a sweep of the dense array
-        assert counts["estep_carried"] + counts["estep_sweep"] >= min_carried, counts
+    else:       # carried over the parameter update by a sweep of the per-pair bound array
+        assert counts["estep_sweep"] >= min_carried, counts
 
 
 @pytest.mark.parametrize("variant", ["force", "force_nocarry"])
@@ -126,7 +121,7 @@ def test_small_fixture_forced_sparse_matches_reference(variant):
 
 
 LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n140000_f32.npz", "force_nocarry"),
-         ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "settle_noproof"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "noproof"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "nosettle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
@@ -164,7 +159,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if "overlap" not in name and variant in ("default", "settle", "settle_noproof", "nosettle", "nocache", "noexit"):
+    if "overlap" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -175,12 +170,10 @@ def test_large_fixture_matches_reference(name, variant):
             assert 0 <= wk["accumulated"] <= wk["active"], wk
             if swept:
                 assert wk["accumulated"] < 0.7 * wk["active"], wk
-        if variant in ("settle", "settle_noproof") and swept:
+        if variant in ("default", "settle") and swept:
             assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
-        if variant == "nosettle":
+        if variant in ("nosettle", "noproof"):
             assert wk["settled_rows"] == 0 and wk["proof_pairs"] == 0, wk
-        if variant == "settle_noproof":
-            assert wk["proof_pairs"] == 0, wk
     if variant == "default" and "overlap" not in name:
         # the workspace regrouped its internal row order by dominant component on the way: every
         # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless
@@ -206,7 +199,7 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_noproof", "force_records", "force_proof_all"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_all"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
@@ -231,16 +224,14 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         q_new = _kside.update_q(prior, ns, x_bar, s)
         hint = m._drift_hint(eng, xd, q, q_new)
         assert hint is not None
-        before = eng.pass_counts()["estep_carried"] + eng.pass_counts()["estep_sweep"]
+        before = eng.pass_counts()["estep_sweep"]
         q = q_new
         ns, x_bar, s, _h = m._pass(eng, xd, q, s, hint=(*hint, float((hint[0] - hint[1] / 30.0).min())))
-        if eng.pass_counts()["estep_carried"] + eng.pass_counts()["estep_sweep"] == before:
+        if eng.pass_counts()["estep_sweep"] == before:
             continue
         wk = eng.work()
         settled_seen = max(settled_seen, wk["settled_rows"])
         proof_seen = max(proof_seen, wk["proof_pairs"])
-        if variant == "force_records":
-            assert eng.launch_info.startswith("estep_carried"), eng.launch_info
         if it >= 6 and wk["accumulated"] >= 0:
             cached_seen = max(cached_seen, wk["active"] - wk["accumulated"])
         lb = eng.ln_rho().cpu().numpy()
@@ -258,15 +249,14 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         checked += 1
     assert checked >= 3, eng.pass_counts()
     assert cached_seen > 0.1 * N, cached_seen       # single-component rows the M-step did not accumulate again
-    if variant in ("force_settle", "force_settle_noproof"):  # rows that were not evaluated at all: read out exactly all the same
-        assert settled_seen > 0.1 * N, settled_seen
-    if variant == "force_settle":                            # ... many of them on the strength of the int8 proof round
+    if variant in ("force", "force_settle"):     # rows that were not evaluated at all: read out exactly all the same -
+        assert settled_seen > 0.1 * N, settled_seen          # many of them on the strength of the int8 proof round
         assert proof_seen > 0.01 * N, proof_seen
-    if variant == "force_settle_noproof":
-        assert proof_seen == 0
+    if variant == "force_noproof":
+        assert proof_seen == 0 and settled_seen == 0
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_settle_noproof"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof"])
 def test_cache_survives_unusual_call_orders(variant):
     """The cache of single-component rows is internal state of the workspace: whatever order the entry points are
     called in - an M-step twice, an E-step twice without an M-step, read-outs between the two - the statistics and
