@@ -564,7 +564,7 @@ class TiledDataPass:
             self._tmp = torch.zeros(self.stats_len, dtype=torch.float64, device=self.device)
             self._tail_tmp = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
             self._tail_acc = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
-        except torch.OutOfMemoryError:
+        except RuntimeError:               # (out of memory next to a workspace that just fitted)
             self.inner.close()
             raise
         self._tail_in = None           # job-wide counters of the previous pass (summed over tiles, and over ranks by the caller)
@@ -771,7 +771,9 @@ def open_data_pass(K, D, x_dtype, n_rows, device, tile_rows=None):
             if "GMMVB_ENOMEM" not in str(e):
                 raise
             return None
-        except torch.OutOfMemoryError:
+        except RuntimeError as e:              # torch's own allocations next to a workspace that just fitted
+            if "out of memory" not in str(e).lower():
+                raise
             return None
         free, total = torch.cuda.mem_get_info(dev)
         if free < max(4 << 30, total // 16):          # no room left to work in

@@ -145,10 +145,6 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
         ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
         ws->opt_debug = std::getenv("GMMVB_DEBUG") != nullptr;
-        v = std::getenv("GMMVB_X_TB");                             // experiment: pins the bound pass's output blocks
-        ws->opt_tb_pin = v ? std::atoi(v) : 0;
-        v = std::getenv("GMMVB_X_REGROUP_ACT");                    // experiment: active pairs per row at which a regrouping is forced
-        if (v) ws->opt_regroup_act = std::atof(v);
     }
     {
         const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0;
@@ -899,10 +895,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // record, which only a pass that rebuilds everything (bound or dense) can digest.
     // The rows are regrouped by dominant component at a bound pass (which rebuilds everything row-indexed anyway).  With
     // the proof round bound passes have become rare: the first time the responsibilities are sparse enough for the grouping
-    // to pay (at most 4 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
+    // to pay (at most 2.5 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
     // kernels over ungrouped rows are 15-40 % slower for the rest of the fit.
     if (mode == kSweep && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
-        ws->e_state == 1 && known && L.act <= ws->opt_regroup_act * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
+        ws->e_state == 1 && known && L.act <= 2.5 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
         ws->xc_ldx == ldx)
         mode = kBound;
     auto regroup_due = [&]() {
@@ -947,9 +943,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // when more than half of its candidates are spare, if that level is unknown.
         const int t32 = (ws->D + 31) / 32;
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
-        if (ws->opt_tb_pin >= 1 && ws->opt_tb_pin <= t32) {
-            ws->bound_tb = ws->opt_tb_pin;
-        } else if (known && L.mode == kBound) {
+        if (known && L.mode == kBound) {
             const int cur = ws->bound_tb;
             ws->tb_cand[cur] = L.eval / pairs_l;
             ws->tb_act[cur] = L.act / pairs_l;

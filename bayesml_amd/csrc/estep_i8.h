@@ -676,9 +676,12 @@ __global__ __launch_bounds__(512) void estep_i8_proof(const unsigned char* __res
         // t + 1 are requested before tile t is computed (two register sets, the loop is unrolled by two)
         int nt = 0;
         while (nt < kI8PairTiles && chunk0 + ((int64_t)nt * NW + wave) * 32 < count) ++nt;
-        auto request = [&](int t, i4v (&xd)[ND][T32], int64_t& row, int& en) {
+        auto entry = [&](int t) -> int {                    // list entry of this lane's pair in tile t
             const int64_t e = chunk0 + ((int64_t)t * NW + wave) * 32 + c;
-            row = list[e < count ? e : count - 1];
+            return list[e < count ? e : count - 1];
+        };
+        auto request = [&](int idx, i4v (&xd)[ND][T32], int64_t& row, int& en) {
+            row = idx;
             const unsigned char* src = xq + row * RS + 16 * h;
 #pragma unroll
             for (int a = 0; a < ND; ++a)
@@ -706,16 +709,22 @@ __global__ __launch_bounds__(512) void estep_i8_proof(const unsigned char* __res
                 lb[(int64_t)k * npad + row] = (lo == lo) ? lo : -__builtin_huge_val();
             }
         };
+        // Two register sets: the digits of tile t + 1 are requested before tile t is computed, and the list entry of tile
+        // t + 2 before that - a tile's digit loads then wait for nothing but addresses that arrived a tile ago.
         i4v xa[ND][T32], xb[ND][T32];
         int64_t ra = 0, rb = 0;
         int ea = 0, eb = 0;
-        if (nt > 0) request(0, xa, ra, ea);
+        int i1 = nt > 1 ? entry(1) : 0;
+        if (nt > 0) request(entry(0), xa, ra, ea);
         for (int t = 0; t < nt; t += 2) {
-            if (t + 1 < nt) request(t + 1, xb, rb, eb);
+            const int i2 = t + 2 < nt ? entry(t + 2) : 0;
+            if (t + 1 < nt) request(i1, xb, rb, eb);
             evaluate(t, xa, ra, ea);
             if (t + 1 >= nt) break;
-            if (t + 2 < nt) request(t + 2, xa, ra, ea);
+            const int i3 = t + 3 < nt ? entry(t + 3) : 0;
+            if (t + 2 < nt) request(i2, xa, ra, ea);
             evaluate(t + 1, xb, rb, eb);
+            i1 = i3;
         }
     }
 }

@@ -653,9 +653,9 @@ __global__ void hmm_readout_kernel(const double* __restrict__ alpha_tm, const do
 }
 
 // ---- Viterbi (estimate_latent_vars(loss="0-1", viterbi=True), _hiddenmarkovnormal.py:1465-1481) ----------
-// First version: the max-plus recursion is run sequentially by ONE wave (lane = state), 8 time steps of
-// ln rho prefetched per lane; the back-pointers are chased through LDS-staged blocks.  A chunked max-plus
-// scan (the same structure as the sum-product kernels above) is the planned replacement.
+// Short sequences: the max-plus recursion is run sequentially by ONE wave (lane = state), 8 time steps of ln rho
+// prefetched per lane; the back-pointers are chased through LDS-staged blocks.  It reproduces the reference's sums bit
+// for bit.  Long sequences go through the chunked form further down (hmm_vit_*): at T = 1e7 the single wave needs ~10 s.
 template <int KT>
 __global__ __launch_bounds__(64) void hmm_viterbi_forward_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                                  const double* __restrict__ ln_pi_tilde,
@@ -733,6 +733,220 @@ __global__ __launch_bounds__(256) void hmm_viterbi_backtrack_kernel(const unsign
         }
         __syncthreads();
     }
+}
+
+
+// ---- chunked Viterbi -----------------------------------------------------------------------------------------------
+// omega_t = ln rho_t + max_i (omega_{t-1}(i) + ln a~_ij) is a max-plus matrix-vector recursion, and max-plus products
+// are associative, so the sequence is cut into chunks of L steps like the sum-product pass above:
+//   hmm_vit_chunk_kernel    per chunk and start state i: the best score of reaching every state j at the chunk's end from
+//                           state i at its start  ->  M_c (K x K), chunk- and start-state-parallel;
+//   hmm_vit_scan_kernel     one workgroup: omega at every chunk start, omega_{c+1} = omega_c (x) M_c (the M_c staged
+//                           through LDS a few chunks ahead of the wave that consumes them);
+//   hmm_vit_replay_kernel   per chunk: the reference's recursion from the now known start vector, writing the
+//                           back-pointers phi_t (first maximiser, like numpy.argmax) - chunk-parallel;
+//   hmm_vit_backmap / backscan / fill   the backtrack the same way: per chunk the map end state -> start state, a
+//                           sequential pass over the chunks' maps, then every chunk fills its own stretch of the path.
+// The start vectors come out of re-associated sums, so they differ from the sequential recursion's by rounding (1e-16
+// relative, ~1e-7 absolute at T = 1e7, where the scores reach -5e8): two paths whose scores agree to that level could be
+// told apart differently than by the reference's strictly sequential sums.  Scores of competing paths differ by O(1) on
+// anything but constructed ties; tests hold the chunked path to the sequential kernel's and to the reference fixtures'.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_vit_chunk_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                            const double* __restrict__ ln_a_tilde, int K, int64_t T, int64_t L,
+                                                            double* __restrict__ M /*[chunks][Kp][Kp]*/) {
+    constexpr int Kp = 16 * KT;
+    const int j = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i0 = (int)blockIdx.y * 4 + wave;              // this wave's start state
+    if (i0 >= K) return;
+    const int64_t c = blockIdx.x;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const double NEG = -1.0e300;
+    double col[Kp];
+#pragma unroll
+    for (int i = 0; i < Kp; ++i) col[i] = (i < K && j < K) ? ln_a_tilde[i * K + j] : NEG;
+    const double* lr = lnrho + (int64_t)(j < K ? j : 0) * npad;
+    double v = (j == i0) ? 0.0 : NEG;
+    for (int64_t tb = t0; tb < t1; tb += 8) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = (tb + u < t1) ? lr[tb + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (tb + u < t1) {
+                double best = NEG * 2.0;
+#pragma unroll
+                for (int i = 0; i < Kp; ++i) {
+                    const double s = __shfl(v, i) + col[i];
+                    best = s > best ? s : best;
+                }
+                v = j < K ? e[u] + best : NEG;
+            }
+        }
+    }
+    if (j < Kp) M[((int64_t)c * Kp + i0) * Kp + j] = v;
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_vit_scan_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                           const double* __restrict__ ln_pi_tilde,
+                                                           const double* __restrict__ M, int K, int64_t chunks,
+                                                           double* __restrict__ wstart /*[chunks][Kp]*/) {
+    constexpr int Kp = 16 * KT;
+    constexpr int B = 8192 / (Kp * Kp) < 1 ? 1 : 8192 / (Kp * Kp);        // chunks per 64-KB LDS buffer
+    constexpr int PER = (B * Kp * Kp + 255) / 256;                        // doubles per thread and group
+    __shared__ double buf[2][B * Kp * Kp];
+    const int tid = threadIdx.x, j = tid & 63;
+    const bool lead = tid < 64;
+    const double NEG = -1.0e300;
+    double w = (lead && j < K) ? lnrho[(int64_t)j * npad] + ln_pi_tilde[j] : NEG;
+    const int64_t groups = (chunks + B - 1) / B;
+    double stage[PER];
+    auto request = [&](int64_t g) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t e = (int64_t)q * 256 + tid;
+            const int64_t src = g * B * Kp * Kp + e;
+            stage[q] = (e < (int64_t)B * Kp * Kp && src < chunks * Kp * Kp) ? M[src] : 0.0;
+        }
+    };
+    auto deposit = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = q * 256 + tid;
+            if (e < B * Kp * Kp) buf[b][e] = stage[q];
+        }
+    };
+    if (groups > 0) {
+        request(0);
+        deposit(0);
+    }
+    __syncthreads();
+    for (int64_t g = 0; g < groups; ++g) {
+        if (g + 1 < groups) request(g + 1);                 // in flight while the leading wave works through group g
+        if (lead) {
+            const double* mb = buf[g & 1];
+            for (int b = 0; b < B; ++b) {
+                const int64_t c = g * B + b;
+                if (c >= chunks) break;
+                if (j < Kp) wstart[c * Kp + j] = w;
+                double best = NEG * 2.0;
+                for (int i = 0; i < K; ++i) {
+                    const double s = __shfl(w, i) + mb[(b * Kp + i) * Kp + (j < Kp ? j : 0)];
+                    best = s > best ? s : best;
+                }
+                w = j < K ? best : NEG;
+            }
+        }
+        if (g + 1 < groups) deposit((int)((g + 1) & 1));
+        __syncthreads();
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(64) void hmm_vit_replay_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                            const double* __restrict__ ln_a_tilde,
+                                                            const double* __restrict__ wstart, int K, int64_t T, int64_t L,
+                                                            int64_t chunks, unsigned char* __restrict__ phi /*[T][Kp]*/,
+                                                            int* __restrict__ last_state) {
+    constexpr int Kp = 16 * KT;
+    const int j = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const double NEG = -1.0e300;
+    double col[Kp];
+#pragma unroll
+    for (int i = 0; i < Kp; ++i) col[i] = (i < K && j < K) ? ln_a_tilde[i * K + j] : NEG;
+    const double* lr = lnrho + (int64_t)(j < K ? j : 0) * npad;
+    double omega = (j < K) ? wstart[c * Kp + j] : NEG;
+    for (int64_t tb = t0; tb < t1; tb += 8) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = (tb + u < t1) ? lr[tb + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (tb + u < t1) {
+                double best = NEG * 2.0;
+                int arg = 0;
+#pragma unroll
+                for (int i = 0; i < Kp; ++i) {
+                    const double v = __shfl(omega, i) + col[i];
+                    if (v > best) {          // strict: first maximiser, like numpy.argmax
+                        best = v;
+                        arg = i;
+                    }
+                }
+                omega = j < K ? e[u] + best : NEG;
+                if (j < Kp) phi[(tb + u) * Kp + j] = (unsigned char)arg;
+            }
+        }
+    }
+    if (c == chunks - 1) {               // first maximiser of omega_{T-1}
+        double best = omega;
+        int arg = j;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o);
+            const int oa = __shfl_xor(arg, o);
+            if (ob > best || (ob == best && oa < arg)) {
+                best = ob;
+                arg = oa;
+            }
+        }
+        if (j == 0) *last_state = arg;
+    }
+}
+
+// map[c][j] = state at the chunk's start time (t0 - 1) of the survivor path that is in state j at its last time (t1 - 1)
+__global__ __launch_bounds__(64) void hmm_vit_backmap_kernel(const unsigned char* __restrict__ phi, int Kp, int64_t T, int64_t L,
+                                                             unsigned char* __restrict__ map /*[chunks][Kp]*/) {
+    const int j = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    if (j >= Kp) return;
+    int s = j;
+    for (int64_t t = t1 - 1; t >= t0; --t) s = phi[t * Kp + s];
+    map[c * Kp + j] = (unsigned char)s;
+}
+
+// endst[c] = state of the best path at the last time of chunk c; sequential over the chunks' maps (LDS-staged blocks)
+__global__ __launch_bounds__(256) void hmm_vit_backscan_kernel(const unsigned char* __restrict__ map, int Kp, int64_t chunks,
+                                                               const int* __restrict__ last_state, int* __restrict__ endst) {
+    constexpr int BLK = 512;
+    __shared__ unsigned char tile[BLK * 64];
+    __shared__ int cur;
+    if (threadIdx.x == 0) cur = *last_state;
+    __syncthreads();
+    for (int64_t hi = chunks - 1; hi >= 0; hi -= BLK) {
+        const int64_t lo = hi - BLK + 1 > 0 ? hi - BLK + 1 : 0;
+        const int64_t n = (hi - lo + 1) * Kp;
+        for (int64_t e = threadIdx.x; e < n; e += blockDim.x) tile[e] = map[lo * Kp + e];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k = cur;
+            for (int64_t c = hi; c >= lo; --c) {
+                endst[c] = k;
+                k = tile[(c - lo) * Kp + k];
+            }
+            cur = k;
+        }
+        __syncthreads();
+    }
+}
+
+// every chunk writes its own stretch of the path, z[t0 - 1 .. t1 - 1] except z[t0 - 1] for c > 0 (the previous chunk's)
+__global__ __launch_bounds__(64) void hmm_vit_fill_kernel(const unsigned char* __restrict__ phi, int Kp, int64_t T, int64_t L,
+                                                          int64_t chunks, const int* __restrict__ endst, int32_t* __restrict__ z) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= chunks) return;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    int s = endst[c];
+    for (int64_t t = t1 - 1; t >= t0; --t) {
+        z[t] = s;
+        s = phi[t * Kp + s];
+    }
+    if (c == 0) z[0] = s;
 }
 
 }  // namespace gmmvb

@@ -166,6 +166,39 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     gmmvb_hmm_state* h = ws->hmm;
     hipStream_t st = (hipStream_t)stream;
+    // Long sequences: chunked max-plus scan (hmm.h, hmm_vit_*); its scratch is the forward-backward pass's (chunk products,
+    // boundary vectors), which nothing reads once that pass has returned.  Short ones: the single sequential wave.
+    const int64_t L = n_rows >= 65536 ? 256 : (n_rows >= 512 ? 32 : 0);
+    if (L > 0) {
+        const int64_t chunks = (n_rows - 1 + L - 1) / L;
+        double* M = h->prod;                                             // [chunks][Kp][Kp]   (chunks <= max_chunks)
+        double* wstart = h->fstart;                                      // [chunks][Kp]
+        unsigned char* map = reinterpret_cast<unsigned char*>(h->bend);  // [chunks][Kp] bytes
+        int* endst = reinterpret_cast<int*>(h->fstart_s);                // [chunks] ints
+        if (chunks > h->max_chunks || chunks * (int64_t)sizeof(int) > (h->max_chunks / kHmmSuper + 2) * h->Kp * (int64_t)sizeof(double))
+            return fail(GMMVB_ESTATE, "Viterbi scratch too small for this sequence");
+#define VITC(KTT)                                                                                                           \
+    hipLaunchKernelGGL((hmm_vit_chunk_kernel<KTT>), dim3((unsigned)chunks, (unsigned)((h->K + 3) / 4)), dim3(256), 0, st,   \
+                       ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M);                                             \
+    hipLaunchKernelGGL((hmm_vit_scan_kernel<KTT>), dim3(1), dim3(256), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, M, h->K, \
+                       chunks, wstart);                                                                                      \
+    hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,           \
+                       ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state)
+        switch (h->KT) {
+            case 1: VITC(1); break;
+            case 2: VITC(2); break;
+            case 3: VITC(3); break;
+            default: VITC(4); break;
+        }
+#undef VITC
+        hipLaunchKernelGGL(hmm_vit_backmap_kernel, dim3((unsigned)chunks), dim3(64), 0, st, h->phi, h->Kp, n_rows, L, map);
+        hipLaunchKernelGGL(hmm_vit_backscan_kernel, dim3(1), dim3(256), 0, st, map, h->Kp, chunks, h->last_state, endst);
+        hipLaunchKernelGGL(hmm_vit_fill_kernel, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, st, h->phi, h->Kp, n_rows, L,
+                           chunks, endst, z_dev);
+        hipError_t ec = hipGetLastError();
+        if (ec != hipSuccess) return fail(GMMVB_EHIP, "chunked viterbi launch", ec);
+        return GMMVB_OK;
+    }
 #define VIT(KTT)                                                                                                     \
     hipLaunchKernelGGL((hmm_viterbi_forward_kernel<KTT>), dim3(1), dim3(64), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, \
                        ln_a_tilde_dev, h->K, n_rows, h->phi, h->last_state)

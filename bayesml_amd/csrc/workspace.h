@@ -156,8 +156,6 @@ struct gmmvb_workspace {
     int64_t xq_rows = 0, xq_ldx = 0;
     int pivot_gen = 0, xq_gen = -1, img_gen = -2;
     bool opt_proof = true;             // env GMMVB_PROOF=0: settled rows with candidates go straight to the f64 gather
-    int opt_tb_pin = 0;                // (experiment switch GMMVB_X_TB)
-    double opt_regroup_act = 2.5;      // (experiment switch GMMVB_X_REGROUP_ACT)
     bool opt_proof_all = false;        // env GMMVB_PROOF=all: the candidates of every other row go through the proof round too
     double* ppart = nullptr;           // [blocks] pairs of the proof round per selection block
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]

@@ -181,7 +181,8 @@ def test_full_driver_matches_reference(name):
             assert np.max(np.abs(m.estimate_latent_vars(xs, "squared", viterbi=False) - g["marginal_sq"])) < 1e-7
 
 
-@pytest.mark.parametrize("K,D,T", [(5, 3, 1), (12, 4, 700), (40, 2, 3000)])
+# T < 512: the single sequential wave; 512 <= T < 65536: the chunked max-plus scan with chunks of 32 steps; beyond: 256
+@pytest.mark.parametrize("K,D,T", [(5, 3, 1), (12, 4, 511), (12, 4, 700), (40, 2, 3000), (64, 2, 1537), (32, 16, 200001)])
 def test_viterbi_kernel_against_oracle(K, D, T):
     from bayesml_amd import hiddenmarkovnormal as hmm
     x, _ = orc.synth_hmm(max(2, K // 2), D, T, np.float64, seed=7 * K + T)

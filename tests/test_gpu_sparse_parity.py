@@ -172,8 +172,8 @@ def test_large_fixture_matches_reference(name, variant):
                 assert wk["accumulated"] < 0.7 * wk["active"], wk
         if variant in ("default", "settle") and swept:
             assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
-        if variant in ("nosettle", "noproof"):
-            assert wk["settled_rows"] == 0 and wk["proof_pairs"] == 0, wk
+        if variant in ("nosettle", "noproof"):      # (without settled rows the proof round still serves the bound passes)
+            assert wk["settled_rows"] == 0 and (wk["proof_pairs"] == 0 or variant == "nosettle"), wk
     if variant == "default" and "overlap" not in name:
         # the workspace regrouped its internal row order by dominant component on the way: every
         # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless

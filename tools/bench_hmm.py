@@ -125,6 +125,15 @@ def main():
     # balance): algorithmic bytes per time step = the row of x read once (D * 4) + one [K] f64 state vector written by the
     # forward recursion and read back by the backward one (the reference materialises ln_rho, alpha, beta, gamma [T, K]
     # and xi [T, K, K]); the kernels of DESIGN.md section 5b sweep about twelve [T][16 ceil(K/16)] f64 arrays per iteration.
+    # Viterbi path of the whole sequence under the last posterior (chunked max-plus scan, hmm.h hmm_vit_*)
+    qf = q if getattr(q, "ln_pi_tilde", None) is not None else _kside.hmm_features(q)
+    eng.set_params(qf.c, qf.m, qf.u)
+    eng.estep(xd)
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    z = eng.viterbi(qf.ln_pi_tilde, qf.ln_a_tilde)
+    torch.cuda.synchronize()
+    viterbi_ms = (time.perf_counter() - tv) * 1e3
     Kp = 16 * ((K + 15) // 16)
     alg = D * 4 + 2 * K * 8
     swept = 12 * Kp * 8 + D * 4 + 16 * ((D + 15) // 16) * 8
@@ -139,7 +148,9 @@ def main():
         "unit": "time steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"HMM-VB K={K} D={D} T={T}, x stored f32, one VB iteration per step"},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "final_vl": vl}))
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "final_vl": vl,
+        "viterbi": {"ms": viterbi_ms, "time_steps_per_s": T / (viterbi_ms * 1e-3), "states_visited": int(torch.unique(z).numel()),
+                    "note": "hmmvb_viterbi over all T steps after the emission E-step (round 2: one sequential wave, ~10 s)"}}))
 
 
 if __name__ == "__main__":
