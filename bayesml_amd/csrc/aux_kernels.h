@@ -535,6 +535,21 @@ __global__ void perm_invert_kernel(const int* __restrict__ perm, int64_t n_rows,
     if (i < n_rows) iperm[perm[i]] = (int)i;
 }
 
+// The per-row state of the cache of single-component rows follows the rows into their new order: new internal row i holds
+// the caller's row perm_new[i], which sat at internal row iperm_old[perm_new[i]] before (iperm_old null: the caller's order).
+__global__ void regroup_state_kernel(const int* __restrict__ perm_new, const int* __restrict__ iperm_old, int64_t n_rows,
+                                     const unsigned char* __restrict__ lock, const unsigned char* __restrict__ lcomp,
+                                     const float* __restrict__ dlock, unsigned char* __restrict__ lock_new,
+                                     unsigned char* __restrict__ lcomp_new, float* __restrict__ dlock_new) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const int c = perm_new[i];
+    const int src = iperm_old ? iperm_old[c] : c;
+    lock_new[i] = lock[src];
+    lcomp_new[i] = lcomp[src];
+    dlock_new[i] = dlock[src];
+}
+
 // xp[i][:] = x[perm[i]][:] (packed, ld = D)
 template <typename XT>
 __global__ void permute_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,

@@ -737,7 +737,8 @@ static hipError_t recenter_rows(gmmvb_workspace* ws, int64_t n_rows, hipStream_t
 // Regroup the internal row order by the best component of the last E-step (aux_kernels.h): new permutation, permuted copy
 // of x, centred copy rebuilt from it.  Everything row-indexed in the workspace is stale afterwards: the caller (a bound
 // pass) rebuilds it.
-static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, hipStream_t st) {
+static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, hipStream_t st,
+                               bool keep_state) {
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
     hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K, ws->khat,
                        ws->masks, ws->blk);
@@ -747,6 +748,17 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     hipLaunchKernelGGL(perm_compose_kernel, dim3((unsigned)((n_rows + 255) / 256), ws->K), dim3(256), 0, st, ws->lists, ws->npad,
                        ws->counts, ws->sorted ? ws->perm : nullptr, ws->perm_tmp);
     std::swap(ws->perm, ws->perm_tmp);
+    if (keep_state) {
+        // the cache of single-component rows is a sum over rows - it does not care about their order; what is kept per row
+        // (in the cache or not, for which component, the settled rows' distance bound) moves with the rows.  The records'
+        // byte arrays and the threshold array are free at this point of a bound pass (rec_build_kernel rewrites them).
+        hipLaunchKernelGGL(regroup_state_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->perm,
+                           ws->sorted ? ws->iperm : nullptr, n_rows, ws->lock, ws->lcomp, ws->dlock, ws->rec_sel, ws->rec_flags,
+                           ws->rthr);
+        std::swap(ws->lock, ws->rec_sel);
+        std::swap(ws->lcomp, ws->rec_flags);
+        std::swap(ws->dlock, ws->rthr);
+    }
     hipLaunchKernelGGL(perm_invert_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->perm, n_rows, ws->iperm);
     const int64_t total = n_rows * ws->D;
     const unsigned pg = (unsigned)((total + 255) / 256);
@@ -866,7 +878,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
                 // (a pair of the proof round costs about a third of an exact evaluation)
-                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + 0.33 * L.proof) / pairs_l;
+                // (a bound pass's own proof stage works through the candidates its coarse bounds leave - not a sign of erosion)
+                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + (L.mode == kSweep ? 0.33 * L.proof : 0.0)) / pairs_l;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
                 const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
@@ -908,7 +921,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     };
     bool settle = false;
     if (ws->lock) {
-        const bool keep = mode != kDense && same_rows && !ws->lock_reset && !ws->delta_pending && !regroup_due();
+        // (a regrouping of the rows takes the per-row state along: regroup_rows)
+        const bool keep = mode != kDense && same_rows && !ws->lock_reset && !ws->delta_pending;
         if (ws->lock_reset || (ws->lock_live && !keep)) {
             if (mode == kSweep) mode = kBound;
             (void)hipMemsetAsync(ws->lock, 0, (size_t)ws->npad, st);
@@ -985,7 +999,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     bool sorted_now = false;
     if (regroup_due()) {
         span_begin(ws, kSpanSelect, st);
-        e = regroup_rows(ws, x_dev, ldx, n_rows, st);
+        e = regroup_rows(ws, x_dev, ldx, n_rows, st, ws->lock_live);
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "regrouping the rows", e);
         ws->moved_since_sort = 0.0;

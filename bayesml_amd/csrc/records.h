@@ -806,7 +806,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                                                               double* __restrict__ mpart /*rows whose best component changed*/,
                                                               float* __restrict__ ub32 /*[K][npad] per-pair bounds (sweeps)*/,
                                                               unsigned char* __restrict__ lock /*null: no cache of single-component rows*/,
-                                                              float* __restrict__ dlock, double settle_margin /*< 0: rows never settle*/,
+                                                              float* __restrict__ dlock, double settle_margin /*< 0: rows never settle; >= 1e300: every single-component row does*/,
                                                               unsigned long long* __restrict__ dmask, int* __restrict__ dblk,
                                                               unsigned long long* __restrict__ mmask, int* __restrict__ mblk,
                                                               double* __restrict__ spart, double* __restrict__ gpart,
@@ -1048,8 +1048,11 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     // in every pass in which that holds - it is kept in the cache and the row left out of the M-step's lists (mmask).
     //   lock 0 -> 3  the row enters the cache of its component;  1 -> 1  it stays;  1 -> 2  it leaves;  1 -> 4  it moves
     //   to another component (fill_lists_kernel gives the delta lists' entries their signs and settles the state).
-    // Settling goes one step further: if every other component is at least settle_margin nats below the 2^-100 line the
-    // row is also left out of the E-step's lists (masks); the next sweep then only checks its carried bounds.
+    // Settling goes one step further: the row is also left out of the E-step's lists (masks); the next sweep only checks
+    // its carried bounds, and what they no longer prove goes through the int8 proof round instead of an exact evaluation.
+    // By default every single-component row settles (whatever its carried bounds say, the proof round is cheaper than the
+    // exact evaluation of the row's component plus its candidates); with a margin only rows whose other components all
+    // lie at least that many nats below the 2^-100 line.
     unsigned long long mm[4] = {mk[0], mk[1], mk[2], mk[3]};         // the M-step's lists
     int in_lists = 0, m_pairs = 0;
     if (valid && lock != nullptr && fl != 4u) {
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         if (single) {
             lcomp[n] = (unsigned char)row_arg;
             mm[row_arg >> 6] &= ~(1ull << (row_arg & 63));
-            if (settle_margin >= 0.0 && row_second < row_l - k100Ln2 - settle_margin) {
+            if (settle_margin >= 1e300 || (settle_margin >= 0.0 && row_second < row_l - k100Ln2 - settle_margin)) {
                 dlock[n] = f32_up(dist_of(cvec[row_arg], row_best) * (1.0 + 1e-9));
                 mk[row_arg >> 6] &= ~(1ull << (row_arg & 63));
             }

@@ -141,7 +141,7 @@ struct gmmvb_workspace {
     bool skip_used = false;            // some pass since the cache was last emptied was allowed to settle rows
     bool lock_reset = false;           // the settled state belongs to something else now: drop it at the next E-step
     bool settled_fresh = false;        // read-outs: the settled rows' ln rho / lse were re-evaluated for the parameters in force
-    double settle_margin = 0.0;        // nats of slack demanded before a row is settled (< 0: never settle)
+    double settle_margin = 1e300;      // nats of slack demanded before a row is settled (< 0: never; 1e300: every single-component row)
     bool cache_on = true;              // env GMMVB_MSTEP_CACHE=0: no cache of single-component rows
     bool gather_exit = true;           // env GMMVB_GATHER_EXIT=0: no early way out in the candidate gather
     // further switches, all read ONCE when the workspace is created (no getenv on the per-iteration path)
