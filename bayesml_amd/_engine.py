@@ -83,16 +83,14 @@ class EngineLimitError(ValueError):
     """The model's shape is outside what this version of the engine supports (the reference has no such limit)."""
 
 
-MAX_DEGREE = 128          # include/gmmvb.h: 1 <= D <= 128 (8 feature tiles of 16)
+MAX_MFMA_DEGREE = 128     # up to here the data pass runs on the MFMA kernels; beyond, on the plain f64 kernels of csrc/generic.h
 MAX_HMM_CLASSES = 64      # hmmvb_enable: K <= 64
 
 
 def check_limits(c_degree: int, c_num_classes: int = 1, hmm: bool = False):
     """Raised at model construction, so that an unsupported shape does not surface as an EngineError from inside
-    update_posterior after the sample matrix has already been copied to the GPU."""
-    if c_degree > MAX_DEGREE:
-        raise EngineLimitError(f"bayesml_amd supports c_degree <= {MAX_DEGREE} in this version (got {c_degree}); "
-                               "bayesml itself has no such limit")
+    update_posterior after the sample matrix has already been copied to the GPU.  (c_degree has no limit: above 128 the
+    engine switches to its generic f64 kernels - same results, far slower.)"""
     if hmm and c_num_classes > MAX_HMM_CLASSES:
         raise EngineLimitError(f"bayesml_amd.hiddenmarkovnormal supports c_num_classes <= {MAX_HMM_CLASSES} in this "
                                f"version (got {c_num_classes}); bayesml itself has no such limit")

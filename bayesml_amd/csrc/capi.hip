@@ -10,6 +10,7 @@
 #include <string>
 
 #include "aux_kernels.h"
+#include "generic.h"
 #include "launch.h"
 #include "records.h"
 
@@ -63,7 +64,6 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     *out = nullptr;
     if (K < 1 || D < 1 || max_rows < 1) return fail(GMMVB_EINVAL, "K, D and max_rows must be positive");
     if (x_dtype != GMMVB_F32 && x_dtype != GMMVB_F64) return fail(GMMVB_EINVAL, "x_dtype must be GMMVB_F32 or GMMVB_F64");
-    if (D > 16 * kMaxTiles) return fail(GMMVB_EUNSUPPORTED, "D > 128 is not supported by this version");
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipGetDevice", e);
@@ -80,6 +80,44 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     ws->max_rows = max_rows;
     ws->npad = round_up(max_rows, 64);
     ws->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (D > 16 * kMaxTiles) {
+        // more than 8 feature tiles: the plain f64 kernels of generic.h (no parameter images, no pruning, no lists)
+        ws->generic = true;
+        ws->sparse = false;
+        ws->prune = 0;
+        ws->sort_rows = false;
+        ws->cache_on = false;
+        ws->gen_S = (int)std::min<int64_t>(64, std::max<int64_t>(1, max_rows / 16384));
+        const int64_t tiles = tri_pairs(ws->T);
+        struct { double** p; int64_t n; } gb[] = {
+            {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad}, {&ws->cvec, K}, {&ws->pivot, D},
+            {&ws->gen_u, (int64_t)K * D * D}, {&ws->gen_m, (int64_t)K * D}, {&ws->gen_first, (int64_t)ws->gen_S * K * (D + 2)},
+            {&ws->gen_second, (int64_t)ws->gen_S * K * tiles * 256}, {&ws->ctr, 8}};
+        for (auto& b : gb) {
+            e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
+            if (e != hipSuccess) {
+                gmmvb_workspace_destroy(ws);
+                return fail(GMMVB_ENOMEM, "hipMalloc (workspace)", e);
+            }
+            ws->bytes += b.n * (int64_t)sizeof(double);
+        }
+        e = hipMemset(ws->pivot, 0, (size_t)D * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 8 * sizeof(double));
+        if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 8 * sizeof(double), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ctr_ev, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            const size_t lds = (size_t)D * generic_rows(D) * sizeof(double);
+            e = hipFuncSetAttribute((const void*)estep_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)estep_generic_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        if (e != hipSuccess) {
+            gmmvb_workspace_destroy(ws);
+            return fail(GMMVB_EHIP, "workspace initialisation", e);
+        }
+        *out = ws;
+        return GMMVB_OK;
+    }
     {
         const int kpw = mstep_components_per_wg(ws->T, false);     // the smaller of the two forms: sizes the slabs
         ws->KG = (K + kpw - 1) / kpw;
@@ -196,7 +234,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
-                      ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart};
+                      ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart, ws->gen_u, ws->gen_m, ws->gen_first,
+                      ws->gen_second};
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
@@ -419,6 +458,15 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemcpyAsync(ws->cvec, c_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(c)", e);
+    if (ws->generic) {
+        e = hipMemcpyAsync(ws->gen_m, m_dev, (size_t)ws->K * ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ws->gen_u, u_dev, (size_t)ws->K * ws->D * ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(m, u)", e);
+        ws->have_params = true;
+        ws->params_used = false;
+        return GMMVB_OK;
+    }
     hipLaunchKernelGGL(pack_params_kernel, dim3(ws->K), dim3(256), 0, st, u_dev, m_dev, ws->K, ws->D, ws->T,
                        ws->img_len, ws->img);
     e = hipGetLastError();
@@ -823,6 +871,45 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (!ws->have_params) return fail(GMMVB_ESTATE, "gmmvb_set_params has not been called");
     hipStream_t st = (hipStream_t)stream;
     const int is64 = ws->x_dtype == GMMVB_F64;
+    if (ws->generic) {
+        const int R = generic_rows(ws->D);
+        const dim3 grid((unsigned)((n_rows + R - 1) / R), (unsigned)ws->K);
+        const size_t lds = (size_t)ws->D * R * sizeof(double);
+        if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
+        ws->n_spans = 0;
+        span_begin(ws, kSpanEstepMain, st);
+        if (is64)
+            hipLaunchKernelGGL(estep_generic_kernel<double>, grid, dim3(64), lds, st, (const double*)x_dev, ldx, n_rows, ws->D,
+                               ws->gen_u, ws->gen_m, ws->cvec, R, ws->lnrho, ws->npad);
+        else
+            hipLaunchKernelGGL(estep_generic_kernel<float>, grid, dim3(64), lds, st, (const float*)x_dev, ldx, n_rows, ws->D,
+                               ws->gen_u, ws->gen_m, ws->cvec, R, ws->lnrho, ws->npad);
+        span_end(ws, st);
+        if (ws->prof) {
+            (void)hipEventRecord(ws->ev[1], st);
+            ws->ev_e = true;
+        }
+        span_begin(ws, kSpanLse, st);
+        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)((n_rows + kLseRows - 1) / kLseRows)), dim3(256), 0, st, ws->lnrho,
+                           ws->npad, n_rows, ws->K, ws->lse, nullptr, nullptr, 1);
+        span_end(ws, st);
+        hipError_t eg = hipGetLastError();
+        if (eg != hipSuccess) return fail(GMMVB_EHIP, "estep_generic launch", eg);
+        ++ws->passes[0];
+        ws->ctr_pending = false;
+        ws->lag.valid = false;
+        ws->act_rows = 0;
+        ws->exp_counted = false;
+        ws->rec_live = ws->rec_valid = false;
+        ws->e_state = 1;
+        ws->e_rows = n_rows;
+        ws->params_used = true;
+        ws->have_drift = false;
+        ws->prev_pass = 0;
+        ws->evaluated = (double)n_rows * ws->K;
+        std::snprintf(ws->info, sizeof(ws->info), "estep_generic_f64<D=%d> grid=%ux%ux64 rows/workgroup=%d", ws->D, grid.x, grid.y, R);
+        return GMMVB_OK;
+    }
     const bool i8 = ws->estep_variant == kEstepI8;
     EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
     EstepI8Args a8{x_dev, ldx, n_rows, ws->D, ws->img_i8, ws->pivot_i8, ws->cvec, ws->K, ws->lnrho, ws->npad};
@@ -1277,6 +1364,44 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (ws->e_state == 0 || ws->e_rows != n_rows)
         return fail(GMMVB_ESTATE, "no responsibilities for these rows: call gmmvb_estep or gmmvb_load_responsibilities first");
     hipStream_t st = (hipStream_t)stream;
+    if (ws->generic) {
+        const int direct = ws->e_state == 2 ? 1 : (ws->e_state == 3 ? 2 : 0);
+        const double* lr = ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho;
+        const double* aux = ws->e_state == 3 ? ws->lnrho : nullptr;
+        int S = ws->gen_S;
+        const int64_t rps = round_up((n_rows + S - 1) / S, 64);
+        S = (int)((n_rows + rps - 1) / rps);
+        const int tiles = tri_pairs(ws->T);
+        if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
+        span_begin(ws, kSpanMstepMain, st);
+        if (ws->x_dtype == GMMVB_F64) {
+            hipLaunchKernelGGL(mstep_generic_first_kernel<double>, dim3(ws->K, S), dim3(256), 0, st, (const double*)x_dev, ldx, n_rows,
+                               ws->D, ws->pivot, lr, ws->lse, aux, ws->npad, ws->K, rps, direct, ws->gen_first);
+            hipLaunchKernelGGL(mstep_generic_second_kernel<double>, dim3(tiles, ws->K, S), dim3(256), 0, st, (const double*)x_dev, ldx,
+                               n_rows, ws->D, ws->pivot, lr, ws->lse, aux, ws->npad, ws->K, rps, direct, ws->T, ws->gen_second);
+        } else {
+            hipLaunchKernelGGL(mstep_generic_first_kernel<float>, dim3(ws->K, S), dim3(256), 0, st, (const float*)x_dev, ldx, n_rows,
+                               ws->D, ws->pivot, lr, ws->lse, aux, ws->npad, ws->K, rps, direct, ws->gen_first);
+            hipLaunchKernelGGL(mstep_generic_second_kernel<float>, dim3(tiles, ws->K, S), dim3(256), 0, st, (const float*)x_dev, ldx,
+                               n_rows, ws->D, ws->pivot, lr, ws->lse, aux, ws->npad, ws->K, rps, direct, ws->T, ws->gen_second);
+        }
+        span_end(ws, st);
+        if (ws->prof) {
+            (void)hipEventRecord(ws->ev[3], st);
+            ws->ev_m = true;
+        }
+        span_begin(ws, kSpanReduce, st);
+        const int64_t elems = ws->D + 2 + (int64_t)tiles * 256;
+        hipLaunchKernelGGL(reduce_generic_kernel, dim3((unsigned)((elems + 255) / 256), ws->K), dim3(256), 0, st, ws->gen_first,
+                           ws->gen_second, S, ws->K, ws->D, ws->T, stats_dev);
+        span_end(ws, st);
+        hipError_t eg = hipGetLastError();
+        if (eg != hipSuccess) return fail(GMMVB_EHIP, "mstep_generic launch", eg);
+        ++ws->passes[5];
+        const size_t used = std::strlen(ws->info);
+        std::snprintf(ws->info + used, sizeof(ws->info) - used, " | mstep_generic_f64<D=%d> tiles=%d splits=%d", ws->D, tiles, S);
+        return GMMVB_OK;
+    }
     // row splits: ~4 workgroups per CU in total, whole 64-row groups per split, S a multiple of 8 where possible
     int64_t S = ws->S_cap;
     const int64_t groups = (n_rows + 63) / 64;

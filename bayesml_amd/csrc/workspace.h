@@ -168,6 +168,13 @@ struct gmmvb_workspace {
     const void* xc_src = nullptr;   // the x it was made from (null = not prepared)
     int64_t xc_rows = 0, xc_ldx = 0;
     bool xc_stale = false;     // the rows were regrouped since xc was made: it is rebuilt from xp when a kernel needs it
+    // c_degree > 128 (generic.h): plain f64 kernels on the raw parameters, no images, no lists
+    bool generic = false;
+    double* gen_u = nullptr;           // [K][D][D]
+    double* gen_m = nullptr;           // [K][D]
+    double* gen_first = nullptr;       // [gen_S][K][D + 2] partial ns, h, a per row split
+    double* gen_second = nullptr;      // [gen_S][K][tri_pairs(T)][256] partial B tiles per row split
+    int gen_S = 1;
     int64_t bytes = 0;
     bool have_params = false;
     int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly, 3 HMM gamma

@@ -21,7 +21,9 @@
  *   - all K-sized quantities and all outputs are IEEE binary64.  The sample matrix x stays in its
  *     storage dtype (f32 or f64) in HBM and is widened on load; all arithmetic is f64
  *     (v_mfma_f64_16x16x4_f64), because f32 arithmetic misses the 1e-5 parity target.
- *   - supported shapes in this version: 1 <= D <= 128, K >= 1, n_rows <= max_rows.
+ *   - shapes: K >= 1, D >= 1, n_rows <= max_rows.  Up to D = 128 (8 feature tiles) the data pass runs on the f64 MFMA
+ *     kernels; beyond, on plain f64 vector kernels (csrc/generic.h): same results, no pruning, far slower.  The K-sized
+ *     entry points (gmmvb_kside_*) keep their matrices in LDS and stop at D = 128.
  */
 #ifndef GMMVB_H
 #define GMMVB_H
@@ -37,7 +39,7 @@ extern "C" {
 enum gmmvb_status {
     GMMVB_OK = 0,
     GMMVB_EINVAL = 1,       /* bad argument (null pointer, bad shape, n_rows > max_rows, misaligned x) */
-    GMMVB_EUNSUPPORTED = 2, /* shape outside this version's range (D > 128)                            */
+    GMMVB_EUNSUPPORTED = 2, /* shape outside this version's range (gmmvb_kside_*: D > 128; HMM: K > 64)    */
     GMMVB_EHIP = 3,         /* a HIP runtime call failed (see gmmvb_last_error)                       */
     GMMVB_ENOMEM = 4,       /* device allocation failed                                               */
     GMMVB_ESTATE = 5        /* call order violated (e.g. mstep before estep / load_responsibilities)  */
