@@ -405,7 +405,8 @@ class KStepper:
         self.scal = torch.zeros(len(TERM_KEYS) + 1, dtype=torch.float64, device=dev)
         self._graph = None
         self._calls = 0
-        self._use_graph = dev.type == "cuda" and os.environ.get("BAYESML_AMD_KSIDE_GRAPH", "1") != "0"
+        # (beyond D = 128 the factorisations go through torch.linalg - MAGMA / rocSOLVER -, which cannot be captured)
+        self._use_graph = dev.type == "cuda" and D <= 128 and os.environ.get("BAYESML_AMD_KSIDE_GRAPH", "1") != "0"
         self._fused = dev.type == "cuda" and D <= 128 and os.environ.get("BAYESML_AMD_KSIDE_FUSED", "1") != "0"
         if self._fused:
             from . import _engine

@@ -810,7 +810,12 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     hipLaunchKernelGGL(perm_invert_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ws->perm, n_rows, ws->iperm);
     const int64_t total = n_rows * ws->D;
     const unsigned pg = (unsigned)((total + 255) / 256);
-    if (ws->x_dtype == GMMVB_F64)
+    const int64_t esz = ws->x_dtype == GMMVB_F64 ? 8 : 4;
+    if ((ws->D * esz) % 16 == 0 && (ldx * esz) % 16 == 0 && (uintptr_t)x_dev % 16 == 0) {
+        const int p16 = (int)(ws->D * esz / 16);
+        hipLaunchKernelGGL(permute_rows16_kernel, dim3((unsigned)((n_rows * p16 + 255) / 256)), dim3(256), 0, st,
+                           (const uint4*)x_dev, ldx * esz / 16, n_rows, p16, ws->perm, (uint4*)ws->xp);
+    } else if (ws->x_dtype == GMMVB_F64)
         hipLaunchKernelGGL(permute_rows_kernel<double>, dim3(pg), dim3(256), 0, st, (const double*)x_dev, ldx, n_rows, ws->D,
                            ws->perm, (double*)ws->xp);
     else
@@ -840,6 +845,7 @@ static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepI8Args& a8, 
     EstepI8Args ab = a8;
     ab.img = ws->img_i8b;
     ab.khat = ws->khat;
+    ab.ub = ws->ub32;           // the bounds go straight into the f32 array the sweeps carry
     return launch_estep_i8_bound(is64, vec, ws->bound_tb, (int)grid, st, ab, name);
 }
 

@@ -421,7 +421,8 @@ __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned cons
 template <int ND, bool BOUND, int T32, int TI, bool REV>
 __device__ __forceinline__ double estep_i8_component(unsigned im_lds, const i4v (&xd)[ND][T32], double ck,
                                                    const i8_lane_consts& lc, int lane, int c, int h, int64_t n0,
-                                                   int64_t n_rows, double* __restrict__ lnrho_k) {
+                                                   int64_t n_rows, double* __restrict__ lnrho_k,
+                                                   float* __restrict__ ub_k /*BOUND: the f32 bound array's row instead*/) {
     using ord = i8_order<ND, T32, REV>;
     constexpr int P = tri_pairs(TI);
     const unsigned frag_addr = im_lds + lane * 16;                              // layout step s at + 1024 s
@@ -443,7 +444,10 @@ __device__ __forceinline__ double estep_i8_component(unsigned im_lds, const i4v 
     const int64_t row = n0 + c;
     // BOUND: an upper bound of ln rho; 2^-16 of q covers the f32 rounding of its 128 squares and additions
     const double v = BOUND ? fma(-0.5 * (double)q, 1.0 - 1.52587890625e-05, ck + 1e-12 * fabs(ck)) : ck - 0.5 * (double)q;
-    if (h == 0 && row < n_rows) lnrho_k[row] = v;
+    if (h == 0 && row < n_rows) {
+        if constexpr (BOUND) ub_k[row] = __double2float_ru(v);       // what the sweeps carry (records.h): rounded up
+        else lnrho_k[row] = v;
+    }
     return v;
 }
 
@@ -457,7 +461,8 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
                                                     const unsigned char* __restrict__ img /*[K][IMGB]*/,
                                                     const double* __restrict__ pivot, const double* __restrict__ cvec,
                                                     int K, double* __restrict__ lnrho /*[K][npad]*/, int64_t npad,
-                                                    int* __restrict__ khat /*[n_rows] first maximiser over k, or null*/) {
+                                                    int* __restrict__ khat /*[n_rows] first maximiser over k, or null*/,
+                                                    float* __restrict__ ub /*[K][npad] BOUND: the bounds go here, in f32*/) {
     constexpr int IMGB = i8_img_bytes(ND, T32);
     constexpr int KB = i8_kb(ND, T32);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][KB * IMGB];   // the ONLY LDS object of the kernel
@@ -514,10 +519,12 @@ __global__ __launch_bounds__(64 * NW) void estep_i8(const XT* __restrict__ x, in
                 double v;
                 if (T32 > 1 && wave >= NW / 2)      // the second wave of each SIMD (wave uniform: no divergence)
                     v = estep_i8_component<ND, BOUND, TB, T32, true>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
-                                                                     n_rows, lnrho + (int64_t)k * npad);
+                                                                     n_rows, lnrho + (int64_t)k * npad,
+                                                                     BOUND ? ub + (int64_t)k * npad : nullptr);
                 else
                     v = estep_i8_component<ND, BOUND, TB, T32, false>(buf + kk * IMGB, xd, cvec[k], lc, lane, c, h, n0,
-                                                                      n_rows, lnrho + (int64_t)k * npad);
+                                                                      n_rows, lnrho + (int64_t)k * npad,
+                                                                      BOUND ? ub + (int64_t)k * npad : nullptr);
                 if (v > best) {
                     best = v;
                     arg = k;

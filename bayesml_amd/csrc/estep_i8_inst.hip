@@ -23,7 +23,7 @@ hipError_t launch_pack_i8(const double* u, const double* m, const double* pivot,
 template <int ND, bool BOUND, int T32, int TB, typename XT, bool VEC>
 static hipError_t go(int grid, hipStream_t st, const EstepI8Args& a) {
     hipLaunchKernelGGL((estep_i8<ND, BOUND, T32, TB, XT, VEC, 8>), dim3(grid), dim3(512), 0, st,
-                       static_cast<const XT*>(a.x), a.ldx, a.n_rows, a.D, a.img, a.pivot, a.cvec, a.K, a.lnrho, a.npad, a.khat);
+                       static_cast<const XT*>(a.x), a.ldx, a.n_rows, a.D, a.img, a.pivot, a.cvec, a.K, a.lnrho, a.npad, a.khat, a.ub);
     return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ struct EstepI8Args {
     const unsigned char* img; const double* pivot; const double* cvec; int K;
     double* lnrho; int64_t npad;
     int* khat = nullptr;      // optional: first maximiser over k of what the kernel stores, per row
+    float* ub = nullptr;      // bound pass: [K][npad] f32 upper bounds (rounded up) - written INSTEAD of lnrho
 };
 // bound = 1: the 3-digit image / kernel of the pruned E-step's bound pass
 int estep_i8_image_bytes(int D, int bound);

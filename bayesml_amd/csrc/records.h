@@ -117,15 +117,21 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
     float rest = -__builtin_huge_valf();
     const int kb = GIVEN ? khat[n] : -1;
     for (int k0 = 0; k0 < K; k0 += 8) {            // eight loads in flight per thread
+        // GIVEN: the bound pass has left its bounds in ub32 (f32, rounded up) - only khat's exact value is in lnrho;
+        // otherwise every entry of lnrho is an exact value (dense pass) and ub32 is made from it here
         double pre[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pre[q] = (k0 + q < K) ? lnrho[(int64_t)(k0 + q) * npad + n] : 0.0;
+        for (int q = 0; q < 8; ++q) {
+            if (k0 + q >= K) pre[q] = 0.0;
+            else if (GIVEN) pre[q] = (double)ub32[(int64_t)(k0 + q) * npad + n];
+            else pre[q] = lnrho[(int64_t)(k0 + q) * npad + n];
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = k0 + q;
             if (k >= K) break;
             const double v = pre[q];
-            ub32[(int64_t)k * npad + n] = f32_up(v);
+            if (!GIVEN) ub32[(int64_t)k * npad + n] = f32_up(v);
             if (GIVEN && k == kb) continue;
             rec_insert(ds, ks, vs, rest, f32_down(dist_of(cvec[k], v)), (unsigned short)k, f32_up(v));
         }
@@ -135,7 +141,9 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
         const int at = kRecSlots - 1;
         if (ks[at] != kRecEmpty) rest = (vs[at] > rest || vs[at] != vs[at]) ? vs[at] : rest;
         ks[at] = (unsigned short)kb;
-        ds[at] = f32_down(dist_of(cvec[kb], lnrho[(int64_t)kb * npad + n]));
+        const double vb = lnrho[(int64_t)kb * npad + n];
+        ds[at] = f32_down(dist_of(cvec[kb], vb));
+        ub32[(int64_t)kb * npad + n] = f32_up(vb);
         ex = 1u << at;
     } else {
 #pragma unroll
