@@ -937,7 +937,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     enum { kDense = 0, kBound = 1, kSweep = 3 };      // (2 was the pass on per-row records, gone in round 3)
     int mode = kDense;
     const gmmvb_pass_counters& L = ws->sharded ? ws->pol : ws->lag;
-    const bool can_prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr && ws->rec_k != nullptr;
+    // (a pruned E-step leaves exact ln rho for the listed pairs only, so its M-step has to run over the lists - which read
+    // the rows through the workspace's prepared copy: without gmmvb_prepare_rows for this matrix the pass stays dense)
+    const bool can_prune = ws->prune != 0 && ws->estep_variant == kEstepLds8 && ws->hmm == nullptr && ws->rec_k != nullptr &&
+                           ws->xc != nullptr && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx;
     const int64_t size_rows = ws->sharded ? ws->shard_rows / ws->shard_ranks : n_rows;
     const bool big = ws->prune == 2 || size_rows * (int64_t)ws->K >= (int64_t(1) << 23);
     const bool same_rows = ws->bounds_rows == n_rows && ws->bounds_x == x_dev && ws->bounds_ldx == ldx;
@@ -1439,11 +1442,8 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (sparse) {      // the lists pay off when most pairs are negligible (at most 35 % active)
         const double pairs = (double)n_rows * ws->K;
         if (ws->rec_live) {
-            // a pass on records is sparse by construction; the last counters that have arrived can still veto
-            // (not in a sharded job: its ranks would have to agree, and the previous pass's sums are spent by now)
-            poll_counters(ws);
-            if (!ws->sharded && ws->lag.valid && ws->lag.rows == (double)n_rows && ws->lag.act > 0.35 * pairs && !ws->lock_live)
-                sparse = false;
+            // a pruned E-step leaves exact values for the listed pairs only (the others are bounded in the f32 array, not in
+            // ln rho): its M-step always runs over the lists, however many pairs are active
         } else {
             // after a dense E-step the host has been waiting for that kernel anyway: read this pass's own count
             rc = fetch_counters(ws);
@@ -1452,6 +1452,8 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
     }
     if (sparse && ws->K > 256) sparse = false;
+    if (ws->rec_live && ws->e_state == 1 && !sparse)
+        return fail(GMMVB_ESTATE, "a pruned E-step needs the list M-step over the matrix of the E-step (gmmvb_prepare_rows)");
     if (ws->lock_live && !sparse)
         return fail(GMMVB_ESTATE, "settled rows need the list M-step over the matrix of the E-step (gmmvb_prepare_rows)");
     if (sparse) {      // E-step output: only the samples that can change the f64 sums, through per-component lists
