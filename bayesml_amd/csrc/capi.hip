@@ -1226,12 +1226,33 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_end(ws, st);
                 ++ws->passes[7];
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step active-pair evaluation", e);
-                span_begin(ws, kSpanSelect, st);
                 const bool proof = proof_capable && (ws->skip_used || ws->opt_proof_all);       // (some rows may be settled)
+                // Settled rows of components that moved noticeably: a fresh lower bound of their own pair first (three int8
+                // digits), so that the sweep compares the other components' bounds with a tight reference instead of one
+                // carried through Gamma and delta (records.h, own_first).  While the summary of the drift says that no
+                // component moves that much the round is skipped altogether.
+                const bool own_round = proof && ws->skip_used && !(ws->typical_gamma >= 0.995);
+                if (own_round) {
+                    span_begin(ws, kSpanSelect, st);
+                    hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->lcomp,
+                                       ws->npad, n_rows, ws->K, ws->rmask, ws->rblk, ws->drift);
+                    launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+                    hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
+                                       ws->K, ws->rblk, ws->lists, ws->npad);
+                    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
+                                       estep_i8_pairs_per_chunk(), ws->plan);
+                    span_end(ws, st);
+                    span_begin(ws, kSpanProof, st);
+                    e = launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists,
+                                              ws->npad, ws->counts, ws->plan, nullptr, ws->lnrho, ws->npad);
+                    span_end(ws, st);
+                    if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round (settled rows' own pairs)", e);
+                }
+                span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
                                    settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
-                                   ws->rblk, ws->opt_proof_all ? 1 : 0);
+                                   ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0);
                 if (proof) {
                     // proof round: settled rows whose carried bounds left candidates - their component and the candidates
                     // get two-sided bounds from three int8 digits; rows that are proven stay settled, the others join
@@ -1264,7 +1285,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, nullptr, nullptr, 0);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, nullptr, nullptr, 0, 0);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;

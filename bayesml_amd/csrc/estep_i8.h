@@ -635,7 +635,8 @@ __host__ __device__ constexpr int i8_pairs_per_chunk() { return 8 * 32 * kI8Pair
 // plan[k] = component k's first chunk of i8_pairs_per_chunk() list entries, plan[K] = total (gather_plan_kernel); a fixed
 // grid of persistent workgroups takes contiguous runs of chunks and restages the 31-KB digit image only when the
 // component changes.  For every listed pair (row, k):
-//   ub[k][row] <- an upper bound of ln rho_{row,k}, rounded up to f32 (the array the sweeps carry, records.h);
+//   ub[k][row] <- an upper bound of ln rho_{row,k}, rounded up to f32 (the array the sweeps carry, records.h) - unless
+//                 ub is null (a round that only serves lower bounds);
 //   lb[k][row] <- a lower bound of it (f64; -inf when the image or the sample admits no bound - the caller then
 //                 treats the row as unproven and evaluates it exactly).
 template <int T32>
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(512) void estep_i8_proof(const unsigned char* __res
                 // 2^-16 of q covers the f32 rounding of its 32 T32 squares and additions (as in estep_i8_component)
                 const double up = fma(-0.5 * (double)q_lo, 1.0 - 1.52587890625e-05, ck + 1e-12 * fabs(ck));
                 const double lo = fma(-0.5 * (double)q_hi, 1.0 + 1.52587890625e-05, ck - 1e-12 * fabs(ck));
-                ub[(int64_t)k * npad + row] = __double2float_ru(up);
+                if (ub) ub[(int64_t)k * npad + row] = __double2float_ru(up);
                 lb[(int64_t)k * npad + row] = (lo == lo) ? lo : -__builtin_huge_val();
             }
         };

@@ -321,6 +321,13 @@ __device__ __forceinline__ void sweep_chain(unsigned (&s)[kRecSlots + 1], unsign
     s[kRecSlots] = min(s[kRecSlots], key);
 }
 
+// A settled row's reference is a lower bound of ln rho of its one component under the new parameters.  Carried from the
+// previous pass (d' = Gamma d + delta) it loses about d^2 (Gamma - 1) + d delta nats - hundreds while the components still
+// move by per cents, and every nat it is too low lets more components' bounds through as candidates.  For components that
+// moved by more than this the settled rows' own pair goes through the proof round BEFORE the sweep (the lower bound in
+// the ln rho array, estep_i8_proof without its upper-bound store); both kernels decide with this one predicate.
+__device__ __forceinline__ bool own_first(double big_gamma, double delta) { return big_gamma > 1.004 || delta > 0.04; }
+
 template <bool PREV>
 __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__ ub, const double* __restrict__ u, int64_t npad,
                                                              int64_t n_rows, int K,
@@ -336,17 +343,21 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              const unsigned char* __restrict__ lcomp /*[npad] component a cached row is in*/,
                                                              unsigned long long* __restrict__ pmask /*null: no proof round*/,
                                                              int* __restrict__ pblk,
-                                                             int proof_all /*candidates of rows with an exact reference too*/) {
+                                                             int proof_all /*candidates of rows with an exact reference too*/,
+                                                             int own_fresh /*the ln rho array holds fresh lower bounds of the
+                                                                             settled rows' own pairs (own_first components)*/) {
     __shared__ int wcnt[4][256];
     __shared__ int pcnt[4][256];
     __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
     __shared__ double sc[256];
+    __shared__ unsigned char sfirst[256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int W = (K + 63) / 64;
     for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = pcnt[wave][k] = 0;
     for (int k = tid; k < K; k += kSelRows) {
+        sfirst[k] = (own_fresh && own_first(drift[3 * K + k], drift[K + k])) ? 1 : 0;
         const double g = drift[k] * (1.0 - 1e-6);
         sp[k] = make_float4(g > 0.0 ? f32_down(g) : 0.0f, f32_up(drift[K + k]), f32_up(c_new[k]), f32_down(drift[2 * K + k]));
         sq[k] = make_float2(f32_up(drift[3 * K + k] * (1.0 + 1e-6)), f32_down(c_new[k]));
@@ -389,8 +400,15 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         float d_set = 0.0f, thr_set = 0.0f;
         if (by_bound) {
             kset = lcomp[n];
-            // the distance bound: the previous pass's carried through Gamma and delta
-            const float dn = fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
+            // the distance bound: from the lower bound the proof round has just made for the new parameters (components
+            // that moved), or the previous pass's carried through Gamma and delta
+            float dn;
+            if (sfirst[kset]) {
+                const double lbn = u[(int64_t)kset * npad + n];
+                dn = f32_up(dist_of(sc[kset], lbn) * (1.0 + 1e-9));            // (-inf: +inf, every component a candidate)
+            } else {
+                dn = fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
+            }
             const float lb = sq[kset].y - dn * dn * 0.5000005f;
             d_set = dn;
             thr_set = (lb - fabsf(lb) * 2.4e-7f) - 69.5f;
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                     pm[w] = mk[w];
                     mk[w] = 0ull;
                 }
-                pm[kset >> 6] |= 1ull << (kset & 63);
+                if (!sfirst[kset]) pm[kset >> 6] |= 1ull << (kset & 63);      // (else its lower bound is fresh already)
                 proof_row = true;
             } else {
                 mk[kset >> 6] |= 1ull << (kset & 63);          // loose: its component and the candidates are evaluated -
@@ -1180,14 +1198,17 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
                                                                 const unsigned long long* __restrict__ emask,
                                                                 const unsigned char* __restrict__ lcomp, int64_t npad, int64_t n_rows,
                                                                 int K, unsigned long long* __restrict__ masks,
-                                                                int* __restrict__ blk_cnt) {
+                                                                int* __restrict__ blk_cnt,
+                                                                const double* __restrict__ drift = nullptr /*only the rows of
+                                                                    own_first components (the sweep's first proof round)*/) {
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
     const int W = (K + 63) / 64;
     const int wave = threadIdx.x >> 6;
     for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
-    const int kh = (valid && row_settled(lock, emask, npad, W, n)) ? (int)lcomp[n] : -1;
+    int kh = (valid && row_settled(lock, emask, npad, W, n)) ? (int)lcomp[n] : -1;
+    if (kh >= 0 && drift != nullptr && !own_first(drift[3 * K + kh], drift[K + kh])) kh = -1;
     for (int w = 0; w < W; ++w) {
         const unsigned long long mk = (kh >= 0 && (kh >> 6) == w) ? 1ull << (kh & 63) : 0ull;
         if (valid) masks[(int64_t)w * npad + n] = mk;
