@@ -1235,7 +1235,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (own_round) {
                     span_begin(ws, kSpanSelect, st);
                     hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->lcomp,
-                                       ws->npad, n_rows, ws->K, ws->rmask, ws->rblk, ws->drift);
+                                       ws->npad, n_rows, ws->K, ws->rmask, ws->rblk, ws->drift, ws->spart);
                     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
                     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
                                        ws->K, ws->rblk, ws->lists, ws->npad);
@@ -1271,7 +1271,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     span_begin(ws, kSpanSelect, st);
                     hipLaunchKernelGGL(rec_proof_decide_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->rmask, ws->masks,
                                        ws->npad, n_rows, ws->K, ws->cvec, ws->ub32, ws->lnrho, ws->lcomp, ws->dlock, ws->rthr,
-                                       ws->blk, ws->epart, ws->ppart);
+                                       ws->blk, ws->epart, ws->ppart, own_round ? ws->spart : nullptr);
                     proof_ran = true;
                 }
                 span_end(ws, st);

@@ -605,7 +605,9 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
                                                                     const unsigned char* __restrict__ lcomp,
                                                                     float* __restrict__ dlock, float* __restrict__ rthr,
                                                                     int* __restrict__ blk_cnt, double* __restrict__ epart,
-                                                                    double* __restrict__ ppart) {
+                                                                    double* __restrict__ ppart,
+                                                                    const double* __restrict__ own_part /*[blocks] pairs of the
+                                                                        round before the sweep (own_first), or null*/) {
     __shared__ int wcnt[4][256];
     __shared__ int wsum[2][4];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
         blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
-        ppart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
+        ppart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]) + (own_part ? own_part[blockIdx.x] : 0.0);
     }
 }
 
@@ -1200,7 +1202,8 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
                                                                 int K, unsigned long long* __restrict__ masks,
                                                                 int* __restrict__ blk_cnt,
                                                                 const double* __restrict__ drift = nullptr /*only the rows of
-                                                                    own_first components (the sweep's first proof round)*/) {
+                                                                    own_first components (the sweep's first proof round)*/,
+                                                                double* __restrict__ listed_part = nullptr /*[blocks] rows listed*/) {
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;
@@ -1215,8 +1218,20 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
         count_word(mk, w, wave, wcnt);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += kSelRows)
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    int tot = 0;
+    for (int k = threadIdx.x; k < K; k += kSelRows) {
+        const int c = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = c;
+        tot += c;
+    }
+    if (listed_part) {
+        __shared__ int wtot[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if ((threadIdx.x & 63) == 0) wtot[wave] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) listed_part[blockIdx.x] = (double)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);
+    }
 }
 
 __global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const unsigned long long* __restrict__ emask,
