@@ -999,9 +999,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     ws->forget = false;
     // The cache of single-component rows (and the settled rows among them) survives every pruned pass over the same rows
-    // whose M-step applied the delta lists - all of them end in rec_finish_kernel.  A dense pass, a regrouping of the rows,
-    // new data or parameters unrelated to the last pass drop it; rows that were settled then have no active pair on
-    // record, which only a pass that rebuilds everything (bound or dense) can digest.
+    // whose M-step applied the delta lists - all of them end in rec_finish_kernel - including the one that regroups the
+    // rows (regroup_rows moves the per-row state along).  A dense pass, new data or parameters unrelated to the last pass
+    // drop it; rows that were settled then have no active pair on record, which only a pass that rebuilds everything
+    // (bound or dense) can digest.
     // The rows are regrouped by dominant component at a bound pass (which rebuilds everything row-indexed anyway).  With
     // the proof round bound passes have become rare: the first time the responsibilities are sparse enough for the grouping
     // to pay (at most 2.5 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
