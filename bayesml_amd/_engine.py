@@ -321,11 +321,14 @@ class DataPass:
 
     def work(self) -> dict:
         """Pairs of the last E-step (gmmvb_last_work): active, evaluated exactly, accumulated by the list M-step, and the
-        rows the E-step did not evaluate at all (settled), pairs of the int8 proof round."""
+        rows the E-step did not evaluate at all (settled), pairs of the int8 proof round, and the share of the per-pair bound
+        array the sweep went through (sweep_share; -1: the last E-step was not a lazy sweep)."""
         out = (ctypes.c_double * 8)()
         _check(self.lib, self.lib.gmmvb_last_work(self._ws, out), "gmmvb_last_work")
+        tiles = (self.rows + 255) // 256 if getattr(self, "rows", 0) else 0
+        share = float(out[6]) / (tiles * self.K) if out[6] >= 0 and tiles else -1.0
         return dict(active=float(out[0]), evaluated=float(out[1]), accumulated=float(out[2]), settled_rows=float(out[3]),
-                    early_exits=float(out[4]), proof_pairs=float(out[5]))
+                    early_exits=float(out[4]), proof_pairs=float(out[5]), sweep_share=share)
 
     def profile(self, on: bool = True):
         _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")
@@ -615,7 +618,7 @@ class TiledDataPass:
 
     def work(self):
         return self._work if self._work is not None else dict(active=-1.0, evaluated=0.0, accumulated=-1.0, settled_rows=0.0,
-                                                              early_exits=0.0, proof_pairs=0.0)
+                                                              early_exits=0.0, proof_pairs=0.0, sweep_share=-1.0)
 
     def split_stats(self, stats):
         return self.inner.split_stats(stats)
@@ -698,7 +701,7 @@ class TiledDataPass:
                 self._tail_in = self._tail_acc.clone()      # a single process: the tiles' sums are the job's
             self._spars = (act if counted else -1.0, ev)
             self._work = dict(active=act if counted else -1.0, evaluated=ev, accumulated=acc if counted else -1.0,
-                              settled_rows=0.0, early_exits=0.0, proof_pairs=0.0)
+                              settled_rows=0.0, early_exits=0.0, proof_pairs=0.0, sweep_share=-1.0)
             self._ms = (e_ms, m_ms)
             self._held = (n + self.tile_rows - 1) // self.tile_rows - 1
             self.rows = n

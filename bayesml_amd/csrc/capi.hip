@@ -177,6 +177,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round (rows then never settle);
         ws->opt_proof = !(v && std::strcmp(v, "0") == 0);          // "all": every spare candidate goes through it first
         ws->opt_proof_all = v && std::strcmp(v, "all") == 0;
+        v = std::getenv("GMMVB_SWEEP_LAZY");                       // "0": every sweep reads all K bounds of every row
+        ws->opt_lazy = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_MSTEP_CACHE");
@@ -240,7 +242,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
                      ws->lock, ws->lcomp, ws->dlock, ws->rthr, ws->exit_ctr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
-                     ws->rmask, ws->rblk, ws->xq, ws->xqe, ws->ppart};
+                     ws->rmask, ws->rblk, ws->xq, ws->xqe, ws->ppart, ws->tmeta};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -417,6 +419,7 @@ int gmmvb_debug_proof(gmmvb_workspace* ws, int k, int64_t n_rows, float* ub_dev,
     if (!ws->xq || !ws->img_i8b || ws->xq_src == nullptr || ws->xq_rows != n_rows || ws->xq_gen != ws->img_gen || !ws->have_params)
         return fail(GMMVB_ESTATE, "no digit planes for these rows: gmmvb_set_pivot, gmmvb_prepare_rows, gmmvb_set_params first");
     hipStream_t st = (hipStream_t)stream;
+    ws->tmeta_valid = false;                                       // (the bound array is written behind the sweeps' back)
     const unsigned grid = (unsigned)((std::max<int64_t>(n_rows, ws->K) + 255) / 256);
     hipLaunchKernelGGL(debug_all_rows_kernel, dim3(grid), dim3(256), 0, st, ws->lists + (int64_t)k * ws->npad, ws->counts, ws->K, k,
                        n_rows);
@@ -502,10 +505,10 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->lcomp, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dlock, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rthr, (size_t)np * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&ws->exit_ctr, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ws->exit_ctr, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->exit_host, sizeof(unsigned long long), hipHostMallocDefault);
-    if (e == hipSuccess) *ws->exit_host = 0;
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->exit_ctr, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ws->exit_ctr, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->exit_host, 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) ws->exit_host[0] = ws->exit_host[1] = 0;
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mmask, (size_t)words * np * sizeof(unsigned long long));
@@ -536,6 +539,10 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_flags, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->ub32, (size_t)ws->K * np * sizeof(float));
     if (e == hipSuccess) ws->bytes += (int64_t)ws->K * np * (int64_t)sizeof(float);
+    if (ws->opt_lazy && ws->K <= kSelRows) {       // the lazy sweep's state per tile of kSelRows rows and component
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->tmeta, (size_t)sel_blocks * ws->K * sizeof(float4));
+        if (e == hipSuccess) ws->bytes += sel_blocks * ws->K * (int64_t)sizeof(float4);
+    }
     const size_t esz = ws->x_dtype == GMMVB_F64 ? 8 : 4;
     if (ws->sort_rows) {
         if (e == hipSuccess) e = hipMalloc(&ws->xp, (size_t)ws->max_rows * ws->D * esz);
@@ -566,11 +573,13 @@ static int fetch_counters(gmmvb_workspace* ws) {
             ws->lag.settled = 0.0;
             ws->lag.listed = ws->lag.accum = ws->lag.act;
             ws->lag.exits = 0.0;
+            ws->lag.cols = -1.0;
             ws->lag.proof = 0.0;
             ws->lag.moved = 0.0;
         } else {
             ws->lag.proof = ws->ctr_host[7];
-            ws->lag.exits = (ws->exit_host && ws->gather_exit) ? (double)*ws->exit_host : 0.0;
+            ws->lag.exits = (ws->exit_host && ws->gather_exit) ? (double)ws->exit_host[0] : 0.0;
+            ws->lag.cols = (ws->exit_host && ws->pend_lazy) ? (double)ws->exit_host[1] : -1.0;
             ws->lag.settled = ws->ctr_host[4];
             ws->lag.listed = ws->ctr_host[5];
             ws->lag.accum = ws->ctr_host[6];                               // a bound pass / sweep also evaluated every row's (previous) best component
@@ -710,7 +719,8 @@ int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
     out[3] = ws->lag.mode == 0 ? 0.0 : ws->lag.settled;
     out[4] = ws->lag.mode == 0 ? 0.0 : ws->lag.exits;
     out[5] = ws->lag.mode == 0 ? 0.0 : ws->lag.proof;
-    out[6] = out[7] = 0.0;
+    out[6] = ws->lag.mode == 3 ? ws->lag.cols : -1.0;
+    out[7] = 0.0;
     return GMMVB_OK;
 }
 
@@ -1109,7 +1119,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
     const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
-    bool counted = false, proof_ran = false;
+    bool counted = false, proof_ran = false, tmeta_kept = false;
+    const bool tmeta_was_valid = ws->tmeta_valid;
+    ws->tmeta_valid = false;            // (only a lazy sweep that ran to its end leaves the tile state in step with the bounds)
     if (mode == kDense) {
         rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
         grid = (n_rows + rpw - 1) / rpw;
@@ -1250,10 +1262,22 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round (settled rows' own pairs)", e);
                 }
                 span_begin(ws, kSpanSelect, st);
-                hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
-                                   ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
-                                   ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0);
+                if (ws->tmeta) {
+                    (void)hipMemsetAsync(ws->exit_ctr + 1, 0, sizeof(unsigned long long), st);
+                    // (the tile state is void after any pass that rewrote the bounds wholesale: the first sweep after it
+                    // opens every column and takes stock)
+                    hipLaunchKernelGGL((rec_sweep_kernel<true, true>), dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho,
+                                       ws->npad, n_rows, ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart,
+                                       ws->opart, settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp,
+                                       proof ? ws->rmask : nullptr, ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0,
+                                       ws->tmeta, tmeta_was_valid ? 0 : 1, ws->exit_ctr + 1);
+                    tmeta_kept = true;
+                } else {
+                    hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad,
+                                       n_rows, ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
+                                       settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
+                                       ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0, nullptr, 0);
+                }
                 if (proof) {
                     // proof round: settled rows whose carried bounds left candidates - their component and the candidates
                     // get two-sided bounds from three int8 digits; rows that are proven stay settled, the others join
@@ -1286,7 +1310,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 hipLaunchKernelGGL(rec_sweep_kernel<false>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad, n_rows,
                                    ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
-                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, nullptr, nullptr, 0, 0);
+                                   settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, nullptr, nullptr, 0, 0, nullptr, 0);
                 span_end(ws, st);
             }
             ws->sweep_prev = prev_lists;
@@ -1318,11 +1342,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             ws->delta_pending = true;
         }
     }
+    ws->tmeta_valid = tmeta_kept;
+    ws->pend_lazy = tmeta_kept;
     // counters -> pinned host memory, behind an event (read by the next pass, or by gmmvb_last_sparsity)
     if (counted) {
         e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 8 * sizeof(double), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && ws->exit_ctr && mode != kDense)
-            e = hipMemcpyAsync(ws->exit_host, ws->exit_ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+            e = hipMemcpyAsync(ws->exit_host, ws->exit_ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(ws->ctr_ev, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step counters", e);
         ws->ctr_pending = true;

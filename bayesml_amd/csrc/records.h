@@ -328,7 +328,50 @@ __device__ __forceinline__ void sweep_chain(unsigned (&s)[kRecSlots + 1], unsign
 // the ln rho array, estep_i8_proof without its upper-bound store); both kernels decide with this one predicate.
 __device__ __forceinline__ bool own_first(double big_gamma, double delta) { return big_gamma > 1.004 || delta > 0.04; }
 
-template <bool PREV>
+// One step of the carry for a stored bound `old`, p = (gamma, delta, c' up, c the bound was stored under, down): the
+// kernel's per-pair arithmetic.  Every operation is monotone in `old` (round-to-nearest is), so applied to the LARGEST
+// bound of a set of pairs of one component it gives a value >= the carried bound of every pair of the set - which is what
+// the lazy form of the sweep lives on.
+__device__ __forceinline__ float sweep_carry(float old, float4 p) {
+    const float qd = p.w - old;
+    const float sq = __builtin_amdgcn_sqrtf(qd + qd);              // NaN for qd < 0 or NaN: no information
+    const float t = fmaxf(fmaf(p.x, sq, -p.y), 0.0f);              // NaN -> 0: the trivial bound c'
+    const float w = fminf(t * t * 0.4999995f, 3.0e38f);
+    const float r = p.z - w;
+    return fmaf(fabsf(r), 2.4e-7f, r);
+}
+
+// largest value over the wave's lanes, in every lane (NaN operands lose against numbers: callers' values are never NaN)
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// LAZY (PREV only): the sweep does not touch what it can prove irrelevant for a whole tile of 256 rows (= workgroup).
+// Per tile and component it keeps (tmeta, [tiles][K] float4)
+//   tub   the largest stored bound of the tile's rows (+inf: unknown - entries of the column have been or will be replaced
+//         by fresh values behind the sweep's back: rec_finish_kernel, estep_i8_proof),
+//   gc, dc   the carry composed over the passes since the column's entries were last rewritten
+//            (d'' >= g2 (g1 d - d1) - d2 = g1 g2 d - (g2 d1 + d2)),
+//   ce    the constant c_k those entries were stored under.
+// sweep_carry(tub, composed) bounds the carried value of every pair of the column; if it lies below the LOWEST threshold of
+// the tile's rows, no row has a candidate there and neither the column's entries nor the composition change hands: the
+// entries stay as they are (bounds under the parameters of the pass that wrote them), gc / dc take the step in.  A column
+// is opened - its entries carried with the composed step and rewritten under the new parameters - if that test fails, if
+// a row of the tile holds an exact value there (fresh pairs, a settled row's own component: later kernels write fresh
+// values into such entries) or if tub is unknown.  The carry being monotone, the largest entry of an opened column in
+// which nothing is a candidate is sweep_carry(tub) itself; a column with candidates is marked unknown (the candidates'
+// entries are about to be replaced by tighter values) and its true maximum is taken the next time it is opened.  With the
+// rows grouped by dominant component a tile's rows share their near components, and the far ones - most of the K - are
+// never read: the sweep was 5 GB of traffic per pass at the benchmark shape, the largest kernel of a converged step.
+template <bool PREV, bool LAZY = false>
 __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__ ub, const double* __restrict__ u, int64_t npad,
                                                              int64_t n_rows, int K,
                                                              const double* __restrict__ drift,
@@ -345,23 +388,39 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                                                              int* __restrict__ pblk,
                                                              int proof_all /*candidates of rows with an exact reference too*/,
                                                              int own_fresh /*the ln rho array holds fresh lower bounds of the
-                                                                             settled rows' own pairs (own_first components)*/) {
+                                                                             settled rows' own pairs (own_first components)*/,
+                                                             float4* __restrict__ tmeta = nullptr /*LAZY: [tiles][K]*/,
+                                                             int tmeta_reset = 0 /*LAZY: the stored tile state is void*/,
+                                                             unsigned long long* __restrict__ col_ctr = nullptr /*LAZY: += columns opened*/) {
+    static_assert(!LAZY || PREV, "the lazy sweep is a form of the PREV sweep");
     __shared__ int wcnt[4][256];
     __shared__ int pcnt[4][256];
-    __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down
+    __shared__ float4 sp[256];          // gamma (1 - 1e-6) down, delta up, c' up, c old down  (LAZY: composed since the column was written)
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
     __shared__ double sc[256];
     __shared__ unsigned char sfirst[256];
+    __shared__ float s_delta[256];      // this pass's delta, rounded up
     __shared__ int wsum[2][4];
-    const int tid = threadIdx.x, wave = tid >> 6;
+    __shared__ unsigned char s_force[LAZY ? 256 : 1];      // a row of the tile holds an exact value in this column
+    __shared__ float s_thr[LAZY ? 4 : 1];                  // per wave: lowest threshold of its rows
+    __shared__ unsigned long long s_open[LAZY ? 4 : 1];    // columns the tile's rows go through
+    __shared__ unsigned long long s_redo[LAZY ? 4 : 1];    // ... of which the true maximum is wanted (unknown, not forced)
+    __shared__ unsigned long long s_any[LAZY ? 4 : 1][4];  // per wave: columns in which one of its rows has a candidate
+    __shared__ float s_red[LAZY ? 4 : 1][LAZY ? 256 : 1];  // per wave: largest carried bound of the redo columns
+    __shared__ float s_skip[LAZY ? 4 : 1];                 // per wave (of columns): largest bound among the closed columns
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int W = (K + 63) / 64;
-    for (int k = tid & 63; k < K; k += 64) wcnt[wave][k] = pcnt[wave][k] = 0;
+    for (int k = lane; k < K; k += 64) wcnt[wave][k] = pcnt[wave][k] = 0;
+    float4 step = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int k = tid; k < K; k += kSelRows) {
         sfirst[k] = (own_fresh && own_first(drift[3 * K + k], drift[K + k])) ? 1 : 0;
         const double g = drift[k] * (1.0 - 1e-6);
-        sp[k] = make_float4(g > 0.0 ? f32_down(g) : 0.0f, f32_up(drift[K + k]), f32_up(c_new[k]), f32_down(drift[2 * K + k]));
+        step = make_float4(g > 0.0 ? f32_down(g) : 0.0f, f32_up(drift[K + k]), f32_up(c_new[k]), f32_down(drift[2 * K + k]));
+        if constexpr (!LAZY) sp[k] = step;
+        s_delta[k] = step.y;
         sq[k] = make_float2(f32_up(drift[3 * K + k] * (1.0 + 1e-6)), f32_down(c_new[k]));
         sc[k] = c_new[k];
+        if constexpr (LAZY) s_force[k] = 0;
     }
     __syncthreads();
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
@@ -369,11 +428,16 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned long long pm[4] = {0ull, 0ull, 0ull, 0ull};        // pairs of the proof round (a settled row with candidates)
     int listed = 0, over_i = 0;
+    // ---- the row's reference value and threshold ---------------------------------------------------------------------
+    const double ninf = -__builtin_huge_val();
+    unsigned long long fresh[4] = {0ull, 0ull, 0ull, 0ull};      // pairs already exact under the new parameters
+    unsigned long long nocand[4] = {0ull, 0ull, 0ull, 0ull};
+    double vb = ninf;
+    bool by_bound = false, over = false;
+    int kset = -1;
+    float d_set = 0.0f, thr_f = __builtin_huge_valf();
     if (valid) {
-        const double ninf = -__builtin_huge_val();
         const int kb = PREV ? -1 : khat[n];
-        unsigned long long fresh[4] = {0ull, 0ull, 0ull, 0ull};      // pairs already exact under the new parameters
-        double vb = ninf;
         if (PREV) {
             for (int w = 0; w < W; ++w) {
                 fresh[w] = masks[(int64_t)w * npad + n];
@@ -395,9 +459,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         // statistics cache - and left out of the lists by rec_finish_kernel) has nothing evaluated for it: the reference
         // is a LOWER bound of ln rho under the new parameters, from the carried upper bound of its distance,
         // d' = Gamma d + delta.  No candidate against it: the row stays settled.
-        const bool by_bound = PREV && lock != nullptr && lock[n] == 1 && (fresh[0] | fresh[1] | fresh[2] | fresh[3]) == 0ull;
-        int kset = -1;
-        float d_set = 0.0f, thr_set = 0.0f;
+        by_bound = PREV && lock != nullptr && lock[n] == 1 && (fresh[0] | fresh[1] | fresh[2] | fresh[3]) == 0ull;
+        float thr_set = 0.0f;
         if (by_bound) {
             kset = lcomp[n];
             // the distance bound: from the lower bound the proof round has just made for the new parameters (components
@@ -407,66 +470,161 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                 const double lbn = u[(int64_t)kset * npad + n];
                 dn = f32_up(dist_of(sc[kset], lbn) * (1.0 + 1e-9));            // (-inf: +inf, every component a candidate)
             } else {
-                dn = fmaf(sq[kset].x, dlock[n], sp[kset].y) * (1.0f + 2.4e-7f);
+                dn = fmaf(sq[kset].x, dlock[n], s_delta[kset]) * (1.0f + 2.4e-7f);
             }
             const float lb = sq[kset].y - dn * dn * 0.5000005f;
             d_set = dn;
             thr_set = (lb - fabsf(lb) * 2.4e-7f) - 69.5f;
         }
-        const bool over = !by_bound && !(thr > ninf);          // NaN / -inf: nothing to compare with
-        const float thr_f = by_bound ? thr_set : (over ? -__builtin_huge_valf() : f32_down(thr));   // over: every pair is a candidate
+        over = !by_bound && !(thr > ninf);          // NaN / -inf: nothing to compare with
+        thr_f = by_bound ? thr_set : (over ? -__builtin_huge_valf() : f32_down(thr));   // over: every pair is a candidate
         if (over) fresh[0] = fresh[1] = fresh[2] = fresh[3] = 0ull;
         rthr[n] = thr_f;                                       // (-inf: everything is evaluated in full)
-        unsigned long long nocand[4] = {fresh[0], fresh[1], fresh[2], fresh[3]};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) nocand[w] = fresh[w];
         if (by_bound) nocand[kset >> 6] |= 1ull << (kset & 63);
+    }
+    // ---- LAZY: which columns the tile has to open --------------------------------------------------------------------
+    float4 meta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), comp = meta;
+    bool col_open = false, col_forced = false, col_redo = false;
+    float col_bound = 0.0f;
+    if constexpr (LAZY) {
+        if (valid) {
+            for (int w = 0; w < W; ++w) {
+                unsigned long long m = nocand[w];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    s_force[64 * w + b] = 1;
+                }
+            }
+        }
+        float tmin = thr_f == thr_f ? thr_f : -__builtin_huge_valf();       // (invalid rows: +inf)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o));
+        if (lane == 0) s_thr[wave] = tmin;
+        __syncthreads();
+        const float tile_thr = fminf(fminf(s_thr[0], s_thr[1]), fminf(s_thr[2], s_thr[3]));
+        float skip = -__builtin_huge_valf();
+        if (tid < K) {
+            const int k = tid;
+            meta = tmeta_reset ? make_float4(__builtin_huge_valf(), 1.0f, 0.0f, step.w) : tmeta[(int64_t)blockIdx.x * K + k];
+            // the composition takes this pass's step in
+            // (products of two floats are exact in f64)
+            comp = make_float4(f32_down((double)meta.y * (double)step.x),
+                               f32_up(((double)step.x * (double)meta.z + (double)step.y) * (1.0 + 1e-15)), step.z, meta.w);
+            col_bound = sweep_carry(meta.x, comp);
+            col_forced = s_force[k] != 0;
+            const bool unknown = !(meta.x < __builtin_huge_valf());
+            col_open = col_forced || unknown || !(col_bound < tile_thr);
+            col_redo = col_open && unknown && !col_forced;
+            sp[k] = comp;
+            if (!col_open) {
+                tmeta[(int64_t)blockIdx.x * K + k] = make_float4(meta.x, comp.x, comp.y, meta.w);
+                skip = col_bound;
+            }
+        }
+        const unsigned long long ob = __builtin_amdgcn_ballot_w64(col_open), rb = __builtin_amdgcn_ballot_w64(col_redo);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) skip = fmaxf(skip, __shfl_xor(skip, o));
+        if (lane == 0) {
+            s_open[wave] = ob;
+            s_redo[wave] = rb;
+            s_skip[wave] = skip;
+            if (col_ctr && ob) atomicAdd(col_ctr, (unsigned long long)__builtin_popcountll(ob));
+        }
+        __syncthreads();
+    }
+    // ---- the sweep over the row's bounds ---------------------------------------------------------------------------------
+    unsigned long long anyw[4] = {0ull, 0ull, 0ull, 0ull};       // LAZY: columns with a candidate among the wave's rows
+    float mine[4] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    bool stays = false;
+    {
         unsigned s[kRecSlots + 1];
 #pragma unroll
         for (int j = 0; j <= kRecSlots; ++j) s[j] = 0xFFFFFFFFu;
         float restmax = -__builtin_huge_valf();                // largest bound among the pairs that are not listed
         // uniform base + 32-bit row offset: one address register for the whole loop
         const bool near = npad < (int64_t(1) << 29);
-        const unsigned off = (unsigned)(near ? n : 0) * 4u;
-        auto pair = [&](int k, int bit, float old, unsigned long long fw, unsigned long long nw, unsigned long long& mw) {
-            const float4 p = sp[k];
-            const float qd = p.w - old;
-            const float sq = __builtin_amdgcn_sqrtf(qd + qd);              // NaN for qd < 0 or NaN: no information
-            const float t = fmaxf(fmaf(p.x, sq, -p.y), 0.0f);              // NaN -> 0: the trivial bound c'
-            const float w = fminf(t * t * 0.4999995f, 3.0e38f);
-            const float r = p.z - w;
-            const float ubn = fmaf(fabsf(r), 2.4e-7f, r);
-            char* base = (char*)(ub + (int64_t)k * npad + (near ? 0 : n));
-            *(float*)(base + off) = ubn;
+        const unsigned off = (unsigned)(near ? (valid ? n : 0) : 0) * 4u;
+        const int64_t nn = valid ? n : 0;
+        unsigned long long red_w = 0ull;
+        float mine_w = -__builtin_huge_valf();
+        auto pair = [&](int k, int bit, float old, unsigned long long fw, unsigned long long nw, unsigned long long& mw,
+                        unsigned long long& aw) {
+            const float ubn = sweep_carry(old, sp[k]);
+            char* base = (char*)(ub + (int64_t)k * npad + (near ? 0 : nn));
+            if (valid) *(float*)(base + off) = ubn;
             const unsigned long long b1 = 1ull << bit;
             const bool isf = (fw & b1) != 0ull;                            // (its exact value is written below)
-            const bool cand = !(ubn < thr_f) && (nw & b1) == 0ull;
+            const bool cand = valid && !(ubn < thr_f) && (nw & b1) == 0ull;
             mw |= cand ? b1 : 0ull;
             restmax = fmaxf(restmax, (cand || isf) ? -__builtin_huge_valf() : ubn);
-            sweep_chain(s, isf ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
+            sweep_chain(s, (isf || !valid) ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
+            if constexpr (LAZY) {
+                aw |= __builtin_amdgcn_ballot_w64(cand) != 0ull ? b1 : 0ull;
+                if (red_w & b1) {                                              // (uniform)
+                    const float m = wave_max_f32(valid ? ubn : -__builtin_huge_valf());
+                    mine_w = lane == bit ? m : mine_w;
+                }
+            }
         };
         auto old_of = [&](int k) {
-            const char* base = (const char*)(ub + (int64_t)k * npad + (near ? 0 : n));
+            const char* base = (const char*)(ub + (int64_t)k * npad + (near ? 0 : nn));
             return *(const float*)(base + off);
         };
         for (int w = 0; w < W; ++w) {
             const unsigned long long fw = w == 0 ? fresh[0] : (w == 1 ? fresh[1] : (w == 2 ? fresh[2] : fresh[3]));
             const unsigned long long nw = w == 0 ? nocand[0] : (w == 1 ? nocand[1] : (w == 2 ? nocand[2] : nocand[3]));
-            unsigned long long mw = 0ull;
-            const int kend = K < 64 * w + 64 ? K : 64 * w + 64;
-            int k0 = 64 * w;
-            for (; k0 + 8 <= kend; k0 += 8) {
-                float pre[8];                                  // eight loads in flight per thread
+            unsigned long long mw = 0ull, aw = 0ull;
+            if constexpr (LAZY) {
+                const unsigned long long o0 = s_open[w];
+                unsigned long long ow = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(o0 >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)o0);
+                const unsigned long long r0 = s_redo[w];
+                red_w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(r0 >> 32)) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
+                mine_w = -__builtin_huge_valf();
+                while (ow) {
+                    int kq[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) pre[q] = old_of(k0 + q);
+                    for (int q = 0; q < 8; ++q) {
+                        kq[q] = ow ? __builtin_ctzll(ow) : -1;
+                        ow &= ow - 1;                                       // (0 stays 0)
+                    }
+                    float pre[8];                                           // up to eight loads in flight per thread
 #pragma unroll
-                for (int q = 0; q < 8; ++q) pair(k0 + q, k0 + q - 64 * w, pre[q], fw, nw, mw);
+                    for (int q = 0; q < 8; ++q)
+                        if (kq[q] >= 0) pre[q] = old_of(64 * w + kq[q]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (kq[q] >= 0) pair(64 * w + kq[q], kq[q], pre[q], fw, nw, mw, aw);
+                }
+                if (w == 0) mine[0] = mine_w;
+                else if (w == 1) mine[1] = mine_w;
+                else if (w == 2) mine[2] = mine_w;
+                else mine[3] = mine_w;
+            } else {
+                if (valid) {
+                    const int kend = K < 64 * w + 64 ? K : 64 * w + 64;
+                    int k0 = 64 * w;
+                    for (; k0 + 8 <= kend; k0 += 8) {
+                        float pre[8];                                  // eight loads in flight per thread
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) pre[q] = old_of(k0 + q);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) pair(k0 + q, k0 + q - 64 * w, pre[q], fw, nw, mw, aw);
+                    }
+                    for (; k0 < kend; ++k0) pair(k0, k0 - 64 * w, old_of(k0), fw, nw, mw, aw);
+                }
             }
-            for (; k0 < kend; ++k0) pair(k0, k0 - 64 * w, old_of(k0), fw, nw, mw);
-            if (w == 0) mk[0] = mw;
-            else if (w == 1) mk[1] = mw;
-            else if (w == 2) mk[2] = mw;
-            else mk[3] = mw;
+            if (w == 0) { mk[0] = mw; anyw[0] = aw; }
+            else if (w == 1) { mk[1] = mw; anyw[1] = aw; }
+            else if (w == 2) { mk[2] = mw; anyw[2] = aw; }
+            else { mk[3] = mw; anyw[3] = aw; }
         }
-        bool stays = false, proof_row = false, proof_cand = false;
+        if (valid) {
+        bool proof_row = false, proof_cand = false;
         if (pmask != nullptr && proof_all && !by_bound && !over && (mk[0] | mk[1] | mk[2] | mk[3]) != 0ull) {
             // a row with an exact reference: its candidates (carried bounds that no longer clear the threshold) get fresh
             // int8 bounds first; only those that still do not clear it are evaluated exactly (rec_proof_decide_kernel)
@@ -551,19 +709,26 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             const int k9 = (int)(s[kRecSlots] & 0xFFu);
             rest = ((mk[k9 >> 6] >> (k9 & 63)) & 1ull) ? restmax : sweep_key_bound(s[kRecSlots]);
         }
+        if constexpr (LAZY)      // (the columns the tile left closed: every pair in them lies below this)
+            rest = fmaxf(rest, fmaxf(fmaxf(s_skip[0], s_skip[1]), fmaxf(s_skip[2], s_skip[3])));
+        // (LAZY: a row that stays settled needs no record - nothing reads it before the next pass that rebuilds it, and the
+        // read-outs answer for such rows from the log-normaliser alone, rec_readout_kernel)
+        if (!(LAZY && stays)) {
 #pragma unroll
-        for (int j = 0; j < kRecSlots; ++j) {
-            rec.k[(int64_t)j * rec.npad + n] = ks[j];
-            rec.d[(int64_t)j * rec.npad + n] = ds[j];
+            for (int j = 0; j < kRecSlots; ++j) {
+                rec.k[(int64_t)j * rec.npad + n] = ks[j];
+                rec.d[(int64_t)j * rec.npad + n] = ds[j];
+            }
+            rec.B[n] = rest;
+            rec.exact[n] = (unsigned char)(over ? 0 : ex);
+            rec.sel[n] = (unsigned char)(over ? 0 : sel);
         }
-        rec.B[n] = rest;
-        rec.exact[n] = (unsigned char)(over ? 0 : ex);
-        rec.sel[n] = (unsigned char)(over ? 0 : sel);
         rec.flags[n] = (unsigned char)(stays ? 4 : (proof_row ? 8 : (over ? 1 : ((listed > in_slots ? 2 : 0) | (proof_cand ? 16 : 0)))));
         over_i = over ? 1 : 0;
         for (int w = 0; w < W; ++w) {
             masks[(int64_t)w * npad + n] = mk[w];
             if (pmask) pmask[(int64_t)w * npad + n] = pm[w];
+        }
         }
     }
     for (int w = 0; w < W; ++w) {
@@ -575,11 +740,26 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         listed += __shfl_xor(listed, o);
         over_i += __shfl_xor(over_i, o);
     }
-    if ((tid & 63) == 0) {
+    if (lane == 0) {
         wsum[0][wave] = listed;
         wsum[1][wave] = over_i;
     }
+    if constexpr (LAZY) {
+        if (lane == 0)
+            for (int w = 0; w < 4; ++w) s_any[wave][w] = anyw[w];
+        for (int w = 0; w < W; ++w) s_red[wave][64 * w + lane] = w == 0 ? mine[0] : (w == 1 ? mine[1] : (w == 2 ? mine[2] : mine[3]));
+    }
     __syncthreads();
+    if constexpr (LAZY) {
+        if (tid < K && col_open) {
+            const int k = tid, w = k >> 6;
+            const bool any = (((s_any[0][w] | s_any[1][w] | s_any[2][w] | s_any[3][w]) >> (k & 63)) & 1ull) != 0ull;
+            float tub = col_bound;                         // nothing replaced: the carry of the largest entry is the largest
+            if (col_redo) tub = fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]));
+            if (col_forced || any) tub = __builtin_huge_valf();
+            tmeta[(int64_t)blockIdx.x * K + k] = make_float4(tub, 1.0f, 0.0f, sq[k].y);
+        }
+    }
     for (int k = tid; k < K; k += kSelRows) {
         blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
         if (pmask) pblk[(int64_t)k * gridDim.x + blockIdx.x] = pcnt[0][k] + pcnt[1][k] + pcnt[2][k] + pcnt[3][k];
@@ -1260,8 +1440,10 @@ __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __re
         out[e] = exact ? exp(lnrho[(int64_t)k * npad + n] - lse[n]) : 0.0;
         return;
     }
-    double ub = (double)rec.B[n];
-    if (!exact) {
+    // (a row the lazy sweep left settled has no record of this pass: the cap below answers for it)
+    const bool no_record = rec.flags[n] == 4;
+    double ub = no_record ? __builtin_huge_val() : (double)rec.B[n];
+    if (!exact && !no_record) {
         const unsigned live = rec.exact[n];
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {

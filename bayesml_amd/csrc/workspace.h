@@ -11,6 +11,7 @@ struct gmmvb_hmm_state;      // HMM forward-backward buffers (hmm_capi.hip), all
 struct gmmvb_pass_counters {
     bool valid = false;
     double act = 0.0, eval = 0.0, over = 0.0, settled = 0.0, listed = 0.0, accum = 0.0, proof = 0.0, exits = 0.0, moved = 0.0;
+    double cols = -1.0;          // (tile, component) columns of the bound array the last sweep went through; -1: not a lazy sweep
     double rows = 0.0;           // rows the counters were taken over
     double ranks = 1.0;          // ranks they were summed over
     int mode = 0;                // kind of the pass: 0 dense, 1 bound pass, 2 carried records, 3 sweep
@@ -124,8 +125,10 @@ struct gmmvb_workspace {
     unsigned char* lcomp = nullptr;    // [npad] cached rows: the component whose cache holds the row (K <= 256)
     float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
     float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 100 ln 2)
-    unsigned long long* exit_ctr = nullptr;    // [1] device: candidate pairs of the pass that took the gather's early way out
-    unsigned long long* exit_host = nullptr;   // [1] pinned mirror (copied with the other counters)
+    unsigned long long* exit_ctr = nullptr;    // [2] device: candidate pairs of the pass that took the gather's early way out;
+                                               //     (tile, component) columns the lazy sweep opened
+    unsigned long long* exit_host = nullptr;   // [2] pinned mirror (copied with the other counters)
+    bool pend_lazy = false;                    // the pass behind the pending counters was a lazy sweep
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
     int* dblk = nullptr;               // [K][blocks] their block counts
     unsigned long long* mmask = nullptr;   // [ceil(K / 64)][npad] the M-step's lists: active pairs of the rows not in the cache
@@ -156,7 +159,10 @@ struct gmmvb_workspace {
     int64_t xq_rows = 0, xq_ldx = 0;
     int pivot_gen = 0, xq_gen = -1, img_gen = -2;
     bool opt_proof = true;             // env GMMVB_PROOF=0: settled rows with candidates go straight to the f64 gather
+    bool opt_lazy = true;              // env GMMVB_SWEEP_LAZY=0: every sweep goes through all K bounds of every row
     bool opt_proof_all = false;        // env GMMVB_PROOF=all: the candidates of every other row go through the proof round too
+    float4* tmeta = nullptr;           // [blocks][K] the lazy sweep's state per tile and component (records.h)
+    bool tmeta_valid = false;          // it describes the bound array as it is (only sweeps have written to it since)
     double* ppart = nullptr;           // [blocks] pairs of the proof round per selection block
     // rows grouped by dominant component (aux_kernels.h): internal row i = the caller's row perm[i]
     void* xp = nullptr;        // [max_rows][D] x in internal row order (storage dtype), allocated with the lists

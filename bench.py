@@ -504,7 +504,8 @@ def main():
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars],
                          "accumulated_components_per_sample": [round(wk["accumulated"] / n_local, 2) for wk in works],
                          "settled_rows_per_sample": [round(wk["settled_rows"] / n_local, 3) for wk in works],
-                         "proof_pairs_per_sample": [round(wk.get("proof_pairs", 0.0) / n_local, 3) for wk in works]},
+                         "proof_pairs_per_sample": [round(wk.get("proof_pairs", 0.0) / n_local, 3) for wk in works],
+                         "sweep_share_of_bound_array": [round(wk.get("sweep_share", -1.0), 3) for wk in works]},
         }
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -301,7 +301,9 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
  * the row's relevance threshold (they cost 10 of the 36 tile pairs at D = 128), out[5] pairs of the proof round: settled
  * rows whose carried bounds left candidates get two-sided bounds of their component and of the candidates from three int8
  * digits (about a fifth of an exact evaluation's cost) - rows that are proven to keep a single active component are not
- * evaluated at all (their responsibility is 1.0 to the last bit whatever the value); out[6], out[7] reserved (0). */
+ * evaluated at all (their responsibility is 1.0 to the last bit whatever the value); out[6] after a sweep: the (tile of
+ * 256 rows, component) columns of the per-pair bound array it had to go through, of ceil(n_rows / 256) * K (-1: the pass
+ * was no sweep, or GMMVB_SWEEP_LAZY=0); out[7] reserved (0). */
 int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[8], host*/);
 
 #ifdef __cplusplus

@@ -22,7 +22,7 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_MARGIN",
-            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT")
+            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT", "GMMVB_SWEEP_LAZY")
 VARIANTS = {
     "default": {},
     # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, without
@@ -39,6 +39,9 @@ VARIANTS = {
     "nosettle": {"GMMVB_SETTLE_MARGIN": "-1"},
     "nocache": {"GMMVB_MSTEP_CACHE": "0"},
     "noexit": {"GMMVB_GATHER_EXIT": "0"},
+    # every sweep carries all K bounds of every row (default: per tile of 256 rows only the components within reach)
+    "nolazy": {"GMMVB_SWEEP_LAZY": "0"},
+    "force_nolazy": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SWEEP_LAZY": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
     "force_nocarry": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_CARRY_OFF": "1"},
     "dense": {"GMMVB_ESTEP_PRUNE": "0", "GMMVB_MSTEP_SPARSE": "0"},
@@ -123,7 +126,8 @@ def test_small_fixture_forced_sparse_matches_reference(variant):
 LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n140000_f32.npz", "force_nocarry"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "noproof"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "nosettle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
-         ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"), ("gmm_f3_k64_d128_n140000_f32.npz", "nolazy"),
+         ("gmm_f3_k256_d64_n36000_f32.npz", "nolazy"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
          ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "dense")]
@@ -159,7 +163,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if "overlap" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit"):
+    if "overlap" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -199,7 +203,7 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_all"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_all", "force_nolazy"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
@@ -249,7 +253,7 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         checked += 1
     assert checked >= 3, eng.pass_counts()
     assert cached_seen > 0.1 * N, cached_seen       # single-component rows the M-step did not accumulate again
-    if variant in ("force", "force_settle"):     # rows that were not evaluated at all: read out exactly all the same -
+    if variant in ("force", "force_settle", "force_nolazy"):     # rows that were not evaluated at all: read out exactly all the same -
         assert settled_seen > 0.1 * N, settled_seen          # many of them on the strength of the int8 proof round
         assert proof_seen > 0.01 * N, proof_seen
     if variant == "force_noproof":
