@@ -84,13 +84,15 @@ class EngineLimitError(ValueError):
 
 
 MAX_MFMA_DEGREE = 128     # up to here the data pass runs on the MFMA kernels; beyond, on the plain f64 kernels of csrc/generic.h
-MAX_HMM_CLASSES = 64      # hmmvb_enable: K <= 64
+MAX_HMM_FAST_CLASSES = 64 # up to here the HMM recursions run chunk-parallel on MFMA; beyond, sequentially (csrc/hmm_generic.h)
+MAX_HMM_CLASSES = 65535   # hmmvb_enable: 16-bit back-pointers
 
 
 def check_limits(c_degree: int, c_num_classes: int = 1, hmm: bool = False):
     """Raised at model construction, so that an unsupported shape does not surface as an EngineError from inside
     update_posterior after the sample matrix has already been copied to the GPU.  (c_degree has no limit: above 128 the
-    engine switches to its generic f64 kernels - same results, far slower.)"""
+    engine switches to its generic f64 kernels, and an HMM with more than 64 states to sequential recursions - same
+    results, far slower.)"""
     if hmm and c_num_classes > MAX_HMM_CLASSES:
         raise EngineLimitError(f"bayesml_amd.hiddenmarkovnormal supports c_num_classes <= {MAX_HMM_CLASSES} in this "
                                f"version (got {c_num_classes}); bayesml itself has no such limit")

@@ -6,6 +6,7 @@
 #include <new>
 
 #include "hmm.h"
+#include "hmm_generic.h"
 
 #include <cstdlib>
 
@@ -30,6 +31,10 @@ struct gmmvb_hmm_state {
     double* lnc_partial = nullptr;   // [kLncBlocks]
     unsigned char* phi = nullptr; // [npad][Kp] Viterbi back-pointers (allocated on first use by hmmvb_enable)
     int* last_state = nullptr;
+    // more than 64 states: the sequential kernels of hmm_generic.h
+    bool generic = false;
+    double* a_t = nullptr;        // [K][K] transpose of A~
+    unsigned short* phi16 = nullptr;   // [npad][K] back-pointers, natural order
     int64_t bytes = 0;
 };
 
@@ -38,10 +43,11 @@ void hmm_state_destroy(gmmvb_hmm_state* h) {
     if (!h) return;
     double* bufs[] = {h->rho_tm, h->alpha_tm, h->gamma_tm, h->w_tm, h->gamma_cm, h->mx,
                       h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs, h->lnc_partial,
-                      h->qprod,  h->fstart_s, h->bend_s};
+                      h->qprod,  h->fstart_s, h->bend_s, h->a_t};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (h->phi) (void)hipFree(h->phi);
+    if (h->phi16) (void)hipFree(h->phi16);
     if (h->last_state) (void)hipFree(h->last_state);
     delete h;
 }
@@ -111,6 +117,44 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     return hipGetLastError();
 }
 
+// more than 64 states: one workgroup walks the sequence (hmm_generic.h); prep / finish / gamma transpose as above
+template <typename Kern>
+hipError_t seq_lds(Kern kern, size_t bytes) {
+    return bytes > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)bytes)
+                             : hipSuccess;
+}
+
+hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
+                       double* out, hipStream_t st) {
+    const int K = h->K, Kp = h->Kp;
+    const HmmSeqShape sh = hmm_seq_shape(K);
+    hipError_t e = seq_lds(hmm_seq_forward_kernel, sh.lds_bytes);
+    if (e == hipSuccess) e = seq_lds(hmm_seq_backward_kernel, sh.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hmm_prep_generic_kernel, dim3((unsigned)((T + 63) / 64)), dim3(256), 0, st, ws->lnrho, ws->npad, T, K, Kp,
+                       h->rho_tm, h->mx);
+    hipLaunchKernelGGL(hmm_transpose_kernel, dim3((unsigned)((K * K + 255) / 256)), dim3(256), 0, st, a_tilde, K, h->a_t);
+    hipLaunchKernelGGL(hmm_seq_forward_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, pi_tilde, a_tilde, K, Kp,
+                       T, sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+    hipLaunchKernelGGL(hmm_seq_backward_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, h->a_t, K, Kp, T, sh.P,
+                       sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+    int64_t n_slabs = 0;
+    if (T > 1) {
+        const int64_t steps = (T - 1 + h->xi_waves - 1) / h->xi_waves;
+        n_slabs = (T - 1 + steps - 1) / steps;
+        hipLaunchKernelGGL(hmm_xi_generic_kernel, dim3((unsigned)n_slabs, (unsigned)((Kp / 16) * (Kp / 16))), dim3(256), 0, st,
+                           h->alpha_tm, h->w_tm, Kp, T, steps, h->xi_slabs);
+    }
+    const int n_part = (int)std::min<int64_t>(kLncBlocks, (T + 255) / 256);
+    hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
+    hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
+                       h->lnc_partial, n_part, T, h->gamma_tm, out);
+    hipLaunchKernelGGL(hmm_gamma_to_cm_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0,
+                       st, h->gamma_tm, T, K, Kp, ws->npad, h->gamma_cm);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -120,15 +164,17 @@ int64_t hmmvb_out_len(int K) { return K < 1 ? -1 : (int64_t)K * K + 2 * (int64_t
 int hmmvb_enable(gmmvb_workspace* ws) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     if (ws->hmm) return GMMVB_OK;
-    if (ws->K > 64) return fail(GMMVB_EUNSUPPORTED, "HMM forward-backward supports K <= 64 in this version");
+    if (ws->K > 65535) return fail(GMMVB_EUNSUPPORTED, "HMM: at most 65535 states (16-bit back-pointers)");
     gmmvb_hmm_state* h = new (std::nothrow) gmmvb_hmm_state();
     if (!h) return fail(GMMVB_ENOMEM, "host allocation failed");
     h->K = ws->K;
     h->KT = (ws->K + 15) / 16;
     h->Kp = 16 * h->KT;
     h->npad = ws->npad;
-    h->max_chunks = ws->npad / 16 + 2;          // chunk_len >= 16
-    h->xi_waves = 4 * (int64_t)ws->num_cu;
+    h->generic = ws->K > 64;                    // (the chunk-parallel kernels hold K x K products in registers)
+    h->max_chunks = h->generic ? 1 : ws->npad / 16 + 2;          // chunk_len >= 16
+    h->xi_waves = h->generic ? std::max<int64_t>(16, std::min<int64_t>(4 * (int64_t)ws->num_cu, (int64_t(1) << 27) / ((int64_t)h->Kp * h->Kp)))
+                             : 4 * (int64_t)ws->num_cu;
     const int64_t tk = h->npad * h->Kp;
     struct { double** p; int64_t n; } bufs[] = {
         {&h->rho_tm, tk}, {&h->alpha_tm, tk}, {&h->gamma_tm, tk}, {&h->w_tm, tk},
@@ -137,8 +183,9 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, (h->xi_waves + 4) * h->Kp * h->Kp},
         {&h->lnc_partial, kLncBlocks},
         {&h->qprod, (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp}, {&h->fstart_s, (h->max_chunks / kHmmSuper + 2) * h->Kp},
-        {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}};
+        {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0}};
     for (auto& b : bufs) {
+        if (b.n == 0) continue;
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
         if (e != hipSuccess) {
             hmm_state_destroy(h);
@@ -146,13 +193,14 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         }
         h->bytes += b.n * (int64_t)sizeof(double);
     }
-    hipError_t e2 = hipMalloc((void**)&h->phi, (size_t)(h->npad * h->Kp));
+    hipError_t e2 = h->generic ? hipMalloc((void**)&h->phi16, (size_t)(h->npad * ws->K) * sizeof(unsigned short))
+                               : hipMalloc((void**)&h->phi, (size_t)(h->npad * h->Kp));
     if (e2 == hipSuccess) e2 = hipMalloc((void**)&h->last_state, sizeof(int));
     if (e2 != hipSuccess) {
         hmm_state_destroy(h);
         return fail(GMMVB_ENOMEM, "hipMalloc (Viterbi buffers)", e2);
     }
-    h->bytes += h->npad * h->Kp + 4;
+    h->bytes += (h->generic ? 2 * h->npad * ws->K : h->npad * h->Kp) + 4;
     ws->hmm = h;
     ws->bytes += h->bytes;
     return GMMVB_OK;
@@ -166,6 +214,17 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     gmmvb_hmm_state* h = ws->hmm;
     hipStream_t st = (hipStream_t)stream;
+    if (h->generic) {
+        const HmmSeqShape sh = hmm_seq_shape(h->K);
+        hipError_t eg = seq_lds(hmm_seq_viterbi_kernel, sh.lds_bytes);
+        if (eg != hipSuccess) return fail(GMMVB_EHIP, "viterbi (LDS size)", eg);
+        hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
+                           ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state);
+        hipLaunchKernelGGL(hmm_seq_backtrack_kernel, dim3(1), dim3(64), 0, st, h->phi16, h->K, n_rows, h->last_state, z_dev);
+        eg = hipGetLastError();
+        if (eg != hipSuccess) return fail(GMMVB_EHIP, "viterbi launch (generic)", eg);
+        return GMMVB_OK;
+    }
     // Long sequences: chunked max-plus scan (hmm.h, hmm_vit_*); its scratch is the forward-backward pass's (chunk products,
     // boundary vectors), which nothing reads once that pass has returned.  Short ones: the single sequential wave.
     const int64_t L = n_rows >= 65536 ? 256 : (n_rows >= 512 ? 32 : 0);
@@ -224,6 +283,12 @@ int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
+    if (ws->hmm->generic) {
+        e = run_generic(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "HMM forward-backward launch (generic)", e);
+        ws->e_state = 3;
+        return GMMVB_OK;
+    }
     switch (ws->hmm->KT) {
         case 1: e = run<1>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
         case 2: e = run<2>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;

@@ -89,10 +89,13 @@ def test_forward_backward_matches_reference(name):
 @pytest.mark.parametrize("K,D,T,dtype", [(3, 2, 1, np.float64), (5, 3, 2, np.float64), (7, 4, 17, np.float32),
                                          (16, 8, 1000, np.float64), (20, 5, 3001, np.float32),
                                          (33, 6, 777, np.float64), (64, 4, 5000, np.float32), (2, 1, 40000, np.float64),
-                                         (8, 4, 300001, np.float32), (33, 3, 270000, np.float64)])
+                                         (8, 4, 300001, np.float32), (33, 3, 270000, np.float64),
+                                         (65, 3, 1, np.float64), (70, 3, 900, np.float64), (130, 2, 400, np.float32),
+                                         (150, 2, 300, np.float64)])
 def test_ragged_shapes_against_oracle(K, D, T, dtype):
     """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths - and, past 2^18 steps, the
-    two-level boundary pass (chunks of 256 steps, super-chunk products); random posterior."""
+    two-level boundary pass (chunks of 256 steps, super-chunk products); random posterior.  More than 64 states: the
+    sequential kernels of csrc/hmm_generic.h (transition matrix in LDS up to K = 128, in L2 beyond)."""
     rng = np.random.default_rng(100 * K + D)
     x, _ = orc.synth_hmm(max(2, K // 2), D, T, dtype, seed=K + T, stay=0.8)
     p = orc.HmmPrior.default(K, D)
@@ -182,7 +185,8 @@ def test_full_driver_matches_reference(name):
 
 
 # T < 512: the single sequential wave; 512 <= T < 65536: the chunked max-plus scan with chunks of 32 steps; beyond: 256
-@pytest.mark.parametrize("K,D,T", [(5, 3, 1), (12, 4, 511), (12, 4, 700), (40, 2, 3000), (64, 2, 1537), (32, 16, 200001)])
+@pytest.mark.parametrize("K,D,T", [(5, 3, 1), (12, 4, 511), (12, 4, 700), (40, 2, 3000), (64, 2, 1537), (32, 16, 200001),
+                                   (66, 2, 1), (72, 2, 800), (140, 2, 500)])
 def test_viterbi_kernel_against_oracle(K, D, T):
     from bayesml_amd import hiddenmarkovnormal as hmm
     x, _ = orc.synth_hmm(max(2, K // 2), D, T, np.float64, seed=7 * K + T)
