@@ -143,6 +143,16 @@ def main():
                 "frac": alg * T / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_time_step": alg,
                 "estimated_swept_bytes_per_time_step": swept, "estimated_swept_GBps": swept * T / (ms * 1e-3) / 1e9,
                 "hbm_roofline_time_steps_per_s": 8e12 / alg, "traffic": None}
+    try:            # measured HBM bytes per iteration (tools/hmm_pmc_total.py), only if made for this very workload
+        with open(os.path.join(ROOT, "profiles", "hmm_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        if pm.get("config") == f"K{K} D{D} T{T}":
+            roofline["traffic"] = pm["bytes_per_iteration"]
+            roofline["traffic_GBps"] = pm["bytes_per_iteration"] / (ms * 1e-3) / 1e9
+            roofline["traffic_frac_of_peak"] = roofline["traffic_GBps"] / 8000.0
+            roofline["traffic_source"] = "profiles/hmm_pmc_traffic.json: " + pm["note"]
+    except (OSError, ValueError, KeyError):
+        pass
     print(json.dumps({
         "metric": "HMM-VB time steps/sec at K=32,D=16,T=1e7 (BASELINE.json configs[4])", "value": T * args.steps / el,
         "unit": "time steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

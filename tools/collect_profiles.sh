@@ -7,8 +7,10 @@ cd "$(dirname "$0")/.."
 for f in bench_line.json bench_line_w5s20.json bench_line_c2.json bench_line_c4.json bench_line_profiled.json \
          bench_line_force_dist_native.json bench_line_force_dist_torch.json bench_kernel_summary.md bench_kernel_stats.csv \
          pmc_summary.md small.json full_run.json hmm_bench_line.json hmm_kernel_summary.md gpu_tests.txt \
-         bench_line_c4_strong1.json bench_proof.json hmm_pmc_summary.md; do
+         bench_line_c4_strong1.json bench_line_c4_w5s20.json bench_proof.json hmm_pmc_summary.md hmm_k128_line.json; do
     [ -f gpurun_out/${tag}_$f ] && cp gpurun_out/${tag}_$f profiles/${rnd}_$f
 done
 [ -f gpurun_out/${tag}_pmc_traffic.json ] && cp gpurun_out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
+[ -f gpurun_out/${tag}_hmm_pmc_traffic.json ] && cp gpurun_out/${tag}_hmm_pmc_traffic.json profiles/hmm_pmc_traffic.json
+[ -f gpurun_out/${tag}_gpu_tests.log ] && tail -8 gpurun_out/${tag}_gpu_tests.log > profiles/${rnd}_gpu_tests.txt
 ls -la profiles/${rnd}_* profiles/pmc_traffic.json

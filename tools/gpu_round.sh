@@ -1,6 +1,7 @@
 #!/bin/bash
 # One gpurun call: tests, bench legs, rocprofv3 kernel trace and PMC passes.  usage: tools/gpu_round.sh <tag> <stage>...
-# stages: tests | newtests | bench | trace | pmc | dense | c4 | hmm | full
+# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench
+# (pmc / hmmpmc first: the bench stages quote the traffic files they write)
 # Outputs under gpurun_out/<tag>_*; copy the summaries worth keeping into profiles/.
 set -u
 TAG=$1; shift
@@ -22,6 +23,7 @@ for stage in "$@"; do
     pmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/${TAG}_pmc_$c
            (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c.err); done
          python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE --config "K64 D128 N10000000 f32" --json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.md 2> $OUT/${TAG}_pmc.err; head -60 $OUT/${TAG}_pmc_summary.md
+         [ -s $OUT/${TAG}_pmc_traffic.json ] && cp $OUT/${TAG}_pmc_traffic.json profiles/pmc_traffic.json                  # (later stages of this call quote it)
          find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*.csv" -size +20M -delete ;;
     hmm) timeout 900 python tools/bench_hmm.py > $OUT/${TAG}_hmm_bench_line.json 2> $OUT/${TAG}_hmm.err; tail -c 400 $OUT/${TAG}_hmm.err; head -c 800 $OUT/${TAG}_hmm_bench_line.json; echo ;;
     full) timeout 900 python tools/full_run.py > $OUT/${TAG}_full_run.json 2> $OUT/${TAG}_full.err; tail -c 400 $OUT/${TAG}_full.err; head -c 800 $OUT/${TAG}_full_run.json; echo ;;
@@ -29,6 +31,15 @@ for stage in "$@"; do
     dist) timeout 900 python bench.py --force-dist --no-cpu --no-legs --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_force_dist_torch.json 2> $OUT/${TAG}_dist_torch.err; head -c 400 $OUT/${TAG}_bench_line_force_dist_torch.json; echo
           timeout 900 python bench.py --force-dist --native-allreduce --no-cpu --no-legs --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_force_dist_native.json 2> $OUT/${TAG}_dist_native.err; head -c 400 $OUT/${TAG}_bench_line_force_dist_native.json; echo ;;
     hmmtrace) bash tools/trace_hmm.sh $TAG ;;
+    hmmpmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/${TAG}_hmm_pmc_$c
+           (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_hmm_pmc_$c -- python3 $GRAFT_REPO_ROOT/tools/bench_hmm.py --no-cpu > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_hmm_pmc_$c.err); done
+         python tools/hmm_pmc_total.py $OUT/${TAG}_hmm_pmc_FETCH_SIZE $OUT/${TAG}_hmm_pmc_WRITE_SIZE --config "K32 D16 T10000000" --json $OUT/${TAG}_hmm_pmc_traffic.json > $OUT/${TAG}_hmm_pmc_summary.md 2> $OUT/${TAG}_hmm_pmc.err; cat $OUT/${TAG}_hmm_pmc_summary.md
+         [ -s $OUT/${TAG}_hmm_pmc_traffic.json ] && cp $OUT/${TAG}_hmm_pmc_traffic.json profiles/hmm_pmc_traffic.json      # (later stages of this call quote it)
+         find $OUT/${TAG}_hmm_pmc_FETCH_SIZE $OUT/${TAG}_hmm_pmc_WRITE_SIZE -name "*.csv" -size +20M -delete ;;
+    c4w5) timeout 900 python bench.py --config c4 --no-cpu --no-legs --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_c4_w5s20.json 2> $OUT/${TAG}_c4w5.err; head -c 400 $OUT/${TAG}_bench_line_c4_w5s20.json; echo ;;
+    c4strong) timeout 1200 python bench.py --config c4 --scaling strong --gpus 1 --no-cpu --no-legs --steps 3 --warmup 1 > $OUT/${TAG}_bench_line_c4_strong1.json 2> $OUT/${TAG}_c4strong.err; tail -c 300 $OUT/${TAG}_c4strong.err; head -c 500 $OUT/${TAG}_bench_line_c4_strong1.json; echo ;;
+    proofbench) timeout 600 python tools/bench_proof.py > $OUT/${TAG}_bench_proof.json 2> $OUT/${TAG}_bench_proof.err; head -c 500 $OUT/${TAG}_bench_proof.json; echo ;;
+    hmmbig) timeout 900 python tools/bench_hmm.py --classes 128 --degree 8 --rows 200000 --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_hmm_k128_line.json 2> $OUT/${TAG}_hmmbig.err; head -c 300 $OUT/${TAG}_hmm_k128_line.json; echo ;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
     *) echo "unknown stage $stage" ;;
   esac
