@@ -1,5 +1,6 @@
 // Instantiations of the int8-digit E-step for T32 = ceil(D/32) in 1..4, x in {f32, f64}: the 6-digit E-step and the
 // 3-digit bound pass of the pruned E-step.
+#include <cstdlib>
 #include "estep_i8.h"
 #include "launch.h"
 
@@ -89,6 +90,10 @@ hipError_t launch_estep_i8_proof(int D, int grid, hipStream_t st, const unsigned
                                  const unsigned char* img, const double* cvec, int K, const int* lists, int64_t cap,
                                  const int* counts, const int* plan, float* ub, double* lb, int64_t npad) {
     if (K > 256) return hipErrorInvalidValue;
+    {   // EXPERIMENT: workgroups per CU
+        static const int mult = std::getenv("GMMVB_PROOF_GRID") ? std::atoi(std::getenv("GMMVB_PROOF_GRID")) : 1;
+        grid *= mult > 0 ? mult : 1;
+    }
 #define PC(T)                                                                                                              \
     case T:                                                                                                                \
         hipLaunchKernelGGL((estep_i8_proof<T>), dim3(grid), dim3(512), 0, st, xq, xqe, img, cvec, K, lists, cap, counts,   \

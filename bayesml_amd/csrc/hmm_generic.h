@@ -69,8 +69,10 @@ __device__ __forceinline__ void seq_matvec(const double* mat, int K, const doubl
     for (int j0 = 0; j0 < K; j0 += J) {
         const int j = j0 + jl;
         double acc = 0.0;
-        if (j < K)
+        if (j < K) {
+#pragma unroll 8
             for (int i = i0; i < i1; ++i) acc = fma(vec_lds[i], mat[(int64_t)i * K + j], acc);
+        }
         part_buf[part * J + jl] = acc;
         __syncthreads();
         if (tid < J && j0 + tid < K) {
@@ -139,11 +141,22 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_forward_kernel(const d
     }
     if (tid == 0) cprime[0] = s;
     __syncthreads();
+    // (the time-major arrays are read one step ahead for this thread's first two states: their latency then lies beside the
+    // matrix-vector product instead of in front of the step's dependent arithmetic)
+    const int k0 = tid, k1 = tid + kHmmSeqThreads;
+    const int p0 = hmm_pos(k0 < K ? k0 : 0), p1 = hmm_pos(k1 < K ? k1 : 0);
+    double r0 = (T > 1 && k0 < K) ? rho_tm[Kp + p0] : 0.0, r1 = (T > 1 && k1 < K) ? rho_tm[Kp + p1] : 0.0;
     for (int64_t t = 1; t < T; ++t) {
+        const double c0 = r0, c1 = r1;
+        if (t + 1 < T) {
+            if (k0 < K) r0 = rho_tm[(t + 1) * Kp + p0];
+            if (k1 < K) r1 = rho_tm[(t + 1) * Kp + p1];
+        }
         seq_matvec(mat, K, va, P, J, part_buf, vb);
         double part = 0.0;
         for (int k = tid; k < K; k += kHmmSeqThreads) {
-            const double nw = vb[k] * rho_tm[t * Kp + hmm_pos(k)];
+            const double rr = k == k0 ? c0 : (k == k1 ? c1 : rho_tm[t * Kp + hmm_pos(k)]);
+            const double nw = vb[k] * rr;
             vb[k] = nw;
             part += nw;
         }
@@ -184,18 +197,36 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_backward_kernel(const 
     }
     for (int k = tid; k < K; k += kHmmSeqThreads) be[k] = 1.0 / K;
     __syncthreads();
+    const int k0 = tid, k1 = tid + kHmmSeqThreads;
+    const int p0 = hmm_pos(k0 < K ? k0 : 0), p1 = hmm_pos(k1 < K ? k1 : 0);
+    double a0 = 0.0, a1 = 0.0, r0 = 0.0, r1 = 0.0, cpn = 1.0;         // alpha_t, rho'_t, c'_t one step ahead
+    if (T > 1) {
+        if (k0 < K) { a0 = alpha_tm[(T - 1) * Kp + p0]; r0 = rho_tm[(T - 1) * Kp + p0]; }
+        if (k1 < K) { a1 = alpha_tm[(T - 1) * Kp + p1]; r1 = rho_tm[(T - 1) * Kp + p1]; }
+        cpn = cprime[T - 1];
+    }
     for (int64_t t = T - 1; t >= 1; --t) {
+        const double ca0 = a0, ca1 = a1, cr0 = r0, cr1 = r1, cp = cpn;
+        if (t - 1 >= 1) {
+            if (k0 < K) { a0 = alpha_tm[(t - 1) * Kp + p0]; r0 = rho_tm[(t - 1) * Kp + p0]; }
+            if (k1 < K) { a1 = alpha_tm[(t - 1) * Kp + p1]; r1 = rho_tm[(t - 1) * Kp + p1]; }
+            cpn = cprime[t - 1];
+        }
         double dot = 0.0;
-        for (int k = tid; k < K; k += kHmmSeqThreads) dot = fma(alpha_tm[t * Kp + hmm_pos(k)], be[k], dot);
+        for (int k = tid; k < K; k += kHmmSeqThreads) {
+            const double al = k == k0 ? ca0 : (k == k1 ? ca1 : alpha_tm[t * Kp + hmm_pos(k)]);
+            dot = fma(al, be[k], dot);
+        }
         dot = block_sum_1024(dot, red);
-        const double cp = cprime[t];
         const double ginv = dot > 0.0 ? 1.0 / dot : 0.0;
         const double winv = (dot > 0.0 && cp > 0.0) ? 1.0 / (dot * cp) : 0.0;
         for (int k = tid; k < K; k += kHmmSeqThreads) {
             const int p = hmm_pos(k);
-            const double yy = rho_tm[t * Kp + p] * be[k];
+            const double al = k == k0 ? ca0 : (k == k1 ? ca1 : alpha_tm[t * Kp + p]);
+            const double rr = k == k0 ? cr0 : (k == k1 ? cr1 : rho_tm[t * Kp + p]);
+            const double yy = rr * be[k];
             y[k] = yy;
-            gamma_tm[t * Kp + p] = alpha_tm[t * Kp + p] * be[k] * ginv;
+            gamma_tm[t * Kp + p] = al * be[k] * ginv;
             w_tm[t * Kp + p] = yy * winv;
         }
         for (int k = K + tid; k < Kp; k += kHmmSeqThreads) gamma_tm[t * Kp + hmm_pos(k)] = w_tm[t * Kp + hmm_pos(k)] = 0.0;

@@ -1,33 +1,37 @@
-// Per-row candidate records of the pruned E-step: what is carried from one E-step to the next.
+// Per-row candidate records and per-pair bounds of the pruned E-step.
 //
 // Once the responsibilities are sparse (a handful of the K components matter per sample), the E-step only has to
 // PROVE the other pairs irrelevant (r_nk < 2^-100, invisible in every f64 sum of the reference's _update_q_z /
-// _calc_n_x_bar_s, bayesml/gaussianmixture/_gaussianmixture.py:772-784, 725-732).  The proof object per row n is
-//   up to C = 8 slots (k_j, d_j):   d_j <= || U_k (x_n - m_k) ||  (a lower bound of the whitened distance; for slots
-//                                   evaluated exactly in the last pass it is the distance itself, flagged "exact")
-//   one rest bound B:               ln rho_nk <= B  for EVERY component k that has no slot
-// 55 bytes per row instead of the K x 8 bytes of a dense ln rho row.  A parameter update (m, U) -> (m', U') with
+// _calc_n_x_bar_s, bayesml/gaussianmixture/_gaussianmixture.py:772-784, 725-732).  What is carried from one E-step to
+// the next is one f32 upper bound of ln rho per PAIR (ub, [K][npad], every entry rounded up).  A parameter update
+// (m, U) -> (m', U') with
 //   gamma_k <= sigma_min(U'_k U_k^-1),  Gamma_k >= sigma_max(U'_k U_k^-1),  delta_k >= || U'_k (m'_k - m_k) ||
-// (gmmvb_set_drift) turns them into records for the new parameters without touching x:
-//   d'_j = (gamma_k d_j - delta_k)_+  and the upper bound  ub_j = c'_k - d'_j^2 / 2  of the new ln rho;
-//   for a component without a slot B gives  || U_k (x - m_k) || >= sqrt(2 (c_k - B)_+) =: r_k, hence
-//   B' = max over those k of  c'_k - (gamma_k r_k - delta_k)_+^2 / 2   (K square roots per row, no memory traffic:
-//   every component keeps its own gamma, delta and constants - an aggregate over the components would be ruined by
-//   a single empty component, whose c is 170 above the others at the benchmark's shape);
-//   and for an exact slot a LOWER bound of the new value  lb_j = c'_k - (Gamma_k d_j + delta_k)^2 / 2.
-// With thr = max_j lb_j - 100 ln 2 (a lower bound of the row's best value, minus the 2^-100 margin):
-//   ub_j < thr    -> pair (n, k_j) is irrelevant this pass, nothing to compute;
-//   ub_j >= thr   -> the pair is a candidate: listed, evaluated exactly (f64 MFMA, estep_gather_dev_f64);
-//   a component without a slot whose own bound c'_k - (gamma_k r_k - delta_k)_+^2 / 2 is >= thr is listed as well
-//                    ("refreshed row": its exact value may win it a slot; B' = max over the components NOT listed);
-//   no exact slot at all (no lower bound of the best value), or more than 24 such components:
-//                    ALL K pairs of the row are evaluated exactly ("overflow row"), its record rebuilt from them.
+// (gmmvb_set_drift) turns a bound u under the old parameters into one under the new without touching x:
+//   d = sqrt(2 (c_k - u)_+) <= || U_k (x - m_k) ||,   u' = c'_k - (gamma_k d - delta_k)_+^2 / 2      (rec_sweep_kernel),
+// and a distance d of an exactly known pair into a LOWER bound of its new value, c'_k - (Gamma_k d + delta_k)^2 / 2.
+// With thr = (the row's reference value) - 100 ln 2:
+//   u' < thr    -> the pair is irrelevant this pass, nothing to compute;
+//   u' >= thr   -> the pair is a candidate: listed, evaluated exactly (f64 MFMA, estep_gather_dev_f64) - or, for a settled
+//                  row, bounded from both sides on the int8 pipe first (estep_i8_proof, rec_proof_decide_kernel).
+// The row's reference value is its best exact value of this pass (pairs that were active in the previous pass are
+// evaluated before the sweep), or for a settled row a lower bound of its one component's ln rho.
+//
+// The per-row RECORD is the by-product every pass leaves for its own tail and for the read-outs (55 bytes per row):
+//   up to C = 8 slots (k_j, d_j):   d_j <= || U_k (x_n - m_k) ||  (for slots evaluated exactly in this pass the distance
+//                                   itself, flagged "exact"), the components of largest bound;
+//   one rest bound B:               ln rho_nk <= B  for EVERY component k that has no slot;
+//   flags:  1 overflow row (no usable reference, or more than 24 candidates without a slot: all K pairs are evaluated and
+//           the record rebuilt from them), 2 refreshed row (candidates without a slot were listed too), 4 settled row that
+//           stays settled (nothing evaluated; the lazy sweep writes no record for it), 8 settled row in the proof round,
+//           16 candidates of a row with an exact reference in the proof round (GMMVB_PROOF=all).
+// rec_build_kernel / rec_select_kernel make records from a whole row of bounds (bound pass), rec_sweep_kernel while it
+// carries the bounds, rec_finish_kernel refreshes them from the exact values of the pass.
 // Nothing here needs the host: lists, gather grid and statistics are sized on the device, so an E-step is a fixed
 // sequence of launches without a synchronisation.  The dense [K][npad] ln rho array stays the exchange buffer for
-// exact values (gather kernel -> rec_finish_kernel / M-step / read-outs); only listed entries of it are touched.
+// exact values (gather kernel -> rec_finish_kernel / M-step / read-outs) and for the proof kernel's lower bounds; only
+// listed entries of it are touched.
 //
-// Beside the records the sweep form of the pass (rec_sweep_kernel) keeps one f32 upper bound per PAIR (ub, [K][npad]),
-// and rec_finish_kernel keeps three more things per row (workspace.h):
+// rec_finish_kernel keeps three more things per row (workspace.h):
 //   rthr    the relevance threshold of the pass (best exact value - 100 ln 2): the candidate gather may stop a pair whose
 //           partial sum already lies below it, and a stored value below it is treated as a bound, never flagged exact;
 //   lock / lcomp   whether the row's addend sits in the M-step's cache of single-component rows (r = 1.0 exactly), and for
@@ -278,10 +282,8 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
     }
 }
 
-// The early-regime form of the carried E-step: while the components still move by several per cent per iteration the
-// single rest bound of a record is too coarse (most rows would have to be re-evaluated in full), but the f32 array ub
-// ([K][npad], every entry rounded UP) still holds, for EVERY pair, an upper bound of ln rho under the previous
-// parameters.  One sweep over it
+// The carried E-step: the f32 array ub ([K][npad], every entry rounded UP) holds, for EVERY pair, an upper bound of
+// ln rho under the previous parameters.  One sweep over it
 //   carries every entry over the update with its own component's (gamma, delta):  u' = c'_k - (gamma_k d - delta_k)_+^2 / 2,
 //     d = sqrt(2 (c_k - u)_+), and writes it back (the array stays valid for the next sweep);
 //   takes as the row's reference value v the largest of the pairs that have just been evaluated exactly under the NEW
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
 //              building for this round); `masks` holds them on entry;
 //       !PREV  the row's previous best component khat[n];
 //   lists every other pair with u' >= v - 100 ln 2, and builds the row's record (C slots + rest bound) on the way,
-// so that the pass continues exactly like one on records (gather -> rec_finish_kernel) and later passes can switch to them.
+// so that the pass continues like a bound pass (gather -> rec_finish_kernel).
 //
 // The kernel is bound by its instruction count (K pairs per row, 8 bytes of traffic each), so the per-pair work is
 // ~45 f32 / integer instructions and free of branches:
@@ -410,6 +412,28 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     __shared__ float s_skip[LAZY ? 4 : 1];                 // per wave (of columns): largest bound among the closed columns
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int W = (K + 63) / 64;
+    const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
+    const bool valid = n < n_rows;
+    // what the row needs from global memory and does not depend on the component constants is requested before the first
+    // barrier: the kernel is a chain of dependent loads per workgroup (0.67 ms of its 1.0 ms at the benchmark shape do not
+    // depend on how many columns it opens)
+    unsigned long long fresh[4] = {0ull, 0ull, 0ull, 0ull};      // pairs already exact under the new parameters
+    unsigned lk_pre = 0u;
+    int kset_pre = 0;
+    float dl_pre = 0.0f;
+    double lb_pre = 0.0;                                         // (own_fresh: the settled row's fresh lower bound, if it has one)
+    float4 meta_pre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (valid && PREV) {
+        for (int w = 0; w < W; ++w) fresh[w] = masks[(int64_t)w * npad + n];
+        if (lock != nullptr) {
+            lk_pre = lock[n];
+            kset_pre = lcomp[n];
+            dl_pre = dlock[n];
+            if (own_fresh && lk_pre == 1u) lb_pre = u[(int64_t)kset_pre * npad + n];
+        }
+    }
+    if constexpr (LAZY)
+        if (tid < K && !tmeta_reset) meta_pre = tmeta[(int64_t)blockIdx.x * K + tid];
     for (int k = lane; k < K; k += 64) wcnt[wave][k] = pcnt[wave][k] = 0;
     float4 step = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int k = tid; k < K; k += kSelRows) {
@@ -422,34 +446,31 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         sc[k] = c_new[k];
         if constexpr (LAZY) s_force[k] = 0;
     }
+    // ---- the row's reference value ------------------------------------------------------------------------------------
+    const double ninf = -__builtin_huge_val();
+    double vb = ninf;
+    if (valid && PREV) {
+        for (int w = 0; w < W; ++w) {
+            unsigned long long m = fresh[w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const double v = u[(int64_t)(64 * w + b) * npad + n];
+                vb = (v > vb || v != v) ? v : vb;
+            }
+        }
+    }
     __syncthreads();
-    const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
-    const bool valid = n < n_rows;
     unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned long long pm[4] = {0ull, 0ull, 0ull, 0ull};        // pairs of the proof round (a settled row with candidates)
     int listed = 0, over_i = 0;
-    // ---- the row's reference value and threshold ---------------------------------------------------------------------
-    const double ninf = -__builtin_huge_val();
-    unsigned long long fresh[4] = {0ull, 0ull, 0ull, 0ull};      // pairs already exact under the new parameters
+    // ---- ... and threshold -------------------------------------------------------------------------------------------
     unsigned long long nocand[4] = {0ull, 0ull, 0ull, 0ull};
-    double vb = ninf;
     bool by_bound = false, over = false;
     int kset = -1;
     float d_set = 0.0f, thr_f = __builtin_huge_valf();
     if (valid) {
         const int kb = PREV ? -1 : khat[n];
-        if (PREV) {
-            for (int w = 0; w < W; ++w) {
-                fresh[w] = masks[(int64_t)w * npad + n];
-                unsigned long long m = fresh[w];
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const double v = u[(int64_t)(64 * w + b) * npad + n];
-                    vb = (v > vb || v != v) ? v : vb;
-                }
-            }
-        }
         if constexpr (!PREV) {
             fresh[kb >> 6] = 1ull << (kb & 63);
             vb = u[(int64_t)kb * npad + n];
@@ -459,18 +480,18 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         // statistics cache - and left out of the lists by rec_finish_kernel) has nothing evaluated for it: the reference
         // is a LOWER bound of ln rho under the new parameters, from the carried upper bound of its distance,
         // d' = Gamma d + delta.  No candidate against it: the row stays settled.
-        by_bound = PREV && lock != nullptr && lock[n] == 1 && (fresh[0] | fresh[1] | fresh[2] | fresh[3]) == 0ull;
+        by_bound = PREV && lock != nullptr && lk_pre == 1u && (fresh[0] | fresh[1] | fresh[2] | fresh[3]) == 0ull;
         float thr_set = 0.0f;
         if (by_bound) {
-            kset = lcomp[n];
+            kset = kset_pre;
             // the distance bound: from the lower bound the proof round has just made for the new parameters (components
             // that moved), or the previous pass's carried through Gamma and delta
             float dn;
             if (sfirst[kset]) {
-                const double lbn = u[(int64_t)kset * npad + n];
+                const double lbn = lb_pre;
                 dn = f32_up(dist_of(sc[kset], lbn) * (1.0 + 1e-9));            // (-inf: +inf, every component a candidate)
             } else {
-                dn = fmaf(sq[kset].x, dlock[n], s_delta[kset]) * (1.0f + 2.4e-7f);
+                dn = fmaf(sq[kset].x, dl_pre, s_delta[kset]) * (1.0f + 2.4e-7f);
             }
             const float lb = sq[kset].y - dn * dn * 0.5000005f;
             d_set = dn;
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         float skip = -__builtin_huge_valf();
         if (tid < K) {
             const int k = tid;
-            meta = tmeta_reset ? make_float4(__builtin_huge_valf(), 1.0f, 0.0f, step.w) : tmeta[(int64_t)blockIdx.x * K + k];
+            meta = tmeta_reset ? make_float4(__builtin_huge_valf(), 1.0f, 0.0f, step.w) : meta_pre;
             // the composition takes this pass's step in
             // (products of two floats are exact in f64)
             comp = make_float4(f32_down((double)meta.y * (double)step.x),
