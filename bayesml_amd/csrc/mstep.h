@@ -122,11 +122,8 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     // (a list entry's sign bit marks a row that LEAVES the settled-row cache: weight -1, direct_r == 3)
     if constexpr (LIST) idx_n = (lo + lane < hi) ? list[lo + lane] : 0;
     RawRow nxt = load_row(LIST ? (int64_t)(__shfl(idx_n, g) & 0x7FFFFFFF) : lo + g);
-    // LIST over f32 rows: a second row set is requested TWO steps ahead (8 registers): listed rows are gathered, and one
-    // step of 18 MFMAs does not cover the latency of a gathered row
-    constexpr bool DEEP = LIST && !PRE && sizeof(XT) == 4;
-    RawRow nxt2 = nxt;
-    if constexpr (DEEP) nxt2 = load_row((int64_t)(__shfl(idx_n, 4 + g) & 0x7FFFFFFF));
+    // (measured, round 3: requesting the listed rows TWO steps ahead makes the kernel slower - 2.30 instead of 1.81 ms per
+    // step at the benchmark shape)
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         // responsibilities of 64 samples, one per lane
         const int64_t nl = c0 + lane;
@@ -174,10 +171,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (DEEP) {
-                nxt = nxt2;
-                nxt2 = load_row((int64_t)(__shfl(st >= 14 ? idx_n : idx_l, (4 * (st + 2) + g) & 63) & 0x7FFFFFFF));
-            } else if constexpr (LIST)
+            if constexpr (LIST)
                 nxt = load_row((int64_t)(__shfl(st == 15 ? idx_n : idx_l, (4 * (st + 1) + g) & 63) & 0x7FFFFFFF));
             else
                 nxt = load_row(c0 + 4 * (st + 1) + g);
