@@ -1120,6 +1120,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
     const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
     bool counted = false, proof_ran = false, tmeta_kept = false;
+    ws->lse_stale = false;
     const bool tmeta_was_valid = ws->tmeta_valid;
     ws->tmeta_valid = false;            // (only a lazy sweep that ran to its end leaves the tile state in step with the bounds)
     if (mode == kDense) {
@@ -1161,6 +1162,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             if (e != hipSuccess) return fail(GMMVB_EHIP, "row_lse / lse_mask launch", e);
             counted = true;
             ws->rec_valid = can_prune && big;
+        } else if (ws->hmm != nullptr) {
+            // the HMM pass normalises along the time axis (hmm_prep_kernel takes the row maxima): the mixture's
+            // log-normaliser is only made if a read-out asks for mixture responsibilities before hmmvb_forward_backward
+            ws->lse_stale = true;
+            ws->rec_valid = false;
         } else {
             hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)lse_blocks), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
                                ws->lse, nullptr, nullptr, 1);
@@ -1421,6 +1427,11 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (ws->e_state == 0 || ws->e_rows != n_rows)
         return fail(GMMVB_ESTATE, "no responsibilities for these rows: call gmmvb_estep or gmmvb_load_responsibilities first");
     hipStream_t st = (hipStream_t)stream;
+    if (ws->lse_stale && ws->e_state == 1) {       // a mixture M-step on an HMM workspace: the log-normaliser after all
+        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)((n_rows + kLseRows - 1) / kLseRows)), dim3(256), 0, st, ws->lnrho,
+                           ws->npad, n_rows, ws->K, ws->lse, nullptr, nullptr, 1);
+        ws->lse_stale = false;
+    }
     if (ws->generic) {
         const int direct = ws->e_state == 2 ? 1 : (ws->e_state == 3 ? 2 : 0);
         const double* lr = ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho;
@@ -1704,6 +1715,11 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return fail(GMMVB_EHIP, "rec_readout launch", er);
         return GMMVB_OK;
+    }
+    if (ws->lse_stale && mode == 1 && ws->e_state == 1) {       // (an HMM workspace skips the mixture's log-normaliser)
+        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)((ws->e_rows + kLseRows - 1) / kLseRows)), dim3(256), 0,
+                           (hipStream_t)stream, ws->lnrho, ws->npad, ws->e_rows, ws->K, ws->lse, nullptr, nullptr, 1);
+        ws->lse_stale = false;
     }
     hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        hmm_gamma ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->lse, ws->npad, row0, n_rows, ws->K, mode,

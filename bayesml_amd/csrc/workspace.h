@@ -199,6 +199,7 @@ struct gmmvb_workspace {
     int span_slot[kMaxSpans] = {0};
     hipEvent_t span_ev[2 * kMaxSpans] = {nullptr};
     gmmvb_hmm_state* hmm = nullptr;
+    bool lse_stale = false;            // the last dense E-step of an HMM workspace did not make lse (only a read-out wants it)
 };
 
 namespace gmmvb {
