@@ -1272,11 +1272,19 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     (void)hipMemsetAsync(ws->exit_ctr + 1, 0, sizeof(unsigned long long), st);
                     // (the tile state is void after any pass that rewrote the bounds wholesale: the first sweep after it
                     // opens every column and takes stock)
-                    hipLaunchKernelGGL((rec_sweep_kernel<true, true>), dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho,
-                                       ws->npad, n_rows, ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart,
-                                       ws->opart, settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp,
-                                       proof ? ws->rmask : nullptr, ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0,
-                                       ws->tmeta, tmeta_was_valid ? 0 : 1, ws->exit_ctr + 1);
+#define GMMVB_LAZY_SWEEP(WC)                                                                                                   \
+    hipLaunchKernelGGL((rec_sweep_kernel<true, true, WC>), dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho,        \
+                       ws->npad, n_rows, ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart,            \
+                       ws->opart, settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp,                                 \
+                       proof ? ws->rmask : nullptr, ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0, ws->tmeta,         \
+                       tmeta_was_valid ? 0 : 1, ws->exit_ctr + 1)
+                    switch ((ws->K + 63) / 64) {        // (mask words as a compile-time constant)
+                        case 1: GMMVB_LAZY_SWEEP(1); break;
+                        case 2: GMMVB_LAZY_SWEEP(2); break;
+                        case 3: GMMVB_LAZY_SWEEP(3); break;
+                        default: GMMVB_LAZY_SWEEP(4); break;
+                    }
+#undef GMMVB_LAZY_SWEEP
                     tmeta_kept = true;
                 } else {
                     hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad,

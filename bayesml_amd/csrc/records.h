@@ -373,7 +373,9 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // entries are about to be replaced by tighter values) and its true maximum is taken the next time it is opened.  With the
 // rows grouped by dominant component a tile's rows share their near components, and the far ones - most of the K - are
 // never read: the sweep was 5 GB of traffic per pass at the benchmark shape, the largest kernel of a converged step.
-template <bool PREV, bool LAZY = false>
+// WC > 0: the number of 64-component mask words is a compile-time constant (the loops over them unroll and the
+// four-element mask arrays stay in registers without select chains: a third fewer vector instructions at K <= 64).
+template <bool PREV, bool LAZY = false, int WC = 0>
 __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__ ub, const double* __restrict__ u, int64_t npad,
                                                              int64_t n_rows, int K,
                                                              const double* __restrict__ drift,
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     __shared__ float s_red[LAZY ? 4 : 1][LAZY ? 256 : 1];  // per wave: largest carried bound of the redo columns
     __shared__ float s_skip[LAZY ? 4 : 1];                 // per wave (of columns): largest bound among the closed columns
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int W = (K + 63) / 64;
+    const int W = WC > 0 ? WC : (K + 63) / 64;
     const int64_t n = (int64_t)blockIdx.x * kSelRows + tid;
     const bool valid = n < n_rows;
     // what the row needs from global memory and does not depend on the component constants is requested before the first
@@ -571,6 +573,10 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         const int64_t nn = valid ? n : 0;
         unsigned long long red_w = 0ull;
         float mine_w = -__builtin_huge_valf();
+        // LAZY: a settled row's record has no slots (if the row comes loose, its candidates are listed and the rest bound
+        // covers everything else: "refreshed row"), so a wave whose rows are all settled skips the selection chain - a third
+        // of the per-pair instructions
+        const bool need_chain = !LAZY || __builtin_amdgcn_ballot_w64(valid && !by_bound) != 0ull;
         auto pair = [&](int k, int bit, float old, unsigned long long fw, unsigned long long nw, unsigned long long& mw,
                         unsigned long long& aw) {
             const float ubn = sweep_carry(old, sp[k]);
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             const bool cand = valid && !(ubn < thr_f) && (nw & b1) == 0ull;
             mw |= cand ? b1 : 0ull;
             restmax = fmaxf(restmax, (cand || isf) ? -__builtin_huge_valf() : ubn);
-            sweep_chain(s, (isf || !valid) ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
+            if (need_chain) sweep_chain(s, (isf || !valid) ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
             if constexpr (LAZY) {
                 aw |= __builtin_amdgcn_ballot_w64(cand) != 0ull ? b1 : 0ull;
                 if (red_w & b1) {                                              // (uniform)
@@ -679,6 +685,16 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                 rthr[n] = -__builtin_huge_valf();
             }
         }
+        unsigned sel = 0, ex = 0;
+        int in_slots = 0;
+        // (LAZY: a row that stays settled has no exact pair, no candidate and needs no record - nothing reads it before the
+        // next pass that rebuilds it, and the read-outs answer for such rows from the log-normaliser alone,
+        // rec_readout_kernel: the whole section is skipped, by whole waves where the rows are grouped)
+        if (!(LAZY && stays)) {
+        if (LAZY && by_bound) {              // (whatever the wave's other rows made the chain collect)
+#pragma unroll
+            for (int j = 0; j <= kRecSlots; ++j) s[j] = 0xFFFFFFFFu;
+        }
         // the exact pairs: their values replace the carried bounds, and they compete for slots by value (the single
         // reference pair of the !PREV form always gets one)
         for (int w = 0; w < W; ++w) {
@@ -695,8 +711,6 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         float ds[kRecSlots];
         unsigned short ks[kRecSlots];
         unsigned long long in_slot[4] = {0ull, 0ull, 0ull, 0ull};
-        unsigned sel = 0, ex = 0;
-        int in_slots = 0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
             ks[j] = kRecEmpty;
@@ -705,13 +719,14 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             const int k = (int)(s[j] & 0xFFu);
             ks[j] = (unsigned short)k;
             const unsigned long long bit = 1ull << (k & 63);
-            if (fresh[k >> 6] & bit) {                         // exact, in a slot: not a candidate
-                in_slot[k >> 6] |= bit;
+            const int kw = WC == 1 ? 0 : (k >> 6);            // (one mask word: no select chain over the four)
+            if (fresh[kw] & bit) {                         // exact, in a slot: not a candidate
+                in_slot[kw] |= bit;
                 ex |= 1u << j;
                 ds[j] = f32_down(dist_of(sc[k], PREV ? u[(int64_t)k * npad + n] : vb));
             } else {
                 ds[j] = dist_lower_f32(sc[k], (double)sweep_key_bound(s[j]));
-                if (mk[k >> 6] & bit) {
+                if (mk[kw] & bit) {
                     sel |= 1u << j;
                     ++in_slots;
                 }
@@ -730,11 +745,11 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             const int k9 = (int)(s[kRecSlots] & 0xFFu);
             rest = ((mk[k9 >> 6] >> (k9 & 63)) & 1ull) ? restmax : sweep_key_bound(s[kRecSlots]);
         }
-        if constexpr (LAZY)      // (the columns the tile left closed: every pair in them lies below this)
+        if constexpr (LAZY) {    // (the columns the tile left closed: every pair in them lies below this)
+            if (by_bound) rest = restmax;
             rest = fmaxf(rest, fmaxf(fmaxf(s_skip[0], s_skip[1]), fmaxf(s_skip[2], s_skip[3])));
-        // (LAZY: a row that stays settled needs no record - nothing reads it before the next pass that rebuilds it, and the
-        // read-outs answer for such rows from the log-normaliser alone, rec_readout_kernel)
-        if (!(LAZY && stays)) {
+        }
+        {
 #pragma unroll
             for (int j = 0; j < kRecSlots; ++j) {
                 rec.k[(int64_t)j * rec.npad + n] = ks[j];
@@ -743,6 +758,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             rec.B[n] = rest;
             rec.exact[n] = (unsigned char)(over ? 0 : ex);
             rec.sel[n] = (unsigned char)(over ? 0 : sel);
+        }
         }
         rec.flags[n] = (unsigned char)(stays ? 4 : (proof_row ? 8 : (over ? 1 : ((listed > in_slots ? 2 : 0) | (proof_cand ? 16 : 0)))));
         over_i = over ? 1 : 0;
@@ -864,6 +880,7 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
             const double thr = l - k100Ln2;                              // -inf when the proof kernel had no bound
             unsigned long long kept[4] = {0ull, 0ull, 0ull, 0ull};
             bool any = false;
+            float done_max = -__builtin_huge_valf();       // largest fresh bound among the candidates that are done with
             for (int w = 0; w < W; ++w) {
                 unsigned long long m = pmask[(int64_t)w * npad + n];
                 proved += __builtin_popcountll(m);
@@ -872,10 +889,13 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
                     m &= m - 1;
                     const int k = 64 * w + b;
                     if (k == kset) continue;
-                    const double u = (double)ub32[(int64_t)k * npad + n];
+                    const float uf = ub32[(int64_t)k * npad + n];
+                    const double u = (double)uf;
                     if (!(u < thr)) {                                        // also NaN
                         kept[w] |= 1ull << b;
                         any = true;
+                    } else {
+                        done_max = fmaxf(done_max, uf);
                     }
                 }
             }
@@ -902,6 +922,9 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
                 rec.sel[n] = (unsigned char)sel;
                 rec.exact[n] = 0;
                 rec.flags[n] = (unsigned char)(total > in_slots ? 2 : 0);
+                // (the lazy sweep gives a settled row no slots: a candidate that is done with is covered by the rest bound)
+                const float Bn = rec.B[n];
+                if (done_max > Bn) rec.B[n] = done_max;
                 rthr[n] = -__builtin_huge_valf();
             }
         }
