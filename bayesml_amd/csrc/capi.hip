@@ -175,8 +175,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         v = std::getenv("GMMVB_SETTLE_MARGIN");                    // nats; negative = never settle rows
         if (v) ws->settle_margin = std::atof(v);
         v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round (rows then never settle);
-        ws->opt_proof = !(v && std::strcmp(v, "0") == 0);          // "all": every spare candidate goes through it first
-        ws->opt_proof_all = v && std::strcmp(v, "all") == 0;
+        ws->opt_proof = !(v && std::strcmp(v, "0") == 0);
+        ws->opt_proof_all = !(v && std::strcmp(v, "settled") == 0);     // "settled": only the settled rows' pairs go through it
         v = std::getenv("GMMVB_SWEEP_LAZY");                       // "0": every sweep reads all K bounds of every row
         ws->opt_lazy = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full

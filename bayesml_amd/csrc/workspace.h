@@ -160,7 +160,8 @@ struct gmmvb_workspace {
     int pivot_gen = 0, xq_gen = -1, img_gen = -2;
     bool opt_proof = true;             // env GMMVB_PROOF=0: settled rows with candidates go straight to the f64 gather
     bool opt_lazy = true;              // env GMMVB_SWEEP_LAZY=0: every sweep goes through all K bounds of every row
-    bool opt_proof_all = false;        // env GMMVB_PROOF=all: the candidates of every other row go through the proof round too
+    bool opt_proof_all = true;         // the candidates of rows with an exact reference go through the proof round too (env
+                                       // GMMVB_PROOF=settled: only the settled rows' pairs)
     float4* tmeta = nullptr;           // [blocks][K] the lazy sweep's state per tile and component (records.h)
     bool tmeta_valid = false;          // it describes the bound array as it is (only sweeps have written to it since)
     double* ppart = nullptr;           // [blocks] pairs of the proof round per selection block

@@ -32,8 +32,9 @@ VARIANTS = {
     "settle": {"GMMVB_SETTLE_MARGIN": "5"},
     "force_settle": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SETTLE_MARGIN": "3"},
     "force_noproof": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "0"},
-    # every spare candidate through the proof round first (experiment switch)
-    "force_proof_all": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "all"},
+    # only the settled rows' pairs go through the proof round (default: every candidate does before anything is evaluated in f64)
+    "force_proof_settled": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF": "settled"},
+    "proof_settled": {"GMMVB_PROOF": "settled"},
     # ... without the proof round rows never settle (a settled row that came loose would cost exact evaluations)
     "noproof": {"GMMVB_PROOF": "0"},
     "nosettle": {"GMMVB_SETTLE_MARGIN": "-1"},
@@ -100,7 +101,7 @@ def expect_kernels(counts, variant, min_carried=1, lists=True):
         assert counts["mstep_list"] >= 1, counts
     if variant == "force_nocarry":
         assert counts["estep_carried"] == counts["estep_sweep"] == 0, counts
-    elif variant in ("settle", "force_settle", "force_proof_all"):
+    elif variant in ("settle", "force_settle", "force_proof_settled"):
         assert counts["estep_sweep"] >= 2, counts
     else:       # carried over the parameter update by a sweep of the per-pair bound array
         assert counts["estep_sweep"] >= min_carried, counts
@@ -127,6 +128,7 @@ LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n1400
          ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "noproof"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "nosettle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"), ("gmm_f3_k64_d128_n140000_f32.npz", "nolazy"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "proof_settled"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "nolazy"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
@@ -163,7 +165,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if "overlap" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy"):
+    if "overlap" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -203,7 +205,7 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_all", "force_nolazy"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_settled", "force_nolazy"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
