@@ -430,14 +430,24 @@ def main():
         traffic = traffic_src = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f).get({"estep_i8_bound": "estep_i8", "estep_gather_f64": "estep_gather_dev_f64"}.get(dom_kernel, dom_kernel))
+                pm = json.load(f).get({"estep_i8_bound": "estep_i8", "estep_gather_f64": "estep_gather_dev_f64",
+                                       "mstep_list_f64": "mstep_list_x32_f64" if row_bytes == 4 * D else "mstep_list_f64"}
+                                      .get(dom_kernel, dom_kernel))
             ran = (dom_kernel == "estep_gather_f64" and timed_counts["estep_gather"] > 0) or any(dom_kernel in l for l in launches)
             if pm and pm.get("config") == f"K{K} D{D} N{n_local} {dt}" and ran:
                 # per step like `achieved`: the counters' average per launch x this run's launches of the group per step
                 per_step = groups[dom]["launch_groups_per_step"] if dom else 1.0
-                traffic = (pm["fetch_bytes"] + pm["write_bytes"]) * per_step
-                traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, average per launch x {per_step:.2f} launches per "
-                               "step): " + pm["note"])
+                n_last = int(round(per_step * steps))
+                fl, wl = pm.get("fetch_bytes_raw_launches"), pm.get("write_bytes_launches")
+                if pm.get("window") == f"w{args.warmup}s{steps}" and fl and wl and 0 < n_last <= min(len(fl), len(wl)):
+                    # the passes were made with this very command: the kernel's last n launches are the timed steps'
+                    traffic = (2.0 * sum(fl[-n_last:]) + sum(wl[-n_last:])) / steps
+                    traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, its last {n_last} launches = the {steps} timed "
+                                   "steps of this command, per step): " + pm["note"])
+                else:
+                    traffic = (pm["fetch_bytes"] + pm["write_bytes"]) * per_step
+                    traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, average per launch x {per_step:.2f} launches "
+                                   "per step): " + pm["note"])
         except (OSError, ValueError, KeyError):
             pass
         step_bytes = n_local * row_bytes

@@ -9,6 +9,7 @@ for f in bench_line.json bench_line_w5s20.json bench_line_c2.json bench_line_c4.
          pmc_summary.md small.json full_run.json hmm_bench_line.json hmm_kernel_summary.md gpu_tests.txt \
          bench_line_c4_strong1.json bench_line_c4_w5s20.json bench_proof.json hmm_pmc_summary.md hmm_k128_line.json; do
     [ -f gpurun_out/${tag}_$f ] && cp gpurun_out/${tag}_$f profiles/${rnd}_$f
+    case $f in *.json) [ -f profiles/${rnd}_$f ] && grep -a '^{' profiles/${rnd}_$f > profiles/${rnd}_$f.tmp && mv profiles/${rnd}_$f.tmp profiles/${rnd}_$f ;; esac   # (RCCL prints a banner on stdout)
 done
 [ -f gpurun_out/${tag}_pmc_traffic.json ] && cp gpurun_out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
 [ -f gpurun_out/${tag}_hmm_pmc_traffic.json ] && cp gpurun_out/${tag}_hmm_pmc_traffic.json profiles/hmm_pmc_traffic.json

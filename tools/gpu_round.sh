@@ -22,7 +22,7 @@ for stage in "$@"; do
            find $OUT/${TAG}_trace -name "*kernel_trace.csv" -size +20M -delete ;;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/${TAG}_pmc_$c
            (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c.err); done
-         python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE --config "K64 D128 N10000000 f32" --json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.md 2> $OUT/${TAG}_pmc.err; head -60 $OUT/${TAG}_pmc_summary.md
+         python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE --config "K64 D128 N10000000 f32" --window w5s20 --json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.md 2> $OUT/${TAG}_pmc.err; head -60 $OUT/${TAG}_pmc_summary.md
          [ -s $OUT/${TAG}_pmc_traffic.json ] && cp $OUT/${TAG}_pmc_traffic.json profiles/pmc_traffic.json                  # (later stages of this call quote it)
          find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*.csv" -size +20M -delete ;;
     hmm) timeout 900 python tools/bench_hmm.py > $OUT/${TAG}_hmm_bench_line.json 2> $OUT/${TAG}_hmm.err; tail -c 400 $OUT/${TAG}_hmm.err; head -c 800 $OUT/${TAG}_hmm_bench_line.json; echo ;;

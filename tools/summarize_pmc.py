@@ -23,7 +23,13 @@ def main():
         i = sys.argv.index("--config")
         config = sys.argv[i + 1]
         del sys.argv[i:i + 2]
+    window = None
+    if "--window" in sys.argv:          # e.g. "w5s20": the bench command's warm-up / timed steps the passes were made with
+        i = sys.argv.index("--window")
+        window = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     rows = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> values (largest grid only)
+    seq = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> (dispatch id, value), EVERY launch (any grid)
     grid = {}
     dur = defaultdict(list)
     for d in sys.argv[1:]:
@@ -38,6 +44,7 @@ def main():
                         grid[name] = g
                         rows[name].clear()
                         dur[name].clear()
+                    seq[name][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                     if g == grid[name]:
                         rows[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
                         dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
@@ -77,7 +84,14 @@ def main():
         for base in merged:
             c = {k: sum(v) / len(v) for k, v in merged[base].items()}
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                # per launch, in dispatch order (the template variants of a kernel interleaved as they ran): lets bench.py
+                # take exactly the launches of its timed steps when it runs the command the passes were made with
+                per = {}
+                for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+                    ent = sorted(v for n in names[base] for v in seq[n][cn])
+                    per[cn] = [round(v * 1024) for _d, v in ent]
                 out[base] = dict(
+                    window=window, fetch_bytes_raw_launches=per["FETCH_SIZE"], write_bytes_launches=per["WRITE_SIZE"],
                     kernel=" + ".join(sorted(names[base])), grid_threads=max(grid[n] for n in names[base]),
                     launches=len(merged[base]["FETCH_SIZE"]), fetch_bytes_raw=c["FETCH_SIZE"] * 1024,
                     fetch_bytes=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024, config=config,
