@@ -293,6 +293,19 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
         }
     }
     __syncthreads();
+    // every component's base of this block, for each of the four waves: ONE batch of parallel loads per workgroup (a load
+    // inside the loop below is a dependent memory round trip per component and wave: at K = 256 a wave sees dozens)
+    for (int k = threadIdx.x; k < K; k += kSelRows) {
+        const int c0 = wcnt[0][k], c1 = wcnt[1][k], c2 = wcnt[2][k], c3 = wcnt[3][k];
+        if (c0 + c1 + c2 + c3 > 0) {
+            const int base = blk_base[(int64_t)k * gridDim.x + blockIdx.x];
+            wcnt[0][k] = base;
+            wcnt[1][k] = base + c0;
+            wcnt[2][k] = base + c0 + c1;
+            wcnt[3][k] = base + c0 + c1 + c2;
+        }
+    }
+    __syncthreads();
     const unsigned lk0 = (lock && valid) ? lock[n] : 0u;
     const int kh0 = (lock && valid) ? (int)lcomp[n] : 0;
     if (lk0 >= 2u) lock[n] = lk0 == 2u ? 0 : 1;
@@ -304,8 +317,7 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
             present &= present - 1;
             const int k = 64 * w + b;
             const unsigned long long bal = __ballot((mk >> b) & 1ull);
-            int off = blk_base[(int64_t)k * gridDim.x + blockIdx.x];
-            for (int v = 0; v < wave; ++v) off += wcnt[v][k];
+            const int off = wcnt[wave][k];
             if ((mk >> b) & 1ull) {
                 int entry = (int)n;
                 if (lock) {
