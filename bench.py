@@ -103,6 +103,8 @@ def visible_gpus():
 def launch_ranks(n):
     """Start n rank processes of this script (rank r on GPU r).  The parent never initialises a GPU."""
     have = visible_gpus()
+    if os.environ.get("BENCH_SHARE_GPU") == "1":      # developer switch: every rank on GPU 0, gloo instead of RCCL
+        have = None
     if have is not None and have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
@@ -287,6 +289,11 @@ def main():
     if args.dense:
         os.environ["GMMVB_ESTEP_PRUNE"] = "0"
         os.environ["GMMVB_MSTEP_SPARSE"] = "0"
+    # BENCH_SHARE_GPU=1 (developer switch): all ranks on GPU 0 with the gloo backend - the N > 1 code path of this script
+    # on a one-GPU box (the collective then goes through host memory; the numbers mean nothing)
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
@@ -295,7 +302,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
         comm = RowShard(native=args.native_allreduce, always=args.force_dist)
         # every rank contributes 1: proves the RCCL group really spans `world` processes
@@ -495,7 +505,8 @@ def main():
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
             "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
             "estep_kinds_identical_across_ranks": policy_same,
-            "allreduce": (("gmmvb_allreduce_stats (C ABI, RCCL)" if args.native_allreduce else "torch.distributed nccl (RCCL)")
+            "allreduce": (("gmmvb_allreduce_stats (C ABI, RCCL)" if args.native_allreduce else
+                           ("torch.distributed gloo (BENCH_SHARE_GPU=1: all ranks on one GPU)" if share_gpu else "torch.distributed nccl (RCCL)"))
                           if use_dist else None),
             "steps": steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
