@@ -105,13 +105,17 @@ __device__ __forceinline__ double block_sum256(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);          // fixed order
 }
 
+// PD = D rounded up to 32, 64 or 128: the products are PD x PD x PD (a D = 64 model does an eighth of the 128-wide work),
+// every thread holds a (PD / 16)^2 block of the result.
+template <int PD>
 __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u_old, const double* __restrict__ uinv_old,
                                                     const double* __restrict__ m_old, const double* __restrict__ u_new,
                                                     const double* __restrict__ uinv_new, const double* __restrict__ m_new,
                                                     int D, int sq_small, int sq_big, double* __restrict__ gamma,
                                                     double* __restrict__ delta, double* __restrict__ big,
                                                     double* __restrict__ enorm) {
-    extern __shared__ double sm[];           // [128][kDriftLd]
+    extern __shared__ double sm[];           // [PD][kDriftLd]
+    constexpr int NB = PD / 16;
     __shared__ double red[4];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int k = blockIdx.x, dir = blockIdx.y;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
     const double* R = (dir == 0 ? uinv_new : uinv_old) + base;
     const int sq = dir == 1 ? sq_big : sq_small;
     const double tiny = 2.2250738585072014e-308;
-    double acc[8][8];
+    double acc[NB][NB];
 
     if (dir == 0) {          // delta
         // a wave per row: coalesced row reads, independent rows in flight (a thread per row walked its row with 128
@@ -147,44 +151,44 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
         const double t = block_sum256(part, red);
         if (tid == 0) delta[k] = sqrt(t) * (1.0 + 1e-9);
     }
-    // stage L (zero padded to 128 x 128)
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
+    // stage L (zero padded to PD x PD)
+    for (int e = tid; e < PD * PD; e += 256) {
+        const int i = e / PD, j = e % PD;
         sm[i * kDriftLd + j] = (i < D && j < D) ? L[(int64_t)i * D + j] : 0.0;
     }
     __syncthreads();
     // A = L R : A[i][j] = sum_p L[i][p] R[p][j]   (R straight from global memory / L2: consecutive tx read consecutive j)
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
+        for (int b = 0; b < NB; ++b) acc[a][b] = 0.0;
     // (the rows of R are requested one step ahead and without branches - columns past D read column D - 1 and are
     // zeroed when A is stored: a load waited for inside its own step costs a memory round trip per step, 128 of them)
-    int jc[8];
+    int jc[NB];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) jc[b] = tx + 16 * b < D ? tx + 16 * b : D - 1;
-    double rn[8];
+    for (int b = 0; b < NB; ++b) jc[b] = tx + 16 * b < D ? tx + 16 * b : D - 1;
+    double rn[NB];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) rn[b] = R[jc[b]];
+    for (int b = 0; b < NB; ++b) rn[b] = R[jc[b]];
     for (int p = 0; p < D; ++p) {
-        double lv[8], rv[8];
+        double lv[NB], rv[NB];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) rv[b] = rn[b];
+        for (int b = 0; b < NB; ++b) rv[b] = rn[b];
         const int pn = p + 1 < D ? p + 1 : p;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) rn[b] = R[(int64_t)pn * D + jc[b]];
+        for (int b = 0; b < NB; ++b) rn[b] = R[(int64_t)pn * D + jc[b]];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) lv[a] = sm[(ty + 16 * a) * kDriftLd + p];
+        for (int a = 0; a < NB; ++a) lv[a] = sm[(ty + 16 * a) * kDriftLd + p];
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NB; ++a)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] = fma(lv[a], rv[b], acc[a][b]);
+            for (int b = 0; b < NB; ++b) acc[a][b] = fma(lv[a], rv[b], acc[a][b]);
     }
     __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int i = ty + 16 * a, j = tx + 16 * b;
             sm[i * kDriftLd + j] = j < D ? acc[a][b] - ((dir == 2 && i == j && i < D) ? 1.0 : 0.0) : 0.0;
         }
@@ -193,45 +197,45 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
     double log_lmax = 0.0, w = 1.0;
     for (int it = 0; it <= sq; ++it) {
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NB; ++a)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
+            for (int b = 0; b < NB; ++b) acc[a][b] = 0.0;
         // one wave per SIMD: the operands of step p + 1 are read from LDS while step p's 64 FMAs run
-        double ln[8], rn2[8];
+        double ln[NB], rn2[NB];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) ln[a] = it == 0 ? sm[ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd];
+        for (int a = 0; a < NB; ++a) ln[a] = it == 0 ? sm[ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) rn2[b] = sm[tx + 16 * b];
-        for (int p = 0; p < 128; ++p) {
-            double lv[8], rv[8];
+        for (int b = 0; b < NB; ++b) rn2[b] = sm[tx + 16 * b];
+        for (int p = 0; p < PD; ++p) {
+            double lv[NB], rv[NB];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) lv[a] = ln[a];
+            for (int a = 0; a < NB; ++a) lv[a] = ln[a];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) rv[b] = rn2[b];
-            const int pn = p + 1 < 128 ? p + 1 : p;
+            for (int b = 0; b < NB; ++b) rv[b] = rn2[b];
+            const int pn = p + 1 < PD ? p + 1 : p;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) ln[a] = it == 0 ? sm[pn * kDriftLd + ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd + pn];
+            for (int a = 0; a < NB; ++a) ln[a] = it == 0 ? sm[pn * kDriftLd + ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd + pn];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) rn2[b] = sm[pn * kDriftLd + tx + 16 * b];
+            for (int b = 0; b < NB; ++b) rn2[b] = sm[pn * kDriftLd + tx + 16 * b];
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < NB; ++a)
 #pragma unroll
-                for (int b = 0; b < 8; ++b) acc[a][b] = fma(lv[a], rv[b], acc[a][b]);
+                for (int b = 0; b < NB; ++b) acc[a][b] = fma(lv[a], rv[b], acc[a][b]);
         }
         double ss = 0.0;
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NB; ++a)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) ss = fma(acc[a][b], acc[a][b], ss);
+            for (int b = 0; b < NB; ++b) ss = fma(acc[a][b], acc[a][b], ss);
         double f = sqrt(block_sum256(ss, red));          // (the barrier inside also ends every read of the old matrix)
         f = f > tiny ? f : tiny;                         // also NaN -> tiny: the NaNs then show up in log_lmax below
         log_lmax += w * log(f);
         w *= 0.5;
         const double inv = 1.0 / f;
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NB; ++a)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) sm[(ty + 16 * a) * kDriftLd + tx + 16 * b] = acc[a][b] * inv;
+            for (int b = 0; b < NB; ++b) sm[(ty + 16 * a) * kDriftLd + tx + 16 * b] = acc[a][b] * inv;
         __syncthreads();
     }
     if (tid == 0) {
@@ -548,14 +552,19 @@ extern "C" int gmmvb_kside_drift(int K, int D, const double* u_old_dev, const do
     if (!u_old_dev || !uinv_old_dev || !m_old_dev || !u_new_dev || !uinv_new_dev || !m_new_dev || !gamma_dev || !delta_dev ||
         !big_gamma_dev || !enorm_dev)
         return fail(GMMVB_EINVAL, "null argument");
-    const size_t lds = (size_t)128 * kDriftLd * sizeof(double);
-    {
-        hipError_t e = ensure_dynamic_lds((const void*)drift_kernel, lds);
-        if (e != hipSuccess) return fail(GMMVB_EHIP, "hipFuncSetAttribute(drift_kernel)", e);
+#define GMMVB_DRIFT(PD)                                                                                                       \
+    {                                                                                                                          \
+        const size_t lds = (size_t)PD * kDriftLd * sizeof(double);                                                             \
+        hipError_t e0 = ensure_dynamic_lds((const void*)drift_kernel<PD>, lds);                                                \
+        if (e0 != hipSuccess) return fail(GMMVB_EHIP, "hipFuncSetAttribute(drift_kernel)", e0);                               \
+        hipLaunchKernelGGL(drift_kernel<PD>, dim3(K, 3), dim3(256), lds, (hipStream_t)stream, u_old_dev, uinv_old_dev,        \
+                           m_old_dev, u_new_dev, uinv_new_dev, m_new_dev, D, squarings, squarings_big, gamma_dev, delta_dev,  \
+                           big_gamma_dev, enorm_dev);                                                                          \
     }
-    hipLaunchKernelGGL(drift_kernel, dim3(K, 3), dim3(256), lds, (hipStream_t)stream, u_old_dev, uinv_old_dev, m_old_dev,
-                       u_new_dev, uinv_new_dev, m_new_dev, D, squarings, squarings_big, gamma_dev, delta_dev, big_gamma_dev,
-                       enorm_dev);
+    if (D <= 32) GMMVB_DRIFT(32)
+    else if (D <= 64) GMMVB_DRIFT(64)
+    else GMMVB_DRIFT(128)
+#undef GMMVB_DRIFT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "drift_kernel launch", e);
     return GMMVB_OK;
