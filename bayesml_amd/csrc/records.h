@@ -409,6 +409,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     __shared__ float s_thr[LAZY ? 4 : 1];                  // per wave: lowest threshold of its rows
     __shared__ unsigned long long s_open[LAZY ? 4 : 1];    // columns the tile's rows go through
     __shared__ unsigned long long s_redo[LAZY ? 4 : 1];    // ... of which the true maximum is wanted (unknown, not forced)
+    __shared__ unsigned long long s_keep[LAZY ? 4 : 1];    // ... which only the tile test keeps open: read, not rewritten
     __shared__ unsigned long long s_any[LAZY ? 4 : 1][4];  // per wave: columns in which one of its rows has a candidate
     __shared__ float s_red[LAZY ? 4 : 1][LAZY ? 256 : 1];  // per wave: largest carried bound of the redo columns
     __shared__ float s_skip[LAZY ? 4 : 1];                 // per wave (of columns): largest bound among the closed columns
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     }
     // ---- LAZY: which columns the tile has to open --------------------------------------------------------------------
     float4 meta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), comp = meta;
-    bool col_open = false, col_forced = false, col_redo = false;
+    bool col_open = false, col_forced = false, col_redo = false, col_keep = false;
     float col_bound = 0.0f;
     if constexpr (LAZY) {
         if (valid) {
@@ -541,6 +542,10 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             const bool unknown = !(meta.x < __builtin_huge_valf());
             col_open = col_forced || unknown || !(col_bound < tile_thr);
             col_redo = col_open && unknown && !col_forced;
+            // opened by the tile test alone: its entries are carried on the fly and stay as they are (bounds under the
+            // parameters of the pass that wrote them, like a closed column's) unless one of them turns out a candidate -
+            // half of the sweep's traffic at K = 256 were such rewrites
+            col_keep = col_open && !unknown && !col_forced;
             sp[k] = comp;
             if (!col_open) {
                 tmeta[(int64_t)blockIdx.x * K + k] = make_float4(meta.x, comp.x, comp.y, meta.w);
@@ -548,11 +553,13 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             }
         }
         const unsigned long long ob = __builtin_amdgcn_ballot_w64(col_open), rb = __builtin_amdgcn_ballot_w64(col_redo);
+        const unsigned long long kb2 = __builtin_amdgcn_ballot_w64(col_keep);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) skip = fmaxf(skip, __shfl_xor(skip, o));
         if (lane == 0) {
             s_open[wave] = ob;
             s_redo[wave] = rb;
+            s_keep[wave] = kb2;
             s_skip[wave] = skip;
             if (col_ctr && ob) atomicAdd(col_ctr, (unsigned long long)__builtin_popcountll(ob));
         }
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         const bool near = npad < (int64_t(1) << 29);
         const unsigned off = (unsigned)(near ? (valid ? n : 0) : 0) * 4u;
         const int64_t nn = valid ? n : 0;
-        unsigned long long red_w = 0ull;
+        unsigned long long red_w = 0ull, keep_w = 0ull;
         float mine_w = -__builtin_huge_valf();
         // LAZY: a settled row's record has no slots (if the row comes loose, its candidates are listed and the rest bound
         // covers everything else: "refreshed row"), so a wave whose rows are all settled skips the selection chain - a third
@@ -581,8 +588,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                         unsigned long long& aw) {
             const float ubn = sweep_carry(old, sp[k]);
             char* base = (char*)(ub + (int64_t)k * npad + (near ? 0 : nn));
-            if (valid) *(float*)(base + off) = ubn;
             const unsigned long long b1 = 1ull << bit;
+            if (valid && !(LAZY && (keep_w & b1) != 0ull)) *(float*)(base + off) = ubn;
             const bool isf = (fw & b1) != 0ull;                            // (its exact value is written below)
             const bool cand = valid && !(ubn < thr_f) && (nw & b1) == 0ull;
             mw |= cand ? b1 : 0ull;
@@ -611,6 +618,9 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                 const unsigned long long r0 = s_redo[w];
                 red_w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(r0 >> 32)) << 32) |
                         (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
+                const unsigned long long q0 = s_keep[w];
+                keep_w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)q0);
                 mine_w = -__builtin_huge_valf();
                 while (ow) {
                     int kq[8];
@@ -788,13 +798,31 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
     }
     __syncthreads();
     if constexpr (LAZY) {
+        // a kept column in which a row did turn out a candidate: its entries are about to be replaced by fresh values under
+        // the new parameters, so the whole column goes over to them now (the same carry once more, this time stored)
+        for (int w = 0; w < W; ++w) {
+            unsigned long long fix = s_keep[w] & (s_any[0][w] | s_any[1][w] | s_any[2][w] | s_any[3][w]);
+            while (fix) {
+                const int b = __builtin_ctzll(fix);
+                fix &= fix - 1;
+                const int k = 64 * w + b;
+                if (valid) {
+                    float* e = ub + (int64_t)k * npad + n;
+                    *e = sweep_carry(*e, sp[k]);
+                }
+            }
+        }
         if (tid < K && col_open) {
             const int k = tid, w = k >> 6;
             const bool any = (((s_any[0][w] | s_any[1][w] | s_any[2][w] | s_any[3][w]) >> (k & 63)) & 1ull) != 0ull;
-            float tub = col_bound;                         // nothing replaced: the carry of the largest entry is the largest
-            if (col_redo) tub = fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]));
-            if (col_forced || any) tub = __builtin_huge_valf();
-            tmeta[(int64_t)blockIdx.x * K + k] = make_float4(tub, 1.0f, 0.0f, sq[k].y);
+            if (col_keep && !any) {                        // nothing was written: the column stays in its frame
+                tmeta[(int64_t)blockIdx.x * K + k] = make_float4(meta.x, comp.x, comp.y, meta.w);
+            } else {
+                float tub = col_bound;                     // nothing replaced: the carry of the largest entry is the largest
+                if (col_redo) tub = fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]));
+                if (col_forced || any) tub = __builtin_huge_valf();
+                tmeta[(int64_t)blockIdx.x * K + k] = make_float4(tub, 1.0f, 0.0f, sq[k].y);
+            }
         }
     }
     for (int k = tid; k < K; k += kSelRows) {

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_sparse_parity.py tests/test_gpu_sparse.py tests/test_gpu_full_size.py -x -q -m gpu 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3
+for i in 1 2; do timeout 600 python bench.py --no-cpu --no-legs --steps 20 --warmup 5 2>/dev/null | grep -a "^{" > $OUT/r3R_bench$i.json; done
+timeout 900 python bench.py --config c4 --no-cpu --no-legs --steps 20 --warmup 5 2>/dev/null | grep -a "^{" > $OUT/r3R_c4.json
+python - <<'PY'
+import json
+for f in ("bench1","bench2","c4"):
+    d=json.load(open("gpurun_out/r3R_%s.json"%f))
+    g=d["roofline"]["kernel_groups"]
+    print(f, d["ms_per_step"], {k:round(v["ms"],2) for k,v in g.items() if k.startswith("estep")}, d["per_step"]["estep_ms"][-4:], d["roofline"]["pairs_per_sample"]["proof_round_int8"], d["roofline"]["pairs_per_sample"]["evaluated_exactly"])
+PY
