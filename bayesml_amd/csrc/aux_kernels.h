@@ -282,9 +282,14 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
     const int W = (K + 63) / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int k = lane; k < K; k += 64) wcnt[wave][k] = 0;
-    for (int w = 0; w < W; ++w) {
+    unsigned long long mkw[4] = {0ull, 0ull, 0ull, 0ull}, prw[4] = {0ull, 0ull, 0ull, 0ull};      // (kept for the second pass)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w >= W) break;
         const unsigned long long mk = valid ? masks[(int64_t)w * npad + n] : 0ull;
+        mkw[w] = mk;
         unsigned long long present = wave_or(mk);
+        prw[w] = present;
         while (present) {
             const int b = __builtin_ctzll(present);
             present &= present - 1;
@@ -309,9 +314,11 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
     const unsigned lk0 = (lock && valid) ? lock[n] : 0u;
     const int kh0 = (lock && valid) ? (int)lcomp[n] : 0;
     if (lk0 >= 2u) lock[n] = lk0 == 2u ? 0 : 1;
-    for (int w = 0; w < W; ++w) {
-        const unsigned long long mk = valid ? masks[(int64_t)w * npad + n] : 0ull;
-        unsigned long long present = wave_or(mk);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w >= W) break;
+        const unsigned long long mk = mkw[w];
+        unsigned long long present = prw[w];
         while (present) {
             const int b = __builtin_ctzll(present);
             present &= present - 1;
