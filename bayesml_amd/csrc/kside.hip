@@ -6,6 +6,7 @@
 // G^-1 (-> u = sqrt(nu) G^-1, W = G^-T G^-1) and ln det W^-1 = 2 sum ln diag G.  Plain kernels on the caller's stream,
 // no host synchronisation, no allocation: the whole K-side can be captured in a hipGraph.
 #include "workspace.h"
+#include "common.h"
 
 #include <cstring>
 #include <mutex>
@@ -115,16 +116,14 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
                                                     double* __restrict__ delta, double* __restrict__ big,
                                                     double* __restrict__ enorm) {
     extern __shared__ double sm[];           // [PD][kDriftLd]
-    constexpr int NB = PD / 16;
     __shared__ double red[4];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x;
     const int k = blockIdx.x, dir = blockIdx.y;
     const int64_t base = (int64_t)k * D * D;
     const double* L = (dir == 0 ? u_old : u_new) + base;          // A = L R  (dir 2: A - I)
     const double* R = (dir == 0 ? uinv_new : uinv_old) + base;
     const int sq = dir == 1 ? sq_big : sq_small;
     const double tiny = 2.2250738585072014e-308;
-    double acc[NB][NB];
 
     if (dir == 0) {          // delta
         // a wave per row: coalesced row reads, independent rows in flight (a thread per row walked its row with 128
@@ -157,85 +156,94 @@ __global__ __launch_bounds__(256) void drift_kernel(const double* __restrict__ u
         sm[i * kDriftLd + j] = (i < D && j < D) ? L[(int64_t)i * D + j] : 0.0;
     }
     __syncthreads();
-    // A = L R : A[i][j] = sum_p L[i][p] R[p][j]   (R straight from global memory / L2: consecutive tx read consecutive j)
+    // Every product runs on v_mfma_f64_16x16x4_f64 (round 3; before: 64 FMAs per thread and step with both operands from
+    // LDS, 35 us per 128^3 product where the pipe needs 14): the PD x PD result is TR x TR tiles of 16 x 16, wave w owns
+    // the tile rows w, w + 4, ... (TR / 4 of them, at least one) and all TR tile columns; lane (i = l & 15, g = l >> 4)
+    // supplies X[16 tr + i][p + g] and Y[p + g][16 tc + i] for the four steps p .. p + 3 of the contraction.
+    constexpr int TR = PD / 16, RW = TR >= 4 ? TR / 4 : 1;
+    const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const bool wave_on = wv * RW < TR;                 // (PD = 32: two of the four waves have a tile row)
+    d4 acc[RW][TR];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+        for (int a2 = 0; a2 < RW; ++a2)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[a][b] = 0.0;
-    // (the rows of R are requested one step ahead and without branches - columns past D read column D - 1 and are
-    // zeroed when A is stored: a load waited for inside its own step costs a memory round trip per step, 128 of them)
-    int jc[NB];
+            for (int b2 = 0; b2 < TR; ++b2) acc[a2][b2] = d4{0.0, 0.0, 0.0, 0.0};
+    };
+    // result tile (a2, b2), register r  <->  row 16 (RW wv + a2) + lg + 4 r, column 16 b2 + li
+    // A = L R : R straight from global memory / L2 (rows of R are contiguous in j: lanes li read neighbours)
+    zero_acc();
+    if (wave_on) {
+        for (int p = 0; p < PD; p += 4) {
+            double av[RW], bv[TR];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) jc[b] = tx + 16 * b < D ? tx + 16 * b : D - 1;
-    double rn[NB];
+            for (int a2 = 0; a2 < RW; ++a2) av[a2] = sm[(16 * (RW * wv + a2) + li) * kDriftLd + p + lg];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) rn[b] = R[jc[b]];
-    for (int p = 0; p < D; ++p) {
-        double lv[NB], rv[NB];
+            for (int b2 = 0; b2 < TR; ++b2) {
+                const int rr = p + lg, cc = 16 * b2 + li;
+                bv[b2] = (rr < D && cc < D) ? R[(int64_t)rr * D + cc] : 0.0;
+            }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) rv[b] = rn[b];
-        const int pn = p + 1 < D ? p + 1 : p;
+            for (int a2 = 0; a2 < RW; ++a2)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) rn[b] = R[(int64_t)pn * D + jc[b]];
-#pragma unroll
-        for (int a = 0; a < NB; ++a) lv[a] = sm[(ty + 16 * a) * kDriftLd + p];
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) acc[a][b] = fma(lv[a], rv[b], acc[a][b]);
+                for (int b2 = 0; b2 < TR; ++b2) acc[a2][b2] = mfma_f64(av[a2], bv[b2], acc[a2][b2]);
+        }
     }
     __syncthreads();
+    if (wave_on) {
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+        for (int a2 = 0; a2 < RW; ++a2)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = ty + 16 * a, j = tx + 16 * b;
-            sm[i * kDriftLd + j] = j < D ? acc[a][b] - ((dir == 2 && i == j && i < D) ? 1.0 : 0.0) : 0.0;
-        }
+            for (int b2 = 0; b2 < TR; ++b2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * (RW * wv + a2) + lg + 4 * r, j = 16 * b2 + li;
+                    sm[i * kDriftLd + j] = j < D ? acc[a2][b2][r] - ((dir == 2 && i == j && i < D) ? 1.0 : 0.0) : 0.0;
+                }
+    }
     __syncthreads();
     // G = A^T A, then the squarings; every product is followed by its Frobenius norm
     double log_lmax = 0.0, w = 1.0;
     for (int it = 0; it <= sq; ++it) {
+        zero_acc();
+        if (wave_on) {
+            for (int p = 0; p < PD; p += 4) {
+                double av[RW], bv[TR];
+                // it == 0: X = A^T, i.e. X[row][p] = A[p][row]
 #pragma unroll
-        for (int a = 0; a < NB; ++a)
+                for (int a2 = 0; a2 < RW; ++a2) {
+                    const int row = 16 * (RW * wv + a2) + li;
+                    av[a2] = it == 0 ? sm[(p + lg) * kDriftLd + row] : sm[row * kDriftLd + p + lg];
+                }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[a][b] = 0.0;
-        // one wave per SIMD: the operands of step p + 1 are read from LDS while step p's 64 FMAs run
-        double ln[NB], rn2[NB];
+                for (int b2 = 0; b2 < TR; ++b2) bv[b2] = sm[(p + lg) * kDriftLd + 16 * b2 + li];
 #pragma unroll
-        for (int a = 0; a < NB; ++a) ln[a] = it == 0 ? sm[ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd];
+                for (int a2 = 0; a2 < RW; ++a2)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) rn2[b] = sm[tx + 16 * b];
-        for (int p = 0; p < PD; ++p) {
-            double lv[NB], rv[NB];
-#pragma unroll
-            for (int a = 0; a < NB; ++a) lv[a] = ln[a];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) rv[b] = rn2[b];
-            const int pn = p + 1 < PD ? p + 1 : p;
-#pragma unroll
-            for (int a = 0; a < NB; ++a) ln[a] = it == 0 ? sm[pn * kDriftLd + ty + 16 * a] : sm[(ty + 16 * a) * kDriftLd + pn];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) rn2[b] = sm[pn * kDriftLd + tx + 16 * b];
-#pragma unroll
-            for (int a = 0; a < NB; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[a][b] = fma(lv[a], rv[b], acc[a][b]);
+                    for (int b2 = 0; b2 < TR; ++b2) acc[a2][b2] = mfma_f64(av[a2], bv[b2], acc[a2][b2]);
+            }
         }
         double ss = 0.0;
 #pragma unroll
-        for (int a = 0; a < NB; ++a)
+        for (int a2 = 0; a2 < RW; ++a2)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) ss = fma(acc[a][b], acc[a][b], ss);
+            for (int b2 = 0; b2 < TR; ++b2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss = fma(acc[a2][b2][r], acc[a2][b2][r], ss);
         double f = sqrt(block_sum256(ss, red));          // (the barrier inside also ends every read of the old matrix)
         f = f > tiny ? f : tiny;                         // also NaN -> tiny: the NaNs then show up in log_lmax below
         log_lmax += w * log(f);
         w *= 0.5;
         const double inv = 1.0 / f;
+        if (wave_on) {
 #pragma unroll
-        for (int a = 0; a < NB; ++a)
+            for (int a2 = 0; a2 < RW; ++a2)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) sm[(ty + 16 * a) * kDriftLd + tx + 16 * b] = acc[a][b] * inv;
+                for (int b2 = 0; b2 < TR; ++b2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sm[(16 * (RW * wv + a2) + lg + 4 * r) * kDriftLd + 16 * b2 + li] = acc[a2][b2][r] * inv;
+        }
         __syncthreads();
     }
     if (tid == 0) {
