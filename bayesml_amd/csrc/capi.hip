@@ -1062,9 +1062,17 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         // 0.81 per f64 tile pair of every candidate.  Take the cheapest level among those observed in the last 32
         // bound passes; look one level down when the current one leaves hardly any spare candidates or one level up
         // when more than half of its candidates are spare, if that level is unknown.
+        // When the bounds are going to be carried (sweeps follow for tens of passes), all blocks: every nat of slack a bound
+        // starts with postpones the pass in which it erodes into a candidate - measured at the benchmark shape (round 3):
+        // four blocks instead of the model's three cost 6 ms once and take the following twenty passes from 8.1 to 7.2 ms
+        // each (proof pairs halved, a quarter instead of 43 % of the sweep's columns opened).
         const int t32 = (ws->D + 31) / 32;
+        // (the caller hands over drift hints - a row-tiled pass, whose bounds do not survive the other tiles, does not)
+        const bool carried_after = gmmvb_wants_drift(ws, n_rows) != 0 && ws->have_drift;
         if (ws->bound_tb == 0) ws->bound_tb = t32 > 3 ? 3 : t32;
-        if (known && L.mode == kBound) {
+        if (carried_after) {
+            ws->bound_tb = t32;
+        } else if (known && L.mode == kBound) {
             const int cur = ws->bound_tb;
             ws->tb_cand[cur] = L.eval / pairs_l;
             ws->tb_act[cur] = L.act / pairs_l;
