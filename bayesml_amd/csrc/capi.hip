@@ -48,14 +48,25 @@ enum { kSpanEstepMain = 0, kSpanSelect = 1, kSpanGather = 2, kSpanLse = 3, kSpan
        kSpanReduce = 6, kSpanProof = 7, kSpanSlots = 8 };
 static const char* const kSpanNames[kSpanSlots] = {"estep_main", "estep_select", "estep_gather", "estep_lse_mask",
                                                    "mstep_lists", "mstep_main", "mstep_reduce", "estep_proof"};
+// A failed event record / counter reset inside a pass must not vanish: the first such error is kept in the workspace and
+// gmmvb_estep / gmmvb_mstep return it (GMMVB_EHIP) before they hand anything to the caller.
+static void note_hip(gmmvb_workspace* ws, hipError_t e) {
+    if (e != hipSuccess && ws->hip_err == hipSuccess) ws->hip_err = e;
+}
+static int take_hip(gmmvb_workspace* ws, const char* what) {
+    if (ws->hip_err == hipSuccess) return GMMVB_OK;
+    const hipError_t e = ws->hip_err;
+    ws->hip_err = hipSuccess;
+    return fail(GMMVB_EHIP, what, e);
+}
 static void span_begin(gmmvb_workspace* ws, int slot, hipStream_t st) {
     if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans) return;
     ws->span_slot[ws->n_spans] = slot;
-    (void)hipEventRecord(ws->span_ev[2 * ws->n_spans], st);
+    note_hip(ws, hipEventRecord(ws->span_ev[2 * ws->n_spans], st));
 }
 static void span_end(gmmvb_workspace* ws, hipStream_t st) {
     if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans) return;
-    (void)hipEventRecord(ws->span_ev[2 * ws->n_spans + 1], st);
+    note_hip(ws, hipEventRecord(ws->span_ev[2 * ws->n_spans + 1], st));
     ++ws->n_spans;
 }
 
@@ -372,24 +383,27 @@ int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* 
 // out[22..25] the row's mask words
 int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26] host*/) {
     if (!ws || !out || !ws->rec_k || row < 0 || row >= ws->npad) return fail(GMMVB_EINVAL, "bad argument");
-    (void)hipDeviceSynchronize();
+    hipError_t e = hipDeviceSynchronize();
+    auto get = [&e](void* dst, const void* src, size_t n) {
+        if (e == hipSuccess) e = hipMemcpy(dst, src, n, hipMemcpyDeviceToHost);
+    };
     for (int j = 0; j < kRecSlots; ++j) {
         unsigned short k = 0;
         float d = 0.0f;
-        (void)hipMemcpy(&k, ws->rec_k + (int64_t)j * ws->npad + row, sizeof(k), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&d, ws->rec_d + (int64_t)j * ws->npad + row, sizeof(d), hipMemcpyDeviceToHost);
+        get(&k, ws->rec_k + (int64_t)j * ws->npad + row, sizeof(k));
+        get(&d, ws->rec_d + (int64_t)j * ws->npad + row, sizeof(d));
         out[j] = k == kRecEmpty ? -1.0 : (double)k;
         out[8 + j] = d;
     }
     float B = 0.0f;
     unsigned char ex = 0, sel = 0, fl = 0;
     int kh = 0;
-    (void)hipMemcpy(&B, ws->rec_B + row, sizeof(B), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(&ex, ws->rec_exact + row, 1, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(&sel, ws->rec_sel + row, 1, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(&fl, ws->rec_flags + row, 1, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(&kh, ws->khat + row, sizeof(kh), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(out + 21, ws->lse + row, sizeof(double), hipMemcpyDeviceToHost);
+    get(&B, ws->rec_B + row, sizeof(B));
+    get(&ex, ws->rec_exact + row, 1);
+    get(&sel, ws->rec_sel + row, 1);
+    get(&fl, ws->rec_flags + row, 1);
+    get(&kh, ws->khat + row, sizeof(kh));
+    get(out + 21, ws->lse + row, sizeof(double));
     out[16] = B;
     out[17] = ex;
     out[18] = sel;
@@ -397,9 +411,10 @@ int gmmvb_debug_record(gmmvb_workspace* ws, int64_t row, double* out /*[26] host
     out[20] = kh;
     for (int w = 0; w < 4; ++w) {
         unsigned long long m = 0;
-        if (w < (ws->K + 63) / 64) (void)hipMemcpy(&m, ws->masks + (int64_t)w * ws->npad + row, sizeof(m), hipMemcpyDeviceToHost);
+        if (w < (ws->K + 63) / 64) get(&m, ws->masks + (int64_t)w * ws->npad + row, sizeof(m));
         out[22 + w] = (double)m;
     }
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "reading a record back", e);
     return GMMVB_OK;
 }
 
@@ -862,7 +877,10 @@ static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepI8Args& a8, 
 // masks -> per-component lists -> chunk plan -> exact f64 evaluation of the listed pairs (all sized on the device)
 static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int is64, bool vec, int sel_grid, hipStream_t st,
                                    const float* thr = nullptr) {
-    if (thr) (void)hipMemsetAsync(ws->exit_ctr, 0, sizeof(unsigned long long), st);
+    if (thr) {
+        hipError_t em = hipMemsetAsync(ws->exit_ctr, 0, sizeof(unsigned long long), st);
+        if (em != hipSuccess) return em;
+    }
     span_begin(ws, kSpanSelect, st);
     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, a.n_rows, ws->K, ws->blk,
@@ -891,7 +909,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int R = generic_rows(ws->D);
         const dim3 grid((unsigned)((n_rows + R - 1) / R), (unsigned)ws->K);
         const size_t lds = (size_t)ws->D * R * sizeof(double);
-        if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
+        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[0], st));
         ws->n_spans = 0;
         span_begin(ws, kSpanEstepMain, st);
         if (is64)
@@ -902,7 +920,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                ws->gen_u, ws->gen_m, ws->cvec, R, ws->lnrho, ws->npad);
         span_end(ws, st);
         if (ws->prof) {
-            (void)hipEventRecord(ws->ev[1], st);
+            note_hip(ws, hipEventRecord(ws->ev[1], st));
             ws->ev_e = true;
         }
         span_begin(ws, kSpanLse, st);
@@ -924,7 +942,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->prev_pass = 0;
         ws->evaluated = (double)n_rows * ws->K;
         std::snprintf(ws->info, sizeof(ws->info), "estep_generic_f64<D=%d> grid=%ux%ux64 rows/workgroup=%d", ws->D, grid.x, grid.y, R);
-        return GMMVB_OK;
+        return take_hip(ws, "event record inside the E-step");
     }
     const bool i8 = ws->estep_variant == kEstepI8;
     EstepArgs a{x_dev, ldx, n_rows, ws->D, ws->img, ws->cvec, ws->K, ws->lnrho, ws->npad};
@@ -978,9 +996,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th): below 0.5 the bounds are
             // made afresh.
             const double tg = ws->typical_gamma;
-            const bool carry = false;
             bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5);
-            if ((carry || sweep) && known && L.mode != kDense) {
+            if (sweep && known && L.mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
                 // (a pair of the proof round costs about a third of an exact evaluation)
@@ -1032,8 +1049,10 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const bool keep = mode != kDense && same_rows && !ws->lock_reset && !ws->delta_pending;
         if (ws->lock_reset || (ws->lock_live && !keep)) {
             if (mode == kSweep) mode = kBound;
-            (void)hipMemsetAsync(ws->lock, 0, (size_t)ws->npad, st);
-            (void)hipMemsetAsync(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double), st);
+            // (a failed reset would leave stale addends in the cache: the pass must not go on)
+            e = hipMemsetAsync(ws->lock, 0, (size_t)ws->npad, st);
+            if (e == hipSuccess) e = hipMemsetAsync(ws->cache, 0, (size_t)gmmvb_stats_len(ws->K, ws->D) * sizeof(double), st);
+            if (e != hipSuccess) return fail(GMMVB_EHIP, "resetting the cache of single-component rows", e);
             ws->lock_live = false;
             ws->skip_used = false;
         }
@@ -1107,7 +1126,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
 
     int rpw = 0;
     int64_t grid = 0;
-    if (ws->prof) (void)hipEventRecord(ws->ev[0], st);
+    if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[0], st));
     ws->n_spans = 0;
     // a bound pass rebuilds everything row-indexed anyway: the moment to regroup the internal row order by the best
     // component of the previous pass (once at most 4 components per row are active: later passes are list-driven)
@@ -1142,7 +1161,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
         ++ws->passes[0];
         if (ws->prof) {
-            (void)hipEventRecord(ws->ev[1], st);
+            note_hip(ws, hipEventRecord(ws->ev[1], st));
             ws->ev_e = true;
         }
         const int lse_blocks = (int)((n_rows + kLseRows - 1) / kLseRows);
@@ -1277,7 +1296,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 }
                 span_begin(ws, kSpanSelect, st);
                 if (ws->tmeta) {
-                    (void)hipMemsetAsync(ws->exit_ctr + 1, 0, sizeof(unsigned long long), st);
+                    note_hip(ws, hipMemsetAsync(ws->exit_ctr + 1, 0, sizeof(unsigned long long), st));
                     // (the tile state is void after any pass that rewrote the bounds wholesale: the first sweep after it
                     // opens every column and takes stock)
 #define GMMVB_LAZY_SWEEP(WC)                                                                                                   \
@@ -1341,7 +1360,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         e = lists_and_gather(ws, a, is64, vec, sel_grid, st, ws->gather_exit ? ws->rthr : nullptr);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate evaluation", e);
         if (ws->prof) {
-            (void)hipEventRecord(ws->ev[1], st);
+            note_hip(ws, hipEventRecord(ws->ev[1], st));
             ws->ev_e = true;
         }
         span_begin(ws, kSpanLse, st);
@@ -1349,7 +1368,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                            ws->cvec, ws->lse, ws->khat, ws->masks, ws->blk, ws->apart, ws->mpart, ws->ub32,
                            settle ? ws->lock : nullptr, ws->dlock, skip_margin, settle ? ws->dmask : nullptr,
                            settle ? ws->dblk : nullptr, ws->mmask, ws->mblk, ws->spart, ws->gpart, ws->qpart, ws->rthr, ws->lcomp);
-        if (!proof_ran) (void)hipMemsetAsync(ws->ctr + 7, 0, sizeof(double), st);
+        if (!proof_ran) note_hip(ws, hipMemsetAsync(ws->ctr + 7, 0, sizeof(double), st));
         hipLaunchKernelGGL(sum_parts_kernel, dim3(proof_ran ? 8 : 7), dim3(1024), 0, st, ws->apart, ws->epart, ws->opart, ws->mpart,
                            ws->spart, ws->gpart, ws->qpart, ws->ppart, sel_grid, ws->ctr);
         e = hipGetLastError();
@@ -1407,7 +1426,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (mode == kDense || mode == kBound) ws->sweeps = 0;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
                   (i8 || mode != kDense) ? 512 : estep_threads(ws->estep_variant), rpw);
-    return GMMVB_OK;
+    return take_hip(ws, "event record / counter reset inside the E-step");
 }
 
 int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_t n_rows, void* stream) {
@@ -1456,7 +1475,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int64_t rps = round_up((n_rows + S - 1) / S, 64);
         S = (int)((n_rows + rps - 1) / rps);
         const int tiles = tri_pairs(ws->T);
-        if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
+        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[2], st));
         span_begin(ws, kSpanMstepMain, st);
         if (ws->x_dtype == GMMVB_F64) {
             hipLaunchKernelGGL(mstep_generic_first_kernel<double>, dim3(ws->K, S), dim3(256), 0, st, (const double*)x_dev, ldx, n_rows,
@@ -1471,7 +1490,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
         span_end(ws, st);
         if (ws->prof) {
-            (void)hipEventRecord(ws->ev[3], st);
+            note_hip(ws, hipEventRecord(ws->ev[3], st));
             ws->ev_m = true;
         }
         span_begin(ws, kSpanReduce, st);
@@ -1484,7 +1503,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ++ws->passes[5];
         const size_t used = std::strlen(ws->info);
         std::snprintf(ws->info + used, sizeof(ws->info) - used, " | mstep_generic_f64<D=%d> tiles=%d splits=%d", ws->D, tiles, S);
-        return GMMVB_OK;
+        return take_hip(ws, "event record inside the M-step");
     }
     // row splits: ~4 workgroups per CU in total, whole 64-row groups per split, S a multiple of 8 where possible
     int64_t S = ws->S_cap;
@@ -1535,7 +1554,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         rc = ensure_lists(ws);
         if (rc) return rc;
         const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
-        if (ws->prof) (void)hipEventRecord(ws->ev[2], st);      // the list building is part of the M-step's time
+        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[2], st));      // the list building is part of the M-step's time
         const int cap_chunks0 = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
         const int r_min0 = 1024;           // list entries per chunk (2048: +4 %, 4096: +19 % on the list M-step, round 2)
         MstepListArgs la0{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks0, r_min0,
@@ -1628,7 +1647,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ++ws->passes[6];
     } else {
         ++ws->passes[5];
-        if (ws->prof) (void)hipEventRecord(ws->ev[2], st);
+        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[2], st));
         if (pre && ws->xc_stale) {             // the dense kernel reads the centred copy: bring it to the internal row order
             e = recenter_rows(ws, n_rows, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
@@ -1648,7 +1667,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);
     if (ws->prof) {
-        (void)hipEventRecord(ws->ev[3], st);
+        note_hip(ws, hipEventRecord(ws->ev[3], st));
         ws->ev_m = true;
     }
     const int elems = tri_pairs(ws->T) * 256 + 16 * ws->T + 2;
@@ -1665,7 +1684,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const size_t used = std::strlen(ws->info);
     std::snprintf(ws->info + used, sizeof(ws->info) - used, " | %s grid=%lldx%d splits=%lld rows/split=%lld", name,
                   (long long)grid, mstep_threads(ws->T, pre), (long long)S, (long long)rows_per_split);
-    return GMMVB_OK;
+    return take_hip(ws, "event record inside the M-step");
 }
 
 int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, double* stats_dev,

@@ -187,6 +187,7 @@ struct gmmvb_workspace {
     int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly, 3 HMM gamma
     int64_t e_rows = 0;
     char info[512] = {0};
+    hipError_t hip_err = hipSuccess;   // first failed event record / counter reset of the pass in flight (capi.hip: note_hip)
     // launches since the workspace was created (gmmvb_pass_counts): E dense, E bound pass, E carried bounds,
     // pruned E-step that fell back to the dense kernel, E sweep of carried bounds, M dense, M lists,
     // candidate gathers

@@ -71,7 +71,10 @@ def parse_args():
     ap.add_argument("--ref-rows", type=int, default=20_000)
     ap.add_argument("--overlap", action="store_true", help="hard workload: cluster means 0.3 * randn instead of 2 * randn")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
-    ap.add_argument("--no-legs", action="store_true", help="skip the dense and hard-workload legs")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the dense, hard-workload, spread-sweep, full-fit and HMM legs")
+    ap.add_argument("--legs", default="dense,hard,spread,full,hmm",
+                    help="comma-separated legs of the single-GPU run (dense, hard, spread, full, hmm)")
     ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
     ap.add_argument("--force-dist", action="store_true",
                     help="join an RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
@@ -379,6 +382,10 @@ def main():
         seqs = [None] * world
         dist.all_gather_object(seqs, [kernel_name(l) for l in launches])
         policy_same = all(q == seqs[0] for q in seqs)
+        # every rank's own clock and step times, so that a straggler shows (value uses the max over ranks)
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, dict(rank=rank, elapsed_s=elapsed, ms_per_step=elapsed / args.steps * 1e3,
+                                                wall_ms=[round(v, 2) for v in walls], rows=int(n_local)))
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -387,6 +394,8 @@ def main():
         n_total = int(tot.item())
     else:
         n_total = n_local
+        ranks_info = [dict(rank=0, elapsed_s=elapsed, ms_per_step=elapsed / args.steps * 1e3,
+                           wall_ms=[round(v, 2) for v in walls], rows=int(n_local))]
 
     if rank == 0:
         steps = args.steps
@@ -493,14 +502,24 @@ def main():
         assert roof["frac"] <= 1.0 + 1e-9, roof
 
         last_launch = eng.launch_info
-        dense_leg = hard = None
+        dense_leg = hard = spread_leg = full_leg = hmm_leg = None
         if not args.dense and world == 1 and not args.no_legs:
-            dense_leg = dense_leg_run(w, K, D, n_local, fl_pair)
+            legs = set(args.legs.split(","))
+            if "dense" in legs:
+                dense_leg = dense_leg_run(w, K, D, n_local, fl_pair)
             w.close()
-            del w, x
+            del w
             torch.cuda.empty_cache()
-            if not args.overlap:
+            if "full" in legs and not args.overlap:
+                full_leg = full_fit_leg(K, D, x, dev)
+            del x
+            torch.cuda.empty_cache()
+            if "hard" in legs and not args.overlap:
                 hard = hard_workload_leg(K, D, n_local, tdtype, ndtype, dev, parity=do_cpu)
+            if "spread" in legs and not args.overlap:
+                spread_leg = spread_sweep_leg(K, D, min(n_local, 2_000_000), tdtype, ndtype, dev, parity=do_cpu)
+            if "hmm" in legs and args.config == "c3":
+                hmm_leg = hmm_c5_leg(dev, cpu=do_cpu)
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
             "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
@@ -515,7 +534,8 @@ def main():
                                    f"{', overlapping clusters' if args.overlap else ''})",
                        "classes": K, "degree": D, "rows_per_gpu": n_local, "rows_total": n_total, "x_storage": dt,
                        "cluster_spread": spread, "parallelism": f"rows{world}"},
-            "roofline": roof, "dense": dense_leg, "hard_workload": hard,
+            "roofline": roof, "dense": dense_leg, "hard_workload": hard, "spread_sweep": spread_leg,
+            "full_fit": full_leg, "hmm_c5": hmm_leg, "per_rank": ranks_info,
             "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,
             "launch": last_launch, "warmup_steps": warm,
             "per_step": {"wall_ms": [round(v, 2) for v in walls],
@@ -594,6 +614,102 @@ def hard_workload_leg(K, D, n_local, tdtype, ndtype, dev, warmup=2, steps=3, par
         x_ref = recipe_rows_host(K, D, min(6000, n_local), ndtype, 0.3)
         _base, out["parity"], out["parity_sparse_path"] = cpu_baseline_and_parity(K, D, x_ref, dev, iters=6)
     return out
+
+
+def policy_run(K, D, x, dev, warmup, steps, **switches):
+    """`steps` timed VB iterations after `warmup` on x under the library switches given: ms per step, pass kinds, pairs."""
+    import torch
+    with env_vars(**switches):
+        w = Workload(K, D, x, dev, None)
+    for _ in range(warmup):
+        w.step()
+    c0 = w.eng.pass_counts()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    walls, act, ev, kinds = [], [], [], []
+    for _ in range(steps):
+        ts = time.perf_counter()
+        w.step()
+        walls.append((time.perf_counter() - ts) * 1e3)
+        a, e = w.eng.sparsity()
+        act.append(a / w.n if a >= 0 else float(K))
+        ev.append(e / w.n)
+        kinds.append(kernel_name(w.eng.launch_info.split("|")[0]))
+    torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    c1 = w.eng.pass_counts()
+    out = {"ms_per_step": dt_s / steps * 1e3, "wall_ms": [round(v, 2) for v in walls],
+           "kernel_launches": {k: c1[k] - c0[k] for k in c1 if c1[k] - c0[k]},
+           "estep_kernel": kinds, "active_pairs_per_row": [round(v, 2) for v in act],
+           "evaluated_pairs_per_row": [round(v, 2) for v in ev],
+           "mean_active_pairs_per_row": float(np.mean(act)), "mean_evaluated_pairs_per_row": float(np.mean(ev))}
+    w.close()
+    return out
+
+
+def spread_sweep_leg(K, D, n, tdtype, ndtype, dev, spreads=(0.5, 0.75, 1.0, 1.5), warmup=2, steps=20, parity=True):
+    """The middle of the separation spectrum (the headline's recipe puts the cluster means 2 * randn apart, the hard
+    workload 0.3 * randn): same shape, cluster means spread * randn, iterations 3-22 of one restart under the default
+    policy and with the dense kernels only; the default policy must never be slower than 1.1 x the dense step."""
+    import torch
+    rows = []
+    for sp in spreads:
+        x = device_rows(K, D, n, tdtype, dev, SEED + 101, sp)
+        r = {"spread": sp, "rows": n, "default": policy_run(K, D, x, dev, warmup, steps),
+             "dense": policy_run(K, D, x, dev, warmup, steps, GMMVB_ESTEP_PRUNE="0", GMMVB_MSTEP_SPARSE="0")}
+        for k in ("wall_ms", "estep_kernel", "active_pairs_per_row", "evaluated_pairs_per_row"):
+            r["dense"].pop(k, None)
+        r["default_over_dense"] = r["default"]["ms_per_step"] / r["dense"]["ms_per_step"]
+        del x
+        torch.cuda.empty_cache()
+        if parity:       # a bounded oracle run on rows of the same mixture (6 iterations over 6000 rows), both policies
+            x_ref = recipe_rows_host(K, D, min(6000, n), ndtype, sp)
+            _b, p0, p1 = cpu_baseline_and_parity(K, D, x_ref, dev, iters=6)
+            r["parity"] = {k: p0[k] for k in ("max_rel_err", "passed", "rows", "iterations", "path")}
+            r["parity_sparse_path"] = {k: p1[k] for k in ("max_rel_err", "passed", "rows", "iterations", "path")}
+        rows.append(r)
+    return {"workload": f"K={K} D={D} N={n}, cluster means spread * randn; iterations {warmup + 1}-{warmup + steps} of one restart",
+            "steps": steps, "warmup": warmup, "spreads": rows,
+            "worst_default_over_dense": max(r["default_over_dense"] for r in rows)}
+
+
+def full_fit_leg(K, D, x, dev, max_itr=25, num_init=2):
+    """A whole fit through the public API on the resident matrix: update_posterior(max_itr, num_init, tolerance=0)."""
+    import torch
+    from bayesml_amd import gaussianmixture as gm
+    m = gm.LearnModel(K, D, seed=0, device=dev, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.update_posterior(x, max_itr=1, num_init=1, tolerance=0.0)      # first call: workspace allocation + three data passes
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        c0 = m._engine.pass_counts()
+        t0 = time.perf_counter()
+        m.update_posterior(x, max_itr=max_itr, num_init=num_init, tolerance=0.0)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        c1 = m._engine.pass_counts()
+    passes = num_init * (max_itr + 1) + 1
+    hn = m.get_hn_params()
+    out = {"what": f"update_posterior(max_itr={max_itr}, num_init={num_init}, tolerance=0) through the public API, x resident",
+           "seconds": el, "data_passes": passes, "ms_per_data_pass": el / passes * 1e3,
+           "samples_per_s_per_data_pass": x.shape[0] * passes / el,
+           "first_call_seconds_workspace_plus_3_passes": first,
+           "kernel_launches": {k: c1[k] - c0[k] for k in c1 if c1[k] - c0[k]},
+           "checksum_hn_m_vecs": float(np.abs(hn["hn_m_vecs"]).sum()), "final_vl": float(m.vl)}
+    m._engine.close()
+    m._engine = None
+    return out
+
+
+def hmm_c5_leg(dev, steps=3, warmup=1, cpu=True):
+    """BASELINE.json configs[4] (hiddenmarkovnormal.LearnModel K=32, D=16, T=1e7): tools/bench_hmm.py's measurement."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_hmm
+    a = argparse.Namespace(steps=steps, warmup=warmup, rows=10_000_000, classes=32, degree=16, ref_rows=4000, no_cpu=not cpu)
+    return bench_hmm.measure(a, dev)
 
 
 if __name__ == "__main__":

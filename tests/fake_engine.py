@@ -134,6 +134,25 @@ class CpuDataPass:
         self.estep(x)
         return self.mstep(x, out)
 
+    # ---- one pass policy for all ranks (semantics of gmmvb_set_shard / gmmvb_policy_export / gmmvb_policy_import):
+    # the counters ride behind the statistics block through the iteration's ONE all-reduce; `policy_log` keeps what came
+    # back so that a test can check every rank saw the same job-wide sums at every iteration
+    def set_shard(self, global_rows, n_ranks):
+        self._shard = (int(global_rows), int(n_ranks))
+        self.policy_log = []
+
+    def policy_export(self, tail):
+        r = self.responsibilities()
+        tail.zero_()
+        tail[0] = float((r >= 2.0 ** -100).sum())       # active pairs of this rank's rows
+        tail[1] = float(r.numel())                      # pairs evaluated exactly (the stand-in is dense)
+        tail[9] = float(r.shape[0])                     # rows
+        tail[10] = 1.0                                  # ranks
+        tail[11] = 1.0                                  # ranks whose pass counted its pairs
+
+    def policy_import(self, tail):
+        self.policy_log.append(tail.clone())
+
     def split_stats(self, stats):
         K, D = self.K, self.D
         return (stats[:K], stats[K:2 * K], stats[2 * K:2 * K + K * D].view(K, D),

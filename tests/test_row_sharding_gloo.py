@@ -24,6 +24,50 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _worker8(rank, world, port, cuts, kw, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_engine import cpu_factory
+    from bayesml_amd import RowShard
+    from bayesml_amd import gaussianmixture as gm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = load_golden("gmm_c1_sample.npz")["x"]
+    m = gm.LearnModel(3, 2, seed=0, comm=RowShard())
+    m._data_pass_factory = cpu_factory
+    with redirect_stdout(io.StringIO()) as buf, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.update_posterior(x[cuts[rank]:cuts[rank + 1]], **kw)
+    log = torch.stack(m._engine.policy_log).numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), vl=m.vl, ns=m.ns, stdout=buf.getvalue(), policy=log,
+             shard=np.array(m._engine._shard), **m.get_hn_params())
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_with_policy_tail(tmp_path):
+    """world_size = 8 (the driver's largest run): uneven shards, one of a single row; the pass-policy counters ride behind
+    the statistics block through the same all-reduce and every rank gets the same job-wide sums at every iteration."""
+    world = 8
+    cuts = [0, 1, 130, 260, 391, 500, 640, 871, 1000]
+    kw = dict(num_init=2, max_itr=12)
+    mp.spawn(_worker8, args=(world, _free_port(), cuts, kw, str(tmp_path)), nprocs=world, join=True)
+    ranks = [dict(np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))) for r in range(world)]
+    one = _single(kw)
+    for r, res in enumerate(ranks):
+        for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+            assert rel_err(res[key], one.get_hn_params()[key]) < 1e-9, (r, key)
+        assert abs(float(res["vl"]) - one.vl) < 1e-8 * abs(one.vl)
+        assert list(res["shard"]) == [1000, world]                       # gmmvb_set_shard: the job's rows and ranks
+        pol = res["policy"]                                              # [data passes][GMMVB_POLICY_LEN]
+        assert pol.shape[0] == 2 * (12 + 1) + 1 or pol.shape[0] == 2 * (12 + 1)
+        assert np.all(pol[:, 9] == 1000.0) and np.all(pol[:, 10] == world) and np.all(pol[:, 11] == world)
+        assert np.all(pol[:, 1] == 3000.0)                               # pairs of all ranks' rows
+        assert np.array_equal(pol, ranks[0]["policy"])                   # the same numbers on every rank, every pass
+    assert str(ranks[0]["stdout"]).count("\n") == 2 and all(str(ranks[r]["stdout"]) == "" for r in range(1, world))
+
+
 def _worker(rank, world, port, cuts, kw, out_dir):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -46,19 +46,12 @@ def synth_device(K, D, T, dtype, dev, seed=20250711, stay=0.9, head=None):
     return x
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=10_000_000)
-    ap.add_argument("--classes", type=int, default=32)
-    ap.add_argument("--degree", type=int, default=16)
-    ap.add_argument("--ref-rows", type=int, default=20_000)
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+def measure(args, dev=None):
+    """The measurement itself (also bench.py's ``hmm_c5`` leg): returns the JSON line as a dict."""
     K, D, T = args.classes, args.degree, args.rows
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    if dev is None:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
 
     cpu = parity = None
     x_ref = None
@@ -153,14 +146,29 @@ def main():
             roofline["traffic_source"] = "profiles/hmm_pmc_traffic.json: " + pm["note"]
     except (OSError, ValueError, KeyError):
         pass
-    print(json.dumps({
+    eng.close()
+    m._engine = None
+    del x, xd
+    return ({
         "metric": "HMM-VB time steps/sec at K=32,D=16,T=1e7 (BASELINE.json configs[4])", "value": T * args.steps / el,
         "unit": "time steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"HMM-VB K={K} D={D} T={T}, x stored f32, one VB iteration per step"},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "final_vl": vl,
         "viterbi": {"ms": viterbi_ms, "time_steps_per_s": T / (viterbi_ms * 1e-3), "states_visited": int(torch.unique(z).numel()),
-                    "note": "hmmvb_viterbi over all T steps after the emission E-step (round 2: one sequential wave, ~10 s)"}}))
+                    "note": "hmmvb_viterbi over all T steps after the emission E-step (round 2: one sequential wave, ~10 s)"}})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--classes", type=int, default=32)
+    ap.add_argument("--degree", type=int, default=16)
+    ap.add_argument("--ref-rows", type=int, default=20_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    print(json.dumps(measure(ap.parse_args())))
 
 
 if __name__ == "__main__":
