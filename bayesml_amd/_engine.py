@@ -85,14 +85,23 @@ class EngineLimitError(ValueError):
 
 MAX_MFMA_DEGREE = 128     # up to here the data pass runs on the MFMA kernels; beyond, on the plain f64 kernels of csrc/generic.h
 MAX_HMM_FAST_CLASSES = 64 # up to here the HMM recursions run chunk-parallel on MFMA; beyond, sequentially (csrc/hmm_generic.h)
-MAX_HMM_CLASSES = 65535   # hmmvb_enable: 16-bit back-pointers
+# What the correctness kernels can still LAUNCH (derived from their shapes, so that a too large model is refused at
+# construction instead of failing with GMMVB_EHIP inside update_posterior after the data is on the GPU):
+#   hmm_generic.h: hmm_xi_generic_kernel has grid.y = (ceil(K / 16))^2 <= 65535  ->  K <= 16 * 255;
+#                  hmm_seq_shape(K).lds_bytes = (3 K + 1056) * 8 (+ 4 KB static in Viterbi) <= 160 KB  ->  K <= 6304
+#   generic.h:     generic_rows(D) = 1 still keeps one centred row, D * 8 bytes, in LDS (<= 150 KB)  ->  D <= 19200
+MAX_HMM_CLASSES = 16 * 255
+MAX_DEGREE = 19200
 
 
 def check_limits(c_degree: int, c_num_classes: int = 1, hmm: bool = False):
     """Raised at model construction, so that an unsupported shape does not surface as an EngineError from inside
     update_posterior after the sample matrix has already been copied to the GPU.  (c_degree has no limit: above 128 the
     engine switches to its generic f64 kernels, and an HMM with more than 64 states to sequential recursions - same
-    results, far slower.)"""
+    results, far slower - up to the sizes those kernels can launch.)"""
+    if c_degree > MAX_DEGREE:
+        raise EngineLimitError(f"bayesml_amd supports c_degree <= {MAX_DEGREE} in this version (got {c_degree}); "
+                               "bayesml itself has no such limit")
     if hmm and c_num_classes > MAX_HMM_CLASSES:
         raise EngineLimitError(f"bayesml_amd.hiddenmarkovnormal supports c_num_classes <= {MAX_HMM_CLASSES} in this "
                                f"version (got {c_num_classes}); bayesml itself has no such limit")
@@ -176,9 +185,15 @@ class RcclComm:
             self._comm = None
 
     def __del__(self):
+        # Never destroy the communicator from a finaliser at interpreter exit: by then torch may have torn down its process
+        # group or the HIP runtime, the order differs between ranks, and a hang inside ncclCommDestroy cannot be caught.
+        # Leaking it at exit is safe; RowShard.close() / RcclComm.close() is the orderly way.
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
-        except Exception:      # noqa: BLE001  (interpreter shutdown)
+        except Exception:      # noqa: BLE001
             pass
 
 
@@ -576,6 +591,7 @@ class TiledDataPass:
         self._x = self._r = None
         self._params = None
         self._held = None              # tile whose E-step the inner workspace currently holds
+        self._src = None               # what the read-outs describe: 'loaded' responsibilities or the 'estep' under the parameters
         self._infos, self._work, self._spars, self._ms = [], None, None, (0.0, 0.0)
         self.rows = 0
         self.inner.set_shard(self._global_rows, self.n_tiles)
@@ -662,6 +678,7 @@ class TiledDataPass:
         self._r = torch.as_tensor(r, dtype=torch.float64, device=self.device)
         self.rows = self._r.shape[0]
         self._held = None
+        self._src = "loaded"
 
     # -- the data pass
     def _run(self, x, out, estep):
@@ -671,6 +688,7 @@ class TiledDataPass:
         stats.zero_()
         if estep:
             self._r = None
+            self._src = "estep"
         self._tail_acc.zero_()
         self._infos, act, ev, acc, e_ms, m_ms = [], 0.0, 0.0, 0.0, 0.0, 0.0
         counted = True
@@ -719,12 +737,13 @@ class TiledDataPass:
 
     def mstep(self, x, out=None):
         self._x = x
-        if self._r is not None and self._held is None:
+        if self._src == "loaded":
             return self._run(x, out, False)
         return self._run(x, out, True)             # statistics of the E-step under the parameters in force
 
     def estep(self, x):
         self._x, self.rows, self._held = x, x.shape[0], None
+        self._r, self._src = None, "estep"
 
     # -- read-outs: rows [row0, row0 + n) in the caller's order, tile by tile
     def _readout(self, what, row0, n, dtype, cols):
@@ -738,7 +757,7 @@ class TiledDataPass:
             if self._held != t:
                 xt = self._x[lo:hi]
                 self.inner.prepare_rows(xt)
-                if self._r is not None and self._params is None:
+                if self._src == "loaded":
                     self.inner.load_responsibilities(self._r[lo:hi])
                 else:
                     self.inner.estep(xt)

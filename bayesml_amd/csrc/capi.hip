@@ -644,7 +644,8 @@ __global__ void policy_export_kernel(const double* __restrict__ ctr, const unsig
     out[9] = rows;
     out[10] = 1.0;                      // ranks
     out[11] = counted ? 1.0 : 0.0;      // ranks whose pass counted its pairs
-    for (int i = 12; i < GMMVB_POLICY_LEN; ++i) out[i] = 0.0;
+    out[12] = (double)mode;             // kind of the pass these counters describe (the same on every rank: sum / ranks)
+    for (int i = 13; i < GMMVB_POLICY_LEN; ++i) out[i] = 0.0;
 }
 }  // namespace
 
@@ -704,7 +705,9 @@ static int take_policy(gmmvb_workspace* ws) {
     p.exits = h[8];
     p.rows = h[9];
     p.ranks = h[10];
-    p.mode = ws->pol_mode;
+    // the kind of the pass the counters were taken in travels with them: a row-tiled pass imports the same job-wide tail
+    // before every tile, when this workspace's last pass is already the previous TILE of the current iteration
+    p.mode = h[10] >= 1.0 ? (int)(h[12] / h[10] + 0.5) : ws->pol_mode;
     p.valid = h[10] >= 1.0 && h[11] == h[10];
     if (p.valid && ws->sorted && !ws->pol_first_sorted) ws->moved_since_sort += p.moved;
     ws->pol_pending = false;

@@ -47,9 +47,11 @@ def run(name, K, D, N, spread=2.0, **kw):
 
 
 def main():
-    which = sys.argv[1:] or ["overlap", "k64", "k256"]
+    which = sys.argv[1:] or ["overlap", "mid", "k64", "k256"]
     if "overlap" in which:
         run("gmm_f3_k16_d64_n32768_f32_overlap.npz", 16, 64, 32768, spread=0.3, num_init=1, max_itr=12, tolerance=0.0)
+    if "mid" in which:       # the middle of the separation spectrum: 2-10 components active per row for most of the run
+        run("gmm_f3_k16_d64_n32768_f32_spread1.npz", 16, 64, 32768, spread=1.0, num_init=1, max_itr=12, tolerance=0.0)
     if "k64" in which:
         run("gmm_f3_k64_d128_n140000_f32.npz", 64, 128, 140000, num_init=1, max_itr=12, tolerance=0.0)
     if "k256" in which:

@@ -132,7 +132,11 @@ LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n1400
          ("gmm_f3_k256_d64_n36000_f32.npz", "nolazy"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
-         ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "dense")]
+         ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_overlap.npz", "dense"),
+         # the middle of the separation spectrum (cluster means 1.0 * randn: 2-10 components active per row): where the
+         # policy's choice between dense, bound pass and sweep is closest
+         ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nolazy"),
+         ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nocarry"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "default")]
 
 
 @pytest.mark.parametrize("name,variant", LARGE)
@@ -143,9 +147,9 @@ def test_large_fixture_matches_reference(name, variant):
     K, D, N = int(g["K"]), int(g["D"]), int(g["N"])
     x = orc.synth_gmm(int(g["K_data"]), D, N, np.float32, spread=float(g["spread"]))
     m, counts, trace = run_driver(g, x, variant)
-    if "overlap" in name:
-        if variant == "force":          # everything is a candidate: the pruned E-step must still be exact
-            assert counts["estep_bound"] >= 1, counts
+    if "overlap" in name or "spread1" in name:
+        if variant.startswith("force"):     # (nearly) everything is a candidate: the pruned E-step must still be exact
+            assert counts["estep_bound"] >= 1 and counts["estep_gather"] >= 2, counts
     else:
         expect_kernels(counts, variant)
     check_trace(trace, g, 1e-8)
@@ -165,7 +169,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if "overlap" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled"):
+    if "overlap" not in name and "spread1" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -180,7 +184,7 @@ def test_large_fixture_matches_reference(name, variant):
             assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
         if variant in ("nosettle", "noproof"):      # (without settled rows the proof round still serves the bound passes)
             assert wk["settled_rows"] == 0 and (wk["proof_pairs"] == 0 or variant == "nosettle"), wk
-    if variant == "default" and "overlap" not in name:
+    if variant == "default" and "overlap" not in name and "spread1" not in name:
         # the workspace regrouped its internal row order by dominant component on the way: every
         # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless
         # in the caller's row order

@@ -64,3 +64,36 @@ def test_tiled_run_equals_untiled(init_type, force):
                                        orc.Posterior.from_prior(orc.Prior.default(K, D)), np.random.default_rng(0),
                                        max_itr=8, num_init=2, tolerance=0.0)
         assert rel_err(til.hn_m_vecs, ref.posterior.m) < 1e-7 and rel_err(til.hn_w_mats, ref.posterior.w) < 1e-7
+
+
+def test_tiled_readout_after_loaded_responsibilities():
+    """Responsibilities loaded into an engine that already holds parameters are what the read-outs return (not an E-step
+    under those parameters), and an M-step after an E-step re-runs that E-step - same behaviour as DataPass."""
+    from bayesml_amd._engine import DataPass, TiledDataPass
+    K, D, N = 5, 32, 20_000
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(orc.synth_gmm(K, D, N, np.float32)).to(dev)
+    r = torch.from_numpy(rng.dirichlet(np.ones(K), N)).to(dev)
+    c = torch.zeros(K, dtype=torch.float64, device=dev)
+    m = torch.from_numpy(rng.standard_normal((K, D))).to(dev)
+    u = torch.eye(D, dtype=torch.float64, device=dev).repeat(K, 1, 1).contiguous()
+    outs = []
+    for eng in (DataPass(K, D, x.dtype, N, dev), TiledDataPass(K, D, x.dtype, N, dev, 6016)):
+        eng.set_pivot(torch.zeros(D, dtype=torch.float64, device=dev))
+        eng.prepare_rows(x)
+        eng.set_params(c, m, u)
+        st_e = eng.estep_mstep(x).clone()
+        r_e = eng.responsibilities().clone()
+        eng.load_responsibilities(r)
+        r_back = eng.responsibilities()
+        assert torch.equal(r_back, r)                                        # the loaded values, not an E-step
+        assert torch.equal(eng.argmax(), torch.argmax(r, dim=1).to(torch.int32))
+        st_l = eng.mstep(x).clone()
+        assert float((st_l[:K] - r.sum(dim=0)).abs().max()) < 1e-9
+        eng.estep(x)
+        assert float((eng.responsibilities() - r_e).abs().max()) < 1e-12      # back to the E-step under the parameters
+        outs.append((st_e, st_l, r_e))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).abs().max() / a.abs().max()) < 1e-12
