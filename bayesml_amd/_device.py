@@ -16,10 +16,9 @@ class DeviceModel:
     """Mixin for LearnModel classes.  Expects ``c_degree``, ``c_num_classes``, ``rng``, ``_device``,
     ``_comm``, ``_verbose``, ``_engine``, ``_x_dev``, ``_r_cache``, ``_data_pass_factory`` on the instance."""
 
-    def _open(self, x):
-        """Validate ``x`` like the reference (gaussianmixture ref:829-834, hiddenmarkovnormal ref:1055-1061),
-        move it to the GPU once, (re)create the workspace, set the pivot, build the centred copy."""
-        D, K = self.c_degree, self.c_num_classes
+    def _check_rows(self, x):
+        """Validate ``x`` like the reference (gaussianmixture ref:829-834, hiddenmarkovnormal ref:1055-1061) -> [N, D]."""
+        D = self.c_degree
         if isinstance(x, torch.Tensor):
             if not (x.dtype.is_floating_point and x.dim() >= 1):
                 raise DataFormatError("x must be a numpy.ndarray whose ndim >= 1.")
@@ -27,7 +26,12 @@ class DeviceModel:
             _check.float_vecs(x, "x", DataFormatError)
         if x.shape[-1] != D:
             raise DataFormatError(f"x.shape[-1] must be self.c_degree: x.shape[-1]={x.shape[-1]}, self.c_degree={D}")
-        x = x.reshape(-1, D)
+        return x.reshape(-1, D)
+
+    def _open(self, x):
+        """Validate ``x``, move it to the GPU once, (re)create the workspace, set the pivot, build the centred copy."""
+        D, K = self.c_degree, self.c_num_classes
+        x = self._check_rows(x)
         if self._data_pass_factory is not None:
             eng = self._data_pass_factory(K, D, x)
             xd = eng.adopt(x)
@@ -55,6 +59,7 @@ class DeviceModel:
                 tiling = getattr(self, "_row_tiling", False)
                 eng = open_data_pass(K, D, xd.dtype, xd.shape[0], dev) if tiling else DataPass(K, D, xd.dtype, xd.shape[0], dev)
         self._engine, self._x_dev, self._r_cache = eng, xd, None
+        self._small_r = None               # (responsibilities of an earlier small-problem fit)
         self._comm.bind_rows(xd.shape[0], xd.device)
         if hasattr(eng, "set_shard") and not getattr(self._comm, "restart_parallel", False):
             eng.set_shard(self._comm.global_rows, self._comm.world)      # row shards decide their pass policy together

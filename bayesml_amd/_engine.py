@@ -58,6 +58,9 @@ SYMBOLS = {
     "gmmvb_set_shard": (_int, [_vp, _i64, _int]),
     "gmmvb_policy_export": (_int, [_vp, _vp, _vp]),
     "gmmvb_policy_import": (_int, [_vp, _vp, _vp]),
+    "gmmvb_small_supported": (_int, [_int, _int, _i64]),
+    "gmmvb_small_out_len": (_i64, [_int, _int, _int]),
+    "gmmvb_small_fit": (_int, [_int, _int, _int, _vp, _i64, _i64, _vp, _vp, _int, _int, _vp, _int, ctypes.c_double, _vp, _vp, _vp]),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
     "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),

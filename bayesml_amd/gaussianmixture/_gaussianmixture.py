@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from .. import _check, _kside, base
+from . import _small
 from .._device import DeviceModel
 from .._dist import SingleProcess
 from .._exceptions import CriteriaError, DataFormatError, ParameterFormatError, ResultWarning
@@ -238,6 +239,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._engine = None
         self._x_dev = None
         self._r_cache = None
+        self._small_r = None                # device responsibilities of a small-problem fit (_small.py), fetched lazily
+        self._small_fit_impl = None         # test seam of the small-problem launch (tests/fake_engine.py); None = gmmvb_small_fit
 
         self.vl = 0.0
         self._vl_p_x = self._vl_p_z = self._vl_p_pi = self._vl_p_mu_lambda = 0.0
@@ -387,6 +390,11 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         Per VB iteration the host does: one parameter hand-over, one data-pass call, (one all-reduce), one K-side
         step (a hipGraph replay) and ONE device-to-host copy of nine doubles (the lower bound's terms and the mean
         drift)."""
+        x = self._check_rows(x)
+        if _small.applicable(self, x.shape[0], max_itr, num_init, init_type):
+            # every restart and iteration in one launch (csrc/small.hip); same draws, same winner rule, same progress lines
+            return _small.fit(self, x, max_itr, num_init, tolerance, init_type)
+        self._small_r = None
         eng, xd = self._open(x)
         K, D = self.c_num_classes, self.c_degree
         dev = xd.device
@@ -514,8 +522,16 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         return _kside.subsample_moments_init(q, size, a, B, eng.pivot, _kside.features)
 
     # lazily fetched [N, K] arrays of the last data pass (the reference keeps them as attributes)
+    def _reset_small(self):
+        self._r_cache = None
+        self._small_r = None
+
     @property
     def r_vecs(self):
+        if self._small_r is not None:
+            if self._r_cache is None:
+                self._r_cache = self._small_r if isinstance(self._small_r, np.ndarray) else _np(self._small_r)
+            return self._r_cache
         if self._engine is None:
             return None
         if self._r_cache is None:

@@ -73,8 +73,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the dense, hard-workload, spread-sweep, full-fit and HMM legs")
-    ap.add_argument("--legs", default="dense,hard,spread,full,hmm",
-                    help="comma-separated legs of the single-GPU run (dense, hard, spread, full, hmm)")
+    ap.add_argument("--legs", default="dense,hard,spread,full,hmm,small",
+                    help="comma-separated legs of the single-GPU run (dense, hard, spread, full, hmm, small)")
     ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
     ap.add_argument("--force-dist", action="store_true",
                     help="join an RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
@@ -502,7 +502,7 @@ def main():
         assert roof["frac"] <= 1.0 + 1e-9, roof
 
         last_launch = eng.launch_info
-        dense_leg = hard = spread_leg = full_leg = hmm_leg = None
+        dense_leg = hard = spread_leg = full_leg = hmm_leg = small_leg = None
         if not args.dense and world == 1 and not args.no_legs:
             legs = set(args.legs.split(","))
             if "dense" in legs:
@@ -520,6 +520,8 @@ def main():
                 spread_leg = spread_sweep_leg(K, D, min(n_local, 2_000_000), tdtype, ndtype, dev, parity=do_cpu)
             if "hmm" in legs and args.config == "c3":
                 hmm_leg = hmm_c5_leg(dev, cpu=do_cpu)
+            if "small" in legs:
+                small_leg = small_c1_leg(dev)
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
             "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
@@ -535,7 +537,7 @@ def main():
                        "classes": K, "degree": D, "rows_per_gpu": n_local, "rows_total": n_total, "x_storage": dt,
                        "cluster_spread": spread, "parallelism": f"rows{world}"},
             "roofline": roof, "dense": dense_leg, "hard_workload": hard, "spread_sweep": spread_leg,
-            "full_fit": full_leg, "hmm_c5": hmm_leg, "per_rank": ranks_info,
+            "full_fit": full_leg, "hmm_c5": hmm_leg, "small_c1": small_leg, "per_rank": ranks_info,
             "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,
             "launch": last_launch, "warmup_steps": warm,
             "per_step": {"wall_ms": [round(v, 2) for v in walls],
@@ -701,6 +703,45 @@ def full_fit_leg(K, D, x, dev, max_itr=25, num_init=2):
            "checksum_hn_m_vecs": float(np.abs(hn["hn_m_vecs"]).sum()), "final_vl": float(m.vl)}
     m._engine.close()
     m._engine = None
+    return out
+
+
+def small_c1_leg(dev, reps=5):
+    """BASELINE.json configs[0] (K=3, D=2, N=1000) through the public API with the reference's defaults (10 restarts, up
+    to 100 iterations each, tolerance 1e-8): one launch runs all of it (csrc/small.hip).  The reference takes 0.16 s on the
+    survey container's CPU."""
+    import contextlib
+    import io
+    import torch
+    from bayesml_amd import gaussianmixture as gm
+    gen = gm.GenModel(3, 2, pi_vec=np.array([0.3, 0.3, 0.4]), mu_vecs=np.array([[-4.0, 0.0], [4.0, 0.0], [0.0, 5.0]]), seed=123)
+    x1, _ = gen.gen_sample(1000)
+    out = {}
+    for label, flag in (("one_launch", "1"), ("general_engine", "0")):
+        old = os.environ.get("BAYESML_AMD_SMALL")
+        os.environ["BAYESML_AMD_SMALL"] = flag
+        times, iters, vl = [], 0, None
+        try:
+            for _ in range(reps):                     # (the first call pays library / code-object loads)
+                m = gm.LearnModel(3, 2, seed=0, device=dev)
+                buf = io.StringIO()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with warnings.catch_warnings(), contextlib.redirect_stdout(buf):
+                    warnings.simplefilter("ignore")
+                    m.update_posterior(x1)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                iters, vl = buf.getvalue().count("t="), float(m.vl)
+                if m._engine is not None:
+                    m._engine.close()
+        finally:
+            os.environ.pop("BAYESML_AMD_SMALL", None)
+            if old is not None:
+                os.environ["BAYESML_AMD_SMALL"] = old
+        out[label] = {"seconds_first_call": times[0], "seconds": min(times[1:]), "vb_iterations": iters, "final_vl": vl}
+    out["workload"] = "gaussianmixture.LearnModel K=3 D=2 N=1000, update_posterior() defaults (10 restarts, tolerance 1e-8)"
+    out["reference_seconds_survey_container_cpu"] = 0.16
     return out
 
 

@@ -148,6 +148,28 @@ int gmmvb_set_shard(gmmvb_workspace* ws, int64_t global_rows, int n_ranks);
 int gmmvb_policy_export(gmmvb_workspace* ws, double* out_dev /*[GMMVB_POLICY_LEN]*/, void* stream);
 int gmmvb_policy_import(gmmvb_workspace* ws, const double* summed_dev /*[GMMVB_POLICY_LEN]*/, void* stream);
 
+/* ---- Small problems: the whole restart x iteration loop of update_posterior in ONE launch (csrc/small.hip) ----------
+ * Replaces, for shapes gmmvb_small_supported accepts (D <= 8, K <= 32, K (1 + D + D (D + 1) / 2) <= 256, n_rows <= 16384:
+ * the sizes of BayesML's tutorials, where the general path is bound by its launches), the reference's driver loops
+ *   for i in range(num_init): ... for t in range(max_itr): _update_q_mu_lambda / _update_q_pi / _update_q_z / _calc_vl,
+ *   convergence test abs((vl - vl_before) / vl_before) < tolerance        (_gaussianmixture.py:846-872)
+ * Workgroup r runs restart r; the caller draws the restarts' initial states in the reference's order:
+ *   prior_dev = [alpha K | m KD | kappa K | nu K | w_inv KDD | ln B(W0, nu0) K | ln C(alpha0) 1]   (h0_* and :661-669)
+ *   init_type 0 ("subsampling", :786-796):           init_dev = per restart [m KD | w_inv KDD] of the K sub-samples
+ *   init_type 1 ("random_responsibility", :734-736): init_dev = per restart r [n_rows][K]
+ * out_dev, per restart (gmmvb_small_out_len doubles):
+ *   [ number of lower bounds L | converged 0/1 | p_x p_z p_pi p_mu_lambda q_z q_pi q_mu_lambda vl of the last pass |
+ *     trace[max_itr + 1] (L valid) | alpha K | m KD | kappa K | nu K | w_inv KDD | w KDD |
+ *     E[ln pi] K | E[ln det Lambda] K | ln B(W, nu) K | ns K | x_bar KD | s KDD ]
+ * - the posterior that produced the restart's last data pass and that pass's moments (what ref :895 recomputes for the
+ * winner).  r_dev (optional): [n_restarts][n_rows][K] responsibilities of every restart's last pass.  The winner rule
+ * (:873) and the progress lines stay with the caller. */
+int gmmvb_small_supported(int K, int D, int64_t n_rows);
+int64_t gmmvb_small_out_len(int K, int D, int max_itr);
+int gmmvb_small_fit(int K, int D, int x_dtype, const void* x_dev, int64_t ldx, int64_t n_rows, const double* pivot_dev /*[D]*/,
+                    const double* prior_dev, int n_restarts, int init_type, const double* init_dev, int max_itr,
+                    double tolerance, double* out_dev, double* r_dev, void* stream);
+
 /* ---- Gaussian-emission HMM (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py) -------------------------
  * The emission term is the GMM E-step without E[ln pi]: call gmmvb_set_params with
  *   c[k] = (E[ln det Lambda_k] - D ln 2pi - D/kappa_k)/2     (_calc_rho, :988-996)

@@ -161,3 +161,57 @@ class CpuDataPass:
 
 def cpu_factory(K, D, x):
     return CpuDataPass(K, D, x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_small_fit(K, D, x, pivot, prior, init, n_restarts, init_type, max_itr, tolerance):
+    """CPU stand-in for ``gmmvb_small_fit`` (csrc/small.hip) with the contract of include/gmmvb.h: every restart from its
+    initial state to convergence, results in the ABI's ``out`` layout.  TEST INFRASTRUCTURE: built on the oracle's
+    restatement of the reference, injected through ``LearnModel._small_fit_impl`` so that the host side of the
+    small-problem path (draw order, winner rule, progress lines, attribute hand-over) is tested without a GPU."""
+    import numpy as np
+    from oracle import gmm_vb_oracle as orc
+    x64 = np.asarray(x, dtype=np.float64)
+    n = x64.shape[0]
+    cut = np.cumsum([0, K, K * D, K, K, K * D * D, K])
+    alpha0, m0, kappa0, nu0, w0_inv, _lnb = (prior[cut[j]:cut[j + 1]] for j in range(6))
+    w0_inv = w0_inv.reshape(K, D, D)
+    p = orc.Prior(alpha=alpha0.copy(), m=m0.reshape(K, D).copy(), kappa=kappa0.copy(), nu=nu0.copy(),
+                  w=np.linalg.inv(w0_inv)).refresh()
+    L = 2 + 8 + (max_itr + 1) + 7 * K + 2 * K * D + 3 * K * D * D
+    out = np.zeros((n_restarts, L))
+    r_all = np.zeros((n_restarts, n, K))
+    keys = ("p_x", "p_z", "p_pi", "p_mu_lambda", "q_z", "q_pi", "q_mu_lambda", "vl")
+    for i in range(n_restarts):
+        q = orc.Posterior.from_prior(p)
+        if init_type == 0:
+            q.m = init[i, :K * D].reshape(K, D).copy()
+            q.w_inv = init[i, K * D:].reshape(K, D, D).copy()
+            q.w = np.linalg.inv(q.w_inv)
+            q.refresh_lambda()
+            st = orc.data_pass(x64, q)
+        else:
+            r = init[i].reshape(n, K)
+            ns, x_bar, s = orc.m_step_stats(x64, r)
+            st = orc.Stats(np.zeros_like(r), r, ns, x_bar, s)
+        terms = orc.lower_bound(p, q, st)
+        trace, conv = [terms["vl"]], False
+        for _t in range(max_itr):
+            before = trace[-1]
+            orc.update_q_mu_lambda(p, q, st)
+            orc.update_q_pi(p, q, st)
+            st = orc.data_pass(x64, q, st.s)
+            terms = orc.lower_bound(p, q, st)
+            trace.append(terms["vl"])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if np.abs((terms["vl"] - before) / before) < tolerance:
+                    conv = True
+                    break
+        out[i, 0], out[i, 1] = len(trace), float(conv)
+        out[i, 2:10] = [terms[k] for k in keys]
+        out[i, 10:10 + len(trace)] = trace
+        out[i, 10 + max_itr + 1:] = np.concatenate([q.alpha, q.m.reshape(-1), q.kappa, q.nu, q.w_inv.reshape(-1), q.w.reshape(-1),
+                                                    q.e_ln_pi, q.e_ln_lambda_det, q.ln_b_w_nu, st.ns, st.x_bar.reshape(-1),
+                                                    st.s.reshape(-1)])
+        r_all[i] = st.r
+    return out, r_all

@@ -246,6 +246,47 @@ def test_driver_protocol_and_rng_order(name):
         assert len(kl[1]) == K and len(kl[2]) == K
 
 
+@pytest.mark.parametrize("name", DRIVER)
+def test_small_problem_path_host_side(name):
+    """The small-problem path (gaussianmixture/_small.py: every restart and iteration in one launch) with the launch
+    replaced by its CPU stand-in: the reference's draws in the reference's order, winner, progress lines, posterior and
+    the attributes update_posterior leaves - against the REFERENCE's fixtures."""
+    from fake_engine import cpu_small_fit
+    g = load_golden(name)
+    x = g["x"] if "x" in g else load_golden("gmm_c1_sample.npz")["x"]
+    K, D = int(g["K"]), int(g["D"])
+    kw = json.loads(str(g["kw"]))
+    m = gm.LearnModel(K, D, seed=int(g["seed"]))
+    m._small_fit_impl = cpu_small_fit
+    buf = io.StringIO()
+    with warnings.catch_warnings(record=True) as w, redirect_stdout(buf):
+        warnings.simplefilter("always")
+        ret = m.update_posterior(x, **kw)
+    assert ret is m and m._engine is None                      # no workspace was opened
+    assert any(issubclass(i.category, bayesml_amd.ResultWarning) for i in w) == bool(g["result_warning"])
+    lines = [ln for ln in buf.getvalue().split("\n") if ln.strip()]
+    tr = g["vl_trace"]
+    assert len(lines) == tr.shape[0]
+    assert max(i for i, ln in enumerate(lines) if ln.endswith("*")) == int(g["winner"])
+    assert ["(converged)" in ln for ln in lines] == [bool(c) for c in g["converged"]]
+    for i, ln in enumerate(lines):
+        segs = [s for s in ln.split("\r") if s]
+        ref = tr[i][~np.isnan(tr[i])]
+        assert len(segs) == len(ref) and segs[0].startswith(f"{i}. VL: ")
+        vals = [float(s.split("VL: ")[1].split(" ")[0].rstrip("*")) for s in segs]
+        assert np.allclose(vals, ref, rtol=1e-10)
+    for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+        assert rel_err(m.get_hn_params()[key], g[key]) < 1e-9, key
+    assert rel_err(m.hn_w_mats_inv, g["hn_w_mats_inv"]) < 1e-9
+    assert rel_err(m.ns, g["ns"]) < 1e-9 and m.r_vecs.shape == (x.reshape(-1, D).shape[0], K)
+    assert abs(m.vl - float(g["final_vl"])) <= 1e-10 * abs(float(g["final_vl"]))
+    # the general driver on the same seed consumes the Generator identically: both leave it in the same state
+    m2 = cpu_model(K, D, seed=int(g["seed"]))
+    quiet(m2.update_posterior, x, **kw)
+    assert m.rng.bit_generator.state == m2.rng.bit_generator.state
+    assert rel_err(m.hn_m_vecs, m2.hn_m_vecs) < 1e-7
+
+
 def test_num_init_zero_keeps_posterior_and_warns():
     x = load_golden("gmm_c1_sample.npz")["x"]
     m = cpu_model(3, 2, seed=0)
