@@ -949,4 +949,171 @@ __global__ __launch_bounds__(64) void hmm_vit_fill_kernel(const unsigned char* _
     if (c == 0) z[0] = s;
 }
 
+// ---- chunk matrices with a lane per START state, and a two-level scan over them (round 4) ------------------------------
+// hmm_vit_chunk_kernel above spends a wave per (chunk, start state) with the END state on the lane: 32 cross-lane
+// broadcasts of omega per step, half of the lanes idle at K = 32 - 223 ms of the 320-ms Viterbi pass at T = 1e7, thirteen
+// times the vector-ALU time of its K^2 additions and maxima.  Here the lane is the start state and keeps its whole omega
+// vector in registers: every operand of  omega'(j) = e_t(j) + max_i (omega(i) + ln a~_ij)  is then either the lane's own
+// register or uniform (ln a~_ij through scalar loads, e_t(j) a broadcast LDS read), the K x K loop is fully unrolled, and a
+// wave serves 64 / KP chunks.  Same operations per entry as the kernel above: bit-identical M_c.  K <= 32.
+template <int KP>
+__global__ __launch_bounds__(64) void hmm_vit_chunk_lane_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                                const double* __restrict__ a_pad /*[KP][KP], -1e300 padded*/,
+                                                                int K, int64_t T, int64_t L, int64_t chunks,
+                                                                double* __restrict__ M /*[chunks][KP][KP]*/) {
+    static_assert(KP == 16 || KP == 32, "the omega vector lives in registers");
+    constexpr int CW = 64 / KP;                       // chunks per wave
+    __shared__ double es[CW][8][KP];
+    const int lane = threadIdx.x, h = lane / KP, i0 = lane % KP;
+    const int64_t c = (int64_t)blockIdx.x * CW + h;
+    const bool live = c < chunks;
+    const int64_t cc = live ? c : chunks - 1;
+    const int64_t t0 = 1 + cc * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const double NEG = -1.0e300;
+    const double* lr = lnrho + (int64_t)(i0 < K ? i0 : 0) * npad;       // (staging: this lane fetches state i0's emissions)
+    double w[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) w[j] = (j == i0 && i0 < K) ? 0.0 : NEG;
+    // (all chunks of a launch but the last have L steps; the wave runs to the longest of its chunks)
+    const int64_t steps = t1 - t0;
+    int64_t wave_steps = steps;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t other = __shfl_xor(wave_steps, o);
+        wave_steps = other > wave_steps ? other : wave_steps;
+    }
+    for (int64_t sb = 0; sb < wave_steps; sb += 8) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = (sb + u < steps) ? lr[t0 + sb + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) es[h][u][i0] = e[u];
+#pragma unroll 1
+        for (int u = 0; u < 8; ++u) {
+            if (sb + u >= wave_steps) break;
+            const bool on = sb + u < steps;
+            double wn[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                double best = w[0] + a_pad[j];
+#pragma unroll
+                for (int i = 1; i < KP; ++i) best = fmax(best, w[i] + a_pad[i * KP + j]);
+                wn[j] = j < K ? es[h][u][j] + best : NEG;
+            }
+#pragma unroll
+            for (int j = 0; j < KP; ++j) w[j] = on ? wn[j] : w[j];
+        }
+    }
+    if (live) {
+        double* out = M + ((int64_t)c * KP + i0) * KP;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) out[j] = w[j];
+    }
+}
+
+__global__ void hmm_vit_pad_kernel(const double* __restrict__ ln_a_tilde, int K, int KP, double* __restrict__ a_pad) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int i = e / KP, j = e - i * KP;
+    a_pad[e] = (i < K && j < K) ? ln_a_tilde[i * K + j] : -1.0e300;
+}
+
+// P_s = M_c0 (x) M_c0+1 (x) ... over the kHmmSuper chunks of super-chunk s (max-plus products, K^3 each; a workgroup per
+// super-chunk, the running product and the next factor in LDS)
+template <int KP>
+__global__ __launch_bounds__(256) void hmm_vit_super_kernel(const double* __restrict__ M, int K, int64_t chunks,
+                                                            double* __restrict__ P /*[supers][KP][KP]*/) {
+    __shared__ double pa[KP * KP], pb[KP * KP], mc[KP * KP];
+    const int tid = threadIdx.x;
+    const int64_t s = blockIdx.x;
+    const int64_t c0 = s * kHmmSuper, c1 = (c0 + kHmmSuper < chunks) ? c0 + kHmmSuper : chunks;
+    for (int e = tid; e < KP * KP; e += 256) pa[e] = M[c0 * KP * KP + e];
+    __syncthreads();
+    double* cur = pa;
+    double* nxt = pb;
+    for (int64_t c = c0 + 1; c < c1; ++c) {
+        for (int e = tid; e < KP * KP; e += 256) mc[e] = M[c * KP * KP + e];
+        __syncthreads();
+        for (int e = tid; e < KP * KP; e += 256) {
+            const int i = e / KP, j = e - i * KP;
+            double best = -2.0e300;
+            if (i < K && j < K) {
+                for (int k = 0; k < K; ++k) {
+                    const double v = cur[i * KP + k] + mc[k * KP + j];
+                    best = v > best ? v : best;
+                }
+            } else {
+                best = -1.0e300;
+            }
+            nxt[e] = best;
+        }
+        __syncthreads();
+        double* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    for (int e = tid; e < KP * KP; e += 256) P[s * KP * KP + e] = cur[e];
+}
+
+// omega at every super-chunk start: one wave, omega_{s+1} = omega_s (x) P_s, the next product's column prefetched
+template <int KP>
+__global__ __launch_bounds__(64) void hmm_vit_scan2_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                           const double* __restrict__ ln_pi_tilde, const double* __restrict__ P,
+                                                           int K, int64_t supers, double* __restrict__ sstart /*[supers][KP]*/) {
+    const int j = threadIdx.x;
+    const int jj = j < KP ? j : 0;
+    const double NEG = -1.0e300;
+    double w = j < K ? lnrho[(int64_t)j * npad] + ln_pi_tilde[j] : NEG;
+    double col[KP], nxt[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) nxt[i] = supers > 0 ? P[i * KP + jj] : 0.0;
+    for (int64_t s = 0; s < supers; ++s) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i) col[i] = nxt[i];
+        if (s + 1 < supers) {
+#pragma unroll
+            for (int i = 0; i < KP; ++i) nxt[i] = P[((s + 1) * KP + i) * KP + jj];
+        }
+        if (j < KP) sstart[s * KP + j] = w;
+        double best = NEG * 2.0;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            const double v = __shfl(w, i) + col[i];
+            best = (i < K && v > best) ? v : best;
+        }
+        w = j < K ? best : NEG;
+    }
+}
+
+// omega at every chunk start of super-chunk s from its start vector: omega_{c+1} = omega_c (x) M_c (a wave per super-chunk)
+template <int KP>
+__global__ __launch_bounds__(64) void hmm_vit_fill2_kernel(const double* __restrict__ M, int K, int64_t chunks,
+                                                           const double* __restrict__ sstart, double* __restrict__ wstart) {
+    const int j = threadIdx.x;
+    const int jj = j < KP ? j : 0;
+    const double NEG = -1.0e300;
+    const int64_t s = blockIdx.x;
+    const int64_t c0 = s * kHmmSuper, c1 = (c0 + kHmmSuper < chunks) ? c0 + kHmmSuper : chunks;
+    double w = j < K ? sstart[s * KP + j] : NEG;
+    double col[KP], nxt[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) nxt[i] = M[(c0 * KP + i) * KP + jj];
+    for (int64_t c = c0; c < c1; ++c) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i) col[i] = nxt[i];
+        if (c + 1 < c1) {
+#pragma unroll
+            for (int i = 0; i < KP; ++i) nxt[i] = M[((c + 1) * KP + i) * KP + jj];
+        }
+        if (j < KP) wstart[c * KP + j] = w;
+        double best = NEG * 2.0;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            const double v = __shfl(w, i) + col[i];
+            best = (i < K && v > best) ? v : best;
+        }
+        w = j < K ? best : NEG;
+    }
+}
+
 }  // namespace gmmvb

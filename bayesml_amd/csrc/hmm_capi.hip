@@ -236,11 +236,33 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         int* endst = reinterpret_cast<int*>(h->fstart_s);                // [chunks] ints
         if (chunks > h->max_chunks || chunks * (int64_t)sizeof(int) > (h->max_chunks / kHmmSuper + 2) * h->Kp * (int64_t)sizeof(double))
             return fail(GMMVB_ESTATE, "Viterbi scratch too small for this sequence");
+        // chunk matrices: up to 32 states with a lane per start state (hmm_vit_chunk_lane_kernel), beyond with a wave per
+        // (chunk, start state).  Chunk starts: with more than two super-chunks through super-chunk products (a sequential
+        // pass over chunks / 64 products instead of over every chunk), else the single workgroup's pass.
+        const int64_t supers = (chunks + kHmmSuper - 1) / kHmmSuper;
+        const bool two_level = supers > 2 && h->qprod != nullptr && h->bend_s != nullptr;
+        double* a_pad = h->xi_slabs;                                     // [Kp][Kp] (the forward-backward pass's slabs are free here)
+        double* sstart = h->bend_s;                                      // [supers][Kp]
 #define VITC(KTT)                                                                                                           \
-    hipLaunchKernelGGL((hmm_vit_chunk_kernel<KTT>), dim3((unsigned)chunks, (unsigned)((h->K + 3) / 4)), dim3(256), 0, st,   \
-                       ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M);                                             \
-    hipLaunchKernelGGL((hmm_vit_scan_kernel<KTT>), dim3(1), dim3(256), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, M, h->K, \
-                       chunks, wstart);                                                                                      \
+    if (KTT <= 2) {                                                                                                         \
+        constexpr int KPL = KTT <= 1 ? 16 : 32;                                                                             \
+        hipLaunchKernelGGL(hmm_vit_pad_kernel, dim3((KPL * KPL + 255) / 256), dim3(256), 0, st, ln_a_tilde_dev, h->K, KPL, a_pad); \
+        hipLaunchKernelGGL((hmm_vit_chunk_lane_kernel<KPL>), dim3((unsigned)((chunks + 64 / KPL - 1) / (64 / KPL))), dim3(64), 0, \
+                           st, ws->lnrho, ws->npad, a_pad, h->K, n_rows, L, chunks, M);                                     \
+    } else {                                                                                                                \
+        hipLaunchKernelGGL((hmm_vit_chunk_kernel<KTT>), dim3((unsigned)chunks, (unsigned)((h->K + 3) / 4)), dim3(256), 0, st, \
+                           ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M);                                        \
+    }                                                                                                                       \
+    if (two_level) {                                                                                                        \
+        hipLaunchKernelGGL((hmm_vit_super_kernel<16 * KTT>), dim3((unsigned)supers), dim3(256), 0, st, M, h->K, chunks, h->qprod); \
+        hipLaunchKernelGGL((hmm_vit_scan2_kernel<16 * KTT>), dim3(1), dim3(64), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, \
+                           h->qprod, h->K, supers, sstart);                                                                 \
+        hipLaunchKernelGGL((hmm_vit_fill2_kernel<16 * KTT>), dim3((unsigned)supers), dim3(64), 0, st, M, h->K, chunks, sstart, \
+                           wstart);                                                                                         \
+    } else {                                                                                                                \
+        hipLaunchKernelGGL((hmm_vit_scan_kernel<KTT>), dim3(1), dim3(256), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, M, h->K, \
+                           chunks, wstart);                                                                                 \
+    }                                                                                                                       \
     hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,           \
                        ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state)
         switch (h->KT) {

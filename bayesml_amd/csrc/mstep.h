@@ -59,21 +59,26 @@ __host__ __device__ constexpr int mstep_owned(int ws, int sub, int t) {
 // LIST = true: [lo, hi) are positions in `list` (ascending rows of x whose responsibility for this component is not
 // negligible, see "sparse responsibilities" below); entry e stands for row list[e].
 // FULL = true: D == 16 T is known (whole feature tiles): no per-element range test in the loop.
-template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE, bool LIST = false, bool FULL = false>
+// AHEAD2 (LIST, FULL): the gathered rows are requested TWO steps ahead and the pivot is read from LDS (`pv_lds`, [16 T]):
+// the sixteen registers the pivot held pay for the second row in flight, so the kernel stays at two waves per SIMD.
+template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE, bool LIST = false, bool FULL = false, bool AHEAD2 = false>
 __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                            const double* __restrict__ pivot, const double* __restrict__ lr,
                                            const double* __restrict__ lse, const double* __restrict__ aux_k,
                                            int64_t lo, int64_t hi, int direct_r, double* __restrict__ out,
-                                           const int* __restrict__ list = nullptr) {
+                                           const int* __restrict__ list = nullptr, const double* __restrict__ pv_lds = nullptr) {
+    static_assert(!AHEAD2 || (LIST && FULL && !PRE), "two rows in flight: the f32 list form");
     constexpr int P = tri_pairs(T);
     constexpr int NP = mstep_owned(WS, SUB, T);   // tile pairs owned by this wave
     const int lane = threadIdx.x & 63;
     const int i = lane & 15;
     const int g = lane >> 4;
 
-    double pv[T];
+    double pv[AHEAD2 ? 1 : T];
+    if constexpr (!AHEAD2) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) pv[t] = (!PRE && (FULL || T * i + t < D)) ? pivot[T * i + t] : 0.0;
+        for (int t = 0; t < T; ++t) pv[t] = (!PRE && (FULL || T * i + t < D)) ? pivot[T * i + t] : 0.0;
+    }
     d4 acc[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[p] = d4{0.0, 0.0, 0.0, 0.0};
@@ -124,8 +129,10 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     // (a list entry's sign bit marks a row that LEAVES the settled-row cache: weight -1, direct_r == 3)
     if constexpr (LIST) idx_n = (lo + lane < hi) ? list[lo + lane] : 0;
     RawRow nxt = load_row(LIST ? (int64_t)(__shfl(idx_n, g) & 0x7FFFFFFF) : lo + g);
-    // (measured, round 3: requesting the listed rows TWO steps ahead makes the kernel slower - 2.30 instead of 1.81 ms per
-    // step at the benchmark shape)
+    RawRow nx2 = nxt;
+    if constexpr (AHEAD2) nx2 = load_row((int64_t)(__shfl(idx_n, (4 + g) & 63) & 0x7FFFFFFF));
+    // (round 3 measured two rows in flight at 2.30 instead of 1.81 ms per step: with 144 accumulator registers the kernel sits
+    // exactly at the 256 registers of two waves per SIMD, and eight more halved the occupancy)
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         // responsibilities of 64 samples, one per lane
         const int64_t nl = c0 + lane;
@@ -155,11 +162,13 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
         for (int st = 0; st < 16; ++st) {
             if (LIST && c0 + 4 * st >= hi) break;      // the list ended inside this batch (wave uniform)
             const RawRow cur = nxt;
+            if constexpr (AHEAD2) nxt = nx2;
             const double rr = rr_n;
             double xq[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 if constexpr (PRE) xq[t] = (double)cur.v[t];
+                else if constexpr (AHEAD2) xq[t] = (double)cur.v[t] - pv_lds[T * i + t];
                 else if constexpr (FULL) xq[t] = (double)cur.v[t] - pv[t];
                 else xq[t] = (T * i + t < D) ? (double)cur.v[t] - pv[t] : 0.0;
             }
@@ -174,7 +183,9 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LIST)
+            if constexpr (AHEAD2)
+                nx2 = load_row((int64_t)(__shfl(st >= 14 ? idx_n : idx_l, (4 * (st + 2) + g) & 63) & 0x7FFFFFFF));
+            else if constexpr (LIST)
                 nxt = load_row((int64_t)(__shfl(st == 15 ? idx_n : idx_l, (4 * (st + 1) + g) & 63) & 0x7FFFFFFF));
             else
                 nxt = load_row(c0 + 4 * (st + 1) + g);
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
 // one or two active components per row every listed row is read about once, so the kernel's HBM traffic is the rows
 // themselves - 4 D bytes instead of 8 D - and the conversion and pivot subtraction (the very operations that made the
 // centred copy: identical values) ride in the shadow of the MFMAs.
-template <int T>
+template <int T, bool AHEAD2 = false>
 __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     const float* __restrict__ x, int64_t ldx, int64_t n_rows, int D, const double* __restrict__ pivot,
     const double* __restrict__ lnrho, const double* __restrict__ lse, const int* __restrict__ lists, int64_t cap,
@@ -436,7 +447,12 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     int direct_r /*0, or 3: delta lists*/) {
     constexpr int WS = mstep_ws(T);
     constexpr int KPW = mstep_waves(T, true) / WS;
+    __shared__ double s_pv[AHEAD2 ? 16 * T : 1];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (AHEAD2) {
+        if (threadIdx.x < 16 * T) s_pv[threadIdx.x] = pivot[threadIdx.x];
+        __syncthreads();
+    }
     const int c = (int)blockIdx.x * KPW + wave / WS;
     if (c >= plan[K]) return;
     int k = 0;
@@ -458,12 +474,12 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     const int* list = lists + (int64_t)k * cap;
     double* out = slabs + (int64_t)c * slab_len(T);
     if constexpr (WS == 1) {
-        mstep_body<T, 1, 0, float, true, false, true, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
+        mstep_body<T, 1, 0, float, true, false, true, true, AHEAD2>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list, s_pv);
     } else {
         if (sub == 0)
-            mstep_body<T, 2, 0, float, true, false, true, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
+            mstep_body<T, 2, 0, float, true, false, true, true, AHEAD2>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list, s_pv);
         else
-            mstep_body<T, 2, 1, float, true, false, true, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
+            mstep_body<T, 2, 1, float, true, false, true, true, AHEAD2>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list, s_pv);
     }
 }
 

@@ -79,7 +79,10 @@ static hipError_t go_ring(int grid, hipStream_t st, const MstepListArgs& a) {
 template <int T>
 static hipError_t go_list(int grid, hipStream_t st, const MstepListArgs& a) {
     hipLaunchKernelGGL(mstep_plan_kernel, dim3(1), dim3(64), 0, st, a.counts, a.K, a.cap_chunks, a.r_min, a.plan);
-    if (a.x32)
+    if (a.x32 && a.ahead2 && T == 8)
+        hipLaunchKernelGGL((mstep_list_x32_f64<T, true>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.x32, a.ldx, a.n_rows,
+                           a.D, a.pivot, a.lnrho, a.lse, a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs, a.direct_r);
+    else if (a.x32)
         hipLaunchKernelGGL((mstep_list_x32_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.x32, a.ldx, a.n_rows,
                            a.D, a.pivot, a.lnrho, a.lse, a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs, a.direct_r);
     else
