@@ -58,12 +58,17 @@ def markov_chain(pi: torch.Tensor, a_mat: torch.Tensor, length: int, gen: torch.
     U = pad.view(C, L)
     if K == 1:
         return torch.zeros(length, dtype=torch.int64, device=dev)
-    # pass 1: every start state through every chunk
+    # pass 1: every start state through every chunk.  The gathered CDF rows are a [chunks, K, K - 1] temporary per step
+    # (2.5 GB at K = 256, T = 1e7 with all chunks at once): blocks of chunks keep it under 256 MB.
+    blk = max(1, min(C, (256 << 20) // (8 * K * K)))
     st = torch.arange(K, device=dev).expand(C, K).contiguous()           # [C, K]
-    for t in range(L):
-        st = (U[:, t, None, None] >= cdf_a[st]).sum(-1)
-        if t == 0:
-            st[0, :] = first                                              # the sequence's first step draws from pi
+    for c0 in range(0, C, blk):
+        sb, ub = st[c0:c0 + blk], U[c0:c0 + blk]
+        for t in range(L):
+            sb = (ub[:, t, None, None] >= cdf_a[sb]).sum(-1)
+            if t == 0 and c0 == 0:
+                sb[0, :] = first                                          # the sequence's first step draws from pi
+        st[c0:c0 + blk] = sb
     end = st.cpu()
     starts = torch.zeros(C, dtype=torch.int64)
     s = 0

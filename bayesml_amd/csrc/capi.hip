@@ -195,10 +195,6 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         v = std::getenv("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
         ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
-        v = std::getenv("GMMVB_MSTEP_RING");                       // "0": the list M-step keeps its rows in registers
-        ws->opt_ring = v && std::strcmp(v, "1") == 0;
-        v = std::getenv("GMMVB_MSTEP_AHEAD");                      // "2": two gathered rows in flight per wave
-        ws->opt_ahead2 = v && std::strcmp(v, "2") == 0;
         ws->opt_debug = std::getenv("GMMVB_DEBUG") != nullptr;
     }
     {
@@ -1578,8 +1574,6 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             la0.n_rows = n_rows;
             la0.D = ws->D;
             la0.pivot = ws->pivot;
-            la0.ring = ws->opt_ring;
-            la0.ahead2 = ws->opt_ahead2;
         }
         if (!la0.x32 && ws->xc_stale) {        // this list kernel reads the centred copy: bring it to the internal row order
             e = recenter_rows(ws, n_rows, st);

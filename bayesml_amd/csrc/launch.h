@@ -76,8 +76,6 @@ struct MstepListArgs {
     int64_t npad; int K; double* slabs;
     const float* x32 = nullptr; int64_t ldx = 0; int64_t n_rows = 0; int D = 0; const double* pivot = nullptr;   // f32 rows instead of xc
     int direct_r = 0;      // 3: delta lists of the settled-row cache (weights +-1 from the entries' sign bits)
-    bool ring = false;     // f32 rows through the LDS-DMA ring (mstep_list_ring_f64)
-    bool ahead2 = false;   // f32 rows requested two steps ahead, pivot in LDS (T = 8)
 };
 hipError_t launch_mstep_list(int T, int grid, hipStream_t st, const MstepListArgs& a, const char** name);
 

@@ -59,26 +59,21 @@ __host__ __device__ constexpr int mstep_owned(int ws, int sub, int t) {
 // LIST = true: [lo, hi) are positions in `list` (ascending rows of x whose responsibility for this component is not
 // negligible, see "sparse responsibilities" below); entry e stands for row list[e].
 // FULL = true: D == 16 T is known (whole feature tiles): no per-element range test in the loop.
-// AHEAD2 (LIST, FULL): the gathered rows are requested TWO steps ahead and the pivot is read from LDS (`pv_lds`, [16 T]):
-// the sixteen registers the pivot held pay for the second row in flight, so the kernel stays at two waves per SIMD.
-template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE, bool LIST = false, bool FULL = false, bool AHEAD2 = false>
+template <int T, int WS, int SUB, typename XT, bool VEC, bool PRE, bool LIST = false, bool FULL = false>
 __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                            const double* __restrict__ pivot, const double* __restrict__ lr,
                                            const double* __restrict__ lse, const double* __restrict__ aux_k,
                                            int64_t lo, int64_t hi, int direct_r, double* __restrict__ out,
-                                           const int* __restrict__ list = nullptr, const double* __restrict__ pv_lds = nullptr) {
-    static_assert(!AHEAD2 || (LIST && FULL && !PRE), "two rows in flight: the f32 list form");
+                                           const int* __restrict__ list = nullptr) {
     constexpr int P = tri_pairs(T);
     constexpr int NP = mstep_owned(WS, SUB, T);   // tile pairs owned by this wave
     const int lane = threadIdx.x & 63;
     const int i = lane & 15;
     const int g = lane >> 4;
 
-    double pv[AHEAD2 ? 1 : T];
-    if constexpr (!AHEAD2) {
+    double pv[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) pv[t] = (!PRE && (FULL || T * i + t < D)) ? pivot[T * i + t] : 0.0;
-    }
+    for (int t = 0; t < T; ++t) pv[t] = (!PRE && (FULL || T * i + t < D)) ? pivot[T * i + t] : 0.0;
     d4 acc[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[p] = d4{0.0, 0.0, 0.0, 0.0};
@@ -129,10 +124,11 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     // (a list entry's sign bit marks a row that LEAVES the settled-row cache: weight -1, direct_r == 3)
     if constexpr (LIST) idx_n = (lo + lane < hi) ? list[lo + lane] : 0;
     RawRow nxt = load_row(LIST ? (int64_t)(__shfl(idx_n, g) & 0x7FFFFFFF) : lo + g);
-    RawRow nx2 = nxt;
-    if constexpr (AHEAD2) nx2 = load_row((int64_t)(__shfl(idx_n, (4 + g) & 63) & 0x7FFFFFFF));
-    // (round 3 measured two rows in flight at 2.30 instead of 1.81 ms per step: with 144 accumulator registers the kernel sits
-    // exactly at the 256 registers of two waves per SIMD, and eight more halved the occupancy)
+    // Measured dead ends of the LIST form (T = 8 sits exactly at the 256 registers of two waves per SIMD - 144 of them
+    // accumulators): rows requested TWO steps ahead, in registers (round 3: 2.30 instead of 1.81 ms per step; round 4 with the
+    // pivot moved to LDS to pay for them: 1.76 instead of 1.57) or staged six steps ahead through an LDS ring by LDS-DMA
+    // (round 4: 1.75 instead of 1.57): the loop is bound by what it issues beside the MFMAs, not by the gather's latency.
+    // What did help (round 4): no per-element range test and no row clamp when D == 16 T (FULL): 1.87 -> 1.57 ms.
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         // responsibilities of 64 samples, one per lane
         const int64_t nl = c0 + lane;
@@ -162,13 +158,11 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
         for (int st = 0; st < 16; ++st) {
             if (LIST && c0 + 4 * st >= hi) break;      // the list ended inside this batch (wave uniform)
             const RawRow cur = nxt;
-            if constexpr (AHEAD2) nxt = nx2;
             const double rr = rr_n;
             double xq[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 if constexpr (PRE) xq[t] = (double)cur.v[t];
-                else if constexpr (AHEAD2) xq[t] = (double)cur.v[t] - pv_lds[T * i + t];
                 else if constexpr (FULL) xq[t] = (double)cur.v[t] - pv[t];
                 else xq[t] = (T * i + t < D) ? (double)cur.v[t] - pv[t] : 0.0;
             }
@@ -183,9 +177,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (AHEAD2)
-                nx2 = load_row((int64_t)(__shfl(st >= 14 ? idx_n : idx_l, (4 * (st + 2) + g) & 63) & 0x7FFFFFFF));
-            else if constexpr (LIST)
+            if constexpr (LIST)
                 nxt = load_row((int64_t)(__shfl(st == 15 ? idx_n : idx_l, (4 * (st + 1) + g) & 63) & 0x7FFFFFFF));
             else
                 nxt = load_row(c0 + 4 * (st + 1) + g);
@@ -439,7 +431,7 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_f64(
 // one or two active components per row every listed row is read about once, so the kernel's HBM traffic is the rows
 // themselves - 4 D bytes instead of 8 D - and the conversion and pivot subtraction (the very operations that made the
 // centred copy: identical values) ride in the shadow of the MFMAs.
-template <int T, bool AHEAD2 = false>
+template <int T>
 __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     const float* __restrict__ x, int64_t ldx, int64_t n_rows, int D, const double* __restrict__ pivot,
     const double* __restrict__ lnrho, const double* __restrict__ lse, const int* __restrict__ lists, int64_t cap,
@@ -447,12 +439,7 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     int direct_r /*0, or 3: delta lists*/) {
     constexpr int WS = mstep_ws(T);
     constexpr int KPW = mstep_waves(T, true) / WS;
-    __shared__ double s_pv[AHEAD2 ? 16 * T : 1];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if constexpr (AHEAD2) {
-        if (threadIdx.x < 16 * T) s_pv[threadIdx.x] = pivot[threadIdx.x];
-        __syncthreads();
-    }
     const int c = (int)blockIdx.x * KPW + wave / WS;
     if (c >= plan[K]) return;
     int k = 0;
@@ -474,217 +461,12 @@ __global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_x32_f64(
     const int* list = lists + (int64_t)k * cap;
     double* out = slabs + (int64_t)c * slab_len(T);
     if constexpr (WS == 1) {
-        mstep_body<T, 1, 0, float, true, false, true, true, AHEAD2>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list, s_pv);
+        mstep_body<T, 1, 0, float, true, false, true, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
     } else {
         if (sub == 0)
-            mstep_body<T, 2, 0, float, true, false, true, true, AHEAD2>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list, s_pv);
+            mstep_body<T, 2, 0, float, true, false, true, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
         else
-            mstep_body<T, 2, 1, float, true, false, true, true, AHEAD2>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list, s_pv);
-    }
-}
-
-// ---- list M-step with the gathered rows staged through an LDS ring by LDS-DMA --------------------------------------------
-// mstep_list_x32_f64 keeps 36 accumulator tiles (144 AGPRs) next to ~110 VGPRs: two waves per SIMD, and the row of step s + 1
-// is all it can have in flight while step s runs - 0.5 us of look-ahead against a gather from HBM (every listed row is read
-// about once).  Measured: 54-66 % of the f64 MFMA pipe where the dense kernel (contiguous rows, L2 hits) reaches 90 %.
-// Registers are what limits the look-ahead, so the rows do not go through registers here: `global_load_lds` (16 bytes per
-// lane, LDS address = wave-uniform base + 16 lane) copies the four rows of step s + DEPTH straight into a per-wave ring,
-// and the step reads its operands from LDS.  Per block of kRingBlock list entries: (A) row numbers and responsibilities
-// (exp of ln rho - lse) go to LDS once - the per-step shuffles of the register form become broadcast LDS reads -, (B) the
-// steps: wait for the ring slot (vmcnt counts the younger DMA instructions only: nothing else touches memory in this
-// phase), read it, re-arm the slot for step s + DEPTH, convert / centre / weight, MFMAs.  The arithmetic and its order are
-// those of mstep_body: bit-identical slabs.  f32 rows with whole feature tiles, T = 4 or 8.
-constexpr int kRingDepth = 6;
-constexpr int kRingBlock = 512;
-__host__ __device__ constexpr int ring_step_bytes(int t) { return 4 * 64 * t; }               // four rows of 16 T floats
-__host__ __device__ constexpr int ring_wave_bytes(int t) { return kRingDepth * ring_step_bytes(t) + kRingBlock * 12; }
-
-template <int T, int WS, int SUB>
-__device__ __forceinline__ void mstep_ring_body(const float* __restrict__ x, int64_t ldx, const double* __restrict__ pivot,
-                                                const double* __restrict__ lr, const double* __restrict__ lse, int64_t lo,
-                                                int64_t hi, int direct_r, double* __restrict__ out,
-                                                const int* __restrict__ list, char* __restrict__ wlds /*this wave's LDS*/,
-                                                const double* __restrict__ s_pv /*LDS: the pivot, [16 T]*/) {
-    static_assert(T == 4 || T == 8, "whole 1-KB DMA instructions per step");
-    constexpr int P = tri_pairs(T);
-    constexpr int NP = mstep_owned(WS, SUB, T);
-    constexpr int SB = ring_step_bytes(T);
-    constexpr int NI = T / 4;                      // DMA instructions per step (1 KB each)
-    constexpr int RPI = 4 / NI;                    // rows per instruction
-    constexpr int PPR = 64 / RPI;                  // 16-byte pieces per row
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 15, g = lane >> 4;
-    char* ring = wlds;
-    int* s_idx = reinterpret_cast<int*>(wlds + kRingDepth * SB);
-    double* s_r = reinterpret_cast<double*>(wlds + kRingDepth * SB + kRingBlock * 4);
-
-    // (the pivot stays in LDS: sixteen registers less, which is what keeps two waves on a SIMD at T = 8)
-    const double* pvl = s_pv + T * i;
-    d4 acc[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) acc[p] = d4{0.0, 0.0, 0.0, 0.0};
-    double asum[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) asum[t] = 0.0;
-    double nsum = 0.0, hsum = 0.0;
-    const int64_t ldb = ldx * 4;                   // row pitch in bytes
-    const char* xb = reinterpret_cast<const char*>(x) + (lane % PPR) * 16;
-    const int dma_row = lane / PPR;                // row of the instruction this lane copies a piece of
-
-    for (int64_t b0 = lo; b0 < hi; b0 += kRingBlock) {
-        const int nb = (int)((hi - b0 < kRingBlock) ? hi - b0 : kRingBlock);
-        const int nsteps = (nb + 3) >> 2;
-        // ---- (A) row numbers and weights of the block
-        for (int e0 = 0; e0 < kRingBlock; e0 += 64) {
-            const int e = e0 + lane;
-            int idx = 0;
-            double r_l = 0.0;
-            if (e < nb) {
-                idx = list[b0 + e];
-                const int64_t src = (int64_t)(idx & 0x7FFFFFFF);
-                if (direct_r == 3) {               // delta lists of the settled-row cache: whole rows in (+1) or out (-1)
-                    r_l = idx < 0 ? -1.0 : 1.0;
-                } else {
-                    const double tt = lr[src] - lse[src];
-                    r_l = exp(tt);
-                    hsum = fma(r_l, tt, hsum);
-                }
-                nsum += r_l;
-            }
-            s_idx[e] = idx & 0x7FFFFFFF;
-            s_r[e] = r_l;
-            if (e0 + 64 >= nb) break;              // (wave uniform; entries past it are never read: steps stop at nsteps)
-        }
-        // (entries nb .. 4 nsteps - 1 of the last step: row 0, weight 0)
-        if (lane < 4 && nb + lane < 4 * nsteps) {
-            s_idx[nb + lane] = 0;
-            s_r[nb + lane] = 0.0;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        // ---- (B) the steps
-        auto arm = [&](int s) {                    // DMA the rows of step s (clamped: the pipeline stays full to the end)
-            const int sc = s < nsteps ? s : nsteps - 1;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int row = s_idx[4 * sc + RPI * j + dma_row];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (int64_t)row * ldb),
-                                                 (__attribute__((address_space(3))) void*)(ring + (s % kRingDepth) * SB + j * 1024),
-                                                 16, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int s = 0; s < kRingDepth; ++s) arm(s);
-        for (int s = 0; s < nsteps; ++s) {
-            // the slot of step s: every DMA instruction older than the NI (DEPTH - 1) youngest has landed
-            if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            static_assert(kRingDepth == 6, "the waits above are NI * (kRingDepth - 1)");
-            const char* slot = ring + (s % kRingDepth) * SB + g * (64 * T) + i * (4 * T);
-            float xv[T];
-#pragma unroll
-            for (int t = 0; t < T; t += 4) {
-                const f4 v = *reinterpret_cast<const f4*>(slot + 4 * t);
-                xv[t] = v[0];
-                xv[t + 1] = v[1];
-                xv[t + 2] = v[2];
-                xv[t + 3] = v[3];
-            }
-            const double rr = s_r[4 * s + g];
-            double pv[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) pv[t] = pvl[t];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: it may be overwritten
-            arm(s + kRingDepth);
-            double xq[T], ra[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) xq[t] = (double)xv[t] - pv[t];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                if (mstep_owner(WS, t) == SUB) {
-                    ra[t] = rr * xq[t];
-                    asum[t] += ra[t];
-                } else {
-                    ra[t] = 0.0;
-                }
-            }
-#pragma unroll
-            for (int t2 = 0; t2 < T; ++t2) {
-#pragma unroll
-                for (int t1 = 0; t1 <= t2; ++t1) {
-                    if (mstep_owner(WS, t1) == SUB)
-                        acc[mstep_slot(WS, t2, t1)] = mfma_f64(ra[t1], xq[t2], acc[mstep_slot(WS, t2, t1)]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the clamped tail copies: the ring is reused by the next block
-    }
-
-#pragma unroll
-    for (int t2 = 0; t2 < T; ++t2) {
-#pragma unroll
-        for (int t1 = 0; t1 <= t2; ++t1) {
-            if (mstep_owner(WS, t1) == SUB) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    out[(pair_index(t2, t1) * 4 + r) * 64 + lane] = acc[mstep_slot(WS, t2, t1)][r];
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (mstep_owner(WS, t) == SUB) {
-            const double v = sum_groups(asum[t]);
-            if (g == 0) out[P * 256 + T * i + t] = v;
-        }
-    }
-    if (SUB == 0) {
-        nsum = sum_wave(nsum);
-        hsum = sum_wave(hsum);
-        if (lane == 0) {
-            out[P * 256 + 16 * T + 0] = nsum;
-            out[P * 256 + 16 * T + 1] = hsum;
-        }
-    }
-}
-
-template <int T>
-__global__ __launch_bounds__(64 * mstep_waves(T, true)) void mstep_list_ring_f64(
-    const float* __restrict__ x, int64_t ldx, const double* __restrict__ pivot, const double* __restrict__ lnrho,
-    const double* __restrict__ lse, const int* __restrict__ lists, int64_t cap, const int* __restrict__ counts,
-    const int* __restrict__ plan, int64_t npad, int K, double* __restrict__ slabs, int direct_r /*0, or 3: delta lists*/) {
-    constexpr int WS = mstep_ws(T);
-    constexpr int KPW = mstep_waves(T, true) / WS;
-    extern __shared__ __attribute__((aligned(16))) char ring_lds[];      // [16 T doubles: pivot][waves][ring_wave_bytes]
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* s_pv = reinterpret_cast<double*>(ring_lds);
-    if (threadIdx.x < 16 * T) s_pv[threadIdx.x] = pivot[threadIdx.x];
-    __syncthreads();
-    const int c = (int)blockIdx.x * KPW + wave / WS;
-    if (c >= plan[K]) return;
-    int k = 0;
-    {
-        int lo = 0, hi = K;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (plan[mid] <= c) lo = mid;
-            else hi = mid;
-        }
-        k = lo;
-    }
-    const int R = plan[K + 1];
-    const int sub = wave % WS;
-    const int64_t lo = (int64_t)(c - plan[k]) * R;
-    int64_t hi = lo + R;
-    if (hi > counts[k]) hi = counts[k];
-    const double* lr = lnrho + (int64_t)k * npad;
-    const int* list = lists + (int64_t)k * cap;
-    double* out = slabs + (int64_t)c * slab_len(T);
-    char* wlds = ring_lds + 16 * T * 8 + wave * ring_wave_bytes(T);
-    if constexpr (WS == 1) {
-        mstep_ring_body<T, 1, 0>(x, ldx, pivot, lr, lse, lo, hi, direct_r, out, list, wlds, s_pv);
-    } else {
-        if (sub == 0) mstep_ring_body<T, 2, 0>(x, ldx, pivot, lr, lse, lo, hi, direct_r, out, list, wlds, s_pv);
-        else mstep_ring_body<T, 2, 1>(x, ldx, pivot, lr, lse, lo, hi, direct_r, out, list, wlds, s_pv);
+            mstep_body<T, 2, 1, float, true, false, true, true>(x, ldx, n_rows, D, pivot, lr, lse, nullptr, lo, hi, direct_r, out, list);
     }
 }
 

@@ -59,30 +59,10 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
     return hipErrorInvalidValue;
 }
 
-// f32 rows staged through an LDS ring by LDS-DMA (mstep.h); GMMVB_MSTEP_RING=0 (read when a workspace is created) keeps the
-// register-pipelined form
-template <int T>
-static hipError_t go_ring(int grid, hipStream_t st, const MstepListArgs& a) {
-    const size_t lds = (size_t)mstep_waves(T, true) * ring_wave_bytes(T) + 16 * T * 8;
-    static bool armed = false;
-    if (!armed) {
-        hipError_t e = hipFuncSetAttribute((const void*)mstep_list_ring_f64<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        armed = true;
-    }
-    hipLaunchKernelGGL(mstep_plan_kernel, dim3(1), dim3(64), 0, st, a.counts, a.K, a.cap_chunks, a.r_min, a.plan);
-    hipLaunchKernelGGL((mstep_list_ring_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), lds, st, a.x32, a.ldx, a.pivot,
-                       a.lnrho, a.lse, a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs, a.direct_r);
-    return hipGetLastError();
-}
-
 template <int T>
 static hipError_t go_list(int grid, hipStream_t st, const MstepListArgs& a) {
     hipLaunchKernelGGL(mstep_plan_kernel, dim3(1), dim3(64), 0, st, a.counts, a.K, a.cap_chunks, a.r_min, a.plan);
-    if (a.x32 && a.ahead2 && T == 8)
-        hipLaunchKernelGGL((mstep_list_x32_f64<T, true>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.x32, a.ldx, a.n_rows,
-                           a.D, a.pivot, a.lnrho, a.lse, a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs, a.direct_r);
-    else if (a.x32)
+    if (a.x32)
         hipLaunchKernelGGL((mstep_list_x32_f64<T>), dim3(grid), dim3(64 * mstep_waves(T, true)), 0, st, a.x32, a.ldx, a.n_rows,
                            a.D, a.pivot, a.lnrho, a.lse, a.lists, a.cap, a.counts, a.plan, a.npad, a.K, a.slabs, a.direct_r);
     else
@@ -97,10 +77,6 @@ static hipError_t go_list(int grid, hipStream_t st, const MstepListArgs& a) {
         return go_list<TT>(grid, st, a);
 
 hipError_t launch_mstep_list(int T, int grid, hipStream_t st, const MstepListArgs& a, const char** name) {
-    if (a.x32 && a.ring && (a.ldx * 4) % 16 == 0 && (T == 4 || T == 8)) {
-        *name = T == 8 ? "mstep_list_ring_f64<T=8,x=f32>" : "mstep_list_ring_f64<T=4,x=f32>";
-        return T == 8 ? go_ring<8>(grid, st, a) : go_ring<4>(grid, st, a);
-    }
     switch (T) {
         LCASE(1) LCASE(2) LCASE(3) LCASE(4) LCASE(5) LCASE(6) LCASE(7) LCASE(8)
     }

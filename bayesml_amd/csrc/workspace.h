@@ -150,8 +150,6 @@ struct gmmvb_workspace {
     // further switches, all read ONCE when the workspace is created (no getenv on the per-iteration path)
     bool opt_carry_off = false;        // GMMVB_ESTEP_CARRY_OFF: ignore gmmvb_set_drift
     bool opt_debug = false;            // GMMVB_DEBUG: one line per E-step on stderr
-    bool opt_ring = false;             // GMMVB_MSTEP_RING=1: list M-step through the LDS-DMA ring (experiment)
-    bool opt_ahead2 = false;           // GMMVB_MSTEP_AHEAD=2: two gathered rows in flight (experiment)
     // Proof round (estep_i8.h, records.h): the three int8 digit planes of every row, in the internal row order, made with
     // the centred copy (gmmvb_prepare_rows) and again when the rows are regrouped.  Valid for the matrix xq_src while the
     // pivot they are centred on is the one the component images were packed for (xq_gen == img_gen).

@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"], help="storage dtype of x in HBM")
     ap.add_argument("--ref-rows", type=int, default=20_000)
     ap.add_argument("--overlap", action="store_true", help="hard workload: cluster means 0.3 * randn instead of 2 * randn")
+    ap.add_argument("--spread", type=float, default=None, help="cluster means spread * randn (default 2.0; --overlap = 0.3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the dense, hard-workload, spread-sweep, full-fit and HMM legs")
@@ -326,7 +327,8 @@ def main():
         n_local = total // world + (1 if rank < total % world else 0)
     else:
         n_local = args.rows or cfg["rows"]
-    spread = 0.3 if args.overlap else 2.0
+    spread = args.spread if args.spread is not None else (0.3 if args.overlap else 2.0)
+    args.overlap = args.overlap or spread != 2.0          # (the legs that assume the headline recipe are skipped)
     tdtype = torch.float32 if dt == "f32" else torch.float64
     ndtype = np.float32 if dt == "f32" else np.float64
     esz = 4 if dt == "f32" else 8

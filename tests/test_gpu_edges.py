@@ -97,3 +97,71 @@ def test_sequential_update_entry_points():
         z = m.estimate_latent_vars_and_update(x[301:365], num_init=1, max_itr=5)
     assert z.shape == (64, 3) and np.all(z.sum(axis=1) == 1)
     assert abs(m.hn_kappas.sum() - before - 65.0) < 1e-8
+
+
+def test_component_below_the_relevance_line_is_pinned():
+    """A component whose largest responsibility over all rows lies below 2^-100 (but above the f64 underflow): the
+    reference gives it a tiny positive ns[k], so its x_bar_vecs[k] / s_mats[k] are a weighted mean / scatter (ref :729-732).
+    The engine's behaviour, documented in INTEGRATION.md:
+      dense pass   - ns[k] is that tiny number (to rounding), x_bar / s as in the reference;
+      pruned pass  - every pair of the component is PROVEN below 2^-100 and skipped: ns[k] == 0.0 exactly, and the
+                     reference's own ns[k] > 0 guard then leaves x_bar_vecs[k] = 0 and s_mats[k] at its previous value.
+    Either way the posterior is the reference's: hn_* change by ns[k] ~ 1e-150 relative."""
+    import os
+    from bayesml_amd import gaussianmixture as gm
+    K, D, N = 3, 64, 40000
+    rng = np.random.default_rng(11)
+    mu = np.zeros((K, D))
+    mu[1, 0] = 6.0
+    mu[2, :] = 3.0                                  # no data near it: ln r ~ -300 for every row
+    z = rng.integers(0, 2, N)
+    x = (mu[z] + rng.standard_normal((N, D))).astype(np.float32)
+    p = orc.Prior.default(K, D)
+    q = orc.Posterior.from_prior(p)
+    q.m = mu.copy()
+    q.kappa = np.full(K, 50.0)
+    q.nu = np.full(K, float(D) + 50.0)
+    q.w = np.tile(np.eye(D) / q.nu[0], (K, 1, 1))
+    q.w_inv = np.linalg.inv(q.w)
+    q.alpha = np.array([20.0, 20.0, 1.0])
+    q.refresh_pi()
+    q.refresh_lambda()
+    st = orc.data_pass(x.astype(np.float64), q)
+    assert 0.0 < st.ns[2] < 2.0 ** -100 * N and np.max(st.r[:, 2]) < 2.0 ** -100      # the case under test
+
+    def run(force):
+        old = os.environ.get("GMMVB_ESTEP_PRUNE")
+        os.environ.pop("GMMVB_ESTEP_PRUNE", None)
+        if force:
+            os.environ["GMMVB_ESTEP_PRUNE"] = "force"
+        try:
+            m = gm.LearnModel(K, D, seed=0, device=torch.device("cuda", 0), verbose=False)
+            m.set_hn_params(q.alpha, q.m, q.kappa, q.nu, q.w)
+            m.s_mats[2] = 7.0                       # "previous value" of the stale scatter
+            m.estimate_latent_vars(x, loss="squared")
+            counts = m._engine.pass_counts()
+        finally:
+            os.environ.pop("GMMVB_ESTEP_PRUNE", None)
+            if old is not None:
+                os.environ["GMMVB_ESTEP_PRUNE"] = old
+        return m, counts
+
+    dense, c0 = run(False)
+    assert c0["estep_dense"] >= 1 and c0["estep_bound"] == 0
+    assert dense.ns[2] > 0.0 and abs(dense.ns[2] / st.ns[2] - 1.0) < 1e-6
+    assert rel_err(dense.x_bar_vecs[2], st.x_bar[2]) < 1e-6
+    pruned, c1 = run(True)
+    assert c1["estep_bound"] >= 1
+    assert pruned.ns[2] == 0.0                                           # proven irrelevant, never accumulated
+    assert np.all(pruned.x_bar_vecs[2] == 0.0) and np.all(pruned.s_mats[2] == 7.0)
+    for m in (dense, pruned):                                            # the components that hold the data: unaffected
+        assert rel_err(m.ns[:2], st.ns[:2]) < 1e-10 and rel_err(m.x_bar_vecs[:2], st.x_bar[:2]) < 1e-10
+        assert np.all(m.r_vecs[:, 2] < 2.0 ** -100)
+    # no posterior-level gap: the closed-form update with ns[2] = 0 and with the reference's tiny ns[2]
+    q_ref, q_zero = q.copy(), q.copy()
+    orc.update_q_mu_lambda(p, q_ref, st)
+    st0 = orc.Stats(st.ln_rho, st.r, st.ns.copy(), st.x_bar.copy(), st.s.copy())
+    st0.ns[2], st0.x_bar[2], st0.s[2] = 0.0, 0.0, 7.0
+    orc.update_q_mu_lambda(p, q_zero, st0)
+    for a, b in ((q_ref.m, q_zero.m), (q_ref.w_inv, q_zero.w_inv), (q_ref.kappa, q_zero.kappa), (q_ref.nu, q_zero.nu)):
+        assert np.max(np.abs(a - b)) <= 1e-15 * np.max(np.abs(a))
