@@ -901,6 +901,64 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     return e;
 }
 
+// ---- pass policy: unit costs and the thresholds that follow from them -------------------------------------------------
+// gmmvb_estep / gmmvb_mstep choose between kernels whose results agree to rounding; only the time depends on the choice.
+// Every number the choice uses is one of the unit costs below (measured on MI355X at the benchmark shape, they enter the
+// formulas multiplied by tile counts, so they scale with D) or a threshold derived from them; the few that are plain
+// observations cite the measurement.  Sources: bench.py's `dense` leg (profiles/r4_bench_line_w5s20.json), the kernel
+// trace profiles/r4_bench_kernel_summary.md, the spread sweep (`spread_sweep` leg of the same line), profiles/r*_experiments.md.
+namespace policy {
+// unit costs, in units of 1e-11 s
+constexpr double kI8BlockPair = 0.12;     // int8 bound pass, per 32 x 32 block pair of a (row, component) pair
+constexpr double kI8RowOfY = 0.039;       // ... per row of y its epilogue bounds (32 per output block)
+                                          //   all four blocks at D = 128: 0.12 * 10 + 0.039 * 128 = 6.2 -> 0.062 ns per pair = the
+                                          //   38-ms pass over 6.4e8 pairs of the kernel trace
+constexpr double kF64TilePair = 0.81;     // exact evaluation (estep_gather_dev_f64) per 16 x 16 f64 tile pair: 36 of them at D = 128
+                                          //   = 0.29 ns per pair; trace: 0.31-0.33 ns per pair in bulk
+constexpr double kProofPerExact = 0.33;   // an int8 proof pair (0.10 ns, tools/bench_proof.py) in exact pairs (0.31 ns)
+// dense kernels, ns per pair at D = 128: E 172.0 ms / 6.4e8 = 0.269, M 167.1 ms / 6.4e8 = 0.261 (`dense` leg)
+constexpr double kDenseEns = 0.269, kDenseMns = 0.261;
+constexpr double kBoundNs = 0.062 + 0.010;   // bound pass per pair + record building / selection around it (6 of 44 ms)
+constexpr double kExactNs = 0.31, kProofNs = 0.10;
+constexpr double kListMns = 0.355;        // list M-step per accumulated pair on long lists (22 of 64 active: 78 ms / 2.2e8,
+                                          //   profiles/r3_full_run.json pass 2; 0.29-0.30 on short lists since round 4)
+// The pruned E-step pays the bound pass for every pair and proof + exact evaluation for the active ones:
+//   kBoundNs K + act (kExactNs + kProofNs)  <  kDenseEns K   <=>   act / K < (0.269 - 0.072) / 0.41 = 0.48
+constexpr double kPruneBelow = (kDenseEns - kBoundNs) / (kExactNs + kProofNs);
+// ... and once a bound pass has left `eval` pairs per row for the exact kernels, the dense kernel is the cheaper next pass if
+//   kBoundNs K + eval kExactNs > kDenseEns K   <=>   eval / K > 0.64 (the proof round has run by then: its cost is sunk)
+constexpr double kDenseAgainAbove = (kDenseEns - kBoundNs) / kExactNs;
+// The list M-step wins while act kListMns < K kDenseMns  <=>  act / K < 0.73; a sixth off for building lists that long: 0.6.
+// (Round 3 used 0.35; the spread sweep's spread 0.75 - 31 to 40 of 64 components active for twenty passes - is where it matters.)
+constexpr double kListMBelow = kDenseMns / kListMns * (5.0 / 6.0);
+// An overflow row (no usable reference: all K pairs evaluated) costs K kExactNs against K kBoundNs for bounding it afresh, so
+// carrying stops paying at 0.072 / 0.31 = 0.23 overflow rows per row - and overflow rows multiply by 4-8 from one carried
+// pass to the next (profiles/r2_experiments.md): 0.23 / 8 = 0.029, rounded down
+constexpr double kOverflowRows = 0.02;
+static_assert(kOverflowRows <= kBoundNs / kExactNs / 8.0, "carrying must stop before overflow rows cost a bound pass");
+static_assert(kProofPerExact >= kProofNs / kExactNs && kProofPerExact < 1.1 * kProofNs / kExactNs, "proof pair cost in exact pairs");
+// Spare candidates (listed, then found inactive) of a carried pass grow by about 2.5x per pass (same source): carrying goes on
+// while evaluating next pass's spares costs less than a fresh bound pass
+constexpr double kSpareGrowth = 2.5;
+// A carried pass that evaluates more than this share of the pairs has lost its bounds (a fresh bound pass at the benchmark
+// shape leaves 0.05-0.10: profiles/r3_experiments.md, "bound level" rows)
+constexpr double kCarriedEvalAbove = 0.35;
+// The carry u' = c' - (gamma d - delta)^2 / 2 keeps gamma^2 of a pair's distance: below gamma = 0.5 a pair four thresholds
+// away becomes a candidate - nothing survives; straight from a dense pass (parameters still jumping) the measured limit is
+// higher: gamma < 0.85 left 118 of 256 candidates per row at config 4 (171 ms, profiles/r3_experiments.md)
+constexpr double kGammaNoCarry = 0.5, kGammaNoCarryAfterDense = 0.85;
+// A sweep straight after a dense pass carries K exact values per row: only worth it when few are active
+constexpr double kSweepAfterDenseBelow = 0.1;
+// Regrouping the rows by dominant component (8 ms at the benchmark shape) pays once the passes are list-driven: at most 2.5
+// active components per row to force the one regrouping bound pass, at most 4 to regroup at a bound pass that happens
+// anyway, again after 5 % of the rows have changed their component (profiles/r2_experiments.md: gather + select 7.3 -> 6.4 ms,
+// list M-step 4.8 -> 4.2 ms on grouped rows; profiles/r3_experiments.md r3a2: regrouping at up to 32 active was worse)
+constexpr double kRegroupForceBelow = 2.5, kRegroupBelow = 4.0, kRegroupMoved = 0.05;
+// The own-pair round before the sweep is skipped while no component moves: own_first() needs Gamma > 1.004 or delta > 0.04,
+// which min_k (gamma_k - delta_k / 30) >= 0.995 rules out for every k (1 / 1.004 = 0.996; 0.04 / 30 = 0.0013)
+constexpr double kOwnRoundBelow = 0.995;
+}  // namespace policy
+
 int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream) {
     bool vec = false;
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
@@ -987,7 +1045,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
         bool sparse_ok = ws->prune == 2;
-        if (!sparse_ok && known && !ws->forget) sparse_ok = L.act <= 0.5 * pairs_l;
+        if (!sparse_ok && known && !ws->forget) sparse_ok = L.act <= policy::kPruneBelow * pairs_l;
         if (sparse_ok) {
             mode = kBound;
             const bool hinted = same_rows && ws->have_drift && !ws->opt_carry_off;
@@ -999,29 +1057,29 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th): below 0.5 the bounds are
             // made afresh.
             const double tg = ws->typical_gamma;
-            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < 0.5);
+            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < policy::kGammaNoCarry);
             if (sweep && known && L.mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
                 // (a pair of the proof round costs about a third of an exact evaluation)
                 // (a bound pass's own proof stage works through the candidates its coarse bounds leave - not a sign of erosion)
-                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + (L.mode == kSweep ? 0.33 * L.proof : 0.0)) / pairs_l;
+                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + (L.mode == kSweep ? policy::kProofPerExact * L.proof : 0.0)) / pairs_l;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
-                const double bound_cost = 0.12 * tri_pairs(tb) + 0.039 * 32 * tb, gpp = 0.81 * tri_pairs(ws->T);
-                if (gpp * spare * 2.5 >= bound_cost) sweep = false;
+                const double bound_cost = policy::kI8BlockPair * tri_pairs(tb) + policy::kI8RowOfY * 32 * tb, gpp = policy::kF64TilePair * tri_pairs(ws->T);
+                if (gpp * spare * policy::kSpareGrowth >= bound_cost) sweep = false;
                 // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
                 // (x4 - x8 observed): stop carrying well before they dominate
-                if (L.over > 0.02 * rows_l || L.eval > 0.35 * pairs_l) sweep = false;
+                if (L.over > policy::kOverflowRows * rows_l || L.eval > policy::kCarriedEvalAbove * pairs_l) sweep = false;
             }
-            if (sweep && known && L.mode == kDense && L.act > 0.1 * pairs_l) sweep = false;
+            if (sweep && known && L.mode == kDense && L.act > policy::kSweepAfterDenseBelow * pairs_l) sweep = false;
             // straight from a dense pass the parameters usually still jump (second or third iteration of a restart): the
             // sweep's per-pair bounds are exact values then, but carried over such an update most of them end up
             // candidates (measured at C4: 118 of 256 per row, 171 ms) - a bound pass is the safe first pruned pass
-            if (sweep && known && L.mode == kDense && tg > 0.0 && tg < 0.85) sweep = false;
+            if (sweep && known && L.mode == kDense && tg > 0.0 && tg < policy::kGammaNoCarryAfterDense) sweep = false;
             if (sweep) mode = kSweep;
             // a bound pass that left most pairs candidates (the parameters jumped): back to the dense kernel
-            if (mode == kBound && ws->prune != 2 && known && L.mode == kBound && L.eval > 0.6 * pairs_l) {
+            if (mode == kBound && ws->prune != 2 && known && L.mode == kBound && L.eval > policy::kDenseAgainAbove * pairs_l) {
                 mode = kDense;
                 ++ws->passes[3];
             }
@@ -1038,13 +1096,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // to pay (at most 2.5 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
     // kernels over ungrouped rows are 15-40 % slower for the rest of the fit.
     if (mode == kSweep && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
-        ws->e_state == 1 && known && L.act <= 2.5 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
+        ws->e_state == 1 && known && L.act <= policy::kRegroupForceBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
         ws->xc_ldx == ldx)
         mode = kBound;
     auto regroup_due = [&]() {
         return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
-               L.act <= 4.0 * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
-               (!ws->sorted || ws->moved_since_sort > 0.05 * rows_l);      // (again once that share of the rows has moved on)
+               L.act <= policy::kRegroupBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
+               (!ws->sorted || ws->moved_since_sort > policy::kRegroupMoved * rows_l);      // (again once that share of the rows has moved on)
     };
     bool settle = false;
     if (ws->lock) {
@@ -1080,8 +1138,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                      (int)ws->have_drift, (int)settle);
     if (mode == kBound && ws->img_i8b) {
         // How many output blocks the bound pass evaluates.  Cost model per (sample, component) pair, in units of
-        // 1e-11 s measured at C3 (profiles/r1_v6_*): bound pass 0.12 per block pair + 0.039 per row of y; exact pass
-        // 0.81 per f64 tile pair of every candidate.  Take the cheapest level among those observed in the last 32
+        // 1e-11 s (namespace policy above): bound pass kI8BlockPair per block pair + kI8RowOfY per row of y; exact pass
+        // kF64TilePair per f64 tile pair of every candidate.  Take the cheapest level among those observed in the last 32
         // bound passes; look one level down when the current one leaves hardly any spare candidates or one level up
         // when more than half of its candidates are spare, if that level is unknown.
         // When the bounds are going to be carried (sweeps follow for tens of passes), all blocks: every nat of slack a bound
@@ -1103,12 +1161,12 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (l != cur && (++ws->tb_seen[l] > 32 || ws->tb_act[l] > 1.5 * ws->tb_act[cur] ||
                                  ws->tb_act[l] < ws->tb_act[cur] / 1.5))
                     ws->tb_cand[l] = -1.0;
-            const double gpp = 0.81 * tri_pairs(ws->T);
+            const double gpp = policy::kF64TilePair * tri_pairs(ws->T);
             // carried passes follow a bound pass and inherit its spare candidates: a tighter bound pays for part of itself
             const double heirs = gmmvb_wants_drift(ws, n_rows) ? 3.0 : 0.0;
             auto cost = [&](int l) {
                 const double spare_l = ws->tb_cand[l] > ws->tb_act[l] ? ws->tb_cand[l] - ws->tb_act[l] : 0.0;
-                return 0.12 * tri_pairs(l) + 0.039 * 32 * l + gpp * (ws->tb_cand[l] + heirs * spare_l);
+                return policy::kI8BlockPair * tri_pairs(l) + policy::kI8RowOfY * 32 * l + gpp * (ws->tb_cand[l] + heirs * spare_l);
             };
             int best = cur;
             for (int l = 1; l <= t32; ++l)
@@ -1118,7 +1176,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (cur > 1 && ws->tb_cand[cur - 1] < 0.0 && spare * ws->K < (heirs > 0.0 ? 0.02 : 0.25))
                     best = cur - 1;
                 else if (cur < t32 && ws->tb_cand[cur + 1] < 0.0 &&
-                         spare * gpp > 0.12 * (tri_pairs(cur + 1) - tri_pairs(cur)) + 0.039 * 32)
+                         spare * gpp > policy::kI8BlockPair * (tri_pairs(cur + 1) - tri_pairs(cur)) + policy::kI8RowOfY * 32)
                     best = cur + 1;
             }
             ws->bound_tb = best;
@@ -1280,7 +1338,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 // digits), so that the sweep compares the other components' bounds with a tight reference instead of one
                 // carried through Gamma and delta (records.h, own_first).  While the summary of the drift says that no
                 // component moves that much the round is skipped altogether.
-                const bool own_round = proof && ws->skip_used && !(ws->typical_gamma >= 0.995);
+                const bool own_round = proof && ws->skip_used && !(ws->typical_gamma >= policy::kOwnRoundBelow);
                 if (own_round) {
                     span_begin(ws, kSpanSelect, st);
                     hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->lcomp,
@@ -1536,7 +1594,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const char* name = "";
     hipError_t e;
     bool sparse = ws->sparse && ws->masks && pre && ws->e_state == 1 && ws->act_rows == n_rows;
-    if (sparse) {      // the lists pay off when most pairs are negligible (at most 35 % active)
+    if (sparse) {      // the lists pay off while act kListMns < K kDenseMns (policy::kListMBelow)
         const double pairs = (double)n_rows * ws->K;
         if (ws->rec_live) {
             // a pruned E-step leaves exact values for the listed pairs only (the others are bounded in the f32 array, not in
@@ -1545,7 +1603,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // after a dense E-step the host has been waiting for that kernel anyway: read this pass's own count
             rc = fetch_counters(ws);
             if (rc) return rc;
-            sparse = ws->lag.valid && ws->lag.act <= 0.35 * pairs;
+            sparse = ws->lag.valid && ws->lag.act <= policy::kListMBelow * pairs;
         }
     }
     if (sparse && ws->K > 256) sparse = false;
