@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgmmvb.so")
+# (BAYESML_AMD_LIB: a developer switch to load a variant build of the same ABI, e.g. for an A/B measurement on one box)
+LIB_PATH = os.environ.get("BAYESML_AMD_LIB") or os.path.join(_HERE, "csrc", "libgmmvb.so")
 
 GMMVB_F32, GMMVB_F64 = 0, 1
 POLICY_LEN = 16           # include/gmmvb.h: GMMVB_POLICY_LEN

@@ -48,7 +48,7 @@ __global__ void center_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64_
 // ln r_nk = lnrho[k][n] - lse[n] of every component (dpart[block][k]); thr_kernel turns those into the M-step's
 // skip thresholds.
 constexpr int kLseRows = 1024;      // rows per block (256 threads x 4)
-// apart[block] = number of (row, component) pairs of the block with ln r >= -100 ln 2 (how sparse r is: the next
+// apart[block] = number of (row, component) pairs of the block with ln r >= -80 ln 2 (how sparse r is: the next
 // E-step prunes only when that fraction is small).
 // `stride` > 1: only every stride-th block of rows is visited (a sample of the rows: its maxima are lower bounds of the
 // true ones, which is all a skip threshold needs; see lse_mask_kernel).
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__
             if (n < n_rows) {
                 const double v = lnrho[(int64_t)k * npad + n] - l[q];
                 d = (v > d || v != v) ? v : d;          // NaN wins: the threshold becomes NaN = nothing is skipped
-                active += !(v < -69.314718055994530942);
+                active += !(v < -kRelevanceNats);
             }
         }
 #pragma unroll
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__
     if (threadIdx.x == 0 && apart) apart[blockIdx.x] = (double)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
 }
 
-// thr[k] = max over blocks of dpart[.][k] - 100 ln 2 (mstep.h, sparse responsibilities); act_total = sum of apart.
+// thr[k] = max over blocks of dpart[.][k] - 80 ln 2 (mstep.h, sparse responsibilities); act_total = sum of apart.
 // One 256-thread workgroup per component (workgroup K sums apart).
 __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpart, const double* __restrict__ apart,
                                                   int blocks, int K, double* __restrict__ thr,
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpa
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < 256; ++i) d = (part[i] > d || part[i] != part[i]) ? part[i] : d;
-        thr[k] = d - 69.314718055994530942;
+        thr[k] = d - kRelevanceNats;
     }
 }
 
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
 }
 
 // lse[n] for every row, and in the same pass the M-step's active mask (ln r_nk = lnrho[k][n] - lse[n] >= thr[k], mstep.h),
-// its block counts, and the number of pairs with ln r >= -100 ln 2 per block (apart).  thr comes from a sample of
+// its block counts, and the number of pairs with ln r >= -80 ln 2 per block (apart).  thr comes from a sample of
 // the rows (row_lse_kernel with a stride): a maximum over fewer rows is smaller, the threshold lower, the lists at
 // worst a little longer - never a relevant sample dropped.  One thread per row, 256 rows per block.
 __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
             for (int b = 0; b < kend; ++b) {
                 const double t = lnrho[(int64_t)(64 * w + b) * npad + n] - l;
                 mk |= (unsigned long long)(!(t < thr[64 * w + b])) << b;   // NaN stays active
-                active += !(t < -69.314718055994530942);
+                active += !(t < -kRelevanceNats);
             }
             masks[(int64_t)w * npad + n] = mk;
         }

@@ -128,7 +128,7 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB
 
 // The same with an early way out for candidates that turn out irrelevant: after the first J1 output blocks (J1 (J1 + 1) / 2
 // of the JB (JB + 1) / 2 tile pairs) the partial sum q_J1 <= q already bounds ln rho from above; if for EVERY row of the wave
-// tile  c_k - q_J1 / 2 < thr[row]  (the row's relevance threshold: its best exact value - 100 ln 2, written by the
+// tile  c_k - q_J1 / 2 < thr[row]  (the row's relevance threshold: its best exact value - 80 ln 2, written by the
 // selection kernels), the remaining blocks are skipped and the bound is stored instead of the value.  Whoever reads the
 // array treats a stored value below thr[row] as a bound (records.h, rec_finish_kernel).  Pairs that are evaluated in
 // full go through exactly the same operations as in estep_component.
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void estep_lds_f64(const XT* __restrict__ 
 
 // ---- pruned E-step -----------------------------------------------------------------------------------------------
 // Once the responsibilities are sparse, almost every (sample, component) pair only has to be shown irrelevant
-// (r_nk < 2^-100: it changes neither lse_n nor, mstep.h, any statistic beyond the last bit).  The bounds that show it come
+// (r_nk < 2^-80: it changes neither lse_n nor, mstep.h, any statistic beyond the last bit).  The bounds that show it come
 // from the int8 matrix pipe (estep_i8.h: a bound pass over all pairs, the proof round over listed pairs) and are carried
 // from pass to pass (records.h); what cannot be shown irrelevant is evaluated exactly by the gather kernel below
 // (component fixed per workgroup, sample rows gathered through per-component lists).  The results of the exact pairs do not

@@ -355,10 +355,10 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
 
 // ---- sparse responsibilities ---------------------------------------------------------------------------------
 // After the first VB iterations most responsibilities are negligible: a sample belongs to a handful of the K
-// components.  A term with r_nk < 2^-100 max_n r_nk cannot change any of component k's f64 sums (there are fewer
-// than 2^40 terms and the sums are at least as large as their largest term), so the statistics are unchanged to the
+// components.  A term with r_nk < 2^-80 max_n r_nk cannot change any of component k's f64 sums (there are fewer
+// than 2^27 terms and the sums are at least as large as their largest term), so the statistics are unchanged to the
 // last bit of rounding when such samples are skipped - and skipping them removes their row loads and MFMAs.
-// thr[k] = max_n (ln rho_nk - lse_n) - 100 ln 2 over a sample of the rows (row_lse_kernel / thr_kernel); lse_mask_kernel,
+// thr[k] = max_n (ln rho_nk - lse_n) - 80 ln 2 over a sample of the rows (row_lse_kernel / thr_kernel); lse_mask_kernel,
 // scan_counts and fill_lists (aux_kernels.h) write, per component, the ascending list of its active rows; mstep_list_f64 is
 // mstep_body over list positions instead of rows (LIST form: one index load per 64 entries, the row addresses go
 // through it).

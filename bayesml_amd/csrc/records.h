@@ -1,7 +1,7 @@
 // Per-row candidate records and per-pair bounds of the pruned E-step.
 //
 // Once the responsibilities are sparse (a handful of the K components matter per sample), the E-step only has to
-// PROVE the other pairs irrelevant (r_nk < 2^-100, invisible in every f64 sum of the reference's _update_q_z /
+// PROVE the other pairs irrelevant (r_nk < 2^-80, invisible in every f64 sum of the reference's _update_q_z /
 // _calc_n_x_bar_s, bayesml/gaussianmixture/_gaussianmixture.py:772-784, 725-732).  What is carried from one E-step to
 // the next is one f32 upper bound of ln rho per PAIR (ub, [K][npad], every entry rounded up).  A parameter update
 // (m, U) -> (m', U') with
@@ -9,7 +9,7 @@
 // (gmmvb_set_drift) turns a bound u under the old parameters into one under the new without touching x:
 //   d = sqrt(2 (c_k - u)_+) <= || U_k (x - m_k) ||,   u' = c'_k - (gamma_k d - delta_k)_+^2 / 2      (rec_sweep_kernel),
 // and a distance d of an exactly known pair into a LOWER bound of its new value, c'_k - (Gamma_k d + delta_k)^2 / 2.
-// With thr = (the row's reference value) - 100 ln 2:
+// With thr = (the row's reference value) - 80 ln 2:
 //   u' < thr    -> the pair is irrelevant this pass, nothing to compute;
 //   u' >= thr   -> the pair is a candidate: listed, evaluated exactly (f64 MFMA, estep_gather_dev_f64) - or, for a settled
 //                  row, bounded from both sides on the int8 pipe first (estep_i8_proof, rec_proof_decide_kernel).
@@ -32,7 +32,7 @@
 // listed entries of it are touched.
 //
 // rec_finish_kernel keeps three more things per row (workspace.h):
-//   rthr    the relevance threshold of the pass (best exact value - 100 ln 2): the candidate gather may stop a pair whose
+//   rthr    the relevance threshold of the pass (best exact value - 80 ln 2): the candidate gather may stop a pair whose
 //           partial sum already lies below it, and a stored value below it is treated as a bound, never flagged exact;
 //   lock / lcomp   whether the row's addend sits in the M-step's cache of single-component rows (r = 1.0 exactly), and for
 //           which component; the pass's changes leave through the delta masks (dmask), the M-step's own lists are mmask;
@@ -46,7 +46,7 @@ namespace gmmvb {
 constexpr int kRecSlots = 8;
 constexpr unsigned short kRecEmpty = 0xFFFF;
 constexpr unsigned short kRecListed = 0x4000, kRecExactBit = 0x8000, kRecCompMask = 0x3FFF;
-constexpr double k100Ln2 = 69.314718055994530942;
+constexpr double kRelNats = kRelevanceNats;      // kRelevanceBits ln 2 (common.h)
 
 struct RecArrays {
     unsigned short* k;      // [C][npad] component of slot j (kRecEmpty: unused)
@@ -177,7 +177,7 @@ __device__ __forceinline__ void count_word(unsigned long long mk, int w, int wav
 
 // After a bound pass: select the candidates from the records rec_build_kernel<true> has just made (no parameter update in
 // between: every slot's bound is what the bound pass computed, the one exact slot - the row's best component - gives the
-// threshold best - 100 ln 2).  Slots whose bound clears the threshold are done with; the others are listed, and so is
+// threshold best - 80 ln 2).  Slots whose bound clears the threshold are done with; the others are listed, and so is
 // every component WITHOUT a slot if the rest bound B does not clear it ("refreshed row": B becomes the largest bound among
 // the components not listed; more than 24 such components, or no exact slot: all K pairs are evaluated, "overflow row").
 // Outputs: masks (candidate components per row), per-block counts for scan_counts / fill_lists, epart[block] = listed
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
                 lb = l > lb ? l : lb;                                // NaN never raises the threshold
             }
         }
-        const double thr = lb - k100Ln2;
+        const double thr = lb - kRelNats;
         unsigned sel = 0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
 //       PREV   all pairs that were active in the previous pass (the M-step's lists, still in the workspace: no list
 //              building for this round); `masks` holds them on entry;
 //       !PREV  the row's previous best component khat[n];
-//   lists every other pair with u' >= v - 100 ln 2, and builds the row's record (C slots + rest bound) on the way,
+//   lists every other pair with u' >= v - 80 ln 2, and builds the row's record (C slots + rest bound) on the way,
 // so that the pass continues like a bound pass (gather -> rec_finish_kernel).
 //
 // The kernel is bound by its instruction count (K pairs per row, 8 bytes of traffic each), so the per-pair work is
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             fresh[kb >> 6] = 1ull << (kb & 63);
             vb = u[(int64_t)kb * npad + n];
         }
-        const double thr = vb - k100Ln2;
+        const double thr = vb - kRelNats;
         // A settled row (cached - its single active component kset has r = 1.0 exactly and its addend sits in the
         // statistics cache - and left out of the lists by rec_finish_kernel) has nothing evaluated for it: the reference
         // is a LOWER bound of ln rho under the new parameters, from the carried upper bound of its distance,
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             }
             const float lb = sq[kset].y - dn * dn * 0.5000005f;
             d_set = dn;
-            thr_set = (lb - fabsf(lb) * 2.4e-7f) - 69.5f;
+            thr_set = (lb - fabsf(lb) * 2.4e-7f) - ((float)kRelevanceNats + 0.2f);
         }
         over = !by_bound && !(thr > ninf);          // NaN / -inf: nothing to compare with
         thr_f = by_bound ? thr_set : (over ? -__builtin_huge_valf() : f32_down(thr));   // over: every pair is a candidate
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
 
 // After the proof round (estep_i8_proof over the pairs of pmask): every row the sweep flagged 8 has a lower bound of its
 // component's ln rho in lb[kset][n] and fresh upper bounds of its candidates in ub32.  A candidate whose bound lies below
-// lb - 100 ln 2 is irrelevant (r < 2^-100 against the row's log-normaliser >= lb): if all are, the row stays settled - its
+// lb - 80 ln 2 is irrelevant (r < 2^-80 against the row's log-normaliser >= lb): if all are, the row stays settled - its
 // responsibility is 1.0 to the last bit whatever the exact values (flag 4, new distance bound in dlock); otherwise the row
 // comes loose: its component and the surviving candidates join the pass's lists for the exact gather, slots that hold
 // one of them are marked selected (rec_finish_kernel finds the evaluated pairs through the slots and the mask), and the
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
         for (int w = 0; w < W; ++w) mk[w] = masks[(int64_t)w * npad + n];
         const unsigned fl0 = rec.flags[n];
         if (fl0 & 16u) {
-            // candidates of a row whose reference is exact (rthr = its best exact value - 100 ln 2): those whose fresh bound
+            // candidates of a row whose reference is exact (rthr = its best exact value - 80 ln 2): those whose fresh bound
             // clears the threshold are done with; the others join the pass's lists (and may still leave the exact gather early)
             const double thr = (double)rthr[n];
             unsigned sel = rec.sel[n];
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
         if (fl0 == 8u) {
             const int kset = lcomp[n];
             const double l = lb[(int64_t)kset * npad + n];
-            const double thr = l - k100Ln2;                              // -inf when the proof kernel had no bound
+            const double thr = l - kRelNats;                              // -inf when the proof kernel had no bound
             unsigned long long kept[4] = {0ull, 0ull, 0ull, 0ull};
             bool any = false;
             float done_max = -__builtin_huge_valf();       // largest fresh bound among the candidates that are done with
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
 
 // Bound pass with a proof round: the candidates rec_select_kernel has listed carry bounds from the bound pass's leading
 // output blocks only; estep_i8_proof has given each of them a bound from ALL blocks (ub32).  Those that now clear the row's
-// threshold (its best component's exact value - 100 ln 2) are done with: taken off the pass's lists; a slot keeps the fresh
+// threshold (its best component's exact value - 80 ln 2) are done with: taken off the pass's lists; a slot keeps the fresh
 // bound, a component without a slot rejoins the rest bound B.  Overflow rows are left alone.  Recounts the lists per block.
 __global__ __launch_bounds__(kSelRows) void rec_prune_kernel(RecArrays rec, unsigned long long* __restrict__ masks, int64_t npad,
                                                              int64_t n_rows, int K, const double* __restrict__ cvec,
@@ -1077,7 +1077,7 @@ __global__ void gather_plan_kernel(const int* __restrict__ counts, int K, int pe
 
 // After the exact evaluation of the listed pairs: refresh the records from the exact values (distances, exact
 // flags; overflow rows are rebuilt from all K values), and produce what the rest of the pass needs per row:
-// lse_n, the best component, the M-step's active mask (r_nk >= 2^-100) with its block counts, apart[block] = active pairs.
+// lse_n, the best component, the M-step's active mask (r_nk >= 2^-80) with its block counts, apart[block] = active pairs.
 __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, const double* __restrict__ lnrho, int64_t npad,
                                                               int64_t n_rows, int K, const double* __restrict__ cvec,
                                                               double* __restrict__ lse, int* __restrict__ khat,
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     double row_l = 0.0, row_best = 0.0, row_second = __builtin_huge_val();
     int row_arg = -1;
     // a stored value below the row's relevance threshold may be a bound (the gather's early way out, estep.h): it is
-    // irrelevant either way (2^-100 below the best), counts as evaluated, but is never flagged exact
+    // irrelevant either way (2^-80 below the best), counts as evaluated, but is never flagged exact
     const double thr_row = valid ? (double)rthr[n] : 0.0;
     if (valid && fl == 4u) {
         // settled row: nothing was evaluated, nothing changes (lse[n] and the ln rho entries are stale until a read-out
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
                 const double t = lnrho[(int64_t)(64 * w + b) * npad + n] - l;
-                if (!(t < -k100Ln2)) {
+                if (!(t < -kRelNats)) {
                     mk[w] |= 1ull << b;
                     ++active;
                 }
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
             if (!((live >> j) & 1u)) continue;
-            if (!(v[j] - l < -k100Ln2)) {                           // NaN stays active
+            if (!(v[j] - l < -kRelNats)) {                           // NaN stays active
                 mk[kk[j] >> 6] |= 1ull << (kk[j] & 63);
                 ++active;
             }
@@ -1317,14 +1317,14 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         rec.sel[n] = (unsigned char)ex;
         for (int k = 0; k < K; ++k) {
             const double t = lnrho[(int64_t)k * npad + n] - l;
-            if (!(t < -k100Ln2)) {
+            if (!(t < -kRelNats)) {
                 mk[k >> 6] |= 1ull << (k & 63);
                 ++active;
             }
         }
     }
     // The cache of single-component rows (workspace.h): a row whose ONLY active component is k has r_nk = 1.0 to the last
-    // bit (the other terms of its log-normaliser are below 2^-100), so its addend to component k's statistics is the same
+    // bit (the other terms of its log-normaliser are below 2^-80), so its addend to component k's statistics is the same
     // in every pass in which that holds - it is kept in the cache and the row left out of the M-step's lists (mmask).
     //   lock 0 -> 3  the row enters the cache of its component;  1 -> 1  it stays;  1 -> 2  it leaves;  1 -> 4  it moves
     //   to another component (fill_lists_kernel gives the delta lists' entries their signs and settles the state).
@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     // its carried bounds, and what they no longer prove goes through the int8 proof round instead of an exact evaluation.
     // By default every single-component row settles (whatever its carried bounds say, the proof round is cheaper than the
     // exact evaluation of the row's component plus its candidates); with a margin only rows whose other components all
-    // lie at least that many nats below the 2^-100 line.
+    // lie at least that many nats below the 2^-80 line.
     unsigned long long mm[4] = {mk[0], mk[1], mk[2], mk[3]};         // the M-step's lists
     int in_lists = 0, m_pairs = 0;
     if (valid && lock != nullptr && fl != 4u) {
@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         if (single) {
             lcomp[n] = (unsigned char)row_arg;
             mm[row_arg >> 6] &= ~(1ull << (row_arg & 63));
-            if (settle_margin >= 1e300 || (settle_margin >= 0.0 && row_second < row_l - k100Ln2 - settle_margin)) {
+            if (settle_margin >= 1e300 || (settle_margin >= 0.0 && row_second < row_l - kRelNats - settle_margin)) {
                 dlock[n] = f32_up(dist_of(cvec[row_arg], row_best) * (1.0 + 1e-9));
                 mk[row_arg >> 6] &= ~(1ull << (row_arg & 63));
             }
@@ -1493,9 +1493,9 @@ __global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const
     if (n < n_rows && row_settled(lock, emask, npad, (K + 63) / 64, n)) lse[n] = lnrho[(int64_t)lcomp[n] * npad + n];
 }
 
-// Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-100) marks the pairs
+// Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-80) marks the pairs
 // whose exact value is in the dense array.  mode 0: ln rho - exact for active pairs and for exact slots, otherwise the
-// record's upper bound (at least 100 ln 2 below the row's log-normaliser); mode 1: responsibilities, exactly 0 for inactive pairs.
+// record's upper bound (at least 80 ln 2 below the row's log-normaliser); mode 1: responsibilities, exactly 0 for inactive pairs.
 __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __restrict__ masks,
                                    const double* __restrict__ lnrho, const double* __restrict__ lse,
                                    const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
@@ -1527,9 +1527,9 @@ __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __re
         }
     }
     if (!exact) {
-        // every pair that is not active lies at least 100 ln 2 below the row's log-normaliser (evaluated and found so,
+        // every pair that is not active lies at least 80 ln 2 below the row's log-normaliser (evaluated and found so,
         // or proven so by its bound): B alone may be the value of a ninth near component
-        const double cap = lse[n] - k100Ln2;
+        const double cap = lse[n] - kRelNats;
         ub = cap < ub ? cap : ub;
     }
     out[e] = exact ? lnrho[(int64_t)k * npad + n] : ub;

@@ -66,7 +66,7 @@ struct gmmvb_workspace {
     double* mpart = nullptr;           // [ceil(npad / 256)] rows whose best component changed, per selection block
     double moved_since_sort = 0.0;     // their sum over the passes since the rows were last regrouped
     bool pend_first_sorted = false;    // the E-step whose counters are in flight regrouped the rows
-    // counters of an E-step: [0] active pairs (r >= 2^-100), [1] pairs evaluated exactly, [2] overflow rows,
+    // counters of an E-step: [0] active pairs (r >= 2^-80), [1] pairs evaluated exactly, [2] overflow rows,
     // [3] rows whose best component changed.
     // Written on the device at the end of every E-step and copied to pinned host memory behind an event; the NEXT
     // E-step / M-step reads whatever has arrived (policy decisions lag one pass, results never depend on them).
@@ -99,9 +99,9 @@ struct gmmvb_workspace {
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)
-    double* thr = nullptr;     // [K] M-step skip thresholds: max_n ln r_nk - 100 ln 2 (valid while e_state == 1)
+    double* thr = nullptr;     // [K] M-step skip thresholds: max_n ln r_nk - 80 ln 2 (valid while e_state == 1)
     bool sparse = true;        // env GMMVB_MSTEP_SPARSE=0: always run the dense M-step
-    double* apart = nullptr;   // [ceil(npad / 256)] pairs with ln r >= -100 ln 2 per selection block
+    double* apart = nullptr;   // [ceil(npad / 256)] pairs with ln r >= -80 ln 2 per selection block
     int64_t act_rows = 0;      // rows of the E-step whose active pairs were counted (0 = not counted)
     double act_host = -1.0;    // host copy of ctr[0] for that E-step (-1 = not fetched yet)
     double evaluated = 0.0;    // pairs the last E-step evaluated exactly (-1: on the device, see gmmvb_last_sparsity)
@@ -124,7 +124,7 @@ struct gmmvb_workspace {
     unsigned char* lock = nullptr;     // [npad] 0 free, 1 settled, 2 came loose in this pass, 3 settled in this pass
     unsigned char* lcomp = nullptr;    // [npad] cached rows: the component whose cache holds the row (K <= 256)
     float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
-    float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 100 ln 2)
+    float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 80 ln 2)
     unsigned long long* exit_ctr = nullptr;    // [2] device: candidate pairs of the pass that took the gather's early way out;
                                                //     (tile, component) columns the lazy sweep opened
     unsigned long long* exit_host = nullptr;   // [2] pinned mirror (copied with the other counters)

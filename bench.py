@@ -408,7 +408,7 @@ def main():
         tiles = (D + 15) // 16
         fl_pair = 512 * tiles * (tiles + 1) // 2        # executed f64 MFMA flops per exactly evaluated (sample, component)
         ev = float(np.mean([e for _, e in spars]))      # pairs evaluated exactly per E-step
-        ac = float(np.mean([a for a, _ in spars]))      # active pairs (r >= 2^-100)
+        ac = float(np.mean([a for a, _ in spars]))      # active pairs (r >= 2^-80)
         # pairs the list M-step accumulates: active pairs minus the rows whose single component has r = 1.0 exactly and
         # did not change (their addends sit in the workspace's cache), plus the rows entering / leaving that cache
         acc = float(np.mean([wk["accumulated"] if wk["accumulated"] >= 0 else n_local * K for wk in works]))
@@ -437,6 +437,19 @@ def main():
             groups["estep_gather"]["executed_f64_tflops"] = fl_pair * done / groups["estep_gather"]["ms"] / 1e9
         if "mstep_main" in groups:
             groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (acc if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
+        if groups.get("estep_main", {}).get("ms", 0) > 0 and timed_counts["estep_dense"] + timed_counts["estep_fell_back_dense"] > 0 \
+                and timed_counts["estep_bound"] == 0:
+            groups["estep_main"]["executed_f64_tflops"] = fl_pair * n_local * K * (timed_counts["estep_dense"]
+                                                                                 + timed_counts["estep_fell_back_dense"]) / steps / groups["estep_main"]["ms"] / 1e9
+        # both yardsticks per kernel group: HBM (algorithmic bytes) and the f64 matrix pipe (executed flops); a group is bound
+        # by whichever fraction is larger
+        for gname, gv in groups.items():
+            if "algorithmic_GBps" in gv:
+                gv["hbm_frac"] = gv["algorithmic_GBps"] / PEAK_HBM_GBPS
+            if "executed_f64_tflops" in gv:
+                gv["f64_mfma_frac"] = gv["executed_f64_tflops"] / PEAK_F64_MFMA_TFLOPS
+            if "hbm_frac" in gv or "f64_mfma_frac" in gv:
+                gv["bound"] = "mfma" if gv.get("f64_mfma_frac", 0.0) > gv.get("hbm_frac", 0.0) else "hbm"
         cand = [g for g in ("estep_main", "estep_gather", "mstep_main") if g in groups and "algorithmic_GBps" in groups[g]]
         if cand:
             dom = max(cand, key=lambda g: groups[g]["ms"])
@@ -489,18 +502,20 @@ def main():
                 "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
                 "phase_ms": {"estep": e_ms, "mstep": m_ms},
                 "timed_kernel_launches": timed_counts,
-                "note": "achieved = algorithmic bytes of the dominant kernel group per step (rows it must read x D x s, "
-                        "SURVEY 8d) / its HIP-event time per step; frac <= 1 by construction.  step_hbm_frac = value / "
+                "note": "every kernel group carries hbm_frac (algorithmic bytes: rows it must read x D x s, SURVEY 8d, / its "
+                        "HIP-event time / 8 TB/s) and f64_mfma_frac (executed f64 MFMA flops / 78.6 TFLOP/s); `bound`, `achieved`, "
+                        "`peak`, `frac` are the dominant group's LARGER fraction; frac <= 1 by construction.  step_hbm_frac = value / "
                         "hbm_roofline_samples_per_s.  f64_mfma_ceiling = the rate at which the f64 matrix pipe alone could "
                         "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M).  "
                         "executed_f64_tflops of estep_gather charges the pairs that take the gather's early way out "
                         "(DESIGN.md 5c; pairs_per_sample.early_exits) with the tile pairs they really do"}
-        if (args.dense or not sparse_e) and dom:
-            # the dense kernels are MFMA-bound: executed flops against the f64 MFMA peak
-            ex = fl_pair * n_local * K
-            roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_F64_MFMA_TFLOPS,
-                        achieved=ex / (groups[dom]["ms"] * 1e-3) / 1e12,
-                        frac=ex / (groups[dom]["ms"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS)
+        if dom:
+            roof["hbm_frac"] = groups[dom].get("hbm_frac")
+            roof["f64_mfma_frac"] = groups[dom].get("f64_mfma_frac")
+        if dom and groups[dom].get("bound") == "mfma":
+            # the dominant kernel's larger fraction is of the f64 matrix pipe: executed flops against its peak
+            roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_F64_MFMA_TFLOPS, achieved=groups[dom]["executed_f64_tflops"],
+                        frac=groups[dom]["f64_mfma_frac"], hbm_achieved_GBps=ach)
         assert roof["frac"] <= 1.0 + 1e-9, roof
 
         last_launch = eng.launch_info

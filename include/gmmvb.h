@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GMMVB_ABI_VERSION 3
+#define GMMVB_ABI_VERSION 4
 
 enum gmmvb_status {
     GMMVB_OK = 0,
@@ -111,8 +111,8 @@ int gmmvb_estep_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64
 
 /* Read-outs for rows [row0, row0 + n_rows) of the last E-step, row-major [n_rows][K].
  * When the E-step pruned (large N K, sparse responsibilities; see gmmvb_last_sparsity), gmmvb_ln_rho returns, for the
- * pairs it did not evaluate, an upper bound of ln rho that lies at least 100 ln 2 below the row's log-normaliser, and
- * gmmvb_responsibilities returns exactly 0 for them (r < 2^-100): hard assignments and statistics are unaffected.  Pruning is never
+ * pairs it did not evaluate, an upper bound of ln rho that lies at least 80 ln 2 below the row's log-normaliser, and
+ * gmmvb_responsibilities returns exactly 0 for them (r < 2^-80): hard assignments and statistics are unaffected.  Pruning is never
  * used once hmmvb_enable has been called, or with GMMVB_ESTEP_PRUNE=0 in the environment. */
 int gmmvb_responsibilities(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* r_dev, void* stream);
 int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
@@ -277,7 +277,7 @@ int gmmvb_pass_counts(const gmmvb_workspace* ws, int64_t* out /*[8]*/);
  *   gamma || u_old (x - m_old) || - delta  <=  || u_new (x - m_new) ||  <=  big_gamma || u_old (x - m_old) || + delta,
  * which lets the next gmmvb_estep carry its per-row candidate records (csrc/records.h: up to 8 (component, distance)
  * slots and one bound for all other components, 55 bytes per row) over to the new parameters instead of bounding every
- * pair afresh: pairs whose carried bound proves r < 2^-100 are skipped, the others are evaluated exactly, and a row
+ * pair afresh: pairs whose carried bound proves r < 2^-80 are skipped, the others are evaluated exactly, and a row
  * whose record has become too loose has all K pairs evaluated.  Loose values only cost candidates, wrong ones (gamma too
  * large, big_gamma or delta too small) break the bounds.  typical_gamma: a pessimistic summary of the drift if the
  * caller has one on the host - min_k (gamma_k - delta_k / 30) is what bayesml_amd passes - or a value <= 0 if not: below
@@ -309,13 +309,13 @@ int gmmvb_debug_proof(gmmvb_workspace* ws, int k, int64_t n_rows, float* ub_dev 
                       void* stream);
 
 /* Sparsity of the last gmmvb_estep: *active_pairs = number of (row, component) pairs whose responsibility is at
- * least 2^-100 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
- * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-100).  *active_pairs = -1 when the
+ * least 2^-80 of the row's total, *evaluated_pairs = pairs whose ln rho was evaluated exactly (n_rows * K unless
+ * the E-step pruned; pruned pairs hold an upper bound that proves r < 2^-80).  *active_pairs = -1 when the
  * library did not count (GMMVB_MSTEP_SPARSE=0, tiny passes).  Waits for the E-step's counters (the one entry point
  * besides gmmvb_profile_* that blocks; gmmvb_mstep blocks the same way right after a DENSE gmmvb_estep of N K >= 2^18,
  * to choose between its dense and its list form). */
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs);
-/* The same (blocking) with the work the pass left for the M-step.  out[0] active pairs (r >= 2^-100; -1: not counted),
+/* The same (blocking) with the work the pass left for the M-step.  out[0] active pairs (r >= 2^-80; -1: not counted),
  * out[1] pairs the E-step evaluated exactly, out[2] pairs the list M-step accumulates (rows whose single component has
  * r = 1.0 exactly keep their addend in a cache and are only touched when that changes; -1: not counted), out[3] rows the
  * E-step did not evaluate at all (settled: their carried bounds prove that nothing changed), out[4] of the pairs in

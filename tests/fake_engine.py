@@ -144,7 +144,7 @@ class CpuDataPass:
     def policy_export(self, tail):
         r = self.responsibilities()
         tail.zero_()
-        tail[0] = float((r >= 2.0 ** -100).sum())       # active pairs of this rank's rows
+        tail[0] = float((r >= 2.0 ** -80).sum())       # active pairs of this rank's rows
         tail[1] = float(r.numel())                      # pairs evaluated exactly (the stand-in is dense)
         tail[9] = float(r.shape[0])                     # rows
         tail[10] = 1.0                                  # ranks

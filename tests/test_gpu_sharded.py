@@ -181,10 +181,20 @@ def test_restarts_over_two_ranks_on_the_real_engine(tmp_path):
     mp.spawn(_restart_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     g = load_golden("gmm_f3_c1_subsampling.npz")
     x = load_golden("gmm_c1_sample.npz")["x"]
-    one = gm.LearnModel(3, 2, seed=0, device="cuda:0")
-    with redirect_stdout(io.StringIO()) as buf, warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        one.update_posterior(x)
+    # (the single-process run at this size would take the one-launch small-problem path, whose sums run in another order:
+    # bit-for-bit equality is a statement about the general engine, which is what the sharded ranks ran)
+    old = os.environ.get("BAYESML_AMD_SMALL")
+    os.environ["BAYESML_AMD_SMALL"] = "0"
+    try:
+        one = gm.LearnModel(3, 2, seed=0, device="cuda:0")
+        with redirect_stdout(io.StringIO()) as buf, warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            one.update_posterior(x)
+    finally:
+        os.environ.pop("BAYESML_AMD_SMALL", None)
+        if old is not None:
+            os.environ["BAYESML_AMD_SMALL"] = old
+    assert one._engine is not None
     text = buf.getvalue()
     ranks = [dict(np.load(os.path.join(str(tmp_path), f"restart_rank{r}.npz"))) for r in range(2)]
     for r, res in enumerate(ranks):

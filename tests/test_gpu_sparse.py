@@ -1,9 +1,9 @@
 """The sparse-responsibility M-step and the pruned E-step against the dense kernels.
 
-Both only drop work that cannot change the f64 results (responsibilities below 2^-100 of the component's / the
+Both only drop work that cannot change the f64 results (responsibilities below 2^-80 of the component's / the
 sample's largest one), so everything that leaves the data pass has to agree with the dense path to rounding:
 statistics, responsibilities, hard assignments, posterior hyper-parameters.  ln rho itself is allowed to be an
-upper bound for pruned pairs, at least 100 ln 2 below the sample's best component.
+upper bound for pruned pairs, at least 80 ln 2 below the sample's best component.
 The switches are environment variables read when a workspace is created."""
 import os
 import warnings
@@ -72,7 +72,7 @@ def test_driver_sparse_equals_dense(K, K_data, D, N, dtype, iters):
     assert np.all(lb[~same] >= la[~same])
     mx = la.max(axis=1, keepdims=True)
     lse = mx + np.log(np.exp(la - mx).sum(axis=1, keepdims=True))
-    assert np.all((lb <= lse - 69.0) | same)
+    assert np.all((lb <= lse - 55.4) | same)          # 80 ln 2 = 55.45
     if K == K_data:        # (with several components per cluster every pair may be a candidate)
         assert same.mean() < 0.9, "the pruned path did not prune anything"
 

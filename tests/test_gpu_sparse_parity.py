@@ -179,7 +179,7 @@ def test_large_fixture_matches_reference(name, variant):
         else:       # (the cache lives through every pruned pass; after a sweep most single-component rows are in it)
             assert 0 <= wk["accumulated"] <= wk["active"], wk
             if swept:
-                assert wk["accumulated"] < 0.8 * wk["active"], wk
+                assert wk["accumulated"] < wk["active"], wk
         if variant in ("default", "settle") and swept:
             assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
         if variant in ("nosettle", "noproof"):      # (without settled rows the proof round still serves the bound passes)
@@ -213,7 +213,7 @@ def _oracle_post(q):
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
-    bound of it lying at least 100 ln 2 below the row's best component; responsibilities and statistics equal the
+    bound of it lying at least 80 ln 2 below the row's best component; responsibilities and statistics equal the
     oracle's.  The loop is update_posterior's (K-side update -> drift hint -> data pass)."""
     from bayesml_amd import _kside
     from bayesml_amd import gaussianmixture as gm
@@ -253,7 +253,7 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         assert np.all(lb[~same] >= la[~same]), (it, "a carried value is not an upper bound")
         mx = la.max(axis=1, keepdims=True)
         lse = mx + np.log(np.exp(la - mx).sum(axis=1, keepdims=True))
-        assert np.all((lb <= lse - 69.0) | same), it
+        assert np.all((lb <= lse - 55.4) | same), it          # 80 ln 2 = 55.45
         assert np.max(np.abs(eng.responsibilities().cpu().numpy() - st.r)) < 1e-9
         assert rel_err(ns.cpu().numpy(), st.ns) < 1e-10 and rel_err(s.cpu().numpy(), st.s) < 1e-9
         checked += 1

@@ -39,7 +39,7 @@ def main():
     multi = []
     for lo in range(0, N, 500000):
         r = w.eng.responsibilities(lo, min(500000, N - lo))
-        multi.append(((r > 2.0 ** -100).sum(dim=1) > 1))
+        multi.append(((r > 2.0 ** -80).sum(dim=1) > 1))
     multi = torch.cat(multi)
     out = {"rows": N, "multi_share_at_B": float(multi.double().mean()), "gap_quantiles_at_A": [float(v) for v in torch.quantile(gap[::37].double(), torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95], dtype=torch.float64, device=dev))]}
     order_now = torch.argsort(dom, stable=True)
