@@ -1530,6 +1530,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     if (ws->generic) {
         const int direct = ws->e_state == 2 ? 1 : (ws->e_state == 3 ? 2 : 0);
+        if (ws->e_state == 3 && hmm_ensure_gamma_cm(ws->hmm, st) != hipSuccess) return fail(GMMVB_EHIP, "gamma transpose launch");
         const double* lr = ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho;
         const double* aux = ws->e_state == 3 ? ws->lnrho : nullptr;
         int S = ws->gen_S;
@@ -1579,7 +1580,9 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int64_t grid = 8 * ((S + 7) / 8) * KG;
     MstepArgs a{x_dev, ldx, n_rows, ws->D, ws->pivot, ws->lnrho, ws->lse, nullptr, ws->npad, ws->K, KG, (int)S,
                 rows_per_split, ws->e_state == 2 ? 1 : 0, ws->slabs};
+    const bool hmm_small = ws->e_state == 3 && ws->T == 1 && pre;      // reads gamma time-major (hmm_mstep_small_kernel)
     if (ws->e_state == 3) {          // HMM: responsibilities = gamma from the forward-backward pass, h = sum gamma ln rho
+        if (!hmm_small && hmm_ensure_gamma_cm(ws->hmm, st) != hipSuccess) return fail(GMMVB_EHIP, "gamma transpose launch");
         a.lnrho = hmm_gamma_cm(ws->hmm);
         a.aux = ws->lnrho;
         a.direct_r = 2;
@@ -1720,7 +1723,10 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             const int per_wg = 4 * kSmallCw;
             const int KGW = (ws->K + per_wg - 1) / per_wg;
             grid = 8 * ((S + 7) / 8) * KGW;
-            e = launch_mstep_small((int)grid, st, a, KGW, kSmallCw, &name);
+            if (hmm_small)
+                e = launch_hmm_mstep_small((int)grid, st, a, KGW, hmm_gamma_tm(ws->hmm), hmm_padded_states(ws->hmm), &name);
+            else
+                e = launch_mstep_small((int)grid, st, a, KGW, kSmallCw, &name);
         } else {
             e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
         }
@@ -1817,6 +1823,7 @@ static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* ou
                            (hipStream_t)stream, ws->lnrho, ws->npad, ws->e_rows, ws->K, ws->lse, nullptr, nullptr, 1);
         ws->lse_stale = false;
     }
+    if (hmm_gamma && hmm_ensure_gamma_cm(ws->hmm, (hipStream_t)stream) != hipSuccess) return fail(GMMVB_EHIP, "gamma transpose launch");
     hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        hmm_gamma ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->lse, ws->npad, row0, n_rows, ws->K, mode,
                        (ws->e_state == 2 || hmm_gamma) ? 1 : 0, out, ws->sorted ? ws->iperm : nullptr);
@@ -1846,6 +1853,7 @@ int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_d
         if (e != hipSuccess) return fail(GMMVB_EHIP, "argmax read-out", e);
         return GMMVB_OK;
     }
+    if (ws->e_state == 3 && hmm_ensure_gamma_cm(ws->hmm, (hipStream_t)stream) != hipSuccess) return fail(GMMVB_EHIP, "gamma transpose launch");
     hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho, ws->npad, row0, n_rows, ws->K, z_dev, iperm);
     e = hipGetLastError();

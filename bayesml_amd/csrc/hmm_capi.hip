@@ -19,7 +19,10 @@ struct gmmvb_hmm_state {
     double* alpha_tm = nullptr;   // [npad][Kp]
     double* gamma_tm = nullptr;   // [npad][Kp]
     double* w_tm = nullptr;       // [npad][Kp]
-    double* gamma_cm = nullptr;   // [K][npad]  (the M-step's responsibility buffer)
+    double* gamma_cm = nullptr;   // [K][npad]  component-major copy of gamma, made on demand (hmm_ensure_gamma_cm): read-outs and
+                                  //            the M-step kernels of D > 16; the D <= 16 M-step reads gamma_tm itself
+    bool gamma_cm_valid = false;
+    int64_t gamma_rows = 0;       // rows of the last forward-backward pass
     double* mx = nullptr;         // [npad]
     double* cprime = nullptr;     // [npad]
     double* prod = nullptr;       // [max_chunks][Kp][Kp]
@@ -52,6 +55,17 @@ void hmm_state_destroy(gmmvb_hmm_state* h) {
     delete h;
 }
 const double* hmm_gamma_cm(const gmmvb_hmm_state* h) { return h ? h->gamma_cm : nullptr; }
+const double* hmm_gamma_tm(const gmmvb_hmm_state* h) { return h ? h->gamma_tm : nullptr; }
+int hmm_padded_states(const gmmvb_hmm_state* h) { return h ? h->Kp : 0; }
+// gamma component-major for whoever reads it that way: transposed once per forward-backward pass, and only if asked for
+hipError_t hmm_ensure_gamma_cm(gmmvb_hmm_state* h, hipStream_t st) {
+    if (!h || h->gamma_cm_valid || h->gamma_rows < 1) return hipSuccess;
+    const int64_t T = h->gamma_rows;
+    hipLaunchKernelGGL(hmm_gamma_to_cm_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((h->K + 63) / 64)), dim3(256), 0, st,
+                       h->gamma_tm, T, h->K, h->Kp, h->npad, h->gamma_cm);
+    h->gamma_cm_valid = true;
+    return hipGetLastError();
+}
 }  // namespace gmmvb
 
 namespace {
@@ -112,8 +126,8 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
     hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
                        h->lnc_partial, n_part, T, h->gamma_tm, out);
-    hipLaunchKernelGGL(hmm_gamma_to_cm_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0,
-                       st, h->gamma_tm, T, K, Kp, ws->npad, h->gamma_cm);
+    h->gamma_cm_valid = false;                 // (made on demand: hmm_ensure_gamma_cm)
+    h->gamma_rows = T;
     return hipGetLastError();
 }
 
@@ -150,8 +164,8 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
     hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
     hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
                        h->lnc_partial, n_part, T, h->gamma_tm, out);
-    hipLaunchKernelGGL(hmm_gamma_to_cm_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0,
-                       st, h->gamma_tm, T, K, Kp, ws->npad, h->gamma_cm);
+    h->gamma_cm_valid = false;
+    h->gamma_rows = T;
     return hipGetLastError();
 }
 

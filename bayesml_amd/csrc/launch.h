@@ -69,6 +69,9 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
 
 // sparse-responsibility M-step over the centred copy and per-component lists of active rows (mstep.h)
 hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, int cw, const char** name);
+// ... for the HMM: gamma read time-major ([rows][Kp], lane order) through LDS instead of a component-major copy
+hipError_t launch_hmm_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const double* gamma_tm, int Kp,
+                                  const char** name);
 
 struct MstepListArgs {
     const double* xc; const double* lnrho; const double* lse;

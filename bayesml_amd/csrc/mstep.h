@@ -353,6 +353,120 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
     }
 }
 
+// ---- the same for the HMM, with gamma read as the forward-backward pass leaves it --------------------------------------
+// hmmvb_forward_backward writes gamma time-major ([T][Kp], "lane order" within every 16-state block, hmm.h); round 3
+// transposed it to component-major for mstep_small_f64 (hmm_gamma_to_cm_kernel: 1.8 ms and 5.1 GB per iteration at config 5)
+// and then moved every responsibility across lanes twice per use (a 64-bit shuffle per step and component).  Here the
+// workgroup - four waves x CW = 8 components = the 32 states of two 16-blocks - copies the 64 rows x 256 bytes of its states
+// into LDS once per batch (contiguous in memory, one batch ahead), and every use is an LDS read: the row's own value for
+// ns / h, a 16-lane broadcast of sample 4 st + g for the MFMA operand.  Same operations per component in the same order as
+// mstep_small_f64 with direct_r = 2: bit-identical slabs.  aux = ln rho, component-major (the emission E-step's output).
+__host__ __device__ constexpr int lane_order_pos(int state) {          // hmm.h: hmm_pos
+    const int w = state & 15;
+    return (state & ~15) + 4 * (w & 3) + (w >> 2);
+}
+
+template <int CW>
+__global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __restrict__ xc, int64_t n_rows,
+                                                              const double* __restrict__ gamma_tm, int Kp,
+                                                              const double* __restrict__ aux, int64_t npad, int K, int KGW, int S,
+                                                              int64_t rows_per_split, double* __restrict__ slabs) {
+    static_assert(CW == 8, "four waves x CW components = one 32-state slice of a gamma row");
+    constexpr int LD = 33;                                  // padded row: lane stride 33 doubles, conflict-free
+    __shared__ double sg[2][64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int kgw = j % KGW;
+    const int split = (j / KGW) * 8 + xcd;
+    if (split >= S) return;                                 // (whole workgroup)
+    const int k0 = (kgw * 4 + wave) * CW;
+    const int64_t lo = (int64_t)split * rows_per_split;
+    int64_t hi = lo + rows_per_split;
+    if (hi > n_rows) hi = n_rows;
+    // staging: thread -> (row, quarter of the 32-state slice)
+    const int srow = tid >> 2, sq = tid & 3;
+    const int scol = 32 * kgw + 8 * sq;                     // first position of the eight this thread copies
+    double stage[8];
+    auto request = [&](int64_t c0) {
+        const int64_t t = c0 + srow;
+        const bool ok = t < hi && scol < Kp;
+        const double* src = gamma_tm + (ok ? t : lo) * Kp + (scol < Kp ? scol : 0);
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2 v = *reinterpret_cast<const d2*>(src + q);
+            stage[q] = ok ? v[0] : 0.0;
+            stage[q + 1] = ok ? v[1] : 0.0;
+        }
+    };
+    auto deposit = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sg[b][srow * LD + 8 * sq + q] = stage[q];
+    };
+    int pc[CW];                                             // position of component k0 + c inside the slice
+#pragma unroll
+    for (int c = 0; c < CW; ++c) pc[c] = lane_order_pos(k0 + c) - 32 * kgw;
+    d4 acc[CW];
+    double asum[CW], nsum[CW], hsum[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+        asum[c] = nsum[c] = hsum[c] = 0.0;
+    }
+    request(lo);
+    deposit(0);
+    __syncthreads();
+    double xn = xc[(lo + g) * 16 + i];
+    int b = 0;
+    for (int64_t c0 = lo; c0 < hi; c0 += 64, b ^= 1) {
+        if (c0 + 64 < hi) request(c0 + 64);                 // in flight while this batch is worked through
+        const double* sb = sg[b];
+        const int64_t nl = c0 + lane;
+        if (k0 < K) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int k = k0 + c;
+                if (k < K && nl < hi) {
+                    const double v = sb[lane * LD + pc[c]];
+                    if (v > 0.0) hsum[c] = fma(v, aux[(int64_t)k * npad + nl], hsum[c]);
+                    nsum[c] += v;
+                }
+            }
+#pragma unroll 4
+            for (int st = 0; st < 16; ++st) {
+                const double xq = xn;
+                xn = xc[(c0 + 4 * (st + 1) + g) * 16 + i];          // (zero rows up to npad + 64: no clamp)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    const double ra = (k0 + c < K ? sb[(4 * st + g) * LD + pc[c]] : 0.0) * xq;
+                    asum[c] += ra;
+                    acc[c] = mfma_f64(ra, xq, acc[c]);
+                }
+            }
+        }
+        if (c0 + 64 < hi) deposit(b ^ 1);
+        __syncthreads();                                    // the next batch is in LDS; everybody is done with this one
+    }
+    if (k0 >= K) return;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const int k = k0 + c;
+        if (k >= K) break;
+        double* out = slabs + ((int64_t)split * K + k) * slab_len(1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r * 64 + lane] = acc[c][r];
+        const double a = sum_groups(asum[c]);
+        if (g == 0) out[256 + i] = a;
+        const double n = sum_wave(nsum[c]), h = sum_wave(hsum[c]);
+        if (lane == 0) {
+            out[256 + 16 + 0] = n;
+            out[256 + 16 + 1] = h;
+        }
+    }
+}
+
 // ---- sparse responsibilities ---------------------------------------------------------------------------------
 // After the first VB iterations most responsibilities are negligible: a sample belongs to a handful of the K
 // components.  A term with r_nk < 2^-80 max_n r_nk cannot change any of component k's f64 sums (there are fewer

@@ -32,6 +32,14 @@ hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int 
     return hipGetLastError();
 }
 
+hipError_t launch_hmm_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const double* gamma_tm, int Kp,
+                                  const char** name) {
+    *name = "hmm_mstep_small<T=1,8 components per wave,gamma time-major>";
+    hipLaunchKernelGGL((hmm_mstep_small_kernel<8>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(a.x), a.n_rows, gamma_tm,
+                       Kp, a.aux, a.npad, a.K, KGW, a.S, a.rows_per_split, a.slabs);
+    return hipGetLastError();
+}
+
 int mstep_components_per_wg(int T, bool pre) { return mstep_waves(T, pre) / mstep_ws(T); }
 int mstep_threads(int T, bool pre) { return 64 * mstep_waves(T, pre); }
 

@@ -207,6 +207,9 @@ struct gmmvb_workspace {
 namespace gmmvb {
 int fail(int code, const char* what, hipError_t e = hipSuccess);     // sets the thread-local message
 void hmm_state_destroy(gmmvb_hmm_state* h);
-const double* hmm_gamma_cm(const gmmvb_hmm_state* h);                 // [K][npad] responsibilities of the last pass
+const double* hmm_gamma_cm(const gmmvb_hmm_state* h);                 // [K][npad] responsibilities of the last pass (after hmm_ensure_gamma_cm)
+const double* hmm_gamma_tm(const gmmvb_hmm_state* h);                 // [npad][Kp] the same, time-major in lane order (hmm.h)
+int hmm_padded_states(const gmmvb_hmm_state* h);                      // Kp
+hipError_t hmm_ensure_gamma_cm(gmmvb_hmm_state* h, hipStream_t st);   // transposes gamma once per pass, on demand
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 }  // namespace gmmvb
