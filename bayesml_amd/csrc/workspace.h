@@ -96,6 +96,7 @@ struct gmmvb_workspace {
     bool exp_counted = false;          // the last E-step counted its pairs (what gmmvb_policy_export may hand out)
     bool forget = false;               // gmmvb_forget: the next parameters are unrelated to the last E-step's
     double spare_last = -1.0;          // spare candidates per pair of the last pruned pass (diagnostics)
+    double bound_fail_act = -1.0;      // active share of the pairs when a bound pass last left most of them candidates (< 0: never)
     double* cvec = nullptr;    // [K]
     double* pivot = nullptr;   // [D]
     double* dpart = nullptr;   // [ceil(npad / 1024)][K] block maxima of ln r (row_lse_kernel)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: tests, bench legs, rocprofv3 kernel trace and PMC passes.  usage: tools/gpu_round.sh <tag> <stage>...
-# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench
+# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist
 # (pmc / hmmpmc first: the bench stages quote the traffic files they write)
 # Outputs under gpurun_out/<tag>_*; copy the summaries worth keeping into profiles/.
 set -u
@@ -17,9 +17,13 @@ for stage in "$@"; do
     dense) timeout 600 python bench.py --dense --no-cpu > $OUT/${TAG}_bench_line_dense.json 2> $OUT/${TAG}_dense.err; head -c 600 $OUT/${TAG}_bench_line_dense.json; echo ;;
     c4) timeout 900 python bench.py --config c4 --no-cpu > $OUT/${TAG}_bench_line_c4.json 2> $OUT/${TAG}_c4.err; tail -c 600 $OUT/${TAG}_c4.err; head -c 600 $OUT/${TAG}_bench_line_c4.json; echo ;;
     c2) timeout 600 python bench.py --config c2 > $OUT/${TAG}_bench_line_c2.json 2> $OUT/${TAG}_c2.err; tail -c 600 $OUT/${TAG}_c2.err; head -c 600 $OUT/${TAG}_bench_line_c2.json; echo ;;
+    steps) f=$(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_steps.py $f 7 12 24 > $OUT/${TAG}_bench_steps.txt 2>&1; head -12 $OUT/${TAG}_bench_steps.txt ;;
+    spread1) timeout 600 python bench.py --no-cpu --no-legs --rows 2000000 --spread 1.0 --steps 20 --warmup 2 > $OUT/${TAG}_bench_line_spread1.json 2> $OUT/${TAG}_spread1.err; head -c 300 $OUT/${TAG}_bench_line_spread1.json; echo ;;
+    hist) timeout 300 python tools/active_hist.py > $OUT/${TAG}_active_hist.json 2> $OUT/${TAG}_hist.err; head -c 300 $OUT/${TAG}_active_hist.json; echo ;;
     trace) rm -rf $OUT/${TAG}_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_trace.err)
            python tools/summarize_rocprof.py $OUT/${TAG}_trace > $OUT/${TAG}_bench_kernel_summary.md 2>> $OUT/${TAG}_trace.err; head -30 $OUT/${TAG}_bench_kernel_summary.md
-           find $OUT/${TAG}_trace -name "*kernel_trace.csv" -size +20M -delete ;;
+           ;;
+    tracedel) find $OUT/${TAG}_trace -name "*kernel_trace.csv" -size +20M -delete ;;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/${TAG}_pmc_$c
            (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c.err); done
          python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE --config "K64 D128 N10000000 f32" --window w5s20 --json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.md 2> $OUT/${TAG}_pmc.err; head -60 $OUT/${TAG}_pmc_summary.md
