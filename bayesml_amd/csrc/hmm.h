@@ -528,14 +528,25 @@ __global__ __launch_bounds__(256) void hmm_xi_sum_kernel(const double* __restric
     for (int it = 0; it < KT; ++it)
 #pragma unroll
         for (int jt = 0; jt < KT; ++jt) acc[it][jt] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int64_t t = lo; t < hi; t += 4) {
+    // the operands of step group t + 4 are requested before the MFMAs of group t (one group in flight per wave)
+    double an[KT], bn[KT];
+    auto fetch = [&](int64_t t) {
         const int64_t tt = t + g;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            an[kt] = tt < hi ? alpha_tm[(tt - 1) * Kp + 16 * kt + i] : 0.0;
+            bn[kt] = tt < hi ? w_tm[tt * Kp + 16 * kt + i] : 0.0;
+        }
+    };
+    fetch(lo);
+    for (int64_t t = lo; t < hi; t += 4) {
         double a[KT], b[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            a[kt] = tt < hi ? alpha_tm[(tt - 1) * Kp + 16 * kt + i] : 0.0;
-            b[kt] = tt < hi ? w_tm[tt * Kp + 16 * kt + i] : 0.0;
+            a[kt] = an[kt];
+            b[kt] = bn[kt];
         }
+        fetch(t + 4);
 #pragma unroll
         for (int it = 0; it < KT; ++it)
 #pragma unroll

@@ -23,15 +23,22 @@ Legs of the default single-GPU run, all on the same JSON line:
                   falls back to, its executed TFLOP/s against the f64 MFMA peak, and the difference of the
                   statistics block between the two paths on identical parameters
   hard_workload   heavily overlapping clusters (means 0.3 * randn): what the policy does when nothing can be pruned
+  spread_sweep    the middle of the separation spectrum: means spread * randn for spread in {0.5, 0.75, 1.0, 1.5} at N = 2e6,
+                  default policy against dense kernels only over iterations 3-22, each with an oracle parity run
+  full_fit        update_posterior(max_itr=25, num_init=2, tolerance=0) through the public API on the resident matrix
+  hmm_c5          BASELINE.json configs[4]: hiddenmarkovnormal.LearnModel K=32, D=16, T=1e7 (tools/bench_hmm.py's measurement)
+  small_c1        BASELINE.json configs[0] (K=3, D=2, N=1000) with the reference's defaults: the one-launch path and the
+                  general engine
   cpu_baseline    the oracle (NumPy port of the reference's formulation) on this host's cores, 10 VB iterations over
                   the first N_ref rows
   parity          GPU driver vs oracle on those rows after 10 iterations (north_star tolerance 1e-5), twice: with the
                   default policy (dense kernels at that size) and with the sparse path forced (int8 bound pass,
                   carried bounds, candidate gathers, list M-step - the kernels of the timed steps)
 
-roofline: the sparse step is bandwidth/latency bound, so the yardstick is HBM: ``achieved`` =
-algorithmic bytes of the dominant kernel group per launch (rows it has to read x D x s) / its HIP-event
-time; ``step_hbm_frac`` = the whole step's N D s bytes / step time / 8 TB/s (= value / HBM-roofline samples/s).
+roofline: every kernel group carries both fractions - ``hbm_frac`` = algorithmic bytes (rows it
+has to read x D x s) / its HIP-event time / 8 TB/s, ``f64_mfma_frac`` = executed f64 MFMA flops / 78.6 TFLOP/s -
+and ``bound`` names the larger; the line's bound / achieved / peak / frac are the dominant group's.  ``step_hbm_frac`` = the
+whole step's N D s bytes / step time / 8 TB/s (= value / HBM-roofline samples/s).  ``per_rank``: every rank's own step times.
 """
 import argparse
 import gc

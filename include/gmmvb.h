@@ -206,8 +206,9 @@ int hmmvb_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, c
 int hmmvb_debug_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, double* out_dev, void* stream);
 
 /* Optional in-library timing with HIP events recorded on the launch stream: gmmvb_profile_last_ms gives the
- * E-step phase (first launch of gmmvb_estep to its last exact evaluation, i.e. the dense kernel estep_lds_f64, or
- * bound pass + selections + gathers) and the M-step phase (list building + mstep_mfma_f64 / mstep_list_f64) of the
+ * E-step phase (first to last kernel of gmmvb_estep: the dense kernel estep_lds_f64 and the log-normaliser pass, or bound
+ * pass / sweep + selections + proof round + gathers + rec_finish; v4: up to v3 the phase ended before the log-normaliser /
+ * rec_finish kernels) and the M-step phase (list building + mstep_mfma_f64 / mstep_list_f64) of the
  * last passes (bench.py's roofline leg); it waits for those events. */
 int gmmvb_profile_enable(gmmvb_workspace* ws, int on);
 int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms);
