@@ -112,7 +112,8 @@ __device__ __forceinline__ double block_sum_waves(double v, double* red) {
 // PD = D rounded up to 32, 64 or 128: the products are PD x PD x PD (a D = 64 model does an eighth of the 128-wide work),
 // every thread holds a (PD / 16)^2 block of the result.
 // NW waves per workgroup: four, or eight for PD = 128 (round 4: with one wave per SIMD every MFMA group waited out the LDS
-// latency of its operands; two waves per SIMD overlap them, and a wave's accumulator block halves to one tile row).
+// latency of its operands; two waves per SIMD overlap them, and a wave's accumulator block halves to one tile row:
+// 0.31 -> 0.21 ms per launch at the benchmark shape).
 template <int PD, int NW>
 __global__ __launch_bounds__(64 * NW) void drift_kernel(const double* __restrict__ u_old, const double* __restrict__ uinv_old,
                                                     const double* __restrict__ m_old, const double* __restrict__ u_new,
@@ -333,8 +334,7 @@ __global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView 
     double* dev0 = xbar + D;
     double* dq = dev0 + D;
     double* dm = dq + D;
-    double* red = dm + D;          // [NT / 64 * 4] = 64 doubles
-    double* tmp = red + 64;        // [D][16] a panel of the factor (blocked inverse)
+    double* red = dm + D;          // [NT / 64 * 4]
     const int tid = threadIdx.x, k = blockIdx.x;
     const int64_t vb = (int64_t)k * D, mb = (int64_t)k * D * D;
     const double LN_2PI = 1.8378770664093454835606594728112, LN_2 = 0.69314718055994530941723212145818,
@@ -395,64 +395,21 @@ __global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView 
     }
     for (int i = tid; i < D; i += NT) qn.m[vb + i] = (kap0 * pr.m[vb + i] + ns * xbar[i]) / kapn;
     __syncthreads();
-    // ---- Cholesky of W'^-1 in LDS, blocked by 16 columns (round 4: the column-by-column form of chol_inv_kernel is 128
-    // dependent steps of three barriers each; here a panel is three barrier-separated phases - the 16 x 16 diagonal block
-    // factorised by one wave in registers with shuffles, the rows below solved against it with a thread per row, the
-    // trailing block updated with the panel's 16-term dot products on the thread grid - 24 barriers instead of 384)
+    // ---- Cholesky of W'^-1 in LDS (as in chol_inv_kernel).  (Round 4 measured a version blocked by 16 columns - diagonal
+    // block in one wave's registers, panel solve with a thread per row, trailing update from 16-term dot products, and the
+    // inverse block column by block column: 24 + 32 barriers instead of 384 + 256 - at 0.312 ms per launch against 0.298:
+    // the 128 barrier-separated columns are not what the kernel's time is made of.  Not kept.)
     constexpr int TG = NT == 1024 ? 32 : 16;                  // the trailing update runs on a TG x TG thread grid
     const int ti = tid / TG, tj = tid % TG;
-    for (int j0 = 0; j0 < D; j0 += 16) {
-        const int jb = D - j0 < 16 ? D - j0 : 16;
-        if (tid < 64) {                                       // (1) diagonal block: lane t holds row t, columns 0 .. t
-            const int t = tid;
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = (t < jb && c <= t) ? mat[(j0 + t) * ld + j0 + c] : 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double d = sqrt(__shfl(a[k], k));       // NaN for a non-positive pivot: spreads like the reference's inv()
-                if (t == k) a[k] = d;
-                else if (t > k) a[k] = a[k] / d;
-#pragma unroll
-                for (int c = k + 1; c < 16; ++c) {
-                    const double lck = __shfl(a[k], c);
-                    if (t >= c) a[c] = fma(-a[k], lck, a[c]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (t < jb && c <= t) mat[(j0 + t) * ld + j0 + c] = a[c];
-        }
+    for (int j = 0; j < D; ++j) {
+        if (tid == 0) mat[j * ld + j] = sqrt(mat[j * ld + j]);
         __syncthreads();
-        const int r0 = j0 + jb;
-        for (int i = r0 + tid; i < D; i += NT) {              // (2) rows below: L21 = A21 L11^-T, a thread per row
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if (c < jb) {
-                    double v = mat[i * ld + j0 + c];
-#pragma unroll
-                    for (int m = 0; m < c; ++m) v = fma(-x[m], mat[(j0 + c) * ld + j0 + m], v);
-                    x[c] = v / mat[(j0 + c) * ld + j0 + c];
-                } else {
-                    x[c] = 0.0;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < jb) mat[i * ld + j0 + c] = x[c];
-        }
+        const double inv = 1.0 / mat[j * ld + j];
+        for (int i = j + 1 + tid; i < D; i += NT) mat[i * ld + j] *= inv;
         __syncthreads();
-        for (int i = r0 + ti; i < D; i += TG) {               // (3) trailing block: A22 -= L21 L21^T (lower part)
-            double li[16];
-#pragma unroll
-            for (int m = 0; m < 16; ++m) li[m] = m < jb ? mat[i * ld + j0 + m] : 0.0;
-            for (int c = r0 + tj; c <= i; c += TG) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int m = 0; m < 16; ++m) sacc = fma(li[m], m < jb ? mat[c * ld + j0 + m] : 0.0, sacc);
-                mat[i * ld + c] -= sacc;
-            }
+        for (int i = j + 1 + ti; i < D; i += TG) {
+            const double lij = mat[i * ld + j];
+            for (int c = j + 1 + tj; c <= i; c += TG) mat[i * ld + c] = fma(-lij, mat[c * ld + j], mat[i * ld + c]);
         }
         __syncthreads();
     }
@@ -481,72 +438,21 @@ __global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView 
         qn.c[k] = elp + 0.5 * (eld - D * LN_2PI - D / kapn);
     }
     __syncthreads();
-    // ---- in-place inverse of the factor, blocked by 16 columns, last block column first:
-    //   X_pp = G_pp^-1;   X[below, p] = -X[below, below] G[below, p] X_pp   with X[below, below] already in place.
-    // The panel G[below, p] is copied to `tmp` first (its place receives the product), so each block column is four
-    // barrier-separated phases instead of 16 x 2.
-    for (int j0 = ((D - 1) / 16) * 16; j0 >= 0; j0 -= 16) {
-        const int jb = D - j0 < 16 ? D - j0 : 16;
-        const int r0 = j0 + jb, nr = D - r0;
-        for (int e = tid; e < nr * 16; e += NT) {
-            const int i = e >> 4, c = e & 15;
-            tmp[e] = c < jb ? mat[(r0 + i) * ld + j0 + c] : 0.0;
-        }
-        if (tid < 64) {                                       // X_pp: lane c solves column c of the inverse (registers)
-            const int c = tid;
-            double xc[16];
+    // ---- in-place inverse of the factor: column j from the columns right of it; SEG threads share a row's dot product
+    constexpr int SEG = NT / 128;                             // D <= 128 rows
+    const int rl = tid / SEG, seg = tid % SEG;
+    for (int j = D - 1; j >= 0; --j) {
+        const double xjj = 1.0 / mat[j * ld + j];
+        const int i = j + 1 + rl;
+        double v = 0.0;
+        if (i < D)
+            for (int p = j + 1 + seg; p <= i; p += SEG) v = fma(mat[i * ld + p], mat[p * ld + j], v);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double v = 0.0;
-                if (c < jb && i < jb && i >= c) {
-                    if (i == c) {
-                        v = 1.0 / mat[(j0 + i) * ld + j0 + i];
-                    } else {
-                        double acc2 = 0.0;
-#pragma unroll
-                        for (int m = 0; m < 16; ++m)
-                            if (m >= c && m < i) acc2 = fma(mat[(j0 + i) * ld + j0 + m], xc[m], acc2);
-                        v = -acc2 / mat[(j0 + i) * ld + j0 + i];
-                    }
-                }
-                xc[i] = v;
-            }
-            // (every lane has read what it needs of G_pp: one wave, LDS accesses in program order)
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (c < jb && i < jb && i >= c) mat[(j0 + i) * ld + j0 + c] = xc[i];
-        }
+        for (int o = 1; o < SEG; o <<= 1) v += __shfl_xor(v, o);
+        v = -v * xjj;
         __syncthreads();
-        for (int e = tid; e < nr * 16; e += NT) {             // T1 = X[below, below] P   (into the panel's place)
-            const int i = e >> 4, c = e & 15;
-            if (c < jb) {
-                double v = 0.0, v1 = 0.0;
-                int m = 0;
-                for (; m + 1 <= i; m += 2) {
-                    v = fma(mat[(r0 + i) * ld + r0 + m], tmp[m * 16 + c], v);
-                    v1 = fma(mat[(r0 + i) * ld + r0 + m + 1], tmp[(m + 1) * 16 + c], v1);
-                }
-                for (; m <= i; ++m) v = fma(mat[(r0 + i) * ld + r0 + m], tmp[m * 16 + c], v);
-                mat[(r0 + i) * ld + j0 + c] = v + v1;
-            }
-        }
-        __syncthreads();
-        for (int i = r0 + tid; i < D; i += NT) {              // X[below, p] = -T1 X_pp, a thread per row
-            double t1[16], o[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t1[c] = c < jb ? mat[i * ld + j0 + c] : 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 < 16; ++c2) {
-                double v = 0.0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c >= c2 && c < jb && c2 < jb) v = fma(t1[c], mat[(j0 + c) * ld + j0 + c2], v);
-                o[c2] = -v;
-            }
-#pragma unroll
-            for (int c2 = 0; c2 < 16; ++c2)
-                if (c2 < jb) mat[i * ld + j0 + c2] = o[c2];
-        }
+        if (i < D && seg == 0) mat[i * ld + j] = v;
+        if (tid == 0) mat[j * ld + j] = xjj;
         __syncthreads();
     }
     // u' = sqrt(nu') G^-1 and W' = G^-T G^-1 (upper triangle computed, mirrored: exactly symmetric)
@@ -698,7 +604,7 @@ extern "C" int gmmvb_kside_step(int K, int D, const gmmvb_prior_view* prior, con
     std::memcpy(&qa, q, sizeof(qa));
     std::memcpy(&qb, q_next, sizeof(qb));
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = ((size_t)D * (D + 1) + 5 * (size_t)D + 64 + 16 * (size_t)D) * sizeof(double);
+    const size_t lds = ((size_t)D * (D + 1) + 5 * (size_t)D + 64) * sizeof(double);
     const bool wide = D > 32;
     {
         hipError_t e = ensure_dynamic_lds(wide ? (const void*)kside_step_kernel<1024> : (const void*)kside_step_kernel<256>, lds);
