@@ -87,12 +87,17 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     ws->K = K;
     ws->D = D;
     ws->T = (D + 15) / 16;
+    // 128 < D <= 256 (round 4): dense MFMA kernels of their own - the E-step streams U's block rows through LDS
+    // (estep_rows.h), the M-step spreads a component's tile pairs over T / 2 waves (mstep.h) - instantiated for even tile
+    // counts: an odd one is rounded up (zero padded images and centred rows).  No pruning, no lists, K-side through torch.
+    ws->wide = D > 16 * kMaxTiles && D <= 32 * kMaxTiles;
+    if (ws->wide) ws->T = 2 * ((ws->T + 1) / 2);
     ws->x_dtype = x_dtype;
     ws->max_rows = max_rows;
     ws->npad = round_up(max_rows, 64);
     ws->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (D > 16 * kMaxTiles) {
-        // more than 8 feature tiles: the plain f64 kernels of generic.h (no parameter images, no pruning, no lists)
+    if (D > 32 * kMaxTiles) {
+        // more than 16 feature tiles: the plain f64 kernels of generic.h (no parameter images, no pruning, no lists)
         ws->generic = true;
         ws->sparse = false;
         ws->prune = 0;
@@ -150,6 +155,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     {
         const char* v = std::getenv("GMMVB_ESTEP_VARIANT");
         ws->estep_variant = kEstepLds8;      // measured fastest (two waves per SIMD share one LDS image)
+        if (ws->wide) v = nullptr;           // (one E-step kernel past 8 feature tiles)
         // ... except with a single feature tile (D <= 16): the 2.5-KB images stay in L1, staging them through LDS with a
         // barrier per group of components only costs (HMM config 5: emission 4.4 -> 3.1 ms).  No pruning at that size anyway.
         if (ws->T == 1) ws->estep_variant = kEstepDirect;
@@ -171,6 +177,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
         const char* v = std::getenv("GMMVB_MSTEP_SPARSE");         // "0" = always the dense M-step
         ws->sparse = !(v && std::strcmp(v, "0") == 0);
         if (max_rows > 2000000000) ws->sparse = false;             // the sample lists hold 32-bit row numbers
+        if (ws->wide) ws->sparse = false;                          // (dense kernels only past 8 feature tiles)
         if (K == 1) {
             // one component: r = 1 for every row, nothing to prune, list or cache - and the one-pass moment computation of
             // multivariate_normal.LearnModel (K = 1, unit responsibilities) should not pay for a centred copy it never
@@ -1218,12 +1225,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool tmeta_was_valid = ws->tmeta_valid;
     ws->tmeta_valid = false;            // (only a lazy sweep that ran to its end leaves the tile state in step with the bounds)
     if (mode == kDense) {
-        rpw = i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64);
+        rpw = ws->wide ? estep_rows_rows_per_wg() : (i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64));
         grid = (n_rows + rpw - 1) / rpw;
         if (grid > (1 << 20)) grid = 1 << 20;
         span_begin(ws, kSpanEstepMain, st);
-        e = i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
-               : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name);
+        e = ws->wide ? launch_estep_rows(ws->T, is64, (int)grid, st, a, &name)
+                     : (i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
+                           : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name));
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
         ++ws->passes[0];

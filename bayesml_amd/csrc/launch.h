@@ -69,6 +69,10 @@ hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipSt
 
 // sparse-responsibility M-step over the centred copy and per-component lists of active rows (mstep.h)
 hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, int cw, const char** name);
+// 128 < D <= 256 (T = 10, 12, 14, 16): dense M-step from the centred copy, dense E-step with the image streamed through LDS
+hipError_t launch_mstep_wide(int T, int grid, hipStream_t st, const MstepArgs& a, const char** name);
+hipError_t launch_estep_rows(int T, int x_is_f64, int grid, hipStream_t st, const EstepArgs& a, const char** name);
+int estep_rows_rows_per_wg();
 // ... for the HMM: gamma read time-major ([rows][Kp], lane order) through LDS instead of a component-major copy
 hipError_t launch_hmm_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const double* gamma_tm, int Kp,
                                   const char** name);

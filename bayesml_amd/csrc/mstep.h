@@ -20,29 +20,37 @@
 // registers for the whole row range (f64 accumulation, no flush needed) and are written once as a
 // slab in register order; reduce_stats sums slabs over row splits in a fixed order.
 #pragma once
+#include <utility>
 #include "common.h"
 
 namespace gmmvb {
 
-__host__ __device__ constexpr int mstep_ws(int t) { return t >= 8 ? 2 : 1; }
+// T > 8 (128 < D <= 256, round 4): ceil(T / 2) waves share a component, wave w owning the A-operand tiles w and T - 1 - w
+// (T + 1 tile pairs each at even T: 136 accumulator registers at T = 16), one component per workgroup.
+__host__ __device__ constexpr int mstep_ws(int t) { return t > 8 ? (t + 1) / 2 : (t >= 8 ? 2 : 1); }
 // waves per workgroup.  8-wave workgroups (4 components per row stream at T = 8) were measured: L2-side
 // fetch traffic drops 3x (96 -> 33 GB per launch at C3) but the kernel is 12 % slower (the 256-register cap
 // of a 512-thread workgroup costs more than the traffic, which is nowhere near a bandwidth limit) -> 4.
-__host__ __device__ constexpr int mstep_waves(int t, bool pre) { return 4; }
+__host__ __device__ constexpr int mstep_waves(int t, bool pre) { return t > 8 ? mstep_ws(t) : 4; }
 
 // Which of the WS waves of a component owns A-operand tile t1 (and every pair (t2, t1) with it).
 // WS = 2 (T = 8): t1 in {0,3,4,7} -> wave 0, {1,2,5,6} -> wave 1: 18 tile pairs each, and each wave
 // only forms r * x' for its own four t1 (f64 VALU work competes with the f64 MFMA pipe on gfx950).
 __host__ __device__ constexpr int mstep_owner(int ws, int t1) {
-    return ws == 1 ? 0 : (((t1 & 3) == 0 || (t1 & 3) == 3) ? 0 : 1);
+    // (ws > 2 only occurs with T = 2 ws or 2 ws - 1 feature tiles: T - 1 - t1 = the mirror column)
+    return ws == 1 ? 0 : (ws == 2 ? (((t1 & 3) == 0 || (t1 & 3) == 3) ? 0 : 1) : (t1 < ws ? t1 : -1));
+}
+// ... with the number of tiles known (the mirror column of the wide form)
+__host__ __device__ constexpr int mstep_owner_t(int t, int ws, int t1) {
+    return ws <= 2 ? mstep_owner(ws, t1) : (t1 < ws ? t1 : t - 1 - t1);
 }
 // rank of pair (t2, t1) among the pairs owned by the same wave (its accumulator slot)
-__host__ __device__ constexpr int mstep_slot(int ws, int t2, int t1) {
+__host__ __device__ constexpr int mstep_slot_t(int t, int ws, int t2, int t1) {
     int n = 0;
     for (int b = 0; b <= t2; ++b)
         for (int a = 0; a <= b; ++a) {
             if (b == t2 && a == t1) return n;
-            if (mstep_owner(ws, a) == mstep_owner(ws, t1)) ++n;
+            if (mstep_owner_t(t, ws, a) == mstep_owner_t(t, ws, t1)) ++n;
         }
     return n;
 }
@@ -50,7 +58,7 @@ __host__ __device__ constexpr int mstep_owned(int ws, int sub, int t) {
     int n = 0;
     for (int b = 0; b < t; ++b)
         for (int a = 0; a <= b; ++a)
-            if (mstep_owner(ws, a) == sub) ++n;
+            if (mstep_owner_t(t, ws, a) == sub) ++n;
     return n;
 }
 
@@ -169,7 +177,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
             double ra[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                if (mstep_owner(WS, t) == SUB) {
+                if (mstep_owner_t(T, WS, t) == SUB) {
                     ra[t] = rr * xq[t];
                     asum[t] += ra[t];
                 } else {
@@ -187,8 +195,8 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
             for (int t2 = 0; t2 < T; ++t2) {
 #pragma unroll
                 for (int t1 = 0; t1 <= t2; ++t1) {
-                    if (mstep_owner(WS, t1) == SUB)
-                        acc[mstep_slot(WS, t2, t1)] = mfma_f64(ra[t1], xq[t2], acc[mstep_slot(WS, t2, t1)]);
+                    if (mstep_owner_t(T, WS, t1) == SUB)
+                        acc[mstep_slot_t(T, WS, t2, t1)] = mfma_f64(ra[t1], xq[t2], acc[mstep_slot_t(T, WS, t2, t1)]);
                 }
             }
             // keep every loaded element live to here: a dead half of a 16-byte load (tile 0 is never a B
@@ -202,16 +210,16 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     for (int t2 = 0; t2 < T; ++t2) {
 #pragma unroll
         for (int t1 = 0; t1 <= t2; ++t1) {
-            if (mstep_owner(WS, t1) == SUB) {
+            if (mstep_owner_t(T, WS, t1) == SUB) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    out[(pair_index(t2, t1) * 4 + r) * 64 + lane] = acc[mstep_slot(WS, t2, t1)][r];
+                    out[(pair_index(t2, t1) * 4 + r) * 64 + lane] = acc[mstep_slot_t(T, WS, t2, t1)][r];
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        if (mstep_owner(WS, t) == SUB) {
+        if (mstep_owner_t(T, WS, t) == SUB) {
             const double v = sum_groups(asum[t]);
             if (g == 0) out[P * 256 + T * i + t] = v;
         }
@@ -224,6 +232,16 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
             out[P * 256 + 16 * T + 1] = hsum;
         }
     }
+}
+
+// T > 8: the wave's index among the WS waves of its component picks the instance of the body (wave uniform)
+template <int T, int WS, typename XT, bool VEC, bool PRE, int... I>
+__device__ __forceinline__ void mstep_wide_dispatch(int sub, const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                                    const double* __restrict__ pivot, const double* __restrict__ lr,
+                                                    const double* __restrict__ lse, const double* __restrict__ aux_k, int64_t lo,
+                                                    int64_t hi, int direct_r, double* __restrict__ out,
+                                                    std::integer_sequence<int, I...>) {
+    ((sub == I ? mstep_body<T, WS, I, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out) : (void)0), ...);
 }
 
 template <int T, typename XT, bool VEC, bool PRE>
@@ -259,11 +277,14 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
     double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
     if constexpr (WS == 1) {
         mstep_body<T, 1, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out);
-    } else {
+    } else if constexpr (WS == 2) {
         if (sub == 0)
             mstep_body<T, 2, 0, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out);
         else
             mstep_body<T, 2, 1, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out);
+    } else {
+        mstep_wide_dispatch<T, WS, XT, VEC, PRE>(sub, x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out,
+                                                 std::make_integer_sequence<int, WS>{});
     }
 }
 
@@ -481,7 +502,7 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
 // capacity).  Chunk c is one (component, list range) whatever rows it spans, so the work is balanced whether the rows
 // of a component are scattered over the matrix or (after the rows were grouped by component) contiguous; every chunk
 // writes one slab, reduce_chunks_kernel adds a component's slabs in chunk order (fixed order: run-to-run identical).
-__global__ void mstep_plan_kernel(const int* __restrict__ counts, int K, int cap_chunks, int r_min, int* __restrict__ plan) {
+static __global__ void mstep_plan_kernel(const int* __restrict__ counts, int K, int cap_chunks, int r_min, int* __restrict__ plan) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long long total = 0;
     for (int k = 0; k < K; ++k) total += counts[k];

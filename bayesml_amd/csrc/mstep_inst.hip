@@ -61,6 +61,7 @@ static hipError_t dispatch(int x_is_f64, bool vec, bool pre, int grid, hipStream
 
 hipError_t launch_mstep(int T, int x_is_f64, bool vec, bool pre, int grid, hipStream_t st, const MstepArgs& a,
                         const char** name) {
+    if (T > 8) return pre ? launch_mstep_wide(T, grid, st, a, name) : hipErrorInvalidValue;      // (mstep_wide_inst.hip)
     switch (T) {
         CASE(1, false) CASE(2, true) CASE(3, false) CASE(4, true) CASE(5, false) CASE(6, false) CASE(7, false) CASE(8, true)
     }

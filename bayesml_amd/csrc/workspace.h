@@ -177,6 +177,7 @@ struct gmmvb_workspace {
     int64_t xc_rows = 0, xc_ldx = 0;
     bool xc_stale = false;     // the rows were regrouped since xc was made: it is rebuilt from xp when a kernel needs it
     // c_degree > 128 (generic.h): plain f64 kernels on the raw parameters, no images, no lists
+    bool wide = false;                 // 128 < D <= 256: dense MFMA kernels for 9 .. 16 feature tiles (T rounded up to even)
     bool generic = false;
     double* gen_u = nullptr;           // [K][D][D]
     double* gen_m = nullptr;           // [K][D]

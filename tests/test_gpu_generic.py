@@ -1,6 +1,7 @@
-"""c_degree > 128: the data pass leaves the MFMA kernels (8 feature tiles at most) for the plain f64 kernels of
-csrc/generic.h.  Same contract: the public driver must reproduce the oracle's posterior (the reference accepts any positive
-c_degree, ``_gaussianmixture.py:433``)."""
+"""c_degree > 128: up to 256 the data pass runs on dense MFMA kernels of their own (csrc/estep_rows.h: U's block rows streamed
+through LDS; mstep.h: a component's tile pairs spread over T / 2 waves), beyond on the plain f64 kernels of csrc/generic.h.
+Same contract: the public driver must reproduce the oracle's posterior (the reference accepts any positive c_degree,
+``_gaussianmixture.py:433``)."""
 import warnings
 
 import numpy as np
@@ -13,7 +14,8 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("K,D,N,dtype", [(4, 160, 3000, np.float32), (3, 129, 1000, np.float64), (2, 330, 700, np.float32)])
+@pytest.mark.parametrize("K,D,N,dtype", [(4, 160, 3000, np.float32), (3, 129, 1000, np.float64), (2, 330, 700, np.float32),
+                                         (5, 200, 2500, np.float32), (2, 256, 900, np.float64), (3, 241, 777, np.float32)])
 def test_wide_rows_through_the_driver(K, D, N, dtype):
     from bayesml_amd import gaussianmixture as gm
     x = orc.synth_gmm(K, D, N, dtype)
@@ -23,7 +25,12 @@ def test_wide_rows_through_the_driver(K, D, N, dtype):
         m.update_posterior(x, max_itr=5, num_init=2, tolerance=0.0)
         ref = orc.update_posterior(x.astype(np.float64), orc.Prior.default(K, D), orc.Posterior.from_prior(orc.Prior.default(K, D)),
                                    np.random.default_rng(0), max_itr=5, num_init=2, tolerance=0.0)
-    assert "generic" in m._engine.launch_info, m._engine.launch_info
+    info = m._engine.launch_info
+    if D > 256:
+        assert "generic" in info, info
+    else:           # T = 10, 12, 14 or 16 feature tiles (odd counts rounded up)
+        t = 2 * (((D + 15) // 16 + 1) // 2)
+        assert f"estep_rows_f64<T={t}," in info and f"mstep_mfma_f64<T={t},centred-f64" in info, info
     hn = m.get_hn_params()
     for key, val in (("hn_alpha_vec", ref.posterior.alpha), ("hn_m_vecs", ref.posterior.m), ("hn_kappas", ref.posterior.kappa),
                      ("hn_nus", ref.posterior.nu), ("hn_w_mats", ref.posterior.w)):
