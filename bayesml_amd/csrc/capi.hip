@@ -183,7 +183,7 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
             // multivariate_normal.LearnModel (K = 1, unit responsibilities) should not pay for a centred copy it never
             // builds: the M-step reads x directly
             ws->sparse = false;
-            bufs[6].n = 0;
+            if (!ws->wide) bufs[6].n = 0;          // (past 8 feature tiles the M-step only exists over the centred copy)
         }
         v = std::getenv("GMMVB_SORT_ROWS");
         ws->sort_rows = !(v && std::strcmp(v, "0") == 0) && (int64_t)max_rows <= 2000000000;

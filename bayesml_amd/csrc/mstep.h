@@ -234,16 +234,6 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
     }
 }
 
-// T > 8: the wave's index among the WS waves of its component picks the instance of the body (wave uniform)
-template <int T, int WS, typename XT, bool VEC, bool PRE, int... I>
-__device__ __forceinline__ void mstep_wide_dispatch(int sub, const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
-                                                    const double* __restrict__ pivot, const double* __restrict__ lr,
-                                                    const double* __restrict__ lse, const double* __restrict__ aux_k, int64_t lo,
-                                                    int64_t hi, int direct_r, double* __restrict__ out,
-                                                    std::integer_sequence<int, I...>) {
-    ((sub == I ? mstep_body<T, WS, I, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out) : (void)0), ...);
-}
-
 template <int T, typename XT, bool VEC, bool PRE>
 __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
     const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
@@ -283,9 +273,136 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
         else
             mstep_body<T, 2, 1, XT, VEC, PRE>(x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out);
     } else {
-        mstep_wide_dispatch<T, WS, XT, VEC, PRE>(sub, x, ldx, n_rows, D, pivot, lr, lse, aux_k, lo, hi, direct_r, out,
-                                                 std::make_integer_sequence<int, WS>{});
+        static_assert(WS <= 2, "more than eight feature tiles: mstep_wide_f64");
     }
+}
+
+// ---- 128 < D <= 256: T = 10, 12, 14, 16 feature tiles ----------------------------------------------------------------
+// A component's T (T + 1) / 2 accumulator tiles (136 at T = 16: 1088 registers) are spread over T / 2 waves: wave w owns
+// the A-operand tiles w and T - 1 - w, i.e. the tile pairs (t2, w) for t2 >= w and (t2, T - 1 - w) for t2 >= T - 1 - w:
+// T + 1 pairs each.  One component per workgroup; rows from the centred f64 copy (16 T doubles per row, T per lane); the
+// per-step vector work of a wave is two multiplies and two additions beside its T + 1 MFMAs.  Same operations per tile pair
+// in the same order as mstep_body, same slab layout, same reduce.
+template <int T, int SUB>
+__device__ __forceinline__ void mstep_wide_body(const double* __restrict__ xc, int64_t n_rows, const double* __restrict__ lr,
+                                                const double* __restrict__ lse, const double* __restrict__ aux_k, int64_t lo,
+                                                int64_t hi, int direct_r, double* __restrict__ out) {
+    static_assert(T > 8 && T <= 16 && T % 2 == 0, "even tile counts (the workspace rounds an odd one up)");
+    constexpr int P = tri_pairs(T);
+    constexpr int C1 = SUB, C2 = T - 1 - SUB;      // the wave's A-operand tiles (C1 < C2)
+    constexpr int N1 = T - C1, N2 = T - C2;        // tile pairs (t2, C1), t2 = C1 .. T - 1, and (t2, C2), t2 = C2 .. T - 1
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    d4 acc1[N1], acc2[N2];
+#pragma unroll
+    for (int p = 0; p < N1; ++p) acc1[p] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < N2; ++p) acc2[p] = d4{0.0, 0.0, 0.0, 0.0};
+    double asum1 = 0.0, asum2 = 0.0, nsum = 0.0, hsum = 0.0;
+    struct Row { double v[T]; };
+    auto load_row = [&](int64_t row) {             // (zero rows up to npad + 64: no clamp)
+        const double* xp = xc + row * (16 * T) + T * i;
+        Row o;
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+            const v2 v = *reinterpret_cast<const v2*>(xp + t);
+            o.v[t] = v[0];
+            o.v[t + 1] = v[1];
+        }
+        return o;
+    };
+    Row nxt = load_row(lo + g);
+    for (int64_t c0 = lo; c0 < hi; c0 += 64) {
+        const int64_t nl = c0 + lane;
+        double r_l = 0.0;
+        if (nl < hi) {
+            const double v = lr[nl];
+            if (direct_r == 2) {                   // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
+                r_l = v;
+                if (v > 0.0) hsum = fma(v, aux_k[nl], hsum);
+            } else if (direct_r) {
+                r_l = v;
+                if (v > 0.0) hsum = fma(v, log(v), hsum);
+            } else {
+                const double t = v - lse[nl];
+                r_l = exp(t);
+                hsum = fma(r_l, t, hsum);
+            }
+            nsum += r_l;
+        }
+        double rr_n = __shfl(r_l, g);
+#pragma unroll 2
+        for (int st = 0; st < 16; ++st) {
+            const Row cur = nxt;
+            const double rr = rr_n;
+            const double ra1 = rr * cur.v[C1], ra2 = rr * cur.v[C2];
+            asum1 += ra1;
+            asum2 += ra2;
+            __builtin_amdgcn_sched_barrier(0);
+            nxt = load_row(c0 + 4 * (st + 1) + g);
+            rr_n = __shfl(r_l, (4 * (st + 1) + g) & 63);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < N1; ++p) acc1[p] = mfma_f64(ra1, cur.v[C1 + p], acc1[p]);
+#pragma unroll
+            for (int p = 0; p < N2; ++p) acc2[p] = mfma_f64(ra2, cur.v[C2 + p], acc2[p]);
+#pragma unroll
+            for (int t = 0; t < T; ++t) asm volatile("" ::"v"(cur.v[t]));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < N1; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(pair_index(C1 + p, C1) * 4 + r) * 64 + lane] = acc1[p][r];
+#pragma unroll
+    for (int p = 0; p < N2; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(pair_index(C2 + p, C2) * 4 + r) * 64 + lane] = acc2[p][r];
+    {
+        const double a1 = sum_groups(asum1), a2 = sum_groups(asum2);
+        if (g == 0) {
+            out[P * 256 + T * i + C1] = a1;
+            out[P * 256 + T * i + C2] = a2;
+        }
+    }
+    if (SUB == 0) {
+        nsum = sum_wave(nsum);
+        hsum = sum_wave(hsum);
+        if (lane == 0) {
+            out[P * 256 + 16 * T + 0] = nsum;
+            out[P * 256 + 16 * T + 1] = hsum;
+        }
+    }
+}
+
+template <int T, int... I>
+__device__ __forceinline__ void mstep_wide_dispatch(int sub, const double* __restrict__ xc, int64_t n_rows,
+                                                    const double* __restrict__ lr, const double* __restrict__ lse,
+                                                    const double* __restrict__ aux_k, int64_t lo, int64_t hi, int direct_r,
+                                                    double* __restrict__ out, std::integer_sequence<int, I...>) {
+    ((sub == I ? mstep_wide_body<T, I>(xc, n_rows, lr, lse, aux_k, lo, hi, direct_r, out) : (void)0), ...);
+}
+
+template <int T>
+__global__ __launch_bounds__(32 * T) void mstep_wide_f64(const double* __restrict__ xc, int64_t n_rows,
+                                                         const double* __restrict__ lnrho, const double* __restrict__ lse,
+                                                         const double* __restrict__ aux, int64_t npad, int K, int KG, int S,
+                                                         int64_t rows_per_split, int direct_r,
+                                                         double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // T / 2 waves, one component
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int j = bid >> 3;
+    const int k = j % KG;                          // (KG = K: one component per workgroup)
+    const int split = (j / KG) * 8 + xcd;
+    if (split >= S || k >= K) return;
+    const int64_t lo = (int64_t)split * rows_per_split;
+    int64_t hi = lo + rows_per_split;
+    if (hi > n_rows) hi = n_rows;
+    const double* lr = lnrho + (int64_t)k * npad;
+    const double* aux_k = aux ? aux + (int64_t)k * npad : nullptr;
+    double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
+    mstep_wide_dispatch<T>(sub, xc, n_rows, lr, lse, aux_k, lo, hi, direct_r, out, std::make_integer_sequence<int, T / 2>{});
 }
 
 // ---- one feature tile (D <= 16): many components per wave ----------------------------------------------------------

@@ -30,7 +30,7 @@ def test_wide_rows_through_the_driver(K, D, N, dtype):
         assert "generic" in info, info
     else:           # T = 10, 12, 14 or 16 feature tiles (odd counts rounded up)
         t = 2 * (((D + 15) // 16 + 1) // 2)
-        assert f"estep_rows_f64<T={t}," in info and f"mstep_mfma_f64<T={t},centred-f64" in info, info
+        assert f"estep_rows_f64<T={t}," in info and f"mstep_wide_f64<T={t},centred-f64" in info, info
     hn = m.get_hn_params()
     for key, val in (("hn_alpha_vec", ref.posterior.alpha), ("hn_m_vecs", ref.posterior.m), ("hn_kappas", ref.posterior.kappa),
                      ("hn_nus", ref.posterior.nu), ("hn_w_mats", ref.posterior.w)):
