@@ -1586,7 +1586,14 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int64_t rows_per_split = round_up((n_rows + S - 1) / S, 64);
     if (ws->split_rows && rows_per_split > ws->split_rows) rows_per_split = ws->split_rows;
     S = (n_rows + rows_per_split - 1) / rows_per_split;
-    const bool pre = ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx;
+    bool pre = ws->xc && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx;
+    if (ws->wide && !pre && ws->xc) {
+        // past 8 feature tiles the M-step only exists over the centred copy: made here if the caller has not
+        // (multivariate_normal.LearnModel's one-pass moments call gmmvb_mstep straight after gmmvb_load_responsibilities)
+        rc = gmmvb_prepare_rows(ws, x_dev, ldx, n_rows, stream);
+        if (rc) return rc;
+        pre = true;
+    }
     const int kpw = mstep_components_per_wg(ws->T, pre);
     const int KG = (ws->K + kpw - 1) / kpw;
     int64_t grid = 8 * ((S + 7) / 8) * KG;

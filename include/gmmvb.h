@@ -22,7 +22,9 @@
  *     storage dtype (f32 or f64) in HBM and is widened on load; all arithmetic is f64
  *     (v_mfma_f64_16x16x4_f64), because f32 arithmetic misses the 1e-5 parity target.
  *   - shapes: K >= 1, D >= 1, n_rows <= max_rows.  Up to D = 128 (8 feature tiles) the data pass runs on the f64 MFMA
- *     kernels; beyond, on plain f64 vector kernels (csrc/generic.h): same results, no pruning, far slower.  The K-sized
+ *     kernels with pruning; for 128 < D <= 256 on dense f64 MFMA kernels of their own (the parameter image streamed through
+ *     LDS by block rows; gmmvb_mstep then works from the workspace's centred copy and makes it if gmmvb_prepare_rows has not
+ *     been called); beyond, on plain f64 vector kernels (csrc/generic.h): same results, far slower.  The K-sized
  *     entry points (gmmvb_kside_*) keep their matrices in LDS and stop at D = 128.
  */
 #ifndef GMMVB_H

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: tests, bench legs, rocprofv3 kernel trace and PMC passes.  usage: tools/gpu_round.sh <tag> <stage>...
-# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist
+# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist wide
 # (pmc / hmmpmc first: the bench stages quote the traffic files they write)
 # Outputs under gpurun_out/<tag>_*; copy the summaries worth keeping into profiles/.
 set -u
@@ -19,6 +19,12 @@ for stage in "$@"; do
     c2) timeout 600 python bench.py --config c2 > $OUT/${TAG}_bench_line_c2.json 2> $OUT/${TAG}_c2.err; tail -c 600 $OUT/${TAG}_c2.err; head -c 600 $OUT/${TAG}_bench_line_c2.json; echo ;;
     steps) f=$(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_steps.py $f 7 12 24 > $OUT/${TAG}_bench_steps.txt 2>&1; head -12 $OUT/${TAG}_bench_steps.txt ;;
     spread1) timeout 600 python bench.py --no-cpu --no-legs --rows 2000000 --spread 1.0 --steps 20 --warmup 2 > $OUT/${TAG}_bench_line_spread1.json 2> $OUT/${TAG}_spread1.err; head -c 300 $OUT/${TAG}_bench_line_spread1.json; echo ;;
+    wide) for d in 128 160 200 256; do timeout 300 python bench.py --dense --no-cpu --no-legs --classes 32 --degree $d --rows 1000000 --steps 3 --warmup 1 2>/dev/null | grep -a "^{" > $OUT/${TAG}_bench_line_dense_k32_d$d.json; python - $OUT/${TAG}_bench_line_dense_k32_d$d.json $d <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); g = d["roofline"]["kernel_groups"]
+print("D =", sys.argv[2], "ms/step", round(d["ms_per_step"], 2), {k: (round(v["ms"], 2), round(v.get("executed_f64_tflops", 0), 1)) for k, v in g.items() if v["ms"] > 0.05}, d["launch"][:60])
+PY
+          done ;;
     hist) timeout 300 python tools/active_hist.py > $OUT/${TAG}_active_hist.json 2> $OUT/${TAG}_hist.err; head -c 300 $OUT/${TAG}_active_hist.json; echo ;;
     trace) rm -rf $OUT/${TAG}_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_trace.err)
            python tools/summarize_rocprof.py $OUT/${TAG}_trace > $OUT/${TAG}_bench_kernel_summary.md 2>> $OUT/${TAG}_trace.err; head -30 $OUT/${TAG}_bench_kernel_summary.md
