@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: tests, bench legs, rocprofv3 kernel trace and PMC passes.  usage: tools/gpu_round.sh <tag> <stage>...
-# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist wide
+# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist wide share8
 # (pmc / hmmpmc first: the bench stages quote the traffic files they write)
 # Outputs under gpurun_out/<tag>_*; copy the summaries worth keeping into profiles/.
 set -u
@@ -25,6 +25,7 @@ d = json.load(open(sys.argv[1])); g = d["roofline"]["kernel_groups"]
 print("D =", sys.argv[2], "ms/step", round(d["ms_per_step"], 2), {k: (round(v["ms"], 2), round(v.get("executed_f64_tflops", 0), 1)) for k, v in g.items() if v["ms"] > 0.05}, d["launch"][:60])
 PY
           done ;;
+    share8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --config c4 --rows 200000 --steps 12 --warmup 5 --no-cpu --no-legs 2> $OUT/${TAG}_share8.err | grep -a "^{" > $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_share8.err; head -c 700 $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; echo ;;
     hist) timeout 300 python tools/active_hist.py > $OUT/${TAG}_active_hist.json 2> $OUT/${TAG}_hist.err; head -c 300 $OUT/${TAG}_active_hist.json; echo ;;
     trace) rm -rf $OUT/${TAG}_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_trace.err)
            python tools/summarize_rocprof.py $OUT/${TAG}_trace > $OUT/${TAG}_bench_kernel_summary.md 2>> $OUT/${TAG}_trace.err; head -30 $OUT/${TAG}_bench_kernel_summary.md
