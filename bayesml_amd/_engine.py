@@ -27,6 +27,7 @@ SYMBOLS = {
     "gmmvb_last_error": (ctypes.c_char_p, []),
     "gmmvb_stats_len": (_i64, [_int, _int]),
     "gmmvb_workspace_create": (_int, [_int, _int, _int, _i64, ctypes.POINTER(_vp)]),
+    "gmmvb_workspace_create_tile": (_int, [_vp, _i64, ctypes.POINTER(_vp)]),
     "gmmvb_workspace_destroy": (_int, [_vp]),
     "gmmvb_workspace_bytes": (_i64, [_vp]),
     "gmmvb_set_pivot": (_int, [_vp, _vp, _vp]),
@@ -273,7 +274,9 @@ class DataPass:
     tensors; nothing here synchronises with the host.
     """
 
-    def __init__(self, K: int, D: int, x_dtype: torch.dtype, max_rows: int, device=None):
+    def __init__(self, K: int, D: int, x_dtype: torch.dtype, max_rows: int, device=None, tile_of: "DataPass" = None):
+        """``tile_of``: another DataPass of the same (K, D, dtype) whose pass-local buffers this one shares
+        (gmmvb_workspace_create_tile: a further tile of a row-tiled job)."""
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise EngineUnavailableError("no ROCm GPU visible to PyTorch; the GMM-VB data pass runs on MI355X only")
@@ -284,9 +287,14 @@ class DataPass:
         self.stats_len = int(self.lib.gmmvb_stats_len(self.K, self.D))
         handle = _vp()
         with torch.cuda.device(self.device):
-            rc = self.lib.gmmvb_workspace_create(self.K, self.D, GMMVB_F64 if x_dtype == torch.float64 else GMMVB_F32,
-                                                 self.max_rows, ctypes.byref(handle))
-        _check(self.lib, rc, "gmmvb_workspace_create")
+            if tile_of is not None:
+                if (tile_of.K, tile_of.D, tile_of.x_dtype, tile_of.device) != (self.K, self.D, x_dtype, self.device):
+                    raise ValueError("a further tile has the shape, dtype and device of the group's first workspace")
+                rc = self.lib.gmmvb_workspace_create_tile(tile_of._ws, self.max_rows, ctypes.byref(handle))
+            else:
+                rc = self.lib.gmmvb_workspace_create(self.K, self.D, GMMVB_F64 if x_dtype == torch.float64 else GMMVB_F32,
+                                                     self.max_rows, ctypes.byref(handle))
+        _check(self.lib, rc, "gmmvb_workspace_create_tile" if tile_of is not None else "gmmvb_workspace_create")
         self._ws = handle
         self._keep = []      # tensors whose memory an enqueued kernel may still read
 
@@ -566,79 +574,149 @@ class DataPass:
 
 
 class TiledDataPass:
-    """The same surface as ``DataPass`` for a sample matrix whose per-pair workspace does not fit the GPU (the workspace
-    keeps 16 bytes per (row, component) pair: K = 256, N = 1e8 would need 410 GB next to the 25.6 GB matrix - the reference
-    has no such coupling, it allocates its [N, K] arrays on the host).
+    """The same surface as ``DataPass`` for a sample matrix whose per-pair workspace does not fit the GPU (a workspace keeps
+    5.5 KB per row at K = 256, D = 64: N = 1e8 would need 550 GB next to the 25.6 GB matrix - the reference has no such
+    coupling, it allocates its [N, K] arrays on the host, ``_gaussianmixture.py:835-836``).
 
-    The rows are cut into tiles of ``tile_rows`` rows that go through ONE workspace, one after the other, in every data pass;
-    the statistics blocks add up (they are linear in the rows, like over row shards).  Nothing per-pair survives from one
-    tile to the next, so a tile's E-step cannot carry bounds from the previous iteration: it is the dense kernel while the
-    responsibilities are dense and a fresh int8 bound pass afterwards (the tiles share the pass policy through the same
-    job-wide counters as the ranks of a sharded job, gmmvb_set_shard).  Read-outs re-run the E-step of the tiles they touch."""
+    The rows are cut into tiles of ``tile_rows`` rows that go through the data pass one after the other; the statistics
+    blocks add up (they are linear in the rows, like over row shards).  Two forms:
 
-    def __init__(self, K, D, x_dtype, n_rows, device, tile_rows):
+    * ``resident=True`` (round 4): one workspace PER TILE (``gmmvb_workspace_create_tile``).  What a tile carries from one VB
+      iteration to the next - f32 bounds, records, digit planes, settled rows and their cache, row order, policy counters
+      (1.7 KB per row) - stays in its workspace; the pass-local two thirds (f64 ln rho, lists, centred copy, slabs) exist
+      once, sized for one tile.  Every tile sweeps its carried bounds exactly like a row shard of a multi-GPU job does.
+    * ``resident=False``: ONE workspace for all tiles, for matrices where even that does not fit.  Nothing per-pair survives
+      from one tile to the next, so a tile's E-step is the dense kernel while the responsibilities are dense and a fresh
+      int8 bound pass afterwards (the tiles share the pass policy through the job-wide counters of gmmvb_set_shard).
+
+    Read-outs re-run the E-step of the tiles they touch."""
+
+    def __init__(self, K, D, x_dtype, n_rows, device, tile_rows, resident=False):
         self.K, self.D, self.x_dtype, self.max_rows = int(K), int(D), x_dtype, int(n_rows)
         self.tile_rows = int(min(tile_rows, n_rows))
         self.n_tiles = (self.max_rows + self.tile_rows - 1) // self.tile_rows
+        self.resident = bool(resident)
         self.inner = DataPass(K, D, x_dtype, self.tile_rows, device)
+        self.tiles = [self.inner]
         self.device, self.lib, self.stats_len = self.inner.device, self.inner.lib, self.inner.stats_len
         try:
+            if self.resident:
+                for t in range(1, self.n_tiles):
+                    lo, hi = self._tile(t)
+                    self.tiles.append(DataPass(K, D, x_dtype, hi - lo, device, tile_of=self.inner))
             self._tmp = torch.zeros(self.stats_len, dtype=torch.float64, device=self.device)
             self._tail_tmp = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
             self._tail_acc = torch.zeros(POLICY_LEN, dtype=torch.float64, device=self.device)
-        except RuntimeError:               # (out of memory next to a workspace that just fitted)
-            self.inner.close()
+        except (RuntimeError, EngineError):       # (out of memory next to the workspaces that just fitted)
+            self.close()
             raise
         self._tail_in = None           # job-wide counters of the previous pass (summed over tiles, and over ranks by the caller)
         self._ranks = 1
         self._global_rows = self.max_rows
         self._x = self._r = None
         self._params = None
-        self._held = None              # tile whose E-step the inner workspace currently holds
+        self._held = None              # tile whose E-step output the pass-local buffers currently hold
         self._src = None               # what the read-outs describe: 'loaded' responsibilities or the 'estep' under the parameters
-        self._infos, self._work, self._spars, self._ms = [], None, None, (0.0, 0.0)
+        self._infos, self._work, self._spars, self._ms, self._spans = [], None, None, (0.0, 0.0), {}
+        self._lazy = 0                 # resident tiles whose counters of the last pass have not been read back yet
         self.rows = 0
-        self.inner.set_shard(self._global_rows, self.n_tiles)
+        # one workspace for all tiles: its counters describe another tile every time, so the tiles decide together from
+        # job-wide sums.  Resident tiles each have their own lagged counters (and decide for themselves) unless the job is
+        # also sharded over ranks (set_shard below).
+        self._joint_policy = not self.resident
+        if self._joint_policy:
+            self.inner.set_shard(self._global_rows, self.n_tiles)
 
     # -- plumbing shared with DataPass
     _ws = property(lambda self: self.inner._ws)
     PASS_NAMES = DataPass.PASS_NAMES
 
     def close(self):
-        self.inner.close()
+        for t in reversed(getattr(self, "tiles", [])):
+            t.close()
 
     def _tile(self, t):
         lo = t * self.tile_rows
         return lo, min(self.max_rows, lo + self.tile_rows)
 
+    def _eng(self, t):
+        return self.tiles[t] if self.resident else self.inner
+
     @property
     def workspace_bytes(self):
-        return self.inner.workspace_bytes
+        return sum(t.workspace_bytes for t in self.tiles)
 
     @property
     def launch_info(self):
-        return f"{self.n_tiles} tiles x {self.tile_rows} rows: " + (self._infos[0] if self._infos else "")
+        kind = "resident tiles" if self.resident else "tiles through one workspace"
+        return f"{self.n_tiles} {kind} x {self.tile_rows} rows: " + (self._infos[0] if self._infos else "")
 
     @property
     def regroup_count(self):
-        return self.inner.regroup_count
+        return sum(t.regroup_count for t in self.tiles)
 
     def pass_counts(self):
-        return self.inner.pass_counts()
+        out = dict.fromkeys(self.PASS_NAMES, 0)
+        for t in self.tiles:
+            for k, v in t.pass_counts().items():
+                out[k] += v
+        return out
 
-    def profile(self, on=True):
-        self.inner.profile(on)
+    # counters and event times of the last data pass, summed over its tiles.  One workspace: read back tile by tile inside
+    # the pass (a host synchronisation per tile).  Resident tiles keep their own counters and events: read here, on demand,
+    # after the pass (the driver synchronises once per VB iteration anyway).
+    def _gather(self):
+        if self._lazy:
+            acc = self._new_acc()
+            for t in range(self._lazy):
+                self._add_tile(acc, self.tiles[t], *self._tile(t))
+            self._finish(acc)
+            self._lazy = 0
+
+    @staticmethod
+    def _new_acc():
+        return dict(active=0.0, evaluated=0.0, accumulated=0.0, settled_rows=0.0, early_exits=0.0, proof_pairs=0.0,
+                    counted=True, e_ms=0.0, m_ms=0.0, spans={})
+
+    def _add_tile(self, acc, eng, lo, hi):
+        eng.rows = hi - lo
+        a, e = eng.sparsity()
+        wk = eng.work()
+        acc["counted"] = acc["counted"] and a >= 0
+        acc["active"] += max(a, 0.0)
+        acc["evaluated"] += e
+        for key in ("accumulated", "settled_rows", "early_exits", "proof_pairs"):
+            acc[key] += max(wk[key], 0.0)
+        if getattr(self, "_prof", False):
+            k = eng.last_kernel_ms()
+            acc["e_ms"] += k[0]
+            acc["m_ms"] += k[1]
+            for g, (ms, cnt) in eng.kernel_spans().items():
+                o = acc["spans"].get(g, (0.0, 0))
+                acc["spans"][g] = (o[0] + ms, o[1] + cnt)
+
+    def _finish(self, acc):
+        counted = acc["counted"]
+        self._spars = (acc["active"] if counted else -1.0, acc["evaluated"])
+        self._work = dict(active=acc["active"] if counted else -1.0, evaluated=acc["evaluated"],
+                          accumulated=acc["accumulated"] if counted else -1.0, settled_rows=acc["settled_rows"],
+                          early_exits=acc["early_exits"], proof_pairs=acc["proof_pairs"], sweep_share=-1.0)
+        self._ms, self._spans = (acc["e_ms"], acc["m_ms"]), acc["spans"]
 
     def last_kernel_ms(self):
+        self._gather()
         return self._ms
 
     def kernel_spans(self):
-        return {}
+        self._gather()
+        return dict(self._spans)
 
     def sparsity(self):
+        self._gather()
         return self._spars if self._spars is not None else (-1.0, 0.0)
 
     def work(self):
+        self._gather()
         return self._work if self._work is not None else dict(active=-1.0, evaluated=0.0, accumulated=-1.0, settled_rows=0.0,
                                                               early_exits=0.0, proof_pairs=0.0, sweep_share=-1.0)
 
@@ -647,30 +725,45 @@ class TiledDataPass:
 
     # -- state
     def set_pivot(self, pivot):
-        self.inner.set_pivot(pivot)
+        for t in self.tiles:
+            t.set_pivot(pivot)
         self.pivot = self.inner.pivot
 
     def prepare_rows(self, x):
-        self._x, self._held = x, None          # tiles are prepared when they are processed
+        self._x, self._held = x, None
+        if self.resident:                      # digit planes and row order belong to the tile's workspace: made once
+            if x.shape[0] > self.max_rows:
+                raise ValueError("more rows than the tiled workspace was created for")
+            for t in range((x.shape[0] + self.tile_rows - 1) // self.tile_rows):
+                lo, hi = t * self.tile_rows, min(x.shape[0], (t + 1) * self.tile_rows)
+                self.tiles[t].prepare_rows(x[lo:hi])
+        # (one workspace: tiles are prepared when they are processed)
 
     def set_params(self, c, m, u):
-        self.inner.set_params(c, m, u)
+        for t in self.tiles:
+            t.set_params(c, m, u)
         self._params = (c, m, u)
         self._held = None
 
     def wants_drift(self, n_rows):
-        return False                           # nothing to carry: a tile's bounds do not survive the other tiles
+        # one workspace: nothing to carry, a tile's bounds do not survive the other tiles
+        return self.resident and self.inner.wants_drift(min(int(n_rows), self.tile_rows))
 
     def set_drift(self, *a, **k):
-        pass
+        if self.resident:
+            for t in self.tiles:
+                t.set_drift(*a, **k)
 
     def forget(self):
-        self.inner.forget()
+        for t in self.tiles:
+            t.forget()
         self._tail_in = None
 
     def set_shard(self, global_rows, n_ranks):
         self._global_rows, self._ranks = int(global_rows), int(n_ranks)
-        self.inner.set_shard(self._global_rows, self._ranks * self.n_tiles)
+        self._joint_policy = (not self.resident) or self._ranks > 1
+        for t in self.tiles:
+            t.set_shard(self._global_rows, self._ranks * self.n_tiles if self._joint_policy else 1)
 
     def policy_export(self, tail):
         tail.copy_(self._tail_acc)
@@ -694,46 +787,45 @@ class TiledDataPass:
             self._r = None
             self._src = "estep"
         self._tail_acc.zero_()
-        self._infos, act, ev, acc, e_ms, m_ms = [], 0.0, 0.0, 0.0, 0.0, 0.0
-        counted = True
+        self._infos, self._lazy = [], 0
+        acc = self._new_acc()
         n = x.shape[0]
-        for t in range((n + self.tile_rows - 1) // self.tile_rows):
+        n_t = (n + self.tile_rows - 1) // self.tile_rows
+        for t in range(n_t):
             lo, hi = t * self.tile_rows, min(n, (t + 1) * self.tile_rows)
             xt = x[lo:hi]
-            self.inner.prepare_rows(xt)
+            eng = self._eng(t)
+            if not self.resident:
+                eng.prepare_rows(xt)
             if estep:
-                if self._tail_in is not None:
-                    self.inner.policy_import(self._tail_in)
-                self.inner.estep_mstep(xt, out=self._tmp)
-                self.inner.policy_export(self._tail_tmp)
-                self._tail_acc += self._tail_tmp
+                if self._joint_policy and self._tail_in is not None:
+                    eng.policy_import(self._tail_in)
+                eng.estep_mstep(xt, out=self._tmp)
+                if self._joint_policy:
+                    eng.policy_export(self._tail_tmp)
+                    self._tail_acc += self._tail_tmp
             else:
-                self.inner.load_responsibilities(self._r[lo:hi])
-                self.inner.mstep(xt, out=self._tmp)
+                eng.load_responsibilities(self._r[lo:hi])
+                eng.mstep(xt, out=self._tmp)
             stats += self._tmp
-            self._infos.append(self.inner.launch_info)
-            if estep:
-                a, e = self.inner.sparsity()
-                wk = self.inner.work()
-                counted = counted and a >= 0
-                act, ev, acc = act + max(a, 0.0), ev + e, acc + max(wk["accumulated"], 0.0)
-                if self.inner.lib.gmmvb_profile_last_ms is not None and getattr(self, "_prof", False):
-                    k = self.inner.last_kernel_ms()
-                    e_ms, m_ms = e_ms + k[0], m_ms + k[1]
+            self._infos.append(eng.launch_info)
+            if estep and not self.resident:
+                self._add_tile(acc, eng, lo, hi)
         if estep:
             if self._tail_in is None or self._ranks == 1:
                 self._tail_in = self._tail_acc.clone()      # a single process: the tiles' sums are the job's
-            self._spars = (act if counted else -1.0, ev)
-            self._work = dict(active=act if counted else -1.0, evaluated=ev, accumulated=acc if counted else -1.0,
-                              settled_rows=0.0, early_exits=0.0, proof_pairs=0.0, sweep_share=-1.0)
-            self._ms = (e_ms, m_ms)
-            self._held = (n + self.tile_rows - 1) // self.tile_rows - 1
+            if self.resident:
+                self._lazy = n_t
+            else:
+                self._finish(acc)
+            self._held = n_t - 1
             self.rows = n
         return stats
 
-    def profile(self, on=True):          # noqa: F811
+    def profile(self, on=True):
         self._prof = bool(on)
-        self.inner.profile(on)
+        for t in self.tiles:
+            t.profile(on)
 
     def estep_mstep(self, x, out=None):
         self._x = x
@@ -758,16 +850,18 @@ class TiledDataPass:
             t = pos // self.tile_rows
             lo, hi = self._tile(t)
             hi = min(hi, self.rows)
+            eng = self._eng(t)
             if self._held != t:
                 xt = self._x[lo:hi]
-                self.inner.prepare_rows(xt)
+                if not self.resident:
+                    eng.prepare_rows(xt)
                 if self._src == "loaded":
-                    self.inner.load_responsibilities(self._r[lo:hi])
+                    eng.load_responsibilities(self._r[lo:hi])
                 else:
-                    self.inner.estep(xt)
+                    eng.estep(xt)
                 self._held = t
             take = min(hi, row0 + n) - pos
-            out[pos - row0: pos - row0 + take] = getattr(self.inner, what)(pos - lo, take)
+            out[pos - row0: pos - row0 + take] = getattr(eng, what)(pos - lo, take)
             pos += take
         return out
 
@@ -781,13 +875,17 @@ class TiledDataPass:
         return self._readout("argmax", row0, n, torch.int32, False)
 
 
-def open_data_pass(K, D, x_dtype, n_rows, device, tile_rows=None):
+def open_data_pass(K, D, x_dtype, n_rows, device, tile_rows=None, resident=None):
     """A DataPass for all rows if its workspace fits the GPU - leaving room for the K-sized state and the caller's
-    temporaries -, else a TiledDataPass (halving the tile until it does).  ``tile_rows`` (or BAYESML_AMD_TILE_ROWS in the
-    environment) forces tiles of that many rows."""
+    temporaries -, else a TiledDataPass: resident tiles (one workspace per tile, carried bounds) of the largest size that
+    fits, halving down to 1/64 of the rows; if none does, tiles through ONE workspace.  ``tile_rows`` (or
+    BAYESML_AMD_TILE_ROWS in the environment) forces tiles of that many rows, ``resident`` (BAYESML_AMD_TILE_RESIDENT=0/1,
+    default 1) their form."""
     forced = tile_rows or int(os.environ.get("BAYESML_AMD_TILE_ROWS", "0"))
+    if resident is None:
+        resident = os.environ.get("BAYESML_AMD_TILE_RESIDENT", "1") != "0"
     if forced and forced < n_rows:
-        return TiledDataPass(K, D, x_dtype, n_rows, device, forced)
+        return TiledDataPass(K, D, x_dtype, n_rows, device, forced, resident=resident)
     dev = torch.device(device)
 
     def fits(make):
@@ -809,11 +907,16 @@ def open_data_pass(K, D, x_dtype, n_rows, device, tile_rows=None):
         return eng
 
     eng = fits(lambda: DataPass(K, D, x_dtype, n_rows, dev))
-    rows = (n_rows + 1) // 2
-    while eng is None and rows >= 1 << 16:
-        torch.cuda.empty_cache()
-        eng = fits(lambda: TiledDataPass(K, D, x_dtype, n_rows, dev, (rows + 63) // 64 * 64))
+    sizes, rows = [], (n_rows + 1) // 2
+    while rows >= 1 << 16:
+        sizes.append((rows + 63) // 64 * 64)
         rows = (rows + 1) // 2
+    for form, cand in ((True, sizes[:6]), (False, sizes)) if resident else ((False, sizes),):
+        for r in cand:
+            if eng is not None:
+                break
+            torch.cuda.empty_cache()
+            eng = fits(lambda: TiledDataPass(K, D, x_dtype, n_rows, dev, r, resident=form))
     if eng is None:
-        raise EngineError(f"no workspace fits the GPU even for tiles of {rows * 2} rows (K={K}, D={D})")
+        raise EngineError(f"no workspace fits the GPU even for tiles of {sizes[-1] if sizes else n_rows} rows (K={K}, D={D})")
     return eng

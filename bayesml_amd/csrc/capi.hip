@@ -70,7 +70,45 @@ static void span_end(gmmvb_workspace* ws, hipStream_t st) {
     ++ws->n_spans;
 }
 
-int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace** out) {
+// ---- the scratch of a tile group (workspace.h: gmmvb_scratch) -----------------------------------------------------------
+// `w` loses the buffers to another workspace of its group: its E-step output, lists and centred copy are gone.  What it
+// carries into its next E-step (bounds, records, settled rows, digit planes, row order, policy counters) is untouched; that
+// E-step starts its first round from the rows' best components instead of the previous pass's lists.
+static void yield_scratch(gmmvb_workspace* w) {
+    // its counters, masks and block counts (per tile) still describe that pass: gmmvb_last_sparsity / gmmvb_last_work answer,
+    // and the next sweep rebuilds its first round's lists from them (blk_fresh stays as it is)
+    w->lost_estep = w->e_state == 1;
+    w->e_state = 0;
+    w->active_lists = false;
+    if (w->mlists_done) w->mlists_lost = true;
+    w->mlists_done = false;
+    w->rec_live = false;
+    w->settled_fresh = false;
+    if (w->xc_src) w->xc_stale = true;         // rebuilt from the rows when a kernel needs it (restore_xc)
+}
+static void claim_scratch(gmmvb_workspace* ws) {
+    gmmvb_scratch* s = ws->scratch;
+    if (!s || s->owner == ws) return;
+    if (s->owner) yield_scratch(s->owner);
+    s->owner = ws;
+}
+static void release_scratch(gmmvb_workspace* ws) {
+    gmmvb_scratch* s = ws->scratch;
+    if (!s) return;
+    if (s->owner == ws) s->owner = nullptr;
+    if (--s->refs <= 0) {          // (a creation that failed half-way has not handed its buffers over yet)
+        double* d[] = {s->lnrho ? s->lnrho : ws->lnrho, s->xc ? s->xc : ws->xc, s->slabs ? s->slabs : ws->slabs};
+        for (double* p : d)
+            if (p) (void)hipFree(p);
+        if (s->lists) (void)hipFree(s->lists);
+        delete s;
+    }
+    ws->scratch = nullptr;
+    ws->lnrho = ws->xc = ws->slabs = nullptr;
+    ws->lists = nullptr;
+}
+
+static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace* first, gmmvb_workspace** out) {
     if (!out) return fail(GMMVB_EINVAL, "out is null");
     *out = nullptr;
     if (K < 1 || D < 1 || max_rows < 1) return fail(GMMVB_EINVAL, "K, D and max_rows must be positive");
@@ -84,6 +122,17 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
 
     gmmvb_workspace* ws = new (std::nothrow) gmmvb_workspace();
     if (!ws) return fail(GMMVB_ENOMEM, "host allocation failed");
+    if (first) {
+        ws->scratch = first->scratch;
+        ++ws->scratch->refs;
+    } else {
+        ws->scratch = new (std::nothrow) gmmvb_scratch();
+        if (!ws->scratch) {
+            delete ws;
+            return fail(GMMVB_ENOMEM, "host allocation failed");
+        }
+        ws->scratch->refs = 1;
+    }
     ws->K = K;
     ws->D = D;
     ws->T = (D + 15) / 16;
@@ -117,6 +166,8 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
             }
             ws->bytes += b.n * (int64_t)sizeof(double);
         }
+        ws->scratch->lnrho = ws->lnrho;            // (freed with the scratch; the generic path has no tile groups)
+        ws->scratch->npad = ws->npad;
         e = hipMemset(ws->pivot, 0, (size_t)D * sizeof(double));
         if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 8 * sizeof(double));
         if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 8 * sizeof(double), hipHostMallocDefault);
@@ -228,12 +279,34 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     }
     for (auto& b : bufs) {
         if (b.n == 0) continue;
+        const bool shared = b.p == &ws->lnrho || b.p == &ws->xc || b.p == &ws->slabs;
+        if (shared && first) continue;             // a further tile of a group: the first tile's buffers (below)
         e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
         if (e != hipSuccess) {
+            if (shared) *b.p = nullptr;
             gmmvb_workspace_destroy(ws);
             return fail(GMMVB_ENOMEM, "hipMalloc (workspace)", e);
         }
         ws->bytes += b.n * (int64_t)sizeof(double);
+    }
+    {
+        gmmvb_scratch* sc = ws->scratch;
+        if (!first) {
+            sc->lnrho = ws->lnrho;
+            sc->xc = ws->xc;
+            sc->slabs = ws->slabs;
+            sc->npad = ws->npad;
+            sc->xc_len = bufs[6].n;
+            sc->slabs_len = bufs[5].n;
+        } else {
+            if (ws->npad > sc->npad || bufs[6].n > sc->xc_len || bufs[5].n > sc->slabs_len || (bufs[6].n > 0 && !sc->xc)) {
+                gmmvb_workspace_destroy(ws);
+                return fail(GMMVB_EINVAL, "a further tile must not be larger than the group's first workspace");
+            }
+            ws->lnrho = sc->lnrho;
+            ws->xc = bufs[6].n > 0 ? sc->xc : nullptr;
+            ws->slabs = sc->slabs;
+        }
     }
     if (ws->sparse && K <= 256 && ensure_lists(ws) != GMMVB_OK) {      // not inside somebody's timed iteration
         gmmvb_workspace_destroy(ws);
@@ -251,8 +324,24 @@ int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_wo
     return GMMVB_OK;
 }
 
+int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace** out) {
+    return create_workspace(K, D, x_dtype, max_rows, nullptr, out);
+}
+
+int gmmvb_workspace_create_tile(gmmvb_workspace* first, int64_t max_rows, gmmvb_workspace** out) {
+    if (!out) return fail(GMMVB_EINVAL, "out is null");
+    *out = nullptr;
+    if (!first || !first->scratch) return fail(GMMVB_EINVAL, "null argument");
+    if (first->generic || first->hmm != nullptr)
+        return fail(GMMVB_EUNSUPPORTED, "tile groups: mixture workspaces with c_degree <= 256 only (the HMM's time axis does not tile)");
+    if (max_rows < 1 || max_rows > first->max_rows)
+        return fail(GMMVB_EINVAL, "a further tile must not be larger than the group's first workspace");
+    return create_workspace(first->K, first->D, first->x_dtype, max_rows, first, out);
+}
+
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
+    release_scratch(ws);
     double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart, ws->gen_u, ws->gen_m, ws->gen_first,
                       ws->gen_second};
@@ -440,6 +529,7 @@ int gmmvb_debug_proof(gmmvb_workspace* ws, int k, int64_t n_rows, float* ub_dev,
     if (!ws || !ub_dev || !lb_dev || k < 0 || k >= ws->K) return fail(GMMVB_EINVAL, "bad argument");
     if (!ws->xq || !ws->img_i8b || ws->xq_src == nullptr || ws->xq_rows != n_rows || ws->xq_gen != ws->img_gen || !ws->have_params)
         return fail(GMMVB_ESTATE, "no digit planes for these rows: gmmvb_set_pivot, gmmvb_prepare_rows, gmmvb_set_params first");
+    claim_scratch(ws);
     hipStream_t st = (hipStream_t)stream;
     ws->tmeta_valid = false;                                       // (the bound array is written behind the sweeps' back)
     const unsigned grid = (unsigned)((std::max<int64_t>(n_rows, ws->K) + 255) / 256);
@@ -455,6 +545,7 @@ int gmmvb_debug_proof(gmmvb_workspace* ws, int k, int64_t n_rows, float* ub_dev,
     if (e != hipSuccess) return fail(GMMVB_EHIP, "proof kernel (diagnostic)", e);
     // whatever the workspace held of an E-step is gone
     ws->e_state = 0;
+    ws->lost_estep = false;
     ws->bounds_rows = 0;
     ws->rec_valid = ws->dense_valid = ws->rec_live = false;
     ws->active_lists = ws->blk_fresh = false;
@@ -514,7 +605,13 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (ws->lists) return GMMVB_OK;
     const int64_t sel_blocks = (ws->npad + kSelRows - 1) / kSelRows, words = (ws->K + 63) / 64;
     const int64_t np = ws->npad;
-    hipError_t e = hipMalloc((void**)&ws->lists, (size_t)ws->K * np * sizeof(int));
+    hipError_t e = hipSuccess;
+    const bool own_lists = ws->scratch->lists == nullptr;
+    if (own_lists) {                   // one set for the tile group, sized for its first (largest) workspace
+        e = hipMalloc((void**)&ws->scratch->lists, (size_t)ws->K * ws->scratch->npad * sizeof(int));
+        if (e != hipSuccess) ws->scratch->lists = nullptr;
+    }
+    if (e == hipSuccess) ws->lists = ws->scratch->lists;
     if (e == hipSuccess) e = hipMalloc((void**)&ws->khat, (size_t)np * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->counts, (size_t)ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->plan, (size_t)(ws->K + 1) * sizeof(int));
@@ -576,7 +673,7 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e != hipSuccess) return fail(GMMVB_ENOMEM, "hipMalloc (sample lists / records)", e);
     // lists, khat, counts, plans, four sets of block counts and their scan parts; four sets of masks; lock / lcomp / dlock /
     // rthr; the cache; eight per-block counters; the records
-    ws->bytes += ((int64_t)ws->K * np + np + 4 * ws->K + 3 + 4 * sel_blocks * ws->K + (int64_t)ws->K * kScanParts) * (int64_t)sizeof(int) +
+    ws->bytes += ((own_lists ? (int64_t)ws->K * ws->scratch->npad : 0) + np + 4 * ws->K + 3 + 4 * sel_blocks * ws->K + (int64_t)ws->K * kScanParts) * (int64_t)sizeof(int) +
                  4 * words * np * 8 + np * (1 + 1 + 4 + 4) + gmmvb_stats_len(ws->K, ws->D) * 8 + 8 * sel_blocks * 8 +
                  np * (kRecSlots * 6 + 4 + 3);
     return GMMVB_OK;
@@ -724,7 +821,7 @@ static int take_policy(gmmvb_workspace* ws) {
 int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs, double* evaluated_pairs) {
     (void)stream;
     if (!ws || !active_pairs || !evaluated_pairs) return fail(GMMVB_EINVAL, "null argument");
-    if (ws->e_state != 1) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    if (ws->e_state != 1 && !ws->lost_estep) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     int rc = fetch_counters(ws);
     if (rc) return rc;
     *evaluated_pairs = ws->lag.mode == 0 ? (double)ws->e_rows * ws->K : ws->lag.eval;
@@ -734,7 +831,7 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
 
 int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
     if (!ws || !out) return fail(GMMVB_EINVAL, "null argument");
-    if (ws->e_state != 1) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    if (ws->e_state != 1 && !ws->lost_estep) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     int rc = fetch_counters(ws);
     if (rc) return rc;
     const bool counted = ws->sparse && ws->act_rows == ws->e_rows;
@@ -764,6 +861,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     bool vec = false;
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
     if (rc) return rc;
+    claim_scratch(ws);                 // (the centred copy is written below)
     ws->bounds_rows = 0;               // (new) sample matrix: nothing of an earlier E-step may be carried over
     if (ws->lock_live) {               // the settled rows belonged to the previous state of affairs
         ws->lock_live = false;
@@ -807,11 +905,14 @@ static hipError_t recenter_rows(gmmvb_workspace* ws, int64_t n_rows, hipStream_t
     const int Dp = 16 * ws->T;
     const int64_t pad_rows = round_up(n_rows, 64) + 64;
     const unsigned cg = (unsigned)((pad_rows * Dp + 255) / 256);
+    // regrouped rows: the workspace's permuted copy; else (the copy was lost to another tile of the group) the caller's matrix
+    const void* src = ws->sorted ? ws->xp : ws->xc_src;
+    const int64_t ld = ws->sorted ? (int64_t)ws->D : ws->xc_ldx;
     if (ws->x_dtype == GMMVB_F64)
-        hipLaunchKernelGGL(center_rows_kernel<double>, dim3(cg), dim3(256), 0, st, (const double*)ws->xp, (int64_t)ws->D, n_rows,
+        hipLaunchKernelGGL(center_rows_kernel<double>, dim3(cg), dim3(256), 0, st, (const double*)src, ld, n_rows,
                            pad_rows, ws->D, Dp, ws->pivot, ws->xc);
     else
-        hipLaunchKernelGGL(center_rows_kernel<float>, dim3(cg), dim3(256), 0, st, (const float*)ws->xp, (int64_t)ws->D, n_rows,
+        hipLaunchKernelGGL(center_rows_kernel<float>, dim3(cg), dim3(256), 0, st, (const float*)src, ld, n_rows,
                            pad_rows, ws->D, Dp, ws->pivot, ws->xc);
     ws->xc_stale = false;
     return hipGetLastError();
@@ -971,6 +1072,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
     if (rc) return rc;
     if (!ws->have_params) return fail(GMMVB_ESTATE, "gmmvb_set_params has not been called");
+    claim_scratch(ws);
     hipStream_t st = (hipStream_t)stream;
     const int is64 = ws->x_dtype == GMMVB_F64;
     if (ws->generic) {
@@ -1004,6 +1106,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ws->exp_counted = false;
         ws->rec_live = ws->rec_valid = false;
         ws->e_state = 1;
+        ws->lost_estep = false;
         ws->e_rows = n_rows;
         ws->params_used = true;
         ws->have_drift = false;
@@ -1048,7 +1151,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const double pairs_l = rows_l * ws->K;
     // the previous pass's M-step left its per-component lists of active rows (and their masks) in the workspace
     // (or the masks and block counts they are built from)
-    const bool prev_lists = (ws->active_lists || ws->blk_fresh) && ws->e_state == 1 && ws->act_rows == n_rows && same_rows;
+    // (an E-step whose output went to another tile of the group still left its masks, block counts and best components)
+    const bool after_estep = ws->e_state == 1 || ws->lost_estep;
+    const bool prev_lists = (ws->active_lists || ws->blk_fresh) && after_estep && ws->act_rows == n_rows && same_rows;
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
         bool sparse_ok = ws->prune == 2;
@@ -1109,11 +1214,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // to pay (at most 2.5 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
     // kernels over ungrouped rows are 15-40 % slower for the rest of the fit.
     if (mode == kSweep && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
-        ws->e_state == 1 && known && L.act <= policy::kRegroupForceBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
+        after_estep && known && L.act <= policy::kRegroupForceBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
         ws->xc_ldx == ldx)
         mode = kBound;
     auto regroup_due = [&]() {
-        return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && ws->e_state == 1 && known &&
+        return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && after_estep && known &&
                L.act <= policy::kRegroupBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
                (!ws->sorted || ws->moved_since_sort > policy::kRegroupMoved * rows_l);      // (again once that share of the rows has moved on)
     };
@@ -1486,6 +1591,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (skip_margin >= 0.0) ws->skip_used = true;
     ws->blk_fresh = counted;
     ws->e_state = 1;
+    ws->lost_estep = false;
     ws->e_rows = n_rows;
     ws->params_used = true;
     ws->have_drift = false;
@@ -1505,12 +1611,14 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
 int gmmvb_load_responsibilities(gmmvb_workspace* ws, const double* r_dev, int64_t n_rows, void* stream) {
     if (!ws || !r_dev) return fail(GMMVB_EINVAL, "null argument");
     if (n_rows < 1 || n_rows > ws->max_rows) return fail(GMMVB_EINVAL, "n_rows must be in [1, max_rows]");
+    claim_scratch(ws);
     const int tb = 256;
     hipLaunchKernelGGL(load_r_kernel, dim3((unsigned)((n_rows + tb - 1) / tb)), dim3(tb), 0, (hipStream_t)stream,
                        r_dev, n_rows, ws->K, ws->lnrho, ws->npad, ws->lse, ws->sorted ? ws->iperm : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "load_r launch", e);
     ws->e_state = 2;
+    ws->lost_estep = false;
     ws->e_rows = n_rows;
     ws->n_spans = 0;
     ws->bounds_rows = 0;               // the array holds responsibilities now, nothing a later E-step may carry over

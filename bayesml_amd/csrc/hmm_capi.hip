@@ -178,6 +178,8 @@ int64_t hmmvb_out_len(int K) { return K < 1 ? -1 : (int64_t)K * K + 2 * (int64_t
 int hmmvb_enable(gmmvb_workspace* ws) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     if (ws->hmm) return GMMVB_OK;
+    if (ws->scratch && ws->scratch->refs > 1)
+        return fail(GMMVB_EUNSUPPORTED, "HMM: the time axis does not tile (this workspace belongs to a tile group)");
     if (ws->K > 65535) return fail(GMMVB_EUNSUPPORTED, "HMM: at most 65535 states (16-bit back-pointers)");
     gmmvb_hmm_state* h = new (std::nothrow) gmmvb_hmm_state();
     if (!h) return fail(GMMVB_ENOMEM, "host allocation failed");

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 struct gmmvb_hmm_state;      // HMM forward-backward buffers (hmm_capi.hip), allocated by hmmvb_enable
+struct gmmvb_workspace;
 
 // What an E-step leaves for the policy of the next one (and for gmmvb_last_work)
 struct gmmvb_pass_counters {
@@ -17,8 +18,28 @@ struct gmmvb_pass_counters {
     int mode = 0;                // kind of the pass: 0 dense, 1 bound pass, 2 carried records, 3 sweep
 };
 
+// Buffers that only live from an E-step to the M-step (or read-out) behind it: ln rho [K][npad] f64, the sample lists
+// [K][npad] i32, the centred f64 copy of the rows and the M-step's slabs - 3.5 KB per row at K = 256, D = 64, two thirds of
+// the workspace.  The workspaces of ONE row-tiled job (gmmvb_workspace_create_tile) share one set, sized for the largest
+// tile: what a tile carries from iteration to iteration (f32 bounds, records, digit planes, settled rows, row order) stays
+// its own.  `owner` is the workspace whose E-step output the buffers hold; another workspace that needs them takes them
+// over (capi.hip: claim_scratch) and the previous owner is back to "no E-step output".  All on one stream.
+struct gmmvb_scratch {
+    double* lnrho = nullptr;
+    double* xc = nullptr;
+    double* slabs = nullptr;
+    int* lists = nullptr;
+    int64_t npad = 0;                  // rows (padded) the buffers were sized for
+    int64_t xc_len = 0, slabs_len = 0; // doubles
+    gmmvb_workspace* owner = nullptr;
+    int refs = 0;
+};
+
 struct gmmvb_workspace {
     int K = 0, D = 0, T = 0, x_dtype = 0;
+    gmmvb_scratch* scratch = nullptr;  // lnrho / xc / slabs / lists below point into it
+    bool lost_estep = false;           // the last E-step's output went to another tile of the group (e_state 0); its counters,
+                                       // masks and block counts are still that pass's
     int64_t max_rows = 0, npad = 0;
     int num_cu = 0, KG = 0, S_cap = 0;
     int64_t split_rows = 0;    // cap on rows per M-step split

@@ -559,7 +559,9 @@ def main():
                                    f"one VB iteration per step ({args.config} of BASELINE.json configs"
                                    f"{', overlapping clusters' if args.overlap else ''})",
                        "classes": K, "degree": D, "rows_per_gpu": n_local, "rows_total": n_total, "x_storage": dt,
-                       "cluster_spread": spread, "parallelism": f"rows{world}"},
+                       "cluster_spread": spread, "parallelism": f"rows{world}",
+                       "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
+                       "row_tiles": getattr(eng, "n_tiles", 1)},
             "roofline": roof, "dense": dense_leg, "hard_workload": hard, "spread_sweep": spread_leg,
             "full_fit": full_leg, "hmm_c5": hmm_leg, "small_c1": small_leg, "per_rank": ranks_info,
             "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,

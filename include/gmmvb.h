@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GMMVB_ABI_VERSION 4
+#define GMMVB_ABI_VERSION 5
 
 enum gmmvb_status {
     GMMVB_OK = 0,
@@ -67,6 +67,19 @@ int64_t gmmvb_stats_len(int K, int D);
 int gmmvb_workspace_create(int K, int D, int x_dtype, int64_t max_rows, gmmvb_workspace** out);
 int gmmvb_workspace_destroy(gmmvb_workspace* ws);
 int64_t gmmvb_workspace_bytes(const gmmvb_workspace* ws);
+
+/* A further workspace of a ROW-TILED job: same K, D, x_dtype as `first`, for up to max_rows <= first's rows, sharing
+ * first's pass-local buffers (ln rho [K][rows] f64, the sample lists [K][rows] i32, the centred copy of the rows, the
+ * M-step's slabs: two thirds of a workspace's bytes) and keeping everything it carries from one VB iteration to the next
+ * (f32 bounds, records, digit planes, settled rows, row order, policy counters) of its own.  This is how a matrix whose
+ * [N, K] arrays do not fit one GPU (reference `_gaussianmixture.py:835-836` keeps them in host RAM) runs with carried
+ * bounds: N = 1e8, K = 256 in eight tiles is 245 GB instead of 550.  Use: per tile gmmvb_prepare_rows once, then per VB
+ * iteration gmmvb_set_params (and gmmvb_set_drift) on every tile and gmmvb_estep_mstep tile after tile, adding up the
+ * statistics blocks.  The shared buffers hold ONE tile's E-step output at a time: a call that writes them on another
+ * tile (gmmvb_estep, gmmvb_load_responsibilities, gmmvb_prepare_rows) takes them over, after which the previous tile's
+ * gmmvb_mstep and read-outs return GMMVB_ESTATE until its next E-step.  All workspaces of a group must be driven on one
+ * stream; they may be destroyed in any order.  Not for HMM workspaces (hmmvb_enable refuses a group member) nor D > 256. */
+int gmmvb_workspace_create_tile(gmmvb_workspace* first, int64_t max_rows, gmmvb_workspace** out);
 
 /* Expansion point for the second moments (default: zeros).  Any fixed vector near the data keeps
  * B/ns - (a/ns)(a/ns)^T free of cancellation; results do not depend on it beyond rounding. */
