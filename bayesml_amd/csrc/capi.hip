@@ -246,6 +246,8 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
         v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round (rows then never settle);
         ws->opt_proof = !(v && std::strcmp(v, "0") == 0);
         ws->opt_proof_all = !(v && std::strcmp(v, "settled") == 0);     // "settled": only the settled rows' pairs go through it
+        v = std::getenv("GMMVB_PROOF_BLOCKED");                    // "0": the proof round walks component after component
+        ws->opt_proof_blocked = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_SWEEP_LAZY");                       // "0": every sweep reads all K bounds of every row
         ws->opt_lazy = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
@@ -1067,6 +1069,18 @@ constexpr double kRegroupForceBelow = 2.5, kRegroupBelow = 4.0, kRegroupMoved = 
 constexpr double kOwnRoundBelow = 0.995;
 }  // namespace policy
 
+// The proof round over the lists just filled from the selection blocks' bases `blk_base`: by row superblocks when the item
+// table fits the M-step's slabs (free during an E-step; estep_i8.h), else component after component.
+static hipError_t proof_round(gmmvb_workspace* ws, hipStream_t st, const int* blk_base, int sel_grid, int64_t n_rows, float* ub) {
+    if (ws->opt_proof_blocked && ws->slabs &&
+        estep_i8_proof_work_bytes(ws->K, n_rows) <= ws->scratch->slabs_len * (int64_t)sizeof(double))
+        return launch_estep_i8_proof_blocked(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists,
+                                             ws->npad, ws->counts, blk_base, sel_grid, ws->slabs, ub, ws->lnrho, ws->npad);
+    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K, estep_i8_pairs_per_chunk(), ws->plan);
+    return launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists, ws->npad,
+                                 ws->counts, ws->plan, ub, ws->lnrho, ws->npad);
+}
+
 int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, void* stream) {
     bool vec = false;
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
@@ -1409,12 +1423,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
                 hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
                                    ws->blk, ws->lists, ws->npad);
-                hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K, estep_i8_pairs_per_chunk(),
-                                   ws->plan);
                 span_end(ws, st);
                 span_begin(ws, kSpanProof, st);
-                e = launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists,
-                                          ws->npad, ws->counts, ws->plan, ws->ub32, ws->lnrho, ws->npad);
+                e = proof_round(ws, st, ws->blk, sel_grid, n_rows, ws->ub32);
                 span_end(ws, st);
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round (bound pass)", e);
                 span_begin(ws, kSpanSelect, st);
@@ -1461,12 +1472,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
                     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
                                        ws->K, ws->rblk, ws->lists, ws->npad);
-                    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
-                                       estep_i8_pairs_per_chunk(), ws->plan);
                     span_end(ws, st);
                     span_begin(ws, kSpanProof, st);
-                    e = launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists,
-                                              ws->npad, ws->counts, ws->plan, nullptr, ws->lnrho, ws->npad);
+                    e = proof_round(ws, st, ws->rblk, sel_grid, n_rows, nullptr);
                     span_end(ws, st);
                     if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round (settled rows' own pairs)", e);
                 }
@@ -1502,12 +1510,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
                     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
                                        ws->K, ws->rblk, ws->lists, ws->npad);
-                    hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
-                                       estep_i8_pairs_per_chunk(), ws->plan);
                     span_end(ws, st);
                     span_begin(ws, kSpanProof, st);
-                    e = launch_estep_i8_proof(ws->D, ws->num_cu, st, ws->xq, ws->xqe, ws->img_i8b, ws->cvec, ws->K, ws->lists,
-                                              ws->npad, ws->counts, ws->plan, ws->ub32, ws->lnrho, ws->npad);
+                    e = proof_round(ws, st, ws->rblk, sel_grid, n_rows, ws->ub32);
                     span_end(ws, st);
                     if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round", e);
                     span_begin(ws, kSpanSelect, st);

@@ -737,4 +737,221 @@ __global__ __launch_bounds__(512) void estep_i8_proof(const unsigned char* __res
     }
 }
 
+
+// ---- the proof round over ROW SUPERBLOCKS (round 4) -------------------------------------------------------------------------
+// estep_i8_proof walks one component's list after the other, so a row with p proof pairs has its digit planes fetched from
+// HBM p times - at K = 256, D = 64 (config 4) p is 6 - 11, and the kernel is bound by exactly those gathered 192-byte reads
+// (45 GB at ~4.8 TB/s in a 9-ms launch).  Here the pairs are regrouped into ITEMS of at most kProofItem entries of one
+// component's list that lie in one superblock of kProofSuperRows rows (the lists are ascending, so that is a contiguous
+// stretch of the list; its ends come from the selection blocks' bases), and the items of a superblock are handed to the
+// workgroups of ONE XCD (workgroup b runs on XCD b mod 8), interleaved so that all of them work on the same one or two
+// superblocks at any time: 0.8 - 1.5 MB of digit planes, which stay in that XCD's 4-MB L2 while every component's items
+// gather from them.  HBM sees every touched row about once.  Same arithmetic per pair, same outputs.
+constexpr int kProofSuperRows = 4096;
+constexpr int kProofItem = 256;            // one 32-entry tile for each of the eight waves
+constexpr int kProofXcds = 8;
+
+__device__ __forceinline__ void proof_unit(const int* __restrict__ blk_base, const int* __restrict__ counts, int nblk, int s,
+                                           int k, int& lo, int& hi) {
+    constexpr int BS = kProofSuperRows / 256;
+    const int b0 = s * BS, b1 = b0 + BS;
+    lo = blk_base[(int64_t)k * nblk + b0];
+    hi = b1 < nblk ? blk_base[(int64_t)k * nblk + b1] : counts[k];
+}
+
+// cum[s][k] = items of superblock s that belong to components < k (cum[s][K] = tot[s] = all of them).  One workgroup per
+// superblock, one thread per component.
+__global__ __launch_bounds__(256) void proof_units_kernel(const int* __restrict__ blk_base /*[K][nblk] exclusive bases*/,
+                                                          const int* __restrict__ counts, int K, int nblk,
+                                                          int* __restrict__ cum /*[n_super][K + 1]*/, int* __restrict__ tot) {
+    __shared__ int sc[256];
+    const int s = blockIdx.x, k = threadIdx.x;
+    int n = 0;
+    if (k < K) {
+        int lo, hi;
+        proof_unit(blk_base, counts, nblk, s, k, lo, hi);
+        n = (hi - lo + kProofItem - 1) / kProofItem;
+    }
+    sc[k] = n;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = k >= o ? sc[k - o] : 0;
+        __syncthreads();
+        sc[k] += v;
+        __syncthreads();
+    }
+    if (k < K) cum[(int64_t)s * (K + 1) + k] = sc[k] - n;
+    if (k == 255) {
+        cum[(int64_t)s * (K + 1) + K] = sc[255];
+        tot[s] = sc[255];
+    }
+}
+
+// Workgroup x of kProofXcds: xb[s] = items of the superblocks s' < s with s' = s = x (mod 8); xtot[x] = their total
+__global__ __launch_bounds__(1024) void proof_order_kernel(const int* __restrict__ tot, int n_super, int* __restrict__ xb,
+                                                           int* __restrict__ xtot) {
+    __shared__ int sc[1024];
+    const int x = blockIdx.x, t = threadIdx.x;
+    const int nx = n_super > x ? (n_super - x + kProofXcds - 1) / kProofXcds : 0;
+    const int per = (nx + 1023) / 1024;
+    const int j0 = t * per, j1 = j0 + per < nx ? j0 + per : nx;
+    int sum = 0;
+    for (int j = j0; j < j1; ++j) sum += tot[x + kProofXcds * j];
+    sc[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? sc[t - o] : 0;
+        __syncthreads();
+        sc[t] += v;
+        __syncthreads();
+    }
+    int run = sc[t] - sum;
+    for (int j = j0; j < j1; ++j) {
+        xb[x + kProofXcds * j] = run;
+        run += tot[x + kProofXcds * j];
+    }
+    if (t == 1023) xtot[x] = sc[1023];
+}
+
+// items[first(x) + xb[s] + cum[s][k] + c] = (k, first list entry, entries, s) for chunk c of unit (s, k)
+__global__ __launch_bounds__(256) void proof_items_kernel(const int* __restrict__ blk_base, const int* __restrict__ counts, int K,
+                                                          int nblk, const int* __restrict__ cum, const int* __restrict__ xb,
+                                                          const int* __restrict__ xtot, i4v* __restrict__ items) {
+    const int s = blockIdx.x, k = threadIdx.x;
+    if (k >= K) return;
+    int first = 0;
+    for (int q = 0; q < s % kProofXcds; ++q) first += xtot[q];
+    int lo, hi;
+    proof_unit(blk_base, counts, nblk, s, k, lo, hi);
+    i4v* dst = items + first + xb[s] + cum[(int64_t)s * (K + 1) + k];
+    for (int e = lo; e < hi; e += kProofItem) *dst++ = i4v{k, e, hi - e < kProofItem ? hi - e : kProofItem, s};
+}
+
+template <int T32>
+__global__ __launch_bounds__(512) void estep_i8_proof_blocked(const unsigned char* __restrict__ xq, const signed char* __restrict__ xqe,
+                                                              const unsigned char* __restrict__ img /*[K][IMGB], 3 digits*/,
+                                                              const double* __restrict__ cvec, int K,
+                                                              const int* __restrict__ lists /*[K][cap]*/, int64_t cap,
+                                                              const i4v* __restrict__ items, const int* __restrict__ xtot,
+                                                              float* __restrict__ ub /*[K][npad]*/, double* __restrict__ lb /*[K][npad]*/,
+                                                              int64_t npad) {
+    constexpr int ND = kBoundDigits, NW = 8;
+    constexpr int IMGB = i8_img_bytes(ND, T32);
+    constexpr int64_t RS = i8_digit_row_bytes(T32);
+    constexpr int NS = T32 <= 3 ? 3 : 2;             // digit register sets = items whose digit planes are in flight + 1
+    constexpr int NI = (IMGB + 512 * 16 - 1) / (512 * 16);      // 16-byte pieces of an image per thread
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][IMGB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int x = (int)(blockIdx.x % kProofXcds), j = (int)(blockIdx.x / kProofXcds), W = (int)(gridDim.x / kProofXcds);
+    int first = 0;
+    for (int q = 0; q < x; ++q) first += xtot[q];
+    const int n_items = xtot[x];
+    const i4v* my = items + first;
+    if (n_items <= j) return;
+    // Every iteration issues the SAME memory operations in the same order (items past the end repeat the workgroup's last
+    // item and only skip the arithmetic and the stores): the compiler's in-order vmcnt bookkeeping then stays exact, and a
+    // wait for the oldest request leaves the younger ones in flight.
+    auto desc = [&](int t) -> i4v {                  // item t of this workgroup: (component, first entry, entries, superblock)
+        const int i = j + t * W;
+        i4v d = my[i < n_items ? i : n_items - 1];
+        if (i >= n_items) d[3] = -1;
+        return d;
+    };
+    auto entry = [&](const i4v& d) -> int {           // row of this lane's pair (the item's last row beyond its end)
+        const int o = wave * 32 + c;
+        return lists[(int64_t)d[0] * cap + d[1] + (o < d[2] ? o : d[2] - 1)];
+    };
+    // The image goes global -> registers -> LDS with ordinary loads (not LDS-DMA): every wait is then the compiler's own,
+    // exact, in-order vmcnt - a blanket vmcnt(0) per item made every item wait for the list entries requested for the
+    // item after next, an HBM round trip (first form of this kernel: no faster than estep_i8_proof).
+    auto image_load = [&](int k, i4v (&ir)[NI]) {
+        const unsigned char* src = img + (int64_t)k * IMGB;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int o = (q * 512 + tid) * 16;
+            ir[q] = *reinterpret_cast<const i4v*>(src + (o < IMGB ? o : IMGB - 16));
+        }
+    };
+    auto image_store = [&](int buf, const i4v (&ir)[NI]) {
+#pragma unroll
+        for (int q = 0; q < NI; ++q)
+            if ((q * 512 + tid) * 16 < IMGB) *reinterpret_cast<i4v*>(&smem[buf][(q * 512 + tid) * 16]) = ir[q];
+    };
+    auto request = [&](int idx, i4v (&xd)[ND][T32], int64_t& row, int& en) {
+        row = idx;
+        const unsigned char* src = xq + row * RS + 16 * h;
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+            for (int it = 0; it < T32; ++it) xd[a][it] = *reinterpret_cast<const i4v*>(src + a * 32 * T32 + 32 * it);
+        en = xqe[row];
+    };
+    auto evaluate = [&](const i4v& d, int buf, const i4v (&xd)[ND][T32], int64_t row, int en) {
+        if (d[3] < 0 || wave * 32 >= d[2]) return;    // (wave-uniform: past the end, or this wave's tile lies beyond the item)
+        const unsigned im_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem[buf]);
+        const bool ok = en != kNoDigits;
+        i8_lane_consts lc;
+        lc.c[0] = lc.c[1] = lc.c[2] = 0.0;
+        lc.c2f = ok ? (float)ldexp(1.0, en - 12 - 7 * (ND - 1)) : 0.0f;
+        lc.cef = ok ? (float)(ldexp(1.0, en) * i8_err(ND, T32) * 1.0001) : __builtin_huge_valf();
+        float q_lo, q_hi;
+        if (T32 > 1 && wave >= NW / 2)
+            estep_i8_two_sided<T32, true>(im_lds, xd, lc, lane, h, q_lo, q_hi);
+        else
+            estep_i8_two_sided<T32, false>(im_lds, xd, lc, lane, h, q_lo, q_hi);
+        if (h == 0 && wave * 32 + c < d[2]) {
+            const int k = d[0];
+            const double ck = cvec[k];
+            const double up = fma(-0.5 * (double)q_lo, 1.0 - 1.52587890625e-05, ck + 1e-12 * fabs(ck));
+            const double lo = fma(-0.5 * (double)q_hi, 1.0 + 1.52587890625e-05, ck - 1e-12 * fabs(ck));
+            if (ub) ub[(int64_t)k * npad + row] = __double2float_ru(up);
+            lb[(int64_t)k * npad + row] = (lo == lo) ? lo : -__builtin_huge_val();
+        }
+    };
+    // Software pipeline over the workgroup's items t = 0, 1, ... (dd[i] = descriptor of item t + i).  In iteration t:
+    //   the image of item t (in registers since iteration t - 1) goes to LDS buffer t & 1; barrier;
+    //   requests, in this order: the image of item t + 1; the list entries of item t + NS; the digit planes of item
+    //             t + NS - 1 (into the register set item t - 1 has left); the descriptor of item t + NS + 2 - what the next
+    //             iteration needs first (image, then entries) is requested first, so waiting for it (vmcnt counts in order)
+    //             leaves the digit planes behind it in flight;
+    //   item t is computed from register set t % NS.
+    // One barrier per item: behind it item t's image is complete, and everybody has left the buffer item t + 1's image will
+    // be written to in the next iteration.
+    i4v xs[NS][ND][T32];
+    int64_t rows[NS];
+    int ens[NS];
+    i4v dd[NS + 2];
+#pragma unroll
+    for (int i = 0; i < NS + 2; ++i) dd[i] = desc(i);
+    i4v ir[NI];
+    image_load(dd[0][0], ir);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        rows[q] = 0;
+        ens[q] = 0;
+        if (q + 1 < NS) request(entry(dd[q]), xs[q], rows[q], ens[q]);
+    }
+    int e_next = entry(dd[NS - 1]);
+    for (int t = 0; dd[0][3] >= 0; t += NS) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            const int buf = (t + p) & 1;
+            image_store(buf, ir);
+            __syncthreads();
+            image_load(dd[1][0], ir);
+            const int e_new = entry(dd[NS]);
+            request(e_next, xs[(p + NS - 1) % NS], rows[(p + NS - 1) % NS], ens[(p + NS - 1) % NS]);
+            e_next = e_new;
+            const i4v dn = desc(t + p + NS + 2);
+            evaluate(dd[0], buf, xs[p], rows[p], ens[p]);
+#pragma unroll
+            for (int i = 0; i < NS + 1; ++i) dd[i] = dd[i + 1];
+            dd[NS + 1] = dn;
+        }
+    }
+}
+
 }  // namespace gmmvb

@@ -1,5 +1,6 @@
 // Instantiations of the int8-digit E-step for T32 = ceil(D/32) in 1..4, x in {f32, f64}: the 6-digit E-step and the
 // 3-digit bound pass of the pruned E-step.
+#include <cstdint>
 #include <cstdlib>
 #include "estep_i8.h"
 #include "launch.h"
@@ -101,6 +102,45 @@ hipError_t launch_estep_i8_proof(int D, int grid, hipStream_t st, const unsigned
         PC(1) PC(2) PC(3) PC(4)
     }
 #undef PC
+    return hipErrorInvalidValue;
+}
+
+
+// The proof round over row superblocks (estep_i8.h, estep_i8_proof_blocked).  `work` holds the item table: per superblock
+// totals and bases, per (superblock, component) item counts, then the items themselves - at most pairs / 256 + one per
+// (superblock, component).  The caller hands over a buffer that is free during the E-step (the M-step's slabs).
+int64_t estep_i8_proof_work_bytes(int K, int64_t n_rows) {
+    const int64_t nblk = (n_rows + 255) / 256;
+    const int64_t n_super = (nblk * 256 + kProofSuperRows - 1) / kProofSuperRows;
+    const int64_t head = ((2 * n_super + kProofXcds + 3) / 4 * 4 + (n_super * (K + 1) + 3) / 4 * 4) * (int64_t)sizeof(int);
+    const int64_t items = n_rows * (int64_t)K / kProofItem + n_super * K + 1;
+    return head + items * (int64_t)sizeof(i4v);
+}
+
+hipError_t launch_estep_i8_proof_blocked(int D, int num_cu, hipStream_t st, const unsigned char* xq, const signed char* xqe,
+                                         const unsigned char* img, const double* cvec, int K, const int* lists, int64_t cap,
+                                         const int* counts, const int* blk_base, int nblk, void* work, float* ub, double* lb,
+                                         int64_t npad) {
+    if (K > 256 || nblk < 1 || !work || ((uintptr_t)work & 15)) return hipErrorInvalidValue;
+    const int n_super = (int)(((int64_t)nblk * 256 + kProofSuperRows - 1) / kProofSuperRows);
+    int* tot = static_cast<int*>(work);
+    int* xb = tot + n_super;
+    int* xtot = xb + n_super;
+    int* cum = tot + (2 * (int64_t)n_super + kProofXcds + 3) / 4 * 4;
+    i4v* items = reinterpret_cast<i4v*>(cum + ((int64_t)n_super * (K + 1) + 3) / 4 * 4);
+    hipLaunchKernelGGL(proof_units_kernel, dim3(n_super), dim3(256), 0, st, blk_base, counts, K, nblk, cum, tot);
+    hipLaunchKernelGGL(proof_order_kernel, dim3(kProofXcds), dim3(1024), 0, st, tot, n_super, xb, xtot);
+    hipLaunchKernelGGL(proof_items_kernel, dim3(n_super), dim3(256), 0, st, blk_base, counts, K, nblk, cum, xb, xtot, items);
+    const int grid = kProofXcds * ((2 * num_cu + kProofXcds - 1) / kProofXcds);      // two workgroups per CU, as estep_i8_proof
+#define PB(T)                                                                                                              \
+    case T:                                                                                                                \
+        hipLaunchKernelGGL((estep_i8_proof_blocked<T>), dim3(grid), dim3(512), 0, st, xq, xqe, img, cvec, K, lists, cap,   \
+                           items, xtot, ub, lb, npad);                                                                     \
+        return hipGetLastError();
+    switch (i8_blocks(D)) {
+        PB(1) PB(2) PB(3) PB(4)
+    }
+#undef PB
     return hipErrorInvalidValue;
 }
 

@@ -14,7 +14,7 @@ d = json.load(open(sys.argv[1]))
 g = d["roofline"]["kernel_groups"]
 print(sys.argv[2], "=", sys.argv[3], "ms/step", round(d["ms_per_step"], 3), "E", round(d["roofline"]["phase_ms"]["estep"], 3), "M",
       round(d["roofline"]["phase_ms"]["mstep"], 3), "mstep_main", round(g.get("mstep_main", {}).get("ms", 0), 3),
-      "tflops", round(g.get("mstep_main", {}).get("executed_f64_tflops", 0), 1), "gather", round(g.get("estep_gather", {}).get("ms", 0), 3),
+      "tflops", round(g.get("mstep_main", {}).get("executed_f64_tflops", 0), 1), "gather", round(g.get("estep_gather", {}).get("ms", 0), 3), "proof", round(g.get("estep_proof", {}).get("ms", 0), 3), "select", round(g.get("estep_select", {}).get("ms", 0), 3),
       "launch", d["launch"].split("|")[-1].strip()[:40])
 PY
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: tests, bench legs, rocprofv3 kernel trace and PMC passes.  usage: tools/gpu_round.sh <tag> <stage>...
-# stages: smoke tests newtests bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist wide share8
+# stages: smoke tests newtests c4trace c4strong1 bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist wide share8
 # (pmc / hmmpmc first: the bench stages quote the traffic files they write)
 # Outputs under gpurun_out/<tag>_*; copy the summaries worth keeping into profiles/.
 set -u
@@ -30,6 +30,11 @@ PY
     trace) rm -rf $OUT/${TAG}_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_trace.err)
            python tools/summarize_rocprof.py $OUT/${TAG}_trace > $OUT/${TAG}_bench_kernel_summary.md 2>> $OUT/${TAG}_trace.err; head -30 $OUT/${TAG}_bench_kernel_summary.md
            ;;
+    c4trace) rm -rf $OUT/${TAG}_c4trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_c4trace -- python3 $GRAFT_REPO_ROOT/bench.py --config c4 --no-cpu --no-legs --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_c4_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_c4trace.err)
+           python tools/summarize_rocprof.py $OUT/${TAG}_c4trace > $OUT/${TAG}_c4_kernel_summary.md 2>> $OUT/${TAG}_c4trace.err; head -40 $OUT/${TAG}_c4_kernel_summary.md
+           f=$(find $OUT/${TAG}_c4trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_steps.py $f 7 12 24 > $OUT/${TAG}_c4_steps.txt 2>&1
+           find $OUT/${TAG}_c4trace -name "*kernel_trace.csv" -size +20M -delete ;;
+    c4strong1) timeout 1200 python bench.py --config c4 --scaling strong --gpus 1 --no-cpu --no-legs --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_c4_strong1.json 2> $OUT/${TAG}_c4strong1.err; tail -c 300 $OUT/${TAG}_c4strong1.err; head -c 500 $OUT/${TAG}_bench_line_c4_strong1.json; echo ;;
     tracedel) find $OUT/${TAG}_trace -name "*kernel_trace.csv" -size +20M -delete ;;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/${TAG}_pmc_$c
            (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_pmc_$c.err); done
