@@ -935,9 +935,12 @@ __global__ __launch_bounds__(512) void estep_i8_proof_blocked(const unsigned cha
         if (q + 1 < NS) request(entry(dd[q]), xs[q], rows[q], ens[q]);
     }
     int e_next = entry(dd[NS - 1]);
-    for (int t = 0; dd[0][3] >= 0; t += NS) {
+    // (at the loop header the compiler merges the prologue's and the back edge's pending loads and waits for all of them:
+    // the body is unrolled over several rounds of the register sets so that this happens once in UNR items)
+    constexpr int UNR = (T32 <= 2 ? 4 : 2) * NS;
+    for (int t = 0; dd[0][3] >= 0; t += UNR) {
 #pragma unroll
-        for (int p = 0; p < NS; ++p) {
+        for (int p = 0; p < UNR; ++p) {
             const int buf = (t + p) & 1;
             image_store(buf, ir);
             __syncthreads();
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(512) void estep_i8_proof_blocked(const unsigned cha
             request(e_next, xs[(p + NS - 1) % NS], rows[(p + NS - 1) % NS], ens[(p + NS - 1) % NS]);
             e_next = e_new;
             const i4v dn = desc(t + p + NS + 2);
-            evaluate(dd[0], buf, xs[p], rows[p], ens[p]);
+            evaluate(dd[0], buf, xs[p % NS], rows[p % NS], ens[p % NS]);
 #pragma unroll
             for (int i = 0; i < NS + 1; ++i) dd[i] = dd[i + 1];
             dd[NS + 1] = dn;

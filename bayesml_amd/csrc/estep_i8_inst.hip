@@ -131,7 +131,10 @@ hipError_t launch_estep_i8_proof_blocked(int D, int num_cu, hipStream_t st, cons
     hipLaunchKernelGGL(proof_units_kernel, dim3(n_super), dim3(256), 0, st, blk_base, counts, K, nblk, cum, tot);
     hipLaunchKernelGGL(proof_order_kernel, dim3(kProofXcds), dim3(1024), 0, st, tot, n_super, xb, xtot);
     hipLaunchKernelGGL(proof_items_kernel, dim3(n_super), dim3(256), 0, st, blk_base, counts, K, nblk, cum, xb, xtot, items);
-    const int grid = kProofXcds * ((2 * num_cu + kProofXcds - 1) / kProofXcds);      // two workgroups per CU, as estep_i8_proof
+    // as many workgroups as are resident at once (182 - 222 registers past one feature block of 32: one per CU) - the items
+    // are dealt out interleaved, and a workgroup that starts late would go through the superblocks a second time
+    const int per_cu = i8_blocks(D) == 1 ? 2 : 1;
+    const int grid = kProofXcds * ((per_cu * num_cu + kProofXcds - 1) / kProofXcds);
 #define PB(T)                                                                                                              \
     case T:                                                                                                                \
         hipLaunchKernelGGL((estep_i8_proof_blocked<T>), dim3(grid), dim3(512), 0, st, xq, xqe, img, cvec, K, lists, cap,   \
