@@ -22,7 +22,7 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_MARGIN",
-            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT", "GMMVB_SWEEP_LAZY")
+            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT", "GMMVB_SWEEP_LAZY", "GMMVB_PROOF_BLOCKED")
 VARIANTS = {
     "default": {},
     # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, without
@@ -43,6 +43,9 @@ VARIANTS = {
     # every sweep carries all K bounds of every row (default: per tile of 256 rows only the components within reach)
     "nolazy": {"GMMVB_SWEEP_LAZY": "0"},
     "force_nolazy": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_SWEEP_LAZY": "0"},
+    # the proof round component after component (default: by row superblocks, estep_i8_proof_blocked)
+    "proof_by_component": {"GMMVB_PROOF_BLOCKED": "0"},
+    "force_proof_by_component": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF_BLOCKED": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
     "force_nocarry": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_CARRY_OFF": "1"},
     "dense": {"GMMVB_ESTEP_PRUNE": "0", "GMMVB_MSTEP_SPARSE": "0"},
@@ -128,7 +131,8 @@ LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n1400
          ("gmm_f3_k64_d128_n140000_f32.npz", "settle"), ("gmm_f3_k64_d128_n140000_f32.npz", "noproof"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "nosettle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"), ("gmm_f3_k64_d128_n140000_f32.npz", "nolazy"),
-         ("gmm_f3_k64_d128_n140000_f32.npz", "proof_settled"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "proof_settled"), ("gmm_f3_k64_d128_n140000_f32.npz", "proof_by_component"),
+         ("gmm_f3_k256_d64_n36000_f32.npz", "force_proof_by_component"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "nolazy"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "default"), ("gmm_f3_k256_d64_n36000_f32.npz", "force"),
