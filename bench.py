@@ -171,8 +171,12 @@ class env_vars:
         self.kv = kv
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.KEYS}
-        os.environ.update(self.kv)
+        self.old = {k: os.environ.get(k) for k in set(self.KEYS) | set(self.kv)}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
     def __exit__(self, *exc):
         for k, v in self.old.items():

@@ -115,14 +115,17 @@ def test_hmm_c5_full_size_properties():
     eng.close()
 
 
-def _sparse_vs_dense(K, D, N, iters, tol):
+def _sparse_vs_dense(K, D, N, iters, tol, tile_rows=0):
     """bench.py's workload at full size: `iters` VB iterations as update_posterior runs them, then the last pass's
-    statistics against a dense data pass on the same parameters."""
+    statistics against a dense data pass on the same parameters.  tile_rows: through resident row tiles of that size."""
     import bench
-    from bayesml_amd._engine import DataPass
+    from bayesml_amd._engine import DataPass, TiledDataPass
     dev = torch.device("cuda", 0)
     x = bench.device_rows(K, D, N, torch.float32, dev, bench.SEED + 1, 2.0)
-    w = bench.Workload(K, D, x, dev, None)
+    with bench.env_vars(BAYESML_AMD_TILE_ROWS=str(tile_rows) if tile_rows else None, BAYESML_AMD_TILE_RESIDENT="1"):
+        w = bench.Workload(K, D, x, dev, None)
+    if tile_rows:
+        assert isinstance(w.eng, TiledDataPass) and w.eng.resident and w.eng.n_tiles == (N + tile_rows - 1) // tile_rows
     seen = dict(settled=0.0, proof=0.0, cached=0.0)
     for _ in range(iters):
         w.step()
@@ -132,9 +135,10 @@ def _sparse_vs_dense(K, D, N, iters, tol):
         if wk["accumulated"] >= 0:
             seen["cached"] = max(seen["cached"], wk["active"] - wk["accumulated"])
     counts = w.eng.pass_counts()
-    assert w.eng.launch_info.startswith("estep_sweep"), w.eng.launch_info          # the compared pass lived on carried bounds
-    assert counts["estep_bound"] >= 1 and counts["estep_sweep"] >= 4 and counts["mstep_list"] >= 5, counts
-    assert counts["estep_gather"] >= 8 and w.eng.regroup_count >= 1, counts
+    tiles = getattr(w.eng, "n_tiles", 1)
+    assert "estep_sweep" in w.eng.launch_info.split("|")[0], w.eng.launch_info      # the compared pass lived on carried bounds
+    assert counts["estep_bound"] >= tiles and counts["estep_sweep"] >= 4 * tiles and counts["mstep_list"] >= 5 * tiles, counts
+    assert counts["estep_gather"] >= 8 * tiles and w.eng.regroup_count >= tiles, counts
     assert seen["cached"] > 0.3 * N and seen["settled"] > 0.1 * N and seen["proof"] > 0, seen
     wk = w.eng.work()
     assert wk["evaluated"] < 0.1 * N * K and 0.99 * N <= wk["active"] < 3.0 * N, wk
@@ -170,3 +174,11 @@ def test_gmm_c3_full_size_sparse():
 def test_gmm_c4_shard_full_size_sparse():
     """One GPU's shard of config 4: K=256, D=64, 1.25e7 rows (N = 1e8 over 8 GPUs)."""
     _sparse_vs_dense(256, 64, 12_500_000, iters=14, tol=1e-12)
+
+
+def test_gmm_c4_shape_through_resident_tiles():
+    """Config 4's shape through four resident row tiles (a workspace per tile sharing the pass-local buffers,
+    gmmvb_workspace_create_tile): every tile runs its own bound pass, regrouping, sweeps, proof rounds and cache, loses the
+    shared buffers to the next tile after every M-step - and the summed statistics equal the dense kernels'."""
+    _sparse_vs_dense(256, 64, 5_000_000, iters=14, tol=1e-12, tile_rows=1_250_048)
+

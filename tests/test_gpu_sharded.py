@@ -91,7 +91,7 @@ def test_c_abi_comm_argument_errors():
 
 
 # ---- sharded AND sparse ----------------------------------------------------------------------------------------------
-def _sparse_worker(rank, world, port, out_dir, divergent):
+def _sparse_worker(rank, world, port, out_dir, divergent, tile_rows=0):
     """The reference fixture K=64, D=128, N=140000 split 35 % / 65 % over two ranks, pruning forced (a shard is below the
     default policy's size threshold).  divergent: rank 1 additionally ignores the drift hint, so it runs a fresh bound pass
     wherever rank 0 carries - results must not depend on it.  Otherwise both ranks decide from the job-wide counters that
@@ -101,6 +101,9 @@ def _sparse_worker(rank, world, port, out_dir, divergent):
     os.environ["GMMVB_ESTEP_PRUNE"] = "force"
     if divergent and rank == 1:
         os.environ["GMMVB_ESTEP_CARRY_OFF"] = "1"
+    if tile_rows:           # every rank's shard through resident row tiles (a workspace per tile, gmmvb_workspace_create_tile)
+        os.environ["BAYESML_AMD_TILE_ROWS"] = str(tile_rows)
+        os.environ["BAYESML_AMD_TILE_RESIDENT"] = "1"
     from bayesml_amd import RowShard
     from bayesml_amd import gaussianmixture as gm
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -117,6 +120,7 @@ def _sparse_worker(rank, world, port, out_dir, divergent):
         warnings.simplefilter("ignore")
         m.update_posterior(x[lo:hi], **json.loads(str(g["kw"])))
     counts = m._engine.pass_counts()
+    counts["tiles"] = getattr(m._engine, "n_tiles", 1)
     np.savez(os.path.join(out_dir, f"sparse_rank{rank}.npz"), vl=m.vl, ns=m.ns, x_bar=m.x_bar_vecs,
              w_inv=m.hn_w_mats_inv, s=m.s_mats, counts=json.dumps(counts), **m.get_hn_params())
     dist.destroy_process_group()
@@ -212,3 +216,28 @@ def test_restarts_over_two_ranks_on_the_real_engine(tmp_path):
         vals = [float(seg.split("VL: ")[1].split(" ")[0].rstrip("*").replace("(converged)", "")) for seg in ln.split("\r") if seg]
         ref = tr[i][~np.isnan(tr[i])]
         assert len(vals) == len(ref) and np.allclose(vals, ref, rtol=1e-9, atol=0), i
+
+
+def test_two_ranks_of_resident_tiles_match_the_reference(tmp_path):
+    """Row shards AND row tiles: each of the two ranks runs its shard of the reference fixture through resident tiles of
+    24000 rows (3 and 4 of them); the tiles of both ranks decide from the job-wide counters (the policy tail is summed over
+    tiles, then over ranks) and every tile carries its own bounds."""
+    import json
+    mp.spawn(_sparse_worker, args=(2, _free_port(), str(tmp_path), False, 24000), nprocs=2, join=True)
+    g = load_golden("gmm_f3_k64_d128_n140000_f32.npz")
+    res = [dict(np.load(os.path.join(str(tmp_path), f"sparse_rank{r}.npz"))) for r in range(2)]
+    c0, c1 = (json.loads(str(r["counts"])) for r in res)
+    assert (c0["tiles"], c1["tiles"]) == (3, 4), (c0, c1)
+    for c in (c0, c1):
+        assert c["estep_bound"] >= c["tiles"] and c["estep_sweep"] >= 3 * c["tiles"] and c["mstep_list"] >= 3 * c["tiles"], c
+    # one policy for all tiles of all ranks: the same kinds of pass per tile
+    for key in ("estep_dense", "estep_bound", "estep_fell_back_dense", "estep_sweep"):
+        assert c0[key] * c1["tiles"] == c1[key] * c0["tiles"], (key, c0, c1)
+    for r in res:
+        for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus"):
+            assert rel_err(r[key], g[key]) < 1e-6, key
+        assert rel_err(r["ns"], g["ns"]) < 1e-6 and rel_err(r["x_bar"], g["x_bar_vecs"]) < 1e-6
+        assert abs(float(r["vl"]) - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
+    for key in ("hn_m_vecs", "hn_w_mats", "ns"):          # both ranks hold the same posterior, bit for bit
+        assert np.array_equal(res[0][key], res[1][key]), key
+
