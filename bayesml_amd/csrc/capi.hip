@@ -209,11 +209,21 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
         if (ws->wide) v = nullptr;           // (one E-step kernel past 8 feature tiles)
         // ... except with a single feature tile (D <= 16): the 2.5-KB images stay in L1, staging them through LDS with a
         // barrier per group of components only costs (HMM config 5: emission 4.4 -> 3.1 ms).  No pruning at that size anyway.
-        if (ws->T == 1) ws->estep_variant = kEstepDirect;
+        // (round 4) ... and with one tile the vector ALU, which can skip U's upper triangle, beats the matrix pipe (estep.h,
+        // estep_rows16_f64: HMM emission 3.1 -> 2.7 ms); GMMVB_ESTEP_VARIANT=direct keeps the MFMA kernel
+        if (ws->T == 1) ws->estep_variant = kEstepValu16;
         if (v && std::strcmp(v, "lds8") == 0) ws->estep_variant = kEstepLds8;
         if (v && std::strcmp(v, "direct") == 0) ws->estep_variant = kEstepDirect;
         if (v && std::strcmp(v, "lds4") == 0) ws->estep_variant = kEstepLds;
         if (v && std::strcmp(v, "i8") == 0) ws->estep_variant = kEstepI8;
+    }
+    if (ws->estep_variant == kEstepValu16) {
+        e = hipMalloc((void**)&ws->tri, (size_t)K * estep_tri_image_doubles() * sizeof(double));
+        if (e != hipSuccess) {
+            gmmvb_workspace_destroy(ws);
+            return fail(GMMVB_ENOMEM, "hipMalloc (packed triangular images)", e);
+        }
+        ws->bytes += (int64_t)K * estep_tri_image_doubles() * (int64_t)sizeof(double);
     }
     struct { double** p; int64_t n; } bufs[] = {
         {&ws->lnrho, (int64_t)K * ws->npad}, {&ws->lse, ws->npad},
@@ -344,7 +354,7 @@ int gmmvb_workspace_create_tile(gmmvb_workspace* first, int64_t max_rows, gmmvb_
 int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (!ws) return GMMVB_OK;
     release_scratch(ws);
-    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
+    double* bufs[] = {ws->lnrho, ws->lse, ws->img, ws->tri, ws->cvec, ws->pivot, ws->slabs, ws->xc, ws->dpart, ws->thr,
                       ws->apart, ws->ctr, ws->drift, ws->epart, ws->opart, ws->mpart, ws->gen_u, ws->gen_m, ws->gen_first,
                       ws->gen_second};
     int* ibufs[] = {ws->lists, ws->khat, ws->counts, ws->blk, ws->scan_parts, ws->plan, ws->plan_m, ws->perm, ws->iperm, ws->perm_tmp};
@@ -589,6 +599,10 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
                        ws->img_len, ws->img);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_kernel", e);
+    if (ws->tri) {
+        e = launch_pack_tri16(u_dev, m_dev, ws->K, ws->D, ws->tri, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_tri16_kernel", e);
+    }
     if (ws->pivot_i8) {
         // the digits are taken about the pivot in force now; the int8 kernels read this copy, not ws->pivot
         e = hipMemcpyAsync(ws->pivot_i8, ws->pivot, (size_t)ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
@@ -1344,13 +1358,16 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool tmeta_was_valid = ws->tmeta_valid;
     ws->tmeta_valid = false;            // (only a lazy sweep that ran to its end leaves the tile state in step with the bounds)
     if (mode == kDense) {
-        rpw = ws->wide ? estep_rows_rows_per_wg() : (i8 ? estep_i8_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64));
+        const bool valu16 = ws->estep_variant == kEstepValu16 && ws->tri != nullptr;
+        rpw = ws->wide ? estep_rows_rows_per_wg()
+                       : (i8 ? estep_i8_rows_per_wg() : (valu16 ? estep_rows16_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64)));
         grid = (n_rows + rpw - 1) / rpw;
         if (grid > (1 << 20)) grid = 1 << 20;
         span_begin(ws, kSpanEstepMain, st);
         e = ws->wide ? launch_estep_rows(ws->T, is64, (int)grid, st, a, &name)
                      : (i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
-                           : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name));
+                           : (valu16 ? launch_estep_rows16(is64, vec, (int)grid, st, a, ws->tri, &name)
+                                     : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name)));
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
         ++ws->passes[0];

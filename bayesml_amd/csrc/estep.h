@@ -228,6 +228,87 @@ __global__ __launch_bounds__(256) void estep_mfma_f64(const XT* __restrict__ x, 
     }
 }
 
+// ---- one feature tile (D <= 16) on the vector ALU (round 4) -------------------------------------------------------------
+// With a single 16 x 16 tile the matrix pipe cannot skip the upper triangle of U_k: estep_mfma_f64 spends 4 MFMAs = 8192
+// flop per 16 rows and component where 2 x 136 multiply-adds are needed, and it runs AT the f64 matrix peak (HMM config 5:
+// 3.1 ms for K = 32, T = 1e7).  The vector ALU has the same f64 peak on gfx950 (one v_fma_f64 per lane every 4 cycles) and
+// takes the triangle as it is: a lane is a row, x_n sits in 16 registers, and every multiplier - U_k[j][i], the bias
+// -(U_k m_k)[j], c_k - is uniform over the wave (scalar loads from a packed lower-triangular image, 160 doubles per
+// component: row j at j (j + 1) / 2, the bias at 136).  152 v_fma_f64 per row and component instead of the MFMAs'
+// 256-equivalent, and 512-byte coalesced stores (a lane per row) instead of 128-byte ones.  Same formulation as the MFMA
+// kernels (y = U x - U m, q = sum y^2); the order of the additions inside a row of U differs from the matrix pipe's, so the
+// values differ from estep_mfma_f64's by rounding (the parity tests hold both to the oracle).
+constexpr int kTriImg = 160;                 // doubles per component of the packed image (136 + 16, padded)
+
+static __global__ void pack_tri16_kernel(const double* __restrict__ u, const double* __restrict__ m, int K, int D,
+                                         double* __restrict__ tri /*[K][kTriImg]*/) {
+    const int k = blockIdx.x;
+    const double* uk = u + (int64_t)k * D * D;
+    const double* mk = m + (int64_t)k * D;
+    double* out = tri + (int64_t)k * kTriImg;
+    for (int e = threadIdx.x; e < kTriImg; e += blockDim.x) {
+        double v = 0.0;
+        if (e < 136) {
+            int j = 0;
+            while ((j + 1) * (j + 2) / 2 <= e) ++j;
+            const int i = e - j * (j + 1) / 2;
+            if (j < D && i < D) v = uk[(int64_t)j * D + i];
+        } else if (e < 152) {
+            const int j = e - 136;
+            double sacc = 0.0;
+            if (j < D)
+                for (int i = 0; i <= j; ++i) sacc = fma(uk[(int64_t)j * D + i], mk[i], sacc);      // (as pack_params_kernel)
+            v = -sacc;
+        }
+        out[e] = v;
+    }
+}
+
+// One row per lane.  What bounds the kernel is the delivery of the multipliers, not the multiply-adds: a uniform multiplier
+// is 8 bytes per v_fma_f64 and SIMD, and the scalar cache hands a CU about 2 bytes per cycle (19 s_load_dwordx16 per
+// component and wave: 6 GB through the scalar caches per pass at HMM config 5) - 2.7 ms where the multiply-adds alone would
+// take 1.3.  Measured and dropped (profiles/r4_experiments.md): several rows per lane (the compiler then requests all of a
+// component's multipliers at its top - 300 SGPRs, spilled to vector lanes and read back with a v_readlane per multiply-add),
+// the same with hand-placed s_load / s_waitcnt (scalar loads return out of order, so one unit of look-ahead is all
+// lgkmcnt(0) allows: 3.5 ms), and multipliers broadcast from LDS (the same 2 useful bytes per cycle).
+template <typename XT, bool VEC>
+__global__ __launch_bounds__(256) void estep_rows16_f64(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
+                                                        const double* __restrict__ tri /*[K][kTriImg]*/,
+                                                        const double* __restrict__ cvec, int K,
+                                                        double* __restrict__ lnrho /*[K][npad]*/, int64_t npad) {
+    const int64_t n_tiles = (n_rows + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t n = tile * 256 + threadIdx.x;
+        const int64_t row = n < n_rows ? n : n_rows - 1;
+        double xr[16];
+        const XT* xp = x + row * ldx;
+        if constexpr (VEC) {
+            typedef XT v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const v4 v = *reinterpret_cast<const v4*>(xp + 4 * b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[4 * b + e] = (double)v[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xr[i] = i < D ? (double)xp[i] : 0.0;
+        }
+        for (int k = 0; k < K; ++k) {
+            const double* __restrict__ t = tri + (int64_t)k * kTriImg;        // uniform: scalar loads
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double y = t[136 + j];
+#pragma unroll
+                for (int i = 0; i <= j; ++i) y = fma(t[j * (j + 1) / 2 + i], xr[i], y);
+                q = fma(y, y, q);
+            }
+            if (n < n_rows) lnrho[(int64_t)k * npad + n] = cvec[k] - 0.5 * q;
+        }
+    }
+}
+
 // ---- LDS-staged variant ----------------------------------------------------------------------
 // NW = 4: one wave per SIMD, 16*NB samples per wave.  NW = 8: two waves per SIMD with half the samples
 // each (same samples per workgroup and per LDS fill), so one wave's epilogue / LDS waits / barrier

@@ -48,6 +48,31 @@ hipError_t launch_estep(int variant, int T, int x_is_f64, bool vec, int grid, hi
     return hipErrorInvalidValue;
 }
 
+// ---- one feature tile on the vector ALU (estep.h: estep_rows16_f64) -----------------------------------------------------
+int estep_tri_image_doubles() { return kTriImg; }
+int estep_rows16_rows_per_wg() { return 256; }
+hipError_t launch_pack_tri16(const double* u, const double* m, int K, int D, double* tri, hipStream_t st) {
+    hipLaunchKernelGGL(pack_tri16_kernel, dim3(K), dim3(64), 0, st, u, m, K, D, tri);
+    return hipGetLastError();
+}
+hipError_t launch_estep_rows16(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a, const double* tri,
+                               const char** name) {
+#define R16(XT, V, NM)                                                                                                    \
+    {                                                                                                                     \
+        *name = NM;                                                                                                       \
+        hipLaunchKernelGGL((estep_rows16_f64<XT, V>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx,  \
+                           a.n_rows, a.D, tri, a.cvec, a.K, a.lnrho, a.npad);                                             \
+        return hipGetLastError();                                                                                         \
+    }
+    if (x_is_f64) {
+        if (vec) R16(double, true, "estep_rows16_f64<x=f64,vec>")
+        R16(double, false, "estep_rows16_f64<x=f64,masked>")
+    }
+    if (vec) R16(float, true, "estep_rows16_f64<x=f32,vec>")
+    R16(float, false, "estep_rows16_f64<x=f32,masked>")
+#undef R16
+}
+
 // ---- pruned E-step -------------------------------------------------------------------------------------------
 // feature tiles from which the pruned E-step is built (D >= 49): the gather kernel is instantiated for T = 4 .. 8
 int estep_bound_blocks(int T) { return T >= 6 ? 3 : (T >= 4 ? 2 : 0); }

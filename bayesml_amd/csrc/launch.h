@@ -17,11 +17,18 @@ struct MstepArgs {
 };
 
 // rows of x handled by one E-step workgroup for (variant, T, dtype); doubles per component parameter image
-enum EstepVariant { kEstepLds = 0, kEstepDirect = 1, kEstepLds8 = 2, kEstepI8 = 3 };
+enum EstepVariant { kEstepLds = 0, kEstepDirect = 1, kEstepLds8 = 2, kEstepI8 = 3, kEstepValu16 = 4 };
 int estep_rows_per_wg(int variant, int T, int x_is_f64);
 int estep_threads(int variant);
 int estep_image_doubles(int T);
 // pruned E-step (estep.h): exact kernel over per-component sample lists; the bounds come from estep_i8.h
+// D <= 16 on the vector ALU (estep.h: estep_rows16_f64): packed lower-triangular images [K][estep_tri_image_doubles()],
+// estep_rows16_rows_per_wg() rows per workgroup (a lane per row, several rows per lane)
+int estep_tri_image_doubles();
+int estep_rows16_rows_per_wg();
+hipError_t launch_pack_tri16(const double* u, const double* m, int K, int D, double* tri, hipStream_t st);
+hipError_t launch_estep_rows16(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a, const double* tri,
+                               const char** name);
 int estep_bound_blocks(int T);                    // 0 = the pruned path is not built for this T (D < 49)
 int estep_gather_rows_per_wg(int T, int x_is_f64);
 // exact f64 evaluation of listed pairs (device lists [K][cap], device counts), chunk plan on the device

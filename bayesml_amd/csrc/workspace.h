@@ -48,6 +48,7 @@ struct gmmvb_workspace {
     double* img = nullptr;     // [K][img_len] parameter images (layout: estep.h)
     int img_len = 0;
     int estep_variant = 0;     // kEstepLds8 (default); env GMMVB_ESTEP_VARIANT=direct|lds4|i8 selects the others
+    double* tri = nullptr;             // [K][estep_tri_image_doubles()] packed lower-triangular images (D <= 16: estep_rows16_f64)
     unsigned char* img_i8 = nullptr;   // [K][img_i8_len] int8-digit parameter images (estep_i8.h), variant kEstepI8 only
     int img_i8_len = 0;
     double* pivot_i8 = nullptr;        // [D] the pivot those images (and the sample digits) are centred on
