@@ -7,6 +7,7 @@
 
 #include "hmm.h"
 #include "hmm_generic.h"
+#include "hmm_wide.h"
 
 #include <cstdlib>
 
@@ -34,8 +35,10 @@ struct gmmvb_hmm_state {
     double* lnc_partial = nullptr;   // [kLncBlocks]
     unsigned char* phi = nullptr; // [npad][Kp] Viterbi back-pointers (allocated on first use by hmmvb_enable)
     int* last_state = nullptr;
-    // more than 64 states: the sequential kernels of hmm_generic.h
+    // more than 64 states: the sequential kernels of hmm_generic.h; 65 .. 128 states and long sequences: the chunk-parallel
+    // kernels of hmm_wide.h for the forward-backward pass (generic stays set: prep, xi-sum, Viterbi are the generic ones)
     bool generic = false;
+    bool wide = false;
     double* a_t = nullptr;        // [K][K] transpose of A~
     unsigned short* phi16 = nullptr;   // [npad][K] back-pointers, natural order
     int64_t bytes = 0;
@@ -139,6 +142,46 @@ hipError_t seq_lds(Kern kern, size_t bytes) {
                              : hipSuccess;
 }
 
+// 65 .. 128 states, long sequences: chunk products / boundary pass / replays of hmm_wide.h between the generic prep and xi-sum
+constexpr int64_t kHmmWideChunk = 256;
+constexpr int64_t kHmmWideMinSteps = 2048;        // (shorter sequences: the sequential kernels - a handful of chunks fills nothing)
+
+template <int KT>
+hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
+                    double* out, hipStream_t st) {
+    const int K = h->K, Kp = h->Kp;
+    const int64_t L = kHmmWideChunk;
+    const int64_t n_chunks = (T - 1 + L - 1) / L;
+    if (n_chunks > h->max_chunks) return hipErrorInvalidValue;
+    const size_t fb = hmm_wide_frag_bytes<KT>();
+    hipError_t e = seq_lds(hmm_chunk_products_wide_kernel<KT>, fb + 64);
+    if (e == hipSuccess) e = seq_lds(hmm_forward_replay_wide_kernel<KT>, fb);
+    if (e == hipSuccess) e = seq_lds(hmm_backward_replay_wide_kernel<KT>, fb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hmm_prep_generic_kernel, dim3((unsigned)((T + 63) / 64)), dim3(256), 0, st, ws->lnrho, ws->npad, T, K, Kp,
+                       h->rho_tm, h->mx);
+    hipLaunchKernelGGL((hmm_chunk_products_wide_kernel<KT>), dim3((unsigned)n_chunks), dim3(256), fb + 64, st, h->rho_tm, a_tilde, K,
+                       T, L, n_chunks, h->prod);
+    hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde, h->prod, K,
+                       n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+    const unsigned grid = (unsigned)((n_chunks + 63) / 64);          // 16 chunks per wave, 4 waves per workgroup
+    hipLaunchKernelGGL((hmm_forward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                       h->fstart, h->alpha_tm, h->cprime);
+    hipLaunchKernelGGL((hmm_backward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                       h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+    const int64_t steps = (T - 1 + h->xi_waves - 1) / h->xi_waves;
+    const int64_t n_slabs = (T - 1 + steps - 1) / steps;
+    hipLaunchKernelGGL(hmm_xi_generic_kernel, dim3((unsigned)n_slabs, (unsigned)((Kp / 16) * (Kp / 16))), dim3(256), 0, st, h->alpha_tm,
+                       h->w_tm, Kp, T, steps, h->xi_slabs);
+    const int n_part = (int)std::min<int64_t>(kLncBlocks, (T + 255) / 256);
+    hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
+    hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
+                       h->lnc_partial, n_part, T, h->gamma_tm, out);
+    h->gamma_cm_valid = false;
+    h->gamma_rows = T;
+    return hipGetLastError();
+}
+
 hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
                        double* out, hipStream_t st) {
     const int K = h->K, Kp = h->Kp;
@@ -188,7 +231,8 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     h->Kp = 16 * h->KT;
     h->npad = ws->npad;
     h->generic = ws->K > 64;                    // (the chunk-parallel kernels hold K x K products in registers)
-    h->max_chunks = h->generic ? 1 : ws->npad / 16 + 2;          // chunk_len >= 16
+    h->wide = ws->K > 64 && ws->K <= 128 && std::getenv("GMMVB_HMM_WIDE_OFF") == nullptr;      // hmm_wide.h (developer switch: off)
+    h->max_chunks = h->wide ? ws->npad / kHmmWideChunk + 2 : (h->generic ? 1 : ws->npad / 16 + 2);          // chunk_len >= 16
     h->xi_waves = h->generic ? std::max<int64_t>(16, std::min<int64_t>(4 * (int64_t)ws->num_cu, (int64_t(1) << 27) / ((int64_t)h->Kp * h->Kp)))
                              : 16 * (int64_t)ws->num_cu;       // four xi-sum waves per SIMD: the kernel streams two [T][Kp] arrays and a wave
                                                                // has one load group in flight (round 4; one wave per SIMD: 1.9 ms, 2.6 TB/s)
@@ -322,6 +366,17 @@ int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
+    if (ws->hmm->wide && n_rows >= kHmmWideMinSteps) {
+        switch (ws->hmm->KT) {
+            case 5: e = run_wide<5>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+            case 6: e = run_wide<6>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+            case 7: e = run_wide<7>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+            default: e = run_wide<8>(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st); break;
+        }
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "HMM forward-backward launch (65 .. 128 states)", e);
+        ws->e_state = 3;
+        return GMMVB_OK;
+    }
     if (ws->hmm->generic) {
         e = run_generic(ws, ws->hmm, n_rows, pi_tilde_dev, a_tilde_dev, out_dev, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "HMM forward-backward launch (generic)", e);

@@ -91,11 +91,16 @@ def test_forward_backward_matches_reference(name):
                                          (33, 6, 777, np.float64), (64, 4, 5000, np.float32), (2, 1, 40000, np.float64),
                                          (8, 4, 300001, np.float32), (33, 3, 270000, np.float64),
                                          (65, 3, 1, np.float64), (70, 3, 900, np.float64), (130, 2, 400, np.float32),
-                                         (150, 2, 300, np.float64)])
+                                         (150, 2, 300, np.float64),
+                                         # 65 .. 128 states over 2048 steps or more: the chunk-parallel kernels of hmm_wide.h
+                                         (70, 3, 5000, np.float64), (96, 2, 2048, np.float32), (81, 2, 2305, np.float64),
+                                         (112, 3, 3000, np.float32), (128, 2, 4100, np.float64)])
 def test_ragged_shapes_against_oracle(K, D, T, dtype):
     """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths - and, past 2^18 steps, the
     two-level boundary pass (chunks of 256 steps, super-chunk products); random posterior.  More than 64 states: the
-    sequential kernels of csrc/hmm_generic.h (transition matrix in LDS up to K = 128, in L2 beyond)."""
+    sequential kernels of csrc/hmm_generic.h (transition matrix in LDS up to K = 128, in L2 beyond) - and for 65 .. 128
+    states over at least 2048 steps the chunk-parallel ones of csrc/hmm_wide.h (5 .. 8 tiles of 16 states, ragged last
+    chunk, ragged last tile)."""
     rng = np.random.default_rng(100 * K + D)
     x, _ = orc.synth_hmm(max(2, K // 2), D, T, dtype, seed=K + T, stay=0.8)
     p = orc.HmmPrior.default(K, D)
