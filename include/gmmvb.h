@@ -41,7 +41,7 @@ extern "C" {
 enum gmmvb_status {
     GMMVB_OK = 0,
     GMMVB_EINVAL = 1,       /* bad argument (null pointer, bad shape, n_rows > max_rows, misaligned x) */
-    GMMVB_EUNSUPPORTED = 2, /* shape outside this version's range (gmmvb_kside_*: D > 128; HMM: K > 64)    */
+    GMMVB_EUNSUPPORTED = 2, /* shape outside this version's range (gmmvb_kside_*: D > 128)                 */
     GMMVB_EHIP = 3,         /* a HIP runtime call failed (see gmmvb_last_error)                       */
     GMMVB_ENOMEM = 4,       /* device allocation failed                                               */
     GMMVB_ESTATE = 5        /* call order violated (e.g. mstep before estep / load_responsibilities)  */
