@@ -27,6 +27,7 @@ struct gmmvb_hmm_state {
     double* mx = nullptr;         // [npad]
     double* cprime = nullptr;     // [npad]
     double* prod = nullptr;       // [max_chunks][Kp][Kp]
+    double* prod_t = nullptr;     // [max_chunks][Kp][Kp] their transposes (65 .. 128 states: the backward boundary pass reads them)
     double* fstart = nullptr;     // [max_chunks][Kp]
     double* bend = nullptr;       // [max_chunks][Kp]
     double* qprod = nullptr;      // [max_chunks / kHmmSuper + 2][Kp][Kp] super-chunk products (two-level boundary pass)
@@ -49,7 +50,7 @@ void hmm_state_destroy(gmmvb_hmm_state* h) {
     if (!h) return;
     double* bufs[] = {h->rho_tm, h->alpha_tm, h->gamma_tm, h->w_tm, h->gamma_cm, h->mx,
                       h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs, h->lnc_partial,
-                      h->qprod,  h->fstart_s, h->bend_s, h->a_t};
+                      h->qprod,  h->fstart_s, h->bend_s, h->a_t, h->prod_t};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (h->phi) (void)hipFree(h->phi);
@@ -161,18 +162,18 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
     hipLaunchKernelGGL(hmm_prep_generic_kernel, dim3((unsigned)((T + 63) / 64)), dim3(256), 0, st, ws->lnrho, ws->npad, T, K, Kp,
                        h->rho_tm, h->mx);
     hipLaunchKernelGGL((hmm_chunk_products_wide_kernel<KT>), dim3((unsigned)n_chunks), dim3(256), fb + 64, st, h->rho_tm, a_tilde, K,
-                       T, L, n_chunks, h->prod);
-    hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde, h->prod, K,
-                       n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+                       T, L, n_chunks, h->prod, h->prod_t);
+    hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde, h->prod,
+                       h->prod_t, K, n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
     const unsigned grid = (unsigned)((n_chunks + 63) / 64);          // 16 chunks per wave, 4 waves per workgroup
     hipLaunchKernelGGL((hmm_forward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
                        h->fstart, h->alpha_tm, h->cprime);
     hipLaunchKernelGGL((hmm_backward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
                        h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
-    const int64_t steps = (T - 1 + h->xi_waves - 1) / h->xi_waves;
+    const int64_t steps = round_up((T - 1 + h->xi_waves - 1) / h->xi_waves, 4);
     const int64_t n_slabs = (T - 1 + steps - 1) / steps;
-    hipLaunchKernelGGL(hmm_xi_generic_kernel, dim3((unsigned)n_slabs, (unsigned)((Kp / 16) * (Kp / 16))), dim3(256), 0, st, h->alpha_tm,
-                       h->w_tm, Kp, T, steps, h->xi_slabs);
+    hipLaunchKernelGGL((hmm_xi_sum_wide_kernel<KT>), dim3((unsigned)n_slabs), dim3(256), 0, st, h->alpha_tm, h->w_tm, T, steps,
+                       h->xi_slabs);
     const int n_part = (int)std::min<int64_t>(kLncBlocks, (T + 255) / 256);
     hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
     hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
@@ -244,7 +245,8 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, (h->xi_waves + 4) * h->Kp * h->Kp},
         {&h->lnc_partial, kLncBlocks},
         {&h->qprod, (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp}, {&h->fstart_s, (h->max_chunks / kHmmSuper + 2) * h->Kp},
-        {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0}};
+        {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0},
+        {&h->prod_t, h->wide ? h->max_chunks * h->Kp * h->Kp : 0}};
     for (auto& b : bufs) {
         if (b.n == 0) continue;
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));

@@ -9,7 +9,7 @@
 //   * a chunk's transfer product spread over the four waves of a workgroup by column blocks of P^T (they are independent:
 //     P^T <- diag(rho'_t) A~^T P^T acts on every column alone; only the rescaling needs the workgroup's common maximum),
 // the same kernels run for KT = 5 .. 8 tiles of 16 states.  The boundary pass is a sequential pass over the chunk products
-// (a row-vector x matrix per chunk, 1024 threads); the state arrays, the xi-sum (hmm_xi_generic_kernel), the read-outs and
+// (a row-vector x matrix per chunk, 1024 threads); the xi-sum is split over a workgroup's waves by row tiles; the state arrays, the read-outs and
 // everything behind them are the ones of the other paths.  Cost: T 2 Kp^3 flop of chunk products on the f64 matrix pipe
 // (0.6 s at K = 128, T = 1e7), everything else is small beside it.
 #pragma once
@@ -59,7 +59,8 @@ template <int KT>
 __global__ __launch_bounds__(256) void hmm_chunk_products_wide_kernel(const double* __restrict__ rho_tm,
                                                                       const double* __restrict__ a_tilde, int K, int64_t T,
                                                                       int64_t L, int64_t n_chunks,
-                                                                      double* __restrict__ prod /*[n_chunks][Kp][Kp]*/) {
+                                                                      double* __restrict__ prod /*[n_chunks][Kp][Kp]*/,
+                                                                      double* __restrict__ prod_t /*the transposes*/) {
     constexpr int Kp = 16 * KT, JPW = (KT + 3) / 4;
     extern __shared__ double frag[];                      // fragments, then [2][4] maxima
     double* smax = frag + KT * KT * 4 * 64;
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(256) void hmm_chunk_products_wide_kernel(const doub
                     for (int r = 0; r < 4; ++r) pt[jj][it][r] *= sc;
         }
     }
+    // P (row = column index of P^T) for the forward pass of the boundary scan, P^T for the backward one: either reads its
+    // operand with the state on consecutive threads
     double* out = prod + c * Kp * Kp;
+    double* out_t = prod_t + c * Kp * Kp;
 #pragma unroll
     for (int jj = 0; jj < JPW; ++jj) {
         const int jt = wave * JPW + jj;
@@ -122,7 +126,10 @@ __global__ __launch_bounds__(256) void hmm_chunk_products_wide_kernel(const doub
 #pragma unroll
         for (int it = 0; it < KT; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(16 * jt + j) * Kp + 16 * it + g + 4 * r] = pt[jj][it][r];
+            for (int r = 0; r < 4; ++r) {
+                out[(16 * jt + j) * Kp + 16 * it + g + 4 * r] = pt[jj][it][r];
+                out_t[(16 * it + g + 4 * r) * Kp + 16 * jt + j] = pt[jj][it][r];
+            }
     }
 }
 
@@ -132,8 +139,8 @@ __global__ __launch_bounds__(256) void hmm_chunk_products_wide_kernel(const doub
 constexpr int kHmmWideScanThreads = 1024;
 template <int KT>
 __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_kernel(
-    const double* __restrict__ rho_tm, const double* __restrict__ pi_tilde, const double* __restrict__ prod, int K,
-    int64_t n_chunks, double* __restrict__ fstart, double* __restrict__ bend, double* __restrict__ cprime,
+    const double* __restrict__ rho_tm, const double* __restrict__ pi_tilde, const double* __restrict__ prod,
+    const double* __restrict__ prod_t, int K, int64_t n_chunks, double* __restrict__ fstart, double* __restrict__ bend, double* __restrict__ cprime,
     double* __restrict__ alpha_tm, double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
     constexpr int Kp = 16 * KT, PARTS = kHmmWideScanThreads / 128, JP = Kp / PARTS;      // JP contraction indices per thread
     static_assert(Kp <= 128 && Kp % PARTS == 0, "up to 128 states");
@@ -183,14 +190,16 @@ __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_ke
         if (tid < Kp && n_chunks > 0) bend[(n_chunks - 1) * Kp + tid] = v;
     }
     if (n_chunks < 2) return;
-    // entries of a chunk product this thread multiplies: forward P[jj][i] (column i), backward P[i][jj] (row i), jj in its part
+    // entries of a chunk product this thread multiplies: forward P[jj][i] (column i), backward P[i][jj] = P^T[jj][i] (row i),
+    // jj in its part - consecutive threads read consecutive addresses either way (a first form read P[i][jj] from the one
+    // array: 11 us per chunk)
     double cur[JP], nxt[JP];
     auto fetch = [&](int64_t c, double (&dst)[JP]) {
-        const double* P = prod + c * Kp * Kp;
+        const double* P = (fwd ? prod : prod_t) + c * Kp * Kp;
 #pragma unroll
         for (int q = 0; q < JP; ++q) {
             const int jj = p * JP + q;
-            dst[q] = i < Kp ? (fwd ? P[jj * Kp + i] : P[i * Kp + jj]) : 0.0;
+            dst[q] = i < Kp ? P[jj * Kp + i] : 0.0;
         }
     };
     if (fwd) fetch(0, nxt);
@@ -363,6 +372,58 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_wide_kernel(const dou
             *reinterpret_cast<d4*>(gamma_tm + 16 * it + 4 * g) = gm;
             *reinterpret_cast<d4*>(w_tm + 16 * it + 4 * g) = d4{0.0, 0.0, 0.0, 0.0};      // xi_0 = 0
         }
+    }
+}
+
+// H6 wide: raw[pi][pj] = sum_t alpha_tm[t-1][pi] w_tm[t][pj] (hmm.h: hmm_xi_sum_kernel), one slab per WORKGROUP: wave w
+// accumulates the row tiles it = w RPW .. of the K x K sum over the workgroup's stretch of time steps
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_xi_sum_wide_kernel(const double* __restrict__ alpha_tm, const double* __restrict__ w_tm,
+                                                              int64_t T, int64_t steps_per_wg, double* __restrict__ slabs) {
+    constexpr int Kp = 16 * KT, RPW = (KT + 3) / 4;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t lo = 1 + (int64_t)blockIdx.x * steps_per_wg;
+    int64_t hi = lo + steps_per_wg;
+    if (hi > T) hi = T;
+    d4 acc[RPW][KT];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt) acc[rr][jt] = d4{0.0, 0.0, 0.0, 0.0};
+    double an[RPW], bn[KT];
+    auto fetch = [&](int64_t t) {
+        const int64_t tt = t + g;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int it = wave * RPW + rr;
+            an[rr] = (tt < hi && it < KT) ? alpha_tm[(tt - 1) * Kp + 16 * it + i] : 0.0;
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) bn[kt] = tt < hi ? w_tm[tt * Kp + 16 * kt + i] : 0.0;
+    };
+    fetch(lo);
+    for (int64_t t = lo; t < hi; t += 4) {
+        double a[RPW], b[KT];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) a[rr] = an[rr];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) b[kt] = bn[kt];
+        fetch(t + 4);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) acc[rr][jt] = mfma_f64(a[rr], b[jt], acc[rr][jt]);
+    }
+    double* out = slabs + (int64_t)blockIdx.x * Kp * Kp;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int it = wave * RPW + rr;
+        if (it >= KT) continue;
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * it + g + 4 * r) * Kp + 16 * jt + i] = acc[rr][jt][r];
     }
 }
 
