@@ -721,8 +721,8 @@ __global__ __launch_bounds__(64) void hmm_viterbi_forward_kernel(const double* _
 __global__ __launch_bounds__(256) void hmm_viterbi_backtrack_kernel(const unsigned char* __restrict__ phi, int Kp,
                                                                     int64_t T, const int* __restrict__ last_state,
                                                                     int32_t* __restrict__ z) {
-    constexpr int BLK = 512;
-    __shared__ unsigned char tile[BLK * 64];
+    __shared__ unsigned char tile[512 * 64];
+    const int BLK = 512 * 64 / Kp;             // chunks per LDS block (Kp <= 128)
     __shared__ int cur;
     if (threadIdx.x == 0) {
         cur = *last_state;
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64) void hmm_vit_replay_kernel(const double* __rest
 }
 
 // map[c][j] = state at the chunk's start time (t0 - 1) of the survivor path that is in state j at its last time (t1 - 1)
-__global__ __launch_bounds__(64) void hmm_vit_backmap_kernel(const unsigned char* __restrict__ phi, int Kp, int64_t T, int64_t L,
+__global__ __launch_bounds__(128) void hmm_vit_backmap_kernel(const unsigned char* __restrict__ phi, int Kp, int64_t T, int64_t L,
                                                              unsigned char* __restrict__ map /*[chunks][Kp]*/) {
     const int j = threadIdx.x;
     const int64_t c = blockIdx.x;
@@ -924,8 +924,8 @@ __global__ __launch_bounds__(64) void hmm_vit_backmap_kernel(const unsigned char
 // endst[c] = state of the best path at the last time of chunk c; sequential over the chunks' maps (LDS-staged blocks)
 __global__ __launch_bounds__(256) void hmm_vit_backscan_kernel(const unsigned char* __restrict__ map, int Kp, int64_t chunks,
                                                                const int* __restrict__ last_state, int* __restrict__ endst) {
-    constexpr int BLK = 512;
-    __shared__ unsigned char tile[BLK * 64];
+    __shared__ unsigned char tile[512 * 64];
+    const int BLK = 512 * 64 / Kp;             // chunks per LDS block (Kp <= 128)
     __shared__ int cur;
     if (threadIdx.x == 0) cur = *last_state;
     __syncthreads();

@@ -28,6 +28,7 @@ struct gmmvb_hmm_state {
     double* cprime = nullptr;     // [npad]
     double* prod = nullptr;       // [max_chunks][Kp][Kp]
     double* prod_t = nullptr;     // [max_chunks][Kp][Kp] their transposes (65 .. 128 states: the backward boundary pass reads them)
+    double* qprod_t = nullptr;    // [max_chunks / kHmmSuper + 2][Kp][Kp] transposes of the super-chunk products (65 .. 128 states)
     double* fstart = nullptr;     // [max_chunks][Kp]
     double* bend = nullptr;       // [max_chunks][Kp]
     double* qprod = nullptr;      // [max_chunks / kHmmSuper + 2][Kp][Kp] super-chunk products (two-level boundary pass)
@@ -50,7 +51,7 @@ void hmm_state_destroy(gmmvb_hmm_state* h) {
     if (!h) return;
     double* bufs[] = {h->rho_tm, h->alpha_tm, h->gamma_tm, h->w_tm, h->gamma_cm, h->mx,
                       h->cprime, h->prod,     h->fstart,   h->bend, h->xi_slabs, h->lnc_partial,
-                      h->qprod,  h->fstart_s, h->bend_s, h->a_t, h->prod_t};
+                      h->qprod,  h->fstart_s, h->bend_s, h->a_t, h->prod_t, h->qprod_t};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (h->phi) (void)hipFree(h->phi);
@@ -163,8 +164,24 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
                        h->rho_tm, h->mx);
     hipLaunchKernelGGL((hmm_chunk_products_wide_kernel<KT>), dim3((unsigned)n_chunks), dim3(256), fb + 64, st, h->rho_tm, a_tilde, K,
                        T, L, n_chunks, h->prod, h->prod_t);
-    hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde, h->prod,
-                       h->prod_t, K, n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+    if (n_chunks > 2 * kHmmSuper) {
+        // two levels: products of 64 chunk products, the sequential pass over those, every super-chunk fills in its own chunks
+        const int64_t n_super = (n_chunks + kHmmSuper - 1) / kHmmSuper;
+        e = seq_lds(hmm_super_products_wide_kernel<KT>, fb + 64);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hmm_super_products_wide_kernel<KT>), dim3((unsigned)n_super), dim3(256), fb + 64, st, h->prod_t, n_chunks,
+                           h->qprod, h->qprod_t);
+        hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(1, 2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde,
+                           h->qprod, h->qprod_t, K, n_super, nullptr, nullptr, h->fstart_s, h->bend_s, h->cprime, h->alpha_tm,
+                           h->gamma_tm, h->w_tm);
+        hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3((unsigned)n_super, 2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm,
+                           pi_tilde, h->prod, h->prod_t, K, n_chunks, h->fstart_s, h->bend_s, h->fstart, h->bend, h->cprime,
+                           h->alpha_tm, h->gamma_tm, h->w_tm);
+    } else {
+        hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(1, 2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde,
+                           h->prod, h->prod_t, K, n_chunks, nullptr, nullptr, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm,
+                           h->w_tm);
+    }
     const unsigned grid = (unsigned)((n_chunks + 63) / 64);          // 16 chunks per wave, 4 waves per workgroup
     hipLaunchKernelGGL((hmm_forward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
                        h->fstart, h->alpha_tm, h->cprime);
@@ -246,7 +263,8 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         {&h->lnc_partial, kLncBlocks},
         {&h->qprod, (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp}, {&h->fstart_s, (h->max_chunks / kHmmSuper + 2) * h->Kp},
         {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0},
-        {&h->prod_t, h->wide ? h->max_chunks * h->Kp * h->Kp : 0}};
+        {&h->prod_t, h->wide ? h->max_chunks * h->Kp * h->Kp : 0},
+        {&h->qprod_t, h->wide ? (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp : 0}};
     for (auto& b : bufs) {
         if (b.n == 0) continue;
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
@@ -258,6 +276,10 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     }
     hipError_t e2 = h->generic ? hipMalloc((void**)&h->phi16, (size_t)(h->npad * ws->K) * sizeof(unsigned short))
                                : hipMalloc((void**)&h->phi, (size_t)(h->npad * h->Kp));
+    if (e2 == hipSuccess && h->wide) {          // (65 .. 128 states: byte back-pointers of the chunked Viterbi pass)
+        e2 = hipMalloc((void**)&h->phi, (size_t)(h->npad * h->Kp));
+        h->bytes += h->npad * h->Kp;
+    }
     if (e2 == hipSuccess) e2 = hipMalloc((void**)&h->last_state, sizeof(int));
     if (e2 != hipSuccess) {
         hmm_state_destroy(h);
@@ -277,6 +299,45 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     gmmvb_hmm_state* h = ws->hmm;
     hipStream_t st = (hipStream_t)stream;
+    if (h->wide && h->phi && n_rows >= kHmmWideMinSteps) {
+        // 65 .. 128 states: the chunked max-plus pass with two end states per lane and ln a~ in LDS (hmm_wide.h); scratch as below
+        const int64_t L = kHmmWideChunk;
+        const int64_t chunks = (n_rows - 1 + L - 1) / L;
+        double* M = h->prod;
+        double* wstart = h->fstart;
+        unsigned char* map = reinterpret_cast<unsigned char*>(h->bend);
+        int* endst = reinterpret_cast<int*>(h->fstart_s);
+        if (chunks > h->max_chunks || chunks * (int64_t)sizeof(int) > (h->max_chunks / kHmmSuper + 2) * h->Kp * (int64_t)sizeof(double))
+            return fail(GMMVB_ESTATE, "Viterbi scratch too small for this sequence");
+        const size_t lds = (size_t)h->Kp * h->Kp * sizeof(double);
+        hipError_t ew = hipSuccess;
+#define VITW(KTT)                                                                                                              \
+    ew = seq_lds(hmm_vit_chunk_wide_kernel<KTT>, lds);                                                                         \
+    if (ew == hipSuccess) ew = seq_lds(hmm_vit_replay_wide_kernel<KTT>, lds);                                                  \
+    if (ew == hipSuccess) {                                                                                                    \
+        hipLaunchKernelGGL((hmm_vit_chunk_wide_kernel<KTT>), dim3((unsigned)chunks, (unsigned)((h->K + 4 * kVitWideWaves - 1) / (4 * kVitWideWaves))), dim3(64 * kVitWideWaves), lds, st, \
+                           ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M);                                           \
+        hipLaunchKernelGGL((hmm_vit_scan_wide_kernel<KTT>), dim3(1), dim3(kHmmWideScanThreads), 0, st, ws->lnrho, ws->npad,     \
+                           ln_pi_tilde_dev, M, h->K, chunks, wstart);                                                          \
+        hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3((unsigned)((chunks + kVitWideWaves - 1) / kVitWideWaves)), dim3(64 * kVitWideWaves), lds, st, ws->lnrho, \
+                           ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state);                  \
+    }
+        switch (h->KT) {
+            case 5: VITW(5) break;
+            case 6: VITW(6) break;
+            case 7: VITW(7) break;
+            default: VITW(8) break;
+        }
+#undef VITW
+        if (ew != hipSuccess) return fail(GMMVB_EHIP, "chunked viterbi (65 .. 128 states: LDS size)", ew);
+        hipLaunchKernelGGL(hmm_vit_backmap_kernel, dim3((unsigned)chunks), dim3(128), 0, st, h->phi, h->Kp, n_rows, L, map);
+        hipLaunchKernelGGL(hmm_vit_backscan_kernel, dim3(1), dim3(256), 0, st, map, h->Kp, chunks, h->last_state, endst);
+        hipLaunchKernelGGL(hmm_vit_fill_kernel, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, st, h->phi, h->Kp, n_rows, L,
+                           chunks, endst, z_dev);
+        ew = hipGetLastError();
+        if (ew != hipSuccess) return fail(GMMVB_EHIP, "chunked viterbi launch (65 .. 128 states)", ew);
+        return GMMVB_OK;
+    }
     if (h->generic) {
         const HmmSeqShape sh = hmm_seq_shape(h->K);
         hipError_t eg = seq_lds(hmm_seq_viterbi_kernel, sh.lds_bytes);

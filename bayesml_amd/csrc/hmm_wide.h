@@ -8,8 +8,8 @@
 //     (fragment f = (it KT + kt) 4 + s, lane l: M[16 it + (l & 15)][16 kt + (l >> 4) + 4 s]; 128 KB at K = 128), and
 //   * a chunk's transfer product spread over the four waves of a workgroup by column blocks of P^T (they are independent:
 //     P^T <- diag(rho'_t) A~^T P^T acts on every column alone; only the rescaling needs the workgroup's common maximum),
-// the same kernels run for KT = 5 .. 8 tiles of 16 states.  The boundary pass is a sequential pass over the chunk products
-// (a row-vector x matrix per chunk, 1024 threads); the xi-sum is split over a workgroup's waves by row tiles; the state arrays, the read-outs and
+// the same kernels run for KT = 5 .. 8 tiles of 16 states.  The boundary pass is a sequential pass over chunk products (a
+// row-vector x matrix per chunk, 1024 threads) - over the products of 64 chunks each first, when there are many; the xi-sum is split over a workgroup's waves by row tiles; the state arrays, the read-outs and
 // everything behind them are the ones of the other paths.  Cost: T 2 Kp^3 flop of chunk products on the f64 matrix pipe
 // (0.6 s at K = 128, T = 1e7), everything else is small beside it.
 #pragma once
@@ -133,14 +133,88 @@ __global__ __launch_bounds__(256) void hmm_chunk_products_wide_kernel(const doub
     }
 }
 
-// H3 wide: the sequential pass over the chunk products.  Workgroup 0 forward (fstart[c + 1] ~ fstart[c] P_c), workgroup 1
-// backward (bend[c - 1] ~ P_c bend[c]); 1024 threads = (state i, eighth p of the contraction index), the next chunk's
-// entries requested while the current ones are reduced.  Natural state order, like hmm_boundary_scan_kernel.
+// H3a wide: Q_s = product of the (up to) kHmmSuper chunk products of super-chunk s, as Q_s and Q_s^T - the chunk-products
+// kernel with the step's operand changing: R^T <- P_c^T R^T, the fragments of P_c^T restaged into LDS for every chunk.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_super_products_wide_kernel(const double* __restrict__ prod_t, int64_t n_chunks,
+                                                                      double* __restrict__ qprod, double* __restrict__ qprod_t) {
+    constexpr int Kp = 16 * KT, JPW = (KT + 3) / 4;
+    extern __shared__ double frag[];
+    double* smax = frag + KT * KT * 4 * 64;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t sblk = blockIdx.x;
+    const int64_t c0 = sblk * kHmmSuper;
+    const int64_t c1 = c0 + kHmmSuper < n_chunks ? c0 + kHmmSuper : n_chunks;
+    d4 pt[JPW][KT];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj)
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[jj][it][r] = (it == wave * JPW + jj && (g + 4 * r) == j) ? 1.0 : 0.0;
+    int par = 0;
+    for (int64_t c = c0; c < c1; ++c) {
+        __syncthreads();                                  // everybody is done with the previous chunk's fragments
+        fill_frags<KT>(prod_t + c * Kp * Kp, Kp, /*transpose=*/false, frag);      // M = P_c^T
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            if (wave * JPW + jj >= KT) continue;
+            d4 nw[KT];
+            apply_lds<KT>(frag, pt[jj], nw);
+#pragma unroll
+            for (int it = 0; it < KT; ++it) pt[jj][it] = nw[it];
+        }
+        double m = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj)
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmax(m, pt[jj][it][r]);
+        m = max_wave(m);
+        if (lane == 0) smax[par * 4 + wave] = m;
+        __syncthreads();
+        m = fmax(fmax(smax[par * 4], smax[par * 4 + 1]), fmax(smax[par * 4 + 2], smax[par * 4 + 3]));
+        par ^= 1;
+        const double sc = m > 0.0 ? 1.0 / m : 1.0;
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj)
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[jj][it][r] *= sc;
+    }
+    double* out = qprod + sblk * Kp * Kp;
+    double* out_t = qprod_t + sblk * Kp * Kp;
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const int jt = wave * JPW + jj;
+        if (jt >= KT) continue;
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[(16 * jt + j) * Kp + 16 * it + g + 4 * r] = pt[jj][it][r];
+                out_t[(16 * it + g + 4 * r) * Kp + 16 * jt + j] = pt[jj][it][r];
+            }
+    }
+}
+
+// H3 wide: the sequential pass over chunk products.  blockIdx.y = 0 forward (fstart[c + 1] ~ fstart[c] P_c), 1 backward
+// (bend[c - 1] ~ P_c bend[c]); 1024 threads = (state i, eighth p of the contraction index), the next product's entries
+// requested while the current ones are reduced.  Natural state order, like hmm_boundary_scan_kernel.
+//   in_f == nullptr: the whole sequence of n_chunks products in one workgroup per direction (grid (1, 2)); the forward
+//                    start vector is alpha_0 (made here, with c'_0), the backward one uniform;
+//   in_f != nullptr: workgroup blockIdx.x fills in the chunks of ITS super-chunk (kHmmSuper products) from the super-chunk's
+//                    start / end vector in_f[x] / in_b[x] - the second level of a two-level pass whose first level is this
+//                    same kernel over the super-chunk products (hmm_super_products_wide_kernel).
 constexpr int kHmmWideScanThreads = 1024;
 template <int KT>
 __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_kernel(
     const double* __restrict__ rho_tm, const double* __restrict__ pi_tilde, const double* __restrict__ prod,
-    const double* __restrict__ prod_t, int K, int64_t n_chunks, double* __restrict__ fstart, double* __restrict__ bend, double* __restrict__ cprime,
+    const double* __restrict__ prod_t, int K, int64_t n_chunks, const double* __restrict__ in_f, const double* __restrict__ in_b,
+    double* __restrict__ fstart, double* __restrict__ bend, double* __restrict__ cprime,
     double* __restrict__ alpha_tm, double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
     constexpr int Kp = 16 * KT, PARTS = kHmmWideScanThreads / 128, JP = Kp / PARTS;      // JP contraction indices per thread
     static_assert(Kp <= 128 && Kp % PARTS == 0, "up to 128 states");
@@ -148,7 +222,10 @@ __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_ke
     __shared__ double spart[PARTS][128];
     __shared__ double sred[2];
     const int tid = threadIdx.x, i = tid & 127, p = tid >> 7;
-    const bool fwd = blockIdx.x == 0;
+    const bool fwd = blockIdx.y == 0;
+    const bool fill = in_f != nullptr;
+    const int64_t c_lo = fill ? (int64_t)blockIdx.x * kHmmSuper : 0;
+    const int64_t c_hi = fill ? (c_lo + kHmmSuper < n_chunks ? c_lo + kHmmSuper : n_chunks) : n_chunks;
     auto normalise = [&](double v) -> double {          // threads tid < 128 hold v_i; everybody gets v_i / sum (for i = tid & 127)
         __syncthreads();
         if (tid < 128) sv[tid] = v;
@@ -162,7 +239,13 @@ __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_ke
         return tot > 0.0 ? sv[i] / tot : 0.0;
     };
     double v;
-    if (fwd) {
+    if (fill) {
+        v = i < Kp ? (fwd ? in_f : in_b)[(int64_t)blockIdx.x * Kp + i] : 0.0;
+        if (tid < Kp) {
+            if (fwd) fstart[c_lo * Kp + tid] = v;
+            else bend[(c_hi - 1) * Kp + tid] = v;
+        }
+    } else if (fwd) {
         double a0 = (tid < K) ? rho_tm[hmm_pos(tid)] * pi_tilde[tid] : 0.0;
         if (tid >= 128) a0 = 0.0;
         __syncthreads();
@@ -189,7 +272,7 @@ __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_ke
         v = i < K ? 1.0 / K : 0.0;
         if (tid < Kp && n_chunks > 0) bend[(n_chunks - 1) * Kp + tid] = v;
     }
-    if (n_chunks < 2) return;
+    if (c_hi - c_lo < 2) return;
     // entries of a chunk product this thread multiplies: forward P[jj][i] (column i), backward P[i][jj] = P^T[jj][i] (row i),
     // jj in its part - consecutive threads read consecutive addresses either way (a first form read P[i][jj] from the one
     // array: 11 us per chunk)
@@ -202,11 +285,11 @@ __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_ke
             dst[q] = i < Kp ? P[jj * Kp + i] : 0.0;
         }
     };
-    if (fwd) fetch(0, nxt);
-    else fetch(n_chunks - 1, nxt);
-    const int64_t steps = n_chunks - 1;
+    if (fwd) fetch(c_lo, nxt);
+    else fetch(c_hi - 1, nxt);
+    const int64_t steps = c_hi - c_lo - 1;
     for (int64_t s = 0; s < steps; ++s) {
-        const int64_t c = fwd ? s : n_chunks - 1 - s;            // the product applied in this step
+        const int64_t c = fwd ? c_lo + s : c_hi - 1 - s;          // the product applied in this step
 #pragma unroll
         for (int q = 0; q < JP; ++q) cur[q] = nxt[q];
         if (s + 1 < steps) fetch(fwd ? c + 1 : c - 1, nxt);
@@ -424,6 +507,210 @@ __global__ __launch_bounds__(256) void hmm_xi_sum_wide_kernel(const double* __re
         for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(16 * it + g + 4 * r) * Kp + 16 * jt + i] = acc[rr][jt][r];
+    }
+}
+
+// ---- chunked Viterbi for 65 .. 128 states (hmm.h: hmm_vit_*) ------------------------------------------------------------------
+// The lane is the END state - two of them per lane, j and j + 64 - and ln a~ sits in LDS (row i contiguous over j); a wave
+// carries FOUR start states at once, so every pair of LDS reads feeds eight add / max pairs.
+constexpr int kVitWideStarts = 4;          // start states per wave
+__device__ __forceinline__ double readlane_f64(double v, int l) {          // l uniform
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(__double_as_longlong(v) & 0xffffffffll), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// M_c[i0][j] = best score of reaching j at the chunk's end from i0 at its start.  grid = (chunks, ceil(K / 32)), 8 waves (two
+// per SIMD: the 128 KB of ln a~ allow one workgroup per CU, and a single wave per SIMD waits for every LDS read).
+constexpr int kVitWideWaves = 8;
+template <int KT>
+__global__ __launch_bounds__(64 * kVitWideWaves) void hmm_vit_chunk_wide_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                                 const double* __restrict__ ln_a_tilde, int K, int64_t T, int64_t L,
+                                                                 double* __restrict__ M /*[chunks][Kp][Kp]*/) {
+    constexpr int Kp = 16 * KT, SB = kVitWideStarts;
+    extern __shared__ double a_lds[];                  // [Kp][Kp]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double NEG = -1.0e300;
+    for (int e = threadIdx.x; e < Kp * Kp; e += 64 * kVitWideWaves) {
+        const int i = e / Kp, j = e - i * Kp;
+        a_lds[e] = (i < K && j < K) ? ln_a_tilde[i * K + j] : NEG;
+    }
+    __syncthreads();
+    const int64_t c = blockIdx.x;
+    const int i00 = ((int)blockIdx.y * kVitWideWaves + wave) * SB;        // this wave's first start state
+    if (i00 >= K) return;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const int j0 = lane, j1 = lane + 64;
+    const double* lr0 = lnrho + (int64_t)(j0 < K ? j0 : 0) * npad;
+    const double* lr1 = lnrho + (int64_t)(j1 < K ? j1 : 0) * npad;
+    double v0[SB], v1[SB];
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        v0[sb] = (j0 == i00 + sb) ? 0.0 : NEG;
+        v1[sb] = (j1 == i00 + sb) ? 0.0 : NEG;
+    }
+    for (int64_t tb = t0; tb < t1; tb += 8) {
+        double e0[8], e1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            e0[u] = (tb + u < t1) ? lr0[tb + u] : 0.0;
+            e1[u] = (tb + u < t1) ? lr1[tb + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (tb + u >= t1) break;
+            double b0[SB], b1[SB];
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) b0[sb] = b1[sb] = NEG * 2.0;
+#pragma unroll 8
+            for (int i = 0; i < Kp; ++i) {
+                const double a0 = a_lds[i * Kp + j0];
+                const double a1 = Kp > 64 ? a_lds[i * Kp + (j1 < Kp ? j1 : 0)] : NEG;
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    const double w = i < 64 ? readlane_f64(v0[sb], i) : readlane_f64(v1[sb], i - 64);
+                    const double s0 = w + a0, s1 = w + a1;
+                    b0[sb] = s0 > b0[sb] ? s0 : b0[sb];
+                    b1[sb] = s1 > b1[sb] ? s1 : b1[sb];
+                }
+            }
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                v0[sb] = j0 < K ? e0[u] + b0[sb] : NEG;
+                v1[sb] = j1 < K ? e1[u] + b1[sb] : NEG;
+            }
+        }
+    }
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        const int i0 = i00 + sb;
+        if (i0 >= Kp) break;
+        double* row = M + ((int64_t)c * Kp + i0) * Kp;
+        row[j0] = i0 < K ? v0[sb] : NEG;
+        if (j1 < Kp) row[j1] = i0 < K ? v1[sb] : NEG;
+    }
+}
+
+// wstart[c] = omega at the start of chunk c: omega_{c+1} = omega_c (x) M_c, one workgroup, 1024 threads = (end state j,
+// eighth p of the start states); the next chunk's entries requested while the current ones are reduced
+template <int KT>
+__global__ __launch_bounds__(kHmmWideScanThreads) void hmm_vit_scan_wide_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                                                const double* __restrict__ ln_pi_tilde,
+                                                                                const double* __restrict__ M, int K, int64_t chunks,
+                                                                                double* __restrict__ wstart /*[chunks][Kp]*/) {
+    constexpr int Kp = 16 * KT, PARTS = kHmmWideScanThreads / 128, IP = Kp / PARTS;
+    __shared__ double sw[128];
+    __shared__ double spart[PARTS][128];
+    const int tid = threadIdx.x, j = tid & 127, p = tid >> 7;
+    const double NEG = -1.0e300;
+    double w = (j < K) ? lnrho[(int64_t)j * npad] + ln_pi_tilde[j] : NEG;
+    double cur[IP], nxt[IP];
+    auto fetch = [&](int64_t c, double (&dst)[IP]) {
+        const double* P = M + c * Kp * Kp;
+#pragma unroll
+        for (int q = 0; q < IP; ++q) dst[q] = (j < Kp && p * IP + q < K) ? P[(p * IP + q) * Kp + j] : NEG;      // (rows >= K are not written)
+    };
+    if (chunks > 0) fetch(0, nxt);
+    for (int64_t c = 0; c < chunks; ++c) {
+        if (tid < Kp) wstart[c * Kp + tid] = w;
+#pragma unroll
+        for (int q = 0; q < IP; ++q) cur[q] = nxt[q];
+        if (c + 1 < chunks) fetch(c + 1, nxt);
+        __syncthreads();
+        if (tid < 128) sw[tid] = w;
+        __syncthreads();
+        double best = NEG * 2.0;
+#pragma unroll
+        for (int q = 0; q < IP; ++q) {
+            const int i = p * IP + q;
+            const double s = (i < K ? sw[i] : NEG) + cur[q];
+            best = s > best ? s : best;
+        }
+        spart[p][j] = best;
+        __syncthreads();
+        double b = spart[0][j];
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q) b = spart[q][j] > b ? spart[q][j] : b;
+        w = j < K ? b : NEG;
+    }
+}
+
+// per chunk: the reference's recursion from the known start vector, back-pointers phi[t][Kp] (first maximiser).  Eight waves
+// = eight chunks share ln a~ in LDS; lane = end states j and j + 64.
+template <int KT>
+__global__ __launch_bounds__(64 * kVitWideWaves) void hmm_vit_replay_wide_kernel(const double* __restrict__ lnrho, int64_t npad,
+                                                                  const double* __restrict__ ln_a_tilde,
+                                                                  const double* __restrict__ wstart, int K, int64_t T, int64_t L,
+                                                                  int64_t chunks, unsigned char* __restrict__ phi /*[T][Kp]*/,
+                                                                  int* __restrict__ last_state) {
+    constexpr int Kp = 16 * KT;
+    extern __shared__ double a_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double NEG = -1.0e300;
+    for (int e = threadIdx.x; e < Kp * Kp; e += 64 * kVitWideWaves) {
+        const int i = e / Kp, j = e - i * Kp;
+        a_lds[e] = (i < K && j < K) ? ln_a_tilde[i * K + j] : NEG;
+    }
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * kVitWideWaves + wave;
+    if (c >= chunks) return;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const int j0 = lane, j1 = lane + 64;
+    const double* lr0 = lnrho + (int64_t)(j0 < K ? j0 : 0) * npad;
+    const double* lr1 = lnrho + (int64_t)(j1 < K ? j1 : 0) * npad;
+    double om0 = j0 < K ? wstart[c * Kp + j0] : NEG;
+    double om1 = j1 < K ? wstart[c * Kp + j1] : NEG;
+    for (int64_t tb = t0; tb < t1; tb += 8) {
+        double e0[8], e1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            e0[u] = (tb + u < t1) ? lr0[tb + u] : 0.0;
+            e1[u] = (tb + u < t1) ? lr1[tb + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (tb + u >= t1) break;
+            double b0 = NEG * 2.0, b1 = NEG * 2.0;
+            int g0 = 0, g1 = 0;
+#pragma unroll 4
+            for (int i = 0; i < Kp; ++i) {
+                const double w = i < 64 ? readlane_f64(om0, i) : readlane_f64(om1, i - 64);
+                const double s0 = w + a_lds[i * Kp + j0];
+                const double s1 = w + a_lds[i * Kp + (j1 < Kp ? j1 : 0)];
+                if (s0 > b0) {           // strict: first maximiser, like numpy.argmax
+                    b0 = s0;
+                    g0 = i;
+                }
+                if (s1 > b1) {
+                    b1 = s1;
+                    g1 = i;
+                }
+            }
+            om0 = j0 < K ? e0[u] + b0 : NEG;
+            om1 = j1 < K ? e1[u] + b1 : NEG;
+            phi[(tb + u) * Kp + j0] = (unsigned char)g0;
+            if (j1 < Kp) phi[(tb + u) * Kp + j1] = (unsigned char)g1;
+        }
+    }
+    if (c == chunks - 1) {               // first maximiser of omega_{T-1}
+        double best = om0;
+        int arg = j0;
+        if (om1 > best) {
+            best = om1;
+            arg = j1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o);
+            const int oa = __shfl_xor(arg, o);
+            if (ob > best || (ob == best && oa < arg)) {
+                best = ob;
+                arg = oa;
+            }
+        }
+        if (lane == 0) *last_state = arg;
     }
 }
 

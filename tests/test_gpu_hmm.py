@@ -94,7 +94,9 @@ def test_forward_backward_matches_reference(name):
                                          (150, 2, 300, np.float64),
                                          # 65 .. 128 states over 2048 steps or more: the chunk-parallel kernels of hmm_wide.h
                                          (70, 3, 5000, np.float64), (96, 2, 2048, np.float32), (81, 2, 2305, np.float64),
-                                         (112, 3, 3000, np.float32), (128, 2, 4100, np.float64)])
+                                         (112, 3, 3000, np.float32), (128, 2, 4100, np.float64),
+                                         # ... and past 128 chunks of 256 steps their two-level boundary pass
+                                         (70, 2, 40000, np.float64), (128, 2, 33500, np.float32)])
 def test_ragged_shapes_against_oracle(K, D, T, dtype):
     """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths - and, past 2^18 steps, the
     two-level boundary pass (chunks of 256 steps, super-chunk products); random posterior.  More than 64 states: the
@@ -191,7 +193,10 @@ def test_full_driver_matches_reference(name):
 
 # T < 512: the single sequential wave; 512 <= T < 65536: the chunked max-plus scan with chunks of 32 steps; beyond: 256
 @pytest.mark.parametrize("K,D,T", [(5, 3, 1), (12, 4, 511), (12, 4, 700), (40, 2, 3000), (64, 2, 1537), (32, 16, 200001),
-                                   (66, 2, 1), (72, 2, 800), (140, 2, 500)])
+                                   (66, 2, 1), (72, 2, 800), (140, 2, 500),
+                                   # 65 .. 128 states over 2048 steps or more: the chunked pass of hmm_wide.h (two end states per
+                                   # lane, four start states per wave, ragged last chunk / tile)
+                                   (72, 2, 2048), (100, 3, 5001), (128, 2, 2700), (81, 2, 20000)])
 def test_viterbi_kernel_against_oracle(K, D, T):
     from bayesml_amd import hiddenmarkovnormal as hmm
     x, _ = orc.synth_hmm(max(2, K // 2), D, T, np.float64, seed=7 * K + T)
