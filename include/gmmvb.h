@@ -73,7 +73,7 @@ int64_t gmmvb_workspace_bytes(const gmmvb_workspace* ws);
  * M-step's slabs: two thirds of a workspace's bytes) and keeping everything it carries from one VB iteration to the next
  * (f32 bounds, records, digit planes, settled rows, row order, policy counters) of its own.  This is how a matrix whose
  * [N, K] arrays do not fit one GPU (reference `_gaussianmixture.py:835-836` keeps them in host RAM) runs with carried
- * bounds: N = 1e8, K = 256 in eight tiles is 245 GB instead of 550.  Use: per tile gmmvb_prepare_rows once, then per VB
+ * bounds: N = 1e8, K = 256 in eight tiles is 219 GB instead of 550.  Use: per tile gmmvb_prepare_rows once, then per VB
  * iteration gmmvb_set_params (and gmmvb_set_drift) on every tile and gmmvb_estep_mstep tile after tile, adding up the
  * statistics blocks.  The shared buffers hold ONE tile's E-step output at a time: a call that writes them on another
  * tile (gmmvb_estep, gmmvb_load_responsibilities, gmmvb_prepare_rows) takes them over, after which the previous tile's
