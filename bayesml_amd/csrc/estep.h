@@ -135,13 +135,13 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB
 template <int NB, typename XT, int JB, int J1, int BOFF, typename ImgPtr>
 __device__ __forceinline__ bool estep_component_exit(ImgPtr im, const XT (&xr)[NB][JB][4], double ck, int lane, int g,
                                                      const int64_t (&rows)[NB], double* __restrict__ lnrho_k,
-                                                     const float* __restrict__ thr, float margin) {
+                                                     const float (&thv)[NB] /*thr[row] of the tile's rows*/, float margin) {
     static_assert(J1 >= 1 && J1 < JB, "the way out lies strictly inside the block loop");
     constexpr int P = BOFF / 256;
     typedef double d2 __attribute__((ext_vector_type(2)));
     float th[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) th[nb] = rows[nb] >= 0 ? thr[rows[nb]] - margin : __builtin_huge_valf();
+    for (int nb = 0; nb < NB; ++nb) th[nb] = rows[nb] >= 0 ? thv[nb] - margin : __builtin_huge_valf();
     d4 acc[JB][NB];
 #pragma unroll
     for (int jt = 0; jt < JB; ++jt) {
@@ -433,10 +433,12 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
         const int* list = lists + (int64_t)k * cap;
         const double ck = cvec[k];
         double* out = lnrho + (int64_t)k * npad;
-        for (int t = 0; t < kGatherTiles; ++t) {
+        // Software pipeline over the chunk's tiles (round 4): while tile t is computed, the rows of tile t + 1 are in flight
+        // (second register set) and the list entries of tile t + 2 have been requested - before, a wave's list -> rows -> MFMA
+        // chain was serial and only the other waves of the SIMD covered it.  Every iteration issues the same loads (tiles
+        // past the list's end repeat its last entry and skip the arithmetic), so the compiler's in-order vmcnt stays exact.
+        auto rows_of = [&](int t, int64_t (&ld)[NB], int64_t (&stv)[NB]) {
             const int64_t e0 = chunk0 + ((int64_t)t * NW + wave) * 16 * NB;
-            if (e0 >= count) break;
-            int64_t ld[NB], stv[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int64_t e = e0 + 16 * nb + n;
@@ -444,15 +446,46 @@ __global__ __launch_bounds__(512) void estep_gather_dev_f64(const XT* __restrict
                 ld[nb] = row;
                 stv[nb] = e < count ? row : -1;
             }
-            XT xr[NB][T][4];
-            load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld, g, xr);
+        };
+        auto live = [&](int t) { return chunk0 + ((int64_t)t * NW + wave) * 16 * NB < count; };
+        auto thr_of = [&](const int64_t (&ld)[NB], float (&tv)[NB]) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) tv[nb] = EXIT ? thr[ld[nb]] : 0.0f;
+        };
+        auto compute = [&](int t, const XT (&xr)[NB][T][4], const int64_t (&stv)[NB], const float (&tv)[NB]) {
+            if (!live(t)) return;                      // (wave-uniform)
             if constexpr (EXIT) {
-                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, thr, exit_margin)) {
-                    const int64_t left = count - e0;
+                if (estep_component_exit<NB, XT, T, T / 2, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out, tv, exit_margin)) {
+                    const int64_t left = count - (chunk0 + ((int64_t)t * NW + wave) * 16 * NB);
                     my_exits += (unsigned long long)(left < 16 * NB ? left : 16 * NB);
                 }
             } else
                 estep_component<NB, XT, T, tri_pairs(T) * 256>(smem, xr, ck, lane, g, stv, out);
+        };
+        static_assert(kGatherTiles % 2 == 0, "the tile loop is unrolled by two register sets");
+        int64_t ld0[NB], st0[NB], ld1[NB], st1[NB], ld2[NB], st2[NB], ld3[NB], st3[NB];
+        XT xa[NB][T][4], xb[NB][T][4];
+        float ta[NB], tb[NB];
+        rows_of(0, ld0, st0);
+        rows_of(1, ld1, st1);
+        load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld0, g, xa);
+        thr_of(ld0, ta);
+        for (int t = 0; t < kGatherTiles; t += 2) {
+            rows_of(t + 2, ld2, st2);
+            load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld1, g, xb);
+            thr_of(ld1, tb);
+            compute(t, xa, st0, ta);
+            rows_of(t + 3, ld3, st3);
+            load_x_tile<T, NB, XT, VEC>(x, ldx, D, ld2, g, xa);
+            thr_of(ld2, ta);
+            compute(t + 1, xb, st1, tb);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                ld0[nb] = ld2[nb];
+                st0[nb] = st2[nb];
+                ld1[nb] = ld3[nb];
+                st1[nb] = st3[nb];
+            }
         }
     }
     // one atomic per wave (an integer counter: order-free; one per exit would serialise 5e5 of them on one address)
