@@ -512,6 +512,11 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
     static_assert(CW == 8, "four waves x CW components = one 32-state slice of a gamma row");
     constexpr int LD = 33;                                  // padded row: lane stride 33 doubles, conflict-free
     __shared__ double sg[2][64 * LD];
+    // (round 4) the batch's 64 rows of x go through LDS too, a batch ahead like gamma: the four waves share them, and the
+    // MFMA operand of step st is the lane-linear read sx[64 st + lane].  Before, every wave loaded its operand from global
+    // memory one step (eight MFMAs, 0.2 us) ahead - far less than a memory round trip, and the kernel ran at 48 % of what
+    // its MFMAs need.  The batch's ln rho values (h = sum gamma ln rho) are requested a batch ahead as well.
+    __shared__ double sx[2][64 * 16];
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
@@ -539,9 +544,12 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
             stage[q + 1] = ok ? v[1] : 0.0;
         }
     };
+    d4 xstage = {0.0, 0.0, 0.0, 0.0};
+    auto request_x = [&](int64_t c0) { xstage = *reinterpret_cast<const d4*>(xc + c0 * 16 + tid * 4); };      // (zero rows past n_rows: no clamp)
     auto deposit = [&](int b) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) sg[b][srow * LD + 8 * sq + q] = stage[q];
+        *reinterpret_cast<d4*>(&sx[b][tid * 4]) = xstage;
     };
     int pc[CW];                                             // position of component k0 + c inside the slice
 #pragma unroll
@@ -553,14 +561,29 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
         acc[c] = d4{0.0, 0.0, 0.0, 0.0};
         asum[c] = nsum[c] = hsum[c] = 0.0;
     }
+    double aux_n[CW];                                       // ln rho of the NEXT batch's row of this lane (clamped address)
+    auto request_aux = [&](int64_t c0) {
+        const int64_t nl = c0 + lane < hi ? c0 + lane : hi - 1;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) aux_n[c] = aux[(int64_t)(k0 + c < K ? k0 + c : 0) * npad + nl];
+    };
     request(lo);
+    request_x(lo);
+    request_aux(lo);
     deposit(0);
     __syncthreads();
-    double xn = xc[(lo + g) * 16 + i];
     int b = 0;
     for (int64_t c0 = lo; c0 < hi; c0 += 64, b ^= 1) {
-        if (c0 + 64 < hi) request(c0 + 64);                 // in flight while this batch is worked through
+        double aux_c[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) aux_c[c] = aux_n[c];
+        if (c0 + 64 < hi) {                                 // in flight while this batch is worked through
+            request(c0 + 64);
+            request_x(c0 + 64);
+            request_aux(c0 + 64);
+        }
         const double* sb = sg[b];
+        const double* xb = sx[b];
         const int64_t nl = c0 + lane;
         if (k0 < K) {
 #pragma unroll
@@ -568,14 +591,13 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
                 const int k = k0 + c;
                 if (k < K && nl < hi) {
                     const double v = sb[lane * LD + pc[c]];
-                    if (v > 0.0) hsum[c] = fma(v, aux[(int64_t)k * npad + nl], hsum[c]);
+                    if (v > 0.0) hsum[c] = fma(v, aux_c[c], hsum[c]);
                     nsum[c] += v;
                 }
             }
 #pragma unroll 4
             for (int st = 0; st < 16; ++st) {
-                const double xq = xn;
-                xn = xc[(c0 + 4 * (st + 1) + g) * 16 + i];          // (zero rows up to npad + 64: no clamp)
+                const double xq = xb[64 * st + lane];
 #pragma unroll
                 for (int c = 0; c < CW; ++c) {
                     const double ra = (k0 + c < K ? sb[(4 * st + g) * LD + pc[c]] : 0.0) * xq;
