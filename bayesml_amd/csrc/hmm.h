@@ -254,7 +254,14 @@ __global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __
 // replay workgroups).  With two levels the chunks are short (256 steps: 39063 chunks, 610 replay workgroups), the
 // products of kHmmSuper consecutive chunks are multiplied up in parallel (H3a), the sequential pass runs over the 611
 // super-chunk products (H3 itself), and every super-chunk then fills in its own chunks' start / end vectors (H3b).
-constexpr int kHmmSuper = 64;
+#ifndef GMMVB_HMM_SUPER
+#define GMMVB_HMM_SUPER 64
+#endif
+#ifndef GMMVB_HMM_LONG_CHUNK
+#define GMMVB_HMM_LONG_CHUNK 256
+#endif
+constexpr int kHmmSuper = GMMVB_HMM_SUPER;
+constexpr int kHmmLongChunk = GMMVB_HMM_LONG_CHUNK;      // chunk length of sequences past 2^18 steps (two-level boundary pass)
 
 // H3a: Q_s = P_{sG} P_{sG+1} ... (G = kHmmSuper chunks), rescaled to max 1 after every product.  One workgroup per s.
 template <int KT>

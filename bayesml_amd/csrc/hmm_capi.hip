@@ -81,7 +81,7 @@ constexpr int kLncBlocks = 1024;
 // (L steps of ~4 us forward+backward): L ~ sqrt(T * 1.5 / 4), a power of two in [16, 4096]
 // Long sequences (more than 2^18 steps): chunks of 256 steps and a two-level boundary pass (hmm.h, H3a / H3b).
 int64_t chunk_len(int64_t T, bool one_level) {
-    if (T > (int64_t(1) << 18) && !one_level) return 256;
+    if (T > (int64_t(1) << 18) && !one_level) return kHmmLongChunk;
     int64_t L = 16;
     while (L < 4096 && 8 * L * L < 3 * T) L *= 2;
     return L;
@@ -99,7 +99,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     if (n_chunks > 0)
         hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
                            h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod);
-    const bool two_level = T > (int64_t(1) << 18) && L == 256 && n_chunks > 2 * kHmmSuper;
+    const bool two_level = T > (int64_t(1) << 18) && L == kHmmLongChunk && n_chunks > 2 * kHmmSuper;
     if (two_level) {
         const int64_t n_super = (n_chunks + kHmmSuper - 1) / kHmmSuper;
         hipLaunchKernelGGL((hmm_super_products_kernel<KT>), dim3((unsigned)n_super), dim3(256), 0, st, h->prod, n_chunks, h->qprod);
