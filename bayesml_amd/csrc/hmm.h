@@ -371,7 +371,11 @@ __global__ __launch_bounds__(128) void hmm_boundary_fill_kernel(const double* __
     }
 }
 
-// H4: forward replay.  One wave = 16 chunks (MFMA columns).  alpha_tm / rho_tm in lane order.
+#ifndef GMMVB_REPLAY_CHUNKS
+#define GMMVB_REPLAY_CHUNKS 16
+#endif
+constexpr int kReplayChunks = GMMVB_REPLAY_CHUNKS;      // chunks per replay wave (8 or 16)
+// H4: forward replay.  One wave = kReplayChunks chunks (MFMA columns).  alpha_tm / rho_tm in lane order.
 template <int KT>
 __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* __restrict__ rho_tm,
                                                                  const double* __restrict__ a_tilde, int K, int64_t T,
@@ -380,8 +384,12 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
                                                                  double* __restrict__ alpha_tm, double* __restrict__ cprime) {
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + j;
+    // kReplayChunks chunks per wave: with fewer than 16 the MFMA columns j and j + kReplayChunks carry the same chunk (only
+    // the first copy stores).  Measured with 8 (twice as many waves for these chains of dependent steps): 24.7 / 25.0 ms per
+    // iteration against 24.4 / 24.9 with 16 - no gain, 16 it stays (round 4)
+    const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kReplayChunks + (j % kReplayChunks);
     const bool live = c < n_chunks;
+    const bool first_copy = j < kReplayChunks;
     double aop[KT][KT][4];
     load_aop<KT>(a_tilde, K, /*transpose=*/true, K, aop);      // alpha^T_new = A~^T alpha^T_old
     d4 al[KT];
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
     for (int64_t s = 0; s < L; ++s) {
         const int64_t t = t0 + s;
         const bool on = live && t < T;
+        const bool st = on && first_copy;
         d4 nw[KT];
         apply<KT>(aop, al, nw);
         double part = 0.0;
@@ -416,9 +425,9 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
         for (int it = 0; it < KT; ++it) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) al[it][r] = nw[it][r] * inv;
-            if (on) *reinterpret_cast<d4*>(alpha_tm + t * Kp + 16 * it + 4 * g) = al[it];
+            if (st) *reinterpret_cast<d4*>(alpha_tm + t * Kp + 16 * it + 4 * g) = al[it];
         }
-        if (on && g == 0) cprime[t] = cp;
+        if (st && g == 0) cprime[t] = cp;
     }
 }
 
@@ -433,8 +442,9 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* 
                                                                   double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + j;
+    const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kReplayChunks + (j % kReplayChunks);
     const bool live = c < n_chunks;
+    const bool first_copy = j < kReplayChunks;
     double aop[KT][KT][4];
     load_aop<KT>(a_tilde, K, /*transpose=*/false, K, aop);     // beta_{t-1} ~ A~ (rho'_t o beta_t)
     d4 be[KT];
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* 
                 gm[r] = al[it][r] * be[it][r] * ginv;
                 ww[r] = y[it][r] * winv;
             }
-            if (on) {
+            if (on && first_copy) {
                 *reinterpret_cast<d4*>(gamma_tm + t * Kp + 16 * it + 4 * g) = gm;
                 *reinterpret_cast<d4*>(w_tm + t * Kp + 16 * it + 4 * g) = ww;
             }

@@ -112,7 +112,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
                            n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
     }
     if (n_chunks > 0) {
-        const unsigned grid = (unsigned)((n_chunks + 63) / 64);      // 16 chunks per wave, 4 waves per block
+        const unsigned grid = (unsigned)((n_chunks + 4 * kReplayChunks - 1) / (4 * kReplayChunks));      // kReplayChunks chunks per wave, 4 waves per block
         hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
                            n_chunks, h->fstart, h->alpha_tm, h->cprime);
         hipLaunchKernelGGL((hmm_backward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
