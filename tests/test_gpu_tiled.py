@@ -109,6 +109,22 @@ def test_tiled_readout_after_loaded_responsibilities():
             assert float((a - b).abs().max() / a.abs().max()) < 1e-12
 
 
+def test_resident_tiles_f64_rows_forced_sparse():
+    """f64 rows: the list M-step reads the centred copy, which resident tiles share - after another tile's turn it is rebuilt
+    from the tile's own (regrouped) rows."""
+    from bayesml_amd._engine import TiledDataPass
+    K, D, N = 12, 64, 100_000
+    x = orc.synth_gmm(K, D, N, np.float64)
+    one = _fit(x, K, D, 0, "subsampling", True)
+    til = _fit(x, K, D, 30016, "subsampling", True, True)
+    assert isinstance(til._engine, TiledDataPass) and til._engine.resident
+    c = til._engine.pass_counts()
+    assert c["estep_sweep"] >= 4 and c["mstep_list"] >= 4, c
+    for key in ("hn_alpha_vec", "hn_m_vecs", "hn_kappas", "hn_nus", "hn_w_mats"):
+        assert rel_err(til.get_hn_params()[key], one.get_hn_params()[key]) < 1e-9, key
+    assert abs(til.vl - one.vl) < 1e-10 * abs(one.vl)
+
+
 def test_resident_tiles_under_the_default_policy():
     """Tiles large enough for the default policy to prune (K x tile rows >= 2^23): every tile runs bound passes and sweeps
     of its own carried bounds, and the fit equals the untiled one."""
