@@ -309,3 +309,150 @@ def test_pred_and_update_and_latent_update_paths():
     assert np.allclose(m.h0_m_vecs, m.h0_m_vecs) and m.hn_kappas.sum() > m.h0_kappas.sum() - 1e-9
     z = quiet(m.estimate_latent_vars_and_update, x[201:260], num_init=1, max_itr=5)
     assert z.shape == (59, 3) and np.all(z.sum(axis=1) == 1)
+
+
+# ---- row tiles (bayesml_amd/_engine.py: TiledDataPass) without a GPU: the bookkeeping around the per-tile workspaces -------
+class _FakeTile:
+    """Stands in for _engine.DataPass: statistics = [sum of the rows' first column, row count, parameter tag]."""
+    PASS_NAMES = ("estep_dense", "estep_bound", "estep_carried", "estep_fell_back_dense", "estep_sweep", "mstep_dense",
+                  "mstep_list", "estep_gather")
+    made = []
+
+    def __init__(self, K, D, x_dtype, max_rows, device=None, tile_of=None):
+        self.K, self.D, self.x_dtype, self.max_rows, self.device = K, D, x_dtype, max_rows, torch.device("cpu")
+        self.tile_of, self.lib, self.stats_len = tile_of, None, 3
+        self.closed, self.params, self.pivot, self.prepared, self.held, self.esteps, self.drift = False, None, None, None, None, 0, None
+        self.shard, self.rows = None, 0
+        _FakeTile.made.append(self)
+
+    workspace_bytes = property(lambda self: 1000 if self.tile_of is None else 300)
+    launch_info = property(lambda self: "estep_sweep_bounds | mstep_list")
+    regroup_count = property(lambda self: 1)
+
+    def close(self):
+        self.closed = True
+
+    def _stats_out(self, out):
+        return out if out is not None else torch.zeros(3, dtype=torch.float64)
+
+    def set_pivot(self, p):
+        self.pivot = torch.as_tensor(p)
+
+    def prepare_rows(self, x):
+        self.prepared = x
+
+    def set_params(self, c, m, u):
+        self.params = float(c)
+
+    def wants_drift(self, n):
+        return True
+
+    def set_drift(self, *a, **k):
+        self.drift = a
+
+    def forget(self):
+        pass
+
+    def set_shard(self, rows, ranks):
+        self.shard = (rows, ranks)
+
+    def policy_export(self, tail):
+        tail.fill_(1.0)
+
+    def policy_import(self, tail):
+        self.imported = tail.clone()
+
+    def estep(self, x):
+        self.held, self.rows = x, x.shape[0]
+        self.esteps += 1
+
+    def estep_mstep(self, x, out=None):
+        self.estep(x)
+        out.copy_(torch.tensor([float(x[:, 0].sum()), float(x.shape[0]), self.params], dtype=torch.float64))
+        return out
+
+    def load_responsibilities(self, r):
+        self.held, self.rows = ("r", r), r.shape[0]
+
+    def mstep(self, x, out=None):
+        out.copy_(torch.tensor([float(self.held[1].sum()), float(x.shape[0]), -1.0], dtype=torch.float64))
+        return out
+
+    def pass_counts(self):
+        return dict(zip(self.PASS_NAMES, [0, 0, 0, 0, self.esteps, 0, self.esteps, 0]))
+
+    def profile(self, on=True):
+        pass
+
+    def sparsity(self):
+        return float(self.rows), 2.0 * self.rows
+
+    def work(self):
+        return dict(active=float(self.rows), evaluated=2.0 * self.rows, accumulated=0.5 * self.rows, settled_rows=0.25 * self.rows,
+                    early_exits=0.0, proof_pairs=3.0 * self.rows, sweep_share=0.5)
+
+    def last_kernel_ms(self):
+        return 1.0, 0.5
+
+    def kernel_spans(self):
+        return {"estep_select": (0.25, 2)}
+
+    def responsibilities(self, row0, n):
+        assert not isinstance(self.held, tuple)
+        return self.held[row0:row0 + n, :self.K].to(torch.float64)
+
+    def split_stats(self, s):
+        return s
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_row_tiles_host_logic(monkeypatch, resident):
+    from bayesml_amd import _engine
+    monkeypatch.setattr(_engine, "DataPass", _FakeTile)
+    _FakeTile.made = []
+    K, D, N = 2, 3, 1000
+    x = torch.arange(N * D, dtype=torch.float32).reshape(N, D)
+    eng = _engine.TiledDataPass(K, D, torch.float32, N, "cpu", 300, resident=resident)
+    tiles = _FakeTile.made
+    assert eng.n_tiles == 4 and len(tiles) == (4 if resident else 1)
+    if resident:            # further tiles share the first one's pass-local buffers and are sized for their own rows
+        assert all(t.tile_of is tiles[0] for t in tiles[1:]) and [t.max_rows for t in tiles] == [300, 300, 300, 100]
+        assert eng.workspace_bytes == 1000 + 3 * 300
+        assert eng.wants_drift(N)
+    else:
+        assert tiles[0].shard == (N, 4) and not eng.wants_drift(N)        # one workspace: the tiles decide from job-wide sums
+    eng.set_pivot(torch.zeros(D, dtype=torch.float64))
+    eng.prepare_rows(x)
+    if resident:
+        assert [t.prepared.shape[0] for t in tiles] == [300, 300, 300, 100]
+    eng.set_params(torch.tensor(7.0), None, None)
+    eng.set_drift(1, 2, 3)
+    assert all((t.drift == (1, 2, 3)) == resident for t in tiles)
+    eng.profile(True)
+    stats = eng.estep_mstep(x)
+    assert float(stats[0]) == float(x[:, 0].sum()) and float(stats[1]) == N and float(stats[2]) == 4 * 7.0
+    wk = eng.work()                           # summed over the tiles (resident: read back after the pass)
+    assert wk["active"] == N and wk["evaluated"] == 2 * N and wk["proof_pairs"] == 3 * N and wk["settled_rows"] == 0.25 * N
+    assert eng.sparsity() == (float(N), 2.0 * N)
+    assert eng.last_kernel_ms() == (4.0, 2.0) and eng.kernel_spans() == {"estep_select": (1.0, 8)}
+    assert eng.pass_counts()["estep_sweep"] == 4
+    # read-outs: the last tile's E-step output is what the buffers hold; any other tile is evaluated again
+    before = [t.esteps for t in tiles]
+    r = eng.responsibilities(290, 20)          # rows 290..309: tiles 0 and 1
+    assert r.shape == (20, K) and torch.equal(r[:, 0], x[290:310, 0].to(torch.float64))
+    after = [t.esteps for t in tiles]
+    assert sum(after) - sum(before) == 2
+    # a sharded job: the tiles of all ranks share one policy, the tail is the sum over this rank's tiles
+    eng.set_shard(5 * N, 5)
+    assert all(t.shard == (5 * N, 20) for t in tiles)
+    eng.estep_mstep(x)
+    tail = torch.zeros(_engine.POLICY_LEN, dtype=torch.float64)
+    eng.policy_export(tail)
+    assert float(tail[0]) == 4.0
+    # loaded responsibilities go tile by tile too
+    rr = torch.ones(N, K, dtype=torch.float64)
+    eng.load_responsibilities(rr)
+    st = eng.mstep(x)
+    assert float(st[0]) == N * K and float(st[1]) == N
+    eng.close()
+    assert all(t.closed for t in tiles)
