@@ -6,9 +6,16 @@ namespace gmmvb {
 
 // u [K][D][D] lower triangular (y = u d)  ->  per-component parameter image (layout: estep.h)
 //   [P][half][lane][2] tiles of u (zero padded to 16T) | [T][g][r] bias = -(u m) | zero pad to 1 KB
+// (also copies c -> cvec and, if asked, the pivot the int8 images are packed about: two device-to-device copies less per
+// parameter hand-over, each of which was a dispatch on the iteration's critical path)
 __global__ void pack_params_kernel(const double* __restrict__ u, const double* __restrict__ m, int K, int D,
-                                   int T, int img_len, double* __restrict__ img) {
+                                   int T, int img_len, double* __restrict__ img, const double* __restrict__ c_src = nullptr,
+                                   double* __restrict__ c_dst = nullptr, const double* __restrict__ pivot_src = nullptr,
+                                   double* __restrict__ pivot_dst = nullptr) {
     const int k = blockIdx.x;
+    if (c_dst && threadIdx.x == 0) c_dst[k] = c_src[k];
+    if (pivot_dst && k == 0)
+        for (int f = threadIdx.x; f < D; f += blockDim.x) pivot_dst[f] = pivot_src[f];
     const int P = tri_pairs(T);
     const double* uk = u + (int64_t)k * D * D;
     double* im = img + (int64_t)k * img_len;

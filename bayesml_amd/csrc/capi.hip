@@ -470,18 +470,30 @@ int gmmvb_wants_drift(const gmmvb_workspace* ws, int64_t n_rows) {
     return (ws->prune == 2 || n_rows * (int64_t)ws->K >= (int64_t(1) << 23)) ? 1 : 0;
 }
 
+namespace {
+// drift[0..K) = gamma, [K..2K) = delta, [2K..3K) = c of the parameters the records belong to, [3K..4K) = Gamma - one launch
+// instead of four device-to-device copies (each a dispatch of its own on the iteration's critical path)
+__global__ void set_drift_kernel(const double* __restrict__ gamma, const double* __restrict__ delta, const double* __restrict__ big_gamma,
+                                 const double* __restrict__ cvec, int K, double* __restrict__ drift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    drift[k] = gamma[k];
+    drift[K + k] = delta[k];
+    drift[2 * K + k] = cvec[k];
+    drift[3 * K + k] = big_gamma[k];
+}
+}  // namespace
+
 int gmmvb_set_drift(gmmvb_workspace* ws, const double* gamma_dev, const double* delta_dev, const double* big_gamma_dev,
                     double typical_gamma, void* stream) {
     if (!ws || !gamma_dev || !delta_dev || !big_gamma_dev) return fail(GMMVB_EINVAL, "null argument");
     ws->typical_gamma = typical_gamma;
     hipStream_t st = (hipStream_t)stream;
-    const size_t kb = (size_t)ws->K * sizeof(double);
-    hipError_t e = hipMemcpyAsync(ws->drift, gamma_dev, kb, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + ws->K, delta_dev, kb, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + 3 * ws->K, big_gamma_dev, kb, hipMemcpyDeviceToDevice, st);
-    // the constants of the parameters the records belong to (the next gmmvb_set_params overwrites cvec)
-    if (e == hipSuccess) e = hipMemcpyAsync(ws->drift + 2 * ws->K, ws->cvec, kb, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(drift)", e);
+    // (with the constants of the parameters the records belong to: the next gmmvb_set_params overwrites cvec)
+    hipLaunchKernelGGL(set_drift_kernel, dim3((unsigned)((ws->K + 255) / 256)), dim3(256), 0, st, gamma_dev, delta_dev, big_gamma_dev,
+                       ws->cvec, ws->K, ws->drift);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "set_drift_kernel", e);
     ws->have_drift = ws->have_params && ws->params_used;     // else: not the parameters the records belong to
     return GMMVB_OK;
 }
@@ -584,9 +596,10 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
                      void* stream) {
     if (!ws || !c_dev || !m_dev || !u_dev) return fail(GMMVB_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemcpyAsync(ws->cvec, c_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(c)", e);
+    hipError_t e = hipSuccess;
     if (ws->generic) {
+        e = hipMemcpyAsync(ws->cvec, c_dev, (size_t)ws->K * sizeof(double), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "hipMemcpyAsync(c)", e);
         e = hipMemcpyAsync(ws->gen_m, m_dev, (size_t)ws->K * ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess)
             e = hipMemcpyAsync(ws->gen_u, u_dev, (size_t)ws->K * ws->D * ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
@@ -595,8 +608,10 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
         ws->params_used = false;
         return GMMVB_OK;
     }
+    // (c and the int8 images' pivot ride along: the digits are taken about the pivot in force now; the int8 kernels read that
+    // copy, not ws->pivot)
     hipLaunchKernelGGL(pack_params_kernel, dim3(ws->K), dim3(256), 0, st, u_dev, m_dev, ws->K, ws->D, ws->T,
-                       ws->img_len, ws->img);
+                       ws->img_len, ws->img, c_dev, ws->cvec, ws->pivot_i8 ? ws->pivot : nullptr, ws->pivot_i8);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_kernel", e);
     if (ws->tri) {
@@ -604,9 +619,7 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
         if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_tri16_kernel", e);
     }
     if (ws->pivot_i8) {
-        // the digits are taken about the pivot in force now; the int8 kernels read this copy, not ws->pivot
-        e = hipMemcpyAsync(ws->pivot_i8, ws->pivot, (size_t)ws->D * sizeof(double), hipMemcpyDeviceToDevice, st);
-        if (e == hipSuccess && ws->img_i8) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8, 0, st);
+        if (ws->img_i8) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8, 0, st);
         if (e == hipSuccess && ws->img_i8b) e = launch_pack_i8(u_dev, m_dev, ws->pivot_i8, ws->K, ws->D, ws->img_i8b, 1, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_i8_kernel", e);
         ws->img_gen = ws->pivot_gen;
