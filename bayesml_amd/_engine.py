@@ -68,6 +68,8 @@ SYMBOLS = {
     "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "hmmvb_debug_readout": (_int, [_vp, _int, _i64, _i64, _vp, _vp]),
     "hmmvb_readout": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp]),
+    "hmmvb_emission_target": (_int, [_vp, _int, _vp]),
+    "hmmvb_skip_h": (_int, [_vp, _int]),
     "hmmvb_viterbi": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "gmmvb_profile_enable": (_int, [_vp, _int]),
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
@@ -296,6 +298,7 @@ class DataPass:
                                                      self.max_rows, ctypes.byref(handle))
         _check(self.lib, rc, "gmmvb_workspace_create_tile" if tile_of is not None else "gmmvb_workspace_create")
         self._ws = handle
+        self.emission_fused = False       # (HMM) see emission_target
         self._keep = []      # tensors whose memory an enqueued kernel may still read
 
     # -- lifetime
@@ -498,6 +501,21 @@ class DataPass:
     def enable_hmm(self):
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.hmmvb_enable(self._ws), "hmmvb_enable")
+
+    def hmm_skip_h(self, skip: bool = True):
+        """hmmvb_skip_h: the statistics of the HMM passes carry h = 0 (the caller takes sum gamma ln rho from the moments,
+        ``_kside.sum_gamma_ln_rho``) and the M-step does not read the ln rho array."""
+        _check(self.lib, self.lib.hmmvb_skip_h(self._ws, 1 if skip else 0), "hmmvb_skip_h")
+
+    def emission_target(self, fused: bool) -> bool:
+        """hmmvb_emission_target: ``fused`` asks the following ``estep`` calls to write rho' straight into the
+        forward-backward buffers (no ln rho array: ``viterbi`` / ``ln_rho`` need a pass with ``fused=False``, and the
+        statistics' h block is 0).  Returns whether the library does so for this shape."""
+        eff = ctypes.c_int(0)
+        _check(self.lib, self.lib.hmmvb_emission_target(self._ws, 1 if fused else 0, ctypes.byref(eff)),
+               "hmmvb_emission_target")
+        self.emission_fused = bool(eff.value)
+        return self.emission_fused
 
     def forward_backward(self, pi_tilde, a_tilde):
         """(ms [K, K], gamma_0 [K], gamma_last [K], sum ln c) of the pass over the rows of the last estep;

@@ -319,6 +319,20 @@ def hmm_update_q(p: HmmPriorT, ns, ms, x_bar, s) -> HmmPostT:
     return hmm_features(HmmPostT(p.eta + ns, p.zeta + ms, m, kappa, p.nu + ns, w_inv))
 
 
+def sum_gamma_ln_rho(q, ns, x_bar, s) -> torch.Tensor:
+    """sum_tk gamma_tk ln rho_tk (first term of -E[ln q(Z)], _hiddenmarkovnormal.py:905) from the pass's moments instead of
+    the N x K arrays: ln rho_tk = c_k - (x_t - m_k)^T nu_k W_k (x_t - m_k) / 2 (ref:989-996, ``q`` = the parameters the
+    emission was evaluated under), so the gamma-weighted sum over t is
+    ns_k (c_k - ((s_k o nu_k W_k).sum() + (x_bar_k - m_k)^T nu_k W_k (x_bar_k - m_k)) / 2) - the expression the reference
+    uses for E[ln p(x|z)] (ref:871-877).  Used when the emission went straight into the forward-backward buffers and no
+    ln rho array exists (``DataPass.emission_target``)."""
+    e_lambda = q.nu[:, None, None] * q.w
+    dev = x_bar - q.m
+    quad = torch.einsum("ki,kij,kj->k", dev, e_lambda, dev)
+    per = q.c - 0.5 * ((s * e_lambda).sum(dim=(1, 2)) + quad)
+    return torch.where(ns > 0, ns * per, torch.zeros_like(ns)).sum()
+
+
 def hmm_lower_bound(p: HmmPriorT, q: HmmPostT, ns, ms, x_bar, s, gamma0, sum_gamma_ln_rho, sum_ln_c) -> dict:
     """_calc_vl, _hiddenmarkovnormal.py:883-943 (nine terms)."""
     K, D = q.m.shape

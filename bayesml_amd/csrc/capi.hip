@@ -1370,8 +1370,12 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->lse_stale = false;
     const bool tmeta_was_valid = ws->tmeta_valid;
     ws->tmeta_valid = false;            // (only a lazy sweep that ran to its end leaves the tile state in step with the bounds)
+    bool emission_to_hmm = false;
     if (mode == kDense) {
         const bool valu16 = ws->estep_variant == kEstepValu16 && ws->tri != nullptr;
+        // an HMM pass that only the forward-backward recursions will read: rho' rows and row maxima straight into the HMM
+        // state, no ln rho array (hmmvb_emission_target; hmm.h H0 + H1)
+        emission_to_hmm = valu16 && !ws->wide && !i8 && !ws->sorted && hmm_fused_emission(ws->hmm);
         rpw = ws->wide ? estep_rows_rows_per_wg()
                        : (i8 ? estep_i8_rows_per_wg() : (valu16 ? estep_rows16_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64)));
         grid = (n_rows + rpw - 1) / rpw;
@@ -1379,7 +1383,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         span_begin(ws, kSpanEstepMain, st);
         e = ws->wide ? launch_estep_rows(ws->T, is64, (int)grid, st, a, &name)
                      : (i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
-                           : (valu16 ? launch_estep_rows16(is64, vec, (int)grid, st, a, ws->tri, &name)
+                           : (valu16 ? (emission_to_hmm ? hmm_launch_emission_rows16(ws->hmm, is64, vec, st, a, ws->tri, &name)
+                                                        : launch_estep_rows16(is64, vec, (int)grid, st, a, ws->tri, &name))
                                      : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name)));
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
@@ -1625,7 +1630,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->mlists_done = ws->mlists_lost = false;
     if (skip_margin >= 0.0) ws->skip_used = true;
     ws->blk_fresh = counted;
-    ws->e_state = 1;
+    ws->e_state = emission_to_hmm ? 4 : 1;
+    ws->hmm_no_lnrho = emission_to_hmm;
     ws->lost_estep = false;
     ws->e_rows = n_rows;
     ws->params_used = true;
@@ -1675,7 +1681,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     int rc = check_x(ws, x_dev, ldx, n_rows, &vec);
     if (rc) return rc;
     if (!stats_dev) return fail(GMMVB_EINVAL, "stats_dev is null");
-    if (ws->e_state == 0 || ws->e_rows != n_rows)
+    if (ws->e_state == 0 || ws->e_state == 4 || ws->e_rows != n_rows)
         return fail(GMMVB_ESTATE, "no responsibilities for these rows: call gmmvb_estep or gmmvb_load_responsibilities first");
     hipStream_t st = (hipStream_t)stream;
     if (ws->lse_stale && ws->e_state == 1) {       // a mixture M-step on an HMM workspace: the log-normaliser after all
@@ -1687,7 +1693,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int direct = ws->e_state == 2 ? 1 : (ws->e_state == 3 ? 2 : 0);
         if (ws->e_state == 3 && hmm_ensure_gamma_cm(ws->hmm, st) != hipSuccess) return fail(GMMVB_EHIP, "gamma transpose launch");
         const double* lr = ws->e_state == 3 ? hmm_gamma_cm(ws->hmm) : ws->lnrho;
-        const double* aux = ws->e_state == 3 ? ws->lnrho : nullptr;
+        const double* aux = ws->e_state == 3 && !ws->hmm_skip_h ? ws->lnrho : nullptr;
         int S = ws->gen_S;
         const int64_t rps = round_up((n_rows + S - 1) / S, 64);
         S = (int)((n_rows + rps - 1) / rps);
@@ -1746,7 +1752,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (ws->e_state == 3) {          // HMM: responsibilities = gamma from the forward-backward pass, h = sum gamma ln rho
         if (!hmm_small && hmm_ensure_gamma_cm(ws->hmm, st) != hipSuccess) return fail(GMMVB_EHIP, "gamma transpose launch");
         a.lnrho = hmm_gamma_cm(ws->hmm);
-        a.aux = ws->lnrho;
+        a.aux = (ws->hmm_no_lnrho || ws->hmm_skip_h) ? nullptr : ws->lnrho;     // (nullptr: h stays 0, see hmmvb_skip_h / hmmvb_emission_target)
         a.direct_r = 2;
     }
     if (pre) {
@@ -1962,9 +1968,11 @@ static int refresh_settled(gmmvb_workspace* ws, hipStream_t st) {
 
 static int readout(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out, void* stream, int mode) {
     if (!ws || !out) return fail(GMMVB_EINVAL, "null argument");
-    if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    if (ws->e_state == 0 || ws->e_state == 4) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
     if (mode == 0 && ws->e_state == 2) return fail(GMMVB_ESTATE, "ln rho is undefined after gmmvb_load_responsibilities");
+    if (mode == 0 && ws->e_state == 3 && ws->hmm_no_lnrho)
+        return fail(GMMVB_ESTATE, "the last gmmvb_estep formed no ln rho array (hmmvb_emission_target 1)");
     const int64_t total = n_rows * ws->K;
     const bool hmm_gamma = ws->e_state == 3 && mode == 1;      // responsibilities of an HMM pass = gamma
     if (ws->e_state == 1 && ws->rec_live) {                    // the pass lived on records: only listed pairs are exact
@@ -2004,7 +2012,7 @@ int gmmvb_ln_rho(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, double* out_
 
 int gmmvb_argmax(gmmvb_workspace* ws, int64_t row0, int64_t n_rows, int32_t* z_dev, void* stream) {
     if (!ws || !z_dev) return fail(GMMVB_EINVAL, "null argument");
-    if (ws->e_state == 0) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
+    if (ws->e_state == 0 || ws->e_state == 4) return fail(GMMVB_ESTATE, "no E-step output in the workspace");
     if (row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows) return fail(GMMVB_EINVAL, "row range outside the last E-step");
     hipError_t e;
     const int* iperm = ws->sorted ? ws->iperm : nullptr;

@@ -271,6 +271,36 @@ static __global__ void pack_tri16_kernel(const double* __restrict__ u, const dou
 // component's multipliers at its top - 300 SGPRs, spilled to vector lanes and read back with a v_readlane per multiply-add),
 // the same with hand-placed s_load / s_waitcnt (scalar loads return out of order, so one unit of look-ahead is all
 // lgkmcnt(0) allows: 3.5 ms), and multipliers broadcast from LDS (the same 2 useful bytes per cycle).
+// || U_k (x - m_k) ||^2 of one row from a packed component image (pack_tri16_kernel); t uniform: scalar loads
+__device__ __forceinline__ double rows16_quadratic(const double* __restrict__ t, const double (&xr)[16]) {
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double y = t[136 + j];
+#pragma unroll
+        for (int i = 0; i <= j; ++i) y = fma(t[j * (j + 1) / 2 + i], xr[i], y);
+        q = fma(y, y, q);
+    }
+    return q;
+}
+
+// a row of x (16 features, zero-padded) as doubles
+template <typename XT, bool VEC>
+__device__ __forceinline__ void rows16_load(const XT* __restrict__ xp, int D, double (&xr)[16]) {
+    if constexpr (VEC) {
+        typedef XT v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const v4 v = *reinterpret_cast<const v4*>(xp + 4 * b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[4 * b + e] = (double)v[e];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xr[i] = i < D ? (double)xp[i] : 0.0;
+    }
+}
+
 template <typename XT, bool VEC>
 __global__ __launch_bounds__(256) void estep_rows16_f64(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D,
                                                         const double* __restrict__ tri /*[K][kTriImg]*/,
@@ -281,29 +311,9 @@ __global__ __launch_bounds__(256) void estep_rows16_f64(const XT* __restrict__ x
         const int64_t n = tile * 256 + threadIdx.x;
         const int64_t row = n < n_rows ? n : n_rows - 1;
         double xr[16];
-        const XT* xp = x + row * ldx;
-        if constexpr (VEC) {
-            typedef XT v4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const v4 v = *reinterpret_cast<const v4*>(xp + 4 * b);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xr[4 * b + e] = (double)v[e];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xr[i] = i < D ? (double)xp[i] : 0.0;
-        }
+        rows16_load<XT, VEC>(x + row * ldx, D, xr);
         for (int k = 0; k < K; ++k) {
-            const double* __restrict__ t = tri + (int64_t)k * kTriImg;        // uniform: scalar loads
-            double q = 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double y = t[136 + j];
-#pragma unroll
-                for (int i = 0; i <= j; ++i) y = fma(t[j * (j + 1) / 2 + i], xr[i], y);
-                q = fma(y, y, q);
-            }
+            const double q = rows16_quadratic(tri + (int64_t)k * kTriImg, xr);
             if (n < n_rows) lnrho[(int64_t)k * npad + n] = cvec[k] - 0.5 * q;
         }
     }

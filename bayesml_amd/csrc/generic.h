@@ -52,7 +52,7 @@ __device__ __forceinline__ double generic_weight(const double* __restrict__ lr, 
                                                  const double* __restrict__ aux, int64_t n, int direct_r, double& h) {
     const double v = lr[n];
     if (direct_r == 2) {                  // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
-        if (v > 0.0) h = fma(v, aux[n], h);
+        if (v > 0.0 && aux) h = fma(v, aux[n], h);           // (no aux: h stays 0, hmmvb_skip_h)
         return v;
     }
     if (direct_r) {                       // responsibilities given directly

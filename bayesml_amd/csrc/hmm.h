@@ -25,6 +25,7 @@
 // lane reads/writes 4 contiguous doubles per 16-state block.
 #pragma once
 #include "common.h"
+#include "estep.h"
 
 namespace gmmvb {
 
@@ -63,6 +64,48 @@ __global__ __launch_bounds__(256) void hmm_prep_kernel(const double* __restrict_
         if (t0 + t >= T) break;
         const int k = hmm_state(p);
         rho_tm[(t0 + t) * Kp + p] = k < K ? exp(tile[k * LD + t] - smx[t]) : 0.0;
+    }
+}
+
+// H0 + H1 in one kernel for one feature tile (D <= 16) and KP <= 32 padded states: the emission of estep_rows16_f64 (a row
+// per lane, the components one after the other) keeps a row's K values of ln rho in LDS instead of writing the [K][npad] array,
+// and the wave writes them out as rho' rows, time-major in lane order, with the row maxima - what hmm_prep_kernel makes of
+// the array, bit for bit (same multiply-adds, same exp arguments).  Saves the array's round trip: 2 x 2.56 GB and a launch
+// of ~1 ms at config 5.  A workgroup is one wave with its own 17 KB tile: nine waves per CU (the emission is bound by the
+// delivery of its uniform multipliers, estep.h, and does not need more).  No ln rho array is formed: what reads it
+// (hmmvb_viterbi, mixture read-outs) needs a pass with the other target (hmmvb_emission_target).
+template <typename XT, bool VEC, int KP>
+__global__ __launch_bounds__(64) void hmm_emission_rows16_kernel(const XT* __restrict__ x, int64_t ldx, int64_t T, int D,
+                                                                 const double* __restrict__ tri /*[K][kTriImg]*/,
+                                                                 const double* __restrict__ cvec, int K,
+                                                                 double* __restrict__ rho_tm, double* __restrict__ mx) {
+    constexpr int LD = KP + 1;
+    __shared__ double tile[64 * LD];
+    __shared__ double smx[64];
+    const int lane = threadIdx.x;
+    const int64_t n_tiles = (T + 63) / 64;
+    for (int64_t ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        const int64_t t0 = ti * 64, n = t0 + lane;
+        const int64_t row = n < T ? n : T - 1;
+        double xr[16];
+        rows16_load<XT, VEC>(x + row * ldx, D, xr);
+        double m = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double v = cvec[k] - 0.5 * rows16_quadratic(tri + (int64_t)k * kTriImg, xr);
+            tile[lane * LD + k] = v;
+            m = k == 0 ? v : fmax(m, v);
+        }
+        smx[lane] = m;
+        if (n < T) mx[n] = m;
+        __syncthreads();
+#pragma unroll 4
+        for (int e = lane; e < 64 * KP; e += 64) {
+            const int t = e / KP, p = e - t * KP;
+            if (t0 + t >= T) break;
+            const int k = hmm_state(p);
+            rho_tm[(t0 + t) * KP + p] = k < K ? exp(tile[t * LD + k] - smx[t]) : 0.0;
+        }
+        __syncthreads();
     }
 }
 
@@ -432,16 +475,71 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
 }
 
 // H5: backward replay, descending in time.  Writes gamma_tm (lane order) and w_tm; gamma_0 too.
-template <int KT>
-__global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* __restrict__ rho_tm,
+// XI (round 4): the xi sum of H6 inside this kernel, and no w_tm.  The term of time t, alpha_{t-1} (x) w_t, pairs the w_t this
+// iteration makes with the alpha row the NEXT iteration loads anyway; summed over the wave's 16 chunks it is a
+// [Kp x 16] x [16 x Kp] product with the chunk as contraction index - four MFMAs per output tile - whose operands are the
+// transposes of what the lanes hold (chunk on lane & 15, positions on lane >> 4 and registers): both go through a
+// per-wave LDS tile (2 x 16 x (Kp + 2) doubles), a d4 write per 16-state block and lane, 8-byte reads.  The replay runs
+// at a tenth of the matrix pipe and ~4 TB/s: the extra MFMAs and LDS traffic ride in its shadow, and the w array's
+// round trip (written here, read by hmm_xi_sum_kernel with alpha: 7.7 GB per iteration at config 5) and a launch are
+// gone.  One slab per wave (same layout as H6's: hmm_finish_kernel adds them in wave order).  The xi read-out derives
+// w_t = rho'_t gamma_t / (alpha_t c'_t) instead (hmm_readout_kernel).
+constexpr int hmm_xi_ldw(int Kp) { return Kp + 2; }
+template <int KT, bool XI = false>
+__global__ __launch_bounds__(256, XI ? 3 : 1) void hmm_backward_replay_kernel(const double* __restrict__ rho_tm,
                                                                   const double* __restrict__ a_tilde, int K, int64_t T,
                                                                   int64_t L, int64_t n_chunks,
                                                                   const double* __restrict__ bend,
                                                                   const double* __restrict__ alpha_tm,
                                                                   const double* __restrict__ cprime,
-                                                                  double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
+                                                                  double* __restrict__ gamma_tm, double* __restrict__ w_tm,
+                                                                  double* __restrict__ xi_slabs = nullptr) {
     constexpr int Kp = 16 * KT;
+    constexpr int LDW = hmm_xi_ldw(Kp);
+    static_assert(!XI || kReplayChunks == 16, "the fused xi sum takes the 16 MFMA columns as 16 distinct chunks");
+    __shared__ __attribute__((aligned(16))) double xs[XI ? 4 * 2 * 16 * LDW : 2];
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    double* const sa = xs + (XI ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 2 * 16 * LDW : 0);
+    double* const sb = sa + (XI ? 16 * LDW : 0);
+    d4 xacc[XI ? KT : 1][XI ? KT : 1];
+    d4 wprev[XI ? KT : 1];
+    if constexpr (XI) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            wprev[it] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) xacc[it][jt] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    // xacc += sum over the wave's chunks of al (x) wv   (al, wv: one row per chunk, positions as the lanes hold them)
+    auto xi_add = [&](const d4 (&al)[KT], const d4 (&wv)[XI ? KT : 1]) {
+        if constexpr (XI) {
+#pragma unroll
+            for (int it = 0; it < KT; ++it) {
+                *reinterpret_cast<d4*>(sa + j * LDW + 16 * it + 4 * g) = al[it];
+                *reinterpret_cast<d4*>(sb + j * LDW + 16 * it + 4 * g) = wv[it];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double a[KT], b[KT];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    a[kt] = sa[(4 * q + g) * LDW + 16 * kt + j];
+                    b[kt] = sb[(4 * q + g) * LDW + 16 * kt + j];
+                }
+#pragma unroll
+                for (int it = 0; it < KT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < KT; ++jt) xacc[it][jt] = mfma_f64(a[it], b[jt], xacc[it][jt]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
     const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kReplayChunks + (j % kReplayChunks);
     const bool live = c < n_chunks;
     const bool first_copy = j < kReplayChunks;
@@ -475,6 +573,7 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* 
         const double cp = on ? cprime[t] : 1.0;
         const double ginv = dot > 0.0 ? 1.0 / dot : 0.0;
         const double winv = (dot > 0.0 && cp > 0.0) ? 1.0 / (dot * cp) : 0.0;
+        d4 wnow[XI ? KT : 1];
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
             d4 gm, ww;
@@ -486,8 +585,14 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* 
             }
             if (on && first_copy) {
                 *reinterpret_cast<d4*>(gamma_tm + t * Kp + 16 * it + 4 * g) = gm;
-                *reinterpret_cast<d4*>(w_tm + t * Kp + 16 * it + 4 * g) = ww;
+                if constexpr (!XI) *reinterpret_cast<d4*>(w_tm + t * Kp + 16 * it + 4 * g) = ww;
             }
+            if constexpr (XI) wnow[it] = ww;              // (zero where the column is off: rho' = 0 there)
+        }
+        if constexpr (XI) {
+            if (s < L - 1) xi_add(al, wprev);             // the term of time t + 1: alpha_t (x) w_{t+1}
+#pragma unroll
+            for (int it = 0; it < KT; ++it) wprev[it] = wnow[it];
         }
         // beta~_{t-1} ~ A~ y, renormalised to sum 1 (columns that are off keep their start vector)
         d4 nb[KT];
@@ -505,6 +610,21 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) be[it][r] = nb[it][r] * inv;
         }
+    }
+    if constexpr (XI) {                                         // the term of the chunk's first step: alpha_{t0 - 1} (x) w_{t0}
+        d4 al0[KT];
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+            al0[it] = (live && t0 < T) ? *reinterpret_cast<const d4*>(alpha_tm + (t0 - 1) * Kp + 16 * it + 4 * g)
+                                       : d4{0.0, 0.0, 0.0, 0.0};
+        xi_add(al0, wprev);
+        double* out = xi_slabs + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * Kp * Kp;
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(16 * it + g + 4 * r) * Kp + 16 * jt + j] = xacc[it][jt][r];
     }
     if (live && c == 0) {                                       // gamma_0 = alpha_0 o beta~_0, normalised
         double dot = 0.0;
@@ -524,7 +644,7 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_kernel(const double* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) gm[r] = al[it][r] * be[it][r] * ginv;
             *reinterpret_cast<d4*>(gamma_tm + 16 * it + 4 * g) = gm;
-            *reinterpret_cast<d4*>(w_tm + 16 * it + 4 * g) = d4{0.0, 0.0, 0.0, 0.0};      // xi_0 = 0
+            if constexpr (!XI) *reinterpret_cast<d4*>(w_tm + 16 * it + 4 * g) = d4{0.0, 0.0, 0.0, 0.0};      // xi_0 = 0
         }
     }
 }
@@ -656,16 +776,28 @@ __global__ void hmm_gamma_to_cm_kernel(const double* __restrict__ gamma_tm, int6
 //   what 0  alpha_t                       [n][K]
 //   what 1  beta_t = gamma_t / alpha_t    [n][K]   (the reference's scaling: gamma = alpha o beta, :1013-1014; 0 where alpha = 0)
 //   what 3  xi_t = (alpha_{t-1}^T w_t) o A~   [n][K][K], xi_0 = 0 (the reference's convention, :1068)
+// w_tm == nullptr (the backward replay summed xi itself and wrote no w): w_t = rho'_t gamma_t / (alpha_t c'_t), 0 where alpha_t = 0
+// (then every xi_t[.][j] is 0: alpha_t[j] = rho'_t[j] (alpha_{t-1} A~)[j] / c'_t is a sum of the non-negative terms in question).
 __global__ void hmm_readout_kernel(const double* __restrict__ alpha_tm, const double* __restrict__ gamma_tm,
                                    const double* __restrict__ w_tm, const double* __restrict__ a_tilde, int K, int Kp,
-                                   int what, int64_t row0, int64_t n_rows, double* __restrict__ out) {
+                                   int what, int64_t row0, int64_t n_rows, double* __restrict__ out,
+                                   const double* __restrict__ rho_tm = nullptr, const double* __restrict__ cprime = nullptr) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     auto pos = [](int s) { return (s & ~15) + 4 * ((s & 15) & 3) + ((s & 15) >> 2); };
     if (what == 3) {
         if (e >= n_rows * K * K) return;
         const int64_t t = row0 + e / ((int64_t)K * K);
         const int i = (int)((e / K) % K), j = (int)(e % K);
-        out[e] = t == 0 ? 0.0 : alpha_tm[(t - 1) * Kp + pos(i)] * a_tilde[i * K + j] * w_tm[t * Kp + pos(j)];
+        double w = 0.0;
+        if (t > 0) {
+            if (w_tm) {
+                w = w_tm[t * Kp + pos(j)];
+            } else {
+                const double al = alpha_tm[t * Kp + pos(j)];
+                w = al > 0.0 ? rho_tm[t * Kp + pos(j)] * gamma_tm[t * Kp + pos(j)] / (al * cprime[t]) : 0.0;
+            }
+        }
+        out[e] = t == 0 ? 0.0 : alpha_tm[(t - 1) * Kp + pos(i)] * a_tilde[i * K + j] * w;
         return;
     }
     if (e >= n_rows * K) return;

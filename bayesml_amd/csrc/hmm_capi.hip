@@ -6,6 +6,7 @@
 #include <new>
 
 #include "hmm.h"
+#include "launch.h"
 #include "hmm_generic.h"
 #include "hmm_wide.h"
 
@@ -44,6 +45,10 @@ struct gmmvb_hmm_state {
     double* a_t = nullptr;        // [K][K] transpose of A~
     unsigned short* phi16 = nullptr;   // [npad][K] back-pointers, natural order
     int64_t bytes = 0;
+    int64_t xi_slab_cap = 0;      // slabs xi_slabs has room for
+    bool xi_separate = false;     // developer switch GMMVB_HMM_XI_SEPARATE: hmm_xi_sum_kernel as in round 3
+    bool w_valid = false;         // the last pass wrote w_tm (false: the backward replay summed xi itself, hmm.h H5 XI)
+    bool fuse_emission = false;   // hmmvb_emission_target: gmmvb_estep writes rho' / mx here (hmm.h H0 + H1) and no ln rho array
 };
 
 namespace gmmvb {
@@ -62,6 +67,32 @@ void hmm_state_destroy(gmmvb_hmm_state* h) {
 const double* hmm_gamma_cm(const gmmvb_hmm_state* h) { return h ? h->gamma_cm : nullptr; }
 const double* hmm_gamma_tm(const gmmvb_hmm_state* h) { return h ? h->gamma_tm : nullptr; }
 int hmm_padded_states(const gmmvb_hmm_state* h) { return h ? h->Kp : 0; }
+// the emission of one feature tile straight into rho' / mx (hmm_emission_rows16_kernel): asked for, and a shape it covers
+bool hmm_fused_emission(const gmmvb_hmm_state* h) { return h && h->fuse_emission && !h->generic && h->Kp <= 32; }
+hipError_t hmm_launch_emission_rows16(gmmvb_hmm_state* h, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a,
+                                      const double* tri, const char** name) {
+    const int64_t tiles = (a.n_rows + 63) / 64;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, int64_t(1) << 20);
+#define EM(XT, V, KP)                                                                                                       \
+    hipLaunchKernelGGL((hmm_emission_rows16_kernel<XT, V, KP>), dim3(grid), dim3(64), 0, st, static_cast<const XT*>(a.x), a.ldx, \
+                       a.n_rows, a.D, tri, a.cvec, a.K, h->rho_tm, h->mx)
+#define EMK(XT, V)                \
+    {                             \
+        if (h->Kp == 16)          \
+            EM(XT, V, 16);        \
+        else                      \
+            EM(XT, V, 32);        \
+    }
+    *name = "hmm_emission_rows16_kernel";
+    if (x_is_f64) {
+        if (vec) EMK(double, true) else EMK(double, false)
+    } else {
+        if (vec) EMK(float, true) else EMK(float, false)
+    }
+#undef EMK
+#undef EM
+    return hipGetLastError();
+}
 // gamma component-major for whoever reads it that way: transposed once per forward-backward pass, and only if asked for
 hipError_t hmm_ensure_gamma_cm(gmmvb_hmm_state* h, hipStream_t st) {
     if (!h || h->gamma_cm_valid || h->gamma_rows < 1) return hipSuccess;
@@ -93,9 +124,10 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     const int K = h->K, Kp = h->Kp;
     const int64_t L = chunk_len(T, false);
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
-    hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
-                       ((size_t)Kp * (kPrepSteps + 1) + kPrepSteps) * sizeof(double), st, ws->lnrho, ws->npad, T, K, Kp, h->rho_tm,
-                       h->mx);
+    if (ws->e_state != 4)          // (4: the emission kernel has written rho' and mx itself)
+        hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
+                           ((size_t)Kp * (kPrepSteps + 1) + kPrepSteps) * sizeof(double), st, ws->lnrho, ws->npad, T, K, Kp,
+                           h->rho_tm, h->mx);
     if (n_chunks > 0)
         hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
                            h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod);
@@ -111,22 +143,32 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K,
                            n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
     }
+    const unsigned grid = (unsigned)((n_chunks + 4 * kReplayChunks - 1) / (4 * kReplayChunks));      // kReplayChunks chunks per wave, 4 waves per block
+    // the xi sum inside the backward replay (one slab per replay wave) unless the slabs do not fit / developer switch
+    // (up to 32 states: with three or four 16-state blocks the accumulators no longer fit beside the operator's registers)
+    const bool xi_fused = KT <= 2 && n_chunks > 0 && kReplayChunks == 16 && (int64_t)grid * 4 <= h->xi_slab_cap && !h->xi_separate;
     if (n_chunks > 0) {
-        const unsigned grid = (unsigned)((n_chunks + 4 * kReplayChunks - 1) / (4 * kReplayChunks));      // kReplayChunks chunks per wave, 4 waves per block
         hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
                            n_chunks, h->fstart, h->alpha_tm, h->cprime);
-        hipLaunchKernelGGL((hmm_backward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
-                           n_chunks, h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+        if constexpr (KT <= 2 && kReplayChunks == 16) {
+            if (xi_fused)
+                hipLaunchKernelGGL((hmm_backward_replay_kernel<KT, true>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
+                                   n_chunks, h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, h->xi_slabs);
+        }
+        if (!xi_fused)
+            hipLaunchKernelGGL((hmm_backward_replay_kernel<KT, false>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
+                               n_chunks, h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, nullptr);
     }
+    h->w_valid = !xi_fused;
     // xi sum over t = 1 .. T-1
     int64_t n_waves = h->xi_waves;
     int64_t steps = T > 1 ? round_up((T - 1 + n_waves - 1) / n_waves, 4) : 4;
-    n_waves = T > 1 ? (T - 1 + steps - 1) / steps : 0;
+    n_waves = T > 1 && !xi_fused ? (T - 1 + steps - 1) / steps : 0;
     if (n_waves > 0)
         hipLaunchKernelGGL((hmm_xi_sum_kernel<KT>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, h->alpha_tm,
                            h->w_tm, T, steps, h->xi_slabs);
     // waves of the last block beyond n_waves write slabs too (zeros): include them only if they exist
-    const int64_t n_slabs = n_waves > 0 ? ((n_waves + 3) / 4) * 4 : 0;
+    const int64_t n_slabs = xi_fused ? (int64_t)grid * 4 : (n_waves > 0 ? ((n_waves + 3) / 4) * 4 : 0);
     const int n_part = (int)std::min<int64_t>(kLncBlocks, (T + 255) / 256);
     hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
     hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
@@ -195,6 +237,7 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
     hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
     hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
                        h->lnc_partial, n_part, T, h->gamma_tm, out);
+    h->w_valid = true;
     h->gamma_cm_valid = false;
     h->gamma_rows = T;
     return hipGetLastError();
@@ -225,6 +268,7 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
     hipLaunchKernelGGL(hmm_lnc_partial_kernel, dim3(n_part), dim3(256), 0, st, h->cprime, h->mx, T, h->lnc_partial);
     hipLaunchKernelGGL(hmm_finish_kernel, dim3((unsigned)((K * K + 7) / 8)), dim3(256), 0, st, h->xi_slabs, n_slabs, a_tilde, K, Kp,
                        h->lnc_partial, n_part, T, h->gamma_tm, out);
+    h->w_valid = true;
     h->gamma_cm_valid = false;
     h->gamma_rows = T;
     return hipGetLastError();
@@ -254,12 +298,16 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     h->xi_waves = h->generic ? std::max<int64_t>(16, std::min<int64_t>(4 * (int64_t)ws->num_cu, (int64_t(1) << 27) / ((int64_t)h->Kp * h->Kp)))
                              : 16 * (int64_t)ws->num_cu;       // four xi-sum waves per SIMD: the kernel streams two [T][Kp] arrays and a wave
                                                                // has one load group in flight (round 4; one wave per SIMD: 1.9 ms, 2.6 TB/s)
+    // room for one xi slab per replay wave (hmm.h H5 XI): sequences past 2^18 steps have chunks of kHmmLongChunk steps, 16 to a
+    // wave; shorter ones at most ~850 chunks (chunk_len)
+    h->xi_slab_cap = std::max<int64_t>(h->xi_waves + 4, h->generic ? 0 : h->npad / (16 * kHmmLongChunk) + 72);
+    h->xi_separate = std::getenv("GMMVB_HMM_XI_SEPARATE") != nullptr;
     const int64_t tk = h->npad * h->Kp;
     struct { double** p; int64_t n; } bufs[] = {
         {&h->rho_tm, tk}, {&h->alpha_tm, tk}, {&h->gamma_tm, tk}, {&h->w_tm, tk},
         {&h->gamma_cm, (int64_t)ws->K * h->npad}, {&h->mx, h->npad}, {&h->cprime, h->npad},
         {&h->prod, h->max_chunks * h->Kp * h->Kp}, {&h->fstart, h->max_chunks * h->Kp},
-        {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, (h->xi_waves + 4) * h->Kp * h->Kp},
+        {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, h->xi_slab_cap * h->Kp * h->Kp},
         {&h->lnc_partial, kLncBlocks},
         {&h->qprod, (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp}, {&h->fstart_s, (h->max_chunks / kHmmSuper + 2) * h->Kp},
         {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0},
@@ -295,6 +343,8 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
                   int32_t* z_dev, void* stream) {
     if (!ws || !ln_pi_tilde_dev || !ln_a_tilde_dev || !z_dev) return fail(GMMVB_EINVAL, "null argument");
     if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
+    if (ws->e_state == 4)
+        return fail(GMMVB_ESTATE, "the last gmmvb_estep formed no ln rho array (hmmvb_emission_target 1): run it with target 0");
     if (ws->e_state != 1 || ws->e_rows != n_rows)
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     gmmvb_hmm_state* h = ws->hmm;
@@ -421,11 +471,26 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
     return GMMVB_OK;
 }
 
+int hmmvb_skip_h(gmmvb_workspace* ws, int skip) {
+    if (!ws) return fail(GMMVB_EINVAL, "null argument");
+    if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
+    ws->hmm_skip_h = skip != 0;
+    return GMMVB_OK;
+}
+
+int hmmvb_emission_target(gmmvb_workspace* ws, int fused, int* in_effect) {
+    if (!ws) return fail(GMMVB_EINVAL, "null argument");
+    if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
+    ws->hmm->fuse_emission = fused != 0 && ws->tri != nullptr && std::getenv("GMMVB_HMM_FUSED_EMISSION_OFF") == nullptr;
+    if (in_effect) *in_effect = hmm_fused_emission(ws->hmm) ? 1 : 0;
+    return GMMVB_OK;
+}
+
 int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi_tilde_dev, const double* a_tilde_dev,
                            double* out_dev, void* stream) {
     if (!ws || !pi_tilde_dev || !a_tilde_dev || !out_dev) return fail(GMMVB_EINVAL, "null argument");
     if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
-    if (ws->e_state != 1 || ws->e_rows != n_rows)
+    if ((ws->e_state != 1 && ws->e_state != 4) || ws->e_rows != n_rows)
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
@@ -468,7 +533,8 @@ int hmmvb_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, c
     gmmvb_hmm_state* h = ws->hmm;
     const int64_t total = n_rows * h->K * (what == 3 ? h->K : 1);
     hipLaunchKernelGGL(hmm_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->alpha_tm,
-                       h->gamma_tm, h->w_tm, a_tilde_dev, h->K, h->Kp, what, row0, n_rows, out_dev);
+                       h->gamma_tm, h->w_valid ? h->w_tm : nullptr, a_tilde_dev, h->K, h->Kp, what, row0, n_rows, out_dev, h->rho_tm,
+                       h->cprime);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "hmm_readout launch", e);
     return GMMVB_OK;

@@ -150,7 +150,7 @@ __device__ __forceinline__ void mstep_body(const XT* __restrict__ x, int64_t ldx
                 r_l = idx_l < 0 ? -1.0 : 1.0;
             } else if (direct_r == 2) {                 // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
                 r_l = v;
-                if (v > 0.0) hsum = fma(v, aux_k[src], hsum);
+                if (v > 0.0 && aux_k) hsum = fma(v, aux_k[src], hsum);      // (no ln rho array: h stays 0, hmmvb_emission_target)
             } else if (direct_r) {
                 r_l = v;
                 if (v > 0.0) hsum = fma(v, log(v), hsum);
@@ -319,7 +319,7 @@ __device__ __forceinline__ void mstep_wide_body(const double* __restrict__ xc, i
             const double v = lr[nl];
             if (direct_r == 2) {                   // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
                 r_l = v;
-                if (v > 0.0) hsum = fma(v, aux_k[nl], hsum);
+                if (v > 0.0 && aux_k) hsum = fma(v, aux_k[nl], hsum);
             } else if (direct_r) {
                 r_l = v;
                 if (v > 0.0) hsum = fma(v, log(v), hsum);
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
                 const double v = lnrho[(int64_t)k * npad + nl];
                 if (direct_r == 2) {                 // HMM: r = gamma, h accumulates sum gamma * ln rho (aux)
                     r = v;
-                    if (v > 0.0) hsum[c] = fma(v, aux[(int64_t)k * npad + nl], hsum[c]);
+                    if (v > 0.0 && aux) hsum[c] = fma(v, aux[(int64_t)k * npad + nl], hsum[c]);
                 } else if (direct_r) {
                     r = v;
                     if (v > 0.0) hsum[c] = fma(v, log(v), hsum[c]);
@@ -504,7 +504,9 @@ __host__ __device__ constexpr int lane_order_pos(int state) {          // hmm.h:
     return (state & ~15) + 4 * (w & 3) + (w >> 2);
 }
 
-template <int CW>
+// AUX = false: the emission went straight to the forward-backward buffers and no ln rho array exists (hmm.h H0 + H1): h
+// stays 0 - the host takes sum gamma ln rho from the moments, in closed form - and a third of the kernel's reads is gone.
+template <int CW, bool AUX = true>
 __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __restrict__ xc, int64_t n_rows,
                                                               const double* __restrict__ gamma_tm, int Kp,
                                                               const double* __restrict__ aux, int64_t npad, int K, int KGW, int S,
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
     auto request_aux = [&](int64_t c0) {
         const int64_t nl = c0 + lane < hi ? c0 + lane : hi - 1;
 #pragma unroll
-        for (int c = 0; c < CW; ++c) aux_n[c] = aux[(int64_t)(k0 + c < K ? k0 + c : 0) * npad + nl];
+        for (int c = 0; c < CW; ++c) aux_n[c] = AUX ? aux[(int64_t)(k0 + c < K ? k0 + c : 0) * npad + nl] : 0.0;
     };
     request(lo);
     request_x(lo);
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
                 const int k = k0 + c;
                 if (k < K && nl < hi) {
                     const double v = sb[lane * LD + pc[c]];
-                    if (v > 0.0) hsum[c] = fma(v, aux_c[c], hsum[c]);
+                    if (AUX && v > 0.0) hsum[c] = fma(v, aux_c[c], hsum[c]);
                     nsum[c] += v;
                 }
             }

@@ -209,7 +209,8 @@ struct gmmvb_workspace {
     int gen_S = 1;
     int64_t bytes = 0;
     bool have_params = false;
-    int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly, 3 HMM gamma
+    int e_state = 0;           // 0 none, 1 E-step output, 2 responsibilities loaded directly, 3 HMM gamma,
+                               // 4 emission as rho' / mx in the HMM state, no ln rho array (hmmvb_emission_target)
     int64_t e_rows = 0;
     char info[512] = {0};
     hipError_t hip_err = hipSuccess;   // first failed event record / counter reset of the pass in flight (capi.hip: note_hip)
@@ -226,6 +227,8 @@ struct gmmvb_workspace {
     int span_slot[kMaxSpans] = {0};
     hipEvent_t span_ev[2 * kMaxSpans] = {nullptr};
     gmmvb_hmm_state* hmm = nullptr;
+    bool hmm_skip_h = false;           // hmmvb_skip_h: the M-step of an HMM pass leaves h = 0 (and does not read the ln rho array)
+    bool hmm_no_lnrho = false;         // the last E-step handed its emission to the HMM state (e_state 4, then 3): no ln rho array
     bool lse_stale = false;            // the last dense E-step of an HMM workspace did not make lse (only a read-out wants it)
 };
 
@@ -235,6 +238,7 @@ void hmm_state_destroy(gmmvb_hmm_state* h);
 const double* hmm_gamma_cm(const gmmvb_hmm_state* h);                 // [K][npad] responsibilities of the last pass (after hmm_ensure_gamma_cm)
 const double* hmm_gamma_tm(const gmmvb_hmm_state* h);                 // [npad][Kp] the same, time-major in lane order (hmm.h)
 int hmm_padded_states(const gmmvb_hmm_state* h);                      // Kp
+bool hmm_fused_emission(const gmmvb_hmm_state* h);                    // gmmvb_estep hands rho' / mx straight to the HMM state (e_state 4)
 hipError_t hmm_ensure_gamma_cm(gmmvb_hmm_state* h, hipStream_t st);   // transposes gamma once per pass, on demand
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 }  // namespace gmmvb

@@ -294,7 +294,10 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         ms, g0, gl, sum_ln_c = eng.forward_backward(q.pi_tilde, q.a_tilde)
         ns, h, a, B = eng.split_stats(eng.mstep(xd))
         x_bar, s = _kside.moments_from_stats(ns, a, B, eng.pivot, s_prev)
-        return dict(ns=ns, ms=ms, x_bar=x_bar, s=s, g0=g0, gl=gl, sum_g_ln_rho=h.sum(), sum_ln_c=sum_ln_c)
+        # sum gamma ln rho (ref:905) from the moments, in the closed form the reference uses for E[ln p(x|z)] (ref:871-877):
+        # the M-step then neither reads the ln rho array nor accumulates h (hmmvb_skip_h)
+        sum_g_ln_rho = _kside.sum_gamma_ln_rho(q, ns, x_bar, s)
+        return dict(ns=ns, ms=ms, x_bar=x_bar, s=s, g0=g0, gl=gl, sum_g_ln_rho=sum_g_ln_rho, sum_ln_c=sum_ln_c)
 
     def _random_pass(self, eng, xd, s_prev):
         """_init_random_responsibility (ref:941-950): gamma and ms from host Dirichlet draws; ln rho = 0 and
@@ -324,6 +327,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         """Variational-Bayes update of ``hn_*`` from one observed sequence (driver of ref:1028-1134)."""
         eng, xd = self._open(x)
         eng.enable_hmm()
+        eng.hmm_skip_h(True)
         self._length = xd.shape[0]
         dev = xd.device
         prior = self._prior_tensors(dev)
@@ -522,6 +526,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         """One-hot Viterbi path (``viterbi=True``, "0-1" only) or posterior marginals (ref:1425-1499)."""
         eng, xd = self._open(x)
         eng.enable_hmm()
+        eng.hmm_skip_h(True)
         self._length = xd.shape[0]
         q = self._post_tensors(xd.device)
         K = self.c_num_classes

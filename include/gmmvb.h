@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GMMVB_ABI_VERSION 5
+#define GMMVB_ABI_VERSION 6
 
 enum gmmvb_status {
     GMMVB_OK = 0,
@@ -202,6 +202,22 @@ int64_t hmmvb_out_len(int K);
 int hmmvb_enable(gmmvb_workspace* ws);
 int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi_tilde_dev, const double* a_tilde_dev,
                            double* out_dev, void* stream);
+/* skip = 1: the gmmvb_mstep calls that follow hmmvb_forward_backward leave the h block of the statistics at 0 and do not read
+ * the ln rho array (a third of that kernel's traffic): sum_t gamma_tk ln rho_tk, the only use of h on the HMM path
+ * (_hiddenmarkovnormal.py:905), follows from the moments of the same block in closed form,
+ * ns_k (c_k - ((s_k o nu_k W_k).sum() + (x_bar_k - m_k)^T nu_k W_k (x_bar_k - m_k)) / 2), the expression the reference
+ * itself uses for E[ln p(x|z)] (:871-877).  Default 0. */
+int hmmvb_skip_h(gmmvb_workspace* ws, int skip);
+
+/* Where the next gmmvb_estep calls of an HMM workspace put the emission.  fused = 0 (default): the ln rho array, as for a
+ * mixture - hmmvb_forward_backward, hmmvb_viterbi and the ln rho read-out all work from it.  fused = 1: for shapes the
+ * library covers (*in_effect = 1: one feature tile, D <= 16, and at most 32 states) the emission kernel writes
+ * rho' = exp(ln rho - row maximum) and the maxima straight into the forward-backward buffers and forms NO ln rho array
+ * (its 16 N K bytes of traffic and a launch per pass are saved).  Then only hmmvb_forward_backward may follow;
+ * hmmvb_viterbi and gmmvb_ln_rho return GMMVB_ESTATE until a pass with target 0, and the statistics block of the following
+ * gmmvb_mstep carries h = 0 as with hmmvb_skip_h.  Other shapes: *in_effect = 0 and nothing changes.  in_effect may be null. */
+int hmmvb_emission_target(gmmvb_workspace* ws, int fused, int* in_effect);
+
 /* Viterbi path (estimate_latent_vars(loss="0-1", viterbi=True), :1465-1481) from the emission ln rho of the
  * last gmmvb_estep: z_dev[t] = state index of the most probable path (first maximiser on ties). */
 int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde_dev, const double* ln_a_tilde_dev,

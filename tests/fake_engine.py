@@ -68,6 +68,14 @@ class CpuDataPass:
     def enable_hmm(self):
         self._hmm_gamma = None
 
+    emission_fused = False
+
+    def hmm_skip_h(self, skip=True):        # (the fake computes h anyway; the host ignores it)
+        pass
+
+    def emission_target(self, fused):       # (the fake keeps its ln rho array: never in effect)
+        return False
+
     def forward_backward(self, pi_tilde, a_tilde):
         ln_rho = self._ln_rho
         T, K = ln_rho.shape

@@ -207,3 +207,69 @@ def test_viterbi_kernel_against_oracle(K, D, T):
     q = orc.HmmPosterior(m.hn_eta_vec.copy(), m.hn_zeta_vecs.copy(), m.hn_m_vecs.copy(), m.hn_kappas.copy(),
                          m.hn_nus.copy(), m.hn_w_mats.copy(), m.hn_w_mats_inv.copy()).refresh()
     assert np.array_equal(m.estimate_latent_vars(x, "0-1", viterbi=True), orc.viterbi(x, q))
+
+
+@pytest.mark.parametrize("K,D,T,dtype", [(32, 16, 4096, np.float32), (5, 3, 777, np.float64), (16, 16, 70001, np.float32),
+                                         (17, 9, 1, np.float64), (32, 12, 263000, np.float32)])
+def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
+    """hmmvb_emission_target(1): rho' and the row maxima straight from the emission kernel - the same bits as the ln rho
+    array followed by hmm_prep_kernel, so everything behind is bit-identical; no ln rho array (Viterbi / ln rho read-out
+    refuse), h = 0 in the statistics and sum gamma ln rho from the moments (ref:905 against ref:871-877) to rounding."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass, EngineError
+    dev = torch.device("cuda", 0)
+    x, _ = orc.synth_hmm(K, D, T, np.dtype(dtype), seed=3)
+    rng = np.random.default_rng(5)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
+    m = t(x[rng.integers(0, T, K)].astype(np.float64))
+    g = rng.normal(size=(K, D, D)) * 0.2 + np.eye(D)
+    w_inv = t(g @ g.transpose(0, 2, 1) * (D + 3.0))
+    f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), m, t(rng.uniform(1, 3, K)),
+                                     t(rng.uniform(D + 1, D + 6, K)), w_inv))
+    c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
+    f.c = c
+    pi = t(rng.dirichlet(np.ones(K)))
+    a = t(rng.dirichlet(np.ones(K), K))
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    outs = []
+    for fused in (False, True):
+        eng = DataPass(K, D, xd.dtype, T, dev)
+        eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+        eng.prepare_rows(xd)
+        eng.enable_hmm()
+        assert eng.emission_target(fused) == fused
+        eng.set_params(c, f.m, f.u)
+        eng.estep(xd)
+        if fused:
+            with pytest.raises(EngineError):
+                eng.viterbi(torch.log(pi), torch.log(a))
+            with pytest.raises(EngineError):
+                eng.ln_rho(0, 1)
+        ms, g0, gl, lnc = eng.forward_backward(pi, a)
+        stats = eng.mstep(xd).clone()
+        ns, h, am, B = eng.split_stats(stats)
+        x_bar, s = _kside.moments_from_stats(ns, am, B, eng.pivot, torch.zeros(K, D, D, dtype=torch.float64, device=dev))
+        closed = float(_kside.sum_gamma_ln_rho(f, ns, x_bar, s))
+        if not fused:                  # hmmvb_skip_h: the same statistics with h = 0
+            eng.hmm_skip_h(True)
+            st2 = eng.mstep(xd).clone()
+            eng.hmm_skip_h(False)
+            assert torch.equal(st2[:K], stats[:K]) and torch.equal(st2[2 * K:], stats[2 * K:]) and float(st2[K:2 * K].abs().sum()) == 0.0
+        outs.append(dict(ms=ms.clone(), g0=g0.clone(), gl=gl.clone(), lnc=float(lnc), stats=stats, h=float(h.sum()),
+                         closed=closed, gamma=eng.responsibilities(max(0, T - 500), min(T, 500)).clone(),
+                         alpha=eng.hmm_readout("alpha", 0, min(T, 300)).clone()))
+        if fused:                      # back to the array: Viterbi works again on the same workspace
+            assert eng.emission_target(False) is False
+            eng.estep(xd)
+            z = eng.viterbi(torch.log(pi), torch.log(a))
+            assert z.shape[0] == T
+        eng.close()
+    u, v = outs
+    for k in ("ms", "g0", "gl", "gamma", "alpha"):
+        assert torch.equal(u[k], v[k]), k
+    assert u["lnc"] == v["lnc"]
+    assert v["h"] == 0.0
+    hs = 2 * K
+    assert torch.equal(u["stats"][:K], v["stats"][:K]) and torch.equal(u["stats"][hs:], v["stats"][hs:])
+    assert abs(u["closed"] - u["h"]) <= 1e-11 * abs(u["h"]) + 1e-9
+    assert abs(v["closed"] - u["h"]) <= 1e-11 * abs(u["h"]) + 1e-9

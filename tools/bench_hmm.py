@@ -94,6 +94,8 @@ def measure(args, dev=None):
     m = hmm.LearnModel(K, D, seed=0, device=dev, verbose=False)
     eng, xd = m._open(x)
     eng.enable_hmm()
+    eng.hmm_skip_h(True)                                                        # as update_posterior does
+    eng.emission_target(os.environ.get("BENCH_HMM_FUSED_EMISSION") is not None)  # (developer switch: hmm.h H0 + H1, slower)
     prior = m._prior_tensors(dev)
     q = _kside.hmm_post_from_prior(prior)
     size, a, B = m._subsample_moments(eng, xd, T)
@@ -120,6 +122,7 @@ def measure(args, dev=None):
     # and xi [T, K, K]); the kernels of DESIGN.md section 5b sweep about twelve [T][16 ceil(K/16)] f64 arrays per iteration.
     # Viterbi path of the whole sequence under the last posterior (chunked max-plus scan, hmm.h hmm_vit_*)
     qf = q if getattr(q, "ln_pi_tilde", None) is not None else _kside.hmm_features(q)
+    eng.emission_target(False)              # (the Viterbi pass reads the ln rho array)
     eng.set_params(qf.c, qf.m, qf.u)
     eng.estep(xd)
     torch.cuda.synchronize()
