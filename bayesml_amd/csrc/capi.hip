@@ -1375,7 +1375,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const bool valu16 = ws->estep_variant == kEstepValu16 && ws->tri != nullptr;
         // an HMM pass that only the forward-backward recursions will read: rho' rows and row maxima straight into the HMM
         // state, no ln rho array (hmmvb_emission_target; hmm.h H0 + H1)
-        emission_to_hmm = valu16 && !ws->wide && !i8 && !ws->sorted && hmm_fused_emission(ws->hmm);
+        emission_to_hmm = ws->T == 1 && !ws->wide && !i8 && !ws->sorted && hmm_fused_emission(ws->hmm);
         rpw = ws->wide ? estep_rows_rows_per_wg()
                        : (i8 ? estep_i8_rows_per_wg() : (valu16 ? estep_rows16_rows_per_wg() : estep_rows_per_wg(ws->estep_variant, ws->T, is64)));
         grid = (n_rows + rpw - 1) / rpw;
@@ -1383,9 +1383,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         span_begin(ws, kSpanEstepMain, st);
         e = ws->wide ? launch_estep_rows(ws->T, is64, (int)grid, st, a, &name)
                      : (i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
-                           : (valu16 ? (emission_to_hmm ? hmm_launch_emission_rows16(ws->hmm, is64, vec, st, a, ws->tri, &name)
-                                                        : launch_estep_rows16(is64, vec, (int)grid, st, a, ws->tri, &name))
-                                     : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name)));
+                           : (emission_to_hmm ? hmm_launch_emission16(ws->hmm, is64, vec, st, a, &name)
+                              : (valu16 ? launch_estep_rows16(is64, vec, (int)grid, st, a, ws->tri, &name)
+                                     : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name))));
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
         ++ws->passes[0];

@@ -126,6 +126,40 @@ __device__ __forceinline__ void estep_component(ImgPtr im, const XT (&xr)[NB][JB
     }
 }
 
+// One feature tile (JB = 1): the quadratic form itself, summed over the lane groups (every lane of sample n gets it) - for
+// callers that keep the values in registers (hmm.h: hmm_emission_mfma16_kernel).  Same operations as estep_component; the
+// operands of a component are loaded apart from their use so that the caller can request a component ahead.
+struct Comp16 {
+    double a[4], b[4];
+};
+__device__ __forceinline__ Comp16 load_component16(const double* __restrict__ im, int lane, int g) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 a01 = *reinterpret_cast<const d2*>(im + lane * 2);
+    const d2 a23 = *reinterpret_cast<const d2*>(im + 128 + lane * 2);
+    const d2 b01 = *reinterpret_cast<const d2*>(im + 256 + g * 4);
+    const d2 b23 = *reinterpret_cast<const d2*>(im + 256 + g * 4 + 2);
+    return Comp16{{a01[0], a01[1], a23[0], a23[1]}, {b01[0], b01[1], b23[0], b23[1]}};
+}
+template <int NB, typename XT>
+__device__ __forceinline__ void component16_mfma(const Comp16& c, const XT (&xr)[NB][1][4], d4 (&acc)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = d4{c.b[0], c.b[1], c.b[2], c.b[3]};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_f64(c.a[s], (double)xr[nb][0][s], acc[nb]);
+}
+template <int NB>
+__device__ __forceinline__ void component16_q(const d4 (&acc)[NB], double (&q)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = fma(acc[nb][r], acc[nb][r], t);
+        q[nb] = sum_groups(t);
+    }
+}
+
 // The same with an early way out for candidates that turn out irrelevant: after the first J1 output blocks (J1 (J1 + 1) / 2
 // of the JB (JB + 1) / 2 tile pairs) the partial sum q_J1 <= q already bounds ln rho from above; if for EVERY row of the wave
 // tile  c_k - q_J1 / 2 < thr[row]  (the row's relevance threshold: its best exact value - 80 ln 2, written by the

@@ -67,45 +67,91 @@ __global__ __launch_bounds__(256) void hmm_prep_kernel(const double* __restrict_
     }
 }
 
-// H0 + H1 in one kernel for one feature tile (D <= 16) and KP <= 32 padded states: the emission of estep_rows16_f64 (a row
-// per lane, the components one after the other) keeps a row's K values of ln rho in LDS instead of writing the [K][npad] array,
-// and the wave writes them out as rho' rows, time-major in lane order, with the row maxima - what hmm_prep_kernel makes of
-// the array, bit for bit (same multiply-adds, same exp arguments).  Saves the array's round trip: 2 x 2.56 GB and a launch
-// of ~1 ms at config 5.  A workgroup is one wave with its own 17 KB tile: nine waves per CU (the emission is bound by the
-// delivery of its uniform multipliers, estep.h, and does not need more).  No ln rho array is formed: what reads it
-// (hmmvb_viterbi, mixture read-outs) needs a pass with the other target (hmmvb_emission_target).
-template <typename XT, bool VEC, int KP>
-__global__ __launch_bounds__(64) void hmm_emission_rows16_kernel(const XT* __restrict__ x, int64_t ldx, int64_t T, int D,
-                                                                 const double* __restrict__ tri /*[K][kTriImg]*/,
-                                                                 const double* __restrict__ cvec, int K,
-                                                                 double* __restrict__ rho_tm, double* __restrict__ mx) {
-    constexpr int LD = KP + 1;
-    __shared__ double tile[64 * LD];
-    __shared__ double smx[64];
-    const int lane = threadIdx.x;
-    const int64_t n_tiles = (T + 63) / 64;
-    for (int64_t ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
-        const int64_t t0 = ti * 64, n = t0 + lane;
-        const int64_t row = n < T ? n : T - 1;
-        double xr[16];
-        rows16_load<XT, VEC>(x + row * ldx, D, xr);
-        double m = 0.0;
-        for (int k = 0; k < K; ++k) {
-            const double v = cvec[k] - 0.5 * rows16_quadratic(tri + (int64_t)k * kTriImg, xr);
-            tile[lane * LD + k] = v;
-            m = k == 0 ? v : fmax(m, v);
+// H0 + H1 in one kernel for one feature tile (D <= 16) and up to 64 states: the emission on the matrix pipe (estep.h:
+// estep_component, four MFMAs per component and 16 rows) leaves ||U_k (x_n - m_k)||^2 of sample n = lane & 15 in all four
+// lane groups, so group g keeps the components k = g (mod 4) - which is exactly what a lane owns of a time-major row in
+// lane order: states 16 it + g + 4 r at positions 16 it + 4 g + r, four contiguous doubles per 16-state block.  A wave
+// therefore holds the K values of ln rho of its 64 rows in registers (8 per lane and row tile at K = 32), takes the row
+// maxima with two shuffles and writes rho' = exp(ln rho - max) as whole 256-byte rows, and the maxima - what
+// hmm_prep_kernel makes of the [K][npad] array, without the array: its round trip (2 x 2.56 GB at config 5) and a launch
+// are gone.  The component loop is unrolled (the register index of a kept value must be static; ~40 instructions per
+// component).  (A first form kept the row-per-lane vector-ALU emission of estep_rows16_f64 and its K values per row in
+// LDS: 17 KB per wave = nine waves per CU, 4.7 ms against 2.4 + 1.0 for the two kernels it replaced.)
+// No ln rho array is formed: what reads it (hmmvb_viterbi, the ln rho read-out) needs a pass with the other target
+// (hmmvb_emission_target).
+template <typename XT, bool VEC, int KT>
+__global__ __launch_bounds__(256, 2) void hmm_emission_mfma16_kernel(const XT* __restrict__ x, int64_t ldx, int64_t T, int D,
+                                                                  const double* __restrict__ img /*[K][img_doubles(1)]*/,
+                                                                  const double* __restrict__ cvec, int K,
+                                                                  double* __restrict__ rho_tm, double* __restrict__ mx) {
+    constexpr int NB = KT == 1 ? 4 : 2, Kp = 16 * KT, IMG = img_doubles(1);      // (row tiles per wave: what the registers hold)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t n_tiles = (T + 16 * NB - 1) / (16 * NB);
+    double cl[4 * KT];                                   // c of the components this lane keeps: 4 kq + g
+#pragma unroll
+    for (int kq = 0; kq < 4 * KT; ++kq) cl[kq] = cvec[4 * kq + g < K ? 4 * kq + g : 0];
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t ld[NB], stv[NB];
+        tile_rows<NB>(tile * 16 * NB, n, T, ld, stv);
+        XT xr[NB][1][4];
+        load_x_tile<1, NB, XT, VEC>(x, ldx, D, ld, g, xr);
+        double mine[NB][4 * KT];
+        // The component loop is unrolled (static register indices) and the operands of component k + 1 are requested before
+        // component k is computed.  Left alone the compiler requests ALL operands at the loop's top (8 doubles per lane and
+        // component; loads from a const __restrict__ array are "invariant" and move across memory barriers, but not above the
+        // empty asm their offset goes through) and issues the MFMAs of many components ahead, keeping their accumulators:
+        // the asm statements on offsets and partial sums pin the order.  The f64 vector ALU does not run beside f64 MFMAs
+        // (same units), so what is issued per component counts: the squares are summed in the lane, and every four
+        // components one butterfly over the lane groups leaves component 4 kq + g's total in group g - where it is kept.
+        // States past K (padding) run on component 0's operands and are discarded.
+        auto fetch = [&](int kk) {
+            int off = (kk < K ? kk : 0) * IMG;
+            asm volatile("" : "+s"(off));
+            return load_component16(img + off, lane, g);
+        };
+        Comp16 nxt = fetch(0);
+        double part[4][NB];
+#pragma unroll
+        for (int k = 0; k < Kp; ++k) {
+            const Comp16 cur = nxt;
+            if (k + 1 < Kp) nxt = fetch(k + 1);
+            d4 acc[NB];
+            component16_mfma<NB, XT>(cur, xr, acc);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                double t = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t = fma(acc[nb][r], acc[nb][r], t);
+                asm volatile("" : "+v"(t));
+                part[k & 3][nb] = t;
+            }
+            if ((k & 3) == 3) {
+                const int kq = k >> 2;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const double q = sum_groups_scatter4(part[0][nb], part[1][nb], part[2][nb], part[3][nb]);
+                    mine[nb][kq] = 4 * kq + g < K ? cl[kq] - 0.5 * q : -__builtin_huge_val();
+                }
+            }
         }
-        smx[lane] = m;
-        if (n < T) mx[n] = m;
-        __syncthreads();
-#pragma unroll 4
-        for (int e = lane; e < 64 * KP; e += 64) {
-            const int t = e / KP, p = e - t * KP;
-            if (t0 + t >= T) break;
-            const int k = hmm_state(p);
-            rho_tm[(t0 + t) * KP + p] = k < K ? exp(tile[t * LD + k] - smx[t]) : 0.0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            double m = mine[nb][0];
+#pragma unroll
+            for (int e = 1; e < 4 * KT; ++e) m = fmax(m, mine[nb][e]);
+            m = max_groups(m);
+            if (stv[nb] >= 0) {
+#pragma unroll
+                for (int it = 0; it < KT; ++it) {
+                    d4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = 16 * it + g + 4 * r < K ? exp(mine[nb][4 * it + r] - m) : 0.0;
+                    *reinterpret_cast<d4*>(rho_tm + stv[nb] * Kp + 16 * it + 4 * g) = o;
+                }
+                if (g == 0) mx[stv[nb]] = m;
+            }
         }
-        __syncthreads();
     }
 }
 

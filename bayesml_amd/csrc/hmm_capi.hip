@@ -67,23 +67,22 @@ void hmm_state_destroy(gmmvb_hmm_state* h) {
 const double* hmm_gamma_cm(const gmmvb_hmm_state* h) { return h ? h->gamma_cm : nullptr; }
 const double* hmm_gamma_tm(const gmmvb_hmm_state* h) { return h ? h->gamma_tm : nullptr; }
 int hmm_padded_states(const gmmvb_hmm_state* h) { return h ? h->Kp : 0; }
-// the emission of one feature tile straight into rho' / mx (hmm_emission_rows16_kernel): asked for, and a shape it covers
-bool hmm_fused_emission(const gmmvb_hmm_state* h) { return h && h->fuse_emission && !h->generic && h->Kp <= 32; }
-hipError_t hmm_launch_emission_rows16(gmmvb_hmm_state* h, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a,
-                                      const double* tri, const char** name) {
-    const int64_t tiles = (a.n_rows + 63) / 64;
-    const unsigned grid = (unsigned)std::min<int64_t>(tiles, int64_t(1) << 20);
-#define EM(XT, V, KP)                                                                                                       \
-    hipLaunchKernelGGL((hmm_emission_rows16_kernel<XT, V, KP>), dim3(grid), dim3(64), 0, st, static_cast<const XT*>(a.x), a.ldx, \
-                       a.n_rows, a.D, tri, a.cvec, a.K, h->rho_tm, h->mx)
-#define EMK(XT, V)                \
-    {                             \
-        if (h->Kp == 16)          \
-            EM(XT, V, 16);        \
-        else                      \
-            EM(XT, V, 32);        \
+// the emission of one feature tile straight into rho' / mx (hmm_emission_mfma16_kernel): asked for, and a shape it covers
+// (up to 32 states: beyond, a wave's K values per row no longer fit its registers beside the pipeline's operands)
+bool hmm_fused_emission(const gmmvb_hmm_state* h) { return h && h->fuse_emission && !h->generic && h->KT <= 2; }
+hipError_t hmm_launch_emission16(gmmvb_hmm_state* h, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a, const char** name) {
+    const int64_t rows_per_wg = 4 * 16 * (h->KT == 1 ? 4 : 2);       // (hmm.h: NB row tiles per wave)
+    const int64_t wgs = (a.n_rows + rows_per_wg - 1) / rows_per_wg;
+    const unsigned grid = (unsigned)std::min<int64_t>(wgs, int64_t(1) << 20);
+#define EM(XT, V, KTT)                                                                                                      \
+    hipLaunchKernelGGL((hmm_emission_mfma16_kernel<XT, V, KTT>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx, \
+                       a.n_rows, a.D, a.img, a.cvec, a.K, h->rho_tm, h->mx)
+#define EMK(XT, V)                                    \
+    switch (h->KT) {                                  \
+        case 1: EM(XT, V, 1); break;                  \
+        default: EM(XT, V, 2); break;                 \
     }
-    *name = "hmm_emission_rows16_kernel";
+    *name = "hmm_emission_mfma16_kernel";
     if (x_is_f64) {
         if (vec) EMK(double, true) else EMK(double, false)
     } else {
@@ -481,7 +480,7 @@ int hmmvb_skip_h(gmmvb_workspace* ws, int skip) {
 int hmmvb_emission_target(gmmvb_workspace* ws, int fused, int* in_effect) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
-    ws->hmm->fuse_emission = fused != 0 && ws->tri != nullptr && std::getenv("GMMVB_HMM_FUSED_EMISSION_OFF") == nullptr;
+    ws->hmm->fuse_emission = fused != 0 && ws->T == 1 && !ws->wide && std::getenv("GMMVB_HMM_FUSED_EMISSION_OFF") == nullptr;
     if (in_effect) *in_effect = hmm_fused_emission(ws->hmm) ? 1 : 0;
     return GMMVB_OK;
 }

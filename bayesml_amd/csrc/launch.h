@@ -31,9 +31,9 @@ int estep_rows16_rows_per_wg();
 hipError_t launch_pack_tri16(const double* u, const double* m, int K, int D, double* tri, hipStream_t st);
 hipError_t launch_estep_rows16(int x_is_f64, bool vec, int grid, hipStream_t st, const EstepArgs& a, const double* tri,
                                const char** name);
-// the same emission written as rho' rows and row maxima into the HMM state (hmm.h: hmm_emission_rows16_kernel; hmm_capi.hip)
-hipError_t hmm_launch_emission_rows16(::gmmvb_hmm_state* h, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a,
-                                      const double* tri, const char** name);
+// the emission of one feature tile written as rho' rows and row maxima into the HMM state (hmm.h: hmm_emission_mfma16_kernel;
+// hmm_capi.hip)
+hipError_t hmm_launch_emission16(::gmmvb_hmm_state* h, int x_is_f64, bool vec, hipStream_t st, const EstepArgs& a, const char** name);
 int estep_bound_blocks(int T);                    // 0 = the pruned path is not built for this T (D < 49)
 int estep_gather_rows_per_wg(int T, int x_is_f64);
 // exact f64 evaluation of listed pairs (device lists [K][cap], device counts), chunk plan on the device

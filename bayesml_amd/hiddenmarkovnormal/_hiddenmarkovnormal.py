@@ -328,6 +328,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         eng, xd = self._open(x)
         eng.enable_hmm()
         eng.hmm_skip_h(True)
+        eng.emission_target(True)        # the VB passes read the emission through the forward-backward recursions only
         self._length = xd.shape[0]
         dev = xd.device
         prior = self._prior_tensors(dev)
@@ -527,6 +528,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         eng, xd = self._open(x)
         eng.enable_hmm()
         eng.hmm_skip_h(True)
+        eng.emission_target(not viterbi)     # (the Viterbi pass reads the ln rho array)
         self._length = xd.shape[0]
         q = self._post_tensors(xd.device)
         K = self.c_num_classes

@@ -210,11 +210,12 @@ def test_viterbi_kernel_against_oracle(K, D, T):
 
 
 @pytest.mark.parametrize("K,D,T,dtype", [(32, 16, 4096, np.float32), (5, 3, 777, np.float64), (16, 16, 70001, np.float32),
-                                         (17, 9, 1, np.float64), (32, 12, 263000, np.float32)])
+                                         (17, 9, 1, np.float64), (32, 12, 263000, np.float32), (40, 16, 5000, np.float64),
+                                         (64, 7, 3001, np.float32)])
 def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
-    """hmmvb_emission_target(1): rho' and the row maxima straight from the emission kernel - the same bits as the ln rho
-    array followed by hmm_prep_kernel, so everything behind is bit-identical; no ln rho array (Viterbi / ln rho read-out
-    refuse), h = 0 in the statistics and sum gamma ln rho from the moments (ref:905 against ref:871-877) to rounding."""
+    """hmmvb_emission_target(1): rho' and the row maxima straight from the emission kernel instead of the ln rho array
+    followed by hmm_prep_kernel; no ln rho array (Viterbi / ln rho read-out refuse), h = 0 in the statistics and
+    sum gamma ln rho from the moments (ref:905 against ref:871-877) to rounding."""
     from bayesml_amd import _kside
     from bayesml_amd._engine import DataPass, EngineError
     dev = torch.device("cuda", 0)
@@ -237,7 +238,8 @@ def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
         eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
         eng.prepare_rows(xd)
         eng.enable_hmm()
-        assert eng.emission_target(fused) == fused
+        assert eng.emission_target(fused) == (fused and K <= 32)         # (in effect up to 32 states, D <= 16)
+        fused = eng.emission_fused
         eng.set_params(c, f.m, f.u)
         eng.estep(xd)
         if fused:
@@ -265,11 +267,14 @@ def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
             assert z.shape[0] == T
         eng.close()
     u, v = outs
+    # (the fused emission runs on the matrix pipe, the array form on the vector ALU: same values to rounding)
     for k in ("ms", "g0", "gl", "gamma", "alpha"):
-        assert torch.equal(u[k], v[k]), k
-    assert u["lnc"] == v["lnc"]
-    assert v["h"] == 0.0
+        assert float((u[k] - v[k]).abs().max()) <= 1e-11 * max(1.0, float(u[k].abs().max())), k
+    assert abs(u["lnc"] - v["lnc"]) <= 1e-12 * abs(u["lnc"]) + 1e-9
+    assert v["h"] == 0.0 or K > 32
     hs = 2 * K
-    assert torch.equal(u["stats"][:K], v["stats"][:K]) and torch.equal(u["stats"][hs:], v["stats"][hs:])
+    for lo, hi in ((0, K), (hs, None)):
+        a_, b_ = u["stats"][lo:hi], v["stats"][lo:hi]
+        assert float((a_ - b_).abs().max()) <= 1e-10 * float(a_.abs().max())
     assert abs(u["closed"] - u["h"]) <= 1e-11 * abs(u["h"]) + 1e-9
     assert abs(v["closed"] - u["h"]) <= 1e-11 * abs(u["h"]) + 1e-9

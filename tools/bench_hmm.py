@@ -95,7 +95,7 @@ def measure(args, dev=None):
     eng, xd = m._open(x)
     eng.enable_hmm()
     eng.hmm_skip_h(True)                                                        # as update_posterior does
-    eng.emission_target(os.environ.get("BENCH_HMM_FUSED_EMISSION") is not None)  # (developer switch: hmm.h H0 + H1, slower)
+    eng.emission_target(os.environ.get("BENCH_HMM_LN_RHO_ARRAY") is None)       # (developer switch: the ln rho array + hmm_prep_kernel)
     prior = m._prior_tensors(dev)
     q = _kside.hmm_post_from_prior(prior)
     size, a, B = m._subsample_moments(eng, xd, T)
