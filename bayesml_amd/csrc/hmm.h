@@ -17,7 +17,9 @@
 //   H3  boundary_scan  : the short sequential pass over chunks (start vector of every chunk)
 //   H4  forward_replay : 16 chunks per wave as the 16 MFMA columns, K^2 per step; writes alpha, c'
 //   H5  backward_replay: same shape, descending; writes gamma (time-major) and w
-//   H6  xi_sum         : the [K x T] x [T x K] product over time on MFMA, slabs per wave
+//   H6  xi_sum         : the [K x T] x [T x K] product over time on MFMA, slabs per wave (up to 32 states: inside H5)
+//   H0+H1 (D <= 16, K <= 32): the emission itself writes rho' and the row maxima (hmm_emission_mfma16_kernel); otherwise
+//                        hmm_prep_kernel makes them from the E-step's ln rho array
 // State vectors live in the MFMA C/D layout (state on register/lane-group, chunk on lane & 15) and the
 // contraction index of step s is taken as {16 kt + g + 4 s}, which makes the accumulator of one time
 // step directly the B operand of the next: no cross-lane movement, no LDS, in the whole recursion.
