@@ -117,3 +117,31 @@ def test_driver_protocol_and_rng_order(name):
         assert np.array_equal(quiet(m.estimate_latent_vars, xs, "0-1", True), g["viterbi_01"])
         assert np.array_equal(quiet(m.estimate_latent_vars, xs, "0-1", False), g["marginal_01"])
         assert np.max(np.abs(quiet(m.estimate_latent_vars, xs, "squared", False) - g["marginal_sq"])) < 1e-7
+
+
+@pytest.mark.parametrize("K,D,T,seed", [(4, 2, 300, 0), (7, 5, 211, 1), (3, 16, 64, 2)])
+def test_sum_gamma_ln_rho_from_the_moments(K, D, T, seed):
+    """_kside.sum_gamma_ln_rho (what the engine's HMM passes use instead of the M-step's h block, hmmvb_skip_h) against
+    (gamma_vecs * _ln_rho).sum() of ref:905, with gamma and ln rho from the oracle's restatement of ref:988-1014."""
+    import torch
+    from oracle import hmm_vb_oracle as orc
+    from bayesml_amd import _kside
+    rng = np.random.default_rng(seed)
+    x = orc.synth_hmm(K, D, T, np.float64, seed=seed)[0]
+    g = rng.normal(size=(K, D, D)) * 0.3 + np.eye(D)
+    w_inv = g @ g.transpose(0, 2, 1) * (D + 2.0)
+    q = orc.HmmPosterior(rng.uniform(1, 3, K), rng.uniform(0.5, 2, (K, K)), x[rng.integers(0, T, K)].copy(),
+                         rng.uniform(1, 3, K), rng.uniform(D + 1, D + 5, K), np.linalg.inv(w_inv), w_inv).refresh()
+    ln_rho = orc.emission_ln_rho(x, q)
+    rho = np.exp(ln_rho - ln_rho.max(axis=1, keepdims=True))
+    alpha, beta, cs = orc.forward_backward(rho, q.pi_tilde, q.a_tilde)
+    gamma = alpha * beta
+    direct = float((gamma * ln_rho).sum())
+    ns = gamma.sum(axis=0)
+    x_bar = (gamma.T @ x) / ns[:, None]
+    dev = x[:, None, :] - x_bar[None, :, :]
+    s = np.einsum("tk,tki,tkj->kij", gamma, dev, dev) / ns[:, None, None]
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)   # noqa: E731
+    f = _kside.hmm_features(_kside.HmmPostT(t(q.eta), t(q.zeta), t(q.m), t(q.kappa), t(q.nu), t(q.w_inv)))
+    closed = float(_kside.sum_gamma_ln_rho(f, t(ns), t(x_bar), t(s)))
+    assert abs(closed - direct) <= 1e-11 * abs(direct)
