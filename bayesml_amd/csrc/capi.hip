@@ -1792,7 +1792,8 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         MstepListArgs la0{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks0, r_min0,
                           ws->npad, ws->K, ws->slabs};
         // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
-        if (ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8)) {
+        static const bool list_xc = std::getenv("GMMVB_MLIST_XC") && std::getenv("GMMVB_MLIST_XC")[0] == '1';      // developer switch: the centred f64 copy
+        if (!list_xc && ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8)) {
             if (ws->sorted) {
                 la0.x32 = (const float*)ws->xp;
                 la0.ldx = ws->D;
