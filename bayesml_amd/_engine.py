@@ -70,6 +70,7 @@ SYMBOLS = {
     "hmmvb_readout": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp]),
     "hmmvb_emission_target": (_int, [_vp, _int, _vp]),
     "hmmvb_skip_h": (_int, [_vp, _int]),
+    "hmmvb_last_boundary_pass": (_int, [_vp]),
     "hmmvb_viterbi": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "gmmvb_profile_enable": (_int, [_vp, _int]),
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
@@ -506,6 +507,10 @@ class DataPass:
         """hmmvb_skip_h: the statistics of the HMM passes carry h = 0 (the caller takes sum gamma ln rho from the moments,
         ``_kside.sum_gamma_ln_rho``) and the M-step does not read the ln rho array."""
         _check(self.lib, self.lib.hmmvb_skip_h(self._ws, 1 if skip else 0), "hmmvb_skip_h")
+
+    def last_boundary_pass(self) -> int:
+        """hmmvb_last_boundary_pass: -1 chunk products, 0 the forgetting pass stood, 1 it ran and the products path behind it."""
+        return int(self.lib.hmmvb_last_boundary_pass(self._ws))
 
     def emission_target(self, fused: bool) -> bool:
         """hmmvb_emission_target: ``fused`` asks the following ``estep`` calls to write rho' straight into the

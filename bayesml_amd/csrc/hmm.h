@@ -202,7 +202,8 @@ template <int KT>
 __global__ __launch_bounds__(256) void hmm_chunk_products_kernel(const double* __restrict__ rho_tm,
                                                                  const double* __restrict__ a_tilde, int K, int64_t T,
                                                                  int64_t L, int64_t n_chunks,
-                                                                 double* __restrict__ prod /*[n_chunks][Kp][Kp] (P, natural order)*/) {
+                                                                 double* __restrict__ prod /*[n_chunks][Kp][Kp] (P, natural order)*/, const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;      // (the boundary vectors of the forgetting pass stand: hmm_capi.hip)
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __
                                                                 int64_t n_chunks, double* __restrict__ fstart,
                                                                 double* __restrict__ bend, double* __restrict__ cprime,
                                                                 double* __restrict__ alpha_tm, double* __restrict__ gamma_tm,
-                                                                double* __restrict__ w_tm) {
+                                                                double* __restrict__ w_tm, const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;      // (the boundary vectors of the forgetting pass stand: hmm_capi.hip)
     constexpr int Kp = 16 * KT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ln = lane < Kp ? lane : 0;
@@ -357,7 +359,8 @@ constexpr int kHmmLongChunk = GMMVB_HMM_LONG_CHUNK;      // chunk length of sequ
 // H3a: Q_s = P_{sG} P_{sG+1} ... (G = kHmmSuper chunks), rescaled to max 1 after every product.  One workgroup per s.
 template <int KT>
 __global__ __launch_bounds__(256) void hmm_super_products_kernel(const double* __restrict__ prod, int64_t n_chunks,
-                                                                 double* __restrict__ qprod /*[n_super][Kp][Kp]*/) {
+                                                                 double* __restrict__ qprod /*[n_super][Kp][Kp]*/, const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;      // (the boundary vectors of the forgetting pass stand: hmm_capi.hip)
     constexpr int Kp = 16 * KT, E = (Kp * Kp + 255) / 256;
     __shared__ double A[Kp * Kp], B[Kp * Kp];
     __shared__ double red[4];
@@ -404,7 +407,8 @@ template <int KT>
 __global__ __launch_bounds__(128) void hmm_boundary_fill_kernel(const double* __restrict__ prod, int64_t n_chunks,
                                                                 const double* __restrict__ fstart_s,
                                                                 const double* __restrict__ bend_s,
-                                                                double* __restrict__ fstart, double* __restrict__ bend) {
+                                                                double* __restrict__ fstart, double* __restrict__ bend, const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;      // (the boundary vectors of the forgetting pass stand: hmm_capi.hip)
     constexpr int Kp = 16 * KT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ln = lane < Kp ? lane : 0;
@@ -472,7 +476,11 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
                                                                  const double* __restrict__ a_tilde, int K, int64_t T,
                                                                  int64_t L, int64_t n_chunks,
                                                                  const double* __restrict__ fstart,
-                                                                 double* __restrict__ alpha_tm, double* __restrict__ cprime) {
+                                                                 double* __restrict__ alpha_tm, double* __restrict__ cprime,
+                                                                 int sweep = 0 /*1: no stores, chunks past the first start from the uniform vector*/,
+                                                                 double* __restrict__ end_out = nullptr /*[n_chunks][Kp]: alpha behind chunk c -> row c + 1*/,
+                                                                 const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     // kReplayChunks chunks per wave: with fewer than 16 the MFMA columns j and j + kReplayChunks carry the same chunk (only
@@ -487,8 +495,9 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
 #pragma unroll
     for (int it = 0; it < KT; ++it)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) al[it][r] = live ? fstart[c * Kp + 16 * it + g + 4 * r] : 0.0;
-    if (live && c == 0) {                                        // alpha_0 itself is part of the output
+        for (int r = 0; r < 4; ++r)
+            al[it][r] = !live ? 0.0 : ((sweep && c > 0) ? (16 * it + g + 4 * r < K ? 1.0 / K : 0.0) : fstart[c * Kp + 16 * it + g + 4 * r]);
+    if (live && c == 0 && !sweep) {                              // alpha_0 itself is part of the output
 #pragma unroll
         for (int it = 0; it < KT; ++it) *reinterpret_cast<d4*>(alpha_tm + 16 * it + 4 * g) = al[it];
     }
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
     for (int64_t s = 0; s < L; ++s) {
         const int64_t t = t0 + s;
         const bool on = live && t < T;
-        const bool st = on && first_copy;
+        const bool st = on && first_copy && !sweep;
         d4 nw[KT];
         apply<KT>(aop, al, nw);
         double part = 0.0;
@@ -520,6 +529,93 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
         }
         if (st && g == 0) cprime[t] = cp;
     }
+    if (end_out != nullptr && live && first_copy && c + 1 < n_chunks) {      // (every chunk but the last is whole)
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) end_out[(c + 1) * Kp + 16 * it + g + 4 * r] = al[it][r];
+    }
+}
+
+// The backward recursion alone (no gamma, no xi): beta~ in front of chunk c from the uniform vector behind it -> row c - 1.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_backward_sweep_kernel(const double* __restrict__ rho_tm,
+                                                                 const double* __restrict__ a_tilde, int K, int64_t T,
+                                                                 int64_t L, int64_t n_chunks, double* __restrict__ bend_out) {
+    constexpr int Kp = 16 * KT;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kReplayChunks + (j % kReplayChunks);
+    const bool live = c < n_chunks;
+    double aop[KT][KT][4];
+    load_aop<KT>(a_tilde, K, /*transpose=*/false, K, aop);
+    d4 be[KT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) be[it][r] = (live && 16 * it + g + 4 * r < K) ? 1.0 / K : 0.0;
+    const int64_t t0 = 1 + c * L;
+    for (int64_t s = L - 1; s >= 0; --s) {
+        const int64_t t = t0 + s;
+        const bool on = live && t < T;
+        d4 y[KT];
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            d4 rho = {0.0, 0.0, 0.0, 0.0};
+            if (on) rho = *reinterpret_cast<const d4*>(rho_tm + t * Kp + 16 * it + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[it][r] = rho[r] * be[it][r];
+        }
+        d4 nb[KT];
+        apply<KT>(aop, y, nb);
+        double part = 0.0;
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += nb[it][r];
+        const double tot = sum_groups(part);
+        const double inv = tot > 0.0 ? 1.0 / tot : 0.0;
+        if (on) {
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) be[it][r] = nb[it][r] * inv;
+        }
+    }
+    if (live && j < kReplayChunks && c >= 1) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bend_out[(c - 1) * Kp + 16 * it + g + 4 * r] = be[it][r];
+    }
+}
+
+// alpha_0 and c'_0 (what hmm_boundary_scan_kernel does first), and the uniform vector behind the last chunk
+__global__ __launch_bounds__(64) void hmm_alpha0_kernel(const double* __restrict__ rho_tm, const double* __restrict__ pi_tilde, int K,
+                                                       int Kp, int64_t n_chunks, double* __restrict__ fstart,
+                                                       double* __restrict__ bend, double* __restrict__ cprime) {
+    const int lane = threadIdx.x;
+    double v = lane < K ? rho_tm[hmm_pos(lane)] * pi_tilde[lane] : 0.0;
+    const double s = sum_wave(v);
+    if (lane == 0) cprime[0] = s;
+    v = s > 0.0 ? v / s : 0.0;
+    if (lane < Kp) {
+        fstart[lane] = v;
+        if (n_chunks > 0) bend[(n_chunks - 1) * Kp + lane] = lane < K ? 1.0 / K : 0.0;
+    }
+}
+
+// The forgetting pass's test: the boundary vectors the replays arrived at (started from the sweeps' vectors) against the
+// sweeps' own (started from the uniform vector).  *gate = 1 if any entry differs by more than tol: the products path runs.
+__global__ __launch_bounds__(256) void hmm_boundary_check_kernel(const double* __restrict__ fa, const double* __restrict__ fb,
+                                                                 const double* __restrict__ ba, const double* __restrict__ bb,
+                                                                 int64_t n /*entries of rows 1 .. n_chunks - 1 (forward), 0 .. n_chunks - 2 (backward)*/,
+                                                                 int Kp, double tol, int* __restrict__ gate) {
+    bool bad = false;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const double df = fabs(fa[Kp + e] - fb[Kp + e]), db = fabs(ba[e] - bb[e]);
+        bad = bad || !(df <= tol) || !(db <= tol);           // (NaN: bad)
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) *gate = 1;
 }
 
 // H5: backward replay, descending in time.  Writes gamma_tm (lane order) and w_tm; gamma_0 too.
@@ -541,7 +637,10 @@ __global__ __launch_bounds__(256, XI ? 3 : 1) void hmm_backward_replay_kernel(co
                                                                   const double* __restrict__ alpha_tm,
                                                                   const double* __restrict__ cprime,
                                                                   double* __restrict__ gamma_tm, double* __restrict__ w_tm,
-                                                                  double* __restrict__ xi_slabs = nullptr) {
+                                                                  double* __restrict__ xi_slabs = nullptr,
+                                                                  double* __restrict__ bend_out = nullptr /*beta~ in front of chunk c -> row c - 1*/,
+                                                                  const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     constexpr int LDW = hmm_xi_ldw(Kp);
     static_assert(!XI || kReplayChunks == 16, "the fused xi sum takes the 16 MFMA columns as 16 distinct chunks");
@@ -658,6 +757,12 @@ __global__ __launch_bounds__(256, XI ? 3 : 1) void hmm_backward_replay_kernel(co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) be[it][r] = nb[it][r] * inv;
         }
+    }
+    if (bend_out != nullptr && live && first_copy && c >= 1) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bend_out[(c - 1) * Kp + 16 * it + g + 4 * r] = be[it][r];
     }
     if constexpr (XI) {                                         // the term of the chunk's first step: alpha_{t0 - 1} (x) w_{t0}
         d4 al0[KT];

@@ -48,6 +48,12 @@ struct gmmvb_hmm_state {
     int64_t xi_slab_cap = 0;      // slabs xi_slabs has room for
     bool xi_separate = false;     // developer switch GMMVB_HMM_XI_SEPARATE: hmm_xi_sum_kernel as in round 3
     bool w_valid = false;         // the last pass wrote w_tm (false: the backward replay summed xi itself, hmm.h H5 XI)
+    double* fstart2 = nullptr, *bend2 = nullptr;   // [max_chunks][Kp] the replays' own boundary vectors (forgetting pass)
+    int* gate_dev = nullptr;      // 1: the forgetting pass's vectors do not stand, the products path runs
+    int* gate_host = nullptr;     // pinned copy, read when the next call begins
+    hipEvent_t gate_ev = nullptr;
+    bool gate_pending = false, spec_on = true;
+    int spec_hold = 0, last_gate = -1;   // last_gate: -1 no forgetting pass, 0 it stood, 1 products path behind it
     bool fuse_emission = false;   // hmmvb_emission_target: gmmvb_estep writes rho' / mx here (hmm.h H0 + H1) and no ln rho array
 };
 
@@ -59,6 +65,11 @@ void hmm_state_destroy(gmmvb_hmm_state* h) {
                       h->qprod,  h->fstart_s, h->bend_s, h->a_t, h->prod_t, h->qprod_t};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
+    if (h->fstart2) (void)hipFree(h->fstart2);
+    if (h->bend2) (void)hipFree(h->bend2);
+    if (h->gate_dev) (void)hipFree(h->gate_dev);
+    if (h->gate_host) (void)hipHostFree(h->gate_host);
+    if (h->gate_ev) (void)hipEventDestroy(h->gate_ev);
     if (h->phi) (void)hipFree(h->phi);
     if (h->phi16) (void)hipFree(h->phi16);
     if (h->last_state) (void)hipFree(h->last_state);
@@ -127,37 +138,79 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
                            ((size_t)Kp * (kPrepSteps + 1) + kPrepSteps) * sizeof(double), st, ws->lnrho, ws->npad, T, K, Kp,
                            h->rho_tm, h->mx);
-    if (n_chunks > 0)
-        hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
-                           h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod);
     const bool two_level = T > (int64_t(1) << 18) && L == kHmmLongChunk && n_chunks > 2 * kHmmSuper;
-    if (two_level) {
-        const int64_t n_super = (n_chunks + kHmmSuper - 1) / kHmmSuper;
-        hipLaunchKernelGGL((hmm_super_products_kernel<KT>), dim3((unsigned)n_super), dim3(256), 0, st, h->prod, n_chunks, h->qprod);
-        hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->qprod, K, n_super,
-                           h->fstart_s, h->bend_s, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
-        hipLaunchKernelGGL((hmm_boundary_fill_kernel<KT>), dim3((unsigned)n_super), dim3(128), 0, st, h->prod, n_chunks,
-                           h->fstart_s, h->bend_s, h->fstart, h->bend);
-    } else {
-        hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K,
-                           n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
-    }
     const unsigned grid = (unsigned)((n_chunks + 4 * kReplayChunks - 1) / (4 * kReplayChunks));      // kReplayChunks chunks per wave, 4 waves per block
     // the xi sum inside the backward replay (one slab per replay wave) unless the slabs do not fit / developer switch
     // (up to 32 states: with three or four 16-state blocks the accumulators no longer fit beside the operator's registers)
     const bool xi_fused = KT <= 2 && n_chunks > 0 && kReplayChunks == 16 && (int64_t)grid * 4 <= h->xi_slab_cap && !h->xi_separate;
-    if (n_chunks > 0) {
+    auto replays = [&](const double* fs, const double* be, double* f_out, double* b_out, const int* gate) {
         hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
-                           n_chunks, h->fstart, h->alpha_tm, h->cprime);
+                           n_chunks, fs, h->alpha_tm, h->cprime, 0, f_out, gate);
         if constexpr (KT <= 2 && kReplayChunks == 16) {
             if (xi_fused)
                 hipLaunchKernelGGL((hmm_backward_replay_kernel<KT, true>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
-                                   n_chunks, h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, h->xi_slabs);
+                                   n_chunks, be, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, h->xi_slabs, b_out, gate);
         }
         if (!xi_fused)
             hipLaunchKernelGGL((hmm_backward_replay_kernel<KT, false>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L,
-                               n_chunks, h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, nullptr);
+                               n_chunks, be, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, nullptr, b_out, gate);
+    };
+    // ---- the forgetting pass (round 4): chunk boundary vectors without the chunk products ------------------------------
+    // The scaled recursions forget their start vector: started from the UNIFORM vector, a chunk of 256 steps of a sequence with
+    // informative emissions ends in the same normalised alpha (beta~) as from the true one - to rounding.  So: a sweep of both
+    // recursions over all chunks from uniform starts (K^2 per step, no stores) gives every chunk a start vector, the replays
+    // run from those, and their own end vectors are compared with the sweeps': the difference IS (to first order) the error
+    // of the start vectors used, and at <= 1e-13 they stand.  Otherwise - slow mixing, flat emissions - the gate opens and
+    // the products path below runs behind it (its kernels return at once while the gate is shut), replays included: the
+    // result never depends on the forgetting.  The products are T 2 K^3 flop (10 ms of f64 MFMA at config 5), the sweeps
+    // two more passes of K^2 per step.  A call that needed the products holds the pass off for the next eight calls (the
+    // gate is copied to pinned memory and looked at when the next call begins: no synchronisation).
+    const int* gate = nullptr;
+    if (h->gate_pending && hipEventQuery(h->gate_ev) == hipSuccess) {
+        h->gate_pending = false;
+        if (*h->gate_host != 0) h->spec_hold = 8;
+        h->last_gate = *h->gate_host;
     }
+    bool spec = two_level && h->spec_on && h->gate_dev != nullptr && !h->gate_pending;
+    if (spec && h->spec_hold > 0) {
+        --h->spec_hold;
+        spec = false;
+    }
+    if (spec) {
+        (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
+        hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(64), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
+                           h->cprime);
+        hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                           h->fstart, h->alpha_tm, h->cprime, 1, h->fstart, nullptr);
+        hipLaunchKernelGGL((hmm_backward_sweep_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                           h->bend);
+        replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
+        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+                           (n_chunks - 1) * Kp, Kp, 1e-13, h->gate_dev);
+        (void)hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st);
+        (void)hipEventRecord(h->gate_ev, st);
+        h->gate_pending = true;
+        gate = h->gate_dev;
+    } else {
+        h->last_gate = -1;
+    }
+    // ---- the products path (behind the gate, if the forgetting pass ran) -----------------------------------------------
+    if (n_chunks > 0)
+        hipLaunchKernelGGL((hmm_chunk_products_kernel<KT>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st,
+                           h->rho_tm, a_tilde, K, T, L, n_chunks, h->prod, gate);
+    if (two_level) {
+        const int64_t n_super = (n_chunks + kHmmSuper - 1) / kHmmSuper;
+        hipLaunchKernelGGL((hmm_super_products_kernel<KT>), dim3((unsigned)n_super), dim3(256), 0, st, h->prod, n_chunks, h->qprod,
+                           gate);
+        hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->qprod, K, n_super,
+                           h->fstart_s, h->bend_s, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm, gate);
+        hipLaunchKernelGGL((hmm_boundary_fill_kernel<KT>), dim3((unsigned)n_super), dim3(128), 0, st, h->prod, n_chunks,
+                           h->fstart_s, h->bend_s, h->fstart, h->bend, gate);
+    } else {
+        hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K,
+                           n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+    }
+    if (n_chunks > 0) replays(h->fstart, h->bend, nullptr, nullptr, gate);
     h->w_valid = !xi_fused;
     // xi sum over t = 1 .. T-1
     int64_t n_waves = h->xi_waves;
@@ -311,7 +364,8 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         {&h->qprod, (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp}, {&h->fstart_s, (h->max_chunks / kHmmSuper + 2) * h->Kp},
         {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0},
         {&h->prod_t, h->wide ? h->max_chunks * h->Kp * h->Kp : 0},
-        {&h->qprod_t, h->wide ? (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp : 0}};
+        {&h->qprod_t, h->wide ? (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp : 0},
+        {&h->fstart2, h->generic ? 0 : h->max_chunks * h->Kp}, {&h->bend2, h->generic ? 0 : h->max_chunks * h->Kp}};
     for (auto& b : bufs) {
         if (b.n == 0) continue;
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
@@ -328,6 +382,13 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         h->bytes += h->npad * h->Kp;
     }
     if (e2 == hipSuccess) e2 = hipMalloc((void**)&h->last_state, sizeof(int));
+    if (e2 == hipSuccess && !h->generic) {      // the forgetting pass's gate (run<KT>): device flag, pinned copy, event
+        h->spec_on = std::getenv("GMMVB_HMM_FORGETTING_OFF") == nullptr;
+        e2 = hipMalloc((void**)&h->gate_dev, sizeof(int));
+        if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, sizeof(int));
+        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&h->gate_ev, hipEventDisableTiming);
+        if (e2 == hipSuccess) *h->gate_host = 0;
+    }
     if (e2 != hipSuccess) {
         hmm_state_destroy(h);
         return fail(GMMVB_ENOMEM, "hipMalloc (Viterbi buffers)", e2);
@@ -468,6 +529,18 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "viterbi launch", e);
     return GMMVB_OK;
+}
+
+int hmmvb_last_boundary_pass(gmmvb_workspace* ws) {
+    if (!ws || !ws->hmm) return -2;
+    gmmvb_hmm_state* h = ws->hmm;
+    if (h->gate_pending) {
+        if (hipEventSynchronize(h->gate_ev) != hipSuccess) return -2;
+        h->gate_pending = false;
+        if (*h->gate_host != 0) h->spec_hold = 8;
+        h->last_gate = *h->gate_host;
+    }
+    return h->last_gate;
 }
 
 int hmmvb_skip_h(gmmvb_workspace* ws, int skip) {

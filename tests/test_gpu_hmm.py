@@ -278,3 +278,60 @@ def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
         assert float((a_ - b_).abs().max()) <= 1e-10 * float(a_.abs().max())
     assert abs(u["closed"] - u["h"]) <= 1e-11 * abs(u["h"]) + 1e-9
     assert abs(v["closed"] - u["h"]) <= 1e-11 * abs(u["h"]) + 1e-9
+
+
+@pytest.mark.parametrize("K,D,flat", [(32, 16, False), (8, 3, False), (5, 2, True), (48, 8, False)])
+def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
+    """Sequences past 2^18 steps: chunk boundary vectors from sweeps started at the uniform vector (the scaled recursions
+    forget their start), checked against the replays' own and replaced by the chunk-product path when they do not stand.
+    Informative emissions: the pass stands (0) and the results are those of the products path; flat emissions and a sticky
+    chain: the gate opens (1), the products path runs behind it - same results -, and the next calls go straight to it (-1)."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    dev = torch.device("cuda", 0)
+    T = 270001
+    x, _ = orc.synth_hmm(K, D, T, np.float32, seed=11)
+    rng = np.random.default_rng(13)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
+    m = t(x[rng.integers(0, T, K)].astype(np.float64))
+    scale = 4000.0 if flat else 1.0                     # (flat: every component covers the whole data set)
+    w_inv = t(np.broadcast_to(np.eye(D) * (D + 3.0) * scale, (K, D, D)).copy())
+    f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), m, t(np.full(K, 2.0)),
+                                     t(np.full(K, D + 3.0)), w_inv))
+    c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
+    stay = 0.9999 if flat else 0.9
+    a = t(np.eye(K) * stay + (1.0 - stay) / K)
+    pi = t(rng.dirichlet(np.ones(K)))
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+    def run(forgetting, calls=1):
+        if forgetting:
+            monkeypatch.delenv("GMMVB_HMM_FORGETTING_OFF", raising=False)
+        else:
+            monkeypatch.setenv("GMMVB_HMM_FORGETTING_OFF", "1")
+        eng = DataPass(K, D, xd.dtype, T, dev)
+        eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+        eng.prepare_rows(xd)
+        eng.enable_hmm()
+        eng.set_params(c, f.m, f.u)
+        how = []
+        for _ in range(calls):
+            eng.estep(xd)
+            ms, g0, gl, lnc = eng.forward_backward(pi, a)
+            how.append(eng.last_boundary_pass())
+        stats = eng.mstep(xd).clone()
+        out = dict(ms=ms.clone(), g0=g0.clone(), gl=gl.clone(), lnc=float(lnc), stats=stats,
+                   gamma=torch.cat([eng.responsibilities(0, 600), eng.responsibilities(T // 2, 600),
+                                    eng.responsibilities(T - 600, 600)]).clone(),
+                   alpha=eng.hmm_readout("alpha", 255, 600).clone())
+        eng.close()
+        return out, how
+
+    ref, how0 = run(False)
+    got, how1 = run(True, calls=3)
+    assert how0 == [-1]
+    assert how1 == ([1, -1, -1] if flat else [0, 0, 0]), how1
+    for k in ("ms", "g0", "gl", "gamma", "alpha", "stats"):
+        scale_k = max(1.0, float(ref[k].abs().max()))
+        assert float((ref[k] - got[k]).abs().max()) <= 1e-10 * scale_k, k
+    assert abs(ref["lnc"] - got["lnc"]) <= 1e-11 * abs(ref["lnc"])
