@@ -589,18 +589,22 @@ __global__ __launch_bounds__(256) void hmm_backward_sweep_kernel(const double* _
     }
 }
 
-// alpha_0 and c'_0 (what hmm_boundary_scan_kernel does first), and the uniform vector behind the last chunk
-__global__ __launch_bounds__(64) void hmm_alpha0_kernel(const double* __restrict__ rho_tm, const double* __restrict__ pi_tilde, int K,
-                                                       int Kp, int64_t n_chunks, double* __restrict__ fstart,
-                                                       double* __restrict__ bend, double* __restrict__ cprime) {
-    const int lane = threadIdx.x;
-    double v = lane < K ? rho_tm[hmm_pos(lane)] * pi_tilde[lane] : 0.0;
-    const double s = sum_wave(v);
-    if (lane == 0) cprime[0] = s;
+// alpha_0 and c'_0 (what hmm_boundary_scan_kernel does first), and the uniform vector behind the last chunk (K <= 256)
+__global__ __launch_bounds__(256) void hmm_alpha0_kernel(const double* __restrict__ rho_tm, const double* __restrict__ pi_tilde, int K,
+                                                        int Kp, int64_t n_chunks, double* __restrict__ fstart,
+                                                        double* __restrict__ bend, double* __restrict__ cprime) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double v = tid < K ? rho_tm[hmm_pos(tid)] * pi_tilde[tid] : 0.0;
+    const double w = sum_wave(v);
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+    __syncthreads();
+    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) cprime[0] = s;
     v = s > 0.0 ? v / s : 0.0;
-    if (lane < Kp) {
-        fstart[lane] = v;
-        if (n_chunks > 0) bend[(n_chunks - 1) * Kp + lane] = lane < K ? 1.0 / K : 0.0;
+    if (tid < Kp) {
+        fstart[tid] = v;
+        if (n_chunks > 0) bend[(n_chunks - 1) * Kp + tid] = tid < K ? 1.0 / K : 0.0;
     }
 }
 

@@ -117,6 +117,9 @@ hipError_t hmm_ensure_gamma_cm(gmmvb_hmm_state* h, hipStream_t st) {
 namespace {
 
 constexpr int kLncBlocks = 1024;
+// the forgetting pass stands if no entry of a (sum-1 normalised) boundary vector moves by more than this when its chunk is
+// started from the sweep's vector instead of the uniform one: a fully forgotten start leaves rounding noise of ~1e-15
+constexpr double kHmmForgetTol = 2e-14;
 
 // chunk length: balances the sequential boundary scan (T/L steps of ~1.5 us) against the replay depth
 // (L steps of ~4 us forward+backward): L ~ sqrt(T * 1.5 / 4), a power of two in [16, 4096]
@@ -160,7 +163,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     // informative emissions ends in the same normalised alpha (beta~) as from the true one - to rounding.  So: a sweep of both
     // recursions over all chunks from uniform starts (K^2 per step, no stores) gives every chunk a start vector, the replays
     // run from those, and their own end vectors are compared with the sweeps': the difference IS (to first order) the error
-    // of the start vectors used, and at <= 1e-13 they stand.  Otherwise - slow mixing, flat emissions - the gate opens and
+    // of the start vectors used, and at <= 2e-14 (kHmmForgetTol) they stand.  Otherwise - slow mixing, flat emissions - the gate opens and
     // the products path below runs behind it (its kernels return at once while the gate is shut), replays included: the
     // result never depends on the forgetting.  The products are T 2 K^3 flop (10 ms of f64 MFMA at config 5), the sweeps
     // two more passes of K^2 per step.  A call that needed the products holds the pass off for the next eight calls (the
@@ -178,7 +181,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     }
     if (spec) {
         (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
-        hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(64), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
+        hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(256), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
                            h->cprime);
         hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
                            h->fstart, h->alpha_tm, h->cprime, 1, h->fstart, nullptr);
@@ -186,7 +189,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
                            h->bend);
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
         hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
-                           (n_chunks - 1) * Kp, Kp, 1e-13, h->gate_dev);
+                           (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
         (void)hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st);
         (void)hipEventRecord(h->gate_ev, st);
         h->gate_pending = true;
@@ -256,31 +259,65 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(hmm_prep_generic_kernel, dim3((unsigned)((T + 63) / 64)), dim3(256), 0, st, ws->lnrho, ws->npad, T, K, Kp,
                        h->rho_tm, h->mx);
+    const unsigned grid = (unsigned)((n_chunks + 63) / 64);          // 16 chunks per wave, 4 waves per workgroup
+    auto replays = [&](const double* fs, const double* be, double* f_out, double* b_out, const int* gate) {
+        hipLaunchKernelGGL((hmm_forward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                           fs, h->alpha_tm, h->cprime, 0, f_out, gate);
+        hipLaunchKernelGGL((hmm_backward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                           be, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, 0, b_out, gate);
+    };
+    // the forgetting pass (run<KT> above): here the products are 85 % of the iteration (T 2 Kp^3 flop)
+    const bool two_level = n_chunks > 2 * kHmmSuper;
+    const int* gate = nullptr;
+    if (h->gate_pending && hipEventQuery(h->gate_ev) == hipSuccess) {
+        h->gate_pending = false;
+        if (*h->gate_host != 0) h->spec_hold = 8;
+        h->last_gate = *h->gate_host;
+    }
+    bool spec = two_level && h->spec_on && h->gate_dev != nullptr && !h->gate_pending;
+    if (spec && h->spec_hold > 0) {
+        --h->spec_hold;
+        spec = false;
+    }
+    if (spec) {
+        (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
+        hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(256), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
+                           h->cprime);
+        hipLaunchKernelGGL((hmm_forward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                           h->fstart, h->alpha_tm, h->cprime, 1, h->fstart, nullptr);
+        hipLaunchKernelGGL((hmm_backward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                           h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, 1, h->bend, nullptr);
+        replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
+        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+                           (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
+        (void)hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st);
+        (void)hipEventRecord(h->gate_ev, st);
+        h->gate_pending = true;
+        gate = h->gate_dev;
+    } else {
+        h->last_gate = -1;
+    }
     hipLaunchKernelGGL((hmm_chunk_products_wide_kernel<KT>), dim3((unsigned)n_chunks), dim3(256), fb + 64, st, h->rho_tm, a_tilde, K,
-                       T, L, n_chunks, h->prod, h->prod_t);
-    if (n_chunks > 2 * kHmmSuper) {
+                       T, L, n_chunks, h->prod, h->prod_t, gate);
+    if (two_level) {
         // two levels: products of 64 chunk products, the sequential pass over those, every super-chunk fills in its own chunks
         const int64_t n_super = (n_chunks + kHmmSuper - 1) / kHmmSuper;
         e = seq_lds(hmm_super_products_wide_kernel<KT>, fb + 64);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((hmm_super_products_wide_kernel<KT>), dim3((unsigned)n_super), dim3(256), fb + 64, st, h->prod_t, n_chunks,
-                           h->qprod, h->qprod_t);
+                           h->qprod, h->qprod_t, gate);
         hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(1, 2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde,
                            h->qprod, h->qprod_t, K, n_super, nullptr, nullptr, h->fstart_s, h->bend_s, h->cprime, h->alpha_tm,
-                           h->gamma_tm, h->w_tm);
+                           h->gamma_tm, h->w_tm, gate);
         hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3((unsigned)n_super, 2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm,
                            pi_tilde, h->prod, h->prod_t, K, n_chunks, h->fstart_s, h->bend_s, h->fstart, h->bend, h->cprime,
-                           h->alpha_tm, h->gamma_tm, h->w_tm);
+                           h->alpha_tm, h->gamma_tm, h->w_tm, gate);
     } else {
         hipLaunchKernelGGL((hmm_boundary_scan_wide_kernel<KT>), dim3(1, 2), dim3(kHmmWideScanThreads), 0, st, h->rho_tm, pi_tilde,
                            h->prod, h->prod_t, K, n_chunks, nullptr, nullptr, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm,
                            h->w_tm);
     }
-    const unsigned grid = (unsigned)((n_chunks + 63) / 64);          // 16 chunks per wave, 4 waves per workgroup
-    hipLaunchKernelGGL((hmm_forward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
-                       h->fstart, h->alpha_tm, h->cprime);
-    hipLaunchKernelGGL((hmm_backward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
-                       h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+    replays(h->fstart, h->bend, nullptr, nullptr, gate);
     const int64_t steps = round_up((T - 1 + h->xi_waves - 1) / h->xi_waves, 4);
     const int64_t n_slabs = (T - 1 + steps - 1) / steps;
     hipLaunchKernelGGL((hmm_xi_sum_wide_kernel<KT>), dim3((unsigned)n_slabs), dim3(256), 0, st, h->alpha_tm, h->w_tm, T, steps,
@@ -365,7 +402,8 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0},
         {&h->prod_t, h->wide ? h->max_chunks * h->Kp * h->Kp : 0},
         {&h->qprod_t, h->wide ? (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp : 0},
-        {&h->fstart2, h->generic ? 0 : h->max_chunks * h->Kp}, {&h->bend2, h->generic ? 0 : h->max_chunks * h->Kp}};
+        {&h->fstart2, h->generic && !h->wide ? 0 : h->max_chunks * h->Kp},
+        {&h->bend2, h->generic && !h->wide ? 0 : h->max_chunks * h->Kp}};
     for (auto& b : bufs) {
         if (b.n == 0) continue;
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
@@ -382,7 +420,7 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         h->bytes += h->npad * h->Kp;
     }
     if (e2 == hipSuccess) e2 = hipMalloc((void**)&h->last_state, sizeof(int));
-    if (e2 == hipSuccess && !h->generic) {      // the forgetting pass's gate (run<KT>): device flag, pinned copy, event
+    if (e2 == hipSuccess && (!h->generic || h->wide)) {      // the forgetting pass's gate (run<KT>, run_wide): device flag, pinned copy, event
         h->spec_on = std::getenv("GMMVB_HMM_FORGETTING_OFF") == nullptr;
         e2 = hipMalloc((void**)&h->gate_dev, sizeof(int));
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, sizeof(int));

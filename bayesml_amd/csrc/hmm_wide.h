@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void hmm_chunk_products_wide_kernel(const doub
                                                                       const double* __restrict__ a_tilde, int K, int64_t T,
                                                                       int64_t L, int64_t n_chunks,
                                                                       double* __restrict__ prod /*[n_chunks][Kp][Kp]*/,
-                                                                      double* __restrict__ prod_t /*the transposes*/) {
+                                                                      double* __restrict__ prod_t /*the transposes*/,
+    const int* __restrict__ gate = nullptr /*hmm.h: the forgetting pass stands -> nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT, JPW = (KT + 3) / 4;
     extern __shared__ double frag[];                      // fragments, then [2][4] maxima
     double* smax = frag + KT * KT * 4 * 64;
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(256) void hmm_chunk_products_wide_kernel(const doub
 // kernel with the step's operand changing: R^T <- P_c^T R^T, the fragments of P_c^T restaged into LDS for every chunk.
 template <int KT>
 __global__ __launch_bounds__(256) void hmm_super_products_wide_kernel(const double* __restrict__ prod_t, int64_t n_chunks,
-                                                                      double* __restrict__ qprod, double* __restrict__ qprod_t) {
+                                                                      double* __restrict__ qprod, double* __restrict__ qprod_t,
+    const int* __restrict__ gate = nullptr /*hmm.h: the forgetting pass stands -> nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT, JPW = (KT + 3) / 4;
     extern __shared__ double frag[];
     double* smax = frag + KT * KT * 4 * 64;
@@ -215,7 +219,9 @@ __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_boundary_scan_wide_ke
     const double* __restrict__ rho_tm, const double* __restrict__ pi_tilde, const double* __restrict__ prod,
     const double* __restrict__ prod_t, int K, int64_t n_chunks, const double* __restrict__ in_f, const double* __restrict__ in_b,
     double* __restrict__ fstart, double* __restrict__ bend, double* __restrict__ cprime,
-    double* __restrict__ alpha_tm, double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
+    double* __restrict__ alpha_tm, double* __restrict__ gamma_tm, double* __restrict__ w_tm,
+    const int* __restrict__ gate = nullptr /*hmm.h: the forgetting pass stands -> nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT, PARTS = kHmmWideScanThreads / 128, JP = Kp / PARTS;      // JP contraction indices per thread
     static_assert(Kp <= 128 && Kp % PARTS == 0, "up to 128 states");
     __shared__ double sv[128];
@@ -319,7 +325,11 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_wide_kernel(const doub
                                                                       const double* __restrict__ a_tilde, int K, int64_t T,
                                                                       int64_t L, int64_t n_chunks,
                                                                       const double* __restrict__ fstart,
-                                                                      double* __restrict__ alpha_tm, double* __restrict__ cprime) {
+                                                                      double* __restrict__ alpha_tm, double* __restrict__ cprime,
+                                                                      int sweep = 0 /*hmm.h: hmm_forward_replay_kernel*/,
+                                                                      double* __restrict__ end_out = nullptr,
+                                                                      const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     extern __shared__ double frag[];
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -330,8 +340,9 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_wide_kernel(const doub
 #pragma unroll
     for (int it = 0; it < KT; ++it)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) al[it][r] = live ? fstart[c * Kp + 16 * it + g + 4 * r] : 0.0;
-    if (live && c == 0) {
+        for (int r = 0; r < 4; ++r)
+            al[it][r] = !live ? 0.0 : ((sweep && c > 0) ? (16 * it + g + 4 * r < K ? 1.0 / K : 0.0) : fstart[c * Kp + 16 * it + g + 4 * r]);
+    if (live && c == 0 && !sweep) {
 #pragma unroll
         for (int it = 0; it < KT; ++it) *reinterpret_cast<d4*>(alpha_tm + 16 * it + 4 * g) = al[it];
     }
@@ -358,9 +369,15 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_wide_kernel(const doub
         for (int it = 0; it < KT; ++it) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) al[it][r] = nw[it][r] * inv;
-            if (on) *reinterpret_cast<d4*>(alpha_tm + t * Kp + 16 * it + 4 * g) = al[it];
+            if (on && !sweep) *reinterpret_cast<d4*>(alpha_tm + t * Kp + 16 * it + 4 * g) = al[it];
         }
-        if (on && g == 0) cprime[t] = cp;
+        if (on && !sweep && g == 0) cprime[t] = cp;
+    }
+    if (end_out != nullptr && live && c + 1 < n_chunks) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) end_out[(c + 1) * Kp + 16 * it + g + 4 * r] = al[it][r];
     }
 }
 
@@ -372,7 +389,11 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_wide_kernel(const dou
                                                                        const double* __restrict__ bend,
                                                                        const double* __restrict__ alpha_tm,
                                                                        const double* __restrict__ cprime,
-                                                                       double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
+                                                                       double* __restrict__ gamma_tm, double* __restrict__ w_tm,
+                                                                       int sweep = 0 /*1: the recursion alone from uniform vectors, no loads of alpha, no stores*/,
+                                                                       double* __restrict__ bend_out = nullptr /*beta~ in front of chunk c -> row c - 1*/,
+                                                                       const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     extern __shared__ double frag[];
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -383,7 +404,8 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_wide_kernel(const dou
 #pragma unroll
     for (int it = 0; it < KT; ++it)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) be[it][r] = live ? bend[c * Kp + 16 * it + g + 4 * r] : 0.0;
+        for (int r = 0; r < 4; ++r)
+            be[it][r] = !live ? 0.0 : (sweep ? (16 * it + g + 4 * r < K ? 1.0 / K : 0.0) : bend[c * Kp + 16 * it + g + 4 * r]);
     const int64_t t0 = 1 + c * L;
     for (int64_t s = L - 1; s >= 0; --s) {
         const int64_t t = t0 + s;
@@ -396,14 +418,14 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_wide_kernel(const dou
             al[it] = d4{0.0, 0.0, 0.0, 0.0};
             rho[it] = d4{0.0, 0.0, 0.0, 0.0};
             if (on) {
-                al[it] = *reinterpret_cast<const d4*>(alpha_tm + t * Kp + 16 * it + 4 * g);
+                if (!sweep) al[it] = *reinterpret_cast<const d4*>(alpha_tm + t * Kp + 16 * it + 4 * g);
                 rho[it] = *reinterpret_cast<const d4*>(rho_tm + t * Kp + 16 * it + 4 * g);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) dot = fma(al[it][r], be[it][r], dot);
         }
-        dot = sum_groups(dot);
-        const double cp = on ? cprime[t] : 1.0;
+        if (!sweep) dot = sum_groups(dot);
+        const double cp = (on && !sweep) ? cprime[t] : 1.0;
         const double ginv = dot > 0.0 ? 1.0 / dot : 0.0;
         const double winv = (dot > 0.0 && cp > 0.0) ? 1.0 / (dot * cp) : 0.0;
 #pragma unroll
@@ -415,7 +437,7 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_wide_kernel(const dou
                 gm[r] = al[it][r] * be[it][r] * ginv;
                 ww[r] = y[it][r] * winv;
             }
-            if (on) {
+            if (on && !sweep) {
                 *reinterpret_cast<d4*>(gamma_tm + t * Kp + 16 * it + 4 * g) = gm;
                 *reinterpret_cast<d4*>(w_tm + t * Kp + 16 * it + 4 * g) = ww;
             }
@@ -436,7 +458,13 @@ __global__ __launch_bounds__(256) void hmm_backward_replay_wide_kernel(const dou
                 for (int r = 0; r < 4; ++r) be[it][r] = nb[it][r] * inv;
         }
     }
-    if (live && c == 0) {                                       // gamma_0 = alpha_0 o beta~_0, normalised
+    if (bend_out != nullptr && live && c >= 1) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bend_out[(c - 1) * Kp + 16 * it + g + 4 * r] = be[it][r];
+    }
+    if (live && c == 0 && !sweep) {                             // gamma_0 = alpha_0 o beta~_0, normalised
         double dot = 0.0;
         d4 al[KT];
 #pragma unroll
