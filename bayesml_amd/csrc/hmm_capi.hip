@@ -45,6 +45,7 @@ struct gmmvb_hmm_state {
     double* a_t = nullptr;        // [K][K] transpose of A~
     unsigned short* phi16 = nullptr;   // [npad][K] back-pointers, natural order
     int64_t bytes = 0;
+    int64_t vec_chunks = 0;       // rows of fstart / bend / fstart2 / bend2
     int64_t xi_slab_cap = 0;      // slabs xi_slabs has room for
     bool xi_separate = false;     // developer switch GMMVB_HMM_XI_SEPARATE: hmm_xi_sum_kernel as in round 3
     bool w_valid = false;         // the last pass wrote w_tm (false: the backward replay summed xi itself, hmm.h H5 XI)
@@ -120,6 +121,7 @@ constexpr int kLncBlocks = 1024;
 // the forgetting pass stands if no entry of a (sum-1 normalised) boundary vector moves by more than this when its chunk is
 // started from the sweep's vector instead of the uniform one: a fully forgotten start leaves rounding noise of ~1e-15
 constexpr double kHmmForgetTol = 2e-14;
+constexpr int64_t kHmmGenericChunk = 256;      // more than 128 states: steps per workgroup in the forgetting pass
 
 // chunk length: balances the sequential boundary scan (T/L steps of ~1.5 us) against the replay depth
 // (L steps of ~4 us forward+backward): L ~ sqrt(T * 1.5 / 4), a power of two in [16, 4096]
@@ -342,10 +344,48 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
     hipLaunchKernelGGL(hmm_prep_generic_kernel, dim3((unsigned)((T + 63) / 64)), dim3(256), 0, st, ws->lnrho, ws->npad, T, K, Kp,
                        h->rho_tm, h->mx);
     hipLaunchKernelGGL(hmm_transpose_kernel, dim3((unsigned)((K * K + 255) / 256)), dim3(256), 0, st, a_tilde, K, h->a_t);
+    // The forgetting pass (run<KT>): the same two kernels in their chunk form, a workgroup per 256 steps - sweeps from the
+    // uniform vector, replays from the sweeps' vectors, the test - and the walk of the whole sequence by ONE workgroup
+    // (seconds per million steps) only behind the gate.  Sequences of at least 64 chunks.
+    const int64_t L = kHmmGenericChunk;
+    const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
+    const int* gate = nullptr;
+    if (h->gate_pending && hipEventQuery(h->gate_ev) == hipSuccess) {
+        h->gate_pending = false;
+        if (*h->gate_host != 0) h->spec_hold = 8;
+        h->last_gate = *h->gate_host;
+    }
+    bool spec = h->spec_on && h->gate_dev != nullptr && !h->gate_pending && n_chunks >= 64 && n_chunks <= h->vec_chunks;
+    if (spec && h->spec_hold > 0) {
+        --h->spec_hold;
+        spec = false;
+    }
+    if (spec) {
+        const unsigned g = (unsigned)n_chunks;
+        (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
+        hipLaunchKernelGGL(hmm_seq_forward_kernel, dim3(g), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, pi_tilde, a_tilde, K,
+                           Kp, T, sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->fstart, 1, h->fstart,
+                           nullptr);
+        hipLaunchKernelGGL(hmm_seq_backward_kernel, dim3(g), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, h->a_t, K, Kp, T,
+                           sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->bend, 1, h->bend, nullptr);
+        hipLaunchKernelGGL(hmm_seq_forward_kernel, dim3(g), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, pi_tilde, a_tilde, K,
+                           Kp, T, sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->fstart, 0, h->fstart2,
+                           nullptr);
+        hipLaunchKernelGGL(hmm_seq_backward_kernel, dim3(g), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, h->a_t, K, Kp, T,
+                           sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->bend, 0, h->bend2, nullptr);
+        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+                           (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
+        (void)hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st);
+        (void)hipEventRecord(h->gate_ev, st);
+        h->gate_pending = true;
+        gate = h->gate_dev;
+    } else {
+        h->last_gate = -1;
+    }
     hipLaunchKernelGGL(hmm_seq_forward_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, pi_tilde, a_tilde, K, Kp,
-                       T, sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+                       T, sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, 0, nullptr, 0, nullptr, gate);
     hipLaunchKernelGGL(hmm_seq_backward_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, h->a_t, K, Kp, T, sh.P,
-                       sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm);
+                       sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, 0, nullptr, 0, nullptr, gate);
     int64_t n_slabs = 0;
     if (T > 1) {
         const int64_t steps = (T - 1 + h->xi_waves - 1) / h->xi_waves;
@@ -392,18 +432,20 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     h->xi_slab_cap = std::max<int64_t>(h->xi_waves + 4, h->generic ? 0 : h->npad / (16 * kHmmLongChunk) + 72);
     h->xi_separate = std::getenv("GMMVB_HMM_XI_SEPARATE") != nullptr;
     const int64_t tk = h->npad * h->Kp;
+    // chunk boundary vectors: more than 128 states walk chunks of kHmmGenericChunk steps in the forgetting pass (run_generic)
+    const int64_t vec_chunks = (h->generic && !h->wide) ? h->npad / kHmmGenericChunk + 2 : h->max_chunks;
+    h->vec_chunks = vec_chunks;
     struct { double** p; int64_t n; } bufs[] = {
         {&h->rho_tm, tk}, {&h->alpha_tm, tk}, {&h->gamma_tm, tk}, {&h->w_tm, tk},
         {&h->gamma_cm, (int64_t)ws->K * h->npad}, {&h->mx, h->npad}, {&h->cprime, h->npad},
-        {&h->prod, h->max_chunks * h->Kp * h->Kp}, {&h->fstart, h->max_chunks * h->Kp},
-        {&h->bend, h->max_chunks * h->Kp}, {&h->xi_slabs, h->xi_slab_cap * h->Kp * h->Kp},
+        {&h->prod, h->max_chunks * h->Kp * h->Kp}, {&h->fstart, vec_chunks * h->Kp},
+        {&h->bend, vec_chunks * h->Kp}, {&h->xi_slabs, h->xi_slab_cap * h->Kp * h->Kp},
         {&h->lnc_partial, kLncBlocks},
         {&h->qprod, (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp}, {&h->fstart_s, (h->max_chunks / kHmmSuper + 2) * h->Kp},
         {&h->bend_s, (h->max_chunks / kHmmSuper + 2) * h->Kp}, {&h->a_t, h->generic ? (int64_t)ws->K * ws->K : 0},
         {&h->prod_t, h->wide ? h->max_chunks * h->Kp * h->Kp : 0},
         {&h->qprod_t, h->wide ? (h->max_chunks / kHmmSuper + 2) * h->Kp * h->Kp : 0},
-        {&h->fstart2, h->generic && !h->wide ? 0 : h->max_chunks * h->Kp},
-        {&h->bend2, h->generic && !h->wide ? 0 : h->max_chunks * h->Kp}};
+        {&h->fstart2, vec_chunks * h->Kp}, {&h->bend2, vec_chunks * h->Kp}};
     for (auto& b : bufs) {
         if (b.n == 0) continue;
         hipError_t e = hipMalloc((void**)b.p, (size_t)b.n * sizeof(double));
@@ -420,7 +462,11 @@ int hmmvb_enable(gmmvb_workspace* ws) {
         h->bytes += h->npad * h->Kp;
     }
     if (e2 == hipSuccess) e2 = hipMalloc((void**)&h->last_state, sizeof(int));
-    if (e2 == hipSuccess && (!h->generic || h->wide)) {      // the forgetting pass's gate (run<KT>, run_wide): device flag, pinned copy, event
+    if (e2 == hipSuccess && h->generic && !h->wide) {        // (their padding entries are never written and are compared)
+        for (double* p : {h->fstart, h->bend, h->fstart2, h->bend2})
+            if (e2 == hipSuccess) e2 = hipMemset(p, 0, (size_t)(vec_chunks * h->Kp) * sizeof(double));
+    }
+    if (e2 == hipSuccess) {      // the forgetting pass's gate (run<KT>, run_wide, run_generic): device flag, pinned copy, event
         h->spec_on = std::getenv("GMMVB_HMM_FORGETTING_OFF") == nullptr;
         e2 = hipMalloc((void**)&h->gate_dev, sizeof(int));
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, sizeof(int));

@@ -109,7 +109,15 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_forward_kernel(const d
                                                                          int64_t T, int P, int J, int mat_in_lds,
                                                                          double* __restrict__ alpha_tm,
                                                                          double* __restrict__ cprime,
-                                                                         double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
+                                                                         double* __restrict__ gamma_tm, double* __restrict__ w_tm,
+                                                                         // chunk form (L > 0; hmm.h: the forgetting pass): workgroup c
+                                                                         // walks steps 1 + c L .. from fstart[c] (natural order) - or,
+                                                                         // sweep, from the uniform vector, storing nothing - and leaves
+                                                                         // its last alpha in end_out[c + 1]
+                                                                         int64_t L = 0, const double* __restrict__ fstart = nullptr,
+                                                                         int sweep = 0, double* __restrict__ end_out = nullptr,
+                                                                         const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     extern __shared__ double sh[];
     double* va = sh;                       // [K] alpha_{t-1}
     double* vb = va + K;                   // [K] alpha_{t-1} A~
@@ -122,33 +130,43 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_forward_kernel(const d
         for (int e = tid; e < K * K; e += kHmmSeqThreads) mat_l[e] = a_tilde[e];
         mat = mat_l;
     }
-    double v = 0.0;
-    for (int k = tid; k < K; k += kHmmSeqThreads) v += rho_tm[hmm_pos(k)] * pi_tilde[k];
-    const double s = block_sum_1024(v, red);
-    for (int k = tid; k < K; k += kHmmSeqThreads) {
-        const double a0 = rho_tm[hmm_pos(k)] * pi_tilde[k];
-        const double an = s > 0.0 ? a0 / s : 0.0;
-        va[k] = an;
-        alpha_tm[hmm_pos(k)] = an;
-        if (T == 1) {
-            gamma_tm[hmm_pos(k)] = an;
-            w_tm[hmm_pos(k)] = 0.0;
+    const int64_t chunk = L > 0 ? (int64_t)blockIdx.x : 0;
+    const int64_t t_lo = 1 + chunk * L, t_hi = (L > 0 && t_lo + L < T) ? t_lo + L : T;
+    if (chunk == 0) {
+        double v = 0.0;
+        for (int k = tid; k < K; k += kHmmSeqThreads) v += rho_tm[hmm_pos(k)] * pi_tilde[k];
+        const double s = block_sum_1024(v, red);
+        for (int k = tid; k < K; k += kHmmSeqThreads) {
+            const double a0 = rho_tm[hmm_pos(k)] * pi_tilde[k];
+            const double an = s > 0.0 ? a0 / s : 0.0;
+            va[k] = an;
+            if (!sweep) {
+                alpha_tm[hmm_pos(k)] = an;
+                if (T == 1) {
+                    gamma_tm[hmm_pos(k)] = an;
+                    w_tm[hmm_pos(k)] = 0.0;
+                }
+            }
         }
+        if (!sweep) {
+            for (int k = K + tid; k < Kp; k += kHmmSeqThreads) {          // padding states of the last block of 16
+                alpha_tm[hmm_pos(k)] = 0.0;
+                if (T == 1) gamma_tm[hmm_pos(k)] = w_tm[hmm_pos(k)] = 0.0;
+            }
+            if (tid == 0) cprime[0] = s;
+        }
+    } else {
+        for (int k = tid; k < K; k += kHmmSeqThreads) va[k] = sweep ? 1.0 / K : fstart[chunk * Kp + k];
     }
-    for (int k = K + tid; k < Kp; k += kHmmSeqThreads) {          // padding states of the last block of 16
-        alpha_tm[hmm_pos(k)] = 0.0;
-        if (T == 1) gamma_tm[hmm_pos(k)] = w_tm[hmm_pos(k)] = 0.0;
-    }
-    if (tid == 0) cprime[0] = s;
     __syncthreads();
     // (the time-major arrays are read one step ahead for this thread's first two states: their latency then lies beside the
     // matrix-vector product instead of in front of the step's dependent arithmetic)
     const int k0 = tid, k1 = tid + kHmmSeqThreads;
     const int p0 = hmm_pos(k0 < K ? k0 : 0), p1 = hmm_pos(k1 < K ? k1 : 0);
-    double r0 = (T > 1 && k0 < K) ? rho_tm[Kp + p0] : 0.0, r1 = (T > 1 && k1 < K) ? rho_tm[Kp + p1] : 0.0;
-    for (int64_t t = 1; t < T; ++t) {
+    double r0 = (t_lo < t_hi && k0 < K) ? rho_tm[t_lo * Kp + p0] : 0.0, r1 = (t_lo < t_hi && k1 < K) ? rho_tm[t_lo * Kp + p1] : 0.0;
+    for (int64_t t = t_lo; t < t_hi; ++t) {
         const double c0 = r0, c1 = r1;
-        if (t + 1 < T) {
+        if (t + 1 < t_hi) {
             if (k0 < K) r0 = rho_tm[(t + 1) * Kp + p0];
             if (k1 < K) r1 = rho_tm[(t + 1) * Kp + p1];
         }
@@ -165,12 +183,16 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_forward_kernel(const d
         for (int k = tid; k < K; k += kHmmSeqThreads) {
             const double an = vb[k] * inv;
             va[k] = an;
-            alpha_tm[t * Kp + hmm_pos(k)] = an;
+            if (!sweep) alpha_tm[t * Kp + hmm_pos(k)] = an;
         }
-        for (int k = K + tid; k < Kp; k += kHmmSeqThreads) alpha_tm[t * Kp + hmm_pos(k)] = 0.0;
-        if (tid == 0) cprime[t] = cp;
+        if (!sweep) {
+            for (int k = K + tid; k < Kp; k += kHmmSeqThreads) alpha_tm[t * Kp + hmm_pos(k)] = 0.0;
+            if (tid == 0) cprime[t] = cp;
+        }
         __syncthreads();
     }
+    if (end_out != nullptr && L > 0 && t_hi < T)                    // (a further chunk follows)
+        for (int k = tid; k < K; k += kHmmSeqThreads) end_out[(chunk + 1) * Kp + k] = va[k];
 }
 
 // Backward pass (:1008-1014) with gamma_t and w_t = rho'_t o beta~_t / (c'_t (alpha_t . beta~_t)) (hmm.h): beta~_{T-1}
@@ -181,7 +203,14 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_backward_kernel(const 
                                                                           int64_t T, int P, int J, int mat_in_lds,
                                                                           const double* __restrict__ alpha_tm,
                                                                           const double* __restrict__ cprime,
-                                                                          double* __restrict__ gamma_tm, double* __restrict__ w_tm) {
+                                                                          double* __restrict__ gamma_tm, double* __restrict__ w_tm,
+                                                                          // chunk form (L > 0): workgroup c walks its steps downwards from
+                                                                          // bend[c] (sweep: uniform, no alpha, no stores) and leaves the
+                                                                          // beta~ in front of it in bend_out[c - 1]
+                                                                          int64_t L = 0, const double* __restrict__ bend = nullptr,
+                                                                          int sweep = 0, double* __restrict__ bend_out = nullptr,
+                                                                          const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     extern __shared__ double sh[];
     double* be = sh;                       // [K] beta~_t
     double* y = be + K;                    // [K] rho'_t o beta~_t
@@ -195,41 +224,49 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_backward_kernel(const 
         for (int e = tid; e < K * K; e += kHmmSeqThreads) mat_l[e] = a_tilde_t[e];
         mat = mat_l;
     }
-    for (int k = tid; k < K; k += kHmmSeqThreads) be[k] = 1.0 / K;
+    const int64_t chunk = L > 0 ? (int64_t)blockIdx.x : 0;
+    const int64_t t_lo = 1 + chunk * L, t_hi = (L > 0 && t_lo + L < T) ? t_lo + L : T;      // steps t_hi - 1 .. t_lo
+    for (int k = tid; k < K; k += kHmmSeqThreads) be[k] = (L > 0 && !sweep && t_hi < T) ? bend[chunk * Kp + k] : 1.0 / K;
     __syncthreads();
     const int k0 = tid, k1 = tid + kHmmSeqThreads;
     const int p0 = hmm_pos(k0 < K ? k0 : 0), p1 = hmm_pos(k1 < K ? k1 : 0);
     double a0 = 0.0, a1 = 0.0, r0 = 0.0, r1 = 0.0, cpn = 1.0;         // alpha_t, rho'_t, c'_t one step ahead
-    if (T > 1) {
-        if (k0 < K) { a0 = alpha_tm[(T - 1) * Kp + p0]; r0 = rho_tm[(T - 1) * Kp + p0]; }
-        if (k1 < K) { a1 = alpha_tm[(T - 1) * Kp + p1]; r1 = rho_tm[(T - 1) * Kp + p1]; }
-        cpn = cprime[T - 1];
+    if (t_hi > t_lo) {
+        if (k0 < K) { if (!sweep) a0 = alpha_tm[(t_hi - 1) * Kp + p0]; r0 = rho_tm[(t_hi - 1) * Kp + p0]; }
+        if (k1 < K) { if (!sweep) a1 = alpha_tm[(t_hi - 1) * Kp + p1]; r1 = rho_tm[(t_hi - 1) * Kp + p1]; }
+        if (!sweep) cpn = cprime[t_hi - 1];
     }
-    for (int64_t t = T - 1; t >= 1; --t) {
+    for (int64_t t = t_hi - 1; t >= t_lo; --t) {
         const double ca0 = a0, ca1 = a1, cr0 = r0, cr1 = r1, cp = cpn;
-        if (t - 1 >= 1) {
-            if (k0 < K) { a0 = alpha_tm[(t - 1) * Kp + p0]; r0 = rho_tm[(t - 1) * Kp + p0]; }
-            if (k1 < K) { a1 = alpha_tm[(t - 1) * Kp + p1]; r1 = rho_tm[(t - 1) * Kp + p1]; }
-            cpn = cprime[t - 1];
+        if (t - 1 >= t_lo) {
+            if (k0 < K) { if (!sweep) a0 = alpha_tm[(t - 1) * Kp + p0]; r0 = rho_tm[(t - 1) * Kp + p0]; }
+            if (k1 < K) { if (!sweep) a1 = alpha_tm[(t - 1) * Kp + p1]; r1 = rho_tm[(t - 1) * Kp + p1]; }
+            if (!sweep) cpn = cprime[t - 1];
         }
-        double dot = 0.0;
-        for (int k = tid; k < K; k += kHmmSeqThreads) {
-            const double al = k == k0 ? ca0 : (k == k1 ? ca1 : alpha_tm[t * Kp + hmm_pos(k)]);
-            dot = fma(al, be[k], dot);
+        double ginv = 0.0, winv = 0.0;
+        if (!sweep) {                                                  // (uniform)
+            double dot = 0.0;
+            for (int k = tid; k < K; k += kHmmSeqThreads) {
+                const double al = k == k0 ? ca0 : (k == k1 ? ca1 : alpha_tm[t * Kp + hmm_pos(k)]);
+                dot = fma(al, be[k], dot);
+            }
+            dot = block_sum_1024(dot, red);
+            ginv = dot > 0.0 ? 1.0 / dot : 0.0;
+            winv = (dot > 0.0 && cp > 0.0) ? 1.0 / (dot * cp) : 0.0;
         }
-        dot = block_sum_1024(dot, red);
-        const double ginv = dot > 0.0 ? 1.0 / dot : 0.0;
-        const double winv = (dot > 0.0 && cp > 0.0) ? 1.0 / (dot * cp) : 0.0;
         for (int k = tid; k < K; k += kHmmSeqThreads) {
             const int p = hmm_pos(k);
-            const double al = k == k0 ? ca0 : (k == k1 ? ca1 : alpha_tm[t * Kp + p]);
             const double rr = k == k0 ? cr0 : (k == k1 ? cr1 : rho_tm[t * Kp + p]);
             const double yy = rr * be[k];
             y[k] = yy;
-            gamma_tm[t * Kp + p] = al * be[k] * ginv;
-            w_tm[t * Kp + p] = yy * winv;
+            if (!sweep) {
+                const double al = k == k0 ? ca0 : (k == k1 ? ca1 : alpha_tm[t * Kp + p]);
+                gamma_tm[t * Kp + p] = al * be[k] * ginv;
+                w_tm[t * Kp + p] = yy * winv;
+            }
         }
-        for (int k = K + tid; k < Kp; k += kHmmSeqThreads) gamma_tm[t * Kp + hmm_pos(k)] = w_tm[t * Kp + hmm_pos(k)] = 0.0;
+        if (!sweep)
+            for (int k = K + tid; k < Kp; k += kHmmSeqThreads) gamma_tm[t * Kp + hmm_pos(k)] = w_tm[t * Kp + hmm_pos(k)] = 0.0;
         __syncthreads();
         seq_matvec(mat, K, y, P, J, part_buf, nb);
         double part = 0.0;
@@ -239,7 +276,9 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_backward_kernel(const 
         for (int k = tid; k < K; k += kHmmSeqThreads) be[k] = nb[k] * inv;
         __syncthreads();
     }
-    if (T > 1) {                                                   // gamma_0 = alpha_0 o beta~_0, normalised; xi_0 = 0
+    if (bend_out != nullptr && L > 0 && chunk >= 1)
+        for (int k = tid; k < K; k += kHmmSeqThreads) bend_out[(chunk - 1) * Kp + k] = be[k];
+    if (T > 1 && chunk == 0 && !sweep) {                           // gamma_0 = alpha_0 o beta~_0, normalised; xi_0 = 0
         double dot = 0.0;
         for (int k = tid; k < K; k += kHmmSeqThreads) dot = fma(alpha_tm[hmm_pos(k)], be[k], dot);
         dot = block_sum_1024(dot, red);

@@ -281,7 +281,7 @@ def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
 
 
 @pytest.mark.parametrize("K,D,flat", [(32, 16, False), (8, 3, False), (5, 2, True), (48, 8, False), (96, 8, False),
-                                      (72, 4, True)])
+                                      (72, 4, True), (130, 4, False), (150, 3, True)])
 def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
     """Sequences past 2^18 steps: chunk boundary vectors from sweeps started at the uniform vector (the scaled recursions
     forget their start), checked against the replays' own and replaced by the chunk-product path when they do not stand.
