@@ -116,6 +116,8 @@ def measure(args, dev=None):
         vl = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    boundary_pass = {-1: "chunk products", 0: "forgetting pass stood", 1: "forgetting pass, then chunk products"}.get(
+        eng.last_boundary_pass(), "?")
     # HBM roofline (the chunked scan is bandwidth / latency bound, K^2 flops per byte of state are far below the MFMA
     # balance): algorithmic bytes per time step = the row of x read once (D * 4) + one [K] f64 state vector written by the
     # forward recursion and read back by the backward one (the reference materialises ln_rho, alpha, beta, gamma [T, K]
@@ -137,7 +139,7 @@ def measure(args, dev=None):
     alg = D * 4 + 2 * K * 8
     swept = 12 * Kp * 8 + D * 4 + 16 * ((D + 15) // 16) * 8
     ms = el / args.steps * 1e3
-    roofline = {"bound": "hbm", "kernel": "whole HMM iteration (emission + chunk products + boundary scan + replays + xi sum + M-step)",
+    roofline = {"bound": "hbm", "kernel": "whole HMM iteration (emission, boundary sweeps / chunk products, replays with the xi sum, M-step)",
                 "achieved": alg * T / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": alg * T / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_time_step": alg,
                 "estimated_swept_bytes_per_time_step": swept, "estimated_swept_GBps": swept * T / (ms * 1e-3) / 1e9,
@@ -160,7 +162,7 @@ def measure(args, dev=None):
         "unit": "time steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"HMM-VB K={K} D={D} T={T}, x stored f32, one VB iteration per step"},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "final_vl": vl,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "final_vl": vl, "boundary_pass": boundary_pass,
         "viterbi": None if getattr(args, "no_viterbi", False) else {"ms": viterbi_ms, "time_steps_per_s": T / (viterbi_ms * 1e-3), "states_visited": int(torch.unique(z).numel()),
                     "note": "hmmvb_viterbi over all T steps after the emission E-step (round 2: one sequential wave, ~10 s)"}})
 

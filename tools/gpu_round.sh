@@ -56,7 +56,8 @@ PY
     c4strong) timeout 1200 python bench.py --config c4 --scaling strong --gpus 1 --no-cpu --no-legs --steps 3 --warmup 1 > $OUT/${TAG}_bench_line_c4_strong1.json 2> $OUT/${TAG}_c4strong.err; tail -c 300 $OUT/${TAG}_c4strong.err; head -c 500 $OUT/${TAG}_bench_line_c4_strong1.json; echo ;;
     proofbench) timeout 600 python tools/bench_proof.py > $OUT/${TAG}_bench_proof.json 2> $OUT/${TAG}_bench_proof.err; head -c 500 $OUT/${TAG}_bench_proof.json; echo ;;
     hmmbig) timeout 900 python tools/bench_hmm.py --classes 128 --degree 8 --rows 200000 --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_hmm_k128_line.json 2> $OUT/${TAG}_hmmbig.err; head -c 300 $OUT/${TAG}_hmm_k128_line.json; echo
-            timeout 900 python tools/bench_hmm.py --classes 128 --degree 8 --rows 2000000 --steps 3 --warmup 1 --no-cpu --no-viterbi > $OUT/${TAG}_hmm_k128_t2e6_line.json 2>> $OUT/${TAG}_hmmbig.err; head -c 300 $OUT/${TAG}_hmm_k128_t2e6_line.json; echo ;;
+            timeout 900 python tools/bench_hmm.py --classes 128 --degree 8 --rows 2000000 --steps 3 --warmup 1 --no-cpu --no-viterbi > $OUT/${TAG}_hmm_k128_t2e6_line.json 2>> $OUT/${TAG}_hmmbig.err; head -c 300 $OUT/${TAG}_hmm_k128_t2e6_line.json; echo
+            timeout 900 python tools/bench_hmm.py --classes 256 --degree 8 --rows 500000 --steps 2 --warmup 1 --no-cpu --no-viterbi > $OUT/${TAG}_hmm_k256_t5e5_line.json 2>> $OUT/${TAG}_hmmbig.err; head -c 300 $OUT/${TAG}_hmm_k256_t5e5_line.json; echo ;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
     *) echo "unknown stage $stage" ;;
   esac
