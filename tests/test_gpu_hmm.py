@@ -280,8 +280,8 @@ def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
     assert abs(v["closed"] - u["h"]) <= 1e-11 * abs(u["h"]) + 1e-9
 
 
-@pytest.mark.parametrize("K,D,flat", [(32, 16, False), (8, 3, False), (5, 2, True), (48, 8, False), (96, 8, False),
-                                      (72, 4, True), (130, 4, False), (150, 3, True)])
+@pytest.mark.parametrize("K,D,flat", [(32, 16, False), (8, 3, False), (5, 2, True), (48, 8, False), (64, 5, False),
+                                      (96, 8, False), (72, 4, True), (130, 4, False), (150, 3, True), (6, 2, "cycle")])
 def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
     """Sequences past 2^18 steps: chunk boundary vectors from sweeps started at the uniform vector (the scaled recursions
     forget their start), checked against the replays' own and replaced by the chunk-product path when they do not stand.
@@ -295,6 +295,8 @@ def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
     rng = np.random.default_rng(13)
     t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
     m = t(x[rng.integers(0, T, K)].astype(np.float64))
+    cycle = flat == "cycle"                             # (a nearly deterministic cycle under flat emissions: no forgetting)
+    flat = bool(flat)
     scale = 4000.0 if flat else 1.0                     # (flat: every component covers the whole data set)
     w_inv = t(np.broadcast_to(np.eye(D) * (D + 3.0) * scale, (K, D, D)).copy())
     f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), m, t(np.full(K, 2.0)),
@@ -302,6 +304,8 @@ def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
     c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
     stay = 0.9999 if flat else 0.9
     a = t(np.eye(K) * stay + (1.0 - stay) / K)
+    if cycle:
+        a = t(np.roll(np.eye(K), 1, axis=1) * 0.9999 + 0.0001 / K)
     pi = t(rng.dirichlet(np.ones(K)))
     xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
@@ -336,3 +340,28 @@ def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
         scale_k = max(1.0, float(ref[k].abs().max()))
         assert float((ref[k] - got[k]).abs().max()) <= 1e-10 * scale_k, k
     assert abs(ref["lnc"] - got["lnc"]) <= 1e-11 * abs(ref["lnc"])
+
+
+def test_update_posterior_through_the_forgetting_pass(monkeypatch):
+    """The whole VB loop of a long sequence (public API: fused emission, closed-form sum gamma ln rho, xi in the backward replay,
+    boundary vectors by forgetting) against the same loop on the chunk-product path."""
+    from bayesml_amd import hiddenmarkovnormal as hmm
+    K, D, T = 5, 3, 270001
+    x = orc.synth_hmm(K, D, T, np.float64, seed=21)[0]
+    res = []
+    for off in (True, False):
+        if off:
+            monkeypatch.setenv("GMMVB_HMM_FORGETTING_OFF", "1")
+        else:
+            monkeypatch.delenv("GMMVB_HMM_FORGETTING_OFF", raising=False)
+        m = hmm.LearnModel(K, D, seed=3, device="cuda:0", verbose=False)
+        import io
+        from contextlib import redirect_stdout
+        with redirect_stdout(io.StringIO()):
+            m.update_posterior(x, max_itr=6, num_init=1, tolerance=0.0)
+        res.append((m.get_hn_params(), m._engine.last_boundary_pass() if getattr(m, "_engine", None) is not None else None))
+    (p0, how0), (p1, how1) = res
+    assert how0 == -1 and how1 == 0, (how0, how1)
+    for k in p0:
+        a, b = np.asarray(p0[k]), np.asarray(p1[k])
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, float(np.max(np.abs(a)))), k
