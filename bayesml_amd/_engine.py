@@ -71,6 +71,7 @@ SYMBOLS = {
     "hmmvb_emission_target": (_int, [_vp, _int, _vp]),
     "hmmvb_skip_h": (_int, [_vp, _int]),
     "hmmvb_last_boundary_pass": (_int, [_vp]),
+    "hmmvb_last_viterbi_pass": (_int, [_vp]),
     "hmmvb_viterbi": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "gmmvb_profile_enable": (_int, [_vp, _int]),
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
@@ -511,6 +512,10 @@ class DataPass:
     def last_boundary_pass(self) -> int:
         """hmmvb_last_boundary_pass: -1 chunk products, 0 the forgetting pass stood, 1 it ran and the products path behind it."""
         return int(self.lib.hmmvb_last_boundary_pass(self._ws))
+
+    def last_viterbi_pass(self) -> int:
+        """hmmvb_last_viterbi_pass: -1 chunk matrices / sequential, 0 the coalescence pass stood, 1 chunk matrices behind it."""
+        return int(self.lib.hmmvb_last_viterbi_pass(self._ws))
 
     def emission_target(self, fused: bool) -> bool:
         """hmmvb_emission_target: ``fused`` asks the following ``estep`` calls to write rho' straight into the

@@ -1071,7 +1071,9 @@ __global__ __launch_bounds__(256) void hmm_viterbi_backtrack_kernel(const unsign
 template <int KT>
 __global__ __launch_bounds__(256) void hmm_vit_chunk_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                             const double* __restrict__ ln_a_tilde, int K, int64_t T, int64_t L,
-                                                            double* __restrict__ M /*[chunks][Kp][Kp]*/) {
+                                                            double* __restrict__ M /*[chunks][Kp][Kp]*/,
+    const int* __restrict__ gate = nullptr /*the coalescence pass stands: nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     const int j = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1109,7 +1111,9 @@ template <int KT>
 __global__ __launch_bounds__(256) void hmm_vit_scan_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                            const double* __restrict__ ln_pi_tilde,
                                                            const double* __restrict__ M, int K, int64_t chunks,
-                                                           double* __restrict__ wstart /*[chunks][Kp]*/) {
+                                                           double* __restrict__ wstart /*[chunks][Kp]*/,
+    const int* __restrict__ gate = nullptr /*the coalescence pass stands: nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     constexpr int B = 8192 / (Kp * Kp) < 1 ? 1 : 8192 / (Kp * Kp);        // chunks per 64-KB LDS buffer
     constexpr int PER = (B * Kp * Kp + 255) / 256;                        // doubles per thread and group
@@ -1161,12 +1165,25 @@ __global__ __launch_bounds__(256) void hmm_vit_scan_kernel(const double* __restr
     }
 }
 
+// omega_0 = ln rho_0 + ln pi~ (what the scan kernels start from), as row 0 of the chunk start vectors
+__global__ void hmm_vit_omega0_kernel(const double* __restrict__ lnrho, int64_t npad, const double* __restrict__ ln_pi_tilde, int K,
+                                      int Kp, double* __restrict__ wstart) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < Kp) wstart[j] = j < K ? lnrho[(int64_t)j * npad] + ln_pi_tilde[j] : -1.0e300;
+}
+
 template <int KT>
 __global__ __launch_bounds__(64) void hmm_vit_replay_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                             const double* __restrict__ ln_a_tilde,
                                                             const double* __restrict__ wstart, int K, int64_t T, int64_t L,
                                                             int64_t chunks, unsigned char* __restrict__ phi /*[T][Kp]*/,
-                                                            int* __restrict__ last_state) {
+                                                            int* __restrict__ last_state,
+                                                            // The coalescence pass (hmm_capi.hip: hmmvb_viterbi).  sweep: chunks past the
+                                                            // first start from the zero vector, no back-pointers are stored.  end_out:
+                                                            // omega behind the chunk, minus its maximum, -> row c + 1.
+                                                            int sweep = 0, double* __restrict__ end_out = nullptr,
+                                                            const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     const int j = threadIdx.x;
     const int64_t c = blockIdx.x;
@@ -1176,7 +1193,7 @@ __global__ __launch_bounds__(64) void hmm_vit_replay_kernel(const double* __rest
 #pragma unroll
     for (int i = 0; i < Kp; ++i) col[i] = (i < K && j < K) ? ln_a_tilde[i * K + j] : NEG;
     const double* lr = lnrho + (int64_t)(j < K ? j : 0) * npad;
-    double omega = (j < K) ? wstart[c * Kp + j] : NEG;
+    double omega = (j < K) ? ((sweep && c > 0) ? 0.0 : wstart[c * Kp + j]) : NEG;
     for (int64_t tb = t0; tb < t1; tb += 8) {
         double e[8];
 #pragma unroll
@@ -1195,11 +1212,15 @@ __global__ __launch_bounds__(64) void hmm_vit_replay_kernel(const double* __rest
                     }
                 }
                 omega = j < K ? e[u] + best : NEG;
-                if (j < Kp) phi[(tb + u) * Kp + j] = (unsigned char)arg;
+                if (j < Kp && !sweep) phi[(tb + u) * Kp + j] = (unsigned char)arg;
             }
         }
     }
-    if (c == chunks - 1) {               // first maximiser of omega_{T-1}
+    if (end_out != nullptr && c + 1 < chunks) {
+        const double m = max_wave(omega);
+        if (j < Kp) end_out[(c + 1) * Kp + j] = j < K ? omega - m : NEG;
+    }
+    if (c == chunks - 1 && !sweep) {     // first maximiser of omega_{T-1}
         double best = omega;
         int arg = j;
 #pragma unroll
@@ -1277,7 +1298,9 @@ template <int KP>
 __global__ __launch_bounds__(64) void hmm_vit_chunk_lane_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                                 const double* __restrict__ a_pad /*[KP][KP], -1e300 padded*/,
                                                                 int K, int64_t T, int64_t L, int64_t chunks,
-                                                                double* __restrict__ M /*[chunks][KP][KP]*/) {
+                                                                double* __restrict__ M /*[chunks][KP][KP]*/,
+    const int* __restrict__ gate = nullptr /*the coalescence pass stands: nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     static_assert(KP == 16 || KP == 32, "the omega vector lives in registers");
     constexpr int CW = 64 / KP;                       // chunks per wave
     __shared__ double es[CW][8][KP];
@@ -1339,7 +1362,9 @@ __global__ void hmm_vit_pad_kernel(const double* __restrict__ ln_a_tilde, int K,
 // super-chunk, the running product and the next factor in LDS)
 template <int KP>
 __global__ __launch_bounds__(256) void hmm_vit_super_kernel(const double* __restrict__ M, int K, int64_t chunks,
-                                                            double* __restrict__ P /*[supers][KP][KP]*/) {
+                                                            double* __restrict__ P /*[supers][KP][KP]*/,
+    const int* __restrict__ gate = nullptr /*the coalescence pass stands: nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     __shared__ double pa[KP * KP], pb[KP * KP], mc[KP * KP];
     const int tid = threadIdx.x;
     const int64_t s = blockIdx.x;
@@ -1376,7 +1401,9 @@ __global__ __launch_bounds__(256) void hmm_vit_super_kernel(const double* __rest
 template <int KP>
 __global__ __launch_bounds__(64) void hmm_vit_scan2_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                            const double* __restrict__ ln_pi_tilde, const double* __restrict__ P,
-                                                           int K, int64_t supers, double* __restrict__ sstart /*[supers][KP]*/) {
+                                                           int K, int64_t supers, double* __restrict__ sstart /*[supers][KP]*/,
+    const int* __restrict__ gate = nullptr /*the coalescence pass stands: nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     const int j = threadIdx.x;
     const int jj = j < KP ? j : 0;
     const double NEG = -1.0e300;
@@ -1405,7 +1432,9 @@ __global__ __launch_bounds__(64) void hmm_vit_scan2_kernel(const double* __restr
 // omega at every chunk start of super-chunk s from its start vector: omega_{c+1} = omega_c (x) M_c (a wave per super-chunk)
 template <int KP>
 __global__ __launch_bounds__(64) void hmm_vit_fill2_kernel(const double* __restrict__ M, int K, int64_t chunks,
-                                                           const double* __restrict__ sstart, double* __restrict__ wstart) {
+                                                           const double* __restrict__ sstart, double* __restrict__ wstart,
+    const int* __restrict__ gate = nullptr /*the coalescence pass stands: nothing to do*/) {
+    if (gate != nullptr && *gate == 0) return;
     const int j = threadIdx.x;
     const int jj = j < KP ? j : 0;
     const double NEG = -1.0e300;

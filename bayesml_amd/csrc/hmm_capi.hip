@@ -54,6 +54,7 @@ struct gmmvb_hmm_state {
     int* gate_host = nullptr;     // pinned copy, read when the next call begins
     hipEvent_t gate_ev = nullptr;
     bool gate_pending = false, spec_on = true;
+    bool vit_coalesced = false;   // the last hmmvb_viterbi call ran the coalescence pass (its gate: gate_dev[1])
     int spec_hold = 0, last_gate = -1;   // last_gate: -1 no forgetting pass, 0 it stood, 1 products path behind it
     bool fuse_emission = false;   // hmmvb_emission_target: gmmvb_estep writes rho' / mx here (hmm.h H0 + H1) and no ln rho array
 };
@@ -468,7 +469,7 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     }
     if (e2 == hipSuccess) {      // the forgetting pass's gate (run<KT>, run_wide, run_generic): device flag, pinned copy, event
         h->spec_on = std::getenv("GMMVB_HMM_FORGETTING_OFF") == nullptr;
-        e2 = hipMalloc((void**)&h->gate_dev, sizeof(int));
+        e2 = hipMalloc((void**)&h->gate_dev, 2 * sizeof(int));      // [0] forward-backward, [1] Viterbi
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, sizeof(int));
         if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&h->gate_ev, hipEventDisableTiming);
         if (e2 == hipSuccess) *h->gate_host = 0;
@@ -493,6 +494,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         return fail(GMMVB_ESTATE, "no emission ln rho for these rows: call gmmvb_estep first");
     gmmvb_hmm_state* h = ws->hmm;
     hipStream_t st = (hipStream_t)stream;
+    h->vit_coalesced = false;
     if (h->wide && h->phi && n_rows >= kHmmWideMinSteps) {
         // 65 .. 128 states: the chunked max-plus pass with two end states per lane and ln a~ in LDS (hmm_wide.h); scratch as below
         const int64_t L = kHmmWideChunk;
@@ -561,28 +563,48 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         const bool two_level = supers > 2 && h->qprod != nullptr && h->bend_s != nullptr;
         double* a_pad = h->xi_slabs;                                     // [Kp][Kp] (the forward-backward pass's slabs are free here)
         double* sstart = h->bend_s;                                      // [supers][Kp]
+        // The coalescence pass (the max-plus twin of the forward-backward pass's forgetting, run<KT>): the best paths from all
+        // start states of a chunk of 256 steps normally merge inside it, and then omega behind the chunk - minus its maximum -
+        // does not depend on the chunk's start vector.  A sweep of the replay kernel from zero start vectors (no
+        // back-pointers stored) gives every chunk a start vector, the replay runs from those and its own end vectors are
+        // compared with the sweep's: equal to 1e-9 nats, the back-pointers stand (only differences of omega enter them);
+        // otherwise the gate opens and the chunk-matrix path below runs behind it, replay included.
+        const int* vgate = nullptr;
+        const bool coalesce = L == 256 && chunks >= 64 && h->spec_on && h->gate_dev != nullptr && h->fstart2 != nullptr;
+        h->vit_coalesced = coalesce;
 #define VITC(KTT)                                                                                                           \
+    if (coalesce) {                                                                                                         \
+        vgate = h->gate_dev + 1;                                                                                            \
+        (void)hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st);                                                          \
+        hipLaunchKernelGGL(hmm_vit_omega0_kernel, dim3(1), dim3(64), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, h->K, h->Kp, wstart); \
+        hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,       \
+                           ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr);     \
+        hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,       \
+                           ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, h->fstart2, nullptr);  \
+        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,        \
+                           (chunks - 1) * h->Kp, h->Kp, 1e-9, h->gate_dev + 1);                                             \
+    }                                                                                                                       \
     if (KTT <= 2) {                                                                                                         \
         constexpr int KPL = KTT <= 1 ? 16 : 32;                                                                             \
         hipLaunchKernelGGL(hmm_vit_pad_kernel, dim3((KPL * KPL + 255) / 256), dim3(256), 0, st, ln_a_tilde_dev, h->K, KPL, a_pad); \
         hipLaunchKernelGGL((hmm_vit_chunk_lane_kernel<KPL>), dim3((unsigned)((chunks + 64 / KPL - 1) / (64 / KPL))), dim3(64), 0, \
-                           st, ws->lnrho, ws->npad, a_pad, h->K, n_rows, L, chunks, M);                                     \
+                           st, ws->lnrho, ws->npad, a_pad, h->K, n_rows, L, chunks, M, vgate);                              \
     } else {                                                                                                                \
         hipLaunchKernelGGL((hmm_vit_chunk_kernel<KTT>), dim3((unsigned)chunks, (unsigned)((h->K + 3) / 4)), dim3(256), 0, st, \
-                           ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M);                                        \
+                           ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M, vgate);                                 \
     }                                                                                                                       \
     if (two_level) {                                                                                                        \
-        hipLaunchKernelGGL((hmm_vit_super_kernel<16 * KTT>), dim3((unsigned)supers), dim3(256), 0, st, M, h->K, chunks, h->qprod); \
+        hipLaunchKernelGGL((hmm_vit_super_kernel<16 * KTT>), dim3((unsigned)supers), dim3(256), 0, st, M, h->K, chunks, h->qprod, vgate); \
         hipLaunchKernelGGL((hmm_vit_scan2_kernel<16 * KTT>), dim3(1), dim3(64), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, \
-                           h->qprod, h->K, supers, sstart);                                                                 \
+                           h->qprod, h->K, supers, sstart, vgate);                                                          \
         hipLaunchKernelGGL((hmm_vit_fill2_kernel<16 * KTT>), dim3((unsigned)supers), dim3(64), 0, st, M, h->K, chunks, sstart, \
-                           wstart);                                                                                         \
+                           wstart, vgate);                                                                                  \
     } else {                                                                                                                \
         hipLaunchKernelGGL((hmm_vit_scan_kernel<KTT>), dim3(1), dim3(256), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, M, h->K, \
-                           chunks, wstart);                                                                                 \
+                           chunks, wstart, vgate);                                                                          \
     }                                                                                                                       \
     hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,           \
-                       ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state)
+                       ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, nullptr, vgate)
         switch (h->KT) {
             case 1: VITC(1); break;
             case 2: VITC(2); break;
@@ -613,6 +635,14 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMMVB_EHIP, "viterbi launch", e);
     return GMMVB_OK;
+}
+
+int hmmvb_last_viterbi_pass(gmmvb_workspace* ws) {
+    if (!ws || !ws->hmm) return -2;
+    if (!ws->hmm->vit_coalesced) return -1;
+    int g = 0;
+    if (hipMemcpy(&g, ws->hmm->gate_dev + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -2;      // (synchronises)
+    return g;
 }
 
 int hmmvb_last_boundary_pass(gmmvb_workspace* ws) {

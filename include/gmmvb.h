@@ -208,6 +208,10 @@ int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi
  *       with the sweeps' to 2e-14 -, 1  the forgetting pass ran, its vectors did not stand and the products path ran behind it.
  *   -2  no HMM state / error.  The result of hmmvb_forward_backward is the same in all three cases (to rounding). */
 int hmmvb_last_boundary_pass(gmmvb_workspace* ws);
+/* The same for the last hmmvb_viterbi call: -1 chunk start vectors from the max-plus chunk matrices (or the sequential
+ * kernels), 0 from the coalescence pass (a sweep of the recursion from zero start vectors; the replay's own end vectors agreed
+ * with the sweep's to 1e-9 nats), 1 the pass ran, did not stand, and the chunk-matrix path ran behind it.  Synchronises. */
+int hmmvb_last_viterbi_pass(gmmvb_workspace* ws);
 
 /* skip = 1: the gmmvb_mstep calls that follow hmmvb_forward_backward leave the h block of the statistics at 0 and do not read
  * the ln rho array (a third of that kernel's traffic): sum_t gamma_tk ln rho_tk, the only use of h on the HMM path

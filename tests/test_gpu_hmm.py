@@ -365,3 +365,46 @@ def test_update_posterior_through_the_forgetting_pass(monkeypatch):
     for k in p0:
         a, b = np.asarray(p0[k]), np.asarray(p1[k])
         assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, float(np.max(np.abs(a)))), k
+
+
+@pytest.mark.parametrize("K,D,flat", [(32, 16, False), (6, 2, True), (48, 3, False), (12, 4, "cycle")])
+def test_viterbi_chunk_starts_by_coalescence(K, D, flat, monkeypatch):
+    """hmmvb_viterbi on 65536 steps or more: chunk start vectors from a sweep of the max-plus recursion started at zero (best paths
+    merge inside a chunk), checked against the replay's own; the chunk-matrix path behind a gate otherwise.  Same path either way."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    dev = torch.device("cuda", 0)
+    T = 150001
+    x, _ = orc.synth_hmm(K, D, T, np.float32, seed=17)
+    rng = np.random.default_rng(19)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
+    cycle = flat == "cycle"
+    flat = bool(flat)
+    m = t(x[rng.integers(0, T, K)].astype(np.float64))
+    w_inv = t(np.broadcast_to(np.eye(D) * (D + 3.0) * (1e7 if flat else 1.0), (K, D, D)).copy())
+    f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), m, t(np.full(K, 2.0)),
+                                     t(np.full(K, D + 3.0)), w_inv))
+    c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
+    a = np.eye(K) * 0.9 + 0.1 / K
+    if cycle:
+        a = np.roll(np.eye(K), 1, axis=1) * 0.999999 + 1e-6 / K
+    ln_a, ln_pi = t(np.log(a)), t(np.log(rng.dirichlet(np.ones(K))))
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    out = []
+    for off in (True, False):
+        if off:
+            monkeypatch.setenv("GMMVB_HMM_FORGETTING_OFF", "1")
+        else:
+            monkeypatch.delenv("GMMVB_HMM_FORGETTING_OFF", raising=False)
+        eng = DataPass(K, D, xd.dtype, T, dev)
+        eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+        eng.prepare_rows(xd)
+        eng.enable_hmm()
+        eng.set_params(c, f.m, f.u)
+        eng.estep(xd)
+        z = eng.viterbi(ln_pi, ln_a).clone()
+        out.append((z, eng.last_viterbi_pass()))
+        eng.close()
+    (z0, how0), (z1, how1) = out
+    assert how0 == -1 and how1 == (1 if flat else 0), (how0, how1)
+    assert torch.equal(z0, z1)
