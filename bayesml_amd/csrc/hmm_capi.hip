@@ -507,16 +507,32 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
             return fail(GMMVB_ESTATE, "Viterbi scratch too small for this sequence");
         const size_t lds = (size_t)h->Kp * h->Kp * sizeof(double);
         hipError_t ew = hipSuccess;
+        // (the coalescence pass of the narrow path below, same kernels' wide twins)
+        const int* vgate = nullptr;
+        const bool coalesce = chunks >= 64 && h->spec_on && h->gate_dev != nullptr && h->fstart2 != nullptr;
+        h->vit_coalesced = coalesce;
+        const unsigned rgrid = (unsigned)((chunks + kVitWideWaves - 1) / kVitWideWaves);
 #define VITW(KTT)                                                                                                              \
     ew = seq_lds(hmm_vit_chunk_wide_kernel<KTT>, lds);                                                                         \
     if (ew == hipSuccess) ew = seq_lds(hmm_vit_replay_wide_kernel<KTT>, lds);                                                  \
+    if (ew == hipSuccess && coalesce) {                                                                                        \
+        vgate = h->gate_dev + 1;                                                                                               \
+        (void)hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st);                                                             \
+        hipLaunchKernelGGL(hmm_vit_omega0_kernel, dim3(1), dim3(128), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, h->K, h->Kp, wstart); \
+        hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3(rgrid), dim3(64 * kVitWideWaves), lds, st, ws->lnrho,        \
+                           ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr); \
+        hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3(rgrid), dim3(64 * kVitWideWaves), lds, st, ws->lnrho,        \
+                           ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, h->fstart2, nullptr); \
+        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,           \
+                           (chunks - 1) * h->Kp, h->Kp, 1e-9, h->gate_dev + 1);                                                \
+    }                                                                                                                          \
     if (ew == hipSuccess) {                                                                                                    \
         hipLaunchKernelGGL((hmm_vit_chunk_wide_kernel<KTT>), dim3((unsigned)chunks, (unsigned)((h->K + 4 * kVitWideWaves - 1) / (4 * kVitWideWaves))), dim3(64 * kVitWideWaves), lds, st, \
-                           ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M);                                           \
+                           ws->lnrho, ws->npad, ln_a_tilde_dev, h->K, n_rows, L, M, vgate);                                    \
         hipLaunchKernelGGL((hmm_vit_scan_wide_kernel<KTT>), dim3(1), dim3(kHmmWideScanThreads), 0, st, ws->lnrho, ws->npad,     \
-                           ln_pi_tilde_dev, M, h->K, chunks, wstart);                                                          \
-        hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3((unsigned)((chunks + kVitWideWaves - 1) / kVitWideWaves)), dim3(64 * kVitWideWaves), lds, st, ws->lnrho, \
-                           ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state);                  \
+                           ln_pi_tilde_dev, M, h->K, chunks, wstart, vgate);                                                   \
+        hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3(rgrid), dim3(64 * kVitWideWaves), lds, st, ws->lnrho,        \
+                           ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, nullptr, vgate); \
     }
         switch (h->KT) {
             case 5: VITW(5) break;

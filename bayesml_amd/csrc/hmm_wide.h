@@ -554,7 +554,9 @@ constexpr int kVitWideWaves = 8;
 template <int KT>
 __global__ __launch_bounds__(64 * kVitWideWaves) void hmm_vit_chunk_wide_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                                  const double* __restrict__ ln_a_tilde, int K, int64_t T, int64_t L,
-                                                                 double* __restrict__ M /*[chunks][Kp][Kp]*/) {
+                                                                 double* __restrict__ M /*[chunks][Kp][Kp]*/,
+    const int* __restrict__ gate = nullptr /*hmm.h: the coalescence pass stands*/) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT, SB = kVitWideStarts;
     extern __shared__ double a_lds[];                  // [Kp][Kp]
     const int lane = threadIdx.x & 63;
@@ -626,7 +628,9 @@ template <int KT>
 __global__ __launch_bounds__(kHmmWideScanThreads) void hmm_vit_scan_wide_kernel(const double* __restrict__ lnrho, int64_t npad,
                                                                                 const double* __restrict__ ln_pi_tilde,
                                                                                 const double* __restrict__ M, int K, int64_t chunks,
-                                                                                double* __restrict__ wstart /*[chunks][Kp]*/) {
+                                                                                double* __restrict__ wstart /*[chunks][Kp]*/,
+    const int* __restrict__ gate = nullptr /*hmm.h: the coalescence pass stands*/) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT, PARTS = kHmmWideScanThreads / 128, IP = Kp / PARTS;
     __shared__ double sw[128];
     __shared__ double spart[PARTS][128];
@@ -671,7 +675,11 @@ __global__ __launch_bounds__(64 * kVitWideWaves) void hmm_vit_replay_wide_kernel
                                                                   const double* __restrict__ ln_a_tilde,
                                                                   const double* __restrict__ wstart, int K, int64_t T, int64_t L,
                                                                   int64_t chunks, unsigned char* __restrict__ phi /*[T][Kp]*/,
-                                                                  int* __restrict__ last_state) {
+                                                                  int* __restrict__ last_state,
+                                                                  int sweep = 0 /*hmm.h: hmm_vit_replay_kernel*/,
+                                                                  double* __restrict__ end_out = nullptr,
+                                                                  const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     constexpr int Kp = 16 * KT;
     extern __shared__ double a_lds[];
     const int lane = threadIdx.x & 63;
@@ -688,8 +696,9 @@ __global__ __launch_bounds__(64 * kVitWideWaves) void hmm_vit_replay_wide_kernel
     const int j0 = lane, j1 = lane + 64;
     const double* lr0 = lnrho + (int64_t)(j0 < K ? j0 : 0) * npad;
     const double* lr1 = lnrho + (int64_t)(j1 < K ? j1 : 0) * npad;
-    double om0 = j0 < K ? wstart[c * Kp + j0] : NEG;
-    double om1 = j1 < K ? wstart[c * Kp + j1] : NEG;
+    const bool zero = sweep && c > 0;
+    double om0 = j0 < K ? (zero ? 0.0 : wstart[c * Kp + j0]) : NEG;
+    double om1 = j1 < K ? (zero ? 0.0 : wstart[c * Kp + j1]) : NEG;
     for (int64_t tb = t0; tb < t1; tb += 8) {
         double e0[8], e1[8];
 #pragma unroll
@@ -718,11 +727,18 @@ __global__ __launch_bounds__(64 * kVitWideWaves) void hmm_vit_replay_wide_kernel
             }
             om0 = j0 < K ? e0[u] + b0 : NEG;
             om1 = j1 < K ? e1[u] + b1 : NEG;
-            phi[(tb + u) * Kp + j0] = (unsigned char)g0;
-            if (j1 < Kp) phi[(tb + u) * Kp + j1] = (unsigned char)g1;
+            if (!sweep) {
+                phi[(tb + u) * Kp + j0] = (unsigned char)g0;
+                if (j1 < Kp) phi[(tb + u) * Kp + j1] = (unsigned char)g1;
+            }
         }
     }
-    if (c == chunks - 1) {               // first maximiser of omega_{T-1}
+    if (end_out != nullptr && c + 1 < chunks) {
+        const double m = max_wave(fmax(om0, om1));
+        end_out[(c + 1) * Kp + j0] = j0 < K ? om0 - m : NEG;
+        if (j1 < Kp) end_out[(c + 1) * Kp + j1] = j1 < K ? om1 - m : NEG;
+    }
+    if (c == chunks - 1 && !sweep) {     // first maximiser of omega_{T-1}
         double best = om0;
         int arg = j0;
         if (om1 > best) {

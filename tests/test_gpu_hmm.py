@@ -367,7 +367,8 @@ def test_update_posterior_through_the_forgetting_pass(monkeypatch):
         assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, float(np.max(np.abs(a)))), k
 
 
-@pytest.mark.parametrize("K,D,flat", [(32, 16, False), (6, 2, True), (48, 3, False), (12, 4, "cycle")])
+@pytest.mark.parametrize("K,D,flat", [(32, 16, False), (6, 2, True), (48, 3, False), (12, 4, "cycle"), (96, 3, False),
+                                      (128, 2, False), (72, 2, True)])
 def test_viterbi_chunk_starts_by_coalescence(K, D, flat, monkeypatch):
     """hmmvb_viterbi on 65536 steps or more: chunk start vectors from a sweep of the max-plus recursion started at zero (best paths
     merge inside a chunk), checked against the replay's own; the chunk-matrix path behind a gate otherwise.  Same path either way."""
