@@ -15,6 +15,8 @@
 //   H2  chunk_products : P_c = prod_{t in c} M_t, one wave per chunk, K^3 per step on MFMA (both
 //                        directions use the same P_c: forward as row-vector x P_c, backward as P_c x column)
 //   H3  boundary_scan  : the short sequential pass over chunks (start vector of every chunk)
+//   (round 4: for long sequences H2 / H3 run only behind a gate - the start vectors come from sweeps of H4 / H5 started at
+//    the uniform vector, which the recursions forget, checked against the replays' own end vectors: hmm_capi.hip, run<KT>)
 //   H4  forward_replay : 16 chunks per wave as the 16 MFMA columns, K^2 per step; writes alpha, c'
 //   H5  backward_replay: same shape, descending; writes gamma (time-major) and w
 //   H6  xi_sum         : the [K x T] x [T x K] product over time on MFMA, slabs per wave (up to 32 states: inside H5)
