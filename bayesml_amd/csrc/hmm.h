@@ -474,15 +474,10 @@ __global__ __launch_bounds__(128) void hmm_boundary_fill_kernel(const double* __
 constexpr int kReplayChunks = GMMVB_REPLAY_CHUNKS;      // chunks per replay wave (8 or 16)
 // H4: forward replay.  One wave = kReplayChunks chunks (MFMA columns).  alpha_tm / rho_tm in lane order.
 template <int KT>
-__global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* __restrict__ rho_tm,
-                                                                 const double* __restrict__ a_tilde, int K, int64_t T,
-                                                                 int64_t L, int64_t n_chunks,
-                                                                 const double* __restrict__ fstart,
-                                                                 double* __restrict__ alpha_tm, double* __restrict__ cprime,
-                                                                 int sweep = 0 /*1: no stores, chunks past the first start from the uniform vector*/,
-                                                                 double* __restrict__ end_out = nullptr /*[n_chunks][Kp]: alpha behind chunk c -> row c + 1*/,
-                                                                 const int* __restrict__ gate = nullptr) {
-    if (gate != nullptr && *gate == 0) return;
+__device__ __forceinline__ void hmm_forward_replay_body(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
+                                                        int64_t T, int64_t L, int64_t n_chunks, const double* __restrict__ fstart,
+                                                        double* __restrict__ alpha_tm, double* __restrict__ cprime, int sweep,
+                                                        double* __restrict__ end_out) {
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     // kReplayChunks chunks per wave: with fewer than 16 the MFMA columns j and j + kReplayChunks carry the same chunk (only
@@ -539,11 +534,23 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
     }
 }
 
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* __restrict__ rho_tm,
+                                                                 const double* __restrict__ a_tilde, int K, int64_t T,
+                                                                 int64_t L, int64_t n_chunks,
+                                                                 const double* __restrict__ fstart,
+                                                                 double* __restrict__ alpha_tm, double* __restrict__ cprime,
+                                                                 int sweep = 0 /*1: no stores, chunks past the first start from the uniform vector*/,
+                                                                 double* __restrict__ end_out = nullptr /*[n_chunks][Kp]: alpha behind chunk c -> row c + 1*/,
+                                                                 const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
+    hmm_forward_replay_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, fstart, alpha_tm, cprime, sweep, end_out);
+}
+
 // The backward recursion alone (no gamma, no xi): beta~ in front of chunk c from the uniform vector behind it -> row c - 1.
 template <int KT>
-__global__ __launch_bounds__(256) void hmm_backward_sweep_kernel(const double* __restrict__ rho_tm,
-                                                                 const double* __restrict__ a_tilde, int K, int64_t T,
-                                                                 int64_t L, int64_t n_chunks, double* __restrict__ bend_out) {
+__device__ __forceinline__ void hmm_backward_sweep_body(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
+                                                        int64_t T, int64_t L, int64_t n_chunks, double* __restrict__ bend_out) {
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kReplayChunks + (j % kReplayChunks);
@@ -589,6 +596,18 @@ __global__ __launch_bounds__(256) void hmm_backward_sweep_kernel(const double* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) bend_out[(c - 1) * Kp + 16 * it + g + 4 * r] = be[it][r];
     }
+}
+
+// The two sweeps of the forgetting pass in one launch (blockIdx.y = direction): chains of dependent steps both, twice the waves
+// in flight.
+template <int KT>
+__global__ __launch_bounds__(256) void hmm_sweeps_kernel(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
+                                                         int64_t T, int64_t L, int64_t n_chunks, double* __restrict__ fstart,
+                                                         double* __restrict__ bend) {
+    if (blockIdx.y == 0)
+        hmm_forward_replay_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, fstart, nullptr, nullptr, 1, fstart);
+    else
+        hmm_backward_sweep_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, bend);
 }
 
 // alpha_0 and c'_0 (what hmm_boundary_scan_kernel does first), and the uniform vector behind the last chunk (K <= 256)

@@ -186,9 +186,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
         hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(256), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
                            h->cprime);
-        hipLaunchKernelGGL((hmm_forward_replay_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
-                           h->fstart, h->alpha_tm, h->cprime, 1, h->fstart, nullptr);
-        hipLaunchKernelGGL((hmm_backward_sweep_kernel<KT>), dim3(grid), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+        hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks, h->fstart,
                            h->bend);
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
         hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
