@@ -552,9 +552,40 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         const HmmSeqShape sh = hmm_seq_shape(h->K);
         hipError_t eg = seq_lds(hmm_seq_viterbi_kernel, sh.lds_bytes);
         if (eg != hipSuccess) return fail(GMMVB_EHIP, "viterbi (LDS size)", eg);
+        // chunk form through the coalescence pass (the narrow path below), the walk of the whole sequence by one workgroup behind
+        // its gate; the path is traced back chunk-parallel either way
+        const int64_t L = kHmmGenericChunk;
+        const int64_t chunks = n_rows > 1 ? (n_rows - 1 + L - 1) / L : 0;
+        const bool chunked = chunks >= 2 && chunks <= h->vec_chunks && h->fstart2 != nullptr;
+        const bool coalesce = chunked && chunks >= 64 && h->spec_on && h->gate_dev != nullptr;
+        h->vit_coalesced = coalesce;
+        const int* vgate = nullptr;
+        if (coalesce) {
+            vgate = h->gate_dev + 1;
+            (void)hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st);
+            hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3((unsigned)chunks), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
+                               ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state, L, h->Kp,
+                               h->fstart, 1, h->fstart, nullptr);
+            hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3((unsigned)chunks), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
+                               ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state, L, h->Kp,
+                               h->fstart, 0, h->fstart2, nullptr);
+            hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->fstart, h->fstart,
+                               (chunks - 1) * h->Kp, h->Kp, 1e-9, h->gate_dev + 1);
+        }
         hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
-                           ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state);
-        hipLaunchKernelGGL(hmm_seq_backtrack_kernel, dim3(1), dim3(64), 0, st, h->phi16, h->K, n_rows, h->last_state, z_dev);
+                           ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state, 0, h->Kp,
+                           nullptr, 0, nullptr, vgate);
+        if (chunked) {
+            // scratch: the forward-backward pass's w array ([npad][Kp] doubles; nothing reads it once gmmvb_estep has run again)
+            unsigned short* map = reinterpret_cast<unsigned short*>(h->w_tm);        // [chunks][K]
+            int* endst = reinterpret_cast<int*>(h->w_tm + (chunks * (int64_t)h->K + 3) / 4 + 1);      // [chunks]
+            hipLaunchKernelGGL(hmm_seq_backmap_kernel, dim3((unsigned)chunks), dim3(256), 0, st, h->phi16, h->K, n_rows, L, map);
+            hipLaunchKernelGGL(hmm_seq_backscan_kernel, dim3(1), dim3(64), 0, st, map, h->K, chunks, h->last_state, endst);
+            hipLaunchKernelGGL(hmm_seq_fill_kernel, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, st, h->phi16, h->K, n_rows, L,
+                               chunks, endst, z_dev);
+        } else {
+            hipLaunchKernelGGL(hmm_seq_backtrack_kernel, dim3(1), dim3(64), 0, st, h->phi16, h->K, n_rows, h->last_state, z_dev);
+        }
         eg = hipGetLastError();
         if (eg != hipSuccess) return fail(GMMVB_EHIP, "viterbi launch (generic)", eg);
         return GMMVB_OK;

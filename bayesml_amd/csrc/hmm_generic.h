@@ -322,7 +322,15 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_viterbi_kernel(const d
                                                                          const double* __restrict__ ln_a_tilde, int K, int64_t T,
                                                                          int P, int J, int mat_in_lds,
                                                                          unsigned short* __restrict__ phi,
-                                                                         int* __restrict__ last_state) {
+                                                                         int* __restrict__ last_state,
+                                                                         // chunk form (L > 0; hmm.h: the coalescence pass): workgroup c
+                                                                         // walks steps 1 + c L .. from wstart[c] ([chunks][Kp], natural
+                                                                         // order) - or, sweep, from zero, storing no back-pointers - and
+                                                                         // leaves omega minus its maximum in end_out[c + 1]
+                                                                         int64_t L = 0, int Kp = 0, const double* __restrict__ wstart = nullptr,
+                                                                         int sweep = 0, double* __restrict__ end_out = nullptr,
+                                                                         const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;
     extern __shared__ double sh[];
     double* om = sh;                       // [K] omega_{t-1}
     double* nw = om + K;                   // [K]
@@ -336,10 +344,13 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_viterbi_kernel(const d
         for (int e = tid; e < K * K; e += kHmmSeqThreads) mat_l[e] = ln_a_tilde[e];
         mat = mat_l;
     }
-    for (int k = tid; k < K; k += kHmmSeqThreads) om[k] = lnrho[(int64_t)k * npad] + ln_pi_tilde[k];
+    const int64_t chunk = L > 0 ? (int64_t)blockIdx.x : 0;
+    const int64_t t_lo = 1 + chunk * L, t_hi = (L > 0 && t_lo + L < T) ? t_lo + L : T;
+    for (int k = tid; k < K; k += kHmmSeqThreads)
+        om[k] = chunk == 0 ? lnrho[(int64_t)k * npad] + ln_pi_tilde[k] : (sweep ? 0.0 : wstart[chunk * Kp + k]);
     __syncthreads();
     const double NEG = -__builtin_huge_val();
-    for (int64_t t = 1; t < T; ++t) {
+    for (int64_t t = t_lo; t < t_hi; ++t) {
         for (int j0 = 0; j0 < K; j0 += J) {
             const int j = j0 + jl;
             double best = NEG;
@@ -366,14 +377,19 @@ __global__ __launch_bounds__(kHmmSeqThreads) void hmm_seq_viterbi_kernel(const d
                     }
                 }
                 nw[j0 + tid] = lnrho[(int64_t)(j0 + tid) * npad + t] + b;
-                phi[t * K + j0 + tid] = (unsigned short)a;
+                if (!sweep) phi[t * K + j0 + tid] = (unsigned short)a;
             }
             __syncthreads();
         }
         for (int k = tid; k < K; k += kHmmSeqThreads) om[k] = nw[k];
         __syncthreads();
     }
-    if (tid == 0) {                          // first maximiser of omega_{T-1}
+    if (end_out != nullptr && L > 0 && t_hi < T) {       // (a further chunk follows)
+        double m = NEG;
+        for (int k = 0; k < K; ++k) m = fmax(m, om[k]);          // (every thread: K broadcast reads of LDS)
+        for (int k = tid; k < K; k += kHmmSeqThreads) end_out[(chunk + 1) * Kp + k] = om[k] - m;
+    }
+    if (tid == 0 && t_hi == T && !sweep) {   // first maximiser of omega_{T-1}
         double b = om[0];
         int a = 0;
         for (int k = 1; k < K; ++k)
@@ -393,6 +409,40 @@ __global__ void hmm_seq_backtrack_kernel(const unsigned short* __restrict__ phi,
     for (int64_t t = T - 1; t >= 1; --t) {
         k = phi[t * K + k];
         z[t - 1] = k;
+    }
+}
+
+// The same path chunk-parallel (16-bit back-pointers, natural order): per chunk the map end state -> state in front of the
+// chunk (a thread per end state follows its pointers), one thread walks the chunks' maps back from the last state, and every
+// chunk fills in its stretch.  z[t] for t in [1 + c L - 1, t_hi) is written by chunk c.
+__global__ __launch_bounds__(256) void hmm_seq_backmap_kernel(const unsigned short* __restrict__ phi, int K, int64_t T, int64_t L,
+                                                              unsigned short* __restrict__ map /*[chunks][K]*/) {
+    const int64_t c = blockIdx.x, t_lo = 1 + c * L, t_hi = t_lo + L < T ? t_lo + L : T;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        int s = k;
+        for (int64_t t = t_hi - 1; t >= t_lo; --t) s = phi[t * K + s];
+        map[c * K + k] = (unsigned short)s;
+    }
+}
+__global__ void hmm_seq_backscan_kernel(const unsigned short* __restrict__ map, int K, int64_t chunks, const int* __restrict__ last_state,
+                                        int* __restrict__ endst /*[chunks]: the path's state at the chunk's last step*/) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int s = *last_state;
+    for (int64_t c = chunks - 1; c >= 0; --c) {
+        endst[c] = s;
+        s = map[c * K + s];
+    }
+}
+__global__ __launch_bounds__(64) void hmm_seq_fill_kernel(const unsigned short* __restrict__ phi, int K, int64_t T, int64_t L,
+                                                          int64_t chunks, const int* __restrict__ endst, int32_t* __restrict__ z) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= chunks) return;
+    const int64_t t_lo = 1 + c * L, t_hi = t_lo + L < T ? t_lo + L : T;
+    int s = endst[c];
+    z[t_hi - 1] = s;
+    for (int64_t t = t_hi - 1; t >= t_lo; --t) {
+        s = phi[t * K + s];
+        z[t - 1] = s;
     }
 }
 

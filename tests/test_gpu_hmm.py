@@ -193,7 +193,7 @@ def test_full_driver_matches_reference(name):
 
 # T < 512: the single sequential wave; 512 <= T < 65536: the chunked max-plus scan with chunks of 32 steps; beyond: 256
 @pytest.mark.parametrize("K,D,T", [(5, 3, 1), (12, 4, 511), (12, 4, 700), (40, 2, 3000), (64, 2, 1537), (32, 16, 200001),
-                                   (66, 2, 1), (72, 2, 800), (140, 2, 500),
+                                   (66, 2, 1), (72, 2, 800), (140, 2, 500), (133, 2, 20000),
                                    # 65 .. 128 states over 2048 steps or more: the chunked pass of hmm_wide.h (two end states per
                                    # lane, four start states per wave, ragged last chunk / tile)
                                    (72, 2, 2048), (100, 3, 5001), (128, 2, 2700), (81, 2, 20000)])
@@ -368,7 +368,7 @@ def test_update_posterior_through_the_forgetting_pass(monkeypatch):
 
 
 @pytest.mark.parametrize("K,D,flat", [(32, 16, False), (6, 2, True), (48, 3, False), (12, 4, "cycle"), (96, 3, False),
-                                      (128, 2, False), (72, 2, True)])
+                                      (128, 2, False), (72, 2, True), (130, 2, False), (140, 2, True)])
 def test_viterbi_chunk_starts_by_coalescence(K, D, flat, monkeypatch):
     """hmmvb_viterbi on 65536 steps or more: chunk start vectors from a sweep of the max-plus recursion started at zero (best paths
     merge inside a chunk), checked against the replay's own; the chunk-matrix path behind a gate otherwise.  Same path either way."""
