@@ -183,7 +183,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         spec = false;
     }
     if (spec) {
-        (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
+        if (hipError_t eg = hipMemsetAsync(h->gate_dev, 0, sizeof(int), st); eg != hipSuccess) return eg;      // (the gate must be shut before the check)
         hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(256), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
                            h->cprime);
         hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks, h->fstart,
@@ -191,9 +191,10 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
         hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
-        (void)hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st);
-        (void)hipEventRecord(h->gate_ev, st);
-        h->gate_pending = true;
+        // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
+        // made, they simply try the pass again)
+        h->gate_pending = hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                          hipEventRecord(h->gate_ev, st) == hipSuccess;
         gate = h->gate_dev;
     } else {
         h->last_gate = -1;
@@ -281,7 +282,7 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
         spec = false;
     }
     if (spec) {
-        (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
+        if (hipError_t eg = hipMemsetAsync(h->gate_dev, 0, sizeof(int), st); eg != hipSuccess) return eg;      // (the gate must be shut before the check)
         hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(256), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
                            h->cprime);
         hipLaunchKernelGGL((hmm_forward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
@@ -291,9 +292,10 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
         hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
-        (void)hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st);
-        (void)hipEventRecord(h->gate_ev, st);
-        h->gate_pending = true;
+        // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
+        // made, they simply try the pass again)
+        h->gate_pending = hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                          hipEventRecord(h->gate_ev, st) == hipSuccess;
         gate = h->gate_dev;
     } else {
         h->last_gate = -1;
@@ -361,7 +363,7 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
     }
     if (spec) {
         const unsigned g = (unsigned)n_chunks;
-        (void)hipMemsetAsync(h->gate_dev, 0, sizeof(int), st);
+        if (hipError_t eg = hipMemsetAsync(h->gate_dev, 0, sizeof(int), st); eg != hipSuccess) return eg;      // (the gate must be shut before the check)
         hipLaunchKernelGGL(hmm_seq_forward_kernel, dim3(g), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, pi_tilde, a_tilde, K,
                            Kp, T, sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->fstart, 1, h->fstart,
                            nullptr);
@@ -374,9 +376,10 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
                            sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->bend, 0, h->bend2, nullptr);
         hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
-        (void)hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st);
-        (void)hipEventRecord(h->gate_ev, st);
-        h->gate_pending = true;
+        // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
+        // made, they simply try the pass again)
+        h->gate_pending = hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                          hipEventRecord(h->gate_ev, st) == hipSuccess;
         gate = h->gate_dev;
     } else {
         h->last_gate = -1;
@@ -515,7 +518,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
     if (ew == hipSuccess) ew = seq_lds(hmm_vit_replay_wide_kernel<KTT>, lds);                                                  \
     if (ew == hipSuccess && coalesce) {                                                                                        \
         vgate = h->gate_dev + 1;                                                                                               \
-        (void)hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st);                                                             \
+        ew = hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st);                                                              \
         hipLaunchKernelGGL(hmm_vit_omega0_kernel, dim3(1), dim3(128), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, h->K, h->Kp, wstart); \
         hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3(rgrid), dim3(64 * kVitWideWaves), lds, st, ws->lnrho,        \
                            ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr); \
@@ -562,7 +565,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         const int* vgate = nullptr;
         if (coalesce) {
             vgate = h->gate_dev + 1;
-            (void)hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st);
+            if (hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st) != hipSuccess) return fail(GMMVB_EHIP, "viterbi (gate reset)");
             hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3((unsigned)chunks), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
                                ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state, L, h->Kp,
                                h->fstart, 1, h->fstart, nullptr);
@@ -620,7 +623,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
 #define VITC(KTT)                                                                                                           \
     if (coalesce) {                                                                                                         \
         vgate = h->gate_dev + 1;                                                                                            \
-        (void)hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st);                                                          \
+        if (hipMemsetAsync(h->gate_dev + 1, 0, sizeof(int), st) != hipSuccess) return fail(GMMVB_EHIP, "viterbi (gate reset)"); \
         hipLaunchKernelGGL(hmm_vit_omega0_kernel, dim3(1), dim3(64), 0, st, ws->lnrho, ws->npad, ln_pi_tilde_dev, h->K, h->Kp, wstart); \
         hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,       \
                            ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr);     \
