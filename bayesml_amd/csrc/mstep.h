@@ -597,7 +597,10 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
                     nsum[c] += v;
                 }
             }
-#pragma unroll 4
+#ifndef GMMVB_HMM_MSTEP_UNROLL
+#define GMMVB_HMM_MSTEP_UNROLL 4
+#endif
+#pragma unroll GMMVB_HMM_MSTEP_UNROLL
             for (int st = 0; st < 16; ++st) {
                 const double xq = xb[64 * st + lane];
 #pragma unroll
