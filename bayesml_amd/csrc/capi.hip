@@ -1788,7 +1788,10 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
         if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[2], st));      // the list building is part of the M-step's time
         const int cap_chunks0 = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
-        const int r_min0 = 1024;           // list entries per chunk (2048: +4 %, 4096: +19 % on the list M-step, round 2)
+#ifndef GMMVB_MLIST_RMIN
+#define GMMVB_MLIST_RMIN 1024
+#endif
+        const int r_min0 = GMMVB_MLIST_RMIN;      // list entries per chunk (2048: +4 %, 4096: +19 % on the list M-step, round 2)
         MstepListArgs la0{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks0, r_min0,
                           ws->npad, ws->K, ws->slabs};
         // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
