@@ -251,7 +251,11 @@ template <int KT>
 hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
                     double* out, hipStream_t st) {
     const int K = h->K, Kp = h->Kp;
-    const int64_t L = kHmmWideChunk;
+    // chunks of 256 steps, 64 to a replay workgroup (one per CU: the A fragments fill its LDS) - or of 128 steps while that leaves
+    // CUs without a workgroup (T = 2e6: 123 workgroups of 256-step chunks on 256 CUs; the replays and sweeps are chains of
+    // dependent steps, twice the workgroups halve them; chunks of 64 steps were too short for the forgetting pass at K = 128, D = 8)
+    int64_t L = kHmmWideChunk;
+    if ((T - 1 + L - 1) / L < 64 * (int64_t)ws->num_cu && (T - 1 + L / 2 - 1) / (L / 2) <= h->max_chunks) L /= 2;
     const int64_t n_chunks = (T - 1 + L - 1) / L;
     if (n_chunks > h->max_chunks) return hipErrorInvalidValue;
     const size_t fb = hmm_wide_frag_bytes<KT>();
@@ -425,7 +429,9 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     h->npad = ws->npad;
     h->generic = ws->K > 64;                    // (the chunk-parallel kernels hold K x K products in registers)
     h->wide = ws->K > 64 && ws->K <= 128 && std::getenv("GMMVB_HMM_WIDE_OFF") == nullptr;      // hmm_wide.h (developer switch: off)
-    h->max_chunks = h->wide ? ws->npad / kHmmWideChunk + 2 : (h->generic ? 1 : ws->npad / 16 + 2);          // chunk_len >= 16
+    // (65 .. 128 states: chunks of 256 steps, or of 128 while those do not fill the CUs - run_wide)
+    h->max_chunks = h->wide ? std::min<int64_t>(std::max<int64_t>(64 * (int64_t)ws->num_cu, ws->npad / kHmmWideChunk), ws->npad / 128) + 2
+                            : (h->generic ? 1 : ws->npad / 16 + 2);          // chunk_len >= 16
     h->xi_waves = h->generic ? std::max<int64_t>(16, std::min<int64_t>(4 * (int64_t)ws->num_cu, (int64_t(1) << 27) / ((int64_t)h->Kp * h->Kp)))
                              : 16 * (int64_t)ws->num_cu;       // four xi-sum waves per SIMD: the kernel streams two [T][Kp] arrays and a wave
                                                                // has one load group in flight (round 4; one wave per SIMD: 1.9 ms, 2.6 TB/s)
