@@ -138,13 +138,19 @@ template <int KT>
 hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
                double* out, hipStream_t st) {
     const int K = h->K, Kp = h->Kp;
-    const int64_t L = chunk_len(T, false);
+    int64_t L = chunk_len(T, false);
+    // long sequences whose 256-step chunks are few (64 to a replay workgroup, and the replays / sweeps are chains of dependent
+    // steps whose length is the chunk's): chunks of 128 steps - twice the waves, half the chain
+    const bool long_seq = T > (int64_t(1) << 18) && L == kHmmLongChunk;
+    // (config 5 shape on one box: T = 4e5 2.64 -> 2.12 ms per iteration, 1e6 3.21 -> 2.61, 3e6 4.85 -> 4.56; at 8e6 the shorter
+    // chunks lose, 9.79 -> 10.16: the limit is a replay workgroup per CU)
+    if (long_seq && (T - 1 + L - 1) / L < 64 * (int64_t)ws->num_cu) L /= 2;
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
     if (ws->e_state != 4)          // (4: the emission kernel has written rho' and mx itself)
         hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
                            ((size_t)Kp * (kPrepSteps + 1) + kPrepSteps) * sizeof(double), st, ws->lnrho, ws->npad, T, K, Kp,
                            h->rho_tm, h->mx);
-    const bool two_level = T > (int64_t(1) << 18) && L == kHmmLongChunk && n_chunks > 2 * kHmmSuper;
+    const bool two_level = long_seq && n_chunks > 2 * kHmmSuper;
     const unsigned grid = (unsigned)((n_chunks + 4 * kReplayChunks - 1) / (4 * kReplayChunks));      // kReplayChunks chunks per wave, 4 waves per block
     // the xi sum inside the backward replay (one slab per replay wave) unless the slabs do not fit / developer switch
     // (up to 32 states: with three or four 16-state blocks the accumulators no longer fit beside the operator's registers)
@@ -437,7 +443,7 @@ int hmmvb_enable(gmmvb_workspace* ws) {
                                                                // has one load group in flight (round 4; one wave per SIMD: 1.9 ms, 2.6 TB/s)
     // room for one xi slab per replay wave (hmm.h H5 XI): sequences past 2^18 steps have chunks of kHmmLongChunk steps, 16 to a
     // wave; shorter ones at most ~850 chunks (chunk_len)
-    h->xi_slab_cap = std::max<int64_t>(h->xi_waves + 4, h->generic ? 0 : h->npad / (16 * kHmmLongChunk) + 72);
+    h->xi_slab_cap = std::max<int64_t>(h->xi_waves + 4, h->generic ? 0 : h->npad / (16 * (kHmmLongChunk / 2)) + 72);
     h->xi_separate = std::getenv("GMMVB_HMM_XI_SEPARATE") != nullptr;
     const int64_t tk = h->npad * h->Kp;
     // chunk boundary vectors: more than 128 states walk chunks of kHmmGenericChunk steps in the forgetting pass (run_generic)
