@@ -126,9 +126,12 @@ constexpr int64_t kHmmGenericChunk = 256;      // more than 128 states: steps pe
 
 // chunk length: balances the sequential boundary scan (T/L steps of ~1.5 us) against the replay depth
 // (L steps of ~4 us forward+backward): L ~ sqrt(T * 1.5 / 4), a power of two in [16, 4096]
-// Long sequences (more than 2^18 steps): chunks of 256 steps and a two-level boundary pass (hmm.h, H3a / H3b).
+// Long sequences (more than kHmmLongFrom steps): chunks of 256 steps and a two-level boundary pass (hmm.h, H3a / H3b).
+// (round 4: from 2^15 steps instead of 2^18 - with the forgetting pass the long-sequence form costs two sweeps instead of the chunk
+// products, and its short chunks shorten the replays' chains of dependent steps: T = 2e5 4.1 ms per iteration against 1.5)
+constexpr int64_t kHmmLongFrom = int64_t(1) << 15;
 int64_t chunk_len(int64_t T, bool one_level) {
-    if (T > (int64_t(1) << 18) && !one_level) return kHmmLongChunk;
+    if (T > kHmmLongFrom && !one_level) return kHmmLongChunk;
     int64_t L = 16;
     while (L < 4096 && 8 * L * L < 3 * T) L *= 2;
     return L;
@@ -141,7 +144,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     int64_t L = chunk_len(T, false);
     // long sequences whose 256-step chunks are few (64 to a replay workgroup, and the replays / sweeps are chains of dependent
     // steps whose length is the chunk's): chunks of 128 steps - twice the waves, half the chain
-    const bool long_seq = T > (int64_t(1) << 18) && L == kHmmLongChunk;
+    const bool long_seq = T > kHmmLongFrom && L == kHmmLongChunk;
     // (config 5 shape on one box: T = 4e5 2.64 -> 2.12 ms per iteration, 1e6 3.21 -> 2.61, 3e6 4.85 -> 4.56; at 8e6 the shorter
     // chunks lose, 9.79 -> 10.16: the limit is a replay workgroup per CU)
     if (long_seq && (T - 1 + L - 1) / L < 64 * (int64_t)ws->num_cu) L /= 2;

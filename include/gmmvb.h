@@ -203,7 +203,7 @@ int hmmvb_enable(gmmvb_workspace* ws);
 int hmmvb_forward_backward(gmmvb_workspace* ws, int64_t n_rows, const double* pi_tilde_dev, const double* a_tilde_dev,
                            double* out_dev, void* stream);
 /* How the last hmmvb_forward_backward call got its chunk boundary vectors (diagnostics / tests; waits for that call):
- *   -1  from the chunk transfer products (sequences of up to 2^18 steps, more than 64 states, or the forgetting pass held off),
+ *   -1  from the chunk transfer products (short sequences, or the forgetting pass held off),
  *    0  from the forgetting pass - both recursions swept from uniform start vectors, the replays' own boundary vectors agreed
  *       with the sweeps' to 2e-14 -, 1  the forgetting pass ran, its vectors did not stand and the products path ran behind it.
  *   -2  no HMM state / error.  The result of hmmvb_forward_backward is the same in all three cases (to rounding). */
