@@ -55,7 +55,7 @@ struct gmmvb_hmm_state {
     hipEvent_t gate_ev = nullptr;
     bool gate_pending = false, spec_on = true;
     bool vit_coalesced = false;   // the last hmmvb_viterbi call ran the coalescence pass (its gate: gate_dev[1])
-    int spec_hold = 0, last_gate = -1;   // last_gate: -1 no forgetting pass, 0 it stood, 1 products path behind it
+    int spec_hold = 0, spec_hold_len = 8, last_gate = -1;   // last_gate: -1 no forgetting pass, 0 it stood, 1 products path behind it
     bool fuse_emission = false;   // hmmvb_emission_target: gmmvb_estep writes rho' / mx here (hmm.h H0 + H1) and no ln rho array
 };
 
@@ -137,6 +137,24 @@ int64_t chunk_len(int64_t T, bool one_level) {
     return L;
 }
 
+// The gate of the last forgetting pass, once its pinned copy has arrived: a pass that did not stand holds the next ones off -
+// for 8 calls, then 16, ... 64 while it keeps failing (sticky chains with flat emissions pay for a sweep and a replay each time).
+bool consume_gate(gmmvb_hmm_state* h, bool wait) {
+    if (!h->gate_pending) return true;
+    const hipError_t e = wait ? hipEventSynchronize(h->gate_ev) : hipEventQuery(h->gate_ev);
+    if (e == hipErrorNotReady) return true;
+    if (e != hipSuccess) return false;
+    h->gate_pending = false;
+    h->last_gate = *h->gate_host;
+    if (h->last_gate != 0) {
+        h->spec_hold = h->spec_hold_len;
+        h->spec_hold_len = std::min(64, 2 * h->spec_hold_len);
+    } else {
+        h->spec_hold_len = 8;
+    }
+    return true;
+}
+
 template <int KT>
 hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double* pi_tilde, const double* a_tilde,
                double* out, hipStream_t st) {
@@ -181,11 +199,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     // two more passes of K^2 per step.  A call that needed the products holds the pass off for the next eight calls (the
     // gate is copied to pinned memory and looked at when the next call begins: no synchronisation).
     const int* gate = nullptr;
-    if (h->gate_pending && hipEventQuery(h->gate_ev) == hipSuccess) {
-        h->gate_pending = false;
-        if (*h->gate_host != 0) h->spec_hold = 8;
-        h->last_gate = *h->gate_host;
-    }
+    consume_gate(h, /*wait=*/false);
     bool spec = two_level && h->spec_on && h->gate_dev != nullptr && !h->gate_pending;
     if (spec && h->spec_hold > 0) {
         --h->spec_hold;
@@ -284,11 +298,7 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
     // the forgetting pass (run<KT> above): here the products are 85 % of the iteration (T 2 Kp^3 flop)
     const bool two_level = n_chunks > 2 * kHmmSuper;
     const int* gate = nullptr;
-    if (h->gate_pending && hipEventQuery(h->gate_ev) == hipSuccess) {
-        h->gate_pending = false;
-        if (*h->gate_host != 0) h->spec_hold = 8;
-        h->last_gate = *h->gate_host;
-    }
+    consume_gate(h, /*wait=*/false);
     bool spec = two_level && h->spec_on && h->gate_dev != nullptr && !h->gate_pending;
     if (spec && h->spec_hold > 0) {
         --h->spec_hold;
@@ -364,11 +374,7 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
     const int64_t L = kHmmGenericChunk;
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
     const int* gate = nullptr;
-    if (h->gate_pending && hipEventQuery(h->gate_ev) == hipSuccess) {
-        h->gate_pending = false;
-        if (*h->gate_host != 0) h->spec_hold = 8;
-        h->last_gate = *h->gate_host;
-    }
+    consume_gate(h, /*wait=*/false);
     bool spec = h->spec_on && h->gate_dev != nullptr && !h->gate_pending && n_chunks >= 64 && n_chunks <= h->vec_chunks;
     if (spec && h->spec_hold > 0) {
         --h->spec_hold;
@@ -711,12 +717,7 @@ int hmmvb_last_viterbi_pass(gmmvb_workspace* ws) {
 int hmmvb_last_boundary_pass(gmmvb_workspace* ws) {
     if (!ws || !ws->hmm) return -2;
     gmmvb_hmm_state* h = ws->hmm;
-    if (h->gate_pending) {
-        if (hipEventSynchronize(h->gate_ev) != hipSuccess) return -2;
-        h->gate_pending = false;
-        if (*h->gate_host != 0) h->spec_hold = 8;
-        h->last_gate = *h->gate_host;
-    }
+    if (!consume_gate(h, /*wait=*/true)) return -2;
     return h->last_gate;
 }
 
