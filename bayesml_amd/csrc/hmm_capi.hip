@@ -119,9 +119,16 @@ hipError_t hmm_ensure_gamma_cm(gmmvb_hmm_state* h, hipStream_t st) {
 namespace {
 
 constexpr int kLncBlocks = 1024;
-// the forgetting pass stands if no entry of a (sum-1 normalised) boundary vector moves by more than this when its chunk is
-// started from the sweep's vector instead of the uniform one: a fully forgotten start leaves rounding noise of ~1e-15
-constexpr double kHmmForgetTol = 2e-14;
+// the forgetting pass stands if no entry of a (sum-1 normalised) boundary vector moves by more than this RELATIVE to itself
+// when its chunk is started from the sweep's vector instead of the uniform one (hmm.h, hmm_boundary_check_kernel<true>: a test
+// in the Hilbert metric, in which the recursion is non-expansive): a fully forgotten start leaves the rounding noise of sums
+// of positive terms, a few 1e-16 relative per entry whatever its size
+constexpr double kHmmForgetTol = 2e-13;
+// the Viterbi pass's coalescence test (absolute, nats, on omega - max of a chunk's end vector): the two replays of a chunk
+// round sums that reach ~1e4 in magnitude inside the chunk (ulp 2e-12) differently, so ~1e-11 is the noise; start-vector
+// errors add up to at most chunks x tol over the sequence (max-plus maps are 1-Lipschitz): 8e-6 nats at 4e4 chunks, below
+// the rounding of the sequential recursion's own sums at that length (scores ~5e8: ulp 6e-8 per step)
+constexpr double kVitCoalesceTol = 2e-10;
 constexpr int64_t kHmmGenericChunk = 256;      // more than 128 states: steps per workgroup in the forgetting pass
 
 // chunk length: balances the sequential boundary scan (T/L steps of ~1.5 us) against the replay depth
@@ -193,9 +200,9 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     // informative emissions ends in the same normalised alpha (beta~) as from the true one - to rounding.  So: a sweep of both
     // recursions over all chunks from uniform starts (K^2 per step, no stores) gives every chunk a start vector, the replays
     // run from those, and their own end vectors are compared with the sweeps': the difference IS (to first order) the error
-    // of the start vectors used, and at <= 2e-14 (kHmmForgetTol) they stand.  Otherwise - slow mixing, flat emissions - the gate opens and
+    // of the start vectors used, and at <= 2e-13 RELATIVE per entry (kHmmForgetTol, a Hilbert-metric test) they stand.  Otherwise - slow mixing, flat emissions - the gate opens and
     // the products path below runs behind it (its kernels return at once while the gate is shut), replays included: the
-    // result never depends on the forgetting.  The products are T 2 K^3 flop (10 ms of f64 MFMA at config 5), the sweeps
+    // result depends on the forgetting only through start vectors proven within chunks x 4e-13 of the exact ones in the Hilbert metric.  The products are T 2 K^3 flop (10 ms of f64 MFMA at config 5), the sweeps
     // two more passes of K^2 per step.  A call that needed the products holds the pass off for the next eight calls (the
     // gate is copied to pinned memory and looked at when the next call begins: no synchronisation).
     const int* gate = nullptr;
@@ -212,7 +219,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks, h->fstart,
                            h->bend);
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
-        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
         // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
         // made, they simply try the pass again)
@@ -313,7 +320,7 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
         hipLaunchKernelGGL((hmm_backward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
                            h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, 1, h->bend, nullptr);
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
-        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
         // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
         // made, they simply try the pass again)
@@ -393,7 +400,7 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
                            nullptr);
         hipLaunchKernelGGL(hmm_seq_backward_kernel, dim3(g), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, h->a_t, K, Kp, T,
                            sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->bend, 0, h->bend2, nullptr);
-        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
         // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
         // made, they simply try the pass again)
@@ -517,6 +524,11 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
     gmmvb_hmm_state* h = ws->hmm;
     hipStream_t st = (hipStream_t)stream;
     h->vit_coalesced = false;
+    // the pass takes the forward-backward pass's buffers as scratch (chunk products, boundary vectors, xi slabs, w_tm): whatever
+    // that pass left is gone - said explicitly, not only through e_state (hmmvb_readout checks gamma_rows)
+    h->w_valid = false;
+    h->gamma_rows = 0;
+    h->gamma_cm_valid = false;
     if (h->wide && h->phi && n_rows >= kHmmWideMinSteps) {
         // 65 .. 128 states: the chunked max-plus pass with two end states per lane and ln a~ in LDS (hmm_wide.h); scratch as below
         const int64_t L = kHmmWideChunk;
@@ -545,8 +557,8 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
                            ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr); \
         hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3(rgrid), dim3(64 * kVitWideWaves), lds, st, ws->lnrho,        \
                            ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, h->fstart2, nullptr); \
-        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,           \
-                           (chunks - 1) * h->Kp, h->Kp, 1e-9, h->gate_dev + 1);                                                \
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,           \
+                           (chunks - 1) * h->Kp, h->Kp, kVitCoalesceTol, h->gate_dev + 1);                                                \
     }                                                                                                                          \
     if (ew == hipSuccess) {                                                                                                    \
         hipLaunchKernelGGL((hmm_vit_chunk_wide_kernel<KTT>), dim3((unsigned)chunks, (unsigned)((h->K + 4 * kVitWideWaves - 1) / (4 * kVitWideWaves))), dim3(64 * kVitWideWaves), lds, st, \
@@ -593,8 +605,8 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
             hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3((unsigned)chunks), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
                                ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state, L, h->Kp,
                                h->fstart, 0, h->fstart2, nullptr);
-            hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->fstart, h->fstart,
-                               (chunks - 1) * h->Kp, h->Kp, 1e-9, h->gate_dev + 1);
+            hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->fstart, h->fstart,
+                               (chunks - 1) * h->Kp, h->Kp, kVitCoalesceTol, h->gate_dev + 1);
         }
         hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
                            ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state, 0, h->Kp,
@@ -636,7 +648,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
         // start states of a chunk of 256 steps normally merge inside it, and then omega behind the chunk - minus its maximum -
         // does not depend on the chunk's start vector.  A sweep of the replay kernel from zero start vectors (no
         // back-pointers stored) gives every chunk a start vector, the replay runs from those and its own end vectors are
-        // compared with the sweep's: equal to 1e-9 nats, the back-pointers stand (only differences of omega enter them);
+        // compared with the sweep's: equal to 2e-10 nats (kVitCoalesceTol), the back-pointers stand (only differences of omega enter them);
         // otherwise the gate opens and the chunk-matrix path below runs behind it, replay included.
         const int* vgate = nullptr;
         const bool coalesce = L == 256 && chunks >= 64 && h->spec_on && h->gate_dev != nullptr && h->fstart2 != nullptr;
@@ -650,8 +662,8 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
                            ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr);     \
         hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,       \
                            ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, h->fstart2, nullptr);  \
-        hipLaunchKernelGGL(hmm_boundary_check_kernel, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,        \
-                           (chunks - 1) * h->Kp, h->Kp, 1e-9, h->gate_dev + 1);                                             \
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,        \
+                           (chunks - 1) * h->Kp, h->Kp, kVitCoalesceTol, h->gate_dev + 1);                                             \
     }                                                                                                                       \
     if (KTT <= 2) {                                                                                                         \
         constexpr int KPL = KTT <= 1 ? 16 : 32;                                                                             \
@@ -778,8 +790,8 @@ int hmmvb_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_rows, c
     if (!ws || !ws->hmm || !out_dev) return fail(GMMVB_EINVAL, "null argument");
     if (what != 0 && what != 1 && what != 3) return fail(GMMVB_EINVAL, "what must be 0 (alpha), 1 (beta) or 3 (xi)");
     if (what == 3 && !a_tilde_dev) return fail(GMMVB_EINVAL, "a_tilde_dev is needed for xi");
-    if (ws->e_state != 3 || row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows)
-        return fail(GMMVB_ESTATE, "row range outside the last hmmvb_forward_backward");
+    if (ws->e_state != 3 || row0 < 0 || n_rows < 1 || row0 + n_rows > ws->e_rows || row0 + n_rows > ws->hmm->gamma_rows)
+        return fail(GMMVB_ESTATE, "row range outside the last hmmvb_forward_backward (or hmmvb_viterbi has reused its buffers)");
     gmmvb_hmm_state* h = ws->hmm;
     const int64_t total = n_rows * h->K * (what == 3 ? h->K : 1);
     hipLaunchKernelGGL(hmm_readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->alpha_tm,

@@ -240,6 +240,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._x_dev = None
         self._r_cache = None
         self._small_r = None                # device responsibilities of a small-problem fit (_small.py), fetched lazily
+        self._small_x = None                # that fit's rows (<= 16384 x 8): _ln_rho re-runs the final E-step on them when asked
         self._small_fit_impl = None         # test seam of the small-problem launch (tests/fake_engine.py); None = gmmvb_small_fit
 
         self.vl = 0.0
@@ -394,7 +395,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         if _small.applicable(self, x.shape[0], max_itr, num_init, init_type):
             # every restart and iteration in one launch (csrc/small.hip); same draws, same winner rule, same progress lines
             return _small.fit(self, x, max_itr, num_init, tolerance, init_type)
-        self._small_r = None
+        self._reset_small()
         eng, xd = self._open(x)
         K, D = self.c_num_classes, self.c_degree
         dev = xd.device
@@ -533,6 +534,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
     def _reset_small(self):
         self._r_cache = None
         self._small_r = None
+        self._small_x = None
 
     @property
     def r_vecs(self):
@@ -548,6 +550,21 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
 
     @property
     def _ln_rho(self):
+        if self._small_r is not None:
+            # a small-problem fit keeps no [N, K] ln rho (one launch, csrc/small.hip) and no engine: the reference's final pass
+            # (ref:895) is an E-step under the final posterior - run exactly that on the fit's rows (general engine), leaving the
+            # fit's own r_vecs in place
+            if self._small_x is None:
+                return None
+            keep = (self._small_r, self._small_x, self._r_cache)
+            eng, xd = self._open(self._small_x)
+            self._give_params(eng, self._post_tensors(xd.device))
+            eng.estep(xd)
+            out = _np(eng.ln_rho())
+            eng.close()
+            self._engine = self._x_dev = None
+            self._small_r, self._small_x, self._r_cache = keep
+            return out
         return None if self._engine is None else _np(self._engine.ln_rho())
 
     # ------------------------------------------------------------------ read-outs

@@ -119,6 +119,12 @@ def fit(model, x, max_itr, num_init, tolerance, init_type):
 
     # ---- the reference's winner rule and progress lines, replayed from the traces (ref:861-885)
     model._reset_small()
+    # a workspace of an earlier, larger fit describes other rows: release it, so that the lazily fetched [N, K] attributes
+    # (r_vecs from this launch, _ln_rho on demand from these rows) all describe THIS fit
+    if model._engine is not None and model._data_pass_factory is None:
+        model._engine.close()
+    model._engine = model._x_dev = None
+    model._small_x = x
     t0 = 2 + len(TERM_KEYS)
     best_vl, winner, never_converged = 0.0, 0, True
     for i in range(num_init):

@@ -17,7 +17,12 @@ Configurations (BASELINE.json ``configs``): c3 = K64 D128 N1e7 f32 (default, the
 c4 = K256 D64 1.25e7 rows per GPU (N = 1e8 over 8 GPUs), c2 = K16 D32 N1e6 f64.  ``--scaling weak`` (default):
 every rank holds the configuration's rows; ``--scaling strong``: ``--total-rows`` are split over the ranks.
 
-Legs of the default single-GPU run, all on the same JSON line:
+Output: stdout carries ONE compact JSON line (< 6 KB: the contract's keys, `roofline`, `cpu_baseline`, both parity legs,
+`window`, `full_fit_seconds`, `dense_floor_samples_per_s`, an `hmm_c5` sub-line); the full record with every leg, per-step
+lists and kernel groups goes to ``--detail`` (default gpurun_out/bench_detail.json).  Default legs: dense, full, hmm
+(~20 s); hard, spread, offpath, small on request (``--legs all``).
+
+Legs of the single-GPU run (full record):
   value/roofline  the default policy (sparse where the responsibilities are), timed
   dense           the same data pass with the dense f64 MFMA kernels (every pair evaluated): the floor the policy
                   falls back to, its executed TFLOP/s against the f64 MFMA peak, and the difference of the
@@ -81,8 +86,12 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the dense, hard-workload, spread-sweep, full-fit and HMM legs")
-    ap.add_argument("--legs", default="dense,hard,spread,full,hmm,small",
-                    help="comma-separated legs of the single-GPU run (dense, hard, spread, full, hmm, small)")
+    ap.add_argument("--legs", default="dense,full,hmm",
+                    help="comma-separated legs of the single-GPU run (dense, full, hmm by default: about 20 s together; "
+                         "hard, spread, offpath, small on request; 'all' = every leg)")
+    ap.add_argument("--detail", default=os.path.join("gpurun_out", "bench_detail.json"),
+                    help="file that receives the full record (every leg, per-step lists, kernel groups); stdout carries "
+                         "only the compact line.  '' = do not write it, '-' = print it on stdout BEFORE the compact line")
     ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
     ap.add_argument("--force-dist", action="store_true",
                     help="join an RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
@@ -533,6 +542,8 @@ def main():
         dense_leg = hard = spread_leg = full_leg = hmm_leg = small_leg = None
         if not args.dense and world == 1 and not args.no_legs:
             legs = set(args.legs.split(","))
+            if "all" in legs:
+                legs = {"dense", "hard", "spread", "full", "hmm", "small", "offpath"}
             if "dense" in legs:
                 dense_leg = dense_leg_run(w, K, D, n_local, fl_pair)
             w.close()
@@ -580,10 +591,90 @@ def main():
                          "proof_pairs_per_sample": [round(wk.get("proof_pairs", 0.0) / n_local, 3) for wk in works],
                          "sweep_share_of_bound_array": [round(wk.get("sweep_share", -1.0), 3) for wk in works]},
         }
-        print(json.dumps(out), flush=True)
+        out["window"] = (f"VB iterations {args.warmup + 1}-{args.warmup + steps} of one restart (subsampling initialisation + its "
+                         f"data pass + {args.warmup} warm-up iterations are outside the timed region)")
+        emit(out, args)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d} if d is not None else None
+
+
+def compact_line(out):
+    """The ONE line the driver parses (< 6 KB): the contract's keys + roofline + cpu_baseline + both parity legs + the
+    scalars that say what was measured.  Everything else (per-step lists, kernel groups, legs in full) is in the
+    detail record (--detail)."""
+    r = out["roofline"]
+    roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "f64_mfma_frac",
+                     "step_hbm_frac", "f64_mfma_ceiling_samples_per_s", "hbm_roofline_samples_per_s",
+                     "events_ms_per_step", "outside_events_ms_per_step"))
+    roof["pairs_per_sample"] = {k: round(v, 4) for k, v in r["pairs_per_sample"].items()}
+    roof["kernel_groups_ms"] = {g: round(v["ms"], 4) for g, v in r["kernel_groups"].items()}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = _pick(out["config"], ("workload", "classes", "degree", "rows_per_gpu", "rows_total", "x_storage",
+                                           "cluster_spread", "parallelism", "row_tiles"))
+    line["window"] = out["window"]
+    line["roofline"] = roof
+    line["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+    for k in ("parity", "parity_sparse_path"):
+        line[k] = _pick(out[k], ("max_rel_err", "tolerance", "passed", "rows", "iterations", "path"))
+    w = out["per_step"]["wall_ms"]
+    line["first_step_ms"], line["last_step_ms"] = w[0], w[-1]
+    if out.get("full_fit"):
+        line["full_fit_seconds"] = out["full_fit"]["seconds"]
+        line["full_fit_samples_per_s_per_data_pass"] = out["full_fit"]["samples_per_s_per_data_pass"]
+        line["full_fit_what"] = out["full_fit"]["what"]
+    if out.get("dense"):
+        line["dense_floor_samples_per_s"] = out["dense"]["kernel_only_samples_per_s"]
+        line["dense_floor_f64_mfma_frac"] = {"estep": out["dense"]["estep"]["frac_of_f64_mfma_peak"],
+                                             "mstep": out["dense"]["mstep"]["frac_of_f64_mfma_peak"]}
+        line["sparse_vs_dense_statistics_max_rel_diff"] = out["dense"]["sparse_vs_dense_statistics"]["max_rel_diff"]
+    h = out.get("hmm_c5")
+    if h:
+        line["hmm_c5"] = dict(_pick(h, ("value", "unit", "steps", "warmup", "ms_per_step")),
+                              workload=h["config"]["workload"],
+                              roofline=_pick(h["roofline"], ("bound", "achieved", "peak", "unit", "frac", "hbm_frac",
+                                                             "f64_mfma_frac", "traffic")),
+                              parity_max_rel_err=(h["parity"] or {}).get("max_rel_err"),
+                              cpu_baseline_value=(h["cpu_baseline"] or {}).get("value"),
+                              boundary_pass=h.get("boundary_pass"),
+                              viterbi_ms=(h.get("viterbi") or {}).get("ms"))
+    for k in ("hard_workload", "spread_sweep", "offpath"):
+        if out.get(k):
+            line[k] = out[k].get("summary")
+    if out["n_gpus"] > 1 or out.get("allreduce"):
+        line["rccl_ranks"] = out["rccl_ranks"]
+        line["allreduce"] = out["allreduce"]
+        line["estep_kinds_identical_across_ranks"] = out["estep_kinds_identical_across_ranks"]
+        line["per_rank_ms_per_step"] = [round(p["ms_per_step"], 3) for p in out["per_rank"]]
+    return line
+
+
+def emit(out, args):
+    """Full record to the detail file, the compact line - and nothing else - on stdout."""
+    line = compact_line(out)
+    if args.detail == "-":
+        print(json.dumps(out), flush=True)
+    elif args.detail:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+            with open(args.detail, "w") as f:
+                json.dump(out, f)
+            line["detail"] = args.detail
+        except OSError:
+            pass
+    # the driver's record keeps a bounded tail of stdout: never let the line outgrow it (drop optional blocks first)
+    for drop in (None, "hmm_c5", "offpath", "spread_sweep", "hard_workload", "per_rank_ms_per_step", "full_fit_what"):
+        if drop:
+            line.pop(drop, None)
+        text = json.dumps(line)
+        if len(text) < 6000:
+            break
+    print(text, flush=True)
 
 
 def dense_leg_run(w, K, D, n_local, fl_pair):
@@ -641,6 +732,7 @@ def hard_workload_leg(K, D, n_local, tdtype, ndtype, dev, warmup=2, steps=3, par
     out = {"workload": f"K={K} D={D} N={n_local}, cluster means 0.3 * randn (overlapping)", "steps": steps, "warmup": warmup,
            "samples_per_s": n_local * steps / dt_s, "ms_per_step": dt_s / steps * 1e3,
            "kernel_launches": {k: c1[k] - c0[k] for k in c1}, "per_step": snaps}
+    out["summary"] = {"samples_per_s": out["samples_per_s"], "ms_per_step": out["ms_per_step"]}
     w.close()
     if parity:       # a bounded oracle run on overlapping rows (6 iterations over 6000 rows), both policies
         x_ref = recipe_rows_host(K, D, min(6000, n_local), ndtype, 0.3)
@@ -702,7 +794,10 @@ def spread_sweep_leg(K, D, n, tdtype, ndtype, dev, spreads=(0.5, 0.75, 1.0, 1.5)
         rows.append(r)
     return {"workload": f"K={K} D={D} N={n}, cluster means spread * randn; iterations {warmup + 1}-{warmup + steps} of one restart",
             "steps": steps, "warmup": warmup, "spreads": rows,
-            "worst_default_over_dense": max(r["default_over_dense"] for r in rows)}
+            "worst_default_over_dense": max(r["default_over_dense"] for r in rows),
+            "summary": {"default_over_dense": {str(r["spread"]): round(r["default_over_dense"], 3) for r in rows},
+                        "parity_max_rel_err": max([max(r["parity"]["max_rel_err"], r["parity_sparse_path"]["max_rel_err"])
+                                                   for r in rows if "parity" in r] or [None])}}
 
 
 def full_fit_leg(K, D, x, dev, max_itr=25, num_init=2):

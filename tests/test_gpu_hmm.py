@@ -342,6 +342,86 @@ def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
     assert abs(ref["lnc"] - got["lnc"]) <= 1e-11 * abs(ref["lnc"])
 
 
+def test_forgetting_gate_sees_an_unreachable_state(monkeypatch):
+    """Round-4 advisor's counter-example to an ABSOLUTE boundary test: two states, a~_01 = 1e-40 (exp(psi(0.01)) ~ 1e-44 is
+    reachable with a sparse h0_zeta prior), a~_10 = 0.02, emission means 0 and 0.8.  The exact alpha_t(1) is ~1e-40 while the
+    chain sits in state 0; a sweep restarted from the uniform vector leaves ~1e-19 there after 128 steps - invisible to an
+    absolute 2e-14 test - and a following stretch of 110 steps at x = 1.14 (likelihood ratio e^0.59 per step: 1e28 in all)
+    amplifies exactly that entry to O(1): gamma wrong by O(1) with the gate shut.  The gate's test is relative per entry
+    (Hilbert metric, hmm.h hmm_boundary_check_kernel<true>): it must open, and the result must be the chunk-product path's."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    dev = torch.device("cuda", 0)
+    K, D, T = 2, 1, 270001
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((T, D))
+    for c0 in (300, 1000, 1700):                         # stretches that start on chunk boundaries of 128 and 256 steps
+        x[1 + 256 * c0: 1 + 256 * c0 + 110] = 1.14
+    x = x.astype(np.float32)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
+    f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), t([[0.0], [0.8]]), t(np.full(K, 2.0)),
+                                     t(np.full(K, D + 3.0)), t(np.full((K, 1, 1), D + 3.0))))
+    c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
+    a = t([[1.0, 1e-40], [0.02, 0.98]])
+    pi = t([0.999, 0.001])
+    xd = torch.from_numpy(x).to(dev)
+    res = []
+    for off in (True, False):
+        if off:
+            monkeypatch.setenv("GMMVB_HMM_FORGETTING_OFF", "1")
+        else:
+            monkeypatch.delenv("GMMVB_HMM_FORGETTING_OFF", raising=False)
+        eng = DataPass(K, D, xd.dtype, T, dev)
+        eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+        eng.prepare_rows(xd)
+        eng.enable_hmm()
+        eng.set_params(c, f.m, f.u)
+        eng.estep(xd)
+        ms, g0, gl, lnc = eng.forward_backward(pi, a)
+        how = eng.last_boundary_pass()
+        seg = torch.cat([eng.responsibilities(1 + 256 * c0 - 50, 400) for c0 in (300, 1000, 1700)]).clone()
+        res.append((how, ms.clone(), seg, float(lnc)))
+        eng.close()
+    (how0, ms0, seg0, lnc0), (how1, ms1, seg1, lnc1) = res
+    assert how0 == -1 and how1 == 1, (how0, how1)        # the pass must NOT stand here
+    # the exact answer: the chain stays in state 0 through the stretches (1e-40 x 1e28 is still 1e-12)
+    assert float(seg0[:, 1].max()) < 1e-6
+    assert float((seg0 - seg1).abs().max()) <= 1e-12
+    assert float((ms0 - ms1).abs().max()) <= 1e-9 * float(ms0.abs().max())
+    assert abs(lnc0 - lnc1) <= 1e-12 * abs(lnc0)
+
+
+def test_viterbi_invalidates_the_forward_backward_read_outs():
+    """hmmvb_viterbi takes the forward-backward pass's buffers as scratch: a read-out of that pass afterwards is refused
+    (explicitly: gamma_rows = 0), whatever state the E-step flags are in."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass, EngineError
+    dev = torch.device("cuda", 0)
+    K, D, T = 4, 2, 5000
+    x, _ = orc.synth_hmm(K, D, T, np.float32, seed=3)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)   # noqa: E731
+    rng = np.random.default_rng(1)
+    f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), t(x[rng.integers(0, T, K)].astype(np.float64)),
+                                     t(np.full(K, 2.0)), t(np.full(K, D + 3.0)),
+                                     t(np.broadcast_to(np.eye(D) * (D + 3.0), (K, D, D)).copy())))
+    c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
+    a = np.eye(K) * 0.9 + 0.1 / K
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    eng = DataPass(K, D, xd.dtype, T, dev)
+    eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+    eng.prepare_rows(xd)
+    eng.enable_hmm()
+    eng.set_params(c, f.m, f.u)
+    eng.estep(xd)
+    eng.forward_backward(t(np.full(K, 1.0 / K)), t(a))
+    assert eng.hmm_readout("xi", 10, 5, a_tilde=t(a)).shape == (5, K, K)
+    eng.estep(xd)
+    eng.viterbi(t(np.log(np.full(K, 1.0 / K))), t(np.log(a)))
+    with pytest.raises(EngineError):
+        eng.hmm_readout("xi", 10, 5, a_tilde=t(a))
+    eng.close()
+
+
 def test_update_posterior_through_the_forgetting_pass(monkeypatch):
     """The whole VB loop of a long sequence (public API: fused emission, closed-form sum gamma ln rho, xi in the backward replay,
     boundary vectors by forgetting) against the same loop on the chunk-product path."""

@@ -136,3 +136,28 @@ def test_small_fit_is_bypassed_outside_its_range():
     x = orc.synth_gmm(3, 2, 20000, np.float64)
     m, _t, _w = _run(3, 2, x, 0, dict(num_init=1, max_itr=3))
     assert m._engine is not None and m._small_r is None
+
+
+def test_small_fit_after_a_large_one_leaves_one_consistent_pass():
+    """A small-problem fit releases the workspace of an earlier, larger fit: r_vecs (from the launch) and _ln_rho (the final
+    E-step of ref:895, re-run on demand) both describe the small fit's rows."""
+    from bayesml_amd import gaussianmixture as gm
+    rng = np.random.default_rng(4)
+    mu = np.array([[-4.0, 0.0], [4.0, 0.0], [0.0, 5.0]])
+    big = (mu[rng.integers(0, 3, 40000)] + rng.standard_normal((40000, 2)))
+    small = (mu[rng.integers(0, 3, 700)] + rng.standard_normal((700, 2)))
+    m = gm.LearnModel(3, 2, seed=1, device="cuda:0", verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.update_posterior(big, max_itr=5, num_init=1)
+        assert m._engine is not None and m.r_vecs.shape == (40000, 3)
+        m.update_posterior(small, max_itr=20, num_init=2)
+    assert m._engine is None and m._x_dev is None
+    r = m.r_vecs
+    assert r.shape == (700, 3)
+    ln_rho = m._ln_rho
+    assert ln_rho.shape == (700, 3)
+    soft = np.exp(ln_rho - ln_rho.max(axis=1, keepdims=True))
+    soft /= soft.sum(axis=1, keepdims=True)
+    assert np.max(np.abs(soft - r)) < 1e-9
+    assert m.r_vecs is r and m._engine is None          # the read-out left the fit's own arrays in place

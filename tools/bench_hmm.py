@@ -144,6 +144,18 @@ def measure(args, dev=None):
                 "frac": alg * T / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_time_step": alg,
                 "estimated_swept_bytes_per_time_step": swept, "estimated_swept_GBps": swept * T / (ms * 1e-3) / 1e9,
                 "hbm_roofline_time_steps_per_s": 8e12 / alg, "traffic": None}
+    # the other yardstick: the f64 matrix pipe.  Algorithmic flop per time step, as the reference computes it: emission
+    # K(2 D^2 + 3 D) (ref:988-997), statistics K(2 D^2 + 2 D) + 2 K D (ref:837-845), forward, backward and the xi sum
+    # 2 K^2 each (ref:999-1018), gamma K.  At K = 32, D = 16: 42.5 kflop against 576 B = 74 flop/B, above the pipe's
+    # balance of 78.6 TFLOP/s / 8 TB/s = 9.8 flop/B -> the pipe binds; `bound` names the larger fraction.
+    flop = K * (2 * D * D + 3 * D) + K * (2 * D * D + 2 * D) + 2 * K * D + 3 * 2 * K * K + K
+    tf = flop * T / (ms * 1e-3) / 1e12
+    roofline["hbm_frac"] = roofline["frac"]
+    roofline["hbm_achieved_GBps"] = roofline["achieved"]
+    roofline["algorithmic_flop_per_time_step"] = flop
+    roofline["f64_mfma_frac"] = tf / 78.6
+    if roofline["f64_mfma_frac"] > roofline["hbm_frac"]:
+        roofline.update(bound="mfma", achieved=tf, peak=78.6, unit="TFLOP/s", frac=tf / 78.6)
     try:            # measured HBM bytes per iteration (tools/hmm_pmc_total.py), only if made for this very workload
         with open(os.path.join(ROOT, "profiles", "hmm_pmc_traffic.json")) as f:
             pm = json.load(f)

@@ -13,7 +13,7 @@ for stage in "$@"; do
     newtests) timeout 1500 python -m pytest tests/test_gpu_sparse_parity.py -x -q -m gpu > $OUT/${TAG}_newtests.log 2>&1; tail -15 $OUT/${TAG}_newtests.log ;;
     tests) timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_gpu_tests.log 2>&1; tail -8 $OUT/${TAG}_gpu_tests.log ;;
     bench) timeout 900 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err; tail -c 600 $OUT/${TAG}_bench.err; head -c 1500 $OUT/${TAG}_bench_line.json; echo ;;
-    bench20) timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_w5s20.json 2> $OUT/${TAG}_bench20.err; tail -c 600 $OUT/${TAG}_bench20.err; head -c 600 $OUT/${TAG}_bench_line_w5s20.json; echo ;;
+    bench20) timeout 900 python bench.py --steps 20 --warmup 5 --detail $OUT/${TAG}_bench_detail_w5s20.json > $OUT/${TAG}_bench_line_w5s20.json 2> $OUT/${TAG}_bench20.err; tail -c 600 $OUT/${TAG}_bench20.err; cat $OUT/${TAG}_bench_line_w5s20.json; echo ;;
     dense) timeout 600 python bench.py --dense --no-cpu > $OUT/${TAG}_bench_line_dense.json 2> $OUT/${TAG}_dense.err; head -c 600 $OUT/${TAG}_bench_line_dense.json; echo ;;
     c4) timeout 900 python bench.py --config c4 --no-cpu > $OUT/${TAG}_bench_line_c4.json 2> $OUT/${TAG}_c4.err; tail -c 600 $OUT/${TAG}_c4.err; head -c 600 $OUT/${TAG}_bench_line_c4.json; echo ;;
     c2) timeout 600 python bench.py --config c2 > $OUT/${TAG}_bench_line_c2.json 2> $OUT/${TAG}_c2.err; tail -c 600 $OUT/${TAG}_c2.err; head -c 600 $OUT/${TAG}_bench_line_c2.json; echo ;;
@@ -52,7 +52,7 @@ PY
          python tools/hmm_pmc_total.py $OUT/${TAG}_hmm_pmc_FETCH_SIZE $OUT/${TAG}_hmm_pmc_WRITE_SIZE --config "K32 D16 T10000000" --json $OUT/${TAG}_hmm_pmc_traffic.json > $OUT/${TAG}_hmm_pmc_summary.md 2> $OUT/${TAG}_hmm_pmc.err; cat $OUT/${TAG}_hmm_pmc_summary.md
          [ -s $OUT/${TAG}_hmm_pmc_traffic.json ] && cp $OUT/${TAG}_hmm_pmc_traffic.json profiles/hmm_pmc_traffic.json      # (later stages of this call quote it)
          find $OUT/${TAG}_hmm_pmc_FETCH_SIZE $OUT/${TAG}_hmm_pmc_WRITE_SIZE -name "*.csv" -size +20M -delete ;;
-    c4w5) timeout 900 python bench.py --config c4 --no-cpu --no-legs --steps 20 --warmup 5 > $OUT/${TAG}_bench_line_c4_w5s20.json 2> $OUT/${TAG}_c4w5.err; head -c 400 $OUT/${TAG}_bench_line_c4_w5s20.json; echo ;;
+    c4w5) timeout 900 python bench.py --config c4 --no-cpu --no-legs --steps 20 --warmup 5 --detail $OUT/${TAG}_bench_detail_c4_w5s20.json > $OUT/${TAG}_bench_line_c4_w5s20.json 2> $OUT/${TAG}_c4w5.err; cat $OUT/${TAG}_bench_line_c4_w5s20.json; echo ;;
     c4strong) timeout 1200 python bench.py --config c4 --scaling strong --gpus 1 --no-cpu --no-legs --steps 3 --warmup 1 > $OUT/${TAG}_bench_line_c4_strong1.json 2> $OUT/${TAG}_c4strong.err; tail -c 300 $OUT/${TAG}_c4strong.err; head -c 500 $OUT/${TAG}_bench_line_c4_strong1.json; echo ;;
     proofbench) timeout 600 python tools/bench_proof.py > $OUT/${TAG}_bench_proof.json 2> $OUT/${TAG}_bench_proof.err; head -c 500 $OUT/${TAG}_bench_proof.json; echo ;;
     hmmbig) timeout 900 python tools/bench_hmm.py --classes 128 --degree 8 --rows 200000 --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_hmm_k128_line.json 2> $OUT/${TAG}_hmmbig.err; head -c 300 $OUT/${TAG}_hmm_k128_line.json; echo
