@@ -57,6 +57,9 @@ SYMBOLS = {
     "gmmvb_comm_create": (_int, [_vp, _int, _int, ctypes.POINTER(_vp)]),
     "gmmvb_comm_destroy": (_int, [_vp]),
     "gmmvb_allreduce_stats": (_int, [_vp, _vp, _i64, _vp]),
+    "gmmvb_stats_packed_len": (_i64, [_int, _int]),
+    "gmmvb_stats_pack": (_int, [_int, _int, _vp, _vp, _vp]),
+    "gmmvb_stats_unpack": (_int, [_int, _int, _vp, _vp, _vp]),
     "gmmvb_set_shard": (_int, [_vp, _i64, _int]),
     "gmmvb_policy_export": (_int, [_vp, _vp, _vp]),
     "gmmvb_policy_import": (_int, [_vp, _vp, _vp]),
@@ -250,6 +253,19 @@ def kside_step(K, D, prior_v, q_v, qn_v, stats, pivot, s_prev, ns, x_bar, s, wan
                                          pivot.data_ptr(), s_prev.data_ptr(), ns.data_ptr(), x_bar.data_ptr(), s.data_ptr(),
                                          int(want_drift), gamma.data_ptr(), delta.data_ptr(), big.data_ptr(), scal.data_ptr(),
                                          scratch.data_ptr(), st), "gmmvb_kside_step")
+
+
+def stats_triangle(pack: bool, K: int, D: int, src: torch.Tensor, dst: torch.Tensor):
+    """gmmvb_stats_pack / gmmvb_stats_unpack on the current stream of ``src``' device: the statistics block <-> the block
+    on the wire, [ns | h | a | upper triangles of B] (contiguous float64 device tensors that do not overlap)."""
+    lib = load_library()
+    dev = src.device
+    with torch.cuda.device(dev):
+        st = _vp(torch.cuda.current_stream(dev).cuda_stream)
+        if pack:
+            _check(lib, lib.gmmvb_stats_pack(K, D, src.data_ptr(), dst.data_ptr(), st), "gmmvb_stats_pack")
+        else:
+            _check(lib, lib.gmmvb_stats_unpack(K, D, src.data_ptr(), dst.data_ptr(), st), "gmmvb_stats_unpack")
 
 
 def kside_drift(q_old, q_new, squarings: int, squarings_big: int):

@@ -378,6 +378,31 @@ def _clone_post(src: PostT) -> PostT:
     return q
 
 
+def packed_stats_len(K: int, D: int) -> int:
+    """gmmvb_stats_packed_len: [ns K | h K | a K D | upper triangles of B, K D (D + 1) / 2]."""
+    return K * (2 + D) + K * D * (D + 1) // 2
+
+
+def stats_triangle(pack: bool, K: int, D: int, src: torch.Tensor, dst: torch.Tensor):
+    """The statistics block <-> the block on the wire (gmmvb_stats_pack / gmmvb_stats_unpack): the C-ABI kernels on a
+    GPU, the same index map in torch on the CPU (host-logic and gloo tests)."""
+    if src.is_cuda:
+        from . import _engine
+        _engine.stats_triangle(pack, K, D, src, dst)
+        return
+    head = K * (2 + D)
+    iu = torch.triu_indices(D, D)
+    if pack:
+        dst[:head] = src[:head]
+        dst[head:] = src[head:].view(K, D, D)[:, iu[0], iu[1]].reshape(-1)
+    else:
+        dst[:head] = src[:head]
+        B = dst[head:].view(K, D, D)
+        tri = src[head:].view(K, -1)
+        B[:, iu[0], iu[1]] = tri
+        B[:, iu[1], iu[0]] = tri
+
+
 class KStepper:
     """Everything K-sized that one VB iteration does between two data passes, as ONE unit on the GPU:
 
@@ -407,6 +432,9 @@ class KStepper:
         self.stats_and_tail = torch.zeros(stats_len + 16, dtype=torch.float64, device=dev)
         self.stats = self.stats_and_tail[:stats_len]
         self.tail = self.stats_and_tail[stats_len:]
+        # the block on the wire of a row-sharded job (made on first use): [ns | h | a | upper triangles of B | policy tail] -
+        # B is symmetric, the lower triangles need not travel (include/gmmvb.h, gmmvb_stats_pack)
+        self._wire = None
         self.s_prev = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
         self.q = _clone_post(post_from_prior(prior))
         self.q_next = _clone_post(self.q)
@@ -427,6 +455,22 @@ class KStepper:
             self._eng = _engine
             self._prior_v = _engine.prior_view(prior)
             self._scratch = torch.zeros(13 * K, dtype=torch.float64, device=dev)
+
+    def wire(self):
+        """(whole wire buffer, its packed statistics part, its policy tail) of a row-sharded job."""
+        if self._wire is None:
+            n = packed_stats_len(self.K, self.D)
+            buf = torch.zeros(n + 16, dtype=torch.float64, device=self.stats.device)
+            self._wire = (buf, buf[:n], buf[n:])
+        return self._wire
+
+    def pack(self):
+        """statistics block -> wire buffer (the tail is written there directly by the engine's policy_export)."""
+        stats_triangle(True, self.K, self.D, self.stats, self.wire()[1])
+
+    def unpack(self):
+        """summed wire buffer -> statistics block, B mirrored from its summed upper triangle."""
+        stats_triangle(False, self.K, self.D, self.wire()[1], self.stats)
 
     def load(self, q: PostT):
         """Make ``q`` (with its features) the current posterior."""

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -50,6 +51,32 @@ const Rccl* rccl() {
     });
     const bool ok = g_rccl.handle && g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce;
     return ok ? &g_rccl : nullptr;
+}
+
+// [ns | h | a | B] <-> [ns | h | a | upper triangles of B]: one thread per entry of the FULL block, so that the unpacking
+// writes are contiguous; entry (i, j) of a D x D block lives at tri(min, max) of the packed one
+__device__ __forceinline__ int64_t tri_index(int i, int j, int D) {      // i <= j
+    return (int64_t)i * D - (int64_t)i * (i - 1) / 2 + (j - i);
+}
+template <bool PACK>
+__global__ __launch_bounds__(256) void stats_triangle_kernel(const double* __restrict__ src, double* __restrict__ dst, int K, int D) {
+    const int64_t head = (int64_t)K * (2 + D), dd = (int64_t)D * D, tt = (int64_t)D * (D + 1) / 2;
+    const int64_t full = head + K * dd;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < full; e += (int64_t)gridDim.x * 256) {
+        if (e < head) {
+            dst[e] = src[e];
+            continue;
+        }
+        const int64_t r = e - head;
+        const int k = (int)(r / dd);
+        const int i = (int)((r - k * dd) / D), j = (int)(r - k * dd - (int64_t)i * D);
+        const int64_t t = head + k * tt + tri_index(i < j ? i : j, i < j ? j : i, D);
+        if (PACK) {
+            if (i <= j) dst[t] = src[e];
+        } else {
+            dst[e] = src[t];
+        }
+    }
 }
 
 int nccl_fail(const Rccl* r, const char* what, ncclResult_t rc) {
@@ -101,6 +128,31 @@ int gmmvb_comm_destroy(gmmvb_comm* comm) {
     if (r && comm->comm) (void)r->CommDestroy(comm->comm);
     delete comm;
     return GMMVB_OK;
+}
+
+int64_t gmmvb_stats_packed_len(int K, int D) {
+    return (K < 1 || D < 1) ? -1 : (int64_t)K * (2 + D) + (int64_t)K * D * (D + 1) / 2;
+}
+
+static int stats_triangle(bool pack, int K, int D, const double* src, double* dst, void* stream) {
+    if (K < 1 || D < 1 || !src || !dst) return fail(GMMVB_EINVAL, "bad argument");
+    const int64_t full = (int64_t)K * (2 + D) + (int64_t)K * D * D;
+    const unsigned grid = (unsigned)std::min<int64_t>((full + 255) / 256, 4096);
+    if (pack)
+        hipLaunchKernelGGL(stats_triangle_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, K, D);
+    else
+        hipLaunchKernelGGL(stats_triangle_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, K, D);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, pack ? "stats_pack launch" : "stats_unpack launch", e);
+    return GMMVB_OK;
+}
+
+int gmmvb_stats_pack(int K, int D, const double* stats_dev, double* packed_dev, void* stream) {
+    return stats_triangle(true, K, D, stats_dev, packed_dev, stream);
+}
+
+int gmmvb_stats_unpack(int K, int D, const double* packed_dev, double* stats_dev, void* stream) {
+    return stats_triangle(false, K, D, packed_dev, stats_dev, stream);
 }
 
 int gmmvb_allreduce_stats(gmmvb_comm* comm, double* stats_dev, int64_t len, void* stream) {

@@ -344,15 +344,24 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             eng.estep_mstep(xd, out=ks.stats)
         else:
             eng.mstep(xd, out=ks.stats)
-        if estep and getattr(self._comm, "world", 1) > 1 and hasattr(eng, "policy_export") and not getattr(
-                self._comm, "restart_parallel", False):
-            # row shards: the engine's pass-policy counters ride behind the statistics block, so that every rank's
-            # next E-step decides from the same job-wide numbers - still ONE collective per iteration
-            eng.policy_export(ks.tail)
-            self._comm.all_reduce_(ks.stats_and_tail)
-            eng.policy_import(ks.tail)
+        comm = self._comm
+        sharded = (getattr(comm, "world", 1) > 1 or getattr(comm, "always", False)) and not getattr(comm, "restart_parallel", False)
+        if not sharded:
+            return
+        # row shards: ONE collective per iteration, of the block on the wire - [ns | h | a | upper triangles of B] (B is
+        # symmetric: half of the full block's bytes) - with the engine's pass-policy counters riding behind it, so that every
+        # rank's next E-step decides from the same job-wide numbers
+        buf, _packed, tail = ks.wire()
+        policy = estep and getattr(comm, "world", 1) > 1 and hasattr(eng, "policy_export")
+        if policy:
+            eng.policy_export(tail)
         else:
-            self._comm.all_reduce_(ks.stats)
+            tail.zero_()
+        ks.pack()
+        comm.all_reduce_(buf)
+        ks.unpack()
+        if policy:
+            eng.policy_import(tail)
 
     def _give_params(self, eng, q, hint=None):
         """Hand a posterior's E-step parameters to the engine; ``hint`` = (gamma, delta, big_gamma, mean gamma) of the update

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GMMVB_ABI_VERSION 6
+#define GMMVB_ABI_VERSION 7
 
 enum gmmvb_status {
     GMMVB_OK = 0,
@@ -145,6 +145,20 @@ int gmmvb_comm_unique_id(unsigned char* id_out /*[128]*/);
 int gmmvb_comm_create(const unsigned char* id /*[128]*/, int n_ranks, int rank, gmmvb_comm** out);
 int gmmvb_comm_destroy(gmmvb_comm* comm);
 int gmmvb_allreduce_stats(gmmvb_comm* comm, double* stats_dev, int64_t len, void* stream);
+
+/* The block on the wire (ABI v7).  B_k = sum_n r_nk (x_n - p)(x_n - p)^T is symmetric and gmmvb_mstep mirrors it exactly,
+ * so the lower triangle of every D x D block is redundant in the exchange: gmmvb_stats_pack writes
+ *   [ns K | h K | a K D | upper triangles of B, row by row, K D (D + 1) / 2]   = gmmvb_stats_packed_len(K, D) doubles
+ * (4.3 MB instead of 8.5 MB at K = 64, D = 128 and at K = 256, D = 64), gmmvb_stats_unpack restores the full block after
+ * the all-reduce, mirroring the summed upper triangle - which also makes the reduced B exactly symmetric whatever order a
+ * ring reduces its segments in.  Device pointers; the two buffers must not overlap.  The policy tail of a sharded job
+ * (below) rides behind the packed block the same way it rode behind the full one.
+ *   per pass:  gmmvb_estep_mstep(..., stats); gmmvb_stats_pack(K, D, stats, wire, stream);
+ *              gmmvb_allreduce_stats(comm, wire, gmmvb_stats_packed_len(K, D) [+ GMMVB_POLICY_LEN], stream);
+ *              gmmvb_stats_unpack(K, D, wire, stats, stream) */
+int64_t gmmvb_stats_packed_len(int K, int D);
+int gmmvb_stats_pack(int K, int D, const double* stats_dev, double* packed_dev, void* stream);
+int gmmvb_stats_unpack(int K, int D, const double* packed_dev, double* stats_dev, void* stream);
 
 /* One pass policy for all ranks.  Inside gmmvb_estep the library chooses between its dense kernel, a fresh bound pass
  * and carrying the previous pass's bounds from counters of the previous pass (how many pairs were active, evaluated,

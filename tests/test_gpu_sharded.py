@@ -241,3 +241,25 @@ def test_two_ranks_of_resident_tiles_match_the_reference(tmp_path):
     for key in ("hn_m_vecs", "hn_w_mats", "ns"):          # both ranks hold the same posterior, bit for bit
         assert np.array_equal(res[0][key], res[1][key]), key
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,D", [(64, 128), (256, 64), (3, 5), (1, 1)])
+def test_wire_block_kernels_match_the_index_map(K, D):
+    """gmmvb_stats_pack / gmmvb_stats_unpack against the torch index map of _kside.stats_triangle (the CPU tests' path)."""
+    from bayesml_amd import _kside
+    g = torch.Generator().manual_seed(K * 1000 + D)
+    head = torch.randn(K * (2 + D), dtype=torch.float64, generator=g)
+    B = torch.randn(K, D, D, dtype=torch.float64, generator=g)
+    B = B + B.transpose(1, 2)
+    full = torch.cat([head, B.reshape(-1)])
+    n = _kside.packed_stats_len(K, D)
+    want = torch.zeros(n, dtype=torch.float64)
+    _kside.stats_triangle(True, K, D, full, want)
+    dev = torch.device("cuda", 0)
+    got = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    _kside.stats_triangle(True, K, D, full.to(dev), got)
+    assert torch.equal(got.cpu(), want)
+    back = torch.full_like(full, float("nan")).to(dev)
+    _kside.stats_triangle(False, K, D, got, back)
+    assert torch.equal(back.cpu(), full)

@@ -456,3 +456,32 @@ def test_row_tiles_host_logic(monkeypatch, resident):
     assert float(st[0]) == N * K and float(st[1]) == N
     eng.close()
     assert all(t.closed for t in tiles)
+
+
+def test_wire_block_packs_the_upper_triangles():
+    """The block a row-sharded job all-reduces: [ns | h | a | upper triangles of B] (gmmvb_stats_pack's layout, here the
+    torch index map the CPU tests run) - half of the full block's bytes, and the round trip restores a mirrored block."""
+    import torch
+    from bayesml_amd import _kside
+    K, D = 3, 5
+    g = torch.Generator().manual_seed(0)
+    head = torch.randn(K * (2 + D), dtype=torch.float64, generator=g)
+    B = torch.randn(K, D, D, dtype=torch.float64, generator=g)
+    B = B + B.transpose(1, 2)
+    full = torch.cat([head, B.reshape(-1)])
+    n = _kside.packed_stats_len(K, D)
+    assert n == K * (2 + D) + K * D * (D + 1) // 2
+    wire = torch.zeros(n, dtype=torch.float64)
+    _kside.stats_triangle(True, K, D, full, wire)
+    assert torch.equal(wire[:K * (2 + D)], head)
+    assert torch.equal(wire[K * (2 + D):K * (2 + D) + D], B[0, 0])              # row 0 of the first block, whole
+    assert wire[K * (2 + D) + D] == B[0, 1, 1]                                    # row 1 starts on the diagonal
+    back = torch.full_like(full, float("nan"))
+    _kside.stats_triangle(False, K, D, wire, back)
+    assert torch.equal(back, full)
+    # a block whose lower triangle disagrees comes back mirrored from the UPPER one
+    lop = full.clone()
+    lop[K * (2 + D) + D] += 1.0                                                   # entry (1, 0) of block 0
+    _kside.stats_triangle(True, K, D, lop, wire)
+    _kside.stats_triangle(False, K, D, wire, back)
+    assert torch.equal(back, full)
