@@ -265,6 +265,7 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
         v = std::getenv("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
         ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
+        ws->opt_hmm_mstep_dense = std::getenv("GMMVB_HMM_MSTEP_DENSE") != nullptr;
         ws->opt_debug = std::getenv("GMMVB_DEBUG") != nullptr;
     }
     {
@@ -1896,7 +1897,8 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             const int KGW = (ws->K + per_wg - 1) / per_wg;
             grid = 8 * ((S + 7) / 8) * KGW;
             if (hmm_small)
-                e = launch_hmm_mstep_small((int)grid, st, a, KGW, hmm_gamma_tm(ws->hmm), hmm_padded_states(ws->hmm), &name);
+                e = launch_hmm_mstep_small((int)grid, st, a, KGW, hmm_gamma_tm(ws->hmm), hmm_padded_states(ws->hmm),
+                                           !ws->opt_hmm_mstep_dense, &name);
             else
                 e = launch_mstep_small((int)grid, st, a, KGW, kSmallCw, &name);
         } else {

@@ -477,7 +477,7 @@ template <int KT>
 __device__ __forceinline__ void hmm_forward_replay_body(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
                                                         int64_t T, int64_t L, int64_t n_chunks, const double* __restrict__ fstart,
                                                         double* __restrict__ alpha_tm, double* __restrict__ cprime, int sweep,
-                                                        double* __restrict__ end_out) {
+                                                        double* __restrict__ end_out, int64_t s_from = 0 /*sweep: first step walked*/) {
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     // kReplayChunks chunks per wave: with fewer than 16 the MFMA columns j and j + kReplayChunks carry the same chunk (only
@@ -493,13 +493,13 @@ __device__ __forceinline__ void hmm_forward_replay_body(const double* __restrict
     for (int it = 0; it < KT; ++it)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            al[it][r] = !live ? 0.0 : ((sweep && c > 0) ? (16 * it + g + 4 * r < K ? 1.0 / K : 0.0) : fstart[c * Kp + 16 * it + g + 4 * r]);
+            al[it][r] = !live ? 0.0 : ((sweep && (c > 0 || s_from > 0)) ? (16 * it + g + 4 * r < K ? 1.0 / K : 0.0) : fstart[c * Kp + 16 * it + g + 4 * r]);
     if (live && c == 0 && !sweep) {                              // alpha_0 itself is part of the output
 #pragma unroll
         for (int it = 0; it < KT; ++it) *reinterpret_cast<d4*>(alpha_tm + 16 * it + 4 * g) = al[it];
     }
     const int64_t t0 = 1 + c * L;
-    for (int64_t s = 0; s < L; ++s) {
+    for (int64_t s = s_from; s < L; ++s) {
         const int64_t t = t0 + s;
         const bool on = live && t < T;
         const bool st = on && first_copy && !sweep;
@@ -550,7 +550,8 @@ __global__ __launch_bounds__(256) void hmm_forward_replay_kernel(const double* _
 // The backward recursion alone (no gamma, no xi): beta~ in front of chunk c from the uniform vector behind it -> row c - 1.
 template <int KT>
 __device__ __forceinline__ void hmm_backward_sweep_body(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
-                                                        int64_t T, int64_t L, int64_t n_chunks, double* __restrict__ bend_out) {
+                                                        int64_t T, int64_t L, int64_t n_chunks, double* __restrict__ bend_out,
+                                                        int64_t W /*steps walked: the chunk's first W, from the uniform vector behind them*/) {
     constexpr int Kp = 16 * KT;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kReplayChunks + (j % kReplayChunks);
@@ -563,7 +564,7 @@ __device__ __forceinline__ void hmm_backward_sweep_body(const double* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) be[it][r] = (live && 16 * it + g + 4 * r < K) ? 1.0 / K : 0.0;
     const int64_t t0 = 1 + c * L;
-    for (int64_t s = L - 1; s >= 0; --s) {
+    for (int64_t s = W - 1; s >= 0; --s) {
         const int64_t t = t0 + s;
         const bool on = live && t < T;
         d4 y[KT];
@@ -600,14 +601,20 @@ __device__ __forceinline__ void hmm_backward_sweep_body(const double* __restrict
 
 // The two sweeps of the forgetting pass in one launch (blockIdx.y = direction): chains of dependent steps both, twice the waves
 // in flight.
+// W (round 5): a recursion that forgets its start does so within a few informative steps, not within a chunk: the sweeps walk
+// only the W steps next to the boundary they are after - the LAST W of chunk c - 1 for alpha in front of chunk c, the FIRST W
+// of chunk c for beta~ in front of it - from the uniform vector.  The replays' own boundary vectors are compared with these
+// exactly as before (hmm_boundary_check_kernel), so a W that is too short for the sequence opens the gate like any other
+// start vector that does not stand; hmm_capi.hip then sweeps whole chunks the next time.  W = 32 at config 5: an eighth of
+// the sweeps' steps and of their 5 GB.
 template <int KT>
 __global__ __launch_bounds__(256) void hmm_sweeps_kernel(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
                                                          int64_t T, int64_t L, int64_t n_chunks, double* __restrict__ fstart,
-                                                         double* __restrict__ bend) {
+                                                         double* __restrict__ bend, int64_t W) {
     if (blockIdx.y == 0)
-        hmm_forward_replay_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, fstart, nullptr, nullptr, 1, fstart);
+        hmm_forward_replay_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, fstart, nullptr, nullptr, 1, fstart, L - W);
     else
-        hmm_backward_sweep_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, bend);
+        hmm_backward_sweep_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, bend, W);
 }
 
 // alpha_0 and c'_0 (what hmm_boundary_scan_kernel does first), and the uniform vector behind the last chunk (K <= 256)

@@ -55,6 +55,8 @@ struct gmmvb_hmm_state {
     hipEvent_t gate_ev = nullptr;
     bool gate_pending = false, spec_on = true;
     bool vit_coalesced = false;   // the last hmmvb_viterbi call ran the coalescence pass (its gate: gate_dev[1])
+    int64_t sweep_len = 32;       // steps next to a chunk boundary the forgetting pass's sweeps walk (run<KT>); the whole chunk after a pass that failed with fewer
+    int64_t gate_w = 0, gate_l = 0;      // ... of the pass whose gate is pending, and its chunk length
     int spec_hold = 0, spec_hold_len = 8, last_gate = -1;   // last_gate: -1 no forgetting pass, 0 it stood, 1 products path behind it
     bool fuse_emission = false;   // hmmvb_emission_target: gmmvb_estep writes rho' / mx here (hmm.h H0 + H1) and no ln rho array
 };
@@ -153,7 +155,10 @@ bool consume_gate(gmmvb_hmm_state* h, bool wait) {
     if (e != hipSuccess) return false;
     h->gate_pending = false;
     h->last_gate = *h->gate_host;
-    if (h->last_gate != 0) {
+    if (h->last_gate != 0 && h->gate_w > 0 && h->gate_w < h->gate_l) {
+        // the sweeps walked only the steps next to the boundaries and that was not enough: whole chunks from now on, at once
+        h->sweep_len = int64_t(1) << 40;
+    } else if (h->last_gate != 0) {
         h->spec_hold = h->spec_hold_len;
         h->spec_hold_len = std::min(64, 2 * h->spec_hold_len);
     } else {
@@ -216,8 +221,11 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         if (hipError_t eg = hipMemsetAsync(h->gate_dev, 0, sizeof(int), st); eg != hipSuccess) return eg;      // (the gate must be shut before the check)
         hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(256), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
                            h->cprime);
+        const int64_t W = std::min<int64_t>(L, h->sweep_len);
+        h->gate_w = W;
+        h->gate_l = L;
         hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks, h->fstart,
-                           h->bend);
+                           h->bend, W);
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
         hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
@@ -498,6 +506,7 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     }
     if (e2 == hipSuccess) {      // the forgetting pass's gate (run<KT>, run_wide, run_generic): device flag, pinned copy, event
         h->spec_on = std::getenv("GMMVB_HMM_FORGETTING_OFF") == nullptr;
+        if (const char* v = std::getenv("GMMVB_HMM_SWEEP_LEN")) h->sweep_len = std::max<int64_t>(1, std::atoll(v));      // developer switch
         e2 = hipMalloc((void**)&h->gate_dev, 2 * sizeof(int));      // [0] forward-backward, [1] Viterbi
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, sizeof(int));
         if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&h->gate_ev, hipEventDisableTiming);

@@ -94,8 +94,9 @@ hipError_t launch_mstep_wide(int T, int grid, hipStream_t st, const MstepArgs& a
 hipError_t launch_estep_rows(int T, int x_is_f64, int grid, hipStream_t st, const EstepArgs& a, const char** name);
 int estep_rows_rows_per_wg();
 // ... for the HMM: gamma read time-major ([rows][Kp], lane order) through LDS instead of a component-major copy
+// (sparse: only the MFMA steps with a gamma above the relevance line are walked)
 hipError_t launch_hmm_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const double* gamma_tm, int Kp,
-                                  const char** name);
+                                  bool sparse, const char** name);
 
 struct MstepListArgs {
     const double* xc; const double* lnrho; const double* lse;

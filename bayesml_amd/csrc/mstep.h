@@ -499,6 +499,9 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
 // into LDS once per batch (contiguous in memory, one batch ahead), and every use is an LDS read: the row's own value for
 // ns / h, a 16-lane broadcast of sample 4 st + g for the MFMA operand.  Same operations per component in the same order as
 // mstep_small_f64 with direct_r = 2: bit-identical slabs.  aux = ln rho, component-major (the emission E-step's output).
+// a gamma below the relevance line of common.h (2^-80) is left out of the HMM M-step's first and second moments
+constexpr double kHmmGammaFloor = 8.271806125530277e-25;        // 2^-80
+static_assert(kRelevanceBits == 80, "kHmmGammaFloor is 2^-kRelevanceBits");
 __host__ __device__ constexpr int lane_order_pos(int state) {          // hmm.h: hmm_pos
     const int w = state & 15;
     return (state & ~15) + 4 * (w & 3) + (w >> 2);
@@ -506,7 +509,16 @@ __host__ __device__ constexpr int lane_order_pos(int state) {          // hmm.h:
 
 // AUX = false: the emission went straight to the forward-backward buffers and no ln rho array exists (hmm.h H0 + H1): h
 // stays 0 - the host takes sum gamma ln rho from the moments, in closed form - and a third of the kernel's reads is gone.
-template <int CW, bool AUX = true>
+// SPARSE (round 5): gamma is as sparse as a mixture's responsibilities - with informative emissions a time step belongs to
+// one or two states - and the dense form spends K MFMAs per four steps on products whose weight is below the relevance line
+// (common.h: gamma < 2^-80 is invisible in every f64 sum over fewer than 2^27 terms).  A ballot of the lanes' own values
+// (lane = row of the batch) gives every component of the wave a 64-bit row mask, folded to one bit per MFMA step (four
+// rows); the wave walks the SET bits only - a scalar loop: the masks are wave-uniform - so a (step, component) whose four
+// rows are all below the line costs nothing.  ns stays the sum of ALL gamma values (one add per row and component, as
+// before); a and B drop the terms below the line and nothing else - the steps that run form the same products in the same
+// order.  Config 5 (sticky chain, 3-sigma separated states): 1.3 of 32 components per step are walked, the kernel goes from
+// the matrix pipe's time (3.6 ms) to its memory traffic's.  SPARSE = false (GMMVB_HMM_MSTEP_DENSE) is the round-4 kernel.
+template <int CW, bool AUX = true, bool SPARSE = false>
 __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __restrict__ xc, int64_t n_rows,
                                                               const double* __restrict__ gamma_tm, int Kp,
                                                               const double* __restrict__ aux, int64_t npad, int K, int KGW, int S,
@@ -588,26 +600,50 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
         const double* xb = sx[b];
         const int64_t nl = c0 + lane;
         if (k0 < K) {
+            unsigned long long act[CW];
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const int k = k0 + c;
+                double v = 0.0;
                 if (k < K && nl < hi) {
-                    const double v = sb[lane * LD + pc[c]];
+                    v = sb[lane * LD + pc[c]];
                     if (AUX && v > 0.0) hsum[c] = fma(v, aux_c[c], hsum[c]);
                     nsum[c] += v;
                 }
+                if constexpr (SPARSE) {
+                    // rows of the batch whose gamma for this component is above the relevance line, one bit per MFMA step
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(v >= kHmmGammaFloor);
+                    m |= m >> 1;
+                    m |= m >> 2;
+                    act[c] = m & 0x1111111111111111ull;
+                }
             }
+            if constexpr (SPARSE) {
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    unsigned long long m = act[c];
+                    while (m != 0ull) {                      // (wave-uniform: a scalar loop over the steps that matter)
+                        const int st = __builtin_ctzll(m) >> 2;
+                        m &= m - 1ull;
+                        const double xq = xb[64 * st + lane];
+                        const double ra = sb[(4 * st + g) * LD + pc[c]] * xq;
+                        asum[c] += ra;
+                        acc[c] = mfma_f64(ra, xq, acc[c]);
+                    }
+                }
+            } else {
 #ifndef GMMVB_HMM_MSTEP_UNROLL
 #define GMMVB_HMM_MSTEP_UNROLL 4
 #endif
 #pragma unroll GMMVB_HMM_MSTEP_UNROLL
-            for (int st = 0; st < 16; ++st) {
-                const double xq = xb[64 * st + lane];
+                for (int st = 0; st < 16; ++st) {
+                    const double xq = xb[64 * st + lane];
 #pragma unroll
-                for (int c = 0; c < CW; ++c) {
-                    const double ra = (k0 + c < K ? sb[(4 * st + g) * LD + pc[c]] : 0.0) * xq;
-                    asum[c] += ra;
-                    acc[c] = mfma_f64(ra, xq, acc[c]);
+                    for (int c = 0; c < CW; ++c) {
+                        const double ra = (k0 + c < K ? sb[(4 * st + g) * LD + pc[c]] : 0.0) * xq;
+                        asum[c] += ra;
+                        acc[c] = mfma_f64(ra, xq, acc[c]);
+                    }
                 }
             }
         }

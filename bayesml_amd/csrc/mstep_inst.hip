@@ -33,14 +33,18 @@ hipError_t launch_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int 
 }
 
 hipError_t launch_hmm_mstep_small(int grid, hipStream_t st, const MstepArgs& a, int KGW, const double* gamma_tm, int Kp,
-                                  const char** name) {
-    *name = "hmm_mstep_small<T=1,8 components per wave,gamma time-major>";
-    if (a.aux)
-        hipLaunchKernelGGL((hmm_mstep_small_kernel<8, true>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(a.x), a.n_rows,
-                           gamma_tm, Kp, a.aux, a.npad, a.K, KGW, a.S, a.rows_per_split, a.slabs);
-    else
-        hipLaunchKernelGGL((hmm_mstep_small_kernel<8, false>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(a.x), a.n_rows,
-                           gamma_tm, Kp, a.aux, a.npad, a.K, KGW, a.S, a.rows_per_split, a.slabs);
+                                  bool sparse, const char** name) {
+    *name = sparse ? "hmm_mstep_small<T=1,8 components per wave,gamma time-major,steps above 2^-80>"
+                   : "hmm_mstep_small<T=1,8 components per wave,gamma time-major>";
+#define HMS(AUXV, SP)                                                                                                          \
+    hipLaunchKernelGGL((hmm_mstep_small_kernel<8, AUXV, SP>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(a.x), \
+                       a.n_rows, gamma_tm, Kp, a.aux, a.npad, a.K, KGW, a.S, a.rows_per_split, a.slabs)
+    if (a.aux) {
+        if (sparse) HMS(true, true); else HMS(true, false);
+    } else {
+        if (sparse) HMS(false, true); else HMS(false, false);
+    }
+#undef HMS
     return hipGetLastError();
 }
 

@@ -95,6 +95,9 @@ def parse_args():
     ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
     ap.add_argument("--force-dist", action="store_true",
                     help="join an RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--init-timeout", type=float, default=600.0,
+                    help="seconds a rank may spend joining the process group and finishing its first collective before its "
+                         "watchdog dumps every thread's stack and exits non-zero (a stalled RCCL init must not hang the job)")
     ap.add_argument("--native-allreduce", action="store_true",
                     help="per-iteration all-reduce through the library's own RCCL communicator (gmmvb_allreduce_stats)")
     return ap.parse_args()
@@ -136,10 +139,28 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        env.setdefault("NCCL_DEBUG", "WARN")
+        # fresh child processes, each in its own session (never a re-exec of a process that has touched a GPU)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      start_new_session=True))
+    # a rank that dies (its own watchdog, an RCCL error) must take the others down instead of leaving them in a collective
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = max(rc, abs(code) or 1)
+                print(f"bench.py: rank process {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    try:
+                        os.killpg(q.pid, 15)          # the exact process groups started above
+                    except OSError:
+                        pass
     return rc
 
 
@@ -326,6 +347,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # (RCCL's own account of a failed init goes to stderr)
+        # per-rank watchdog: if joining the group or the first collective stalls, dump every thread's stack and exit 1
+        import faulthandler
+        print(f"bench.py: rank {rank}/{world} joining the process group (watchdog {args.init_timeout:.0f} s)", file=sys.stderr, flush=True)
+        faulthandler.dump_traceback_later(args.init_timeout, exit=True, file=sys.stderr)
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -337,6 +363,7 @@ def main():
         dist.all_reduce(one)
         rccl_ranks = int(one.item())
         assert rccl_ranks == world
+        faulthandler.cancel_dump_traceback_later()
 
     cfg = CONFIGS[args.config]
     K = args.classes or cfg["classes"]

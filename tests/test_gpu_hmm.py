@@ -11,6 +11,18 @@ from oracle import hmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["steps above 2^-80", "every step"])
+def hmm_mstep_mode(request, monkeypatch):
+    """The D <= 16 M-step of an HMM pass walks only the (four steps, state) blocks that hold a gamma above the relevance line
+    (mstep.h, hmm_mstep_small_kernel<.., SPARSE>); GMMVB_HMM_MSTEP_DENSE walks all of them.  Reference fixtures and oracle
+    comparisons run both ways."""
+    if request.param == "every step":
+        monkeypatch.setenv("GMMVB_HMM_MSTEP_DENSE", "1")
+    else:
+        monkeypatch.delenv("GMMVB_HMM_MSTEP_DENSE", raising=False)
+    return request.param
+
+
 def fixture_x(g):
     K, D, T = int(g["K"]), int(g["D"]), int(g["N"])
     if D == 2:
@@ -51,7 +63,7 @@ def device_pass(x, q, dev):
 
 
 @pytest.mark.parametrize("name", ["hmm_f6_k4_d2_t500.npz", "hmm_f6_k32_d16_t4096.npz"])
-def test_forward_backward_matches_reference(name):
+def test_forward_backward_matches_reference(name, hmm_mstep_mode):
     g = load_golden(name)
     x = fixture_x(g)
     q = orc.HmmPosterior(*(g["in_" + k].copy() for k in ("hn_eta_vec", "hn_zeta_vecs", "hn_m_vecs", "hn_kappas",
@@ -97,7 +109,7 @@ def test_forward_backward_matches_reference(name):
                                          (112, 3, 3000, np.float32), (128, 2, 4100, np.float64),
                                          # ... and past 128 chunks of 256 steps their two-level boundary pass
                                          (70, 2, 40000, np.float64), (128, 2, 33500, np.float32)])
-def test_ragged_shapes_against_oracle(K, D, T, dtype):
+def test_ragged_shapes_against_oracle(K, D, T, dtype, hmm_mstep_mode):
     """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths - and, past 2^18 steps, the
     two-level boundary pass (chunks of 256 steps, super-chunk products); random posterior.  More than 64 states: the
     sequential kernels of csrc/hmm_generic.h (transition matrix in LDS up to K = 128, in L2 beyond) - and for 65 .. 128
@@ -143,7 +155,7 @@ DRIVER = ["hmm_f3_k4_subsampling.npz", "hmm_f3_k4_random_resp.npz", "hmm_f3_k8_d
 
 
 @pytest.mark.parametrize("name", DRIVER)
-def test_full_driver_matches_reference(name):
+def test_full_driver_matches_reference(name, hmm_mstep_mode):
     import io
     import json
     import warnings
@@ -212,7 +224,7 @@ def test_viterbi_kernel_against_oracle(K, D, T):
 @pytest.mark.parametrize("K,D,T,dtype", [(32, 16, 4096, np.float32), (5, 3, 777, np.float64), (16, 16, 70001, np.float32),
                                          (17, 9, 1, np.float64), (32, 12, 263000, np.float32), (40, 16, 5000, np.float64),
                                          (64, 7, 3001, np.float32)])
-def test_emission_into_the_forward_backward_buffers(K, D, T, dtype):
+def test_emission_into_the_forward_backward_buffers(K, D, T, dtype, hmm_mstep_mode):
     """hmmvb_emission_target(1): rho' and the row maxima straight from the emission kernel instead of the ln rho array
     followed by hmm_prep_kernel; no ln rho array (Viterbi / ln rho read-out refuse), h = 0 in the statistics and
     sum gamma ln rho from the moments (ref:905 against ref:871-877) to rounding."""
@@ -335,7 +347,9 @@ def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
     ref, how0 = run(False)
     got, how1 = run(True, calls=3)
     assert how0 == [-1]
-    assert how1 == ([1, -1, -1] if flat else [0, 0, 0]), how1
+    # (flat: the sweeps first walk only the 32 steps next to every boundary - the gate opens -, then whole chunks - it opens
+    # again -, and the third call goes straight to the products; up to 128 states.  Beyond, whole chunks from the start.)
+    assert how1 == (([1, 1, -1] if K <= 64 else [1, -1, -1]) if flat else [0, 0, 0]), how1
     for k in ("ms", "g0", "gl", "gamma", "alpha", "stats"):
         scale_k = max(1.0, float(ref[k].abs().max()))
         assert float((ref[k] - got[k]).abs().max()) <= 1e-10 * scale_k, k

@@ -7,7 +7,7 @@ ARGS=${@:-"--steps 20 --warmup 5"}
 OUT=gpurun_out
 mkdir -p $OUT
 for v in "$A" "$B" "$A" "$B"; do
-  env $NAME=$v timeout 600 python bench.py --no-cpu --no-legs $ARGS 2>/dev/null | grep -a "^{" > $OUT/${TAG}_${NAME}_$v.json
+  env $NAME=$v timeout 600 python bench.py --no-cpu --no-legs --detail - $ARGS 2>/dev/null | grep -a "^{" | head -1 > $OUT/${TAG}_${NAME}_$v.json
   python - $OUT/${TAG}_${NAME}_$v.json $NAME $v <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

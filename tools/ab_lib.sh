@@ -8,7 +8,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 for v in base $VAR base $VAR; do
   if [ $v = base ]; then unset BAYESML_AMD_LIB; else export BAYESML_AMD_LIB=$PWD/bayesml_amd/csrc/libgmmvb_$v.so; fi
-  timeout 600 python bench.py --no-cpu --no-legs $ARGS 2>/dev/null | grep -a "^{" > $OUT/${TAG}_$v.json
+  timeout 600 python bench.py --no-cpu --no-legs --detail - $ARGS 2>/dev/null | grep -a "^{" | head -1 > $OUT/${TAG}_$v.json
   python - $OUT/${TAG}_$v.json $v <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
