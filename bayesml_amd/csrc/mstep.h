@@ -502,6 +502,9 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
 // a gamma below the relevance line of common.h (2^-80) is left out of the HMM M-step's first and second moments
 constexpr double kHmmGammaFloor = 8.271806125530277e-25;        // 2^-80
 static_assert(kRelevanceBits == 80, "kHmmGammaFloor is 2^-kRelevanceBits");
+// a component with this many of a batch's 16 MFMA steps above the line takes the dense form's unrolled loop instead of the
+// bit walk (an iteration of the walk waits for its LDS operands, ~3 steps' worth of the unrolled loop)
+constexpr int kHmmDenseFrom = 6;
 __host__ __device__ constexpr int lane_order_pos(int state) {          // hmm.h: hmm_pos
     const int w = state & 15;
     return (state & ~15) + 4 * (w & 3) + (w >> 2);
@@ -622,13 +625,34 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
 #pragma unroll
                 for (int c = 0; c < CW; ++c) {
                     unsigned long long m = act[c];
-                    while (m != 0ull) {                      // (wave-uniform: a scalar loop over the steps that matter)
-                        const int st = __builtin_ctzll(m) >> 2;
+                    if (__builtin_popcountll(m) >= kHmmDenseFrom) {
+                        // most of the component's steps matter (early iterations, a state that holds the whole batch): the
+                        // dense form's static schedule - its LDS reads run ahead of the MFMAs - beats the bit walk
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) {
+                            const double xq = xb[64 * st + lane];
+                            const double ra = sb[(4 * st + g) * LD + pc[c]] * xq;
+                            asum[c] += ra;
+                            acc[c] = mfma_f64(ra, xq, acc[c]);
+                        }
+                        continue;
+                    }
+                    while (m != 0ull) {                      // (wave-uniform: a scalar loop over the steps that matter, two at a time)
+                        const int st0 = __builtin_ctzll(m) >> 2;
                         m &= m - 1ull;
-                        const double xq = xb[64 * st + lane];
-                        const double ra = sb[(4 * st + g) * LD + pc[c]] * xq;
-                        asum[c] += ra;
-                        acc[c] = mfma_f64(ra, xq, acc[c]);
+                        const bool two = m != 0ull;
+                        const int st1 = two ? __builtin_ctzll(m) >> 2 : st0;
+                        m &= m - 1ull;                       // (0 & anything = 0)
+                        const double xq0 = xb[64 * st0 + lane], g0 = sb[(4 * st0 + g) * LD + pc[c]];
+                        const double xq1 = xb[64 * st1 + lane], g1 = sb[(4 * st1 + g) * LD + pc[c]];
+                        const double ra0 = g0 * xq0;
+                        asum[c] += ra0;
+                        acc[c] = mfma_f64(ra0, xq0, acc[c]);
+                        if (two) {
+                            const double ra1 = g1 * xq1;
+                            asum[c] += ra1;
+                            acc[c] = mfma_f64(ra1, xq1, acc[c]);
+                        }
                     }
                 }
             } else {

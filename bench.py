@@ -31,6 +31,8 @@ Legs of the single-GPU run (full record):
   spread_sweep    the middle of the separation spectrum: means spread * randn for spread in {0.5, 0.75, 1.0, 1.5} at N = 2e6,
                   default policy against dense kernels only over iterations 3-22, each with an oracle parity run
   full_fit        update_posterior(max_itr=25, num_init=2, tolerance=0) through the public API on the resident matrix
+  offpath         off the headline's recipe at N = 2e6: K_model = 2 K_data, mixing weights ~ Dirichlet(0.3), anisotropic clusters -
+                  default policy against dense kernels only and an oracle parity run under both policies (opt-in: --legs)
   hmm_c5          BASELINE.json configs[4]: hiddenmarkovnormal.LearnModel K=32, D=16, T=1e7 (tools/bench_hmm.py's measurement)
   small_c1        BASELINE.json configs[0] (K=3, D=2, N=1000) with the reference's defaults: the one-launch path and the
                   general engine
@@ -566,7 +568,7 @@ def main():
         assert roof["frac"] <= 1.0 + 1e-9, roof
 
         last_launch = eng.launch_info
-        dense_leg = hard = spread_leg = full_leg = hmm_leg = small_leg = None
+        dense_leg = hard = spread_leg = full_leg = hmm_leg = small_leg = offpath = None
         if not args.dense and world == 1 and not args.no_legs:
             legs = set(args.legs.split(","))
             if "all" in legs:
@@ -584,6 +586,8 @@ def main():
                 hard = hard_workload_leg(K, D, n_local, tdtype, ndtype, dev, parity=do_cpu)
             if "spread" in legs and not args.overlap:
                 spread_leg = spread_sweep_leg(K, D, min(n_local, 2_000_000), tdtype, ndtype, dev, parity=do_cpu)
+            if "offpath" in legs and not args.overlap:
+                offpath = offpath_leg(K, D, min(n_local, 2_000_000), tdtype, ndtype, dev, parity=do_cpu)
             if "hmm" in legs and args.config == "c3":
                 hmm_leg = hmm_c5_leg(dev, cpu=do_cpu)
             if "small" in legs:
@@ -605,7 +609,7 @@ def main():
                        "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
                        "row_tiles": getattr(eng, "n_tiles", 1)},
             "roofline": roof, "dense": dense_leg, "hard_workload": hard, "spread_sweep": spread_leg,
-            "full_fit": full_leg, "hmm_c5": hmm_leg, "small_c1": small_leg, "per_rank": ranks_info,
+            "full_fit": full_leg, "hmm_c5": hmm_leg, "small_c1": small_leg, "offpath": offpath, "per_rank": ranks_info,
             "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,
             "launch": last_launch, "warmup_steps": warm,
             "per_step": {"wall_ms": [round(v, 2) for v in walls],
@@ -823,6 +827,77 @@ def spread_sweep_leg(K, D, n, tdtype, ndtype, dev, spreads=(0.5, 0.75, 1.0, 1.5)
             "steps": steps, "warmup": warmup, "spreads": rows,
             "worst_default_over_dense": max(r["default_over_dense"] for r in rows),
             "summary": {"default_over_dense": {str(r["spread"]): round(r["default_over_dense"], 3) for r in rows},
+                        "parity_max_rel_err": max([max(r["parity"]["max_rel_err"], r["parity_sparse_path"]["max_rel_err"])
+                                                   for r in rows if "parity" in r] or [None])}}
+
+
+def offpath_mixture(kind, K, D, spread=2.0):
+    """The three workloads off the headline's recipe (equal weights, unit covariances, K_model = K_data):
+    kdata   the rows come from K / 2 clusters: half of the model's components end up empty or as duplicates
+    weights mixing weights ~ Dirichlet(0.3): a few big clusters, many tiny ones
+    aniso   every cluster has its own per-feature standard deviations, log-uniform in [0.3, 3]
+    Returns (means [Kd, D], weights [Kd] or None, scales [Kd, D] or None), drawn on the host from SEED."""
+    rng = np.random.default_rng(SEED + {"kdata": 11, "weights": 12, "aniso": 13}[kind])
+    Kd = K // 2 if kind == "kdata" else K
+    mu = spread * rng.standard_normal((Kd, D))
+    w = rng.dirichlet(np.full(Kd, 0.3)) if kind == "weights" else None
+    sc = np.exp(rng.uniform(np.log(0.3), np.log(3.0), (Kd, D))) if kind == "aniso" else None
+    return mu, w, sc
+
+
+def offpath_rows_host(mix, n, dtype, seed):
+    mu, w, sc = mix
+    rng = np.random.default_rng(seed)
+    z = rng.integers(0, mu.shape[0], n) if w is None else rng.choice(mu.shape[0], size=n, p=w)
+    e = rng.standard_normal((n, mu.shape[1]))
+    return (mu[z] + (e if sc is None else e * sc[z])).astype(dtype)
+
+
+def offpath_rows_device(mix, n, dtype, dev, seed):
+    import torch
+    mu, w, sc = (None if a is None else torch.from_numpy(a).to(dev) for a in mix)
+    x = torch.empty((n, mu.shape[1]), dtype=dtype, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    step = 1 << 20
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        if w is None:
+            z = torch.randint(0, mu.shape[0], (hi - lo,), device=dev, generator=gen)
+        else:
+            z = torch.multinomial(w, hi - lo, replacement=True, generator=gen)
+        e = torch.randn(hi - lo, mu.shape[1], dtype=torch.float64, device=dev, generator=gen)
+        x[lo:hi] = (mu[z] + (e if sc is None else e * sc[z])).to(dtype)
+    return x
+
+
+def offpath_leg(K, D, n, tdtype, ndtype, dev, warmup=2, steps=20, parity=True):
+    """Perf and parity off the happy path: the default policy against the dense kernels (it must not lose more than 10 %),
+    and a 6000-row oracle parity run under both policies, on the three mixtures of offpath_mixture()."""
+    import torch
+    rows = []
+    for kind in ("kdata", "weights", "aniso"):
+        mix = offpath_mixture(kind, K, D)
+        x = offpath_rows_device(mix, n, tdtype, dev, SEED + 301)
+        r = {"kind": kind, "rows": n, "model_components": K, "data_clusters": int(mix[0].shape[0]),
+             "default": policy_run(K, D, x, dev, warmup, steps),
+             "dense": policy_run(K, D, x, dev, warmup, steps, GMMVB_ESTEP_PRUNE="0", GMMVB_MSTEP_SPARSE="0")}
+        for k in ("wall_ms", "estep_kernel", "active_pairs_per_row", "evaluated_pairs_per_row"):
+            r["dense"].pop(k, None)
+        r["default_over_dense"] = r["default"]["ms_per_step"] / r["dense"]["ms_per_step"]
+        del x
+        torch.cuda.empty_cache()
+        if parity:
+            x_ref = offpath_rows_host(mix, min(6000, n), ndtype, SEED + 302)
+            _b, p0, p1 = cpu_baseline_and_parity(K, D, x_ref, dev, iters=6)
+            r["parity"] = {k: p0[k] for k in ("max_rel_err", "passed", "rows", "iterations", "path")}
+            r["parity_sparse_path"] = {k: p1[k] for k in ("max_rel_err", "passed", "rows", "iterations", "path")}
+        rows.append(r)
+    return {"workload": f"K={K} D={D} N={n}: model components = 2 x data clusters | mixing weights ~ Dirichlet(0.3) | per-feature "
+                        f"scales in [0.3, 3]; iterations {warmup + 1}-{warmup + steps} of one restart",
+            "steps": steps, "warmup": warmup, "mixtures": rows,
+            "worst_default_over_dense": max(r["default_over_dense"] for r in rows),
+            "summary": {"default_over_dense": {r["kind"]: round(r["default_over_dense"], 3) for r in rows},
+                        "default_ms_per_step": {r["kind"]: round(r["default"]["ms_per_step"], 2) for r in rows},
                         "parity_max_rel_err": max([max(r["parity"]["max_rel_err"], r["parity_sparse_path"]["max_rel_err"])
                                                    for r in rows if "parity" in r] or [None])}}
 

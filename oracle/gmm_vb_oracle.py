@@ -331,16 +331,25 @@ def estimate_latent_vars(x: np.ndarray, q: Posterior, loss: str = "0-1") -> np.n
 
 # --------------------------------------------------------------------------- workloads
 def synth_gmm(K: int, D: int, N: int, dtype=np.float64, seed: int = 20250711,
-              chunk: int = 1 << 20, spread: float = 2.0) -> np.ndarray:
+              chunk: int = 1 << 20, spread: float = 2.0, weights_alpha: float | None = None,
+              scale_range: tuple | None = None) -> np.ndarray:
     """The benchmark's synthetic sample matrix:
     ``mu = 2*standard_normal((K,D))``, ``z = integers(0,K,N)``,
     ``x = mu[z] + standard_normal((N,D))`` drawn in fixed 2**20-row chunks.
-    ``spread`` scales the means (2 = the benchmark; 0.3 = heavily overlapping clusters, the hard workload)."""
+    ``spread`` scales the means (2 = the benchmark; 0.3 = heavily overlapping clusters, the hard workload).
+    Off the benchmark's recipe (round 5; the defaults draw nothing extra, so the streams of the older fixtures stand):
+    ``weights_alpha``: mixing weights ~ Dirichlet(weights_alpha) instead of equal ones (0.3: a few big clusters, many tiny);
+    ``scale_range = (lo, hi)``: every cluster gets its own per-feature standard deviations, log-uniform in [lo, hi]
+    (anisotropic, axis-aligned covariances) instead of the identity."""
     rng = np.random.default_rng(seed)
     mu = spread * rng.standard_normal((K, D))
+    w = rng.dirichlet(np.full(K, float(weights_alpha))) if weights_alpha is not None else None
+    sc = (np.exp(rng.uniform(np.log(scale_range[0]), np.log(scale_range[1]), (K, D)))
+          if scale_range is not None else None)
     x = np.empty((N, D), dtype=dtype)
     for lo in range(0, N, chunk):
         hi = min(N, lo + chunk)
-        z = rng.integers(0, K, hi - lo)
-        x[lo:hi] = (mu[z] + rng.standard_normal((hi - lo, D))).astype(dtype)
+        z = rng.integers(0, K, hi - lo) if w is None else rng.choice(K, size=hi - lo, p=w)
+        e = rng.standard_normal((hi - lo, D))
+        x[lo:hi] = (mu[z] + (e if sc is None else e * sc[z])).astype(dtype)
     return x

@@ -47,6 +47,7 @@ VARIANTS = {
     "proof_by_component": {"GMMVB_PROOF_BLOCKED": "0"},
     "force_proof_by_component": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF_BLOCKED": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
+    "force_nocache": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_MSTEP_CACHE": "0"},
     "force_nocarry": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_CARRY_OFF": "1"},
     "dense": {"GMMVB_ESTEP_PRUNE": "0", "GMMVB_MSTEP_SPARSE": "0"},
 }
@@ -141,6 +142,12 @@ LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n1400
          # policy's choice between dense, bound pass and sweep is closest
          ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nolazy"),
          ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nocarry"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "default")]
+# off the benchmark's recipe (round 5): twice as many components in the model as in the data (empty and duplicate
+# components), mixing weights ~ Dirichlet(0.3), anisotropic clusters (per-feature scales 0.3 ... 3) - reference fixtures, the
+# pruned path forced (N K = 2^19: the default policy stays dense at this size, which is the fourth variant)
+OFFPATH = [(f"gmm_f3_k16_d64_n32768_f32_{kind}.npz", variant) for kind in ("kdata8", "weights", "aniso")
+           for variant in ("force", "force_nocache", "force_noproof", "default")]
+LARGE += OFFPATH
 
 
 @pytest.mark.parametrize("name,variant", LARGE)
@@ -149,9 +156,15 @@ def test_large_fixture_matches_reference(name, variant):
     prunes and carries (N K >= 2^23), and overlapping clusters (spread 0.3) where it has to fall back."""
     g = load_golden(name)
     K, D, N = int(g["K"]), int(g["D"]), int(g["N"])
-    x = orc.synth_gmm(int(g["K_data"]), D, N, np.float32, spread=float(g["spread"]))
+    x = orc.synth_gmm(int(g["K_data"]), D, N, np.float32, spread=float(g["spread"]),
+                      weights_alpha=float(g["weights_alpha"]) if "weights_alpha" in g else None,
+                      scale_range=tuple(g["scale_range"]) if "scale_range" in g else None)
+    offpath = (name, variant) in OFFPATH
     m, counts, trace = run_driver(g, x, variant)
-    if "overlap" in name or "spread1" in name:
+    if offpath:
+        if variant.startswith("force"):     # the pruned kernels really ran: bound pass, carried sweeps, gathers, list M-step
+            assert counts["estep_bound"] >= 1 and counts["estep_sweep"] >= 1 and counts["estep_gather"] >= 2 and counts["mstep_list"] >= 1, counts
+    elif "overlap" in name or "spread1" in name:
         if variant.startswith("force"):     # (nearly) everything is a candidate: the pruned E-step must still be exact
             assert counts["estep_bound"] >= 1 and counts["estep_gather"] >= 2, counts
     else:
@@ -173,7 +186,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if "overlap" not in name and "spread1" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled"):
+    if not offpath and "overlap" not in name and "spread1" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -188,7 +201,7 @@ def test_large_fixture_matches_reference(name, variant):
             assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
         if variant in ("nosettle", "noproof"):      # (without settled rows the proof round still serves the bound passes)
             assert wk["settled_rows"] == 0 and (wk["proof_pairs"] == 0 or variant == "nosettle"), wk
-    if variant == "default" and "overlap" not in name and "spread1" not in name:
+    if variant == "default" and not offpath and "overlap" not in name and "spread1" not in name:
         # the workspace regrouped its internal row order by dominant component on the way: every
         # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless
         # in the caller's row order

@@ -143,6 +143,29 @@ def test_error_fixture_is_present_and_sane():
     assert e["x_int_dtype"] is None
 
 
+@pytest.mark.parametrize("kind", ["kdata8", "weights", "aniso"])
+def test_full_driver_off_the_benchmark_recipe(kind):
+    """The round-5 fixtures off the benchmark's recipe (K_model = 2 K_data; Dirichlet(0.3) mixing weights; anisotropic
+    clusters): the oracle's driver against the reference's, matrices through the stored functionals."""
+    from conftest import mat_functionals
+    g = load_golden(f"gmm_f3_k16_d64_n32768_f32_{kind}.npz")
+    K, D, N = int(g["K"]), int(g["D"]), int(g["N"])
+    x = orc.synth_gmm(int(g["K_data"]), D, N, np.float32, spread=float(g["spread"]),
+                      weights_alpha=float(g["weights_alpha"]) if "weights_alpha" in g else None,
+                      scale_range=tuple(g["scale_range"]) if "scale_range" in g else None)
+    assert sha(x) == str(g["x_sha256"])
+    p = orc.Prior.default(K, D)
+    res = orc.update_posterior(x.astype(np.float64), p, orc.Posterior.from_prior(p),
+                               np.random.default_rng(int(g["seed"])), **json.loads(str(g["kw"])))
+    ref = g["vl_trace"][0]
+    assert np.allclose(res.vl_trace[0], ref[~np.isnan(ref)], rtol=1e-9, atol=0)
+    q = res.posterior
+    assert rel_err(q.alpha, g["hn_alpha_vec"]) < 1e-9 and rel_err(q.m, g["hn_m_vecs"]) < 1e-9
+    for key, got in (("hn_w_mats", q.w), ("hn_w_mats_inv", q.w_inv)):
+        for fn, val in mat_functionals(got).items():
+            assert rel_err(val, g[f"{key}_{fn}"]) < 1e-7, (key, fn)
+
+
 def test_full_driver_overlapping_clusters_compact_fixture():
     """tests/golden/make_golden_large.py fixture on heavily overlapping clusters (means 0.3 * randn): the oracle's
     driver against the reference's, matrices compared through the stored functionals.  (The two larger fixtures of
