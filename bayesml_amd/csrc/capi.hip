@@ -20,6 +20,9 @@ namespace {
 thread_local std::string g_err;
 }  // namespace
 
+#ifndef GMMVB_T1_SPLITS
+#define GMMVB_T1_SPLITS 24
+#endif
 namespace gmmvb {
 int fail(int code, const char* what, hipError_t e) {
     g_err = what;
@@ -191,7 +194,7 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
     }
     // row splits of the dense M-step: ~4 workgroups per CU; with a single feature tile a step is a row load and one
     // MFMA - latency, not arithmetic - so many more, shorter, splits (HMM config 5)
-    ws->S_cap = (int)round_up(((int64_t)(ws->T == 1 ? 24 : 4) * ws->num_cu + ws->KG - 1) / ws->KG, 8);      // (24: three of the HMM M-step's 50-KB workgroups per CU)
+    ws->S_cap = (int)round_up(((int64_t)(ws->T == 1 ? GMMVB_T1_SPLITS : 4) * ws->num_cu + ws->KG - 1) / ws->KG, 8);      // (24: three of the HMM M-step's 50-KB workgroups per CU)
     if (ws->S_cap < 8) ws->S_cap = 8;
     {
         // Cap on the rows of one M-step split: 16 MB of centred rows (16384 rows at D = 128).  All component groups

@@ -604,13 +604,17 @@ __device__ __forceinline__ void hmm_backward_sweep_body(const double* __restrict
 // W (round 5): a recursion that forgets its start does so within a few informative steps, not within a chunk: the sweeps walk
 // only the W steps next to the boundary they are after - the LAST W of chunk c - 1 for alpha in front of chunk c, the FIRST W
 // of chunk c for beta~ in front of it - from the uniform vector.  The replays' own boundary vectors are compared with these
-// exactly as before (hmm_boundary_check_kernel), so a W that is too short for the sequence opens the gate like any other
-// start vector that does not stand; hmm_capi.hip then sweeps whole chunks the next time.  W = 32 at config 5: an eighth of
-// the sweeps' steps and of their 5 GB.
+// exactly as before (hmm_boundary_check_kernel), so a W that is too short for the sequence opens a gate like any other
+// start vector that does not stand - the FIRST of two: behind it hmm_capi.hip has enqueued the whole-chunk sweeps, the replays
+// and their check, and only if those do not stand either does the second gate open the chunk-product path.  W = 64 at
+// config 5: a quarter of the sweeps' steps and of their 5 GB (1.0 -> 0.3 ms; 9.8 against 10.6 ms per iteration).  W = 32 was
+// not always enough there: with duplicate components (two states with nearly the same emission) the split between them is
+// forgotten at the chain's own mixing rate, 0.9 per step - one pass in seven of the benchmark's needed the whole chunks.
 template <int KT>
 __global__ __launch_bounds__(256) void hmm_sweeps_kernel(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
                                                          int64_t T, int64_t L, int64_t n_chunks, double* __restrict__ fstart,
-                                                         double* __restrict__ bend, int64_t W) {
+                                                         double* __restrict__ bend, int64_t W, const int* __restrict__ gate = nullptr) {
+    if (gate != nullptr && *gate == 0) return;      // (the second stage of the forgetting pass: only if the first did not stand)
     if (blockIdx.y == 0)
         hmm_forward_replay_body<KT>(rho_tm, a_tilde, K, T, L, n_chunks, fstart, nullptr, nullptr, 1, fstart, L - W);
     else
@@ -653,7 +657,9 @@ template <bool REL>
 __global__ __launch_bounds__(256) void hmm_boundary_check_kernel(const double* __restrict__ fa, const double* __restrict__ fb,
                                                                  const double* __restrict__ ba, const double* __restrict__ bb,
                                                                  int64_t n /*entries of rows 1 .. n_chunks - 1 (forward), 0 .. n_chunks - 2 (backward)*/,
-                                                                 int Kp, double tol, int* __restrict__ gate) {
+                                                                 int Kp, double tol, int* __restrict__ gate,
+                                                                 const int* __restrict__ gate_in = nullptr) {
+    if (gate_in != nullptr && *gate_in == 0) return;
     bool bad = false;
     auto differs = [tol](double a, double b) {
         const double d = fabs(a - b);

@@ -55,8 +55,9 @@ struct gmmvb_hmm_state {
     hipEvent_t gate_ev = nullptr;
     bool gate_pending = false, spec_on = true;
     bool vit_coalesced = false;   // the last hmmvb_viterbi call ran the coalescence pass (its gate: gate_dev[1])
-    int64_t sweep_len = 32;       // steps next to a chunk boundary the forgetting pass's sweeps walk (run<KT>); the whole chunk after a pass that failed with fewer
-    int64_t gate_w = 0, gate_l = 0;      // ... of the pass whose gate is pending, and its chunk length
+    int64_t sweep_len = 64;       // steps next to a chunk boundary the forgetting pass's first stage walks (run<KT>; 32 failed one pass in seven at config 5, 64 none)
+    int short_hold = 0, short_hold_len = 4;      // calls that skip the short first stage after it did not stand (4, 8 ... 64 while it keeps failing)
+    bool gate_two_stage = false;  // the pass whose gates are pending had a short first stage
     int spec_hold = 0, spec_hold_len = 8, last_gate = -1;   // last_gate: -1 no forgetting pass, 0 it stood, 1 products path behind it
     bool fuse_emission = false;   // hmmvb_emission_target: gmmvb_estep writes rho' / mx here (hmm.h H0 + H1) and no ln rho array
 };
@@ -154,11 +155,18 @@ bool consume_gate(gmmvb_hmm_state* h, bool wait) {
     if (e == hipErrorNotReady) return true;
     if (e != hipSuccess) return false;
     h->gate_pending = false;
-    h->last_gate = *h->gate_host;
-    if (h->last_gate != 0 && h->gate_w > 0 && h->gate_w < h->gate_l) {
-        // the sweeps walked only the steps next to the boundaries and that was not enough: whole chunks from now on, at once
-        h->sweep_len = int64_t(1) << 40;
-    } else if (h->last_gate != 0) {
+    h->last_gate = h->gate_host[0];
+    if (h->gate_two_stage) {
+        // the first stage's sweeps walked only the steps next to the boundaries: when that was not enough the whole-chunk
+        // stage behind its gate has done the work (a sweep and two replays more): go straight to whole chunks for a while
+        if (h->gate_host[1] != 0) {
+            h->short_hold = h->short_hold_len;
+            h->short_hold_len = std::min(64, 2 * h->short_hold_len);
+        } else {
+            h->short_hold_len = 4;
+        }
+    }
+    if (h->last_gate != 0) {
         h->spec_hold = h->spec_hold_len;
         h->spec_hold_len = std::min(64, 2 * h->spec_hold_len);
     } else {
@@ -218,20 +226,39 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
         spec = false;
     }
     if (spec) {
-        if (hipError_t eg = hipMemsetAsync(h->gate_dev, 0, sizeof(int), st); eg != hipSuccess) return eg;      // (the gate must be shut before the check)
+        int* const gate_b = h->gate_dev;           // opens the chunk-product path
+        int* const gate_a = h->gate_dev + 2;       // opens the whole-chunk stage ([1] is the Viterbi pass's)
+        if (hipError_t eg = hipMemsetAsync(h->gate_dev, 0, sizeof(int), st); eg != hipSuccess) return eg;      // (the gates must be shut before the checks)
+        if (hipError_t eg = hipMemsetAsync(gate_a, 0, sizeof(int), st); eg != hipSuccess) return eg;
         hipLaunchKernelGGL(hmm_alpha0_kernel, dim3(1), dim3(256), 0, st, h->rho_tm, pi_tilde, K, Kp, n_chunks, h->fstart, h->bend,
                            h->cprime);
-        const int64_t W = std::min<int64_t>(L, h->sweep_len);
-        h->gate_w = W;
-        h->gate_l = L;
+        // first stage: the sweeps walk only the W steps next to every boundary (hmm.h, hmm_sweeps_kernel); if the replays' own
+        // boundary vectors agree, done.  Otherwise gate_a opens the second stage - whole-chunk sweeps, replays, check -, and
+        // only if that does not stand either gate_b opens the chunk products.
+        int64_t W = std::min<int64_t>(L, h->sweep_len);
+        if (W < L && h->short_hold > 0) {
+            --h->short_hold;
+            W = L;
+        }
+        h->gate_two_stage = W < L;
+        const int* stage_gate = nullptr;
+        if (W < L) {
+            hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
+                               h->fstart, h->bend, W, nullptr);
+            replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
+            hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+                               (n_chunks - 1) * Kp, Kp, kHmmForgetTol, gate_a, nullptr);
+            stage_gate = gate_a;
+        }
         hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks, h->fstart,
-                           h->bend, W);
-        replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
+                           h->bend, L, stage_gate);
+        replays(h->fstart, h->bend, h->fstart2, h->bend2, stage_gate);
         hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
-                           (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
-        // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
-        // made, they simply try the pass again)
-        h->gate_pending = hipMemcpyAsync(h->gate_host, h->gate_dev, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                           (n_chunks - 1) * Kp, Kp, kHmmForgetTol, gate_b, stage_gate);
+        // (the pinned copies only steer the NEXT calls - hold the pass off after one that needed the products, the short stage
+        // after one that needed whole chunks; if they cannot be made, the next calls simply try again)
+        h->gate_pending = hipMemcpyAsync(h->gate_host, gate_b, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                          hipMemcpyAsync(h->gate_host + 1, gate_a, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
                           hipEventRecord(h->gate_ev, st) == hipSuccess;
         gate = h->gate_dev;
     } else {
@@ -507,10 +534,10 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     if (e2 == hipSuccess) {      // the forgetting pass's gate (run<KT>, run_wide, run_generic): device flag, pinned copy, event
         h->spec_on = std::getenv("GMMVB_HMM_FORGETTING_OFF") == nullptr;
         if (const char* v = std::getenv("GMMVB_HMM_SWEEP_LEN")) h->sweep_len = std::max<int64_t>(1, std::atoll(v));      // developer switch
-        e2 = hipMalloc((void**)&h->gate_dev, 2 * sizeof(int));      // [0] forward-backward, [1] Viterbi
-        if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, sizeof(int));
+        e2 = hipMalloc((void**)&h->gate_dev, 4 * sizeof(int));      // [0] forward-backward (chunk products), [1] Viterbi, [2] forward-backward (whole-chunk stage)
+        if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, 2 * sizeof(int));
         if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&h->gate_ev, hipEventDisableTiming);
-        if (e2 == hipSuccess) *h->gate_host = 0;
+        if (e2 == hipSuccess) h->gate_host[0] = h->gate_host[1] = 0;
     }
     if (e2 != hipSuccess) {
         hmm_state_destroy(h);

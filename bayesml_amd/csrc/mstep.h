@@ -503,8 +503,13 @@ __global__ __launch_bounds__(256) void mstep_small_f64(const double* __restrict_
 constexpr double kHmmGammaFloor = 8.271806125530277e-25;        // 2^-80
 static_assert(kRelevanceBits == 80, "kHmmGammaFloor is 2^-kRelevanceBits");
 // a component with this many of a batch's 16 MFMA steps above the line takes the dense form's unrolled loop instead of the
-// bit walk (an iteration of the walk waits for its LDS operands, ~3 steps' worth of the unrolled loop)
-constexpr int kHmmDenseFrom = 6;
+// bit walk (an iteration of the walk waits for its LDS operands).  Measured at config 5, ms per VB iteration over passes 3-7
+// of a fit (profiles/r5_experiments.md): 6 -> 11.0-11.2, 12 -> 10.65-10.78, never -> 10.58-10.68, every step dense 12.3-12.5;
+// 12 keeps the walk's worst case (all 16 steps of all 8 components) at the dense kernel's time.
+#ifndef GMMVB_HMM_DENSE_FROM
+#define GMMVB_HMM_DENSE_FROM 12
+#endif
+constexpr int kHmmDenseFrom = GMMVB_HMM_DENSE_FROM;
 __host__ __device__ constexpr int lane_order_pos(int state) {          // hmm.h: hmm_pos
     const int w = state & 15;
     return (state & ~15) + 4 * (w & 3) + (w >> 2);
