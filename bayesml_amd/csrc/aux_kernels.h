@@ -466,7 +466,15 @@ __global__ void reduce_stats_kernel(const double* __restrict__ slabs, int S, int
     const int L = slab_len(T);
     if (e >= P * 256 + 16 * T + 2) return;
     double v = 0.0;
-    for (int s = 0; s < S; ++s) v += slabs[((int64_t)s * K + k) * L + e];
+    int s = 0;
+    for (; s + 16 <= S; s += 16) {              // sixteen loads in flight, added in split order (the same bits as one by one)
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = slabs[((int64_t)(s + u) * K + k) * L + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v += t[u];
+    }
+    for (; s < S; ++s) v += slabs[((int64_t)s * K + k) * L + e];
     double* ns = stats;
     double* h = stats + K;
     double* a = stats + 2 * (int64_t)K;
@@ -504,7 +512,17 @@ __global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int
     if (e >= P * 256 + 16 * T + 2) return;
     double v = 0.0;
     const int c0 = plan[k], c1 = plan[k + 1];
-    for (int c = c0; c < c1; ++c) v += slabs[(int64_t)c * L + e];
+    // (a component has ~70 slabs at the benchmark shape and the loop was a chain of dependent round trips to HBM: eight
+    // loads in flight, added in the same chunk order - the same bits)
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(c + u) * L + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; c < c1; ++c) v += slabs[(int64_t)c * L + e];
     auto put = [&](int64_t idx) {
         double o = v;
         if (accumulate) o += stats[idx];

@@ -472,6 +472,10 @@ __global__ __launch_bounds__(128) void hmm_boundary_fill_kernel(const double* __
 #define GMMVB_REPLAY_CHUNKS 16
 #endif
 constexpr int kReplayChunks = GMMVB_REPLAY_CHUNKS;      // chunks per replay wave (8 or 16)
+#ifndef GMMVB_HMM_REPLAY_AHEAD
+#define GMMVB_HMM_REPLAY_AHEAD 4
+#endif
+constexpr int kHmmReplayAhead = GMMVB_HMM_REPLAY_AHEAD;      // steps whose rho' rows a replay / sweep wave keeps in flight
 // H4: forward replay.  One wave = kReplayChunks chunks (MFMA columns).  alpha_tm / rho_tm in lane order.
 template <int KT>
 __device__ __forceinline__ void hmm_forward_replay_body(const double* __restrict__ rho_tm, const double* __restrict__ a_tilde, int K,
@@ -499,32 +503,53 @@ __device__ __forceinline__ void hmm_forward_replay_body(const double* __restrict
         for (int it = 0; it < KT; ++it) *reinterpret_cast<d4*>(alpha_tm + 16 * it + 4 * g) = al[it];
     }
     const int64_t t0 = 1 + c * L;
-    for (int64_t s = s_from; s < L; ++s) {
-        const int64_t t = t0 + s;
-        const bool on = live && t < T;
-        const bool st = on && first_copy && !sweep;
-        d4 nw[KT];
-        apply<KT>(aop, al, nw);
-        double part = 0.0;
+    // The wave's 16 columns read 16 rows of rho' that lie a chunk apart - 16 DRAM pages per step - and a step is ~20 dependent
+    // MFMAs: without help every step waited out an HBM round trip (2.8 us per step at config 5, five times its arithmetic).
+    // The rows of the next kHmmReplayAhead steps are kept in flight in registers (round 5; a rotating buffer, the loop
+    // unrolled by its depth so that every slot is a fixed register).
+    constexpr int PF = kHmmReplayAhead;
+    d4 rbuf[PF][KT];
+    auto fetch = [&](int64_t s, d4 (&dst)[KT]) {      // (unconditional loads from a clamped row: a predicated load would make
+        const int64_t t = t0 + s;                       // the compiler wait for everything in flight; the consumer masks)
+        const int64_t tc = (live && s < L && t < T) ? t : 0;
 #pragma unroll
-        for (int it = 0; it < KT; ++it) {
-            d4 rho = {0.0, 0.0, 0.0, 0.0};
-            if (on) rho = *reinterpret_cast<const d4*>(rho_tm + t * Kp + 16 * it + 4 * g);
+        for (int it = 0; it < KT; ++it) dst[it] = *reinterpret_cast<const d4*>(rho_tm + tc * Kp + 16 * it + 4 * g);
+    };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                nw[it][r] *= rho[r];
-                part += nw[it][r];
+    for (int p = 0; p < PF; ++p) fetch(s_from + p, rbuf[p]);
+    for (int64_t s0 = s_from; s0 < L; s0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int64_t s = s0 + p;
+            if (s >= L) break;                       // (L - s_from need not be a multiple of the depth)
+            const int64_t t = t0 + s;
+            const bool on = live && t < T;
+            const bool st = on && first_copy && !sweep;
+            d4 nw[KT];
+            apply<KT>(aop, al, nw);
+            double part = 0.0;
+            d4 rho[KT];
+#pragma unroll
+            for (int it = 0; it < KT; ++it) rho[it] = on ? rbuf[p][it] : d4{0.0, 0.0, 0.0, 0.0};
+            fetch(s + PF, rbuf[p]);                  // the slot's next tenant, kHmmReplayAhead steps ahead
+#pragma unroll
+            for (int it = 0; it < KT; ++it) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    nw[it][r] *= rho[it][r];
+                    part += nw[it][r];
+                }
             }
-        }
-        const double cp = sum_groups(part);
-        const double inv = cp > 0.0 ? 1.0 / cp : 0.0;
+            const double cp = sum_groups(part);
+            const double inv = cp > 0.0 ? 1.0 / cp : 0.0;
 #pragma unroll
-        for (int it = 0; it < KT; ++it) {
+            for (int it = 0; it < KT; ++it) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) al[it][r] = nw[it][r] * inv;
-            if (st) *reinterpret_cast<d4*>(alpha_tm + t * Kp + 16 * it + 4 * g) = al[it];
+                for (int r = 0; r < 4; ++r) al[it][r] = nw[it][r] * inv;
+                if (st) *reinterpret_cast<d4*>(alpha_tm + t * Kp + 16 * it + 4 * g) = al[it];
+            }
+            if (st && g == 0) cprime[t] = cp;
         }
-        if (st && g == 0) cprime[t] = cp;
     }
     if (end_out != nullptr && live && first_copy && c + 1 < n_chunks) {      // (every chunk but the last is whole)
 #pragma unroll
