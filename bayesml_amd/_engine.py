@@ -543,13 +543,18 @@ class DataPass:
         self.emission_fused = bool(eff.value)
         return self.emission_fused
 
-    def forward_backward(self, pi_tilde, a_tilde):
+    def forward_backward(self, pi_tilde, a_tilde, out: torch.Tensor = None):
         """(ms [K, K], gamma_0 [K], gamma_last [K], sum ln c) of the pass over the rows of the last estep;
-        leaves gamma as the workspace's responsibilities (mstep / responsibilities / argmax use it)."""
+        leaves gamma as the workspace's responsibilities (mstep / responsibilities / argmax use it).
+        ``out``: a float64 device buffer of hmmvb_out_len(K) elements to write them into (views of it are returned)."""
         K = self.K
         pi = _f64(pi_tilde, (K,), self.device)
         a = _f64(a_tilde, (K, K), self.device)
-        out = torch.empty(int(self.lib.hmmvb_out_len(K)), dtype=torch.float64, device=self.device)
+        n_out = int(self.lib.hmmvb_out_len(K))
+        if out is None:
+            out = torch.empty(n_out, dtype=torch.float64, device=self.device)
+        elif out.dtype != torch.float64 or out.numel() != n_out or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous float64 tensor of hmmvb_out_len(K) elements on the engine's device")
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.hmmvb_forward_backward(self._ws, self.rows, pi.data_ptr(), a.data_ptr(),
                                                              out.data_ptr(), self._stream()), "hmmvb_forward_backward")

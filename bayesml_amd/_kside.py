@@ -361,6 +361,117 @@ def hmm_lower_bound(p: HmmPriorT, q: HmmPostT, ns, ms, x_bar, s, gamma0, sum_gam
     return t
 
 
+HMM_TERM_KEYS = ("p_x", "p_z", "p_pi", "p_a", "p_mu_lambda", "q_z", "q_pi", "q_a", "q_mu_lambda", "vl")
+_HMM_POST_FIELDS = ("eta", "zeta", "m", "kappa", "nu", "w_inv", "w", "u", "u_inv", "e_ln_lambda_det", "ln_b_w_nu", "c",
+                    "ln_pi_tilde", "pi_tilde", "ln_a_tilde", "a_tilde", "ln_c_zeta_sum")
+
+
+class HmmKStepper:
+    """The K-sized half of one VB iteration of hiddenmarkovnormal.LearnModel as ONE unit on the GPU (round 5; the mixture's
+    twin is KStepper below):
+
+        statistics block + forward-backward summary -> moments (x_bar, S)                  ref :837-845
+                                                     -> sum gamma ln rho in closed form       ref :905 via :871-877
+                                                     -> lower bound under q (ten terms)       ref :883-943
+                                                     -> q' = closed-form update + features    ref :966-986, :861-881
+
+    About a hundred small torch kernels (the factorisation is the library's own, ``kside_factor``: capturable), captured
+    once in a hipGraph on the second call and replayed: at config 5 the launches were 0.6 ms of a 9.8-ms iteration, below
+    1e5 steps most of it.  The data pass writes ``stats`` (gmmvb_mstep) and ``fb`` (hmmvb_forward_backward) in place; ``q``
+    and ``q_next`` are fixed buffer sets; ``scal`` is the iteration's one device-to-host copy.  Eager on the CPU (host-logic
+    tests) and with BAYESML_AMD_KSIDE_GRAPH=0."""
+
+    def __init__(self, prior: HmmPriorT, pivot: torch.Tensor, stats_len: int):
+        import os
+        K, D = prior.m.shape
+        dev = prior.m.device
+        self.prior, self.pivot, self.K, self.D = prior, pivot, K, D
+        self.stats = torch.zeros(stats_len, dtype=torch.float64, device=dev)
+        self.fb = torch.zeros(K * K + 2 * K + 1, dtype=torch.float64, device=dev)      # [ms | gamma_0 | gamma_last | sum ln c]
+        self.h_scale = torch.ones((), dtype=torch.float64, device=dev)     # 0: the pass had no emission (random-responsibility start)
+        self.s_prev = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
+        self.q = self._buffers(hmm_post_from_prior(prior))
+        self.q_next = self._buffers(self.q)
+        self.ns = torch.zeros(K, dtype=torch.float64, device=dev)
+        self.x_bar = torch.zeros(K, D, dtype=torch.float64, device=dev)
+        self.s = torch.zeros(K, D, D, dtype=torch.float64, device=dev)
+        self.scal = torch.zeros(len(HMM_TERM_KEYS), dtype=torch.float64, device=dev)
+        self._graph = None
+        self._calls = 0
+        self._use_graph = dev.type == "cuda" and D <= 128 and os.environ.get("BAYESML_AMD_KSIDE_GRAPH", "1") != "0"
+
+    @staticmethod
+    def _buffers(src):
+        q = HmmPostT(*(getattr(src, f).clone() for f in _HMM_POST_FIELDS[:6]))
+        for f in _HMM_POST_FIELDS[6:]:
+            setattr(q, f, torch.as_tensor(getattr(src, f)).clone())
+        return q
+
+    @staticmethod
+    def _copy(dst, src):
+        for f in _HMM_POST_FIELDS:
+            getattr(dst, f).copy_(getattr(src, f))
+
+    def load(self, q: HmmPostT):
+        self._copy(self.q, q)
+
+    def fb_views(self):
+        K = self.K
+        return self.fb[:K * K].view(K, K), self.fb[K * K:K * K + K], self.fb[K * K + K:K * K + 2 * K], self.fb[K * K + 2 * K]
+
+    def _body(self):
+        K, D = self.K, self.D
+        st = self.stats
+        ns = st[:K]
+        a = st[2 * K:2 * K + K * D].view(K, D)
+        B = st[2 * K + K * D:].view(K, D, D)
+        ms, g0, _gl, sum_ln_c = self.fb_views()
+        x_bar, s = moments_from_stats(ns, a, B, self.pivot, self.s_prev)
+        sg = sum_gamma_ln_rho(self.q, ns, x_bar, s) * self.h_scale
+        terms = hmm_lower_bound(self.prior, self.q, ns, ms, x_bar, s, g0, sg, sum_ln_c)
+        qn = hmm_update_q(self.prior, ns, ms, x_bar, s)
+        self._copy(self.q_next, qn)
+        self.ns.copy_(ns)
+        self.x_bar.copy_(x_bar)
+        self.s.copy_(s)
+        self.s_prev.copy_(s)
+        self.scal.copy_(torch.stack([terms[k].reshape(()) for k in HMM_TERM_KEYS]))
+
+    def step(self):
+        """Run the K-side on ``stats`` / ``fb``.  Results: ns, x_bar, s, q_next, scal."""
+        self._calls += 1
+        if self._use_graph and self._graph is None and self._calls >= 2:
+            try:                                    # (the first call ran eagerly: library / BLAS warm-up)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body()
+                self._graph = g
+            except Exception as e:                  # noqa: BLE001 - capture is an optimisation, never a requirement
+                import warnings
+                warnings.warn(f"bayesml_amd: HMM K-side hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                self._use_graph = False
+                torch.cuda.synchronize()
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._body()
+
+    def read(self) -> dict:
+        """The lower bound's terms as host floats - the iteration's one host sync."""
+        return dict(zip(HMM_TERM_KEYS, self.scal.tolist()))
+
+    def advance(self):
+        self._copy(self.q, self.q_next)
+
+    def current(self) -> HmmPostT:
+        return self._buffers(self.q)
+
+    def moments(self) -> dict:
+        ms, g0, gl, sum_ln_c = self.fb_views()
+        return dict(ns=self.ns.clone(), ms=ms.clone(), x_bar=self.x_bar.clone(), s=self.s.clone(), g0=g0.clone(), gl=gl.clone())
+
+
 # ----------------------------------------------------------------------------------------------- one K-side step
 _POST_FIELDS = ("alpha", "m", "kappa", "nu", "w_inv", "w", "u", "u_inv", "e_ln_pi", "e_ln_lambda_det", "ln_b_w_nu", "c")
 TERM_KEYS = ("p_x", "p_z", "p_pi", "p_mu_lambda", "q_z", "q_pi", "q_mu_lambda", "vl")

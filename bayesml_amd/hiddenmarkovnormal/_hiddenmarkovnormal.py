@@ -299,9 +299,20 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         sum_g_ln_rho = _kside.sum_gamma_ln_rho(q, ns, x_bar, s)
         return dict(ns=ns, ms=ms, x_bar=x_bar, s=s, g0=g0, gl=gl, sum_g_ln_rho=sum_g_ln_rho, sum_ln_c=sum_ln_c)
 
-    def _random_pass(self, eng, xd, s_prev):
-        """_init_random_responsibility (ref:941-950): gamma and ms from host Dirichlet draws; ln rho = 0 and
-        cs = 1 keep their _init_fb_params values (ref:931-939), so both N-sized VL sums are 0."""
+    @staticmethod
+    def _stepper_pass(eng, xd, ks):
+        """_update_q_z (ref:1020-1026) under the stepper's current posterior: emission -> forward-backward -> statistics,
+        written into the stepper's buffers (the K-sized rest of the iteration is ``ks.step()``)."""
+        q = ks.q
+        eng.set_params(q.c, q.m, q.u)
+        eng.estep(xd)
+        eng.forward_backward(q.pi_tilde, q.a_tilde, out=ks.fb)
+        eng.mstep(xd, out=ks.stats)
+
+    def _random_pass(self, eng, xd, ks):
+        """_init_random_responsibility (ref:941-950): gamma and ms from host Dirichlet draws, written where the data pass
+        writes them (the stepper's statistics block and forward-backward summary); ln rho = 0 and cs = 1 keep their
+        _init_fb_params values (ref:931-939), so both N-sized sums of the lower bound are 0."""
         K, T, dev = self.c_num_classes, xd.shape[0], xd.device
         if T == 1:
             gamma = self.rng.dirichlet(np.ones(K))[np.newaxis, :]
@@ -313,11 +324,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             gamma[0] = xi[1].sum(axis=1)
             ms = xi.sum(axis=0)
         eng.load_responsibilities(torch.from_numpy(np.ascontiguousarray(gamma)).to(dev))
-        ns, _h, a, B = eng.split_stats(eng.mstep(xd))
-        x_bar, s = _kside.moments_from_stats(ns, a, B, eng.pivot, s_prev)
-        t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
-        zero = torch.zeros((), dtype=torch.float64, device=dev)
-        return dict(ns=ns, ms=t(ms), x_bar=x_bar, s=s, g0=t(gamma[0]), gl=t(gamma[-1]), sum_g_ln_rho=zero, sum_ln_c=zero)
+        eng.mstep(xd, out=ks.stats)
+        ks.fb.copy_(torch.from_numpy(np.concatenate([ms.reshape(-1), gamma[0], gamma[-1], [0.0]])).to(dev))
 
     def _vl(self, prior, q, st):
         return _kside.hmm_lower_bound(prior, q, st["ns"], st["ms"], st["x_bar"], st["s"], st["g0"],
@@ -336,29 +344,42 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         keep = {k: np.array(v) for k, v in self.get_hn_params().items()}
         keep["hn_w_mats_inv"] = np.array(self.hn_w_mats_inv)
         best_q, best_vl, never_converged, terms, vl = None, 0.0, True, None, 0.0
+        # the K-sized half of an iteration - moments, lower bound under q, q' - as one unit (a replayed hipGraph on the GPU,
+        # _kside.HmmKStepper); the data pass writes its statistics and the forward-backward summary into the stepper's buffers
+        ks = _kside.HmmKStepper(prior, eng.pivot, eng.stats_len)
+        ks.s_prev.copy_(s_prev)
+
+        def data_pass():
+            self._stepper_pass(eng, xd, ks)
+
         for i in range(num_init):
             self.reset_hn_params()
             q = _kside.hmm_post_from_prior(prior)
             if init_type == "subsampling":
                 size, a, B = self._subsample_moments(eng, xd, self._length)
                 q = _kside.subsample_moments_init(q, size, a, B, eng.pivot, _kside.hmm_features)
-                st = self._pass(eng, xd, q, s_prev)
+                ks.load(q)
+                ks.h_scale.fill_(1.0)
+                data_pass()
             elif init_type == "random_responsibility":
-                st = self._random_pass(eng, xd, s_prev)
+                ks.load(q)
+                ks.h_scale.fill_(0.0)          # (no emission in this pass: both N-sized sums of the lower bound are 0, ref:931-939)
+                self._random_pass(eng, xd, ks)
             else:
                 raise ValueError(f"init_type={init_type} is unsupported. This function supports only "
                                  '"subsampling" and "random_responsibility"')
-            s_prev = st["s"]
-            terms = self._vl(prior, q, st)
-            vl = float(terms["vl"])
+            ks.step()                          # lower bound under q on this pass's moments, and q' from them
+            terms = ks.read()
+            vl = terms["vl"]
             self._say(f"\r{i}. VL: {vl}")
+            ks.h_scale.fill_(1.0)
             for t in range(max_itr):
                 vl_before = vl
-                q = _kside.hmm_update_q(prior, st["ns"], st["ms"], st["x_bar"], st["s"])
-                st = self._pass(eng, xd, q, s_prev)
-                s_prev = st["s"]
-                terms = self._vl(prior, q, st)
-                vl = float(terms["vl"])
+                ks.advance()                   # q <- q'   (_update_q_mu_lambda / _update_q_pi / _update_q_a, ref:1099-1101)
+                data_pass()                    # _update_q_z (ref:1102)
+                ks.step()                      # _calc_vl (ref:1103) - and the next q'
+                terms = ks.read()
+                vl = terms["vl"]
                 self._say(f"\r{i}. VL: {vl} t={t} ")
                 with np.errstate(divide="ignore", invalid="ignore"):
                     if np.abs((vl - vl_before) / vl_before) < tolerance:
@@ -367,10 +388,11 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
                         break
             if i == 0 or vl > best_vl:
                 self._say("*", end="\n")
-                best_vl, best_q = vl, q.clone()
+                best_vl, best_q = vl, ks.current()
             else:
                 self._say("", end="\n")
             self.vl = vl
+        s_prev = ks.s_prev.clone()
         if never_converged:
             warnings.warn("Algorithm has not converged even once.", ResultWarning)
         if best_q is not None:

@@ -76,7 +76,7 @@ class CpuDataPass:
     def emission_target(self, fused):       # (the fake keeps its ln rho array: never in effect)
         return False
 
-    def forward_backward(self, pi_tilde, a_tilde):
+    def forward_backward(self, pi_tilde, a_tilde, out=None):
         ln_rho = self._ln_rho
         T, K = ln_rho.shape
         mx = ln_rho.max(dim=1).values
@@ -99,7 +99,11 @@ class CpuDataPass:
             ms += alpha[t - 1][:, None] * rho[t][None, :] * a_tilde * beta[t][None, :] / cs[t]
         self._hmm_gamma, self._alpha = gamma, alpha
         self._direct = gamma
-        return ms, gamma[0].clone(), gamma[-1].clone(), (torch.log(cs) + mx).sum()
+        res = (ms, gamma[0].clone(), gamma[-1].clone(), (torch.log(cs) + mx).sum())
+        if out is None:
+            return res
+        out.copy_(torch.cat([res[0].reshape(-1), res[1], res[2], res[3].reshape(1)]))          # (the engine's out= contract)
+        return out[:K * K].view(K, K), out[K * K:K * K + K], out[K * K + K:K * K + 2 * K], out[K * K + 2 * K]
 
     def viterbi(self, ln_pi_tilde, ln_a_tilde):
         ln_rho = self._ln_rho

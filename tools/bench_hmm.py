@@ -100,13 +100,19 @@ def measure(args, dev=None):
     q = _kside.hmm_post_from_prior(prior)
     size, a, B = m._subsample_moments(eng, xd, T)
     q = _kside.subsample_moments_init(q, size, a, B, eng.pivot, _kside.hmm_features)
-    st = m._pass(eng, xd, q, torch.zeros(K, D, D, dtype=torch.float64, device=dev))
+    # update_posterior's loop (ref:1099-1105): the data pass writes into the K-side stepper's buffers, the stepper's one unit
+    # (a replayed hipGraph) gives the lower bound and the next posterior, one device-to-host copy per iteration
+    ks = _kside.HmmKStepper(prior, eng.pivot, eng.stats_len)
+    ks.load(q)
+    m._stepper_pass(eng, xd, ks)
+    ks.step()
+    ks.read()
 
     def step():
-        nonlocal q, st
-        q = _kside.hmm_update_q(prior, st["ns"], st["ms"], st["x_bar"], st["s"])
-        st = m._pass(eng, xd, q, st["s"])
-        return float(m._vl(prior, q, st)["vl"])
+        ks.advance()
+        m._stepper_pass(eng, xd, ks)
+        ks.step()
+        return ks.read()["vl"]
 
     for _ in range(args.warmup):
         step()
@@ -123,7 +129,7 @@ def measure(args, dev=None):
     # forward recursion and read back by the backward one (the reference materialises ln_rho, alpha, beta, gamma [T, K]
     # and xi [T, K, K]); the kernels of DESIGN.md section 5b sweep about twelve [T][16 ceil(K/16)] f64 arrays per iteration.
     # Viterbi path of the whole sequence under the last posterior (chunked max-plus scan, hmm.h hmm_vit_*)
-    qf = q if getattr(q, "ln_pi_tilde", None) is not None else _kside.hmm_features(q)
+    qf = ks.current()
     eng.emission_target(False)              # (the Viterbi pass reads the ln rho array)
     eng.set_params(qf.c, qf.m, qf.u)
     eng.estep(xd)
