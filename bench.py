@@ -667,7 +667,7 @@ def compact_line(out):
     h = out.get("hmm_c5")
     if h:
         line["hmm_c5"] = dict(_pick(h, ("value", "unit", "steps", "warmup", "ms_per_step")),
-                              workload=h["config"]["workload"],
+                              workload=h["config"]["workload"], window=h.get("window"),
                               roofline=_pick(h["roofline"], ("bound", "achieved", "peak", "unit", "frac", "hbm_frac",
                                                              "f64_mfma_frac", "traffic")),
                               parity_max_rel_err=(h["parity"] or {}).get("max_rel_err"),
@@ -972,7 +972,7 @@ def small_c1_leg(dev, reps=5):
     return out
 
 
-def hmm_c5_leg(dev, steps=3, warmup=1, cpu=True):
+def hmm_c5_leg(dev, steps=10, warmup=5, cpu=True):
     """BASELINE.json configs[4] (hiddenmarkovnormal.LearnModel K=32, D=16, T=1e7): tools/bench_hmm.py's measurement."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_hmm

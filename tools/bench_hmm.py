@@ -180,6 +180,7 @@ def measure(args, dev=None):
         "unit": "time steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"HMM-VB K={K} D={D} T={T}, x stored f32, one VB iteration per step"},
+        "window": f"VB iterations {args.warmup + 1}-{args.warmup + args.steps} of one restart",
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "final_vl": vl, "boundary_pass": boundary_pass,
         "viterbi": None if getattr(args, "no_viterbi", False) else {"ms": viterbi_ms, "time_steps_per_s": T / (viterbi_ms * 1e-3), "states_visited": int(torch.unique(z).numel()),
                     "note": "hmmvb_viterbi over all T steps after the emission E-step (round 2: one sequential wave, ~10 s)"}})
@@ -187,8 +188,8 @@ def measure(args, dev=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--classes", type=int, default=32)
     ap.add_argument("--degree", type=int, default=16)
