@@ -269,7 +269,6 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
         ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
         ws->opt_hmm_mstep_dense = std::getenv("GMMVB_HMM_MSTEP_DENSE") != nullptr;
-        ws->opt_spec_opener = std::getenv("GMMVB_SPEC_OPENER_OFF") == nullptr;
         ws->opt_debug = std::getenv("GMMVB_DEBUG") != nullptr;
     }
     {
@@ -1249,23 +1248,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         }
     }
     if (ws->forget) ws->bound_fail_act = -1.0;        // (a new restart: nothing is known about its bounds)
-    ws->since_forget = ws->forget ? 0 : ws->since_forget + 1;      // this pass's index in its restart
     ws->forget = false;
-    // The restart opener (round 5).  The second pass of a restart runs under parameters one update away from the
-    // initialisation: at the benchmark shape 19 of 64 components per row are still active, but the only counters at hand are
-    // the FIRST pass's (everything active), so the rule above chose the dense kernel - 176 ms for an answer the pruned path
-    // gives in ~120.  Speculate: run the bound pass and its selection, count the candidates it leaves - the host waits for
-    // that one number (it has nothing else to do behind a 38-ms kernel; gmmvb_mstep after a dense pass waits the same way) -
-    // and go on with the pruned pass only if proof round + exact evaluations of that many pairs beat the dense kernel
-    // (policy::kPruneBelow); otherwise the dense kernel runs after all (+44 ms on that one pass of the restart).
-    bool speculative = false;
-    if (mode == kDense && can_prune && big && ws->since_forget == 1 && known && L.mode == kDense && same_rows && after_estep &&
-        ws->img_i8b != nullptr && !ws->lock_live && ws->opt_spec_opener && !ws->sharded) {
-        // (a row-sharded job would have to agree on the outcome - its ranks must run the same kind of pass, gmmvb_set_shard -
-        // which takes a collective of its own: there the second pass stays dense)
-        mode = kBound;
-        speculative = true;
-    }
     // The cache of single-component rows (and the settled rows among them) survives every pruned pass over the same rows
     // whose M-step applied the delta lists - all of them end in rec_finish_kernel - including the one that regroups the
     // rows (regroup_rows moves the per-row state along).  A dense pass, new data or parameters unrelated to the last pass
@@ -1392,7 +1375,6 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const bool tmeta_was_valid = ws->tmeta_valid;
     ws->tmeta_valid = false;            // (only a lazy sweep that ran to its end leaves the tile state in step with the bounds)
     bool emission_to_hmm = false;
-    for (;;) {          // (one trip; a speculative bound pass that does not pay comes round again as a dense pass)
     if (mode == kDense) {
         const bool valu16 = ws->estep_variant == kEstepValu16 && ws->tri != nullptr;
         // an HMM pass that only the forward-backward recursions will read: rho' rows and row maxima straight into the HMM
@@ -1473,26 +1455,6 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                ws->npad, n_rows, ws->K, ws->cvec, ws->khat, rec, ws->ub32);
             hipLaunchKernelGGL(rec_select_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, n_rows, ws->K, ws->cvec, ws->masks,
                                ws->npad, ws->blk, ws->epart, ws->opart, ws->rthr);
-            if (speculative) {
-                // the candidates the bound pass leaves, counted now (block 1 of sum_parts_kernel: epart -> ctr[1])
-                hipLaunchKernelGGL(sum_parts_kernel, dim3(2), dim3(1024), 0, st, nullptr, ws->epart, nullptr, nullptr, nullptr, nullptr,
-                                   nullptr, nullptr, sel_grid, ws->ctr);
-                span_end(ws, st);
-                e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 2 * sizeof(double), hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipEventRecord(ws->ctr_ev, st);
-                if (e == hipSuccess) e = hipEventSynchronize(ws->ctr_ev);
-                if (e != hipSuccess) return fail(GMMVB_EHIP, "counting the speculative bound pass's candidates", e);
-                const double cand = ws->ctr_host[1] + (double)n_rows;          // (+ every row's best component, evaluated above)
-                speculative = false;
-                if (cand > policy::kPruneBelow * pairs) {
-                    mode = kDense;
-                    ++ws->passes[3];
-                    ws->bound_fail_act = cand / pairs;
-                    if (ws->opt_debug) std::fprintf(stderr, "[gmmvb] estep: speculative bound pass left %.3g candidates per row: dense\n", cand / (double)n_rows);
-                    continue;
-                }
-                span_begin(ws, kSpanSelect, st);
-            }
             if (proof_capable) {
                 // the candidates' bounds come from the bound pass's leading output blocks only: three int8 digits over ALL
                 // blocks first (a third of an exact evaluation's cost), and only what still does not clear the threshold
@@ -1636,8 +1598,6 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             ws->lock_live = true;
             ws->delta_pending = true;
         }
-    }
-    break;
     }
     ws->tmeta_valid = tmeta_kept;
     ws->pend_lazy = tmeta_kept;

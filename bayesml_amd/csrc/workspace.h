@@ -116,8 +116,6 @@ struct gmmvb_workspace {
     int pol_mode = 0;                  // ... of a pass of this mode
     bool pol_first_sorted = false;
     bool exp_counted = false;          // the last E-step counted its pairs (what gmmvb_policy_export may hand out)
-    int since_forget = -1;             // index of the last E-step in its restart (0 = the first pass after gmmvb_forget / creation)
-    bool opt_spec_opener = true;       // env GMMVB_SPEC_OPENER_OFF: no speculative bound pass at the second pass of a restart
     bool forget = false;               // gmmvb_forget: the next parameters are unrelated to the last E-step's
     double spare_last = -1.0;          // spare candidates per pair of the last pruned pass (diagnostics)
     double bound_fail_act = -1.0;      // active share of the pairs when a bound pass last left most of them candidates (< 0: never)
