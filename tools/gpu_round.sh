@@ -27,6 +27,10 @@ print("D =", sys.argv[2], "ms/step", round(d["ms_per_step"], 2), {k: (round(v["m
 PY
           done ;;
     share8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --config c4 --rows 200000 --steps 12 --warmup 5 --no-cpu --no-legs --detail $OUT/${TAG}_bench_detail_eight_ranks_one_gpu.json 2> $OUT/${TAG}_share8.err | grep -a "^{" > $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_share8.err; head -c 700 $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; echo ;;
+    legsall) timeout 1500 python bench.py --steps 20 --warmup 5 --legs all --detail $OUT/${TAG}_bench_detail_all_legs.json > $OUT/${TAG}_bench_line_all_legs.json 2> $OUT/${TAG}_legsall.err; tail -c 300 $OUT/${TAG}_legsall.err; cat $OUT/${TAG}_bench_line_all_legs.json; echo ;;
+    strong8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --config c4 --scaling strong --total-rows 1600000 --steps 12 --warmup 5 --no-cpu --no-legs --detail $OUT/${TAG}_bench_detail_c4_strong_eight_ranks_one_gpu.json 2> $OUT/${TAG}_strong8.err | grep -a "^{" > $OUT/${TAG}_bench_line_c4_strong_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_strong8.err; cat $OUT/${TAG}_bench_line_c4_strong_eight_ranks_one_gpu.json; echo ;;
+    hmmsmall) for t in 10000 100000; do for g in 1 0; do BAYESML_AMD_KSIDE_GRAPH=$g timeout 300 python tools/bench_hmm.py --rows $t --no-cpu --steps 20 --warmup 5 2>/dev/null | grep -a "^{" > $OUT/${TAG}_hmm_t${t}_graph$g.json; python -c "
+import json,sys; d=json.load(open('$OUT/${TAG}_hmm_t${t}_graph$g.json')); print('T=$t graph=$g ms/iteration', round(d['ms_per_step'],3))"; done; done ;;
     hist) timeout 300 python tools/active_hist.py > $OUT/${TAG}_active_hist.json 2> $OUT/${TAG}_hist.err; head -c 300 $OUT/${TAG}_active_hist.json; echo ;;
     trace) rm -rf $OUT/${TAG}_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-legs --steps 20 --warmup 5 --detail $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled_detail.json > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_trace.err)
            python tools/summarize_rocprof.py $OUT/${TAG}_trace > $OUT/${TAG}_bench_kernel_summary.md 2>> $OUT/${TAG}_trace.err; head -30 $OUT/${TAG}_bench_kernel_summary.md
