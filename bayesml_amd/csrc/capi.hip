@@ -193,7 +193,7 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
         ws->KG = (K + kpw - 1) / kpw;
     }
     // row splits of the dense M-step: ~4 workgroups per CU; with a single feature tile a step is a row load and one
-    // MFMA - latency, not arithmetic - so many more, shorter, splits (HMM config 5, DESIGN.md 5b)
+    // MFMA - latency, not arithmetic - so many more, shorter, splits (HMM config 5, DESIGN.md 4c)
     ws->S_cap = (int)round_up(((int64_t)(ws->T == 1 ? GMMVB_T1_SPLITS : 4) * ws->num_cu + ws->KG - 1) / ws->KG, 8);      // (24: three of the HMM M-step's 50-KB workgroups per CU)
     if (ws->S_cap < 8) ws->S_cap = 8;
     {
@@ -1257,7 +1257,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // The rows are regrouped by dominant component at a bound pass (which rebuilds everything row-indexed anyway).  With
     // the proof round bound passes have become rare: the first time the responsibilities are sparse enough for the grouping
     // to pay (at most 2.5 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
-    // kernels over ungrouped rows are 15-40 % slower for the rest of the fit (DESIGN.md 5c).
+    // kernels over ungrouped rows are 15-40 % slower for the rest of the fit (DESIGN.md 4b).
     if (mode == kSweep && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
         after_estep && known && L.act <= policy::kRegroupForceBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
         ws->xc_ldx == ldx)

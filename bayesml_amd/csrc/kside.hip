@@ -319,7 +319,7 @@ __device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /*[NT /
 }
 
 // NT threads per component: 1024 for D > 32 (sixteen waves hide the LDS latency of the factorisation's short dependent
-// steps: 0.61 -> see DESIGN.md 5d), 256 below.
+// steps: 0.61 -> see DESIGN.md 4d), 256 below.
 template <int NT>
 __global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView pr, PostView q, PostView qn,
                                                          const double* __restrict__ stats, const double* __restrict__ pivot,

@@ -23,7 +23,7 @@ lists and kernel groups goes to ``--detail`` (default gpurun_out/bench_detail.js
 (~20 s); hard, spread, offpath, small on request (``--legs all``).
 
 Legs of the single-GPU run (full record):
-  value/roofline  the default policy (sparse where the responsibilities are, DESIGN.md section 5c), timed
+  value/roofline  the default policy (sparse where the responsibilities are, DESIGN.md section 4b), timed
   dense           the same data pass with the dense f64 MFMA kernels (every pair evaluated): the floor the policy
                   falls back to, its executed TFLOP/s against the f64 MFMA peak, and the difference of the
                   statistics block between the two paths on identical parameters
@@ -42,7 +42,7 @@ Legs of the single-GPU run (full record):
                   default policy (dense kernels at that size) and with the sparse path forced (int8 bound pass,
                   carried bounds, candidate gathers, list M-step - the kernels of the timed steps)
 
-roofline (DESIGN.md section 6): every kernel group carries both fractions - ``hbm_frac`` = algorithmic bytes (rows it
+roofline (DESIGN.md section 5): every kernel group carries both fractions - ``hbm_frac`` = algorithmic bytes (rows it
 has to read x D x s) / its HIP-event time / 8 TB/s, ``f64_mfma_frac`` = executed f64 MFMA flops / 78.6 TFLOP/s -
 and ``bound`` names the larger; the line's bound / achieved / peak / frac are the dominant group's.  ``step_hbm_frac`` = the
 whole step's N D s bytes / step time / 8 TB/s (= value / HBM-roofline samples/s).  ``per_rank``: every rank's own step times.
@@ -557,7 +557,7 @@ def main():
                         "hbm_roofline_samples_per_s.  f64_mfma_ceiling = the rate at which the f64 matrix pipe alone could "
                         "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M).  "
                         "executed_f64_tflops of estep_gather charges the pairs that take the gather's early way out "
-                        "(DESIGN.md 5c; pairs_per_sample.early_exits) with the tile pairs they really do"}
+                        "(DESIGN.md 4b; pairs_per_sample.early_exits) with the tile pairs they really do"}
         if dom:
             roof["hbm_frac"] = groups[dom].get("hbm_frac")
             roof["f64_mfma_frac"] = groups[dom].get("f64_mfma_frac")

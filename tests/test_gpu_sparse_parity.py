@@ -187,7 +187,7 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
     if not offpath and "overlap" not in name and "spread1" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled"):
-        # the M-step's cache of single-component rows (DESIGN.md 5d): in use by default, its rows are not accumulated
+        # the M-step's cache of single-component rows (DESIGN.md 4d): in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
         swept = m._engine.launch_info.startswith("estep_sweep")
@@ -202,7 +202,7 @@ def test_large_fixture_matches_reference(name, variant):
         if variant in ("nosettle", "noproof"):      # (without settled rows the proof round still serves the bound passes)
             assert wk["settled_rows"] == 0 and (wk["proof_pairs"] == 0 or variant == "nosettle"), wk
     if variant == "default" and not offpath and "overlap" not in name and "spread1" not in name:
-        # the workspace regrouped its internal row order by dominant component on the way (DESIGN.md 5c): every
+        # the workspace regrouped its internal row order by dominant component on the way (DESIGN.md 4b): every
         # read-out above - responsibilities of the first rows, their column sums, hard assignments - is nevertheless
         # in the caller's row order
         assert m._engine.regroup_count >= 1

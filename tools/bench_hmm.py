@@ -127,7 +127,7 @@ def measure(args, dev=None):
     # HBM roofline (the chunked scan is bandwidth / latency bound, K^2 flops per byte of state are far below the MFMA
     # balance): algorithmic bytes per time step = the row of x read once (D * 4) + one [K] f64 state vector written by the
     # forward recursion and read back by the backward one (the reference materialises ln_rho, alpha, beta, gamma [T, K]
-    # and xi [T, K, K]); the kernels of DESIGN.md section 5b sweep about twelve [T][16 ceil(K/16)] f64 arrays per iteration.
+    # and xi [T, K, K]); the kernels of DESIGN.md section 4c sweep about twelve [T][16 ceil(K/16)] f64 arrays per iteration.
     # Viterbi path of the whole sequence under the last posterior (chunked max-plus scan, hmm.h hmm_vit_*)
     qf = ks.current()
     eng.emission_target(False)              # (the Viterbi pass reads the ln rho array)
