@@ -283,35 +283,55 @@ __global__ __launch_bounds__(64 * mstep_waves(T, PRE)) void mstep_mfma_f64(
 // T + 1 pairs each.  One component per workgroup; rows from the centred f64 copy (16 T doubles per row, T per lane); the
 // per-step vector work of a wave is two multiplies and two additions beside its T + 1 MFMAs.  Same operations per tile pair
 // in the same order as mstep_body, same slab layout, same reduce.
+// Round 5: the rows go through LDS.  Every one of the workgroup's T / 2 waves used to load the whole row from global memory -
+// 16 T doubles per step and wave, the same bytes T / 2 times through one L1 - and at T = 16 that L1 traffic took as long as the
+// wave's T + 1 MFMAs (0.51 of the f64 peak).  Now the workgroup copies a batch of 16 rows (contiguous in the centred copy)
+// into LDS once, a batch ahead through registers, in the order the MFMA operands are read - element (row r, tile t, lane
+// feature i) at ((r >> 2) T + t) 64 + (r & 3) 16 + i, so that the operand of (step, tile) is the lane-linear read
+// sx[(st T + t) 64 + lane]: conflict-free - and a wave reads only the T - SUB tiles it multiplies.  Two buffers, one
+// barrier per batch of four steps (4 (T + 1) MFMAs per wave).
+constexpr int kWideBatch = 16;      // rows per LDS batch
+template <int T>
+__device__ __forceinline__ int wide_lds_index(int r, int f) {       // row r of the batch, feature f = T i + t of the row
+    const int i = f / T, t = f - T * i;
+    return ((r >> 2) * T + t) * 64 + (r & 3) * 16 + i;
+}
 template <int T, int SUB>
 __device__ __forceinline__ void mstep_wide_body(const double* __restrict__ xc, int64_t n_rows, const double* __restrict__ lr,
                                                 const double* __restrict__ lse, const double* __restrict__ aux_k, int64_t lo,
-                                                int64_t hi, int direct_r, double* __restrict__ out) {
+                                                int64_t hi, int direct_r, double* __restrict__ out, double* __restrict__ sx) {
     static_assert(T > 8 && T <= 16 && T % 2 == 0, "even tile counts (the workspace rounds an odd one up)");
     constexpr int P = tri_pairs(T);
     constexpr int C1 = SUB, C2 = T - 1 - SUB;      // the wave's A-operand tiles (C1 < C2)
     constexpr int N1 = T - C1, N2 = T - C2;        // tile pairs (t2, C1), t2 = C1 .. T - 1, and (t2, C2), t2 = C2 .. T - 1
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    typedef double v2 __attribute__((ext_vector_type(2)));
+    constexpr int BUF = kWideBatch * 16 * T;       // doubles per LDS buffer
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     d4 acc1[N1], acc2[N2];
 #pragma unroll
     for (int p = 0; p < N1; ++p) acc1[p] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int p = 0; p < N2; ++p) acc2[p] = d4{0.0, 0.0, 0.0, 0.0};
     double asum1 = 0.0, asum2 = 0.0, nsum = 0.0, hsum = 0.0;
-    struct Row { double v[T]; };
-    auto load_row = [&](int64_t row) {             // (zero rows up to npad + 64: no clamp)
-        const double* xp = xc + row * (16 * T) + T * i;
-        Row o;
-#pragma unroll
-        for (int t = 0; t < T; t += 2) {
-            const v2 v = *reinterpret_cast<const v2*>(xp + t);
-            o.v[t] = v[0];
-            o.v[t + 1] = v[1];
-        }
-        return o;
+    // staging: the batch is 256 T contiguous doubles of the centred copy, the workgroup has 32 T threads: eight each
+    // (zero rows up to npad + 64: no clamp)
+    d4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0;
+    auto request = [&](int64_t row0) {
+        const double* src = xc + row0 * (16 * T) + 8 * tid;
+        s0 = *reinterpret_cast<const d4*>(src);
+        s1 = *reinterpret_cast<const d4*>(src + 4);
     };
-    Row nxt = load_row(lo + g);
+    auto deposit = [&](double* dst) {
+        const int r = (8 * tid) / (16 * T), f0 = 8 * tid - r * (16 * T);      // (16 T is a multiple of 8: one row per thread)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[wide_lds_index<T>(r, f0 + e)] = s0[e];
+            dst[wide_lds_index<T>(r, f0 + 4 + e)] = s1[e];
+        }
+    };
+    request(lo);
+    deposit(sx);
+    __syncthreads();
+    int b = 0;
     for (int64_t c0 = lo; c0 < hi; c0 += 64) {
         const int64_t nl = c0 + lane;
         double r_l = 0.0;
@@ -330,24 +350,29 @@ __device__ __forceinline__ void mstep_wide_body(const double* __restrict__ xc, i
             }
             nsum += r_l;
         }
-        double rr_n = __shfl(r_l, g);
-#pragma unroll 2
-        for (int st = 0; st < 16; ++st) {
-            const Row cur = nxt;
-            const double rr = rr_n;
-            const double ra1 = rr * cur.v[C1], ra2 = rr * cur.v[C2];
-            asum1 += ra1;
-            asum2 += ra2;
-            __builtin_amdgcn_sched_barrier(0);
-            nxt = load_row(c0 + 4 * (st + 1) + g);
-            rr_n = __shfl(r_l, (4 * (st + 1) + g) & 63);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int q = 0; q < 64 / kWideBatch; ++q, b ^= 1) {
+            const int64_t r0 = c0 + kWideBatch * q;
+            if (r0 >= hi) break;                   // (workgroup uniform: lo, hi are)
+            const bool more = r0 + kWideBatch < hi;
+            if (more) request(r0 + kWideBatch);    // in flight while this batch is worked through
+            const double* cur = sx + b * BUF;
 #pragma unroll
-            for (int p = 0; p < N1; ++p) acc1[p] = mfma_f64(ra1, cur.v[C1 + p], acc1[p]);
+            for (int st = 0; st < kWideBatch / 4; ++st) {
+                const double rr = __shfl(r_l, kWideBatch * q + 4 * st + g);
+                double xv[N1];                     // tiles C1 .. T - 1 of the step's four rows (C2 .. T - 1 are among them)
 #pragma unroll
-            for (int p = 0; p < N2; ++p) acc2[p] = mfma_f64(ra2, cur.v[C2 + p], acc2[p]);
+                for (int p = 0; p < N1; ++p) xv[p] = cur[(st * T + C1 + p) * 64 + lane];
+                const double ra1 = rr * xv[0], ra2 = rr * xv[C2 - C1];
+                asum1 += ra1;
+                asum2 += ra2;
 #pragma unroll
-            for (int t = 0; t < T; ++t) asm volatile("" ::"v"(cur.v[t]));
+                for (int p = 0; p < N1; ++p) acc1[p] = mfma_f64(ra1, xv[p], acc1[p]);
+#pragma unroll
+                for (int p = 0; p < N2; ++p) acc2[p] = mfma_f64(ra2, xv[C2 - C1 + p], acc2[p]);
+            }
+            if (more) deposit(sx + (b ^ 1) * BUF);
+            __syncthreads();                       // the next batch is in LDS; everybody is done with this one
         }
     }
 #pragma unroll
@@ -379,8 +404,9 @@ template <int T, int... I>
 __device__ __forceinline__ void mstep_wide_dispatch(int sub, const double* __restrict__ xc, int64_t n_rows,
                                                     const double* __restrict__ lr, const double* __restrict__ lse,
                                                     const double* __restrict__ aux_k, int64_t lo, int64_t hi, int direct_r,
-                                                    double* __restrict__ out, std::integer_sequence<int, I...>) {
-    ((sub == I ? mstep_wide_body<T, I>(xc, n_rows, lr, lse, aux_k, lo, hi, direct_r, out) : (void)0), ...);
+                                                    double* __restrict__ out, double* __restrict__ sx,
+                                                    std::integer_sequence<int, I...>) {
+    ((sub == I ? mstep_wide_body<T, I>(xc, n_rows, lr, lse, aux_k, lo, hi, direct_r, out, sx) : (void)0), ...);
 }
 
 template <int T>
@@ -389,6 +415,7 @@ __global__ __launch_bounds__(32 * T) void mstep_wide_f64(const double* __restric
                                                          const double* __restrict__ aux, int64_t npad, int K, int KG, int S,
                                                          int64_t rows_per_split, int direct_r,
                                                          double* __restrict__ slabs /*[S][K][slab_len(T)]*/) {
+    __shared__ __attribute__((aligned(16))) double sx[2 * kWideBatch * 16 * T];      // two batches of 16 rows (64 KB at T = 16)
     const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // T / 2 waves, one component
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
@@ -402,7 +429,7 @@ __global__ __launch_bounds__(32 * T) void mstep_wide_f64(const double* __restric
     const double* lr = lnrho + (int64_t)k * npad;
     const double* aux_k = aux ? aux + (int64_t)k * npad : nullptr;
     double* out = slabs + ((int64_t)split * K + k) * slab_len(T);
-    mstep_wide_dispatch<T>(sub, xc, n_rows, lr, lse, aux_k, lo, hi, direct_r, out, std::make_integer_sequence<int, T / 2>{});
+    mstep_wide_dispatch<T>(sub, xc, n_rows, lr, lse, aux_k, lo, hi, direct_r, out, sx, std::make_integer_sequence<int, T / 2>{});
 }
 
 // ---- one feature tile (D <= 16): many components per wave ----------------------------------------------------------
