@@ -356,7 +356,7 @@ __global__ __launch_bounds__(128) void hmm_boundary_scan_kernel(const double* __
 #define GMMVB_HMM_LONG_CHUNK 256
 #endif
 constexpr int kHmmSuper = GMMVB_HMM_SUPER;
-constexpr int kHmmLongChunk = GMMVB_HMM_LONG_CHUNK;      // chunk length of sequences past 2^18 steps (two-level boundary pass)
+constexpr int kHmmLongChunk = GMMVB_HMM_LONG_CHUNK;      // chunk length of sequences past 2^15 steps (kHmmLongFrom, hmm_capi.hip) (two-level boundary pass)
 
 // H3a: Q_s = P_{sG} P_{sG+1} ... (G = kHmmSuper chunks), rescaled to max 1 after every product.  One workgroup per s.
 template <int KT>

@@ -492,7 +492,7 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     h->xi_waves = h->generic ? std::max<int64_t>(16, std::min<int64_t>(4 * (int64_t)ws->num_cu, (int64_t(1) << 27) / ((int64_t)h->Kp * h->Kp)))
                              : 16 * (int64_t)ws->num_cu;       // four xi-sum waves per SIMD: the kernel streams two [T][Kp] arrays and a wave
                                                                // has one load group in flight (round 4; one wave per SIMD: 1.9 ms, 2.6 TB/s)
-    // room for one xi slab per replay wave (hmm.h H5 XI): sequences past 2^18 steps have chunks of kHmmLongChunk steps, 16 to a
+    // room for one xi slab per replay wave (hmm.h H5 XI): sequences past 2^15 steps have chunks of kHmmLongChunk steps, 16 to a
     // wave; shorter ones at most ~850 chunks (chunk_len)
     h->xi_slab_cap = std::max<int64_t>(h->xi_waves + 4, h->generic ? 0 : h->npad / (16 * (kHmmLongChunk / 2)) + 72);
     h->xi_separate = std::getenv("GMMVB_HMM_XI_SEPARATE") != nullptr;

@@ -110,7 +110,7 @@ def test_forward_backward_matches_reference(name, hmm_mstep_mode):
                                          # ... and past 128 chunks of 256 steps their two-level boundary pass
                                          (70, 2, 40000, np.float64), (128, 2, 33500, np.float32)])
 def test_ragged_shapes_against_oracle(K, D, T, dtype, hmm_mstep_mode):
-    """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths - and, past 2^18 steps, the
+    """K % 16 != 0 (padded states), T = 1, partial chunks, several chunk lengths - and, past 2^15 steps, the
     two-level boundary pass (chunks of 256 steps, super-chunk products); random posterior.  More than 64 states: the
     sequential kernels of csrc/hmm_generic.h (transition matrix in LDS up to K = 128, in L2 beyond) - and for 65 .. 128
     states over at least 2048 steps the chunk-parallel ones of csrc/hmm_wide.h (5 .. 8 tiles of 16 states, ragged last
@@ -295,7 +295,7 @@ def test_emission_into_the_forward_backward_buffers(K, D, T, dtype, hmm_mstep_mo
 @pytest.mark.parametrize("K,D,flat", [(32, 16, False), (8, 3, False), (5, 2, True), (48, 8, False), (64, 5, False),
                                       (96, 8, False), (72, 4, True), (130, 4, False), (150, 3, True), (6, 2, "cycle")])
 def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
-    """Sequences past 2^18 steps: chunk boundary vectors from sweeps started at the uniform vector (the scaled recursions
+    """Sequences past 2^15 steps: chunk boundary vectors from sweeps started at the uniform vector (the scaled recursions
     forget their start), checked against the replays' own and replaced by the chunk-product path when they do not stand.
     Informative emissions: the pass stands (0) and the results are those of the products path; flat emissions and a sticky
     chain: the gate opens (1), the products path runs behind it - same results -, and the next calls go straight to it (-1)."""
