@@ -122,6 +122,7 @@ hipError_t hmm_ensure_gamma_cm(gmmvb_hmm_state* h, hipStream_t st) {
 namespace {
 
 constexpr int kLncBlocks = 1024;
+constexpr int kHmmCheckBlocks = 1024;      // grid of hmm_boundary_check_kernel (grid-stride over 40 MB of boundary vectors at config 5: 64 blocks took 0.08 ms)
 // the forgetting pass stands if no entry of a (sum-1 normalised) boundary vector moves by more than this RELATIVE to itself
 // when its chunk is started from the sweep's vector instead of the uniform one (hmm.h, hmm_boundary_check_kernel<true>: a test
 // in the Hilbert metric, in which the recursion is non-expansive): a fully forgotten start leaves the rounding noise of sums
@@ -246,14 +247,14 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
             hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
                                h->fstart, h->bend, W, nullptr);
             replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
-            hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+            hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(kHmmCheckBlocks), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                                (n_chunks - 1) * Kp, Kp, kHmmForgetTol, gate_a, nullptr);
             stage_gate = gate_a;
         }
         hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks, h->fstart,
                            h->bend, L, stage_gate);
         replays(h->fstart, h->bend, h->fstart2, h->bend2, stage_gate);
-        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(kHmmCheckBlocks), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, gate_b, stage_gate);
         // (the pinned copies only steer the NEXT calls - hold the pass off after one that needed the products, the short stage
         // after one that needed whole chunks; if they cannot be made, the next calls simply try again)
@@ -355,7 +356,7 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
         hipLaunchKernelGGL((hmm_backward_replay_wide_kernel<KT>), dim3(grid), dim3(256), fb, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
                            h->bend, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, 1, h->bend, nullptr);
         replays(h->fstart, h->bend, h->fstart2, h->bend2, nullptr);
-        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(kHmmCheckBlocks), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
         // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
         // made, they simply try the pass again)
@@ -435,7 +436,7 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
                            nullptr);
         hipLaunchKernelGGL(hmm_seq_backward_kernel, dim3(g), dim3(kHmmSeqThreads), sh.lds_bytes, st, h->rho_tm, h->a_t, K, Kp, T,
                            sh.P, sh.J, sh.mat_in_lds, h->alpha_tm, h->cprime, h->gamma_tm, h->w_tm, L, h->bend, 0, h->bend2, nullptr);
-        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<true>, dim3(kHmmCheckBlocks), dim3(256), 0, st, h->fstart, h->fstart2, h->bend, h->bend2,
                            (n_chunks - 1) * Kp, Kp, kHmmForgetTol, h->gate_dev);
         // (the pinned copy only steers the NEXT calls - hold the pass off after one that needed the products; if it cannot be
         // made, they simply try the pass again)
@@ -593,7 +594,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
                            ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr); \
         hipLaunchKernelGGL((hmm_vit_replay_wide_kernel<KTT>), dim3(rgrid), dim3(64 * kVitWideWaves), lds, st, ws->lnrho,        \
                            ws->npad, ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, h->fstart2, nullptr); \
-        hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,           \
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(kHmmCheckBlocks), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,           \
                            (chunks - 1) * h->Kp, h->Kp, kVitCoalesceTol, h->gate_dev + 1);                                                \
     }                                                                                                                          \
     if (ew == hipSuccess) {                                                                                                    \
@@ -641,7 +642,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
             hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3((unsigned)chunks), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
                                ln_pi_tilde_dev, ln_a_tilde_dev, h->K, n_rows, sh.P, sh.J, sh.mat_in_lds, h->phi16, h->last_state, L, h->Kp,
                                h->fstart, 0, h->fstart2, nullptr);
-            hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(64), dim3(256), 0, st, h->fstart, h->fstart2, h->fstart, h->fstart,
+            hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(kHmmCheckBlocks), dim3(256), 0, st, h->fstart, h->fstart2, h->fstart, h->fstart,
                                (chunks - 1) * h->Kp, h->Kp, kVitCoalesceTol, h->gate_dev + 1);
         }
         hipLaunchKernelGGL(hmm_seq_viterbi_kernel, dim3(1), dim3(kHmmSeqThreads), sh.lds_bytes, st, ws->lnrho, ws->npad,
@@ -698,7 +699,7 @@ int hmmvb_viterbi(gmmvb_workspace* ws, int64_t n_rows, const double* ln_pi_tilde
                            ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 1, wstart, nullptr);     \
         hipLaunchKernelGGL((hmm_vit_replay_kernel<KTT>), dim3((unsigned)chunks), dim3(64), 0, st, ws->lnrho, ws->npad,       \
                            ln_a_tilde_dev, wstart, h->K, n_rows, L, chunks, h->phi, h->last_state, 0, h->fstart2, nullptr);  \
-        hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(64), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,        \
+        hipLaunchKernelGGL(hmm_boundary_check_kernel<false>, dim3(kHmmCheckBlocks), dim3(256), 0, st, wstart, h->fstart2, wstart, wstart,        \
                            (chunks - 1) * h->Kp, h->Kp, kVitCoalesceTol, h->gate_dev + 1);                                             \
     }                                                                                                                       \
     if (KTT <= 2) {                                                                                                         \
