@@ -221,7 +221,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     // gate is copied to pinned memory and looked at when the next call begins: no synchronisation).
     const int* gate = nullptr;
     consume_gate(h, /*wait=*/false);
-    bool spec = two_level && h->spec_on && h->gate_dev != nullptr && !h->gate_pending;
+    bool spec = two_level && h->spec_on && h->gate_dev != nullptr;      // (a gate copy still in flight - a caller that does not synchronise between calls - only means the last outcome is not known yet)
     if (spec && h->spec_hold > 0) {
         --h->spec_hold;
         spec = false;
@@ -342,7 +342,7 @@ hipError_t run_wide(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const do
     const bool two_level = n_chunks > 2 * kHmmSuper;
     const int* gate = nullptr;
     consume_gate(h, /*wait=*/false);
-    bool spec = two_level && h->spec_on && h->gate_dev != nullptr && !h->gate_pending;
+    bool spec = two_level && h->spec_on && h->gate_dev != nullptr;      // (a gate copy still in flight - a caller that does not synchronise between calls - only means the last outcome is not known yet)
     if (spec && h->spec_hold > 0) {
         --h->spec_hold;
         spec = false;
@@ -418,7 +418,7 @@ hipError_t run_generic(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
     const int* gate = nullptr;
     consume_gate(h, /*wait=*/false);
-    bool spec = h->spec_on && h->gate_dev != nullptr && !h->gate_pending && n_chunks >= 64 && n_chunks <= h->vec_chunks;
+    bool spec = h->spec_on && h->gate_dev != nullptr && n_chunks >= 64 && n_chunks <= h->vec_chunks;
     if (spec && h->spec_hold > 0) {
         --h->spec_hold;
         spec = false;
