@@ -448,6 +448,12 @@ def main():
         ranks_info = [dict(rank=0, elapsed_s=elapsed, ms_per_step=elapsed / args.steps * 1e3,
                            wall_ms=[round(v, 2) for v in walls], rows=int(n_local))]
 
+    # RCCL writes its version banner through C stdio, which buffers when stdout is a pipe or a file: left alone it comes out
+    # at process exit - AFTER the JSON line, which must be the last line of stdout.  Every rank empties its C buffers now,
+    # and rank 0 prints only after all have.
+    flush_c_stdio()
+    if use_dist:
+        dist.barrier()
     if rank == 0:
         steps = args.steps
         step_ms = elapsed / steps * 1e3
@@ -630,6 +636,15 @@ def main():
         dist.destroy_process_group()
 
 
+def flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001
+        pass
+    sys.stdout.flush()
+
+
 def _pick(d, keys):
     return {k: d[k] for k in keys if d is not None and k in d} if d is not None else None
 
@@ -705,6 +720,7 @@ def emit(out, args):
         text = json.dumps(line)
         if len(text) < 6000:
             break
+    flush_c_stdio()
     print(text, flush=True)
 
 
