@@ -66,6 +66,7 @@ SYMBOLS = {
     "gmmvb_small_supported": (_int, [_int, _int, _i64]),
     "gmmvb_small_out_len": (_i64, [_int, _int, _int]),
     "gmmvb_small_fit": (_int, [_int, _int, _int, _vp, _i64, _i64, _vp, _vp, _int, _int, _vp, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "hmmvb_kside_dirichlet": (_int, [_int, _vp, _vp, ctypes.c_double, ctypes.c_double] + [_vp] * 18),
     "hmmvb_out_len": (_i64, [_int]),
     "hmmvb_enable": (_int, [_vp]),
     "hmmvb_forward_backward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -253,6 +254,20 @@ def kside_step(K, D, prior_v, q_v, qn_v, stats, pivot, s_prev, ns, x_bar, s, wan
                                          pivot.data_ptr(), s_prev.data_ptr(), ns.data_ptr(), x_bar.data_ptr(), s.data_ptr(),
                                          int(want_drift), gamma.data_ptr(), delta.data_ptr(), big.data_ptr(), scal.data_ptr(),
                                          scratch.data_ptr(), st), "gmmvb_kside_step")
+
+
+def hmm_kside_dirichlet(K, prior, ln_c_eta0, ln_c_zeta0, q, qn, fb, ns, scal_nw, h_scale, scal):
+    """hmmvb_kside_dirichlet on the current stream: the eta / zeta half of the HMM's K-side (contiguous float64 device tensors)."""
+    lib = load_library()
+    dev = fb.device
+    with torch.cuda.device(dev):
+        st = _vp(torch.cuda.current_stream(dev).cuda_stream)
+        _check(lib, lib.hmmvb_kside_dirichlet(
+            K, prior.eta.data_ptr(), prior.zeta.data_ptr(), ln_c_eta0, ln_c_zeta0, q.eta.data_ptr(),
+            q.zeta.data_ptr(), q.ln_pi_tilde.data_ptr(), q.ln_a_tilde.data_ptr(), q.ln_c_zeta_sum.data_ptr(), fb.data_ptr(),
+            ns.data_ptr(), scal_nw.data_ptr(), h_scale.data_ptr(), qn.eta.data_ptr(), qn.zeta.data_ptr(), qn.ln_pi_tilde.data_ptr(),
+            qn.pi_tilde.data_ptr(), qn.ln_a_tilde.data_ptr(), qn.a_tilde.data_ptr(), qn.ln_c_zeta_sum.data_ptr(), scal.data_ptr(),
+            st), "hmmvb_kside_dirichlet")
 
 
 def stats_triangle(pack: bool, K: int, D: int, src: torch.Tensor, dst: torch.Tensor):

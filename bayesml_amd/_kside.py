@@ -399,6 +399,32 @@ class HmmKStepper:
         self._graph = None
         self._calls = 0
         self._use_graph = dev.type == "cuda" and D <= 128 and os.environ.get("BAYESML_AMD_KSIDE_GRAPH", "1") != "0"
+        # The Normal-Wishart half of the step is the mixture's (ref:966-978 = _gaussianmixture.py:758-770; E[ln p(x|z)], the
+        # mu/Lambda terms of the lower bound likewise): on the GPU it runs in the library's one-launch-per-component kernel
+        # (gmmvb_kside_step, csrc/kside.hip) on views of the HMM posterior's own buffers - the mixture's Dirichlet fields are
+        # dummies whose results are ignored - and the K- and K x K-sized Dirichlet part (eta, zeta) in one launch of its own
+        # (hmmvb_kside_dirichlet): five kernels instead of ~100 torch ones, which were most of a short sequence's iteration.
+        self._fused = dev.type == "cuda" and D <= 128 and K <= 256 and os.environ.get("BAYESML_AMD_KSIDE_FUSED", "1") != "0"
+        if self._fused:
+            from types import SimpleNamespace
+            from . import _engine
+            self._eng = _engine
+            z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)   # noqa: E731
+            self._prior_alpha = torch.ones(K, dtype=torch.float64, device=dev)
+            self._prior_v = _engine.prior_view(SimpleNamespace(alpha=self._prior_alpha, m=prior.m, kappa=prior.kappa, nu=prior.nu,
+                                                               w_inv=prior.w_inv, ln_b_w_nu=prior.ln_b_w_nu, ln_c_alpha=0.0))
+
+            def mix_view(q):
+                extra = SimpleNamespace(alpha=torch.ones(K, dtype=torch.float64, device=dev), e_ln_pi=z(K), c=z(K))
+                ns_ = SimpleNamespace(alpha=extra.alpha, m=q.m, kappa=q.kappa, nu=q.nu, w_inv=q.w_inv, w=q.w, u=q.u, u_inv=q.u_inv,
+                                      e_ln_pi=extra.e_ln_pi, e_ln_lambda_det=q.e_ln_lambda_det, ln_b_w_nu=q.ln_b_w_nu, c=extra.c)
+                return ns_
+
+            self._mix = {id(self.q): mix_view(self.q), id(self.q_next): mix_view(self.q_next)}
+            self._scal_g = z(9)
+            self._ln_c0 = (float(prior.ln_c_eta), float(prior.ln_c_zeta_sum))      # (host floats once: no sync per step)
+            self._scratch = z(13 * K)
+            self._dummy = z(K)
 
     @staticmethod
     def _buffers(src):
@@ -419,7 +445,21 @@ class HmmKStepper:
         K = self.K
         return self.fb[:K * K].view(K, K), self.fb[K * K:K * K + K], self.fb[K * K + K:K * K + 2 * K], self.fb[K * K + 2 * K]
 
+    def _body_fused(self):
+        """The step with the Normal-Wishart half in gmmvb_kside_step (see __init__)."""
+        e, q, qn, p = self._eng, self.q, self.q_next, self.prior
+        mq, mqn = self._mix[id(q)], self._mix[id(qn)]
+        e.kside_step(self.K, self.D, self._prior_v, e.post_view(mq), e.post_view(mqn), self.stats, self.pivot, self.s_prev, self.ns,
+                     self.x_bar, self.s, False, self._dummy, self._dummy, self._dummy, self._scal_g, self._scratch)
+        # (the kernel has written ns, x_bar, s, s_prev and q_next's m, kappa, nu, w_inv, w, u, u_inv, E[ln det Lambda], ln B -
+        # and the mixture's c' = E[ln pi'] + the emission constant: the HMM's is the second term)
+        torch.sub(mqn.c, mqn.e_ln_pi, out=qn.c)
+        # the Dirichlet half - the lower bound's eta / zeta terms under q, eta', zeta' and their features - in one launch
+        e.hmm_kside_dirichlet(self.K, p, self._ln_c0[0], self._ln_c0[1], q, qn, self.fb, self.ns, self._scal_g, self.h_scale, self.scal)
+
     def _body(self):
+        if self._fused:
+            return self._body_fused()
         K, D = self.K, self.D
         st = self.stats
         ns = st[:K]
@@ -463,6 +503,36 @@ class HmmKStepper:
 
     def advance(self):
         self._copy(self.q, self.q_next)
+
+    def iterate(self, data_pass, whole: bool):
+        """One VB iteration: q <- q', the data pass under q (``data_pass()``: the C-ABI launches that fill ``stats`` / ``fb``),
+        the K-side.  ``whole`` (short sequences on the GPU): all of it - ~30 data-pass launches and ~100 K-sized ones - is
+        captured in ONE hipGraph on the third call and replayed afterwards; the data pass of a short sequence has no host-side
+        decision in it (no forgetting pass below 2^15 steps, no pruning with an HMM), so the captured launch sequence IS the
+        iteration.  At T = 1e4 an iteration is launch-bound: 1.1 ms with the K-side graph alone."""
+        g = getattr(self, "_it_graph", None)
+        if whole and self._use_graph and g is None:
+            self._it_calls = getattr(self, "_it_calls", 0) + 1
+            if self._it_calls >= 3:                 # (two eager iterations first: library warm-up, the K-side's own graph)
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.advance()
+                        data_pass()
+                        self._body()
+                except Exception as e:              # noqa: BLE001 - capture is an optimisation, never a requirement
+                    import warnings
+                    warnings.warn(f"bayesml_amd: whole-iteration hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                    g = False
+                    torch.cuda.synchronize()
+                self._it_graph = g
+        if g:
+            g.replay()
+            return
+        self.advance()
+        data_pass()
+        self.step()
 
     def current(self) -> HmmPostT:
         return self._buffers(self.q)

@@ -632,3 +632,167 @@ extern "C" int gmmvb_kside_step(int K, int D, const gmmvb_prior_view* prior, con
     if (e != hipSuccess) return fail(GMMVB_EHIP, "kside_finish_kernel launch", e);
     return GMMVB_OK;
 }
+
+// ---- the Dirichlet half of the HMM's K-side in one launch (round 5) ------------------------------------------------------
+// What hiddenmarkovnormal.LearnModel does with eta (initial-state) and zeta (transition rows) between two data passes
+// (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py):
+//   _calc_vl (:883-943)        the lower bound's terms that involve them, under the CURRENT posterior q: E[ln p(z)], E[ln p(pi)],
+//                              E[ln p(A)], -E[ln q(z)], -E[ln q(pi)], -E[ln q(A)] - and the total with the three Normal-Wishart
+//                              terms gmmvb_kside_step has left in scal_nw ([0] p_x, [3] p_mu_lambda, [6] q_mu_lambda)
+//   _update_q_pi, _update_q_a (:980-986)      eta' = eta_0 + ns, zeta' = zeta_0 + ms
+//   _calc_q_pi_features, _calc_q_a_features (:861-868)   ln pi~', pi~' = exp(ln pi~' - max), ln a~', a~' = exp(ln a~' - ONE global
+//                              max), ln C(zeta') summed over the rows
+// One workgroup (K^2 <= 16384 entries), every sum a fixed-order block reduction.  The torch functions of _kside.py
+// (hmm_lower_bound, hmm_update_q, hmm_features) remain the specification; tests/test_gpu_hmm.py holds this kernel to them.
+namespace {
+constexpr int kDirThreads = 1024;
+__device__ __forceinline__ double block_sum_1(double v, double* red) {
+    double a[1] = {v};
+    block_sum_n<1, kDirThreads>(a, red);
+    __syncthreads();
+    return a[0];
+}
+__device__ __forceinline__ double block_max_1(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int w = 1; w < kDirThreads / 64; ++w) t = fmax(t, red[w]);
+    __syncthreads();
+    return t;
+}
+struct HmmDirArgs {
+    const double *eta0, *zeta0;                  // prior [K], [K][K]
+    double ln_c_eta0, ln_c_zeta0;                // ln C(eta_0), sum_i ln C(zeta_0[i])
+    const double *eta, *zeta, *ln_pi, *ln_a, *ln_c_zeta;      // current q: [K], [K][K], [K], [K][K], [1]
+    const double *ms, *g0, *sum_ln_c;            // forward-backward summary: [K][K], [K], [1]
+    const double *ns;                            // [K]
+    const double *scal_nw;                       // gmmvb_kside_step's nine doubles
+    const double *h_scale;                       // [1]: 0 when the pass had no emission (random-responsibility start)
+    double *eta_n, *zeta_n, *ln_pi_n, *pi_n, *ln_a_n, *a_n, *ln_c_zeta_n;      // q'
+    double *scal;                                // [10] p_x p_z p_pi p_a p_mu_lambda q_z q_pi q_a q_mu_lambda vl
+};
+__global__ __launch_bounds__(kDirThreads) void hmm_kside_dirichlet_kernel(int K, HmmDirArgs a) {
+    __shared__ double red[kDirThreads / 64];
+    __shared__ double rowsum[256];               // K <= 256 here (the launcher checks)
+    const int tid = threadIdx.x;
+    const int KK = K * K;
+    // ---- the lower bound's Dirichlet terms under q
+    double amax = -__builtin_huge_val(), pmax = -__builtin_huge_val();
+    for (int e = tid; e < KK; e += kDirThreads) amax = fmax(amax, a.ln_a[e]);
+    for (int k = tid; k < K; k += kDirThreads) pmax = fmax(pmax, a.ln_pi[k]);
+    amax = block_max_1(amax, red);
+    pmax = block_max_1(pmax, red);
+    double s_ms_lna = 0.0, s_z0_lna = 0.0, s_ms_sh = 0.0, s_z_lna = 0.0;
+    for (int e = tid; e < KK; e += kDirThreads) {
+        const double la = a.ln_a[e], m = a.ms[e];
+        s_ms_lna = fma(m, la, s_ms_lna);
+        s_z0_lna = fma(a.zeta0[e] - 1.0, la, s_z0_lna);
+        s_ms_sh = fma(m, la - amax, s_ms_sh);
+        s_z_lna = fma(a.zeta[e] - 1.0, la, s_z_lna);
+    }
+    double s_g_lnp = 0.0, s_e0_lnp = 0.0, s_g_sh = 0.0, s_lg = 0.0, s_e_psi = 0.0, s_eta = 0.0;
+    for (int k = tid; k < K; k += kDirThreads) {
+        const double lp = a.ln_pi[k], g = a.g0[k], et = a.eta[k];
+        s_g_lnp = fma(g, lp, s_g_lnp);
+        s_e0_lnp = fma(a.eta0[k] - 1.0, lp, s_e0_lnp);
+        s_g_sh = fma(g, lp - pmax, s_g_sh);
+        s_lg += lgamma(et);
+        s_e_psi = fma(et - 1.0, digamma_pos(et), s_e_psi);
+        s_eta += et;
+    }
+    s_ms_lna = block_sum_1(s_ms_lna, red);
+    s_z0_lna = block_sum_1(s_z0_lna, red);
+    s_ms_sh = block_sum_1(s_ms_sh, red);
+    s_z_lna = block_sum_1(s_z_lna, red);
+    s_g_lnp = block_sum_1(s_g_lnp, red);
+    s_e0_lnp = block_sum_1(s_e0_lnp, red);
+    s_g_sh = block_sum_1(s_g_sh, red);
+    s_lg = block_sum_1(s_lg, red);
+    s_e_psi = block_sum_1(s_e_psi, red);
+    s_eta = block_sum_1(s_eta, red);
+    if (tid == 0) {
+        const double p_x = a.scal_nw[0], p_ml = a.scal_nw[3], q_ml = a.scal_nw[6];
+        const double sg = p_x * a.h_scale[0];        // sum gamma ln rho = E[ln p(x|z)] in closed form (ref:905 via :871-877)
+        const double p_z = s_g_lnp + s_ms_lna;
+        const double p_pi = a.ln_c_eta0 + s_e0_lnp;
+        const double p_a = a.ln_c_zeta0 + s_z0_lna;
+        const double q_z = -sg - s_ms_sh - s_g_sh + a.sum_ln_c[0];
+        const double q_pi = (s_lg - lgamma(s_eta)) + (s_eta - K) * digamma_pos(s_eta) - s_e_psi;      // entropy of Dirichlet(eta)
+        const double q_a = -a.ln_c_zeta[0] - s_z_lna;
+        a.scal[0] = p_x;
+        a.scal[1] = p_z;
+        a.scal[2] = p_pi;
+        a.scal[3] = p_a;
+        a.scal[4] = p_ml;
+        a.scal[5] = q_z;
+        a.scal[6] = q_pi;
+        a.scal[7] = q_a;
+        a.scal[8] = q_ml;
+        a.scal[9] = p_x + p_z + p_pi + p_a + p_ml + q_z + q_pi + q_a + q_ml;
+    }
+    // ---- q': eta', zeta' and their features
+    double se = 0.0;
+    for (int k = tid; k < K; k += kDirThreads) {
+        const double v = a.eta0[k] + a.ns[k];
+        a.eta_n[k] = v;
+        se += v;
+    }
+    se = block_sum_1(se, red);
+    const double psi_se = digamma_pos(se);
+    double pm = -__builtin_huge_val();
+    for (int k = tid; k < K; k += kDirThreads) {
+        const double v = digamma_pos(a.eta0[k] + a.ns[k]) - psi_se;
+        a.ln_pi_n[k] = v;
+        pm = fmax(pm, v);
+    }
+    pm = block_max_1(pm, red);
+    for (int k = tid; k < K; k += kDirThreads) a.pi_n[k] = exp(a.ln_pi_n[k] - pm);      // (the thread's own stores)
+    // row sums of zeta' in row order (a thread per row: K <= 256 rows of K <= 256 entries)
+    for (int i = tid; i < K; i += kDirThreads) {
+        double r = 0.0;
+        for (int j = 0; j < K; ++j) r += a.zeta0[i * K + j] + a.ms[i * K + j];
+        rowsum[i] = r;
+    }
+    __syncthreads();
+    double am = -__builtin_huge_val(), lgz = 0.0;
+    for (int e = tid; e < KK; e += kDirThreads) {
+        const int i = e / K;
+        const double z = a.zeta0[e] + a.ms[e];
+        a.zeta_n[e] = z;
+        const double v = digamma_pos(z) - digamma_pos(rowsum[i]);
+        a.ln_a_n[e] = v;
+        am = fmax(am, v);
+        lgz += lgamma(z);
+    }
+    am = block_max_1(am, red);
+    for (int e = tid; e < KK; e += kDirThreads) a.a_n[e] = exp(a.ln_a_n[e] - am);
+    double lgr = 0.0;
+    for (int i = tid; i < K; i += kDirThreads) lgr += lgamma(rowsum[i]);
+    lgz = block_sum_1(lgz, red);
+    lgr = block_sum_1(lgr, red);
+    if (tid == 0) a.ln_c_zeta_n[0] = lgr - lgz;
+}
+}  // namespace
+
+extern "C" int hmmvb_kside_dirichlet(int K, const double* eta0_dev, const double* zeta0_dev, double ln_c_eta0, double ln_c_zeta0,
+                                     const double* eta_dev, const double* zeta_dev, const double* ln_pi_dev, const double* ln_a_dev,
+                                     const double* ln_c_zeta_dev, const double* fb_dev, const double* ns_dev,
+                                     const double* scal_nw_dev, const double* h_scale_dev, double* eta_next_dev,
+                                     double* zeta_next_dev, double* ln_pi_next_dev, double* pi_next_dev, double* ln_a_next_dev,
+                                     double* a_next_dev, double* ln_c_zeta_next_dev, double* scal_dev, void* stream) {
+    if (K < 1 || K > 256) return fail(GMMVB_EUNSUPPORTED, "hmmvb_kside_dirichlet: 1 <= K <= 256");
+    if (!eta0_dev || !zeta0_dev || !eta_dev || !zeta_dev || !ln_pi_dev || !ln_a_dev || !ln_c_zeta_dev || !fb_dev || !ns_dev ||
+        !scal_nw_dev || !h_scale_dev || !eta_next_dev || !zeta_next_dev || !ln_pi_next_dev || !pi_next_dev || !ln_a_next_dev ||
+        !a_next_dev || !ln_c_zeta_next_dev || !scal_dev)
+        return fail(GMMVB_EINVAL, "null argument");
+    HmmDirArgs a{eta0_dev, zeta0_dev, ln_c_eta0, ln_c_zeta0, eta_dev, zeta_dev, ln_pi_dev, ln_a_dev, ln_c_zeta_dev,
+                 fb_dev, fb_dev + (size_t)K * K, fb_dev + (size_t)K * K + 2 * (size_t)K, ns_dev, scal_nw_dev, h_scale_dev,
+                 eta_next_dev, zeta_next_dev, ln_pi_next_dev, pi_next_dev, ln_a_next_dev, a_next_dev, ln_c_zeta_next_dev, scal_dev};
+    hipLaunchKernelGGL(hmm_kside_dirichlet_kernel, dim3(1), dim3(kDirThreads), 0, (hipStream_t)stream, K, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMMVB_EHIP, "hmm_kside_dirichlet_kernel launch", e);
+    return GMMVB_OK;
+}

@@ -299,6 +299,11 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         sum_g_ln_rho = _kside.sum_gamma_ln_rho(q, ns, x_bar, s)
         return dict(ns=ns, ms=ms, x_bar=x_bar, s=s, g0=g0, gl=gl, sum_g_ln_rho=sum_g_ln_rho, sum_ln_c=sum_ln_c)
 
+    def _whole_iteration_graph(self, xd) -> bool:
+        """Short sequences (no forgetting pass, chunk-parallel kernels of up to 64 states) on the real engine: the data pass
+        is a fixed launch sequence without host-side decisions and can be captured with the K-side."""
+        return bool(xd.is_cuda and self._data_pass_factory is None and xd.shape[0] <= (1 << 15) and self.c_num_classes <= 64)
+
     @staticmethod
     def _stepper_pass(eng, xd, ks):
         """_update_q_z (ref:1020-1026) under the stepper's current posterior: emission -> forward-backward -> statistics,
@@ -348,6 +353,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         # _kside.HmmKStepper); the data pass writes its statistics and the forward-backward summary into the stepper's buffers
         ks = _kside.HmmKStepper(prior, eng.pivot, eng.stats_len)
         ks.s_prev.copy_(s_prev)
+        whole_iteration = self._whole_iteration_graph(xd)
 
         def data_pass():
             self._stepper_pass(eng, xd, ks)
@@ -375,9 +381,9 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             ks.h_scale.fill_(1.0)
             for t in range(max_itr):
                 vl_before = vl
-                ks.advance()                   # q <- q'   (_update_q_mu_lambda / _update_q_pi / _update_q_a, ref:1099-1101)
-                data_pass()                    # _update_q_z (ref:1102)
-                ks.step()                      # _calc_vl (ref:1103) - and the next q'
+                # q <- q' (_update_q_mu_lambda / _update_q_pi / _update_q_a, ref:1099-1101), _update_q_z (ref:1102), _calc_vl
+                # (ref:1103) and the next q' - for short sequences all of it one replayed hipGraph (HmmKStepper.iterate)
+                ks.iterate(data_pass, whole_iteration)
                 terms = ks.read()
                 vl = terms["vl"]
                 self._say(f"\r{i}. VL: {vl} t={t} ")

@@ -321,6 +321,22 @@ int gmmvb_kside_step(int K, int D, const gmmvb_prior_view* prior, const gmmvb_po
                      double* delta_dev, double* big_gamma_dev, double* scal_dev /*[9]*/, double* scratch_dev /*[13 K]*/,
                      void* stream);
 
+/* The Dirichlet half of hiddenmarkovnormal.LearnModel's K-side in one launch (ABI v7; csrc/kside.hip).  With gmmvb_kside_step on
+ * views of the HMM posterior's Normal-Wishart buffers (the mixture's Dirichlet fields of those views are dummies) it replaces
+ * _hiddenmarkovnormal.py:883-943 (_calc_vl), :980-986 (_update_q_pi, _update_q_a) and :861-868 (their features):
+ *   scal[10] <- p_x p_z p_pi p_a p_mu_lambda q_z q_pi q_a q_mu_lambda vl under the CURRENT posterior (eta, zeta, ln pi~, ln a~,
+ *               ln C(zeta) summed over rows), the forward-backward summary fb = [ms K x K | gamma_0 K | gamma_last K | sum ln c]
+ *               (hmmvb_forward_backward's output) and scal_nw = gmmvb_kside_step's nine doubles ([0], [3], [6] are used);
+ *               h_scale[0] = 0 when the pass had no emission (_init_random_responsibility), else 1;
+ *   eta', zeta' = prior + ns / ms, ln pi~', pi~', ln a~', a~' (one global maximum), ln C(zeta') of the next posterior.
+ * Device pointers, float64; K <= 256. */
+int hmmvb_kside_dirichlet(int K, const double* eta0_dev, const double* zeta0_dev, double ln_c_eta0, double ln_c_zeta0,
+                          const double* eta_dev, const double* zeta_dev, const double* ln_pi_dev, const double* ln_a_dev,
+                          const double* ln_c_zeta_dev, const double* fb_dev, const double* ns_dev, const double* scal_nw_dev,
+                          const double* h_scale_dev, double* eta_next_dev, double* zeta_next_dev, double* ln_pi_next_dev,
+                          double* pi_next_dev, double* ln_a_next_dev, double* a_next_dev, double* ln_c_zeta_next_dev,
+                          double* scal_dev, void* stream);
+
 /* Which kernels have run in this workspace since it was created (for tests and profiling reports):
  *   out[0] dense E-steps, out[1] bound passes of the pruned E-step, out[2] E-steps on carried records, out[3] E-steps
  *   sent back to the dense kernel after a bound pass that pruned nothing, out[4] E-steps on a sweep of carried bounds

@@ -503,3 +503,55 @@ def test_viterbi_chunk_starts_by_coalescence(K, D, flat, monkeypatch):
     (z0, how0), (z1, how1) = out
     assert how0 == -1 and how1 == (1 if flat else 0), (how0, how1)
     assert torch.equal(z0, z1)
+
+
+@pytest.mark.parametrize("K,D", [(32, 16), (5, 3), (64, 7), (40, 33)])
+def test_fused_k_side_against_the_torch_specification(K, D, monkeypatch):
+    """HmmKStepper on the GPU - gmmvb_kside_step on views of the HMM posterior for the Normal-Wishart half,
+    hmmvb_kside_dirichlet for eta / zeta - against the torch functions of _kside.py (BAYESML_AMD_KSIDE_FUSED=0): the ten terms
+    of the lower bound and every field of the next posterior, over chained steps (an empty state among them)."""
+    from bayesml_amd import _kside
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(K * 100 + D)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)   # noqa: E731
+    g = rng.normal(size=(K, D, D)) * 0.3 + np.eye(D)
+    prior = _kside.hmm_prior_from_numpy(rng.uniform(0.3, 2.0, K), rng.uniform(0.3, 2.0, (K, K)), rng.normal(size=(K, D)),
+                                        rng.uniform(0.5, 2.0, K), rng.uniform(D, D + 4.0, K),
+                                        np.linalg.inv(g @ g.transpose(0, 2, 1)), dev)
+    pivot = t(rng.normal(size=D))
+    stats_len = K * (2 + D + D * D)
+    steppers = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("BAYESML_AMD_KSIDE_FUSED", fused)
+        steppers.append(_kside.HmmKStepper(prior, pivot, stats_len))
+    assert steppers[0]._fused and not steppers[1]._fused
+    for it in range(4):
+        # consistent statistics: weighted moments of real points about the pivot (S = B / ns - (a / ns)(a / ns)^T must be PSD)
+        pts = rng.normal(size=(6 * D + 40, D)) * 2.0 + rng.normal(size=D)
+        r = rng.uniform(0.0, 1.0, (pts.shape[0], K)) * (rng.uniform(size=(pts.shape[0], K)) < 0.4)
+        if it == 1:
+            r[:, K // 2] = 0.0                        # an empty state: the ns > 0 guard and the stale S
+        xc = pts - pivot.cpu().numpy()
+        ns = r.sum(axis=0)
+        a = r.T @ xc
+        B = np.einsum("nk,ni,nj->kij", r, xc, xc)
+        stats = np.concatenate([ns, np.zeros(K), a.reshape(-1), B.reshape(-1)])
+        ms = rng.uniform(0.0, 5.0, (K, K))
+        fb = np.concatenate([ms.reshape(-1), rng.dirichlet(np.ones(K)), rng.dirichlet(np.ones(K)), [rng.normal() * 100.0]])
+        for ks in steppers:
+            ks.stats.copy_(t(stats))
+            ks.fb.copy_(t(fb))
+            ks.h_scale.fill_(0.0 if it == 2 else 1.0)
+            ks.step()
+        u, v = steppers
+        su, sv = u.scal.cpu().numpy(), v.scal.cpu().numpy()
+        # (p_x and q_z cancel in vl - sum gamma ln rho IS E[ln p(x|z)] in closed form -: rounding is relative to the largest term)
+        assert np.max(np.abs(su - sv)) <= 1e-12 * np.max(np.abs(sv)), (it, su, sv)
+        for f in _kside._HMM_POST_FIELDS:
+            x, y = getattr(u.q_next, f), getattr(v.q_next, f)
+            assert float((x - y).abs().max()) <= 1e-10 * max(1.0, float(y.abs().max())), (it, f)
+        for name in ("ns", "x_bar", "s"):
+            x, y = getattr(u, name), getattr(v, name)
+            assert float((x - y).abs().max()) <= 1e-11 * max(1.0, float(y.abs().max())), (it, name)
+        for ks in steppers:
+            ks.advance()

@@ -108,10 +108,10 @@ def measure(args, dev=None):
     ks.step()
     ks.read()
 
+    whole = m._whole_iteration_graph(xd)
+
     def step():
-        ks.advance()
-        m._stepper_pass(eng, xd, ks)
-        ks.step()
+        ks.iterate(lambda: m._stepper_pass(eng, xd, ks), whole)
         return ks.read()["vl"]
 
     for _ in range(args.warmup):
