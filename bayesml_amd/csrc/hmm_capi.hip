@@ -56,6 +56,8 @@ struct gmmvb_hmm_state {
     bool gate_pending = false, spec_on = true;
     bool vit_coalesced = false;   // the last hmmvb_viterbi call ran the coalescence pass (its gate: gate_dev[1])
     int64_t sweep_len = 64;       // steps next to a chunk boundary the forgetting pass's first stage walks (run<KT>; 32 failed one pass in seven at config 5, 64 none)
+    int64_t chunk_floor = 0;      // run<KT>: a pass that did not stand on chunks shorter than kHmmLongChunk doubles them for the next ones
+    int64_t gate_l = 0;           // chunk length of the pass whose gates are pending
     int short_hold = 0, short_hold_len = 4;      // calls that skip the short first stage after it did not stand (4, 8 ... 64 while it keeps failing)
     bool gate_two_stage = false;  // the pass whose gates are pending had a short first stage
     int spec_hold = 0, spec_hold_len = 8, last_gate = -1;   // last_gate: -1 no forgetting pass, 0 it stood, 1 products path behind it
@@ -141,6 +143,8 @@ constexpr int64_t kHmmGenericChunk = 256;      // more than 128 states: steps pe
 // (round 4: from 2^15 steps instead of 2^18 - with the forgetting pass the long-sequence form costs two sweeps instead of the chunk
 // products, and its short chunks shorten the replays' chains of dependent steps: T = 2e5 4.1 ms per iteration against 1.5)
 constexpr int64_t kHmmLongFrom = int64_t(1) << 15;
+constexpr int64_t kHmmShortForgetFrom = 4096;      // from here to kHmmLongFrom: the forgetting pass on chunks of kHmmShortChunk steps
+constexpr int64_t kHmmShortChunk = 32;
 int64_t chunk_len(int64_t T, bool one_level) {
     if (T > kHmmLongFrom && !one_level) return kHmmLongChunk;
     int64_t L = 16;
@@ -167,12 +171,17 @@ bool consume_gate(gmmvb_hmm_state* h, bool wait) {
             h->short_hold_len = 4;
         }
     }
-    if (h->last_gate != 0) {
+    if (h->last_gate != 0 && h->gate_l > 0 && h->gate_l < kHmmLongChunk) {
+        // the chunks were shorter than the recursions' memory: longer ones at once (no hold-off - that is for sequences
+        // whose 256-step chunks do not stand either)
+        h->chunk_floor = 2 * h->gate_l;
+    } else if (h->last_gate != 0) {
         h->spec_hold = h->spec_hold_len;
         h->spec_hold_len = std::min(64, 2 * h->spec_hold_len);
     } else {
         h->spec_hold_len = 8;
     }
+    h->gate_l = 0;
     return true;
 }
 
@@ -184,9 +193,22 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     // long sequences whose 256-step chunks are few (64 to a replay workgroup, and the replays / sweeps are chains of dependent
     // steps whose length is the chunk's): chunks of 128 steps - twice the waves, half the chain
     const bool long_seq = T > kHmmLongFrom && L == kHmmLongChunk;
+    // Short sequences (round 5): the one-level products path balances a sequential pass over T / L chunk products against
+    // replay chains of L steps (T = 1e4: L = 64, 157 products one after the other - 0.25 ms - and two 64-step chains); with the
+    // chunk start vectors from the forgetting pass the chunks can be short - 32 steps: a 32-step sweep and two 32-step replay
+    // chains - and the products only run behind the gate.  While a failed gate holds the pass off, the formula's chunks.
+    consume_gate(h, /*wait=*/false);
+    const bool want_spec = h->spec_on && h->gate_dev != nullptr;
+    const bool held = want_spec && h->spec_hold > 0;
+    const bool short_spec = !long_seq && T >= kHmmShortForgetFrom && want_spec && !held;
+    if (short_spec) L = std::min<int64_t>(kHmmLongChunk, std::max<int64_t>(kHmmShortChunk, h->chunk_floor));
     // (config 5 shape on one box: T = 4e5 2.64 -> 2.12 ms per iteration, 1e6 3.21 -> 2.61, 3e6 4.85 -> 4.56; at 8e6 the shorter
     // chunks lose, 9.79 -> 10.16: the limit is a replay workgroup per CU)
-    if (long_seq && (T - 1 + L - 1) / L < 64 * (int64_t)ws->num_cu) L /= 2;
+    // (round 5: down to 32 steps - with the products behind the gates a chunk only has to be long enough for the recursions to
+    // forget their start, and the replays are chains of dependent steps: T = 1e5 ran 128-step chains on 13 workgroups)
+    // ... and up again, for good, when a pass on short chunks did not stand (chunk_floor; consume_gate)
+    if (long_seq)
+        while (L > kHmmShortChunk && L > h->chunk_floor && (T - 1 + L - 1) / L < 64 * (int64_t)ws->num_cu) L /= 2;
     const int64_t n_chunks = T > 1 ? (T - 1 + L - 1) / L : 0;
     if (ws->e_state != 4)          // (4: the emission kernel has written rho' and mx itself)
         hipLaunchKernelGGL(hmm_prep_kernel, dim3((unsigned)((T + kPrepSteps - 1) / kPrepSteps)), dim3(256),
@@ -220,9 +242,9 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
     // two more passes of K^2 per step.  A call that needed the products holds the pass off for the next eight calls (the
     // gate is copied to pinned memory and looked at when the next call begins: no synchronisation).
     const int* gate = nullptr;
-    consume_gate(h, /*wait=*/false);
-    bool spec = two_level && h->spec_on && h->gate_dev != nullptr;      // (a gate copy still in flight - a caller that does not synchronise between calls - only means the last outcome is not known yet)
-    if (spec && h->spec_hold > 0) {
+    // (a gate copy still in flight - a caller that does not synchronise between calls - only means the last outcome is not known yet)
+    bool spec = (two_level || short_spec) && want_spec;
+    if (held && (two_level || (!long_seq && T >= kHmmShortForgetFrom))) {
         --h->spec_hold;
         spec = false;
     }
@@ -242,6 +264,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
             W = L;
         }
         h->gate_two_stage = W < L;
+        h->gate_l = L;
         const int* stage_gate = nullptr;
         if (W < L) {
             hipLaunchKernelGGL((hmm_sweeps_kernel<KT>), dim3(grid, 2), dim3(256), 0, st, h->rho_tm, a_tilde, K, T, L, n_chunks,
@@ -279,7 +302,7 @@ hipError_t run(gmmvb_workspace* ws, gmmvb_hmm_state* h, int64_t T, const double*
                            h->fstart_s, h->bend_s, h->fstart, h->bend, gate);
     } else {
         hipLaunchKernelGGL((hmm_boundary_scan_kernel<KT>), dim3(1), dim3(128), 0, st, h->rho_tm, pi_tilde, h->prod, K,
-                           n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm);
+                           n_chunks, h->fstart, h->bend, h->cprime, h->alpha_tm, h->gamma_tm, h->w_tm, gate);
     }
     if (n_chunks > 0) replays(h->fstart, h->bend, nullptr, nullptr, gate);
     h->w_valid = !xi_fused;

@@ -300,9 +300,10 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         return dict(ns=ns, ms=ms, x_bar=x_bar, s=s, g0=g0, gl=gl, sum_g_ln_rho=sum_g_ln_rho, sum_ln_c=sum_ln_c)
 
     def _whole_iteration_graph(self, xd) -> bool:
-        """Short sequences (no forgetting pass, chunk-parallel kernels of up to 64 states) on the real engine: the data pass
-        is a fixed launch sequence without host-side decisions and can be captured with the K-side."""
-        return bool(xd.is_cuda and self._data_pass_factory is None and xd.shape[0] <= (1 << 15) and self.c_num_classes <= 64)
+        """The shortest sequences (below 4096 steps there is no forgetting pass - no gate, no pinned copy, no host-side hold-off -;
+        chunk-parallel kernels of up to 64 states) on the real engine: the data pass is a fixed launch sequence without
+        host-side decisions and can be captured with the K-side."""
+        return bool(xd.is_cuda and self._data_pass_factory is None and xd.shape[0] < 4096 and self.c_num_classes <= 64)
 
     @staticmethod
     def _stepper_pass(eng, xd, ks):

@@ -345,11 +345,16 @@ def test_boundary_vectors_by_forgetting(K, D, flat, monkeypatch):
         return out, how
 
     ref, how0 = run(False)
-    got, how1 = run(True, calls=3)
+    got, how1 = run(True, calls=4)
     assert how0 == [-1]
-    # (up to 64 states the forgetting pass has two stages - sweeps over the 32 steps next to every boundary, then, behind a
-    # gate of its own, over whole chunks; "stood" = either of them; flat emissions fail both and the products run)
-    assert how1 == ([1, -1, -1] if flat else [0, 0, 0]), how1
+    # Up to 64 states the chunks start at 32 steps (a sequence of this length leaves the CUs idle on longer ones) and double
+    # after a pass that did not stand, up to 256, where the hold-off begins; from 128 steps on the pass has two stages (sweeps
+    # over the 64 steps next to every boundary, then whole chunks behind a gate of its own).  "Stood" = any of that.
+    if K <= 64:
+        assert all(v in (0, 1) for v in how1) and how1[0] == (1 if flat else how1[0]), how1
+        assert (how1[-1] == 1) if flat else (how1[-1] == 0), how1
+    else:
+        assert how1 == ([1, -1, -1, -1] if flat else [0, 0, 0, 0]), how1
     for k in ("ms", "g0", "gl", "gamma", "alpha", "stats"):
         scale_k = max(1.0, float(ref[k].abs().max()))
         assert float((ref[k] - got[k]).abs().max()) <= 1e-10 * scale_k, k
