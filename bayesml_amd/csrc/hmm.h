@@ -83,31 +83,19 @@ __global__ __launch_bounds__(256) void hmm_prep_kernel(const double* __restrict_
 // LDS: 17 KB per wave = nine waves per CU, 4.7 ms against 2.4 + 1.0 for the two kernels it replaced.)
 // No ln rho array is formed: what reads it (hmmvb_viterbi, the ln rho read-out) needs a pass with the other target
 // (hmmvb_emission_target).
-// LDSIMG (round 5, experiment): persistent workgroups of eight waves keep the K component images (272 doubles each) in LDS,
-// filled once, instead of fetching 4 KB per component and wave through L1.
-constexpr int kEmImg = 272;      // doubles of a one-tile component image that load_component16 reads
-template <typename XT, bool VEC, int KT, bool LDSIMG = false>
-__global__ __launch_bounds__(LDSIMG ? 512 : 256, 2) void hmm_emission_mfma16_kernel(const XT* __restrict__ x, int64_t ldx, int64_t T, int D,
+template <typename XT, bool VEC, int KT>
+__global__ __launch_bounds__(256, 2) void hmm_emission_mfma16_kernel(const XT* __restrict__ x, int64_t ldx, int64_t T, int D,
                                                                   const double* __restrict__ img /*[K][img_doubles(1)]*/,
                                                                   const double* __restrict__ cvec, int K,
                                                                   double* __restrict__ rho_tm, double* __restrict__ mx) {
     constexpr int NB = KT == 1 ? 4 : 2, Kp = 16 * KT, IMG = img_doubles(1);      // (row tiles per wave: what the registers hold)
-    constexpr int NWV = LDSIMG ? 8 : 4;
-    __shared__ __attribute__((aligned(16))) double simg[LDSIMG ? Kp * kEmImg : 2];
-    if constexpr (LDSIMG) {
-        for (int e = threadIdx.x; e < Kp * kEmImg; e += 512) {
-            const int k = e / kEmImg;
-            simg[e] = img[(int64_t)(k < K ? k : 0) * IMG + (e - k * kEmImg)];
-        }
-        __syncthreads();
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int64_t n_tiles = (T + 16 * NB - 1) / (16 * NB);
     double cl[4 * KT];                                   // c of the components this lane keeps: 4 kq + g
 #pragma unroll
     for (int kq = 0; kq < 4 * KT; ++kq) cl[kq] = cvec[4 * kq + g < K ? 4 * kq + g : 0];
-    for (int64_t tile = (int64_t)blockIdx.x * NWV + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NWV) {
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         int64_t ld[NB], stv[NB];
         tile_rows<NB>(tile * 16 * NB, n, T, ld, stv);
         XT xr[NB][1][4];
@@ -122,15 +110,9 @@ __global__ __launch_bounds__(LDSIMG ? 512 : 256, 2) void hmm_emission_mfma16_ker
         // components one butterfly over the lane groups leaves component 4 kq + g's total in group g - where it is kept.
         // States past K (padding) run on component 0's operands and are discarded.
         auto fetch = [&](int kk) {
-            if constexpr (LDSIMG) {
-                int off = kk * kEmImg;
-                asm volatile("" : "+v"(off));
-                return load_component16(simg + off, lane, g);
-            } else {
-                int off = (kk < K ? kk : 0) * IMG;
-                asm volatile("" : "+s"(off));
-                return load_component16(img + off, lane, g);
-            }
+            int off = (kk < K ? kk : 0) * IMG;
+            asm volatile("" : "+s"(off));
+            return load_component16(img + off, lane, g);
         };
         Comp16 nxt = fetch(0);
         double part[4][NB];

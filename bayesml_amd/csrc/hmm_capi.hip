@@ -56,7 +56,6 @@ struct gmmvb_hmm_state {
     bool gate_pending = false, spec_on = true;
     bool vit_coalesced = false;   // the last hmmvb_viterbi call ran the coalescence pass (its gate: gate_dev[1])
     int64_t sweep_len = 64;       // steps next to a chunk boundary the forgetting pass's first stage walks (run<KT>; 32 failed one pass in seven at config 5, 64 none)
-    int em_num_cu = 256;          // CUs of the device (hmmvb_enable), for the persistent emission grid
     int64_t chunk_floor = 0;      // run<KT>: a pass that did not stand on chunks shorter than kHmmLongChunk doubles them for the next ones
     int64_t gate_l = 0;           // chunk length of the pass whose gates are pending
     int short_hold = 0, short_hold_len = 4;      // calls that skip the short first stage after it did not stand (4, 8 ... 64 while it keeps failing)
@@ -93,16 +92,9 @@ hipError_t hmm_launch_emission16(gmmvb_hmm_state* h, int x_is_f64, bool vec, hip
     const int64_t rows_per_wg = 4 * 16 * (h->KT == 1 ? 4 : 2);       // (hmm.h: NB row tiles per wave)
     const int64_t wgs = (a.n_rows + rows_per_wg - 1) / rows_per_wg;
     const unsigned grid = (unsigned)std::min<int64_t>(wgs, int64_t(1) << 20);
-    // developer switch GMMVB_HMM_EMISSION_LDS=1: the component images in LDS, persistent workgroups (hmm.h)
-    static const bool lds_img = std::getenv("GMMVB_HMM_EMISSION_LDS") && std::getenv("GMMVB_HMM_EMISSION_LDS")[0] == '1';
-    const unsigned pgrid = (unsigned)std::min<int64_t>((wgs + 1) / 2, 2 * (int64_t)h->em_num_cu);
 #define EM(XT, V, KTT)                                                                                                      \
-    if (lds_img)                                                                                                            \
-        hipLaunchKernelGGL((hmm_emission_mfma16_kernel<XT, V, KTT, true>), dim3(pgrid), dim3(512), 0, st, static_cast<const XT*>(a.x), \
-                           a.ldx, a.n_rows, a.D, a.img, a.cvec, a.K, h->rho_tm, h->mx);                                       \
-    else                                                                                                                    \
-        hipLaunchKernelGGL((hmm_emission_mfma16_kernel<XT, V, KTT>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx, \
-                           a.n_rows, a.D, a.img, a.cvec, a.K, h->rho_tm, h->mx)
+    hipLaunchKernelGGL((hmm_emission_mfma16_kernel<XT, V, KTT>), dim3(grid), dim3(256), 0, st, static_cast<const XT*>(a.x), a.ldx, \
+                       a.n_rows, a.D, a.img, a.cvec, a.K, h->rho_tm, h->mx)
 #define EMK(XT, V)                                    \
     switch (h->KT) {                                  \
         case 1: EM(XT, V, 1); break;                  \
@@ -516,7 +508,6 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     h->KT = (ws->K + 15) / 16;
     h->Kp = 16 * h->KT;
     h->npad = ws->npad;
-    h->em_num_cu = ws->num_cu;
     h->generic = ws->K > 64;                    // (the chunk-parallel kernels hold K x K products in registers)
     h->wide = ws->K > 64 && ws->K <= 128 && std::getenv("GMMVB_HMM_WIDE_OFF") == nullptr;      // hmm_wide.h (developer switch: off)
     // (65 .. 128 states: chunks of 256 steps, or of 128 while those do not fill the CUs - run_wide)
