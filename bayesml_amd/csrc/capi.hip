@@ -62,16 +62,26 @@ static int take_hip(gmmvb_workspace* ws, const char* what) {
     ws->hip_err = hipSuccess;
     return fail(GMMVB_EHIP, what, e);
 }
+// An event record costs the stream about 10 us (the queue drains around the marker packet): at the benchmark shape a converged
+// step has ~36 of them, 0.17 ms of a 3.7 ms step.  Profile level 2 keeps only the spans of the three groups that can dominate a
+// step (the two E-step evaluation groups and the M-step's accumulation) and drops the phase events.
+static bool span_kept(const gmmvb_workspace* ws, int slot) {
+    return !ws->prof_light || slot == kSpanEstepMain || slot == kSpanGather || slot == kSpanMstepMain;
+}
 static void span_begin(gmmvb_workspace* ws, int slot, hipStream_t st) {
-    if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans) return;
+    ws->span_open = false;
+    if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans || !span_kept(ws, slot)) return;
     ws->span_slot[ws->n_spans] = slot;
+    ws->span_open = true;
     note_hip(ws, hipEventRecord(ws->span_ev[2 * ws->n_spans], st));
 }
 static void span_end(gmmvb_workspace* ws, hipStream_t st) {
-    if (!ws->prof || ws->n_spans >= gmmvb_workspace::kMaxSpans) return;
+    if (!ws->span_open) return;
+    ws->span_open = false;
     note_hip(ws, hipEventRecord(ws->span_ev[2 * ws->n_spans + 1], st));
     ++ws->n_spans;
 }
+static bool phase_events(const gmmvb_workspace* ws) { return ws->prof && !ws->prof_light; }
 
 // ---- the scratch of a tile group (workspace.h: gmmvb_scratch) -----------------------------------------------------------
 // `w` loses the buffers to another workspace of its group: its E-step output, lists and centred copy are gone.  What it
@@ -413,6 +423,9 @@ int gmmvb_profile_enable(gmmvb_workspace* ws, int on) {
         }
     }
     ws->prof = on != 0;
+    ws->prof_light = on == 2;
+    ws->span_open = false;
+    ws->ev_e = ws->ev_m = false;
     ws->n_spans = 0;
     return GMMVB_OK;
 }
@@ -1124,7 +1137,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int R = generic_rows(ws->D);
         const dim3 grid((unsigned)((n_rows + R - 1) / R), (unsigned)ws->K);
         const size_t lds = (size_t)ws->D * R * sizeof(double);
-        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[0], st));
+        if (phase_events(ws)) note_hip(ws, hipEventRecord(ws->ev[0], st));
         ws->n_spans = 0;
         span_begin(ws, kSpanEstepMain, st);
         if (is64)
@@ -1134,7 +1147,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             hipLaunchKernelGGL(estep_generic_kernel<float>, grid, dim3(64), lds, st, (const float*)x_dev, ldx, n_rows, ws->D,
                                ws->gen_u, ws->gen_m, ws->cvec, R, ws->lnrho, ws->npad);
         span_end(ws, st);
-        if (ws->prof) {
+        if (phase_events(ws)) {
             note_hip(ws, hipEventRecord(ws->ev[1], st));
             ws->ev_e = true;
         }
@@ -1350,7 +1363,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
 
     int rpw = 0;
     int64_t grid = 0;
-    if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[0], st));
+    if (phase_events(ws)) note_hip(ws, hipEventRecord(ws->ev[0], st));
     ws->n_spans = 0;
     // a bound pass rebuilds everything row-indexed anyway: the moment to regroup the internal row order by the best
     // component of the previous pass (once at most 4 components per row are active: later passes are list-driven)
@@ -1603,7 +1616,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->pend_lazy = tmeta_kept;
     // the E phase of the profile ends behind the pass's LAST kernel (round 4; before, rec_finish / lse_mask - 0.2-0.4 ms of
     // E-step work at the benchmark shape - fell between the two phases and were booked as "outside the data pass")
-    if (ws->prof) {
+    if (phase_events(ws)) {
         note_hip(ws, hipEventRecord(ws->ev[1], st));
         ws->ev_e = true;
     }
@@ -1702,7 +1715,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         const int64_t rps = round_up((n_rows + S - 1) / S, 64);
         S = (int)((n_rows + rps - 1) / rps);
         const int tiles = tri_pairs(ws->T);
-        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[2], st));
+        if (phase_events(ws)) note_hip(ws, hipEventRecord(ws->ev[2], st));
         span_begin(ws, kSpanMstepMain, st);
         if (ws->x_dtype == GMMVB_F64) {
             hipLaunchKernelGGL(mstep_generic_first_kernel<double>, dim3(ws->K, S), dim3(256), 0, st, (const double*)x_dev, ldx, n_rows,
@@ -1716,7 +1729,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                n_rows, ws->D, ws->pivot, lr, ws->lse, aux, ws->npad, ws->K, rps, direct, ws->T, ws->gen_second);
         }
         span_end(ws, st);
-        if (ws->prof) {
+        if (phase_events(ws)) {
             note_hip(ws, hipEventRecord(ws->ev[3], st));
             ws->ev_m = true;
         }
@@ -1790,7 +1803,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         rc = ensure_lists(ws);
         if (rc) return rc;
         const int nblk = (int)((n_rows + kSelRows - 1) / kSelRows);
-        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[2], st));      // the list building is part of the M-step's time
+        if (phase_events(ws)) note_hip(ws, hipEventRecord(ws->ev[2], st));      // the list building is part of the M-step's time
         const int cap_chunks0 = (int)std::min<int64_t>((int64_t)ws->S_cap * ws->K, 1 << 30);
 #ifndef GMMVB_MLIST_RMIN
 #define GMMVB_MLIST_RMIN 1024
@@ -1887,7 +1900,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         ++ws->passes[6];
     } else {
         ++ws->passes[5];
-        if (ws->prof) note_hip(ws, hipEventRecord(ws->ev[2], st));
+        if (phase_events(ws)) note_hip(ws, hipEventRecord(ws->ev[2], st));
         if (pre && ws->xc_stale) {             // the dense kernel reads the centred copy: bring it to the internal row order
             e = recenter_rows(ws, n_rows, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "center_rows launch", e);
@@ -1910,7 +1923,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         span_end(ws, st);
     }
     if (e != hipSuccess) return fail(GMMVB_EHIP, "mstep launch", e);
-    if (ws->prof) {
+    if (phase_events(ws)) {
         note_hip(ws, hipEventRecord(ws->ev[3], st));
         ws->ev_m = true;
     }

@@ -220,6 +220,8 @@ struct gmmvb_workspace {
     // candidate gathers
     int64_t passes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool prof = false;
+    bool prof_light = false;           // gmmvb_profile_enable(ws, 2): only the spans of the groups that can dominate a step
+    bool span_open = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // E begin/end, M begin/end
     bool ev_e = false, ev_m = false;
     // per-kernel-group spans of the last E-step + M-step (gmmvb_profile_spans): slot, begin/end event

@@ -94,6 +94,10 @@ def parse_args():
     ap.add_argument("--detail", default=os.path.join("gpurun_out", "bench_detail.json"),
                     help="file that receives the full record (every leg, per-step lists, kernel groups); stdout carries "
                          "only the compact line.  '' = do not write it, '-' = print it on stdout BEFORE the compact line")
+    ap.add_argument("--spans", choices=("dominant", "full"), default="dominant",
+                    help="HIP-event spans recorded inside the timed steps: 'dominant' = only the kernel groups that can dominate "
+                         "a step (estep_main, estep_gather, mstep_main: what the roofline block needs); 'full' = every group and "
+                         "the E/M phase events (~36 records a step, ~10 us of stream time each)")
     ap.add_argument("--dense", action="store_true", help="no pruning, no sparse M-step: every pair in f64")
     ap.add_argument("--force-dist", action="store_true",
                     help="join an RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
@@ -268,13 +272,15 @@ def cpu_baseline_and_parity(K, D, x_ref, dev, iters=10):
 class Workload:
     """One model + sample matrix driven through the same internals update_posterior uses."""
 
-    def __init__(self, K, D, x, dev, comm):
+    def __init__(self, K, D, x, dev, comm, spans="full"):
         from bayesml_amd import _kside
         from bayesml_amd import gaussianmixture as gm
         self.K, self.D, self.n = K, D, x.shape[0]
         self.m = gm.LearnModel(K, D, seed=0, device=dev, comm=comm, verbose=False)
         self.eng, self.xd = self.m._open(x)
-        self.eng.profile(True)
+        # HIP events in the library (include/gmmvb.h: gmmvb_profile_enable): every record costs the stream ~10 us, so the
+        # timed steps of the headline keep only the spans of the groups that can dominate ("dominant", level 2)
+        self.eng.profile(2 if spans == "dominant" else 1)
         prior = self.m._prior_tensors(dev)
         self.ks = self.m._stepper(self.eng, prior, self.xd)
         q = self.m._init_subsampling(self.eng, self.xd, _kside.post_from_prior(prior), self.m._comm.global_rows)
@@ -302,7 +308,7 @@ class Workload:
     def snapshot(self):
         a, e = self.eng.sparsity()
         em, mm = self.eng.last_kernel_ms()
-        return dict(estep_ms=round(em, 2), mstep_ms=round(mm, 2),
+        return dict(estep_ms=round(em, 2) if em >= 0 else None, mstep_ms=round(mm, 2) if mm >= 0 else None,
                     kernels=[p.strip().split(" ")[0] for p in self.eng.launch_info.split("|")],
                     active_components_per_sample=round(a / self.n, 2) if a >= 0 else None,
                     evaluated_components_per_sample=round(e / self.n, 2),
@@ -391,7 +397,7 @@ def main():
         cpu_base, parity, parity_sparse = cpu_baseline_and_parity(K, D, x_ref, dev)
     do_cpu = rank == 0 and world == 1 and not args.no_cpu
 
-    w = Workload(K, D, x, dev, comm)
+    w = Workload(K, D, x, dev, comm, spans=args.spans)
     eng = w.eng
     torch.cuda.synchronize()
     warm = [dict(w.snapshot(), what="pass after the subsampling initialisation")]
@@ -457,8 +463,9 @@ def main():
     if rank == 0:
         steps = args.steps
         step_ms = elapsed / steps * 1e3
-        e_ms = float(np.mean([k[0] for k in ker]))
-        m_ms = float(np.mean([k[1] for k in ker]))
+        # (phase events only with --spans full)
+        e_ms = float(np.mean([k[0] for k in ker])) if all(k[0] >= 0 for k in ker) else None
+        m_ms = float(np.mean([k[1] for k in ker])) if all(k[1] >= 0 for k in ker) else None
         names = [kernel_name(p) for p in eng.launch_info.split("|")]      # kernels of the last step
         tiles = (D + 15) // 16
         fl_pair = 512 * tiles * (tiles + 1) // 2        # executed f64 MFMA flops per exactly evaluated (sample, component)
@@ -552,6 +559,7 @@ def main():
                                      "accumulated_by_mstep": acc / n_local, "settled_rows": settled / n_local,
                                      "early_exits": exits / n_local,
                                      "proof_round_int8": float(np.mean([wk.get("proof_pairs", 0.0) for wk in works])) / n_local},
+                "spans": args.spans,
                 "kernel_groups": groups,
                 "events_ms_per_step": sum(g["ms"] for g in groups.values()),
                 "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
@@ -619,7 +627,8 @@ def main():
             "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,
             "launch": last_launch, "warmup_steps": warm,
             "per_step": {"wall_ms": [round(v, 2) for v in walls],
-                         "estep_ms": [round(k[0], 2) for k in ker], "mstep_ms": [round(k[1], 2) for k in ker],
+                         "estep_ms": [round(k[0], 2) if k[0] >= 0 else None for k in ker],
+                         "mstep_ms": [round(k[1], 2) if k[1] >= 0 else None for k in ker],
                          "estep_kernel": [kernel_name(l) for l in launches],
                          "active_components_per_sample": [round(a / n_local, 2) if a >= 0 else None for a, _ in spars],
                          "evaluated_components_per_sample": [round(e / n_local, 2) for _, e in spars],
@@ -654,7 +663,7 @@ def compact_line(out):
     scalars that say what was measured.  Everything else (per-step lists, kernel groups, legs in full) is in the
     detail record (--detail)."""
     r = out["roofline"]
-    roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "f64_mfma_frac",
+    roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "f64_mfma_frac", "spans",
                      "step_hbm_frac", "f64_mfma_ceiling_samples_per_s", "hbm_roofline_samples_per_s",
                      "events_ms_per_step", "outside_events_ms_per_step"))
     roof["pairs_per_sample"] = {k: round(v, 4) for k, v in r["pairs_per_sample"].items()}

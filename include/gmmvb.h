@@ -265,7 +265,9 @@ int hmmvb_debug_readout(gmmvb_workspace* ws, int what, int64_t row0, int64_t n_r
  * E-step phase (first to last kernel of gmmvb_estep: the dense kernel estep_lds_f64 and the log-normaliser pass, or bound
  * pass / sweep + selections + proof round + gathers + rec_finish; v4: up to v3 the phase ended before the log-normaliser /
  * rec_finish kernels) and the M-step phase (list building + mstep_mfma_f64 / mstep_list_f64) of the
- * last passes (bench.py's roofline leg); it waits for those events. */
+ * last passes (bench.py's roofline leg); it waits for those events.  on = 2 ("dominant groups only"): an event record
+ * costs the stream ~10 us, a converged step at the benchmark shape has ~36 of them; level 2 records only the spans
+ * estep_main, estep_gather and mstep_main (gmmvb_profile_spans) and no phase events (gmmvb_profile_last_ms gives -1). */
 int gmmvb_profile_enable(gmmvb_workspace* ws, int on);
 int gmmvb_profile_last_ms(gmmvb_workspace* ws, float* estep_ms, float* mstep_ms);
 

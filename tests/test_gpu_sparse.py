@@ -300,3 +300,40 @@ def test_sparse_path_ill_conditioned_components():
     for (sa, ra, _), (sb, rb, _) in zip(dense, sparse):
         assert rel_err(sb, sa) < 1e-11
         assert np.max(np.abs(ra - rb)) < 1e-11
+
+
+def test_profile_levels_record_the_same_results():
+    """gmmvb_profile_enable: level 1 records a span per kernel group and the E/M phase events, level 2 only the groups that
+    can dominate a step (and no phase events); neither changes a bit of what the pass returns."""
+    from bayesml_amd._engine import DataPass
+    K, D, N = 32, 96, 32_000
+    x = orc.synth_gmm(K, D, N, np.float32)
+    m = _fit(x, K, 6, DENSE)
+    dev = torch.device("cuda", 0)
+    from bayesml_amd import _kside
+    hn = m.get_hn_params()
+    t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+    q = _kside.features(_kside.PostT(t(hn["hn_alpha_vec"]), t(hn["hn_m_vecs"]), t(hn["hn_kappas"]), t(hn["hn_nus"]),
+                                     t(np.linalg.inv(hn["hn_w_mats"]))))
+    xd = torch.from_numpy(x).to(dev)
+    pivot = xd[:4096].to(torch.float64).mean(dim=0)
+    got = {}
+    for level in (0, 1, 2):
+        with _env(SPARSE):
+            eng = DataPass(K, D, xd.dtype, N, dev)
+        eng.set_pivot(pivot)
+        eng.prepare_rows(xd)
+        eng.profile(level)
+        eng.set_params(q.c, q.m, q.u)
+        for _ in range(2):              # the second pass runs on carried records / lists
+            stats = eng.estep_mstep(xd).clone()
+        torch.cuda.synchronize()
+        got[level] = (stats, eng.kernel_spans() if level else {}, eng.last_kernel_ms() if level else None)
+        eng.close()
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][0], got[2][0])
+    full, light = got[1][1], got[2][1]
+    assert set(light) <= {"estep_main", "estep_gather", "mstep_main"} and "mstep_main" in light
+    assert set(light) < set(full) and "mstep_reduce" in full
+    for g in light:
+        assert light[g][1] == full[g][1] and light[g][0] > 0
+    assert min(got[1][2]) > 0 and got[2][2] == (-1.0, -1.0)
