@@ -574,6 +574,33 @@ __global__ __launch_bounds__(256) void perm_compose_kernel(const int* __restrict
     perm_new[start + j] = perm_old ? perm_old[src] : src;
 }
 
+// Second key of the regrouping: how firmly a row sits in its best component.  bucket[n] in 0 .. kMarginBuckets - 1 from
+// t = lse - ln rho_best = -ln r_best (1 - r_best ~ t: the runner-up lies about -ln t nats below): settled rows on top, then
+// rows with r_best = 1.0 exactly, then decades of t.  Rows settle in this order as the components sharpen, so within a
+// component's group the settled rows - which the selection kernels skip by whole waves and tiles - stay contiguous, and so
+// do the rows the list-driven kernels still have to read.  (A NaN row lands in bucket 0.)
+constexpr int kMarginBuckets = 8;
+__global__ __launch_bounds__(256) void margin_bucket_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
+                                                            const double* __restrict__ lse, const int* __restrict__ khat,
+                                                            const unsigned char* __restrict__ lock /*null: no settled rows*/,
+                                                            int* __restrict__ bucket) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_rows) return;
+    int b = 0;
+    if (lock != nullptr && lock[n] == 1u) {
+        b = 7;
+    } else {
+        const double t = lse[n] - lnrho[(int64_t)khat[n] * npad + n];
+        if (t <= 0.0) b = 6;
+        else if (t < 1e-20) b = 5;
+        else if (t < 1e-14) b = 4;
+        else if (t < 1e-9) b = 3;
+        else if (t < 1e-5) b = 2;
+        else if (t < 1e-2) b = 1;
+    }
+    bucket[n] = b;
+}
+
 __global__ void perm_invert_kernel(const int* __restrict__ perm, int64_t n_rows, int* __restrict__ iperm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rows) iperm[perm[i]] = (int)i;

@@ -273,6 +273,8 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
         ws->opt_proof_blocked = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_SWEEP_LAZY");                       // "0": every sweep reads all K bounds of every row
         ws->opt_lazy = !(v && std::strcmp(v, "0") == 0);
+        v = std::getenv("GMMVB_REGROUP_MARGIN");     // "0": the rows are regrouped by best component only
+        ws->opt_regroup_margin = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_MSTEP_CACHE");
@@ -968,16 +970,52 @@ static hipError_t recenter_rows(gmmvb_workspace* ws, int64_t n_rows, hipStream_t
 // of x, centred copy rebuilt from it.  Everything row-indexed in the workspace is stale afterwards: the caller (a bound
 // pass) rebuilds it.
 static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, hipStream_t st,
-                               bool keep_state) {
+                               bool keep_state, bool margin_ok) {
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
-    hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K, ws->khat,
-                       ws->masks, ws->blk);
+    const unsigned cgrid = (unsigned)((n_rows + 255) / 256);
+    const int* key = ws->khat;                  // best components in the order the second pass sorts
+    const int* perm_in = ws->sorted ? ws->perm : nullptr;
+    // Two stable counting sorts, least significant key first: how firmly the rows sit in their component
+    // (margin_bucket_kernel; needs the last pass's log-normalisers), then the component.
+    const bool by_margin = ws->opt_regroup_margin && margin_ok && ws->K >= kMarginBuckets;
+    if (by_margin) {
+        int* bucket = ws->perm_tmp;             // (free until the first composition below writes it)
+        hipLaunchKernelGGL(margin_bucket_kernel, dim3(cgrid), dim3(256), 0, st, ws->lnrho, ws->npad, n_rows, ws->lse, ws->khat,
+                           keep_state ? ws->lock : nullptr, bucket);
+        hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows,
+                           kMarginBuckets, bucket, ws->masks, ws->blk);
+        launch_scan_counts(st, ws->blk, sel_grid, kMarginBuckets, ws->counts, ws->scan_parts);
+        hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, kMarginBuckets,
+                           ws->blk, ws->lists, ws->npad);
+        // the best components and the caller's rows in the intermediate order (the keys in the records' slot array, which
+        // the bound pass rewrites anyway)
+        int* key1 = reinterpret_cast<int*>(ws->rec_d);
+        hipLaunchKernelGGL(perm_compose_kernel, dim3(cgrid, kMarginBuckets), dim3(256), 0, st, ws->lists, ws->npad, ws->counts,
+                           ws->khat, key1);
+        hipLaunchKernelGGL(perm_compose_kernel, dim3(cgrid, kMarginBuckets), dim3(256), 0, st, ws->lists, ws->npad, ws->counts,
+                           perm_in, ws->perm_tmp);
+        key = key1;
+        perm_in = ws->perm_tmp;
+    }
+    hipLaunchKernelGGL(select_mask_kernel<3>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lnrho, ws->npad, n_rows, ws->K,
+                       const_cast<int*>(key), ws->masks, ws->blk);
     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K, ws->blk,
                        ws->lists, ws->npad);
-    hipLaunchKernelGGL(perm_compose_kernel, dim3((unsigned)((n_rows + 255) / 256), ws->K), dim3(256), 0, st, ws->lists, ws->npad,
-                       ws->counts, ws->sorted ? ws->perm : nullptr, ws->perm_tmp);
-    std::swap(ws->perm, ws->perm_tmp);
+    if (by_margin) {
+        // (three row-sized index buffers in rotation: the new order goes where the best components were - the bound pass
+        // that follows rewrites them)
+        hipLaunchKernelGGL(perm_compose_kernel, dim3(cgrid, ws->K), dim3(256), 0, st, ws->lists, ws->npad, ws->counts, perm_in,
+                           ws->khat);
+        int* new_perm = ws->khat;
+        ws->khat = ws->perm_tmp;
+        ws->perm_tmp = ws->perm;
+        ws->perm = new_perm;
+    } else {
+        hipLaunchKernelGGL(perm_compose_kernel, dim3(cgrid, ws->K), dim3(256), 0, st, ws->lists, ws->npad, ws->counts, perm_in,
+                           ws->perm_tmp);
+        std::swap(ws->perm, ws->perm_tmp);
+    }
     if (keep_state) {
         // the cache of single-component rows is a sum over rows - it does not care about their order; what is kept per row
         // (in the cache or not, for which component, the settled rows' distance bound) moves with the rows.  The records'
@@ -1370,7 +1408,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     bool sorted_now = false;
     if (regroup_due()) {
         span_begin(ws, kSpanSelect, st);
-        e = regroup_rows(ws, x_dev, ldx, n_rows, st, ws->lock_live);
+        e = regroup_rows(ws, x_dev, ldx, n_rows, st, ws->lock_live, ws->e_state == 1 && !ws->lse_stale);
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "regrouping the rows", e);
         ws->moved_since_sort = 0.0;

@@ -184,6 +184,7 @@ struct gmmvb_workspace {
     bool opt_proof = true;             // env GMMVB_PROOF=0: settled rows with candidates go straight to the f64 gather
     bool opt_hmm_mstep_dense = false;  // env GMMVB_HMM_MSTEP_DENSE: the HMM's small M-step walks every (step, state), not only gamma >= 2^-80
     bool opt_proof_blocked = true;     // env GMMVB_PROOF_BLOCKED=0: estep_i8_proof instead of estep_i8_proof_blocked (row superblocks)
+    bool opt_regroup_margin = true;    // env GMMVB_REGROUP_MARGIN=0: regroup by best component only (no second key: how firmly a row sits in it)
     bool opt_lazy = true;              // env GMMVB_SWEEP_LAZY=0: every sweep goes through all K bounds of every row
     bool opt_proof_all = true;         // the candidates of rows with an exact reference go through the proof round too (env
                                        // GMMVB_PROOF=settled: only the settled rows' pairs)

@@ -22,7 +22,7 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_MARGIN",
-            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT", "GMMVB_SWEEP_LAZY", "GMMVB_PROOF_BLOCKED")
+            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT", "GMMVB_SWEEP_LAZY", "GMMVB_PROOF_BLOCKED", "GMMVB_REGROUP_MARGIN")
 VARIANTS = {
     "default": {},
     # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, without
@@ -47,6 +47,8 @@ VARIANTS = {
     "proof_by_component": {"GMMVB_PROOF_BLOCKED": "0"},
     "force_proof_by_component": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF_BLOCKED": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
+    # the rows regrouped by best component only (default: within a component by how firmly they sit in it)
+    "force_nomargin": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_REGROUP_MARGIN": "0"},
     "force_nocache": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_MSTEP_CACHE": "0"},
     "force_nocarry": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_ESTEP_CARRY_OFF": "1"},
     "dense": {"GMMVB_ESTEP_PRUNE": "0", "GMMVB_MSTEP_SPARSE": "0"},
@@ -141,7 +143,8 @@ LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n1400
          # the middle of the separation spectrum (cluster means 1.0 * randn: 2-10 components active per row): where the
          # policy's choice between dense, bound pass and sweep is closest
          ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nolazy"),
-         ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nocarry"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "default")]
+         ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nocarry"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "default"),
+         ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_nomargin")]
 # off the benchmark's recipe (round 5): twice as many components in the model as in the data (empty and duplicate
 # components), mixing weights ~ Dirichlet(0.3), anisotropic clusters (per-feature scales 0.3 ... 3) - reference fixtures, the
 # pruned path forced (N K = 2^19: the default policy stays dense at this size, which is the fourth variant)
@@ -226,7 +229,8 @@ def _oracle_post(q):
     return o
 
 
-@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_settled", "force_nolazy"])
+@pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_settled", "force_nolazy",
+                                     "force_nomargin"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
