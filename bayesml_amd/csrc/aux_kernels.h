@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpa
 //   scan_parts / scan_apply   exclusive scan of those block counts per component -> block bases and list lengths;
 //   fill_lists_kernel    every block writes its candidates at its bases.
 constexpr int kSelRows = 256;
+// the per-block count / base arrays are block-major (see the scan below)
+__device__ __forceinline__ int64_t blk_at(int k, int64_t b, int K) { return b * K + k; }
 
 __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
 #pragma unroll
@@ -214,65 +216,115 @@ __global__ __launch_bounds__(kSelRows) void select_mask_kernel(const double* __r
     }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += kSelRows)
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[blk_at(k, blockIdx.x, K)] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
 }
 
-// Exclusive scan of the block counts per component, blk[k][b] (component-major: a component's counts are contiguous)
-// <- sum of blk[k][b'] over b' < b; counts[k] = the total.  Two launches of K x kScanParts workgroups: sums of the
-// parts, then every part scans its range from the sum of the parts before it.
-constexpr int kScanParts = 16;
+// Exclusive scan of the block counts per component.  blk is BLOCK-major, blk[b][k] at b K + k (round 5; it was
+// component-major): a selection kernel's workgroup then writes its K counts as one contiguous run instead of K scattered
+// 4-byte stores a whole array row apart - at K = 256 those were 0.8 GB of 64-byte sectors per array and kernel, several
+// arrays per pass -, fill_lists_kernel reads its K bases in one piece, and the scan streams whole rows.
+// blk[b][k] <- sum of blk[b'][k] over b' < b; counts[k] = the total.  Three launches: sums of kScanParts parts (every part a
+// contiguous range of ~40 blocks, all components at once), the exclusive scan of those sums per component, then every part
+// scans its blocks from its base.  Thread t of a part's workgroup: component t % K, row t / K of 256 / K block rows.
+constexpr int kScanParts = 1024;
+constexpr int kScanChunk = 32;            // parts per thread of the middle kernel (kScanParts / kScanChunk chunks per component)
 
-__device__ __forceinline__ int block_excl_scan(int v, int* wtot /*[4] shared*/, int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o);
-        inc += lane >= o ? t : 0;
-    }
-    __syncthreads();                      // wtot may still be read from the previous tile
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
-    total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    return base + inc - v;
-}
-
-__global__ __launch_bounds__(256) void scan_parts_kernel(const int* __restrict__ blk, int blocks, int* __restrict__ parts) {
-    __shared__ int wtot[4];
-    const int k = blockIdx.x, p = blockIdx.y;
+// sums of the parts: part p = blocks [p per, (p + 1) per), all components
+__global__ __launch_bounds__(256) void scan_parts_kernel(const int* __restrict__ blk, int blocks, int K, int* __restrict__ parts) {
+    __shared__ int sh[256];
+    const int p = blockIdx.x;
+    const int R = K <= 256 ? 256 / K : 1;
+    const int t = threadIdx.x, k = t % K, r = t / K;
     const int per = (blocks + kScanParts - 1) / kScanParts;
     const int b0 = p * per, b1 = b0 + per < blocks ? b0 + per : blocks;
     int s = 0;
-    for (int b = b0 + threadIdx.x; b < b1; b += 256) s += blk[(int64_t)k * blocks + b];
-    int total;
-    (void)block_excl_scan(s, wtot, total);
-    if (threadIdx.x == 0) parts[k * kScanParts + p] = total;
+    if (t < R * K)
+        for (int b = b0 + r; b < b1; b += R) s += blk[blk_at(k, b, K)];
+    sh[t] = s;
+    __syncthreads();
+    if (t < K) {
+        int tot = 0;
+        for (int q = 0; q < R; ++q) tot += sh[q * K + t];
+        parts[p * K + t] = tot;
+    }
 }
 
-__global__ __launch_bounds__(256) void scan_apply_kernel(int* __restrict__ blk, int blocks, const int* __restrict__ parts,
-                                                         int* __restrict__ counts) {
-    __shared__ int wtot[4];
-    const int k = blockIdx.x, p = blockIdx.y;
+// parts[p][k] <- sum over p' < p (in place), counts[k] = the total.  One workgroup per eight components: thread
+// (component t % 8, chunk t / 8) takes kScanChunk consecutive parts.
+__global__ __launch_bounds__(256) void scan_mid_kernel(int* __restrict__ parts, int K, int* __restrict__ counts) {
+    static_assert(kScanParts == 32 * kScanChunk, "256 threads = 8 components x 32 chunks");
+    __shared__ int sh[32][8];
+    const int t = threadIdx.x, kk = t & 7, c = t >> 3;
+    const int k = blockIdx.x * 8 + kk;
+    int v[kScanChunk];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) {
+        v[i] = k < K ? parts[(int64_t)(c * kScanChunk + i) * K + k] : 0;
+        s += v[i];
+    }
+    sh[c][kk] = s;
+    __syncthreads();
+    int run = 0;
+    for (int q = 0; q < c; ++q) run += sh[q][kk];
+    if (k < K) {
+#pragma unroll
+        for (int i = 0; i < kScanChunk; ++i) {
+            parts[(int64_t)(c * kScanChunk + i) * K + k] = run;
+            run += v[i];
+        }
+        if (c == 31) counts[k] = run;
+    }
+}
+
+// every part scans its blocks from its base; rows b0 + i R + r, r = 0 .. R - 1, go through the workgroup together
+__global__ __launch_bounds__(256) void scan_apply_kernel(int* __restrict__ blk, int blocks, int K, const int* __restrict__ parts) {
+    __shared__ int sh[256];
+    const int p = blockIdx.x;
+    const int R = K <= 256 ? 256 / K : 1;
+    const int t = threadIdx.x, k = t % K, r = t / K;
+    const bool on = t < R * K;
     const int per = (blocks + kScanParts - 1) / kScanParts;
     const int b0 = p * per, b1 = b0 + per < blocks ? b0 + per : blocks;
-    int run = 0;
-    for (int q = 0; q < p; ++q) run += parts[k * kScanParts + q];
-    for (int t0 = b0; t0 < b1; t0 += 256) {
-        const int b = t0 + threadIdx.x;
-        const int v = b < b1 ? blk[(int64_t)k * blocks + b] : 0;
-        int total;
-        const int ex = block_excl_scan(v, wtot, total);
-        if (b < b1) blk[(int64_t)k * blocks + b] = run + ex;
-        run += total;
+    int run = on ? parts[p * K + k] : 0;
+    if (R == 1) {
+        // one thread per component walks the part's blocks: eight loads at a time, then their eight stores (the same
+        // array: a load behind a store would wait for it)
+        for (int c0 = b0; c0 < b1; c0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (on && c0 + i < b1) ? blk[blk_at(k, c0 + i, K)] : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (on && c0 + i < b1) blk[blk_at(k, c0 + i, K)] = run;
+                run += v[i];
+            }
+        }
+        return;
     }
-    if (p == kScanParts - 1 && threadIdx.x == 0) counts[k] = run;
+    for (int c0 = b0; c0 < b1; c0 += R) {                 // (workgroup-uniform bounds)
+        const int b = c0 + r;
+        const int v = (on && b < b1) ? blk[blk_at(k, b, K)] : 0;
+        __syncthreads();                                  // (sh of the previous round has been read)
+        sh[t] = v;
+        __syncthreads();
+        if (on) {
+            int before = 0, all = 0;
+            for (int q = 0; q < R; ++q) {
+                const int w = sh[q * K + k];
+                before += q < r ? w : 0;
+                all += w;
+            }
+            if (b < b1) blk[blk_at(k, b, K)] = run + before;
+            run += all;
+        }
+    }
 }
 
-inline void launch_scan_counts(hipStream_t st, int* blk, int blocks, int K, int* counts, int* parts /*[K * kScanParts]*/) {
-    hipLaunchKernelGGL(scan_parts_kernel, dim3(K, kScanParts), dim3(256), 0, st, blk, blocks, parts);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(K, kScanParts), dim3(256), 0, st, blk, blocks, parts, counts);
+inline void launch_scan_counts(hipStream_t st, int* blk, int blocks, int K, int* counts, int* parts /*[kScanParts * K]*/) {
+    hipLaunchKernelGGL(scan_parts_kernel, dim3(kScanParts), dim3(256), 0, st, blk, blocks, K, parts);
+    hipLaunchKernelGGL(scan_mid_kernel, dim3((K + 7) / 8), dim3(256), 0, st, parts, K, counts);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(kScanParts), dim3(256), 0, st, blk, blocks, K, parts);
 }
 
 // lock (delta lists of the cache of single-component rows, records.h rec_finish_kernel): a row that leaves its
@@ -289,6 +341,9 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
     const int W = (K + 63) / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int k = lane; k < K; k += 64) wcnt[wave][k] = 0;
+    // this block's base in component threadIdx.x's list (one contiguous run of K ints): requested together with the masks -
+    // behind the count it was a second memory round trip per workgroup, and the kernel is 39 000 workgroups of two round trips
+    const int base_pre = (int)threadIdx.x < K ? blk_base[blk_at((int)threadIdx.x, blockIdx.x, K)] : 0;
     unsigned long long mkw[4] = {0ull, 0ull, 0ull, 0ull}, prw[4] = {0ull, 0ull, 0ull, 0ull};      // (kept for the second pass)
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -310,7 +365,7 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
     for (int k = threadIdx.x; k < K; k += kSelRows) {
         const int c0 = wcnt[0][k], c1 = wcnt[1][k], c2 = wcnt[2][k], c3 = wcnt[3][k];
         if (c0 + c1 + c2 + c3 > 0) {
-            const int base = blk_base[(int64_t)k * gridDim.x + blockIdx.x];
+            const int base = k == (int)threadIdx.x ? base_pre : blk_base[blk_at(k, blockIdx.x, K)];
             wcnt[0][k] = base;
             wcnt[1][k] = base + c0;
             wcnt[2][k] = base + c0 + c1;
@@ -403,7 +458,7 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
     if ((threadIdx.x & 63) == 0) wact[wave] = active;
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += kSelRows)
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[blk_at(k, blockIdx.x, K)] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (threadIdx.x == 0) apart[blockIdx.x] = (double)(wact[0] + wact[1] + wact[2] + wact[3]);
 }
 

@@ -752,16 +752,16 @@ constexpr int kProofItem = 256;            // one 32-entry tile for each of the 
 constexpr int kProofXcds = 8;
 
 __device__ __forceinline__ void proof_unit(const int* __restrict__ blk_base, const int* __restrict__ counts, int nblk, int s,
-                                           int k, int& lo, int& hi) {
+                                           int k, int K, int& lo, int& hi) {
     constexpr int BS = kProofSuperRows / 256;
     const int b0 = s * BS, b1 = b0 + BS;
-    lo = blk_base[(int64_t)k * nblk + b0];
-    hi = b1 < nblk ? blk_base[(int64_t)k * nblk + b1] : counts[k];
+    lo = blk_base[(int64_t)b0 * K + k];                 // (block-major: aux_kernels.h blk_at)
+    hi = b1 < nblk ? blk_base[(int64_t)b1 * K + k] : counts[k];
 }
 
 // cum[s][k] = items of superblock s that belong to components < k (cum[s][K] = tot[s] = all of them).  One workgroup per
 // superblock, one thread per component.
-__global__ __launch_bounds__(256) void proof_units_kernel(const int* __restrict__ blk_base /*[K][nblk] exclusive bases*/,
+__global__ __launch_bounds__(256) void proof_units_kernel(const int* __restrict__ blk_base /*[nblk][K] exclusive bases*/,
                                                           const int* __restrict__ counts, int K, int nblk,
                                                           int* __restrict__ cum /*[n_super][K + 1]*/, int* __restrict__ tot) {
     __shared__ int sc[256];
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void proof_units_kernel(const int* __restrict_
     int n = 0;
     if (k < K) {
         int lo, hi;
-        proof_unit(blk_base, counts, nblk, s, k, lo, hi);
+        proof_unit(blk_base, counts, nblk, s, k, K, lo, hi);
         n = (hi - lo + kProofItem - 1) / kProofItem;
     }
     sc[k] = n;
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void proof_items_kernel(const int* __restrict_
     int first = 0;
     for (int q = 0; q < s % kProofXcds; ++q) first += xtot[q];
     int lo, hi;
-    proof_unit(blk_base, counts, nblk, s, k, lo, hi);
+    proof_unit(blk_base, counts, nblk, s, k, K, lo, hi);
     i4v* dst = items + first + xb[s] + cum[(int64_t)s * (K + 1) + k];
     for (int e = lo; e < hi; e += kProofItem) *dst++ = i4v{k, e, hi - e < kProofItem ? hi - e : kProofItem, s};
 }

@@ -53,7 +53,7 @@ hipError_t launch_estep_i8_proof(int D, int grid, hipStream_t st, const unsigned
                                  const unsigned char* img, const double* cvec, int K, const int* lists, int64_t cap,
                                  const int* counts, const int* plan, float* ub, double* lb, int64_t npad);
 // the same with the pairs regrouped by row superblock so that a row's digit planes are fetched once per pass (estep_i8.h,
-// estep_i8_proof_blocked): blk_base = the selection blocks' exclusive bases the lists were filled from ([K][nblk]), work =
+// estep_i8_proof_blocked): blk_base = the selection blocks' exclusive bases the lists were filled from ([nblk][K]), work =
 // estep_i8_proof_work_bytes(K, n_rows) bytes of 16-byte aligned scratch
 int64_t estep_i8_proof_work_bytes(int K, int64_t n_rows);
 hipError_t launch_estep_i8_proof_blocked(int D, int num_cu, hipStream_t st, const unsigned char* xq, const signed char* xqe,

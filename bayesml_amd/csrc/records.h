@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[blk_at(k, blockIdx.x, K)] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
         opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
@@ -826,8 +826,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         }
     }
     for (int k = tid; k < K; k += kSelRows) {
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
-        if (pmask) pblk[(int64_t)k * gridDim.x + blockIdx.x] = pcnt[0][k] + pcnt[1][k] + pcnt[2][k] + pcnt[3][k];
+        blk_cnt[blk_at(k, blockIdx.x, K)] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        if (pmask) pblk[blk_at(k, blockIdx.x, K)] = pcnt[0][k] + pcnt[1][k] + pcnt[2][k] + pcnt[3][k];
     }
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[blk_at(k, blockIdx.x, K)] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
         ppart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]) + (own_part ? own_part[blockIdx.x] : 0.0);
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(kSelRows) void rec_prune_kernel(RecArrays rec, unsi
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows)
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[blk_at(k, blockIdx.x, K)] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
         ppart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
@@ -1394,10 +1394,10 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
     }
     __syncthreads();
     for (int k = tid; k < K; k += kSelRows) {
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+        blk_cnt[blk_at(k, blockIdx.x, K)] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
         if (dblk) {
-            dblk[(int64_t)k * gridDim.x + blockIdx.x] = dcnt[0][k] + dcnt[1][k] + dcnt[2][k] + dcnt[3][k];
-            mblk[(int64_t)k * gridDim.x + blockIdx.x] = mcnt[0][k] + mcnt[1][k] + mcnt[2][k] + mcnt[3][k];
+            dblk[blk_at(k, blockIdx.x, K)] = dcnt[0][k] + dcnt[1][k] + dcnt[2][k] + dcnt[3][k];
+            mblk[blk_at(k, blockIdx.x, K)] = mcnt[0][k] + mcnt[1][k] + mcnt[2][k] + mcnt[3][k];
         }
     }
     if (tid == 0) {
@@ -1462,7 +1462,13 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
     const int W = (K + 63) / 64;
     const int wave = threadIdx.x >> 6;
     for (int k = threadIdx.x & 63; k < K; k += 64) wcnt[wave][k] = 0;
-    int kh = (valid && row_settled(lock, emask, npad, W, n)) ? (int)lcomp[n] : -1;
+    // (the three per-row loads at once: lock -> mask -> component in turn was three memory round trips per workgroup)
+    const int64_t nn = valid ? n : 0;
+    const unsigned lk = lock[nn];
+    const int lc = (int)lcomp[nn];
+    unsigned long long any = 0ull;
+    for (int w = 0; w < W; ++w) any |= emask[(int64_t)w * npad + nn];
+    int kh = (valid && lk == 1u && any == 0ull) ? lc : -1;          // in the cache and in none of the E-step's lists
     if (kh >= 0 && drift != nullptr && !own_first(drift[3 * K + kh], drift[K + kh])) kh = -1;
     for (int w = 0; w < W; ++w) {
         const unsigned long long mk = (kh >= 0 && (kh >> 6) == w) ? 1ull << (kh & 63) : 0ull;
@@ -1473,7 +1479,7 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
     int tot = 0;
     for (int k = threadIdx.x; k < K; k += kSelRows) {
         const int c = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
-        blk_cnt[(int64_t)k * gridDim.x + blockIdx.x] = c;
+        blk_cnt[blk_at(k, blockIdx.x, K)] = c;
         tot += c;
     }
     if (listed_part) {

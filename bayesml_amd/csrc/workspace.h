@@ -136,7 +136,7 @@ struct gmmvb_workspace {
     bool blk_fresh = false;    // blk still holds the block COUNTS of masks (not yet scanned into bases)
     int* khat = nullptr;       // [npad]
     int* counts = nullptr;     // [K]
-    int* blk = nullptr;        // [K][blocks of 256 rows] candidates per selection block -> block bases
+    int* blk = nullptr;        // [blocks of 256 rows][K] candidates per selection block -> block bases (aux_kernels.h: blk_at)
     int* scan_parts = nullptr; // [K][kScanParts] partial sums of the scan over blk
     unsigned long long* masks = nullptr;   // [ceil(K / 64)][npad] candidate components of every sample
     double* slabs = nullptr;   // [S_cap][K][slab_len]
@@ -153,9 +153,9 @@ struct gmmvb_workspace {
     unsigned long long* exit_host = nullptr;   // [2] pinned mirror (copied with the other counters)
     bool pend_lazy = false;                    // the pass behind the pending counters was a lazy sweep
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
-    int* dblk = nullptr;               // [K][blocks] their block counts
+    int* dblk = nullptr;               // [blocks][K] their block counts
     unsigned long long* mmask = nullptr;   // [ceil(K / 64)][npad] the M-step's lists: active pairs of the rows not in the cache
-    int* mblk = nullptr;               // [K][blocks] their block counts
+    int* mblk = nullptr;               // [blocks][K] their block counts
     double* cache = nullptr;           // [stats_len] statistics of the settled rows
     double* spart = nullptr, *gpart = nullptr, *qpart = nullptr;   // [blocks] settled rows / listed pairs / M-step pairs per selection block
     unsigned long long* rmask = nullptr;   // read-outs of settled rows: their (row, component) pairs ...
