@@ -359,12 +359,15 @@ __device__ __forceinline__ void i8_rows(unsigned const_addr, const i16v (&acc)[N
 //   |y_exact - y| <= c := 2^e_jt 2^en i8_err  (digits)  + 2^-22 (|y| + |b|)  (f32: I to 24 bits, b to 24 bits, one fma)
 //                          + the f64 rounding of b   <=   2^-20 |y| + beta_jt + 2^e_jt cef,
 // and with u = |y| (1 - 2^-20), e = beta_jt + 2^e_jt cef:   y_exact^2 >= (u - e)_+^2 >= u^2 - 2 e u.
-// So a block only accumulates Y2 = sum y^2 and A = sum |y| (7 instructions per row), and the caller forms
+// So a block only accumulates Y2 = sum y^2 (and used to accumulate A = sum |y|: 7 instructions per row), and the caller forms
 // q >= (1 - 2^-19) Y2 - 2 (beta_jt + 2^e_jt cef) A.  A NaN y poisons Y2; an infinite cef / beta makes q = -inf, i.e.
 // the bound +inf ("candidate"): it never lies.  Step GP covers this lane's rows 4 GP .. 4 GP + 3 of block JT.
+// (round 5) A is not accumulated any more: over the lane's 16 rows of the block, A = sum |y| <= 4 sqrt(sum y^2) (Cauchy-
+// Schwarz), which the caller forms from Y2 - one instruction per row less in an epilogue that is as long as the block's
+// MFMAs at D = 128 and twice as long at D = 64; the error term it multiplies is 1e-5 of q, a quarter more of it is nothing.
 template <int JT, int GP>
 __device__ __forceinline__ void i8_rows_bound(unsigned const_addr, const i16v (&acc)[kBoundDigits], i4v (&sb)[2][2],
-                                              float m, float& y2, float& ya) {
+                                              float m, float& y2) {
     if constexpr (GP + 1 < 4) lds_read16<JT * 128 + 16 * (GP + 1)>(sb[(GP + 1) & 1][0], const_addr);
     lds_wait<(GP + 1 < 4) ? 1 : 0>(sb[GP & 1][0]);
     union { i4v v; float f[4]; } r;
@@ -376,10 +379,9 @@ __device__ __forceinline__ void i8_rows_bound(unsigned const_addr, const i16v (&
         const float I = __builtin_fmaf(tf, 128.0f, (float)acc[2][g]);
         const float y = __builtin_fmaf(I, m, -r.f[e]);
         y2 = __builtin_fmaf(y, y, y2);
-        ya += __builtin_fabsf(y);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (GP + 1 < 4) i8_rows_bound<JT, GP + 1>(const_addr, acc, sb, m, y2, ya);
+    if constexpr (GP + 1 < 4) i8_rows_bound<JT, GP + 1>(const_addr, acc, sb, m, y2);
 }
 
 // TWO: also an UPPER bound of sum y_exact^2 in qu:  y_exact^2 <= (|y| (1 + 2^-20) + e)^2, e = beta_jt + 2^e_jt cef, i.e. per
@@ -399,8 +401,11 @@ __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned cons
         union { i4v v; float f[4]; } sc;
         sc.v = JT < 2 ? scales : scales2;
         const float sj = sc.f[2 * (JT & 1)], beta = sc.f[2 * (JT & 1) + 1];
-        float y2 = 0.0f, ya = 0.0f;
-        i8_rows_bound<JT, 0>(const_addr, acc, sb, sj * lc.c2f, y2, ya);
+        float y2 = 0.0f;
+        i8_rows_bound<JT, 0>(const_addr, acc, sb, sj * lc.c2f, y2);
+        // sum |y| over the lane's 16 rows <= sqrt(16 sum y^2); 2e-6 covers the f32 sum (16 x 2^-24) and v_sqrt_f32's ulp
+        // (a NaN y2 stays NaN: the bound says nothing, as before)
+        const float ya = 4.000008f * __builtin_amdgcn_sqrtf(y2);
         const float eb = __builtin_fmaf(sj, lc.cef, beta);
         q = __builtin_fmaf(-2.0f * ya, eb, __builtin_fmaf(y2, 0.9999980926513671875f, q));
         if constexpr (TWO)
