@@ -472,11 +472,50 @@ __global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView 
 __global__ void kside_finish_kernel(int K, const double* __restrict__ partials, double ln_c_alpha,
                                     const double* __restrict__ gamma, const double* __restrict__ delta,
                                     double* __restrict__ scal) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one workgroup of 64 (one thread's 9 K dependent loads were 0.1 ms at K = 256); thread 0 forms the lower bound from the
+    // nine sums
+    __shared__ double ts[kPartials];
+    if (blockIdx.x != 0) return;
+    {
+        // nine sums over the components in a FIXED order: lane l takes k = l, l + 64, ... in turn, then the lanes' sums meet
+        // in a fixed butterfly (round 5; before, one thread added all K in component order - the result differs in the last
+        // bits from that, not from run to run)
+        double acc[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+        for (int k = threadIdx.x; k < K; k += 64) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) acc[q] += partials[(int64_t)k * kPartials + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
+            if (threadIdx.x == 0) ts[q] = acc[q];
+        }
+    }
+    // drift summary min_k (gamma_k - delta_k / 30), a NaN sticks: a minimum, whatever order it is taken in
+    double g = 0.0;
+    if (gamma) {
+        g = __builtin_huge_val();
+        bool nan = false;
+        for (int k = threadIdx.x; k < K; k += 64) {
+            const double v = gamma[k] - delta[k] / 30.0;
+            nan = nan || v != v;
+            g = v < g ? v : g;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_xor(g, o);
+            g = w < g ? w : g;
+            nan = nan || (bool)__shfl_xor((int)nan, o);
+        }
+        if (nan) g = __builtin_nan("");
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double t[kPartials];
-    for (int q = 0; q < kPartials; ++q) t[q] = 0.0;
-    for (int k = 0; k < K; ++k)
-        for (int q = 0; q < 9; ++q) t[q] += partials[(int64_t)k * kPartials + q];
+    for (int q = 0; q < kPartials; ++q) t[q] = q < 9 ? ts[q] : 0.0;
     const double a0 = t[7];
     const double p_x = t[0], p_z = t[1], p_pi = ln_c_alpha + t[2], p_ml = t[3], q_z = -t[4];
     const double q_pi = (t[5] - lgamma(a0)) + (a0 - K) * digamma_pos(a0) - t[6];      // entropy of Dirichlet(alpha)
@@ -489,14 +528,6 @@ __global__ void kside_finish_kernel(int K, const double* __restrict__ partials, 
     scal[5] = q_pi;
     scal[6] = q_ml;
     scal[7] = p_x + p_z + p_pi + p_ml + q_z + q_pi + q_ml;
-    double g = 0.0;
-    if (gamma) {
-        g = __builtin_huge_val();
-        for (int k = 0; k < K; ++k) {
-            const double v = gamma[k] - delta[k] / 30.0;
-            g = (v < g || v != v) ? v : g;
-        }
-    }
     scal[8] = g;
 }
 

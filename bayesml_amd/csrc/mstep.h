@@ -739,19 +739,54 @@ __global__ __launch_bounds__(256) void hmm_mstep_small_kernel(const double* __re
 // of a component are scattered over the matrix or (after the rows were grouped by component) contiguous; every chunk
 // writes one slab, reduce_chunks_kernel adds a component's slabs in chunk order (fixed order: run-to-run identical).
 static __global__ void mstep_plan_kernel(const int* __restrict__ counts, int K, int cap_chunks, int r_min, int* __restrict__ plan) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    long long total = 0;
-    for (int k = 0; k < K; ++k) total += counts[k];
+    // One workgroup (one wave).  The counts arrive with parallel loads, their sum and the chunk counts (a 64-bit division
+    // each) are formed by all lanes, and only the prefix over the chunk counts - additions from LDS - is left to one thread:
+    // a single thread's 2 K dependent loads and K divisions were 42 us at K = 256.
+    __shared__ int sc[1025];
+    __shared__ long long s_total;
+    if (blockIdx.x != 0) return;
+    if (K > 1024) {                                   // (no caller: the lists stop at 256 components)
+        if (threadIdx.x != 0) return;
+        long long total = 0;
+        for (int k = 0; k < K; ++k) total += counts[k];
+        long long R = r_min;
+        const long long room = cap_chunks - K > 0 ? cap_chunks - K : 1;
+        if ((total + R - 1) / R > room) R = ((total + room - 1) / room + 63) / 64 * 64;
+        int c = 0;
+        for (int k = 0; k < K; ++k) {
+            plan[k] = c;
+            c += (int)((counts[k] + R - 1) / R);
+        }
+        plan[K] = c;
+        plan[K + 1] = (int)R;
+        return;
+    }
+    long long part = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        sc[k] = counts[k];
+        part += sc[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);        // (integers: any order)
+    if (threadIdx.x == 0) s_total = part;
+    __syncthreads();
+    const long long total = s_total;
     long long R = r_min;
     const long long room = cap_chunks - K > 0 ? cap_chunks - K : 1;      // every component may end on a partial chunk
     if ((total + R - 1) / R > room) R = ((total + room - 1) / room + 63) / 64 * 64;
-    int c = 0;
-    for (int k = 0; k < K; ++k) {
-        plan[k] = c;
-        c += (int)((counts[k] + R - 1) / R);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) sc[k] = (int)((sc[k] + R - 1) / R);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int k = 0; k < K; ++k) {
+            const int n = sc[k];
+            sc[k] = c;
+            c += n;
+        }
+        sc[K] = c;
+        plan[K + 1] = (int)R;
     }
-    plan[K] = c;
-    plan[K + 1] = (int)R;
+    __syncthreads();
+    for (int k = threadIdx.x; k <= K; k += blockDim.x) plan[k] = sc[k];
 }
 
 template <int T>

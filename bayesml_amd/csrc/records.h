@@ -1065,14 +1065,34 @@ __global__ __launch_bounds__(kSelRows) void rec_prune_kernel(RecArrays rec, unsi
 }
 
 // first[k] = index of component k's first gather chunk (chunk = per_wg list entries), first[K] = number of chunks
+// (one workgroup: the counts come in with parallel loads - a single thread's K dependent loads were 24 us at K = 256 - and
+// the prefix over them is taken from LDS)
 __global__ void gather_plan_kernel(const int* __restrict__ counts, int K, int per_wg, int* __restrict__ first) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int total = 0;
-    for (int k = 0; k < K; ++k) {
-        first[k] = total;
-        total += (counts[k] + per_wg - 1) / per_wg;
+    __shared__ int sc[1025];
+    if (blockIdx.x != 0) return;
+    if (K > 1024) {
+        if (threadIdx.x != 0) return;
+        int total = 0;
+        for (int k = 0; k < K; ++k) {
+            first[k] = total;
+            total += (counts[k] + per_wg - 1) / per_wg;
+        }
+        first[K] = total;
+        return;
     }
-    first[K] = total;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) sc[k] = (counts[k] + per_wg - 1) / per_wg;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int k = 0; k < K; ++k) {
+            const int c = sc[k];
+            sc[k] = total;
+            total += c;
+        }
+        sc[K] = total;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= K; k += blockDim.x) first[k] = sc[k];
 }
 
 // After the exact evaluation of the listed pairs: refresh the records from the exact values (distances, exact
