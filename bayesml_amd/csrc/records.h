@@ -39,6 +39,7 @@
 //   dlock   for a settled row (cached AND left out of the E-step's lists) the upper bound of its distance to that
 //           component, from which the next sweep takes the row's reference value instead of an exact evaluation.
 #pragma once
+#include <type_traits>
 #include "aux_kernels.h"
 
 namespace gmmvb {
@@ -343,17 +344,34 @@ __device__ __forceinline__ float sweep_carry(float old, float4 p) {
     return fmaf(fabsf(r), 2.4e-7f, r);
 }
 
-// largest value over the wave's lanes, in every lane (NaN operands lose against numbers: callers' values are never NaN)
+// v_max_f32 as it is (IEEE maxNum like fmaxf, without the two canonicalising copies the compiler puts in front of it)
+__device__ __forceinline__ float max_f32_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// largest value over the wave's lanes, in every lane (NaN operands lose against numbers: callers' values are never NaN).
+// Four v_max_f32 with a DPP operand inside the rows of 16 lanes, then the four row results through scalar registers.  (Written
+// out: from fmaxf on a DPP copy the compiler makes a move, two canonicalising copies and the maximum per step - 40
+// instructions per call, and the lazy sweep calls this once per re-opened column and wave.)
 __device__ __forceinline__ float wave_max_f32(float v) {
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
     const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
     const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
     const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+    return max_f32_raw(max_f32_raw(a, b), max_f32_raw(c, d));
 }
 
 // LAZY (PREV only): the sweep does not touch what it can prove irrelevant for a whole tile of 256 rows (= workgroup).
@@ -375,8 +393,11 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // never read: the sweep was 5 GB of traffic per pass at the benchmark shape, the largest kernel of a converged step.
 // WC > 0: the number of 64-component mask words is a compile-time constant (the loops over them unroll and the
 // four-element mask arrays stay in registers without select chains: a third fewer vector instructions at K <= 64).
+// (Three and four mask words: five waves per SIMD asked for - 96 registers and 24 bytes of scratch outside the column loop
+// instead of 108: the kernel lives on the other waves hiding its per-pair LDS and memory waits; six - 80 registers, 144
+// bytes of scratch - loses again.  3.79 -> 3.35 ms at K = 256.)
 template <bool PREV, bool LAZY = false, int WC = 0>
-__global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__ ub, const double* __restrict__ u, int64_t npad,
+__global__ __launch_bounds__(kSelRows, (LAZY && WC >= 3 ? 5 : 1)) void rec_sweep_kernel(float* __restrict__ ub, const double* __restrict__ u, int64_t npad,
                                                              int64_t n_rows, int K,
                                                              const double* __restrict__ drift,
                                                              const double* __restrict__ c_new,
@@ -584,8 +605,12 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
         // covers everything else: "refreshed row"), so a wave whose rows are all settled skips the selection chain - a third
         // of the per-pair instructions
         const bool need_chain = !LAZY || __builtin_amdgcn_ballot_w64(valid && !by_bound) != 0ull;
-        auto pair = [&](int k, int bit, float old, unsigned long long fw, unsigned long long nw, unsigned long long& mw,
+        // (CH: the slot-selection chain runs - a compile-time flag of the column loop, which exists twice: with the test inside
+        // the loop the chain's nine registers met the skipping path at a join behind every pair and were copied there, eight
+        // moves per pair)
+        auto pair = [&](auto ch, int k, int bit, float old, unsigned long long fw, unsigned long long nw, unsigned long long& mw,
                         unsigned long long& aw) {
+            constexpr bool CH = decltype(ch)::value;
             const float ubn = sweep_carry(old, sp[k]);
             char* base = (char*)(ub + (int64_t)k * npad + (near ? 0 : nn));
             const unsigned long long b1 = 1ull << bit;
@@ -593,8 +618,8 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
             const bool isf = (fw & b1) != 0ull;                            // (its exact value is written below)
             const bool cand = valid && !(ubn < thr_f) && (nw & b1) == 0ull;
             mw |= cand ? b1 : 0ull;
-            restmax = fmaxf(restmax, (cand || isf) ? -__builtin_huge_valf() : ubn);
-            if (need_chain) sweep_chain(s, (isf || !valid) ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
+            restmax = max_f32_raw(restmax, (cand || isf) ? -__builtin_huge_valf() : ubn);
+            if constexpr (CH) sweep_chain(s, (isf || !valid) ? 0xFFFFFFFFu : sweep_key(ubn, (unsigned)k));
             if constexpr (LAZY) {
                 aw |= __builtin_amdgcn_ballot_w64(cand) != 0ull ? b1 : 0ull;
                 if (red_w & b1) {                                              // (uniform)
@@ -622,21 +647,25 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
                 keep_w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) |
                          (unsigned)__builtin_amdgcn_readfirstlane((int)q0);
                 mine_w = -__builtin_huge_valf();
-                while (ow) {
-                    int kq[8];
+                auto columns = [&](auto ch) {
+                    while (ow) {
+                        int kq[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        kq[q] = ow ? __builtin_ctzll(ow) : -1;
-                        ow &= ow - 1;                                       // (0 stays 0)
+                        for (int q = 0; q < 8; ++q) {
+                            kq[q] = ow ? __builtin_ctzll(ow) : -1;
+                            ow &= ow - 1;                                   // (0 stays 0)
+                        }
+                        float pre[8];                                       // up to eight loads in flight per thread
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (kq[q] >= 0) pre[q] = old_of(64 * w + kq[q]);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (kq[q] >= 0) pair(ch, 64 * w + kq[q], kq[q], pre[q], fw, nw, mw, aw);
                     }
-                    float pre[8];                                           // up to eight loads in flight per thread
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (kq[q] >= 0) pre[q] = old_of(64 * w + kq[q]);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (kq[q] >= 0) pair(64 * w + kq[q], kq[q], pre[q], fw, nw, mw, aw);
-                }
+                };
+                if (need_chain) columns(std::true_type{});
+                else columns(std::false_type{});
                 if (w == 0) mine[0] = mine_w;
                 else if (w == 1) mine[1] = mine_w;
                 else if (w == 2) mine[2] = mine_w;
@@ -650,9 +679,9 @@ __global__ __launch_bounds__(kSelRows) void rec_sweep_kernel(float* __restrict__
 #pragma unroll
                         for (int q = 0; q < 8; ++q) pre[q] = old_of(k0 + q);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) pair(k0 + q, k0 + q - 64 * w, pre[q], fw, nw, mw, aw);
+                        for (int q = 0; q < 8; ++q) pair(std::true_type{}, k0 + q, k0 + q - 64 * w, pre[q], fw, nw, mw, aw);
                     }
-                    for (; k0 < kend; ++k0) pair(k0, k0 - 64 * w, old_of(k0), fw, nw, mw, aw);
+                    for (; k0 < kend; ++k0) pair(std::true_type{}, k0, k0 - 64 * w, old_of(k0), fw, nw, mw, aw);
                 }
             }
             if (w == 0) { mk[0] = mw; anyw[0] = aw; }
