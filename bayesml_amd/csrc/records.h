@@ -166,8 +166,9 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
 }
 
 // per-block component counts of a 64-bit mask word (as in select_mask_kernel)
+template <bool UNIFORM = true>
 __device__ __forceinline__ void count_word(unsigned long long mk, int w, int wave, int (*wcnt)[256]) {
-    unsigned long long present = wave_or(mk);
+    unsigned long long present = UNIFORM ? wave_or(mk) : wave_or_shfl(mk);
     while (present) {
         const int b = __builtin_ctzll(present);
         present &= present - 1;
@@ -1419,10 +1420,10 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         }
     }
     for (int w = 0; w < W; ++w) {
-        count_word(mk[w], w, wave, wcnt);
+        count_word<false>(mk[w], w, wave, wcnt);
         if (dmask) {
-            count_word(dm[w], w, wave, dcnt);
-            count_word(mm[w], w, wave, mcnt);
+            count_word<false>(dm[w], w, wave, dcnt);
+            count_word<false>(mm[w], w, wave, mcnt);
         }
     }
     int moved = (valid && khat[n] != khat_before) ? 1 : 0;
