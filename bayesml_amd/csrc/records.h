@@ -905,11 +905,21 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
             for (int w = 0; w < W; ++w) {
                 unsigned long long m = pmask[(int64_t)w * npad + n];
                 proved += __builtin_popcountll(m);
+                // (four scattered loads in flight per round: one at a time, every proof pair of the row was a memory round
+                // trip of its own - six of them in a row at K = 256)
                 while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const double u = (double)ub32[(int64_t)(64 * w + b) * npad + n];
-                    if (!(u < thr)) kept[w] |= 1ull << b;                    // also NaN
+                    int b[4];
+                    float uf[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        b[q] = m ? __builtin_ctzll(m) : -1;
+                        m &= m - 1;                                          // (0 stays 0)
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) uf[q] = b[q] >= 0 ? ub32[(int64_t)(64 * w + b[q]) * npad + n] : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (b[q] >= 0 && !((double)uf[q] < thr)) kept[w] |= 1ull << b[q];      // also NaN
                 }
             }
 #pragma unroll
@@ -942,18 +952,26 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
             for (int w = 0; w < W; ++w) {
                 unsigned long long m = pmask[(int64_t)w * npad + n];
                 proved += __builtin_popcountll(m);
+                if ((kset >> 6) == w) m &= ~(1ull << (kset & 63));           // (the row's own pair is not a candidate)
                 while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int k = 64 * w + b;
-                    if (k == kset) continue;
-                    const float uf = ub32[(int64_t)k * npad + n];
-                    const double u = (double)uf;
-                    if (!(u < thr)) {                                        // also NaN
-                        kept[w] |= 1ull << b;
-                        any = true;
-                    } else {
-                        done_max = fmaxf(done_max, uf);
+                    int b[4];
+                    float uf[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        b[q] = m ? __builtin_ctzll(m) : -1;
+                        m &= m - 1;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) uf[q] = b[q] >= 0 ? ub32[(int64_t)(64 * w + b[q]) * npad + n] : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (b[q] < 0) continue;
+                        if (!((double)uf[q] < thr)) {                        // also NaN
+                            kept[w] |= 1ull << b[q];
+                            any = true;
+                        } else {
+                            done_max = fmaxf(done_max, uf[q]);
+                        }
                     }
                 }
             }
@@ -1267,13 +1285,17 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
         double mx = -__builtin_huge_val();
         int arg = 0x7fffffff;
         bool nan = false;
+        // (the slots' components, then all their exact values, then the arithmetic: with the loads next to their use every
+        // evaluated pair of the row was a memory round trip of its own)
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j) kk[j] = rec.k[(int64_t)j * rec.npad + n];
+#pragma unroll
+        for (int j = 0; j < kRecSlots; ++j)
+            v[j] = ((live >> j) & 1u) ? lnrho[(int64_t)kk[j] * npad + n] : 0.0;
 #pragma unroll
         for (int j = 0; j < kRecSlots; ++j) {
-            kk[j] = rec.k[(int64_t)j * rec.npad + n];
-            v[j] = 0.0;
             if (!((live >> j) & 1u)) continue;
-            const double x = lnrho[(int64_t)kk[j] * npad + n];
-            v[j] = x;
+            const double x = v[j];
             ub32[(int64_t)kk[j] * npad + n] = f32_up(x);
             rec.d[(int64_t)j * rec.npad + n] = f32_down(dist_of(cvec[kk[j]], x));
             if (x < thr_row) bounds_only |= 1u << j;
