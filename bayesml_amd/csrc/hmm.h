@@ -71,6 +71,43 @@ __global__ __launch_bounds__(256) void hmm_prep_kernel(const double* __restrict_
     }
 }
 
+// exp(x) for x <= 0 in 13 f64 instructions (round 5): x = n ln2/64 + r, |r| <= ln2/128, exp(x) = 2^(n div 64) T[n mod 64] e^r
+// with T[j] = 2^(j/64) from a 64-entry table in LDS and e^r - 1 = r + r^2 (1/2 + r (1/6 + r (1/24 + r/120))) (remainder
+// r^6/720 < 4e-17); n ln2/64 is subtracted in two parts (the leading one has 20 trailing zero bits: exact for |n| < 2^20).
+// About one ulp, like the library's exp - which is 30 f64 instructions, and in hmm_emission_mfma16_kernel the f64 vector
+// instructions run on the units of the f64 MFMAs beside them: its 16 exponentials per lane and tile were two thirds of that
+// kernel's vector work (0.7 of its 3.2 ms at config 5).  x is clamped at -800 (the result underflows to 0 through ldexp).
+__device__ const double kExp2Table64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+__device__ __forceinline__ double exp_nonpos_fast(double x, const double* __restrict__ tab /*[64], LDS*/) {
+    x = fmax(x, -800.0);
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+6);
+    double r = fma(-n, 0x1.62e42fef00000p-7, x);
+    r = fma(-n, 0x1.473de6af278edp-40, r);
+    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+    q = fma(r, q, 0.5);
+    const double p = fma(r * r, q, r);
+    const int ni = (int)n;
+    const double t = tab[ni & 63];
+    return ldexp(fma(t, p, t), ni >> 6);
+}
+
 // H0 + H1 in one kernel for one feature tile (D <= 16) and up to 64 states: the emission on the matrix pipe (estep.h:
 // estep_component, four MFMAs per component and 16 rows) leaves ||U_k (x_n - m_k)||^2 of sample n = lane & 15 in all four
 // lane groups, so group g keeps the components k = g (mod 4) - which is exactly what a lane owns of a time-major row in
@@ -89,6 +126,9 @@ __global__ __launch_bounds__(256, 2) void hmm_emission_mfma16_kernel(const XT* _
                                                                   const double* __restrict__ cvec, int K,
                                                                   double* __restrict__ rho_tm, double* __restrict__ mx) {
     constexpr int NB = KT == 1 ? 4 : 2, Kp = 16 * KT, IMG = img_doubles(1);      // (row tiles per wave: what the registers hold)
+    __shared__ double s_exp2[64];
+    if (threadIdx.x < 64) s_exp2[threadIdx.x] = kExp2Table64[threadIdx.x];
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int64_t n_tiles = (T + 16 * NB - 1) / (16 * NB);
@@ -150,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void hmm_emission_mfma16_kernel(const XT* _
                 for (int it = 0; it < KT; ++it) {
                     d4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = 16 * it + g + 4 * r < K ? exp(mine[nb][4 * it + r] - m) : 0.0;
+                    for (int r = 0; r < 4; ++r) o[r] = 16 * it + g + 4 * r < K ? exp_nonpos_fast(mine[nb][4 * it + r] - m, s_exp2) : 0.0;
                     *reinterpret_cast<d4*>(rho_tm + stv[nb] * Kp + 16 * it + 4 * g) = o;
                 }
                 if (g == 0) mx[stv[nb]] = m;
