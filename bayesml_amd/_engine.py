@@ -81,6 +81,11 @@ SYMBOLS = {
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "gmmvb_profile_spans": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_int)]),
     "gmmvb_profile_span_name": (ctypes.c_char_p, [_int]),
+    "gmmvb_sample_latent": (_int, [_int, _vp, ctypes.c_uint64, _i64, _i64, _vp, _vp]),
+    "gmmvb_sample_chain_work_bytes": (_i64, [_int, _i64]),
+    "gmmvb_sample_chain": (_int, [_int, _vp, _vp, ctypes.c_uint64, _i64, _vp, _vp, _i64, _vp]),
+    "gmmvb_sample_emissions_work_bytes": (_i64, [_int, _i64]),
+    "gmmvb_sample_emissions": (_int, [_int, _int, _vp, _vp, _vp, ctypes.c_uint64, _i64, _i64, _int, _vp, _i64, _vp, _i64, _vp]),
 }
 
 

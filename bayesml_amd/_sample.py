@@ -2,85 +2,110 @@
 
 The reference draws every row in a Python loop (``_gaussianmixture.py:241-264``: one ``choice`` and one
 ``multivariate_normal`` per row; ``_hiddenmarkovnormal.py:344-358`` the same along a Markov chain), minutes per million
-rows.  Here the latent classes are drawn in one batched pass on the device and the emissions as ``mu_z + eps L_z^-T``
-(``Lambda_z = L_z L_z^T``).  Same distribution, reproducible per seed - but not the reference's random stream (the host
-path of ``gen_sample`` keeps that).  PyTorch is plumbing: nothing here is on the posterior-update path.
+rows.  Here the latent classes and the emissions ``mu_z + eps L_z^-1`` (``Lambda_z = L_z L_z^T``) are drawn by the HIP
+kernels of ``csrc/sample.hip`` behind the C ABI (``gmmvb_sample_*``), on a counter-based stream that
+``numpy.random.Philox(key=[seed, stream])`` reproduces on the host value by value (``include/gmmvb.h``).  Same
+distributions, reproducible per seed - but not the reference's random stream (the host path of ``gen_sample`` keeps that).
+The K-sized preparation (cumulative distributions, Cholesky factors) is host NumPy like every other K-sized read-out;
+PyTorch owns the device memory.  No CPU fallback: without the library and a GPU this raises ``EngineUnavailableError``.
 """
 from __future__ import annotations
 
+import ctypes
+
+import numpy as np
 import torch
 
-
-def emission_factors(lambda_mats: torch.Tensor) -> torch.Tensor:
-    """a [K, D, D] with a_k^T a_k = Lambda_k^-1, so that mu_k + eps a_k ~ N(mu_k, Lambda_k^-1) for eps ~ N(0, I)."""
-    chol = torch.linalg.cholesky(lambda_mats)
-    eye = torch.eye(lambda_mats.shape[-1], dtype=lambda_mats.dtype, device=lambda_mats.device).expand_as(chol)
-    return torch.linalg.solve_triangular(chol, eye, upper=False)
+from . import _engine
 
 
-def draw_emissions(z: torch.Tensor, mu: torch.Tensor, a: torch.Tensor, gen: torch.Generator, dtype, chunk: int = 1 << 22):
-    """x [n, D] of ``dtype``: row i ~ N(mu[z_i], Lambda[z_i]^-1), drawn in f64 in chunks of rows grouped by class."""
-    n, (K, D) = z.shape[0], mu.shape
-    x = torch.empty((n, D), dtype=dtype, device=z.device)
-    for lo in range(0, n, chunk):
-        hi = min(n, lo + chunk)
-        zc = z[lo:hi]
-        eps = torch.randn(hi - lo, D, dtype=torch.float64, device=z.device, generator=gen)
-        order = torch.argsort(zc, stable=True)
-        counts = torch.bincount(zc, minlength=K).tolist()
-        out = torch.empty_like(eps)
-        start = 0
-        for k, c in enumerate(counts):
-            if c:
-                idx = order[start:start + c]
-                out[idx] = mu[k] + eps[idx] @ a[k]
-                start += c
-        x[lo:hi] = out.to(dtype)
+def emission_factors(lambda_mats) -> np.ndarray:
+    """A [K, D, D] lower triangular with A_k^T A_k = Lambda_k^-1 (A_k = L_k^-1, Lambda_k = L_k L_k^T), so that
+    mu_k + eps A_k ~ N(mu_k, Lambda_k^-1) for eps ~ N(0, I)."""
+    return np.linalg.inv(np.linalg.cholesky(np.asarray(lambda_mats, dtype=np.float64)))
+
+
+def _device(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise _engine.EngineUnavailableError(
+            f"gen_sample(device={device!r}): the device sampler is a HIP kernel and needs an MI355X; "
+            "call gen_sample without `device` for the reference's host stream")
+    return torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
+
+
+def _dtype_code(dtype) -> int:
+    if dtype == torch.float32:
+        return _engine.GMMVB_F32
+    if dtype == torch.float64:
+        return _engine.GMMVB_F64
+    raise ValueError("dtype must be torch.float32 or torch.float64")
+
+
+def _up(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def draw_emissions(z: torch.Tensor, mu_vecs, lambda_mats, seed: int, dtype, row0: int = 0, grouped: bool = True,
+                   factors=None) -> torch.Tensor:
+    """x [n, D] of ``dtype``: row i ~ N(mu[z_i], Lambda[z_i]^-1) with the normals of global row ``row0 + i``
+    (``grouped``: the kernel visits the rows class by class - same values, the factors stay in L2)."""
+    lib, dev = _engine.load_library(), z.device
+    mu = np.asarray(mu_vecs, dtype=np.float64)
+    K, D = mu.shape
+    x = torch.empty((z.shape[0], D), dtype=dtype, device=dev)
+    if factors is not None:
+        a_d = _up(factors, dev)
+    elif D <= _engine.MAX_MFMA_DEGREE:
+        # the library's LDS-resident factorisation (gmmvb_kside_factor: Lambda = G G^T, G^-1), one workgroup per class; on a
+        # 256-core host the same K small LAPACK calls cost 0.7 s at K 64, D 128 (profiles/r6_sampler.json)
+        a_d = _engine.kside_factor(_up(lambda_mats, dev))[1]
+    else:
+        a_d = _up(emission_factors(lambda_mats), dev)
+    mu_d = _up(mu, dev)
+    nbytes = max(0, lib.gmmvb_sample_emissions_work_bytes(K, z.shape[0])) if grouped else 0
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+    with torch.cuda.device(dev):
+        _engine._check(lib, lib.gmmvb_sample_emissions(K, D, z.data_ptr(), mu_d.data_ptr(), a_d.data_ptr(), int(seed), int(row0),
+                                                       z.shape[0], _dtype_code(dtype), x.data_ptr(), D,
+                                                       work.data_ptr() if nbytes else None, nbytes, _stream(dev)),
+                       "gmmvb_sample_emissions")
     return x
 
 
-def markov_chain(pi: torch.Tensor, a_mat: torch.Tensor, length: int, gen: torch.Generator, chunk: int = 2048) -> torch.Tensor:
+def mixture(pi_vec, mu_vecs, lambda_mats, n: int, seed: int, device, dtype, row0: int = 0):
+    """(x [n, D], z [n] int64) of the mixture: rows ``row0 .. row0 + n`` of the sample that ``seed`` defines."""
+    lib, dev = _engine.load_library(), _device(device)
+    pi = np.asarray(pi_vec, dtype=np.float64)
+    z = torch.empty(n, dtype=torch.int64, device=dev)
+    cdf = _up(np.cumsum(pi), dev)
+    with torch.cuda.device(dev):
+        _engine._check(lib, lib.gmmvb_sample_latent(pi.shape[0], cdf.data_ptr(), int(seed), int(row0), n, z.data_ptr(), _stream(dev)),
+                       "gmmvb_sample_latent")
+    return draw_emissions(z, mu_vecs, lambda_mats, seed, dtype, row0), z
+
+
+def markov_chain(pi_vec, a_mat, length: int, seed: int, device) -> torch.Tensor:
     """z [length] int64 with z_0 ~ pi, z_t ~ a_mat[z_{t-1}] (reference ``_hiddenmarkovnormal.py:349-357``), without a
-    sequential pass over the sequence: with one uniform u_t per step, step t is the map i -> F_i^-1(u_t) (inverse CDF of
-    row i) on the K states, and maps compose.  The sequence is cut into chunks; pass 1 carries ALL K start states through
-    every chunk at once (chunk-parallel, `chunk` small launches), the chunks' end maps are chained on the host (T / chunk
-    integers), pass 2 replays every chunk from its now known start state."""
-    dev = pi.device
+    sequential pass over the sequence: chunk maps on the K states, composed on the device (``gmmvb_sample_chain``)."""
+    lib, dev = _engine.load_library(), _device(device)
+    pi, a = np.asarray(pi_vec, dtype=np.float64), np.asarray(a_mat, dtype=np.float64)
     K = pi.shape[0]
-    u = torch.rand(length, dtype=torch.float64, device=dev, generator=gen)
-    cdf_pi = torch.cumsum(pi, 0)[:-1].contiguous()                       # [K-1]
-    cdf_a = torch.cumsum(a_mat, 1)[:, :-1].contiguous()                  # [K, K-1]
-    first = int((u[0] >= cdf_pi).sum()) if K > 1 else 0
-    L = max(1, min(int(chunk), length))
-    C = (length + L - 1) // L
-    pad = torch.zeros(C * L, dtype=torch.float64, device=dev)
-    pad[:length] = u
-    U = pad.view(C, L)
-    if K == 1:
-        return torch.zeros(length, dtype=torch.int64, device=dev)
-    # pass 1: every start state through every chunk.  The gathered CDF rows are a [chunks, K, K - 1] temporary per step
-    # (2.5 GB at K = 256, T = 1e7 with all chunks at once): blocks of chunks keep it under 256 MB.
-    blk = max(1, min(C, (256 << 20) // (8 * K * K)))
-    st = torch.arange(K, device=dev).expand(C, K).contiguous()           # [C, K]
-    for c0 in range(0, C, blk):
-        sb, ub = st[c0:c0 + blk], U[c0:c0 + blk]
-        for t in range(L):
-            sb = (ub[:, t, None, None] >= cdf_a[sb]).sum(-1)
-            if t == 0 and c0 == 0:
-                sb[0, :] = first                                          # the sequence's first step draws from pi
-        st[c0:c0 + blk] = sb
-    end = st.cpu()
-    starts = torch.zeros(C, dtype=torch.int64)
-    s = 0
-    for c in range(C - 1):
-        s = int(end[c, s])
-        starts[c + 1] = s
-    # pass 2: replay from the known start states
-    cur = starts.to(dev)
-    Z = torch.empty((C, L), dtype=torch.int64, device=dev)
-    for t in range(L):
-        cur = (U[:, t, None] >= cdf_a[cur]).sum(-1)
-        if t == 0:
-            cur[0] = first
-        Z[:, t] = cur
-    return Z.view(-1)[:length].contiguous()
+    z = torch.empty(length, dtype=torch.int64, device=dev)
+    nbytes = lib.gmmvb_sample_chain_work_bytes(K, length)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    cp, ca = _up(np.cumsum(pi), dev), _up(np.cumsum(a, axis=1), dev)
+    with torch.cuda.device(dev):
+        _engine._check(lib, lib.gmmvb_sample_chain(K, cp.data_ptr(), ca.data_ptr(), int(seed), length, z.data_ptr(), work.data_ptr(),
+                                                   nbytes, _stream(dev)), "gmmvb_sample_chain")
+    return z
+
+
+def hidden_markov(pi_vec, a_mat, mu_vecs, lambda_mats, length: int, seed: int, device, dtype):
+    """(x [T, D], z [T] int64) of the HMM."""
+    z = markov_chain(pi_vec, a_mat, length, seed, device)
+    return draw_emissions(z, mu_vecs, lambda_mats, seed, dtype), z

@@ -141,10 +141,10 @@ class GenModel(base.Generative):
         """(x [n, D], one-hot z [n, K]); one ``choice`` + one ``multivariate_normal`` per row so the
         stream matches the reference for a given seed (ref:241-264).
 
-        Extension: with ``device`` (e.g. ``"cuda"``) the sample is drawn ON that device in one batched pass and
-        returned as torch tensors ``(x [n, D] of ``dtype``, z [n] int64 class indices)`` - the reference's per-row
-        Python loop takes minutes per million rows.  The device generator is seeded from ``self.rng`` (reproducible
-        for a given ``seed``), but the stream is not the reference's."""
+        Extension: with ``device`` (e.g. ``"cuda"``) the sample is drawn ON that device by HIP kernels and returned as
+        torch tensors ``(x [n, D] of ``dtype``, z [n] int64 class indices)`` - the reference's per-row Python loop takes
+        minutes per million rows.  The stream is Philox4x64-10 keyed by a seed drawn from ``self.rng`` (reproducible for
+        a given ``seed``, and on the host with ``numpy.random.Philox``), not the reference's."""
         _check.pos_int(sample_size, "sample_size", DataFormatError)
         if device is not None:
             return self._gen_sample_device(int(sample_size), torch.device(device), dtype)
@@ -158,17 +158,12 @@ class GenModel(base.Generative):
         return x, z
 
     def _gen_sample_device(self, n, dev, dtype):
-        """z ~ Categorical(pi_vec), x = mu_z + eps L_z^-T with Lambda_z = L_z L_z^T (``bayesml_amd._sample``)."""
+        """z ~ Categorical(pi_vec), x = mu_z + eps L_z^-1 with Lambda_z = L_z L_z^T: HIP kernels over the Philox stream
+        of a seed drawn from ``self.rng`` (``bayesml_amd._sample``, ``gmmvb_sample_latent`` / ``gmmvb_sample_emissions``);
+        the seed of the last device sample stays readable as ``self.device_sample_seed``."""
         from .. import _sample
-        gen = torch.Generator(device=dev).manual_seed(int(self.rng.integers(0, 2 ** 63 - 1)))
-        pi = torch.as_tensor(self.pi_vec, dtype=torch.float64, device=dev)
-        mu = torch.as_tensor(self.mu_vecs, dtype=torch.float64, device=dev)
-        a = _sample.emission_factors(torch.as_tensor(self.lambda_mats, dtype=torch.float64, device=dev))
-        z = torch.empty(n, dtype=torch.int64, device=dev)
-        for lo in range(0, n, 1 << 22):
-            hi = min(n, lo + (1 << 22))
-            z[lo:hi] = torch.multinomial(pi, hi - lo, replacement=True, generator=gen)
-        return _sample.draw_emissions(z, mu, a, gen, dtype), z
+        self.device_sample_seed = int(self.rng.integers(0, 2 ** 63 - 1))
+        return _sample.mixture(self.pi_vec, self.mu_vecs, self.lambda_mats, n, self.device_sample_seed, dev, dtype)
 
     def save_sample(self, filename, sample_size):
         """``numpy.savez_compressed(filename, x=x, z=z)`` (ref:266-284)."""

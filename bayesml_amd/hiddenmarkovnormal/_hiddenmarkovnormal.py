@@ -137,18 +137,17 @@ class GenModel(base.Generative):
     def gen_sample(self, sample_length, *, device=None, dtype=torch.float64):
         """(x [T, D], one-hot z [T, K]) with the reference's per-step draws (ref:344-358).
 
-        Extension: with ``device`` (e.g. ``"cuda"``) the sequence is drawn ON that device - the Markov chain as a
-        chunk-parallel composition of per-step state maps, the emissions in one batched pass (``bayesml_amd._sample``) -
-        and returned as torch tensors ``(x [T, D] of ``dtype``, z [T] int64 state indices)``; the reference's loop takes
-        2.4 s per 2e4 steps.  Seeded from ``self.rng`` (reproducible per ``seed``), not the reference's stream."""
+        Extension: with ``device`` (e.g. ``"cuda"``) the sequence is drawn ON that device by HIP kernels - the Markov
+        chain as a chunk-parallel composition of per-step state maps (``gmmvb_sample_chain``), the emissions in one pass
+        (``gmmvb_sample_emissions``) - and returned as torch tensors ``(x [T, D] of ``dtype``, z [T] int64 state
+        indices)``; the reference's loop takes 2.4 s per 2e4 steps.  The stream is Philox4x64-10 keyed by a seed drawn
+        from ``self.rng`` (reproducible per ``seed``, and on the host with ``numpy.random.Philox``), not the reference's."""
         _check.pos_int(sample_length, "sample_length", DataFormatError)
         if device is not None:
             from .. import _sample
-            dev = torch.device(device)
-            gen = torch.Generator(device=dev).manual_seed(int(self.rng.integers(0, 2 ** 63 - 1)))
-            t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)      # noqa: E731
-            z = _sample.markov_chain(t(self.pi_vec), t(self.a_mat), int(sample_length), gen)
-            return _sample.draw_emissions(z, t(self.mu_vecs), _sample.emission_factors(t(self.lambda_mats)), gen, dtype), z
+            self.device_sample_seed = int(self.rng.integers(0, 2 ** 63 - 1))
+            return _sample.hidden_markov(self.pi_vec, self.a_mat, self.mu_vecs, self.lambda_mats, int(sample_length),
+                                         self.device_sample_seed, device, dtype)
         K = self.c_num_classes
         z = np.zeros([sample_length, K], dtype=int)
         x = np.empty([sample_length, self.c_degree])

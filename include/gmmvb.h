@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GMMVB_ABI_VERSION 7
+#define GMMVB_ABI_VERSION 8
 
 enum gmmvb_status {
     GMMVB_OK = 0,
@@ -402,6 +402,38 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
  * 256 rows, component) columns of the per-pair bound array it had to go through, of ceil(n_rows / 256) * K (-1: the pass
  * was no sweep, or GMMVB_SWEEP_LAZY=0); out[7] reserved (0). */
 int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[8], host*/);
+
+/* ---- device-side data generation (ABI v8) -------------------------------------------------------------
+ * GenModel.gen_sample of the mixture (bayesml/gaussianmixture/_gaussianmixture.py:241-264: a `choice` and a
+ * `multivariate_normal` per row in a Python loop) and of the HMM (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py:344-358,
+ * the same along a Markov chain) as kernels over a COUNTER-BASED stream that the host can reproduce value by value:
+ * Philox4x64-10 exactly as numpy.random.Philox(key=[seed, stream]) runs it (block L of four 64-bit outputs comes from the
+ * counter value L + 1).  Stream 0 carries one uniform per row / time step t, u_t = (raw_t >> 11) 2^-53; the class drawn
+ * from an inclusive cumulative distribution cdf[K] is the number of its first K - 1 entries that are <= u.  Stream 1 carries
+ * the normals: row r owns the ceil(D / 4) blocks from r ceil(D / 4) on, a block (r0..r3) gives four normals by Box-Muller
+ * (sqrt(-2 ln(1 - (r0 >> 11) 2^-53)) (cos, sin)(2 pi (r1 >> 11) 2^-53), the same from (r2, r3)).  Rows are numbered
+ * globally: `row0` is the number of z_dev[0] / x_dev's first row, so any window of a sample can be drawn on its own (row
+ * shards, tiles).  Not the reference's own stream (PCG64 through Generator.choice / multivariate_normal): same
+ * distributions, reproducible per seed; the host path of gen_sample keeps the reference's stream. */
+/* z[t] ~ Categorical(pi), t in [row0, row0 + n_rows): cdf_dev = inclusive cumulative sums of pi [K] */
+int gmmvb_sample_latent(int K, const double* cdf_dev /*[K]*/, uint64_t seed, int64_t row0, int64_t n_rows,
+                        int64_t* z_dev /*[n_rows]*/, void* stream);
+/* z[0] ~ pi, z[t] ~ a_mat[z[t-1]] for a whole sequence [0, n_rows) without a sequential pass over it: chunks of 256 steps
+ * carry all K start states at once (a step is a map on the states and maps compose), groups of 256 chunk maps are composed
+ * the same way, one thread chains the groups, and the start states flow back down - five launches, no host round trip.
+ * work_dev: gmmvb_sample_chain_work_bytes(K, n_rows) bytes of 256-byte aligned scratch. */
+int64_t gmmvb_sample_chain_work_bytes(int K, int64_t n_rows);
+int gmmvb_sample_chain(int K, const double* cdf_pi_dev /*[K]*/, const double* cdf_a_dev /*[K][K] row-wise cumulative*/,
+                       uint64_t seed, int64_t n_rows, int64_t* z_dev /*[n_rows]*/, void* work_dev, int64_t work_bytes,
+                       void* stream);
+/* x[r] = mu[z[r]] + eps_r A[z[r]] in f64, stored as x_dtype; A[k] lower triangular with A[k]^T A[k] = Lambda_k^-1
+ * (A = L^-1 for Lambda = L L^T); eps_r = the D normals of global row row0 + r.  D <= 600.  work_dev (optional, NULL = none):
+ * gmmvb_sample_emissions_work_bytes(K, n_rows) bytes of scratch in which the rows are grouped by class first, so that the
+ * factors are read from L2 - same values, about ten times faster once K D^2 doubles exceed an L2. */
+int64_t gmmvb_sample_emissions_work_bytes(int K, int64_t n_rows);
+int gmmvb_sample_emissions(int K, int D, const int64_t* z_dev /*[n_rows]*/, const double* mu_dev /*[K][D]*/,
+                           const double* a_dev /*[K][D][D]*/, uint64_t seed, int64_t row0, int64_t n_rows, int x_dtype,
+                           void* x_dev, int64_t ldx, void* work_dev, int64_t work_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_engine.SYMBOLS) == declared, "ctypes table and header disagree"
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.gmmvb_abi_version() == 7
+    assert lib.gmmvb_abi_version() == 8
     assert lib.gmmvb_stats_len(64, 128) == 64 * (2 + 128 + 128 * 128)
     assert lib.gmmvb_stats_len(0, 4) == -1
     assert lib.gmmvb_stats_packed_len(64, 128) == 64 * (2 + 128 + 128 * 129 // 2)

@@ -1,14 +1,17 @@
 """``GenModel.gen_sample(..., device=...)`` (reference ``_gaussianmixture.py:241-264``,
-``_hiddenmarkovnormal.py:344-358``): the batched device samplers draw from the reference's distributions and are
-reproducible per seed.  CPU tests run the same torch code on the "cpu" device; the ``gpu`` tests run it at 1e6 rows on
-the MI355X."""
+``_hiddenmarkovnormal.py:344-358``).  The device samplers are HIP kernels over a counter-based stream
+(Philox4x64-10 = ``numpy.random.Philox``), so the ``gpu`` tests compare them VALUE BY VALUE with the host restatement
+``oracle/sampler_oracle.py`` - class indices exactly, emissions to f64 rounding (the device's log / sincospi against
+NumPy's; the tolerance is written at each comparison) - and the CPU tests pin that restatement: NumPy's generator against
+the Random123 known answers, the host stream's distributions against the reference's."""
 import numpy as np
 import pytest
 import torch
 
-from bayesml_amd import _sample
+from bayesml_amd import _engine, _sample
 from bayesml_amd import gaussianmixture as gm
 from bayesml_amd import hiddenmarkovnormal as hm
+from oracle import sampler_oracle as so
 
 
 def _gmm(K, D, seed):
@@ -29,8 +32,6 @@ def _hmm(K, D, seed):
 
 def _check_emissions(x, z, mu, lam, n_min=2000):
     """Per class: sample mean within 5 sigma of mu_k, sample covariance close to Lambda_k^-1."""
-    x = x.double().cpu().numpy()
-    z = z.cpu().numpy()
     for k in range(mu.shape[0]):
         rows = x[z == k]
         if rows.shape[0] < n_min:
@@ -42,70 +43,111 @@ def _check_emissions(x, z, mu, lam, n_min=2000):
         assert np.max(np.abs(emp - cov)) < 8 * np.max(np.abs(cov)) / np.sqrt(rows.shape[0]), k
 
 
-def test_markov_chain_equals_the_sequential_recursion():
-    rng = np.random.default_rng(0)
-    K, T = 5, 7001
-    pi, a = rng.dirichlet(np.ones(K)), rng.dirichlet(np.ones(K) * 0.5, K)
-    for chunk in (1, 64, 999, 7001, 20000):
-        gen = torch.Generator().manual_seed(42)
-        z = _sample.markov_chain(torch.tensor(pi), torch.tensor(a), T, gen, chunk=chunk).numpy()
-        gen = torch.Generator().manual_seed(42)
-        u = torch.rand(T, dtype=torch.float64, generator=gen).numpy()
-        cp, ca = np.cumsum(pi)[:-1], np.cumsum(a, axis=1)[:, :-1]
-        s = int((u[0] >= cp).sum())
-        seq = [s]
-        for t in range(1, T):
-            s = int((u[t] >= ca[s]).sum())
-            seq.append(s)
-        assert np.array_equal(z, np.array(seq)), chunk
-    one = _sample.markov_chain(torch.ones(1, dtype=torch.float64), torch.ones(1, 1, dtype=torch.float64), 10,
-                               torch.Generator().manual_seed(0))
-    assert one.tolist() == [0] * 10
+# ---- the host stream (CPU) ---------------------------------------------------------------------------------------------
+
+def test_numpy_philox_is_random123_philox4x64_10():
+    """Known answers of Random123's kat_vectors for philox4x64-10, on the independent pure-Python statement; NumPy's
+    generator, the oracle's and the device's stream, equals that statement on the counter value L + 1."""
+    F = (1 << 64) - 1
+    kat = [([0, 0, 0, 0], [0, 0], [0x16554d9eca36314c, 0xdb20fe9d672d0fdc, 0xd7e772cee186176b, 0x7e68b68aec7ba23b]),
+           ([F] * 4, [F, F], [0x87b092c3013fe90b, 0x438c3c67be8d0224, 0x9cc7d7c69cd777b6, 0xa09caebf594f0ba0]),
+           ([0x243f6a8885a308d3, 0x13198a2e03707344, 0xa4093822299f31d0, 0x082efa98ec4e6c89],
+            [0x452821e638d01377, 0xbe5466cf34e90c6c],
+            [0xa528f45403e61d95, 0x38c72dbd566e9788, 0xa5a1610e72fd18b5, 0x57bd43b5e52b7fe6])]
+    for ctr, key, want in kat:
+        assert so.philox4x64_10(ctr, key) == want
+    for seed, stream, first in ((0, 0, 0), (987654321987, 1, 12345678901234), (2 ** 63 - 2, 1, 2 ** 40 + 3)):
+        raw = so.raw_blocks(seed, stream, first, 3)
+        for i in range(3):
+            assert [int(v) for v in raw[i]] == so.philox4x64_10([first + i + 1, 0, 0, 0], [seed, stream])
 
 
-def test_gmm_device_sampler_on_cpu():
+def test_host_stream_windows_and_distributions():
+    seed = 4242
+    u = so.latent_uniforms(seed, 0, 1003)
+    for row0, n in ((0, 5), (1, 7), (3, 1), (6, 997), (1000, 3)):
+        assert np.array_equal(so.latent_uniforms(seed, row0, n), u[row0:row0 + n])
+    eps = so.normals(seed, 0, 200, 7)
+    assert np.array_equal(so.normals(seed, 150, 50, 7), eps[150:])
+    big = so.normals(seed, 0, 100000, 6)
+    assert abs(big.mean()) < 5 / np.sqrt(big.size) and abs(big.var() - 1) < 0.01
+    assert np.max(np.abs(np.corrcoef(big.T) - np.eye(6))) < 0.02
     g = _gmm(3, 4, seed=1)
-    x, z = g.gen_sample(60000, device="cpu", dtype=torch.float32)
-    assert x.shape == (60000, 4) and x.dtype == torch.float32 and z.dtype == torch.int64
-    freq = np.bincount(z.numpy(), minlength=3) / 60000
-    assert np.max(np.abs(freq - g.pi_vec)) < 5 * np.sqrt(0.25 / 60000)
+    z = so.mixture_latent(g.pi_vec, seed, 0, 60000)
+    assert np.max(np.abs(np.bincount(z, minlength=3) / 60000 - g.pi_vec)) < 5 * np.sqrt(0.25 / 60000)
+    x = so.emissions(z, g.mu_vecs, so.emission_factors(g.lambda_mats), seed)
     _check_emissions(x, z, g.mu_vecs, g.lambda_mats)
-    x2, z2 = _gmm(3, 4, seed=1).gen_sample(60000, device="cpu", dtype=torch.float32)
-    assert torch.equal(x, x2) and torch.equal(z, z2)
-    x3, _z3 = _gmm(3, 4, seed=2).gen_sample(60000, device="cpu", dtype=torch.float32)
-    assert not torch.equal(x, x3)
-
-
-def test_hmm_device_sampler_on_cpu():
-    g = _hmm(4, 3, seed=1)
-    T = 80000
-    x, z = g.gen_sample(T, device="cpu")
-    assert x.shape == (T, 3) and x.dtype == torch.float64 and z.shape == (T,)
-    zz = z.numpy()
+    h = _hmm(4, 3, seed=1)
+    zz = so.markov_chain(h.pi_vec, h.a_mat, seed, 80000)
     cnt = np.zeros((4, 4))
     np.add.at(cnt, (zz[:-1], zz[1:]), 1)
-    emp = cnt / cnt.sum(axis=1, keepdims=True)
-    assert np.max(np.abs(emp - g.a_mat)) < 6 * np.sqrt(0.25 / cnt.sum(axis=1).min())
-    _check_emissions(x, z, g.mu_vecs, g.lambda_mats)
-    x2, z2 = _hmm(4, 3, seed=1).gen_sample(T, device="cpu")
-    assert torch.equal(x, x2) and torch.equal(z, z2)
-    # the host path is still the reference's stream (tests/test_host_logic_hmm.py); both accept the same arguments
+    assert np.max(np.abs(cnt / cnt.sum(axis=1, keepdims=True) - h.a_mat)) < 6 * np.sqrt(0.25 / cnt.sum(axis=1).min())
+
+
+def test_device_sampler_has_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_engine.EngineUnavailableError):
+        _gmm(3, 4, seed=1).gen_sample(10, device="cuda")
+    with pytest.raises(_engine.EngineUnavailableError):
+        _hmm(3, 4, seed=1).gen_sample(10, device="cpu")
+    # the host path is still the reference's stream (tests/test_host_logic*.py); both accept the same arguments
     xh, zh = _hmm(4, 3, seed=1).gen_sample(50)
     assert xh.shape == (50, 3) and zh.shape == (50, 4) and np.all(zh.sum(axis=1) == 1)
 
 
+# ---- the HIP kernels against the host stream (GPU) -----------------------------------------------------------------------
+
+EPS_TOL = 2e-13      # |x_dev - x_host| <= EPS_TOL * (1 + |x|): f64 log / sincospi / summation order against NumPy's
+
+
 @pytest.mark.gpu
-def test_gmm_device_sampler_on_gpu():
+@pytest.mark.parametrize("K,D,n,dtype", [(16, 32, 200_000, torch.float64), (3, 2, 1001, torch.float64),
+                                         (64, 128, 20_000, torch.float32), (5, 37, 4099, torch.float64),
+                                         (1, 1, 17, torch.float64), (7, 130, 3000, torch.float32)])
+def test_gmm_device_sampler_equals_the_host_stream(K, D, n, dtype):
+    g = _gmm(K, D, seed=3)
+    x, z = g.gen_sample(n, device="cuda:0", dtype=dtype)
+    assert x.is_cuda and x.shape == (n, D) and x.dtype == dtype and z.dtype == torch.int64
+    seed = g.device_sample_seed
+    z_host = so.mixture_latent(g.pi_vec, seed, 0, n)
+    assert np.array_equal(z.cpu().numpy(), z_host)
+    x_host = so.emissions(z_host, g.mu_vecs, so.emission_factors(g.lambda_mats), seed)
+    xd = x.double().cpu().numpy()
+    tol = EPS_TOL if dtype == torch.float64 else 1.2e-7          # f32 storage: one rounding of the f64 value
+    assert np.all(np.abs(xd - x_host) <= tol * (1 + np.abs(x_host)))
+    # reproducible per model seed, different across seeds
+    x2, z2 = _gmm(K, D, seed=3).gen_sample(n, device="cuda:0", dtype=dtype)
+    assert torch.equal(x, x2) and torch.equal(z, z2)
+    if n > 100:
+        x3, _z3 = _gmm(K, D, seed=4).gen_sample(n, device="cuda:0", dtype=dtype)
+        assert not torch.equal(x, x3)
+
+
+@pytest.mark.gpu
+def test_gmm_device_sampler_windows_and_learner():
+    """Any window of a sample can be drawn on its own (row shards); the sample feeds the learner without leaving the
+    device."""
     g = _gmm(16, 32, seed=3)
     n = 1_000_000
-    x, z = g.gen_sample(n, device="cuda:0", dtype=torch.float32)
-    assert x.is_cuda and x.shape == (n, 32) and x.dtype == torch.float32
+    seed = 77
+    x, z = _sample.mixture(g.pi_vec, g.mu_vecs, g.lambda_mats, n, seed, "cuda:0", torch.float32)
+    for row0, m in ((0, 1000), (333_331, 4097), (n - 5, 5)):
+        xw, zw = _sample.mixture(g.pi_vec, g.mu_vecs, g.lambda_mats, m, seed, "cuda:0", torch.float32, row0=row0)
+        assert torch.equal(zw, z[row0:row0 + m]) and torch.equal(xw, x[row0:row0 + m])
+    # the class-grouped visit order of the emission kernel changes no value that f32 storage keeps (the plain kernel sums
+    # a row's products in two interleaved chains, the grouped one in one)
+    plain = _sample.draw_emissions(z[:200_000], g.mu_vecs, g.lambda_mats, seed, torch.float64, grouped=False)
+    grouped = _sample.draw_emissions(z[:200_000], g.mu_vecs, g.lambda_mats, seed, torch.float64)
+    assert float((plain - grouped).abs().max()) < 1e-13 * float(plain.abs().max())
+    row0 = 900_000
+    z_host = so.mixture_latent(g.pi_vec, seed, row0, 2000)
+    assert np.array_equal(z[row0:row0 + 2000].cpu().numpy(), z_host)
+    x_host = so.emissions(z_host, g.mu_vecs, so.emission_factors(g.lambda_mats), seed, row0=row0)
+    assert np.all(np.abs(x[row0:row0 + 2000].double().cpu().numpy() - x_host) <= 1.2e-7 * (1 + np.abs(x_host)))
     freq = torch.bincount(z, minlength=16).double().cpu().numpy() / n
     assert np.max(np.abs(freq - g.pi_vec)) < 5 * np.sqrt(0.25 / n)
-    _check_emissions(x, z, g.mu_vecs, g.lambda_mats)
-    x2, z2 = _gmm(16, 32, seed=3).gen_sample(n, device="cuda:0", dtype=torch.float32)
-    assert torch.equal(x, x2) and torch.equal(z, z2)
-    # the sample feeds the learner without leaving the device
+    _check_emissions(x.double().cpu().numpy(), z.cpu().numpy(), g.mu_vecs, g.lambda_mats)
     m = gm.LearnModel(16, 32, seed=0, device="cuda:0", verbose=False)
     import warnings
     with warnings.catch_warnings():
@@ -115,16 +157,40 @@ def test_gmm_device_sampler_on_gpu():
 
 
 @pytest.mark.gpu
-def test_hmm_device_sampler_on_gpu():
+@pytest.mark.parametrize("K,D,T", [(8, 16, 100_003), (4, 2, 500), (32, 16, 70_000), (1, 3, 300), (300, 2, 20_000),
+                                   (5, 3, 255), (5, 3, 256), (5, 3, 257), (3, 2, 65_537)])
+def test_hmm_device_sampler_equals_the_sequential_recursion(K, D, T):
+    g = _hmm(K, D, seed=4)
+    x, z = g.gen_sample(T, device="cuda:0", dtype=torch.float64)
+    assert x.is_cuda and x.shape == (T, D) and z.shape == (T,) and z.dtype == torch.int64
+    seed = g.device_sample_seed
+    z_host = so.markov_chain(g.pi_vec, g.a_mat, seed, T)
+    assert np.array_equal(z.cpu().numpy(), z_host)
+    x_host = so.emissions(z_host, g.mu_vecs, so.emission_factors(g.lambda_mats), seed)
+    assert np.all(np.abs(x.cpu().numpy() - x_host) <= EPS_TOL * (1 + np.abs(x_host)))
+    x2, z2 = _hmm(K, D, seed=4).gen_sample(T, device="cuda:0", dtype=torch.float64)
+    assert torch.equal(x, x2) and torch.equal(z, z2)
+
+
+@pytest.mark.gpu
+def test_hmm_device_sampler_full_length():
+    """T = 1e7 (config 5): the chain's transition frequencies and the emissions' moments; the first and the last 1e4
+    steps given the state before them equal the sequential recursion."""
     g = _hmm(8, 16, seed=4)
-    T = 1_000_000
+    T = 10_000_000
     x, z = g.gen_sample(T, device="cuda:0", dtype=torch.float32)
-    assert x.is_cuda and x.shape == (T, 16) and z.shape == (T,)
+    seed = g.device_sample_seed
     zz = z.cpu().numpy()
+    assert np.array_equal(zz[:10000], so.markov_chain(g.pi_vec, g.a_mat, seed, 10000))
+    u = so.latent_uniforms(seed, T - 10000, 10000)
+    ca = np.cumsum(g.a_mat, axis=1)
+    s = int(zz[T - 10001])
+    for t in range(10000):
+        s = int(np.searchsorted(ca[s, :-1], u[t], side="right"))
+        assert s == zz[T - 10000 + t]
     cnt = np.zeros((8, 8))
     np.add.at(cnt, (zz[:-1], zz[1:]), 1)
     emp = cnt / cnt.sum(axis=1, keepdims=True)
     assert np.max(np.abs(emp - g.a_mat)) < 6 * np.sqrt(0.25 / cnt.sum(axis=1).min())
-    _check_emissions(x, z, g.mu_vecs, g.lambda_mats)
-    x2, z2 = _hmm(8, 16, seed=4).gen_sample(T, device="cuda:0", dtype=torch.float32)
-    assert torch.equal(x, x2) and torch.equal(z, z2)
+    sub = slice(0, 2_000_000)
+    _check_emissions(x[sub].double().cpu().numpy(), zz[sub], g.mu_vecs, g.lambda_mats)
