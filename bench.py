@@ -11,16 +11,20 @@ variational lower bound (one host sync).  x is resident in HBM before the timed 
 
 ``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N rank processes itself (before this
 process touches a GPU); under ``python -m torch.distributed.run`` the ranks come from the environment.  Every rank
-joins an RCCL ("nccl") process group and the JSON line reports ``rccl_ranks``.
+joins an RCCL ("nccl") process group and the JSON line reports ``ranks`` and ``backend``.  A SIGTERM / SIGINT to the parent
+stops every rank (they run in their own sessions).
 
 Configurations (BASELINE.json ``configs``): c3 = K64 D128 N1e7 f32 (default, the one the metric is quoted on),
 c4 = K256 D64 1.25e7 rows per GPU (N = 1e8 over 8 GPUs), c2 = K16 D32 N1e6 f64.  ``--scaling weak`` (default):
 every rank holds the configuration's rows; ``--scaling strong``: ``--total-rows`` are split over the ranks.
 
 Output: stdout carries ONE compact JSON line (< 6 KB: the contract's keys, `roofline`, `cpu_baseline`, both parity legs,
-`window`, `full_fit_seconds`, `dense_floor_samples_per_s`, an `hmm_c5` sub-line); the full record with every leg, per-step
-lists and kernel groups goes to ``--detail`` (default gpurun_out/bench_detail.json).  Default legs: dense, full, hmm
-(~20 s); hard, spread, offpath, small on request (``--legs all``).
+`window`, `full_fit_seconds`, `dense_floor_samples_per_s`, the sub-lines `hmm_c5`, `c2`, `c4_shard`, `c4_strong`); the full
+record with every leg, per-step lists and kernel groups goes to ``--detail`` (default gpurun_out/bench_detail.json).
+Default legs: dense, full, hmm, c2, c4, c4strong (about a minute); hard, spread, offpath, small on request (``--legs all``).
+With ``--gpus N`` > 1 the line carries the C3 weak-scaling window and, as `c4_strong`, config 4's N = 1e8 split over the N
+ranks (ms_per_step, per_rank_ms_per_step, allreduce_ms from its own HIP events, estep_kinds_identical_across_ranks); the
+one-GPU record carries the same job as resident row tiles - the strong-scaling curve is the ratio of those sub-lines.
 
 Legs of the single-GPU run (full record):
   value/roofline  the default policy (sparse where the responsibilities are), timed
@@ -34,6 +38,9 @@ Legs of the single-GPU run (full record):
   offpath         off the headline's recipe at N = 2e6: K_model = 2 K_data, mixing weights ~ Dirichlet(0.3), anisotropic clusters -
                   default policy against dense kernels only and an oracle parity run under both policies (opt-in: --legs)
   hmm_c5          BASELINE.json configs[4]: hiddenmarkovnormal.LearnModel K=32, D=16, T=1e7 (tools/bench_hmm.py's measurement)
+  c2, c4_shard    BASELINE.json configs[1] (K16 D32 N1e6 f64) and one GPU's shard of configs[3] (K256 D64, 1.25e7 rows):
+                  VB iterations 6-25 of one restart, dominant kernel, frac_executed and frac_on_F
+  c4_strong       configs[3] itself: N = 1e8 over all ranks (one GPU: eight resident row tiles)
   small_c1        BASELINE.json configs[0] (K=3, D=2, N=1000) with the reference's defaults: the one-launch path and the
                   general engine
   cpu_baseline    the oracle (NumPy port of the reference's formulation) on this host's cores, 10 VB iterations over
@@ -42,7 +49,10 @@ Legs of the single-GPU run (full record):
                   default policy (dense kernels at that size) and with the sparse path forced (int8 bound pass,
                   carried bounds, candidate gathers, list M-step - the kernels of the timed steps)
 
-roofline: every kernel group carries both fractions - ``hbm_frac`` = algorithmic bytes (rows it
+roofline: `frac` = `frac_executed` = f64 MFMA flops the dominant kernel issued / its HIP-event time /
+78.6 TFLOP/s (a utilisation); `frac_on_F` = SURVEY 8d's dense flop count F of that phase x rows / the same time / the same
+peak (>> 1 on the pruned path: an algorithmic saving, not a utilisation); `step_frac_on_F` the same for the whole step.
+Every kernel group carries both fractions - ``hbm_frac`` = algorithmic bytes (rows it
 has to read x D x s) / its HIP-event time / 8 TB/s, ``f64_mfma_frac`` = executed f64 MFMA flops / 78.6 TFLOP/s -
 and ``bound`` names the larger; the line's bound / achieved / peak / frac are the dominant group's.  ``step_hbm_frac`` = the
 whole step's N D s bytes / step time / 8 TB/s (= value / HBM-roofline samples/s).  ``per_rank``: every rank's own step times.
@@ -88,9 +98,13 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the dense, hard-workload, spread-sweep, full-fit and HMM legs")
-    ap.add_argument("--legs", default="dense,full,hmm",
-                    help="comma-separated legs of the single-GPU run (dense, full, hmm by default: about 20 s together; "
-                         "hard, spread, offpath, small on request; 'all' = every leg)")
+    ap.add_argument("--legs", default="dense,full,hmm,c2,c4,c4strong",
+                    help="comma-separated legs (dense, full, hmm and the sub-lines c2, c4 (one shard of config 4), c4strong "
+                         "(config 4's N = 1e8 over all ranks; on one GPU as resident row tiles) by default: about a minute "
+                         "together; hard, spread, offpath, small on request; 'all' = every leg).  With --gpus N > 1 only "
+                         "c4strong runs")
+    ap.add_argument("--strong-total-rows", type=int, default=CONFIGS["c4"]["total"],
+                    help="rows of the whole job in the c4strong sub-line (default config 4's 1e8)")
     ap.add_argument("--detail", default=os.path.join("gpurun_out", "bench_detail.json"),
                     help="file that receives the full record (every leg, per-step lists, kernel groups); stdout carries "
                          "only the compact line.  '' = do not write it, '-' = print it on stdout BEFORE the compact line")
@@ -141,32 +155,64 @@ def launch_ranks(n):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("NCCL_DEBUG", "WARN")
-        # fresh child processes, each in its own session (never a re-exec of a process that has touched a GPU)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      start_new_session=True))
-    # a rank that dies (its own watchdog, an RCCL error) must take the others down instead of leaving them in a collective
+    import signal
+
+    def stop_ranks(grace=5.0):
+        """SIGTERM to every live rank's process group (each rank is the leader of its own session), SIGKILL after `grace`."""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)          # the exact process groups started below
+            except OSError:
+                pass
+        end = time.time() + grace
+        while time.time() < end and any(p.poll() is None for p in live):
+            time.sleep(0.1)
+        for p in live:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+
+    def on_signal(signum, _frame):
+        # `timeout ... python bench.py --gpus N` or Ctrl-C reaches only this parent: the ranks live in their own sessions
+        # and would run on as orphans inside a collective, holding the GPUs
+        print(f"bench.py: signal {signum}; stopping the rank processes", file=sys.stderr)
+        stop_ranks()
+        os._exit(128 + signum)
+
+    old_handlers = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
     rc = 0
-    alive = list(procs)
-    while alive:
-        time.sleep(0.2)
-        for p in list(alive):
-            code = p.poll()
-            if code is None:
-                continue
-            alive.remove(p)
-            if code != 0:
-                rc = max(rc, abs(code) or 1)
-                print(f"bench.py: rank process {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
-                for q in alive:
-                    try:
-                        os.killpg(q.pid, 15)          # the exact process groups started above
-                    except OSError:
-                        pass
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("NCCL_DEBUG", "WARN")
+            # fresh child processes, each in its own session (never a re-exec of a process that has touched a GPU)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          start_new_session=True))
+        # a rank that dies (its own watchdog, an RCCL error) must take the others down instead of leaving them in a collective
+        alive = list(procs)
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:           # (the ranks stopped below exit with -SIGTERM: the first failure is the job's)
+                    rc = abs(code) or 1
+                    print(f"bench.py: rank process {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    stop_ranks()
+    except BaseException:
+        rc = rc or 1
+        raise
+    finally:
+        stop_ranks()               # (no-op when every rank has exited)
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
     return rc
 
 
@@ -221,32 +267,53 @@ class env_vars:
                 os.environ[k] = v
 
 
-def cpu_baseline_and_parity(K, D, x_ref, dev, iters=10):
+def cpu_baseline_and_parity(K, D, x_ref, dev, iters=10, sweep_threads=False):
     """Oracle (test infrastructure) on the host cores vs the GPU driver on the same rows: with the default policy and
     with the sparse path forced (the kernels of the timed steps: int8 bound pass, carried bounds, gathers, lists)."""
     from bayesml_amd import gaussianmixture as gm
     from oracle import gmm_vb_oracle as orc
+    import copy
     x64 = x_ref.astype(np.float64)
     p = orc.Prior.default(K, D)
     q = orc.Posterior.from_prior(p)
     orc.init_subsampling(x64, q, np.random.default_rng(0))
     st = orc.data_pass(x64, q)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        orc.update_q_mu_lambda(p, q, st)
-        orc.update_q_pi(p, q, st)
-        st = orc.data_pass(x64, q, st.s)
-        orc.lower_bound(p, q, st)
-    cpu_s = time.perf_counter() - t0
+
+    def iterate(q_, st_, n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            orc.update_q_mu_lambda(p, q_, st_)
+            orc.update_q_pi(p, q_, st_)
+            st_ = orc.data_pass(x64, q_, st_.s)
+            orc.lower_bound(p, q_, st_)
+        return time.perf_counter() - t0, st_
+
+    # The host's best: one iteration per BLAS thread count on a copy of the state, then the timed run at the fastest
+    # (128 OpenBLAS threads on [20000, 128] operands is oversubscription - round 5 reported 6.2e3 samples/s that way against
+    # the 1.1e4 BASELINE.md section 2 measured on 8 cores)
+    sweep, limits = {}, None
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_info, threadpool_limits
+        default_threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        if sweep_threads:
+            for t in sorted({t for t in (8, 16, 32, 64, 128) if t <= default_threads} | {default_threads}):
+                with threadpool_limits(limits=t):
+                    s_t, _ = iterate(copy.deepcopy(q), copy.deepcopy(st), 1)
+                sweep[t] = x_ref.shape[0] / s_t
+            limits = max(sweep, key=sweep.get)
+        threads = limits or default_threads
     except Exception:      # noqa: BLE001
         threads = os.cpu_count() or 1
+    if limits:
+        with threadpool_limits(limits=limits):
+            cpu_s, st = iterate(q, st, iters)
+    else:
+        cpu_s, st = iterate(q, st, iters)
     base = dict(value=x_ref.shape[0] * iters / cpu_s, unit="samples/s", cores=int(threads), kind="port",
-                sample=f"{iters} VB iterations (K-side + E + M + lower bound, fp64 NumPy/OpenBLAS, "
-                       f"{threads} threads of {os.cpu_count()} cores) over the first {x_ref.shape[0]} rows of the workload",
-                seconds=cpu_s)
+                sample=f"{iters} VB iterations (K-side + E + M + lower bound, fp64 NumPy/OpenBLAS) over the first "
+                       f"{x_ref.shape[0]} rows, {threads} BLAS threads of {os.cpu_count()} cores"
+                       + (f" = best of {sorted(sweep)}" if sweep else ""),
+                threads_swept={str(t): round(v, 1) for t, v in sweep.items()}, seconds=cpu_s)
 
     def rel(a, b):
         return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
@@ -350,7 +417,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
-    rccl_ranks = 1
+    n_ranks, backend = 1, None
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -369,8 +436,9 @@ def main():
         # every rank contributes 1: proves the RCCL group really spans `world` processes
         one = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(one)
-        rccl_ranks = int(one.item())
-        assert rccl_ranks == world
+        n_ranks = int(one.item())
+        backend = dist.get_backend()          # "nccl" = RCCL on ROCm; "gloo" only under BENCH_SHARE_GPU=1
+        assert n_ranks == world
         faulthandler.cancel_dump_traceback_later()
 
     cfg = CONFIGS[args.config]
@@ -394,7 +462,7 @@ def main():
 
     cpu_base = parity = parity_sparse = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu_base, parity, parity_sparse = cpu_baseline_and_parity(K, D, x_ref, dev)
+        cpu_base, parity, parity_sparse = cpu_baseline_and_parity(K, D, x_ref, dev, sweep_threads=True)
     do_cpu = rank == 0 and world == 1 and not args.no_cpu
 
     w = Workload(K, D, x, dev, comm, spans=args.spans)
@@ -454,6 +522,17 @@ def main():
         ranks_info = [dict(rank=0, elapsed_s=elapsed, ms_per_step=elapsed / args.steps * 1e3,
                            wall_ms=[round(v, 2) for v in walls], rows=int(n_local))]
 
+    # config 4 strong-scaled over all ranks (north_star: ">= 6x at 8 GPUs on N = 1e8"): every --gpus N record carries the
+    # same job, so the curve falls out of the driver's N = 1, 2, 4, 8 records without extra flags
+    leg_names = set(args.legs.split(","))
+    if "all" in leg_names:
+        leg_names = {"dense", "hard", "spread", "full", "hmm", "small", "offpath", "c2", "c4", "c4strong"}
+    strong_leg = None
+    if world > 1 and "c4strong" in leg_names and not args.no_legs and not args.dense and args.config == "c3":
+        tot4 = args.strong_total_rows
+        n4 = tot4 // world + (1 if rank < tot4 % world else 0)
+        strong_leg = config_subline("c4", dev, 5, 20, comm=comm, use_dist=True, rows=n4, seed=100 + rank, world=world)
+
     # RCCL writes its version banner through C stdio, which buffers when stdout is a pipe or a file: left alone it comes out
     # at process exit - AFTER the JSON line, which must be the last line of stdout.  Every rank empties its C buffers now,
     # and rank 0 prints only after all have.
@@ -463,130 +542,12 @@ def main():
     if rank == 0:
         steps = args.steps
         step_ms = elapsed / steps * 1e3
-        # (phase events only with --spans full)
-        e_ms = float(np.mean([k[0] for k in ker])) if all(k[0] >= 0 for k in ker) else None
-        m_ms = float(np.mean([k[1] for k in ker])) if all(k[1] >= 0 for k in ker) else None
-        names = [kernel_name(p) for p in eng.launch_info.split("|")]      # kernels of the last step
-        tiles = (D + 15) // 16
-        fl_pair = 512 * tiles * (tiles + 1) // 2        # executed f64 MFMA flops per exactly evaluated (sample, component)
-        ev = float(np.mean([e for _, e in spars]))      # pairs evaluated exactly per E-step
-        ac = float(np.mean([a for a, _ in spars]))      # active pairs (r >= 2^-80)
-        # pairs the list M-step accumulates: active pairs minus the rows whose single component has r = 1.0 exactly and
-        # did not change (their addends sit in the workspace's cache), plus the rows entering / leaving that cache
-        acc = float(np.mean([wk["accumulated"] if wk["accumulated"] >= 0 else n_local * K for wk in works]))
-        settled = float(np.mean([wk["settled_rows"] for wk in works]))
-        exits = float(np.mean([wk["early_exits"] for wk in works]))      # candidates that stopped after T/2 output blocks
-        timed_counts = {k: counts1[k] - counts0[k] for k in counts1}
-        m_sparse = timed_counts["mstep_list"] > 0
-        # ---- per kernel group: mean HIP-event ms per step, algorithmic bytes per step (rows the group must read x D x s)
-        groups = {}
-        for g in sorted({g for s in spans for g in s}):
-            groups[g] = dict(ms=float(np.mean([s.get(g, (0.0, 0))[0] for s in spans])),
-                             launch_groups_per_step=float(np.mean([s.get(g, (0.0, 0))[1] for s in spans])))
-        row_bytes = D * esz
-        sparse_e = timed_counts["estep_bound"] + timed_counts["estep_carried"] + timed_counts["estep_sweep"] > 0
-        alg = {"estep_main": n_local * row_bytes * (timed_counts["estep_dense"] + timed_counts["estep_bound"]
-                                                    + timed_counts["estep_fell_back_dense"]) / steps,
-               "estep_gather": ev * row_bytes if sparse_e else 0.0,
-               "mstep_main": (acc if m_sparse else n_local) * row_bytes}
-        for g, b in alg.items():
-            if g in groups and groups[g]["ms"] > 0:
-                groups[g]["algorithmic_bytes"] = b
-                groups[g]["algorithmic_GBps"] = b / (groups[g]["ms"] * 1e-3) / 1e9
-        if groups.get("estep_gather", {}).get("ms", 0) > 0:
-            half = (tiles // 2) * (tiles // 2 + 1) // 2            # tile pairs of the first T/2 output blocks
-            done = ev - exits * (1.0 - half / (tiles * (tiles + 1) // 2)) if tiles >= 2 else ev
-            groups["estep_gather"]["executed_f64_tflops"] = fl_pair * done / groups["estep_gather"]["ms"] / 1e9
-        if "mstep_main" in groups:
-            groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (acc if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
-        if groups.get("estep_main", {}).get("ms", 0) > 0 and timed_counts["estep_dense"] + timed_counts["estep_fell_back_dense"] > 0 \
-                and timed_counts["estep_bound"] == 0:
-            groups["estep_main"]["executed_f64_tflops"] = fl_pair * n_local * K * (timed_counts["estep_dense"]
-                                                                                 + timed_counts["estep_fell_back_dense"]) / steps / groups["estep_main"]["ms"] / 1e9
-        # both yardsticks per kernel group: HBM (algorithmic bytes) and the f64 matrix pipe (executed flops); a group is bound
-        # by whichever fraction is larger
-        for gname, gv in groups.items():
-            if "algorithmic_GBps" in gv:
-                gv["hbm_frac"] = gv["algorithmic_GBps"] / PEAK_HBM_GBPS
-            if "executed_f64_tflops" in gv:
-                gv["f64_mfma_frac"] = gv["executed_f64_tflops"] / PEAK_F64_MFMA_TFLOPS
-            if "hbm_frac" in gv or "f64_mfma_frac" in gv:
-                gv["bound"] = "mfma" if gv.get("f64_mfma_frac", 0.0) > gv.get("hbm_frac", 0.0) else "hbm"
-        cand = [g for g in ("estep_main", "estep_gather", "mstep_main") if g in groups and "algorithmic_GBps" in groups[g]]
-        if cand:
-            dom = max(cand, key=lambda g: groups[g]["ms"])
-            dom_kernel = {"estep_main": names[0], "estep_gather": "estep_gather_f64", "mstep_main": names[-1]}[dom]
-            ach = groups[dom]["algorithmic_GBps"]
-        else:       # a row-tiled run (the workspace does not fit: _engine.TiledDataPass) keeps no per-group events
-            dom, dom_kernel = None, "tiled data pass (whole step)"
-            ach = n_local * row_bytes / (step_ms * 1e-3) / 1e9
-        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so they come
-        # from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py), and only when that
-        # file was made for the kernel that actually ran here
-        traffic = traffic_src = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f).get({"estep_i8_bound": "estep_i8", "estep_gather_f64": "estep_gather_dev_f64",
-                                       "mstep_list_f64": "mstep_list_x32_f64" if row_bytes == 4 * D else "mstep_list_f64"}
-                                      .get(dom_kernel, dom_kernel))
-            ran = (dom_kernel == "estep_gather_f64" and timed_counts["estep_gather"] > 0) or any(dom_kernel in l for l in launches)
-            if pm and pm.get("config") == f"K{K} D{D} N{n_local} {dt}" and ran:
-                # per step like `achieved`: the counters' average per launch x this run's launches of the group per step
-                per_step = groups[dom]["launch_groups_per_step"] if dom else 1.0
-                n_last = int(round(per_step * steps))
-                fl, wl = pm.get("fetch_bytes_raw_launches"), pm.get("write_bytes_launches")
-                if pm.get("window") == f"w{args.warmup}s{steps}" and fl and wl and 0 < n_last <= min(len(fl), len(wl)):
-                    # the passes were made with this very command: the kernel's last n launches are the timed steps'
-                    traffic = (2.0 * sum(fl[-n_last:]) + sum(wl[-n_last:])) / steps
-                    traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, its last {n_last} launches = the {steps} timed "
-                                   "steps of this command, per step): " + pm["note"])
-                else:
-                    traffic = (pm["fetch_bytes"] + pm["write_bytes"]) * per_step
-                    traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, average per launch x {per_step:.2f} launches "
-                                   "per step): " + pm["note"])
-        except (OSError, ValueError, KeyError):
-            pass
-        step_bytes = n_local * row_bytes
-        roof = {"bound": "hbm", "kernel": dom_kernel, "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                "frac": ach / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "step_algorithmic_bytes": step_bytes,
-                "step_hbm_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
-                "step_hbm_frac": step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                "hbm_roofline_samples_per_s": PEAK_HBM_GBPS * 1e9 / row_bytes,
-                "f64_mfma_ceiling_samples_per_s": (PEAK_F64_MFMA_TFLOPS * 1e12 / (fl_pair * (ev + acc) / n_local)
-                                                   if (ev + acc) > 0 else None),
-                "pairs_per_sample": {"active": ac / n_local, "evaluated_exactly": ev / n_local,
-                                     "accumulated_by_mstep": acc / n_local, "settled_rows": settled / n_local,
-                                     "early_exits": exits / n_local,
-                                     "proof_round_int8": float(np.mean([wk.get("proof_pairs", 0.0) for wk in works])) / n_local},
-                "spans": args.spans,
-                "kernel_groups": groups,
-                "events_ms_per_step": sum(g["ms"] for g in groups.values()),
-                "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
-                "phase_ms": {"estep": e_ms, "mstep": m_ms},
-                "timed_kernel_launches": timed_counts,
-                "note": "every kernel group carries hbm_frac (algorithmic bytes: rows it must read x D x s, SURVEY 8d, / its "
-                        "HIP-event time / 8 TB/s) and f64_mfma_frac (executed f64 MFMA flops / 78.6 TFLOP/s); `bound`, `achieved`, "
-                        "`peak`, `frac` are the dominant group's LARGER fraction; frac <= 1 by construction.  step_hbm_frac = value / "
-                        "hbm_roofline_samples_per_s.  f64_mfma_ceiling = the rate at which the f64 matrix pipe alone could "
-                        "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M).  "
-                        "executed_f64_tflops of estep_gather charges the pairs that take the gather's early way out "
-                        "(DESIGN.md 4b; pairs_per_sample.early_exits) with the tile pairs they really do"}
-        if dom:
-            roof["hbm_frac"] = groups[dom].get("hbm_frac")
-            roof["f64_mfma_frac"] = groups[dom].get("f64_mfma_frac")
-        if dom and groups[dom].get("bound") == "mfma":
-            # the dominant kernel's larger fraction is of the f64 matrix pipe: executed flops against its peak
-            roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_F64_MFMA_TFLOPS, achieved=groups[dom]["executed_f64_tflops"],
-                        frac=groups[dom]["f64_mfma_frac"], hbm_achieved_GBps=ach)
-        assert roof["frac"] <= 1.0 + 1e-9, roof
-
+        roof, groups, fl_pair, timed_counts = build_roofline(eng, K, D, dt, n_local, steps, args.warmup, step_ms, ker, spans,
+                                                             launches, spars, works, counts0, counts1, args.spans)
         last_launch = eng.launch_info
-        dense_leg = hard = spread_leg = full_leg = hmm_leg = small_leg = offpath = None
+        dense_leg = hard = spread_leg = full_leg = hmm_leg = small_leg = offpath = c2_leg = c4_leg = None
         if not args.dense and world == 1 and not args.no_legs:
-            legs = set(args.legs.split(","))
-            if "all" in legs:
-                legs = {"dense", "hard", "spread", "full", "hmm", "small", "offpath"}
+            legs = leg_names
             if "dense" in legs:
                 dense_leg = dense_leg_run(w, K, D, n_local, fl_pair)
             w.close()
@@ -606,9 +567,17 @@ def main():
                 hmm_leg = hmm_c5_leg(dev, cpu=do_cpu)
             if "small" in legs:
                 small_leg = small_c1_leg(dev)
+            if args.config == "c3" and not args.overlap:
+                if "c2" in legs:
+                    c2_leg = config_subline("c2", dev, 5, 20)
+                if "c4" in legs:
+                    c4_leg = config_subline("c4", dev, 5, 20, what="GMM-VB K=256 D=64, one shard of config 4 (1.25e7 of N=1e8 rows), "
+                                                                      "x stored f32, VB iterations 6-25 of one restart")
+                if "c4strong" in legs:
+                    strong_leg = config_subline("c4", dev, 5, 20, rows=args.strong_total_rows, seed=100)
         out = {
             "metric": "GMM-VB E+M samples/sec at K=64,D=128,N=1e7; 1/2/4/8-GPU scaling",
-            "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "value": n_total * steps / elapsed, "unit": "samples/s", "n_gpus": world, "ranks": n_ranks, "backend": backend,
             "estep_kinds_identical_across_ranks": policy_same,
             "allreduce": (("gmmvb_allreduce_stats (C ABI, RCCL)" if args.native_allreduce else
                            ("torch.distributed gloo (BENCH_SHARE_GPU=1: all ranks on one GPU)" if share_gpu else "torch.distributed nccl (RCCL)"))
@@ -624,6 +593,7 @@ def main():
                        "row_tiles": getattr(eng, "n_tiles", 1)},
             "roofline": roof, "dense": dense_leg, "hard_workload": hard, "spread_sweep": spread_leg,
             "full_fit": full_leg, "hmm_c5": hmm_leg, "small_c1": small_leg, "offpath": offpath, "per_rank": ranks_info,
+            "c2": c2_leg, "c4_shard": c4_leg, "c4_strong": strong_leg,
             "cpu_baseline": cpu_base, "parity": parity, "parity_sparse_path": parity_sparse, "final_vl": vl,
             "launch": last_launch, "warmup_steps": warm,
             "per_step": {"wall_ms": [round(v, 2) for v in walls],
@@ -645,6 +615,269 @@ def main():
         dist.destroy_process_group()
 
 
+class TimedComm:
+    """Proxy of a RowShard that brackets the per-iteration collective with its own HIP events on the launch stream (the
+    collective itself may run on RCCL's stream: the second event sits behind the wait for it)."""
+
+    def __init__(self, inner):
+        self._inner, self.events = inner, []
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def all_reduce_(self, t):
+        import torch
+        if not t.is_cuda or not (self._inner.world > 1 or getattr(self._inner, "always", False)):
+            return self._inner.all_reduce_(t)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = self._inner.all_reduce_(t)
+        b.record()
+        self.events.append((a, b))
+        return out
+
+    def take_ms(self):
+        """Event times of the collectives since the last call (the caller has synchronised)."""
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        self.events = []
+        return ms
+
+
+def timed_window(K, D, dt, x, dev, comm, warmup, steps, spans="dominant", use_dist=False):
+    """Workload on x -> `warmup` iterations -> `steps` timed ones (barrier + synchronize on both sides, MAX over ranks).
+    Returns a dict with the window's step time, its roofline block and the per-rank clocks."""
+    import torch
+    import torch.distributed as dist
+    tc = TimedComm(comm) if comm is not None else None
+    w = Workload(K, D, x, dev, tc, spans=spans)
+    eng, n_local = w.eng, x.shape[0]
+    for _ in range(warmup):
+        w.step()
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if tc is not None:
+        torch.cuda.synchronize()
+        tc.take_ms()
+    ker, launches, spars, spans_rec, works, walls = [], [], [], [], [], []
+    counts0 = eng.pass_counts()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        w.step()
+        walls.append((time.perf_counter() - ts) * 1e3)
+        ker.append(eng.last_kernel_ms())
+        spans_rec.append(eng.kernel_spans())
+        launches.append(eng.launch_info)
+        spars.append(eng.sparsity())
+        works.append(eng.work())
+    fence()
+    elapsed = own = time.perf_counter() - t0
+    counts1 = eng.pass_counts()
+    ar_ms = tc.take_ms() if tc is not None else []
+    world, rank = (dist.get_world_size(), dist.get_rank()) if use_dist else (1, 0)
+    policy_same, per_rank, n_total = None, [own / steps * 1e3], n_local
+    if use_dist:
+        seqs = [None] * world
+        dist.all_gather_object(seqs, dict(kinds=[kernel_name(l) for l in launches], ms=own / steps * 1e3, rows=int(n_local),
+                                          allreduce_ms=float(np.mean(ar_ms)) if ar_ms else None))
+        policy_same = all(q["kinds"] == seqs[0]["kinds"] for q in seqs)
+        per_rank = [q["ms"] for q in seqs]
+        elapsed = max(per_rank) * steps / 1e3
+        n_total = sum(q["rows"] for q in seqs)
+        ar_all = [q["allreduce_ms"] for q in seqs if q["allreduce_ms"] is not None]
+    else:
+        ar_all = [float(np.mean(ar_ms))] if ar_ms else []
+    step_ms = elapsed / steps * 1e3
+    roof, groups, _fl, timed_counts = build_roofline(eng, K, D, dt, n_local, steps, warmup, step_ms, ker, spans_rec, launches,
+                                                     spars, works, counts0, counts1, spans)
+    out = dict(step_ms=step_ms, rows_total=n_total, rows_local=n_local, per_rank_ms_per_step=per_rank, roofline=roof,
+               estep_kinds_identical_across_ranks=policy_same, allreduce_ms=(max(ar_all) if ar_all else None),
+               allreduce_ms_per_rank=ar_all, wall_ms=[round(v, 2) for v in walls], timed_counts=timed_counts,
+               row_tiles=getattr(eng, "n_tiles", 1), launch=eng.launch_info)
+    w.close()
+    return out
+
+
+def subline(name, what, win, steps, warmup, world=1):
+    """A compact sub-line of the JSON record for another configuration's window (like `hmm_c5`)."""
+    r = win["roofline"]
+    out = {"workload": what, "ms_per_step": round(win["step_ms"], 4), "steps": steps, "warmup": warmup,
+           "samples_per_s": win["rows_total"] / (win["step_ms"] * 1e-3), "kernel": r["kernel"], "bound": r["bound"],
+           "frac_executed": r.get("frac_executed"), "frac_on_F": r.get("frac_on_F"), "step_frac_on_F": r.get("step_frac_on_F"),
+           "step_hbm_frac": r["step_hbm_frac"], "pruned": r.get("pruned"), "row_tiles": win["row_tiles"],
+           "kernel_groups_ms": {g: round(v["ms"], 3) for g, v in r["kernel_groups"].items() if v["ms"] > 0.005}}
+    if world > 1 or win["allreduce_ms"] is not None:
+        out.update(n_gpus=world, per_rank_ms_per_step=[round(v, 3) for v in win["per_rank_ms_per_step"]],
+                   allreduce_ms=win["allreduce_ms"], estep_kinds_identical_across_ranks=win["estep_kinds_identical_across_ranks"])
+    return out
+
+
+def config_subline(name, dev, warmup, steps, comm=None, use_dist=False, rows=None, seed=0, world=1, what=None):
+    """Window of another BASELINE.json configuration with its own synthetic rows (same recipe), as a sub-line."""
+    import torch
+    cfg = CONFIGS[name]
+    K, D, dt = cfg["classes"], cfg["degree"], cfg["dtype"]
+    n = int(rows or cfg["rows"])
+    x = device_rows(K, D, n, torch.float32 if dt == "f32" else torch.float64, dev, SEED + 1 + seed, 2.0)
+    win = timed_window(K, D, dt, x, dev, comm, warmup, steps, use_dist=use_dist)
+    del x
+    torch.cuda.empty_cache()
+    tot = win["rows_total"]
+    return subline(name, what or f"GMM-VB K={K} D={D} N={tot}{'' if world == 1 else f' over {world} GPUs'}, x stored {dt}, "
+                                 f"VB iterations {warmup + 1}-{warmup + steps} of one restart", win, steps, warmup, world)
+
+
+def build_roofline(eng, K, D, dt, n_local, steps, warmup, step_ms, ker, spans, launches, spars, works, counts0, counts1, spans_mode):
+    """The `roofline` block of a timed window from what the window's steps recorded: per kernel group the
+    HIP-event time, algorithmic bytes and executed f64 MFMA flops; the line's fields are the dominant group's.  Two fractions
+    with one meaning each: `frac_executed` = flops the kernel really issued on the f64 matrix pipe / its time / peak (a
+    utilisation, <= 1), `frac_on_F` = the flops the REFERENCE's dense formulation spends on that phase (E
+    K(2D^2+3D)+6K, M K(2D^2+2D)+2KD per row) / the same time / the same peak - far above 1 once rows and pairs are pruned,
+    where it measures the algorithmic saving, not the hardware."""
+    esz = 4 if dt == "f32" else 8
+    # (phase events only with --spans full)
+    e_ms = float(np.mean([k[0] for k in ker])) if all(k[0] >= 0 for k in ker) else None
+    m_ms = float(np.mean([k[1] for k in ker])) if all(k[1] >= 0 for k in ker) else None
+    names = [kernel_name(p) for p in eng.launch_info.split("|")]      # kernels of the last step
+    tiles = (D + 15) // 16
+    fl_pair = 512 * tiles * (tiles + 1) // 2        # executed f64 MFMA flops per exactly evaluated (sample, component)
+    ev = float(np.mean([e for _, e in spars]))      # pairs evaluated exactly per E-step
+    ac = float(np.mean([a for a, _ in spars]))      # active pairs (r >= 2^-80)
+    # pairs the list M-step accumulates: active pairs minus the rows whose single component has r = 1.0 exactly and
+    # did not change (their addends sit in the workspace's cache), plus the rows entering / leaving that cache
+    acc = float(np.mean([wk["accumulated"] if wk["accumulated"] >= 0 else n_local * K for wk in works]))
+    settled = float(np.mean([wk["settled_rows"] for wk in works]))
+    exits = float(np.mean([wk["early_exits"] for wk in works]))      # candidates that stopped after T/2 output blocks
+    timed_counts = {k: counts1[k] - counts0[k] for k in counts1}
+    m_sparse = timed_counts["mstep_list"] > 0
+    # ---- per kernel group: mean HIP-event ms per step, algorithmic bytes per step (rows the group must read x D x s)
+    groups = {}
+    for g in sorted({g for s in spans for g in s}):
+        groups[g] = dict(ms=float(np.mean([s.get(g, (0.0, 0))[0] for s in spans])),
+                         launch_groups_per_step=float(np.mean([s.get(g, (0.0, 0))[1] for s in spans])))
+    row_bytes = D * esz
+    sparse_e = timed_counts["estep_bound"] + timed_counts["estep_carried"] + timed_counts["estep_sweep"] > 0
+    alg = {"estep_main": n_local * row_bytes * (timed_counts["estep_dense"] + timed_counts["estep_bound"]
+                                                + timed_counts["estep_fell_back_dense"]) / steps,
+           "estep_gather": ev * row_bytes if sparse_e else 0.0,
+           "mstep_main": (acc if m_sparse else n_local) * row_bytes}
+    for g, b in alg.items():
+        if g in groups and groups[g]["ms"] > 0:
+            groups[g]["algorithmic_bytes"] = b
+            groups[g]["algorithmic_GBps"] = b / (groups[g]["ms"] * 1e-3) / 1e9
+    if groups.get("estep_gather", {}).get("ms", 0) > 0:
+        half = (tiles // 2) * (tiles // 2 + 1) // 2            # tile pairs of the first T/2 output blocks
+        done = ev - exits * (1.0 - half / (tiles * (tiles + 1) // 2)) if tiles >= 2 else ev
+        groups["estep_gather"]["executed_f64_tflops"] = fl_pair * done / groups["estep_gather"]["ms"] / 1e9
+    if "mstep_main" in groups:
+        groups["mstep_main"]["executed_f64_tflops"] = fl_pair * (acc if m_sparse else n_local * K) / groups["mstep_main"]["ms"] / 1e9
+    if groups.get("estep_main", {}).get("ms", 0) > 0 and timed_counts["estep_dense"] + timed_counts["estep_fell_back_dense"] > 0 \
+            and timed_counts["estep_bound"] == 0:
+        groups["estep_main"]["executed_f64_tflops"] = fl_pair * n_local * K * (timed_counts["estep_dense"]
+                                                                             + timed_counts["estep_fell_back_dense"]) / steps / groups["estep_main"]["ms"] / 1e9
+    # both yardsticks per kernel group: HBM (algorithmic bytes) and the f64 matrix pipe (executed flops); a group is bound
+    # by whichever fraction is larger
+    for gname, gv in groups.items():
+        if "algorithmic_GBps" in gv:
+            gv["hbm_frac"] = gv["algorithmic_GBps"] / PEAK_HBM_GBPS
+        if "executed_f64_tflops" in gv:
+            gv["f64_mfma_frac"] = gv["executed_f64_tflops"] / PEAK_F64_MFMA_TFLOPS
+        if "hbm_frac" in gv or "f64_mfma_frac" in gv:
+            gv["bound"] = "mfma" if gv.get("f64_mfma_frac", 0.0) > gv.get("hbm_frac", 0.0) else "hbm"
+    cand = [g for g in ("estep_main", "estep_gather", "mstep_main") if g in groups and "algorithmic_GBps" in groups[g]]
+    if cand:
+        dom = max(cand, key=lambda g: groups[g]["ms"])
+        dom_kernel = {"estep_main": names[0], "estep_gather": "estep_gather_f64", "mstep_main": names[-1]}[dom]
+        ach = groups[dom]["algorithmic_GBps"]
+    else:       # a row-tiled run (the workspace does not fit: _engine.TiledDataPass) keeps no per-group events
+        dom, dom_kernel = None, "tiled data pass (whole step)"
+        ach = n_local * row_bytes / (step_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so they come
+    # from the committed rocprofv3 --pmc passes of this same command (tools/summarize_pmc.py), and only when that
+    # file was made for the kernel that actually ran here
+    traffic = traffic_src = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pm = json.load(f).get({"estep_i8_bound": "estep_i8", "estep_gather_f64": "estep_gather_dev_f64",
+                                   "mstep_list_f64": "mstep_list_x32_f64" if row_bytes == 4 * D else "mstep_list_f64"}
+                                  .get(dom_kernel, dom_kernel))
+        ran = (dom_kernel == "estep_gather_f64" and timed_counts["estep_gather"] > 0) or any(dom_kernel in l for l in launches)
+        if pm and pm.get("config") == f"K{K} D{D} N{n_local} {dt}" and ran:
+            # per step like `achieved`: the counters' average per launch x this run's launches of the group per step
+            per_step = groups[dom]["launch_groups_per_step"] if dom else 1.0
+            n_last = int(round(per_step * steps))
+            fl, wl = pm.get("fetch_bytes_raw_launches"), pm.get("write_bytes_launches")
+            if pm.get("window") == f"w{warmup}s{steps}" and fl and wl and 0 < n_last <= min(len(fl), len(wl)):
+                # the passes were made with this very command: the kernel's last n launches are the timed steps'
+                traffic = (2.0 * sum(fl[-n_last:]) + sum(wl[-n_last:])) / steps
+                traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, its last {n_last} launches = the {steps} timed "
+                               "steps of this command, per step): " + pm["note"])
+            else:
+                traffic = (pm["fetch_bytes"] + pm["write_bytes"]) * per_step
+                traffic_src = (f"profiles/pmc_traffic.json ({pm['kernel']}, average per launch x {per_step:.2f} launches "
+                               "per step): " + pm["note"])
+    except (OSError, ValueError, KeyError):
+        pass
+    step_bytes = n_local * row_bytes
+    roof = {"bound": "hbm", "kernel": dom_kernel, "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "step_algorithmic_bytes": step_bytes,
+            "step_hbm_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
+            "step_hbm_frac": step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            "hbm_roofline_samples_per_s": PEAK_HBM_GBPS * 1e9 / row_bytes,
+            "f64_mfma_ceiling_samples_per_s": (PEAK_F64_MFMA_TFLOPS * 1e12 / (fl_pair * (ev + acc) / n_local)
+                                               if (ev + acc) > 0 else None),
+            "pairs_per_sample": {"active": ac / n_local, "evaluated_exactly": ev / n_local,
+                                 "accumulated_by_mstep": acc / n_local, "settled_rows": settled / n_local,
+                                 "early_exits": exits / n_local,
+                                 "proof_round_int8": float(np.mean([wk.get("proof_pairs", 0.0) for wk in works])) / n_local},
+            "spans": spans_mode,
+            "kernel_groups": groups,
+            "events_ms_per_step": sum(g["ms"] for g in groups.values()),
+            "outside_events_ms_per_step": step_ms - sum(g["ms"] for g in groups.values()),
+            "phase_ms": {"estep": e_ms, "mstep": m_ms},
+            "timed_kernel_launches": timed_counts,
+            "note": "every kernel group carries hbm_frac (algorithmic bytes: rows it must read x D x s, SURVEY 8d, / its "
+                    "HIP-event time / 8 TB/s) and f64_mfma_frac (executed f64 MFMA flops / 78.6 TFLOP/s); `bound`, `achieved`, "
+                    "`peak`, `frac` are the dominant group's LARGER fraction; frac <= 1 by construction.  step_hbm_frac = value / "
+                    "hbm_roofline_samples_per_s.  f64_mfma_ceiling = the rate at which the f64 matrix pipe alone could "
+                    "evaluate the (sample, component) pairs this step evaluates exactly (E) and accumulates (M).  "
+                    "executed_f64_tflops of estep_gather charges the pairs that take the gather's early way out "
+                    "(DESIGN.md 4b; pairs_per_sample.early_exits) with the tile pairs they really do"}
+    if dom:
+        roof["hbm_frac"] = groups[dom].get("hbm_frac")
+        roof["f64_mfma_frac"] = groups[dom].get("f64_mfma_frac")
+    if dom and groups[dom].get("bound") == "mfma":
+        # the dominant kernel's larger fraction is of the f64 matrix pipe: executed flops against its peak
+        roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_F64_MFMA_TFLOPS, achieved=groups[dom]["executed_f64_tflops"],
+                    frac=groups[dom]["f64_mfma_frac"], hbm_achieved_GBps=ach)
+    assert roof["frac"] <= 1.0 + 1e-9, roof
+
+    # ---- SURVEY 8d's convention beside the executed one
+    f_e, f_m = K * (2 * D * D + 3 * D) + 6 * K, K * (2 * D * D + 2 * D) + 2 * K * D
+    pruned = bool(sparse_e or m_sparse)
+    for gname, phase_f in (("estep_main", f_e), ("estep_gather", f_e), ("mstep_main", f_m)):
+        gv = groups.get(gname)
+        if gv and gv["ms"] > 0:
+            gv["frac_executed"] = gv.get("f64_mfma_frac")
+            gv["frac_on_F"] = phase_f * n_local / (gv["ms"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS
+    roof["frac_executed"] = groups[dom].get("f64_mfma_frac") if dom else None
+    roof["frac_on_F"] = groups[dom].get("frac_on_F") if dom else None
+    roof["step_frac_on_F"] = (f_e + f_m) * n_local / (step_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS
+    roof["F_flop_per_sample"] = f_e + f_m
+    roof["pruned"] = pruned
+    roof["frac_note"] = ("frac = frac_executed: f64 MFMA flops the kernel issued / its HIP-event time / 78.6 TFLOP/s.  frac_on_F: "
+                         "SURVEY 8d's dense F of that phase x rows / the same time / the same peak"
+                         + ("; pruned: rows and pairs proven irrelevant are skipped, so the F-basis fraction is not a utilisation"
+                            if pruned else ""))
+    return roof, groups, fl_pair, timed_counts
+
+
 def flush_c_stdio():
     try:
         import ctypes
@@ -663,9 +896,8 @@ def compact_line(out):
     scalars that say what was measured.  Everything else (per-step lists, kernel groups, legs in full) is in the
     detail record (--detail)."""
     r = out["roofline"]
-    roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "f64_mfma_frac", "spans",
-                     "step_hbm_frac", "f64_mfma_ceiling_samples_per_s", "hbm_roofline_samples_per_s",
-                     "events_ms_per_step", "outside_events_ms_per_step"))
+    roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_executed", "frac_on_F", "step_frac_on_F", "pruned",
+                     "traffic", "hbm_frac", "spans", "step_hbm_frac", "f64_mfma_ceiling_samples_per_s", "frac_note"))
     roof["pairs_per_sample"] = {k: round(v, 4) for k, v in r["pairs_per_sample"].items()}
     roof["kernel_groups_ms"] = {g: round(v["ms"], 4) for g, v in r["kernel_groups"].items()}
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
@@ -674,7 +906,7 @@ def compact_line(out):
                                            "cluster_spread", "parallelism", "row_tiles"))
     line["window"] = out["window"]
     line["roofline"] = roof
-    line["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+    line["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "threads_swept"))
     for k in ("parity", "parity_sparse_path"):
         line[k] = _pick(out[k], ("max_rel_err", "tolerance", "passed", "rows", "iterations", "path"))
     w = out["per_step"]["wall_ms"]
@@ -692,8 +924,8 @@ def compact_line(out):
     if h:
         line["hmm_c5"] = dict(_pick(h, ("value", "unit", "steps", "warmup", "ms_per_step")),
                               workload=h["config"]["workload"], window=h.get("window"),
-                              roofline=_pick(h["roofline"], ("bound", "achieved", "peak", "unit", "frac", "hbm_frac",
-                                                             "f64_mfma_frac", "traffic")),
+                              roofline=_pick(h["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_executed", "frac_on_F",
+                                                             "hbm_frac", "traffic")),
                               parity_max_rel_err=(h["parity"] or {}).get("max_rel_err"),
                               cpu_baseline_value=(h["cpu_baseline"] or {}).get("value"),
                               boundary_pass=h.get("boundary_pass"),
@@ -701,8 +933,12 @@ def compact_line(out):
     for k in ("hard_workload", "spread_sweep", "offpath"):
         if out.get(k):
             line[k] = out[k].get("summary")
+    for k in ("c2", "c4_shard", "c4_strong"):
+        if out.get(k):
+            line[k] = {f: (round(v, 4) if isinstance(v, float) and f != "samples_per_s" else v) for f, v in out[k].items()
+                       if f not in ("kernel_groups_ms", "steps", "warmup", "step_hbm_frac")}
     if out["n_gpus"] > 1 or out.get("allreduce"):
-        line["rccl_ranks"] = out["rccl_ranks"]
+        line["ranks"], line["backend"] = out["ranks"], out["backend"]
         line["allreduce"] = out["allreduce"]
         line["estep_kinds_identical_across_ranks"] = out["estep_kinds_identical_across_ranks"]
         line["per_rank_ms_per_step"] = [round(p["ms_per_step"], 3) for p in out["per_rank"]]
@@ -723,7 +959,7 @@ def emit(out, args):
         except OSError:
             pass
     # the driver's record keeps a bounded tail of stdout: never let the line outgrow it (drop optional blocks first)
-    for drop in (None, "hmm_c5", "offpath", "spread_sweep", "hard_workload", "per_rank_ms_per_step", "full_fit_what"):
+    for drop in (None, "full_fit_what", "offpath", "spread_sweep", "hard_workload", "per_rank_ms_per_step", "window", "hmm_c5"):
         if drop:
             line.pop(drop, None)
         text = json.dumps(line)

@@ -160,6 +160,11 @@ def measure(args, dev=None):
     roofline["hbm_achieved_GBps"] = roofline["achieved"]
     roofline["algorithmic_flop_per_time_step"] = flop
     roofline["f64_mfma_frac"] = tf / 78.6
+    # one meaning per name, as in bench.py's roofline: frac_on_F = the reference's dense flop count (above) / time / peak;
+    # frac_executed would need the flops the kernels really issue, and the M-step's bit walk (csrc/hmm.h) skips an uncounted
+    # share of its MFMA steps - not reported rather than guessed
+    roofline["frac_on_F"] = tf / 78.6
+    roofline["frac_executed"] = None
     if roofline["f64_mfma_frac"] > roofline["hbm_frac"]:
         roofline.update(bound="mfma", achieved=tf, peak=78.6, unit="TFLOP/s", frac=tf / 78.6)
     try:            # measured HBM bytes per iteration (tools/hmm_pmc_total.py), only if made for this very workload

@@ -26,7 +26,7 @@ d = json.load(open(sys.argv[1])); g = d["roofline"]["kernel_groups"]
 print("D =", sys.argv[2], "ms/step", round(d["ms_per_step"], 2), {k: (round(v["ms"], 2), round(v.get("executed_f64_tflops", 0), 1)) for k, v in g.items() if v["ms"] > 0.05}, d["launch"][:60])
 PY
           done ;;
-    share8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --config c4 --rows 200000 --steps 12 --warmup 5 --no-cpu --no-legs --detail $OUT/${TAG}_bench_detail_eight_ranks_one_gpu.json 2> $OUT/${TAG}_share8.err | grep -a "^{" > $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_share8.err; head -c 700 $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; echo ;;
+    share8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --rows 200000 --strong-total-rows 1600000 --steps 12 --warmup 5 --no-cpu --legs c4strong --detail $OUT/${TAG}_bench_detail_eight_ranks_one_gpu.json 2> $OUT/${TAG}_share8.err | grep -a "^{" > $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_share8.err; head -c 700 $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; echo ;;
     legsall) timeout 1500 python bench.py --steps 20 --warmup 5 --legs all --detail $OUT/${TAG}_bench_detail_all_legs.json > $OUT/${TAG}_bench_line_all_legs.json 2> $OUT/${TAG}_legsall.err; tail -c 300 $OUT/${TAG}_legsall.err; cat $OUT/${TAG}_bench_line_all_legs.json; echo ;;
     strong8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --config c4 --scaling strong --total-rows 1600000 --steps 12 --warmup 5 --no-cpu --no-legs --detail $OUT/${TAG}_bench_detail_c4_strong_eight_ranks_one_gpu.json 2> $OUT/${TAG}_strong8.err | grep -a "^{" > $OUT/${TAG}_bench_line_c4_strong_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_strong8.err; cat $OUT/${TAG}_bench_line_c4_strong_eight_ranks_one_gpu.json; echo ;;
     hmmsmall) for t in 10000 100000; do for g in 1 0; do BAYESML_AMD_KSIDE_GRAPH=$g timeout 300 python tools/bench_hmm.py --rows $t --no-cpu --steps 20 --warmup 5 2>/dev/null | grep -a "^{" > $OUT/${TAG}_hmm_t${t}_graph$g.json; python -c "
