@@ -392,13 +392,14 @@ class DataPass:
     def work(self) -> dict:
         """Pairs of the last E-step (gmmvb_last_work): active, evaluated exactly, accumulated by the list M-step, and the
         rows the E-step did not evaluate at all (settled), pairs of the int8 proof round, and the share of the per-pair bound
-        array the sweep went through (sweep_share; -1: the last E-step was not a lazy sweep)."""
+        array the sweep went through (sweep_share; -1: the last E-step was not a lazy sweep), or - after a projected sweep
+        (csrc/project.h) - the pairs its stateless table did not clear (table_left; -1: the last E-step was none)."""
         out = (ctypes.c_double * 8)()
         _check(self.lib, self.lib.gmmvb_last_work(self._ws, out), "gmmvb_last_work")
         tiles = (self.rows + 255) // 256 if getattr(self, "rows", 0) else 0
         share = float(out[6]) / (tiles * self.K) if out[6] >= 0 and tiles else -1.0
         return dict(active=float(out[0]), evaluated=float(out[1]), accumulated=float(out[2]), settled_rows=float(out[3]),
-                    early_exits=float(out[4]), proof_pairs=float(out[5]), sweep_share=share)
+                    early_exits=float(out[4]), proof_pairs=float(out[5]), sweep_share=share, table_left=float(out[7]))
 
     def profile(self, on: bool = True):
         _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")

@@ -1,6 +1,7 @@
 // K-sized packing, row log-normaliser, slab reduction and read-out kernels (all f64, bandwidth-trivial).
 #pragma once
 #include "common.h"
+#include "rec_common.h"
 
 namespace gmmvb {
 
@@ -159,39 +160,6 @@ __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpa
 //                        and how many candidates each 256-sample block has per component;
 //   scan_parts / scan_apply   exclusive scan of those block counts per component -> block bases and list lengths;
 //   fill_lists_kernel    every block writes its candidates at its bases.
-constexpr int kSelRows = 256;
-// the per-block count / base arrays are block-major (see the scan below)
-__device__ __forceinline__ int64_t blk_at(int k, int64_t b, int K) { return b * K + k; }
-
-// OR over the wave's 64 lanes (all of them active), as a wave-UNIFORM value in scalar registers: four v_or_b32 with a DPP
-// operand inside the rows of 16 lanes, the four row results through v_readlane.  (Round 5.  The shuffle butterfly it replaces
-// cost twelve LDS permutes and left the result in vector registers - the loops over the set bits that follow then ran their
-// control flow, their bit scans and the list addresses that depend on the component on the vector ALU, lane by lane the same.)
-__device__ __forceinline__ unsigned wave_or32(unsigned v) {
-    asm(
-        "s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16) |
-           (unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-}
-__device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
-    return ((unsigned long long)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
-}
-// the shuffle butterfly (result in vector registers): rec_finish_kernel is faster with it (measured: +13 % with the form above)
-__device__ __forceinline__ unsigned long long wave_or_shfl(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
-    return v;
-}
-
 // MODE 0 (best)  : the mask holds khat_n = first maximiser of the bounds u[k][n] (also stored in khat).
 // MODE 3 (given) : like MODE 0 with khat already written (by the bound kernel): u is not read.
 // (Every further candidate is selected from the per-row records, records.h.)

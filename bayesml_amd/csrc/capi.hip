@@ -273,6 +273,11 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
         ws->opt_proof_blocked = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_SWEEP_LAZY");                       // "0": every sweep reads all K bounds of every row
         ws->opt_lazy = !(v && std::strcmp(v, "0") == 0);
+        // the stateless table of project.h - off by default (measured, profiles/r6_experiments.md: on the benchmark's fits it
+        // costs more than the proof pairs it saves): "filter" = it takes pairs off the carried sweep's proof lists, "only" =
+        // it replaces the carried per-pair bounds
+        v = std::getenv("GMMVB_PROJECT");
+        ws->opt_project = (v && std::strcmp(v, "filter") == 0) ? 1 : ((v && std::strcmp(v, "only") == 0) ? 2 : 0);
         v = std::getenv("GMMVB_REGROUP_MARGIN");     // "0": the rows are regrouped by best component only
         ws->opt_regroup_margin = !(v && std::strcmp(v, "0") == 0);
         v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
@@ -377,7 +382,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
                      ws->lock, ws->lcomp, ws->dlock, ws->rthr, ws->exit_ctr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
-                     ws->rmask, ws->rblk, ws->xq, ws->xqe, ws->ppart, ws->tmeta};
+                     ws->rmask, ws->rblk, ws->xq, ws->xqe, ws->ppart, ws->tmeta, ws->gimg, ws->gconst, ws->hk, ws->tile_ref, ws->xqn};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -643,6 +648,15 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
         if (e != hipSuccess) return fail(GMMVB_EHIP, "pack_params_i8_kernel", e);
         ws->img_gen = ws->pivot_gen;
     }
+    // The stateless sweep's table for these parameters (project.h), when a sweep can follow: regrouped rows, their tiles'
+    // references, digit planes about the pivot in force, and a drift hint (the settled rows' own bound is still carried).
+    ws->proj_table = false;
+    if (ws->gimg && ws->opt_project != 0 && ws->sorted && ws->tile_ref_valid && ws->have_drift && ws->xq_gen == ws->pivot_gen &&
+        !ws->opt_carry_off) {
+        e = launch_proj_table(u_dev, m_dev, c_dev, ws->pivot, ws->K, ws->D, ws->hk, ws->gimg, ws->gconst, st);
+        if (e != hipSuccess) return fail(GMMVB_EHIP, "proj_table_kernel", e);
+        ws->proj_table = true;
+    }
     ws->have_params = true;
     ws->params_used = false;
     return GMMVB_OK;
@@ -672,10 +686,10 @@ static int ensure_lists(gmmvb_workspace* ws) {
     if (e == hipSuccess) e = hipMalloc((void**)&ws->lcomp, (size_t)np);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dlock, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rthr, (size_t)np * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&ws->exit_ctr, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ws->exit_ctr, 0, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->exit_host, 2 * sizeof(unsigned long long), hipHostMallocDefault);
-    if (e == hipSuccess) ws->exit_host[0] = ws->exit_host[1] = 0;
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->exit_ctr, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ws->exit_ctr, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws->exit_host, 4 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) ws->exit_host[0] = ws->exit_host[1] = ws->exit_host[2] = ws->exit_host[3] = 0;
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dmask, (size_t)words * np * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->dblk, (size_t)sel_blocks * ws->K * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->mmask, (size_t)words * np * sizeof(unsigned long long));
@@ -697,6 +711,17 @@ static int ensure_lists(gmmvb_workspace* ws) {
         if (e == hipSuccess) e = hipMalloc((void**)&ws->xq, (size_t)(np * rb));
         if (e == hipSuccess) e = hipMalloc((void**)&ws->xqe, (size_t)np);
         if (e == hipSuccess) ws->bytes += np * (rb + 1);
+        // the stateless sweep's table (project.h): needs the digit planes, regrouped rows and at least two feature blocks
+        if (ws->opt_project != 0 && ws->sort_rows && ws->K <= kSelRows && ws->D > 32 && ws->D <= 128) {
+            const int64_t ib = proj_image_len(ws->K, ws->D), cl = proj_const_len(ws->K);
+            if (e == hipSuccess) e = hipMalloc((void**)&ws->gimg, (size_t)ib);
+            if (e == hipSuccess) e = hipMemset(ws->gimg, 0, (size_t)ib);
+            if (e == hipSuccess) e = hipMalloc(&ws->gconst, (size_t)cl * 16);
+            if (e == hipSuccess) e = hipMalloc((void**)&ws->hk, (size_t)ws->K * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void**)&ws->tile_ref, (size_t)sel_blocks * sizeof(int));
+            if (e == hipSuccess) e = hipMalloc((void**)&ws->xqn, (size_t)np * sizeof(float));
+            if (e == hipSuccess) ws->bytes += ib + cl * 16 + ws->K * 4 + sel_blocks * 4 + np * 4;
+        }
     }
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_k, (size_t)kRecSlots * np * sizeof(unsigned short));
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_d, (size_t)kRecSlots * np * sizeof(float));
@@ -741,12 +766,14 @@ static int fetch_counters(gmmvb_workspace* ws) {
             ws->lag.listed = ws->lag.accum = ws->lag.act;
             ws->lag.exits = 0.0;
             ws->lag.cols = -1.0;
+            ws->lag.left = -1.0;
             ws->lag.proof = 0.0;
             ws->lag.moved = 0.0;
         } else {
             ws->lag.proof = ws->ctr_host[7];
             ws->lag.exits = (ws->exit_host && ws->gather_exit) ? (double)ws->exit_host[0] : 0.0;
             ws->lag.cols = (ws->exit_host && ws->pend_lazy) ? (double)ws->exit_host[1] : -1.0;
+            ws->lag.left = (ws->exit_host && ws->pend_proj) ? (double)ws->exit_host[2] : -1.0;
             ws->lag.settled = ws->ctr_host[4];
             ws->lag.listed = ws->ctr_host[5];
             ws->lag.accum = ws->ctr_host[6];                               // a bound pass / sweep also evaluated every row's (previous) best component
@@ -890,7 +917,7 @@ int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
     out[4] = ws->lag.mode == 0 ? 0.0 : ws->lag.exits;
     out[5] = ws->lag.mode == 0 ? 0.0 : ws->lag.proof;
     out[6] = ws->lag.mode == 3 ? ws->lag.cols : -1.0;
-    out[7] = 0.0;
+    out[7] = ws->lag.mode == 3 ? ws->lag.left : -1.0;
     return GMMVB_OK;
 }
 
@@ -916,6 +943,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
         ws->lock_reset = true;
     }
     ws->sorted = false;                // ... and the internal row order is the caller's again
+    ws->tile_ref_valid = false;
     ws->rec_valid = false;
     ws->dense_valid = false;
     ws->lag.valid = false;
@@ -938,7 +966,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->xc_ldx = ldx;
     ws->xc_stale = false;
     if (ws->xq) {              // the int8 digit planes of the proof round, about the same pivot
-        e = launch_x_digits(x_dev, ws->x_dtype == GMMVB_F64, ldx, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st);
+        e = launch_x_digits(x_dev, ws->x_dtype == GMMVB_F64, ldx, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st, ws->xqn);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "x_digits launch", e);
         ws->xq_src = x_dev;
         ws->xq_rows = n_rows;
@@ -1002,6 +1030,10 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K, ws->blk,
                        ws->lists, ws->npad);
+    ws->tile_ref_valid = false;
+    if (ws->tile_ref) {                // the groups' lengths are in counts now: every tile's reference component (project.h)
+        if (launch_proj_tile_ref(ws->counts, ws->K, sel_grid, ws->tile_ref, st) == hipSuccess) ws->tile_ref_valid = true;
+    }
     if (by_margin) {
         // (three row-sized index buffers in rotation: the new order goes where the best components were - the bound pass
         // that follows rewrites them)
@@ -1045,7 +1077,7 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     // M-step of f64 / ragged-D inputs): rebuilt there when needed (recenter_rows), not here - 4 ms and 10 GB at C3
     ws->xc_stale = ws->xc != nullptr;
     if (ws->xq && ws->xq_src == x_dev) {       // the digit planes follow the internal order (3 ms at C3, once or twice per fit)
-        hipError_t eq = launch_x_digits(ws->xp, ws->x_dtype == GMMVB_F64, ws->D, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st);
+        hipError_t eq = launch_x_digits(ws->xp, ws->x_dtype == GMMVB_F64, ws->D, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st, ws->xqn);
         if (eq != hipSuccess) return eq;
         ws->xq_gen = ws->pivot_gen;
     }
@@ -1250,6 +1282,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // (an E-step whose output went to another tile of the group still left its masks, block counts and best components)
     const bool after_estep = ws->e_state == 1 || ws->lost_estep;
     const bool prev_lists = (ws->active_lists || ws->blk_fresh) && after_estep && ws->act_rows == n_rows && same_rows;
+    // The stateless sweep (project.h) needs no carried per-pair bounds: the table gmmvb_set_params made for these parameters,
+    // the digit planes of this matrix about the pivot in force, regrouped rows and the previous pass's lists.
+    const bool can_project = ws->proj_table && ws->gimg != nullptr && ws->sorted && ws->tile_ref_valid && prev_lists &&
+                             ws->xq != nullptr && ws->xqn != nullptr && ws->xq_src == x_dev && ws->xq_rows == n_rows &&
+                             ws->xq_ldx == ldx && ws->xq_gen == ws->pivot_gen && ws->lock != nullptr;
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
         bool sparse_ok = ws->prune == 2;
@@ -1269,7 +1306,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th): below 0.5 the bounds are
             // made afresh.
             const double tg = ws->typical_gamma;
-            bool sweep = hinted && ws->dense_valid && !(tg > 0.0 && tg < policy::kGammaNoCarry);
+            bool sweep = hinted && (ws->dense_valid || (can_project && ws->opt_project == 2)) && !(tg > 0.0 && tg < policy::kGammaNoCarry);
             if (sweep && known && L.mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
@@ -1421,7 +1458,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     const int sel_grid = (int)((n_rows + kSelRows - 1) / kSelRows);
     const RecArrays rec{ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->npad};
-    bool counted = false, proof_ran = false, tmeta_kept = false;
+    bool counted = false, proof_ran = false, tmeta_kept = false, projected = false, filtered = false;
     ws->lse_stale = false;
     const bool tmeta_was_valid = ws->tmeta_valid;
     ws->tmeta_valid = false;            // (only a lazy sweep that ran to its end leaves the tile state in step with the bounds)
@@ -1569,7 +1606,20 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     if (e != hipSuccess) return fail(GMMVB_EHIP, "proof round (settled rows' own pairs)", e);
                 }
                 span_begin(ws, kSpanSelect, st);
-                if (ws->tmeta) {
+                if (can_project && ws->opt_project == 2) {
+                    // bounds from the table of the parameters in force and the rows' digit planes: nothing carried, nothing
+                    // written back (the per-pair array is void afterwards: ws->dense_valid below)
+                    note_hip(ws, hipMemsetAsync(ws->exit_ctr + 2, 0, sizeof(unsigned long long), st));
+                    ProjectArgs pa{ws->xq, ws->xqe, ws->xqn, ws->gimg, ws->gconst, ws->tile_ref, ws->lnrho, ws->npad, n_rows, ws->K,
+                                   ws->D, ws->drift, ws->cvec, ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel,
+                                   ws->rec_flags, ws->masks, ws->blk, ws->epart, ws->opart, settle ? ws->lock : nullptr, ws->dlock,
+                                   ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr, ws->rblk, ws->opt_proof_all ? 1 : 0,
+                                   own_round ? 1 : 0, ws->exit_ctr + 2};
+                    e = launch_rec_project(sel_grid, st, pa);
+                    if (e != hipSuccess) return fail(GMMVB_EHIP, "rec_project launch", e);
+                    name = "estep_sweep_projected";
+                    projected = true;
+                } else if (ws->tmeta) {
                     note_hip(ws, hipMemsetAsync(ws->exit_ctr + 1, 0, sizeof(unsigned long long), st));
                     // (the tile state is void after any pass that rewrote the bounds wholesale: the first sweep after it
                     // opens every column and takes stock)
@@ -1592,6 +1642,18 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                        n_rows, ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
                                        settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
                                        ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0, nullptr, 0);
+                }
+                if (proof && can_project && !projected) {
+                    // the table of the parameters in force first (project.h): a listed pair it clears needs no proof - most of
+                    // them are far pairs whose carried bound has eroded to the relevance line
+                    ProjectArgs pa{ws->xq, ws->xqe, ws->xqn, ws->gimg, ws->gconst, ws->tile_ref, ws->lnrho, ws->npad, n_rows, ws->K,
+                                   ws->D, ws->drift, ws->cvec, ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel,
+                                   ws->rec_flags, ws->masks, ws->blk, ws->epart, ws->opart, ws->lock, ws->dlock, ws->rthr, ws->lcomp,
+                                   ws->rmask, ws->rblk, 0, 0, ws->exit_ctr + 2};
+                    note_hip(ws, hipMemsetAsync(ws->exit_ctr + 2, 0, sizeof(unsigned long long), st));
+                    e = launch_proj_filter(sel_grid, st, pa);
+                    if (e != hipSuccess) return fail(GMMVB_EHIP, "proj_filter launch", e);
+                    filtered = true;
                 }
                 if (proof) {
                     // proof round: settled rows whose carried bounds left candidates - their component and the candidates
@@ -1652,6 +1714,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     }
     ws->tmeta_valid = tmeta_kept;
     ws->pend_lazy = tmeta_kept;
+    ws->pend_proj = projected || filtered;
     // the E phase of the profile ends behind the pass's LAST kernel (round 4; before, rec_finish / lse_mask - 0.2-0.4 ms of
     // E-step work at the benchmark shape - fell between the two phases and were booked as "outside the data pass")
     if (phase_events(ws)) {
@@ -1662,7 +1725,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (counted) {
         e = hipMemcpyAsync(ws->ctr_host, ws->ctr, 8 * sizeof(double), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && ws->exit_ctr && mode != kDense)
-            e = hipMemcpyAsync(ws->exit_host, ws->exit_ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+            e = hipMemcpyAsync(ws->exit_host, ws->exit_ctr, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(ws->ctr_ev, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step counters", e);
         ws->ctr_pending = true;
@@ -1697,7 +1760,8 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     ws->prev_pass = mode;
     // the f32 bound array holds a value or bound under the parameters in force for EVERY pair after a dense pass, a
     // bound pass or a sweep; a pass on records only refreshes the evaluated entries
-    ws->dense_valid = true;
+    // (a projected sweep leaves the array alone: it is void until a dense or bound pass rewrites it)
+    ws->dense_valid = !projected;
     if (mode == kDense || mode == kBound) ws->sweeps = 0;
     std::snprintf(ws->info, sizeof(ws->info), "%s grid=%lldx%d rows/workgroup=%d", name, (long long)grid,
                   (i8 || mode != kDense) ? 512 : estep_threads(ws->estep_variant), rpw);

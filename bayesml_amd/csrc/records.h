@@ -44,37 +44,6 @@
 
 namespace gmmvb {
 
-constexpr int kRecSlots = 8;
-constexpr unsigned short kRecEmpty = 0xFFFF;
-constexpr unsigned short kRecListed = 0x4000, kRecExactBit = 0x8000, kRecCompMask = 0x3FFF;
-constexpr double kRelNats = kRelevanceNats;      // kRelevanceBits ln 2 (common.h)
-
-struct RecArrays {
-    unsigned short* k;      // [C][npad] component of slot j (kRecEmpty: unused)
-    float* d;               // [C][npad] lower bound of the whitened distance, rounded towards zero
-    float* B;               // [npad] upper bound of ln rho for every component without a slot (-inf: there is none)
-    unsigned char* exact;   // [npad] bit j: d_j is the distance itself: d_j <= dist <= d_j (1 + 2^-22)
-    unsigned char* sel;     // [npad] bit j: slot j was listed for exact evaluation in the current pass
-    unsigned char* flags;   // [npad] bit 0: overflow row of the current pass (all K pairs evaluated exactly);
-                            //        bit 1: refreshed row (components without a slot were listed too)
-    int64_t npad;
-};
-
-__device__ __forceinline__ float f32_down(double v) { return __double2float_rd(v); }      // v >= 0: towards zero
-__device__ __forceinline__ float f32_up(double v) { return __double2float_ru(v); }
-
-// whitened distance (lower bound if v is an upper bound of ln rho) from a stored value; NaN -> 0 (always a candidate)
-__device__ __forceinline__ double dist_of(double c, double v) {
-    const double q = 2.0 * (c - v);
-    return q > 0.0 ? sqrt(q) : 0.0;
-}
-// the same as a LOWER bound in f32 (directed rounding all the way: 1e-7 relative looseness), for values that are
-// bounds anyway - the f64 square root is a quarter-rate instruction and the sweep does K of them per row
-__device__ __forceinline__ float dist_lower_f32(double c, double v) {
-    const float q = __double2float_rd(2.0 * (c - v));
-    return q > 0.0f ? sqrtf(q) * (1.0f - 2.4e-7f) : 0.0f;       // two ulps below whatever rounding sqrtf has
-}
-
 // Sorted insertion of (distance cd, component ck, value cv) into the ascending list of the C nearest components;
 // whatever falls off its end belongs to the rest, whose largest value is kept in `rest` (NaN sticks) - unless it is
 // marked kRecListed (it is being evaluated exactly in this pass and will compete for a slot again in rec_finish_kernel).
@@ -163,18 +132,6 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
     rec.exact[n] = (unsigned char)ex;
     rec.sel[n] = 0;
     rec.flags[n] = 0;
-}
-
-// per-block component counts of a 64-bit mask word (as in select_mask_kernel)
-template <bool UNIFORM = true>
-__device__ __forceinline__ void count_word(unsigned long long mk, int w, int wave, int (*wcnt)[256]) {
-    unsigned long long present = UNIFORM ? wave_or(mk) : wave_or_shfl(mk);
-    while (present) {
-        const int b = __builtin_ctzll(present);
-        present &= present - 1;
-        const int c = __builtin_popcountll(__ballot((mk >> b) & 1ull));
-        if ((threadIdx.x & 63) == 0) wcnt[wave][64 * w + b] = c;
-    }
 }
 
 // After a bound pass: select the candidates from the records rec_build_kernel<true> has just made (no parameter update in
@@ -306,31 +263,11 @@ __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int
 //     chain of nine min / max pairs on 32-bit keys: the bound's bits in descending order (upper 24 bits) | component
 //     (K <= 256).  The ninth key is the largest bound without a slot: the rest bound.  Slot distances are recovered
 //     from the keys (bounds rounded up to 15 mantissa bits: 3e-5 relative); exact slots read their value again.
-__device__ __forceinline__ unsigned sweep_key(float ub, unsigned k) {
-    const unsigned bits = __float_as_uint(ub);
-    const unsigned inv = bits ^ (~(unsigned)((int)bits >> 31) & 0x7FFFFFFFu);        // descending in ub, exact
-    return (inv & 0xFFFFFF00u) | k;
-}
-__device__ __forceinline__ float sweep_key_bound(unsigned key) {                     // >= the bound the key was made of
-    const unsigned inv = key & 0xFFFFFF00u;
-    return __uint_as_float(inv ^ (~(unsigned)((int)inv >> 31) & 0x7FFFFFFFu));
-}
-__device__ __forceinline__ void sweep_chain(unsigned (&s)[kRecSlots + 1], unsigned key) {
-#pragma unroll
-    for (int j = 0; j < kRecSlots; ++j) {
-        const unsigned lo = min(s[j], key);
-        key = max(s[j], key);
-        s[j] = lo;
-    }
-    s[kRecSlots] = min(s[kRecSlots], key);
-}
-
 // A settled row's reference is a lower bound of ln rho of its one component under the new parameters.  Carried from the
 // previous pass (d' = Gamma d + delta) it loses about d^2 (Gamma - 1) + d delta nats - hundreds while the components still
 // move by per cents, and every nat it is too low lets more components' bounds through as candidates.  For components that
 // moved by more than this the settled rows' own pair goes through the proof round BEFORE the sweep (the lower bound in
 // the ln rho array, estep_i8_proof without its upper-bound store); both kernels decide with this one predicate.
-__device__ __forceinline__ bool own_first(double big_gamma, double delta) { return big_gamma > 1.004 || delta > 0.04; }
 
 // One step of the carry for a stored bound `old`, p = (gamma, delta, c' up, c the bound was stored under, down): the
 // kernel's per-pair arithmetic.  Every operation is monotone in `old` (round-to-nearest is), so applied to the LARGEST
@@ -718,6 +655,9 @@ __global__ __launch_bounds__(kSelRows, (LAZY && WC >= 3 ? 5 : 1)) void rec_sweep
                 }
                 if (!sfirst[kset]) pm[kset >> 6] |= 1ull << (kset & 63);      // (else its lower bound is fresh already)
                 proof_row = true;
+                // (the new distance bound, should the table of project.h clear every candidate before the proof round:
+                // proj_filter_kernel then keeps the row settled; rec_proof_decide_kernel overwrites it otherwise)
+                dlock[n] = d_set;
             } else {
                 mk[kset >> 6] |= 1ull << (kset & 63);          // loose: its component and the candidates are evaluated -
                 // in full: a candidate that left the gather early would keep a loose bound, erode back to the threshold

@@ -13,6 +13,7 @@ struct gmmvb_pass_counters {
     bool valid = false;
     double act = 0.0, eval = 0.0, over = 0.0, settled = 0.0, listed = 0.0, accum = 0.0, proof = 0.0, exits = 0.0, moved = 0.0;
     double cols = -1.0;          // (tile, component) columns of the bound array the last sweep went through; -1: not a lazy sweep
+    double left = -1.0;          // pairs the stateless table (project.h) did not clear; -1: the pass was no projected sweep
     double rows = 0.0;           // rows the counters were taken over
     double ranks = 1.0;          // ranks they were summed over
     int mode = 0;                // kind of the pass: 0 dense, 1 bound pass, 2 carried records, 3 sweep
@@ -148,9 +149,10 @@ struct gmmvb_workspace {
     unsigned char* lcomp = nullptr;    // [npad] cached rows: the component whose cache holds the row (K <= 256)
     float* dlock = nullptr;            // [npad] settled rows: upper bound of the whitened distance to their component
     float* rthr = nullptr;             // [npad] relevance threshold of the selection round (best exact value - 80 ln 2)
-    unsigned long long* exit_ctr = nullptr;    // [2] device: candidate pairs of the pass that took the gather's early way out;
-                                               //     (tile, component) columns the lazy sweep opened
-    unsigned long long* exit_host = nullptr;   // [2] pinned mirror (copied with the other counters)
+    unsigned long long* exit_ctr = nullptr;    // [4] device: candidate pairs of the pass that took the gather's early way out;
+                                               //     (tile, component) columns the lazy sweep opened; pairs the table of
+                                               //     project.h took off the proof lists (stateless sweep: pairs it left)
+    unsigned long long* exit_host = nullptr;   // [4] pinned mirror (copied with the other counters)
     bool pend_lazy = false;                    // the pass behind the pending counters was a lazy sweep
     unsigned long long* dmask = nullptr;   // [ceil(K / 64)][npad] rows entering / leaving the cache in this pass
     int* dblk = nullptr;               // [blocks][K] their block counts
@@ -188,6 +190,20 @@ struct gmmvb_workspace {
     bool opt_lazy = true;              // env GMMVB_SWEEP_LAZY=0: every sweep goes through all K bounds of every row
     bool opt_proof_all = true;         // the candidates of rows with an exact reference go through the proof round too (env
                                        // GMMVB_PROOF=settled: only the settled rows' pairs)
+    // The stateless sweep (project.h): bounds from the parameters in force and the rows' int8 digit planes instead of the
+    // carried per-pair array.  gimg / gconst are made by gmmvb_set_params when a sweep can follow (regrouped rows, digit
+    // planes about the pivot in force, a drift hint for the settled rows' own bound), tile_ref by the regrouping.
+    unsigned char* gimg = nullptr;     // [K][proj_image_bytes] int8 digit images of g_jk, per reference component j
+    void* gconst = nullptr;            // [K][32 proj_kblocks] float4 constants per (reference, column)
+    float* hk = nullptr;               // [K] half a lower bound of lambda_min(U_k^T U_k)
+    int* tile_ref = nullptr;           // [blocks] reference component of every tile of kSelRows rows (regrouped order)
+    float* xqn = nullptr;              // [npad] || x - pivot ||^2 rounded down, made with the digit planes
+    int opt_project = 0;               // env GMMVB_PROJECT: "filter" (1) the table filters the carried sweep's proof lists, "only" (2)
+                                       // the sweep itself is stateless (rec_project_kernel); default 0: no table (it does not
+                                       // pay on the benchmark's fits, profiles/r6_experiments.md)
+    bool proj_table = false;           // gimg / gconst describe the parameters in force
+    bool tile_ref_valid = false;       // tile_ref describes the row order in force
+    bool pend_proj = false;            // the pass behind the pending counters used the table (exit_ctr[1]: pairs it left / removed)
     float4* tmeta = nullptr;           // [blocks][K] the lazy sweep's state per tile and component (records.h)
     bool tmeta_valid = false;          // it describes the bound array as it is (only sweeps have written to it since)
     double* ppart = nullptr;           // [blocks] pairs of the proof round per selection block

@@ -400,7 +400,9 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
  * digits (about a fifth of an exact evaluation's cost) - rows that are proven to keep a single active component are not
  * evaluated at all (their responsibility is 1.0 to the last bit whatever the value); out[6] after a sweep: the (tile of
  * 256 rows, component) columns of the per-pair bound array it had to go through, of ceil(n_rows / 256) * K (-1: the pass
- * was no sweep, or GMMVB_SWEEP_LAZY=0); out[7] reserved (0). */
+ * was no sweep, or GMMVB_SWEEP_LAZY=0); out[7] after a sweep that used the table of csrc/project.h (bounds from the parameters
+ * in force and the rows' int8 digit planes): the pairs it took off the proof round's lists - with GMMVB_PROJECT=only, where the
+ * table replaces the carried bounds, the pairs it did not clear (-1: the pass used no table). */
 int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[8], host*/);
 
 /* ---- device-side data generation (ABI v8) -------------------------------------------------------------

@@ -22,7 +22,8 @@ from oracle import gmm_vb_oracle as orc
 pytestmark = pytest.mark.gpu
 
 ENV_KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "GMMVB_ESTEP_CARRY_OFF", "GMMVB_SORT_ROWS", "GMMVB_SETTLE_MARGIN",
-            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT", "GMMVB_SWEEP_LAZY", "GMMVB_PROOF_BLOCKED", "GMMVB_REGROUP_MARGIN")
+            "GMMVB_MSTEP_CACHE", "GMMVB_PROOF", "GMMVB_GATHER_EXIT", "GMMVB_SWEEP_LAZY", "GMMVB_PROOF_BLOCKED", "GMMVB_REGROUP_MARGIN",
+            "GMMVB_PROJECT")
 VARIANTS = {
     "default": {},
     # Rows with a single active component are settled (left out of the E-step).  Default: in every pruned pass, without
@@ -47,6 +48,13 @@ VARIANTS = {
     "proof_by_component": {"GMMVB_PROOF_BLOCKED": "0"},
     "force_proof_by_component": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROOF_BLOCKED": "0"},
     "force": {"GMMVB_ESTEP_PRUNE": "force"},
+    # The stateless table of csrc/project.h (bounds from the parameters in force and the rows' int8 digit planes), opt-in:
+    # "project_filter": it takes pairs off the carried sweep's proof lists; "project_only": it replaces the carried per-pair
+    # bounds altogether (rec_project_kernel).  Default: no table - all three must agree with the reference
+    "project_filter": {"GMMVB_PROJECT": "filter"},
+    "force_project_filter": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROJECT": "filter"},
+    "project_only": {"GMMVB_PROJECT": "only"},
+    "force_project_only": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_PROJECT": "only"},
     # the rows regrouped by best component only (default: within a component by how firmly they sit in it)
     "force_nomargin": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_REGROUP_MARGIN": "0"},
     "force_nocache": {"GMMVB_ESTEP_PRUNE": "force", "GMMVB_MSTEP_CACHE": "0"},
@@ -135,6 +143,10 @@ LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n1400
          ("gmm_f3_k64_d128_n140000_f32.npz", "nosettle"), ("gmm_f3_k64_d128_n140000_f32.npz", "nocache"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "noexit"), ("gmm_f3_k64_d128_n140000_f32.npz", "nolazy"),
          ("gmm_f3_k64_d128_n140000_f32.npz", "proof_settled"), ("gmm_f3_k64_d128_n140000_f32.npz", "proof_by_component"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "project_filter"), ("gmm_f3_k256_d64_n36000_f32.npz", "project_filter"),
+         ("gmm_f3_k256_d64_n36000_f32.npz", "force_project_filter"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_project_filter"),
+         ("gmm_f3_k64_d128_n140000_f32.npz", "project_only"), ("gmm_f3_k256_d64_n36000_f32.npz", "project_only"),
+         ("gmm_f3_k256_d64_n36000_f32.npz", "force_project_only"), ("gmm_f3_k16_d64_n32768_f32_spread1.npz", "force_project_only"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "force_proof_by_component"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "nolazy"),
          ("gmm_f3_k256_d64_n36000_f32.npz", "settle"),
@@ -149,7 +161,7 @@ LARGE = [("gmm_f3_k64_d128_n140000_f32.npz", "default"), ("gmm_f3_k64_d128_n1400
 # components), mixing weights ~ Dirichlet(0.3), anisotropic clusters (per-feature scales 0.3 ... 3) - reference fixtures, the
 # pruned path forced (N K = 2^19: the default policy stays dense at this size, which is the fourth variant)
 OFFPATH = [(f"gmm_f3_k16_d64_n32768_f32_{kind}.npz", variant) for kind in ("kdata8", "weights", "aniso")
-           for variant in ("force", "force_nocache", "force_noproof", "default")]
+           for variant in ("force", "force_nocache", "force_noproof", "force_project_filter", "force_project_only", "default")]
 LARGE += OFFPATH
 
 
@@ -189,7 +201,17 @@ def test_large_fixture_matches_reference(name, variant):
     assert np.max(np.abs(m.r_vecs[:64] - g["r_head"])) < 1e-6
     assert np.max(np.abs(m._engine.responsibilities().sum(dim=0).cpu().numpy() - g["r_colsum"])) < 1e-6 * N / K
     assert abs(m.vl - float(g["final_vl"])) <= 1e-8 * abs(float(g["final_vl"]))
-    if not offpath and "overlap" not in name and "spread1" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled"):
+    if m._engine.launch_info.startswith("estep_sweep"):
+        # which sweep it was, and whether the table took part: as a filter (GMMVB_PROJECT=filter), as the sweep itself
+        # (GMMVB_PROJECT=only), or - the default - not at all
+        wk = m._engine.work()
+        if variant in ("project_filter", "force_project_filter"):
+            assert m._engine.launch_info.startswith("estep_sweep_bounds") and wk["table_left"] >= 0, (m._engine.launch_info, wk)
+        elif variant in ("project_only", "force_project_only"):
+            assert m._engine.launch_info.startswith("estep_sweep_projected") and wk["table_left"] >= 0, m._engine.launch_info
+        else:
+            assert m._engine.launch_info.startswith("estep_sweep_bounds") and wk["table_left"] < 0, m._engine.launch_info
+    if not offpath and "overlap" not in name and "spread1" not in name and variant in ("default", "settle", "noproof", "nosettle", "nocache", "noexit", "nolazy", "proof_settled", "project_filter", "project_only"):
         # the M-step's cache of single-component rows: in use by default, its rows are not accumulated
         # again; settled rows are not even evaluated
         wk = m._engine.work()
@@ -200,7 +222,7 @@ def test_large_fixture_matches_reference(name, variant):
             assert 0 <= wk["accumulated"] <= wk["active"], wk
             if swept:
                 assert wk["accumulated"] < wk["active"], wk
-        if variant in ("default", "settle") and swept:
+        if variant in ("default", "settle", "project_filter", "project_only") and swept:
             assert wk["settled_rows"] > 0.2 * N and wk["evaluated"] < wk["active"], wk
         if variant in ("nosettle", "noproof"):      # (without settled rows the proof round still serves the bound passes)
             assert wk["settled_rows"] == 0 and (wk["proof_pairs"] == 0 or variant == "nosettle"), wk
@@ -230,7 +252,7 @@ def _oracle_post(q):
 
 
 @pytest.mark.parametrize("variant", ["force", "force_settle", "force_noproof", "force_proof_settled", "force_nolazy",
-                                     "force_nomargin"])
+                                     "force_nomargin", "force_project_filter", "force_project_only"])
 def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
     """Property behind gmmvb_set_drift, checked right after E-steps that lived on carried bounds: every value in
     the workspace is either the exact ln rho - as the ORACLE computes it for the same posterior - or an upper
@@ -280,9 +302,10 @@ def test_carried_bounds_are_upper_bounds_of_the_oracle(variant):
         checked += 1
     assert checked >= 3, eng.pass_counts()
     assert cached_seen > 0.1 * N, cached_seen       # single-component rows the M-step did not accumulate again
-    if variant in ("force", "force_settle", "force_nolazy"):     # rows that were not evaluated at all: read out exactly all the same -
+    if variant in ("force", "force_settle", "force_nolazy", "force_project_filter", "force_project_only"):     # rows that were not evaluated at all: read out exactly all the same -
         assert settled_seen > 0.1 * N, settled_seen          # many of them on the strength of the int8 proof round
-        assert proof_seen > 0.01 * N, proof_seen
+        if variant in ("force", "force_settle", "force_nolazy"):   # (carried bounds erode into the proof round; with the
+            assert proof_seen > 0.01 * N, proof_seen               # table in front of it next to nothing is left)
     if variant == "force_noproof":
         assert proof_seen == 0 and settled_seen == 0
 
