@@ -81,6 +81,8 @@ SYMBOLS = {
     "gmmvb_profile_last_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "gmmvb_profile_spans": (_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_int)]),
     "gmmvb_profile_span_name": (ctypes.c_char_p, [_int]),
+    "gmmvb_policy_calibrate": (_int, [_vp, _int]),
+    "gmmvb_policy_table": (_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "gmmvb_sample_latent": (_int, [_int, _vp, ctypes.c_uint64, _i64, _i64, _vp, _vp]),
     "gmmvb_sample_chain_work_bytes": (_i64, [_int, _i64]),
     "gmmvb_sample_chain": (_int, [_int, _vp, _vp, ctypes.c_uint64, _i64, _vp, _vp, _i64, _vp]),
@@ -400,6 +402,17 @@ class DataPass:
         share = float(out[6]) / (tiles * self.K) if out[6] >= 0 and tiles else -1.0
         return dict(active=float(out[0]), evaluated=float(out[1]), accumulated=float(out[2]), settled_rows=float(out[3]),
                     early_exits=float(out[4]), proof_pairs=float(out[5]), sweep_share=share, table_left=float(out[7]))
+
+    def policy_table(self) -> dict:
+        """Unit costs (ns per pair) and thresholds of the pass policy in force, and which of them this workspace has measured
+        on its own passes (gmmvb_policy_table; csrc/policy.h)."""
+        out = (ctypes.c_double * 16)()
+        _check(self.lib, self.lib.gmmvb_policy_table(self._ws, out), "gmmvb_policy_table")
+        keys = ("dense_e_ns", "dense_m_ns", "bound_ns", "exact_ns", "proof_ns", "list_m_ns", "literal_dense_e_ns",
+                "literal_dense_m_ns", "literal_bound_ns", "prune_below", "dense_again_above", "list_m_below")
+        d = {k: float(out[i]) for i, k in enumerate(keys)}
+        d.update(measured=int(out[12]), discarded=int(out[13]), calibrating=bool(out[14]))
+        return d
 
     def profile(self, on: bool = True):
         _check(self.lib, self.lib.gmmvb_profile_enable(self._ws, int(on)), "gmmvb_profile_enable")
@@ -784,6 +797,9 @@ class TiledDataPass:
     def sparsity(self):
         self._gather()
         return self._spars if self._spars is not None else (-1.0, 0.0)
+
+    def policy_table(self):
+        return self.inner.policy_table()
 
     def work(self):
         self._gather()

@@ -45,6 +45,7 @@ int64_t gmmvb_stats_len(int K, int D) {
 }
 
 static int ensure_lists(gmmvb_workspace* ws);
+static void cal_poll(gmmvb_workspace* ws);
 
 // profiling spans (gmmvb_profile_spans): HIP events on the launch stream around groups of kernels
 enum { kSpanEstepMain = 0, kSpanSelect = 1, kSpanGather = 2, kSpanLse = 3, kSpanLists = 4, kSpanMstepMain = 5,
@@ -217,7 +218,7 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
     }
     ws->img_len = estep_image_doubles(ws->T);
     {
-        const char* v = std::getenv("GMMVB_ESTEP_VARIANT");
+        const char* v = dev_env("GMMVB_ESTEP_VARIANT");
         ws->estep_variant = kEstepLds8;      // measured fastest (two waves per SIMD share one LDS image)
         if (ws->wide) v = nullptr;           // (one E-step kernel past 8 feature tiles)
         // ... except with a single feature tile (D <= 16): the 2.5-KB images stay in L1, staging them through LDS with a
@@ -259,34 +260,37 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
             ws->sparse = false;
             if (!ws->wide) bufs[6].n = 0;          // (past 8 feature tiles the M-step only exists over the centred copy)
         }
-        v = std::getenv("GMMVB_SORT_ROWS");
+        v = dev_env("GMMVB_SORT_ROWS");
         ws->sort_rows = !(v && std::strcmp(v, "0") == 0) && (int64_t)max_rows <= 2000000000;
         v = std::getenv("GMMVB_ESTEP_PRUNE");
         ws->prune = (v && std::strcmp(v, "0") == 0) ? 0 : ((v && std::strcmp(v, "force") == 0) ? 2 : 1);
         if (!ws->sparse || estep_bound_blocks(ws->T) == 0 || K > 256) ws->prune = 0;
-        v = std::getenv("GMMVB_SETTLE_MARGIN");                    // nats; negative = never settle rows
+        v = dev_env("GMMVB_SETTLE_MARGIN");                    // nats; negative = never settle rows
         if (v) ws->settle_margin = std::atof(v);
-        v = std::getenv("GMMVB_PROOF");                            // "0": no int8 proof round (rows then never settle);
+        v = dev_env("GMMVB_PROOF");                            // "0": no int8 proof round (rows then never settle);
         ws->opt_proof = !(v && std::strcmp(v, "0") == 0);
         ws->opt_proof_all = !(v && std::strcmp(v, "settled") == 0);     // "settled": only the settled rows' pairs go through it
-        v = std::getenv("GMMVB_PROOF_BLOCKED");                    // "0": the proof round walks component after component
+        v = dev_env("GMMVB_PROOF_BLOCKED");                    // "0": the proof round walks component after component
         ws->opt_proof_blocked = !(v && std::strcmp(v, "0") == 0);
-        v = std::getenv("GMMVB_SWEEP_LAZY");                       // "0": every sweep reads all K bounds of every row
+        v = dev_env("GMMVB_SWEEP_LAZY");                       // "0": every sweep reads all K bounds of every row
         ws->opt_lazy = !(v && std::strcmp(v, "0") == 0);
         // the stateless table of project.h - off by default (measured, profiles/r6_experiments.md: on the benchmark's fits it
         // costs more than the proof pairs it saves): "filter" = it takes pairs off the carried sweep's proof lists, "only" =
         // it replaces the carried per-pair bounds
-        v = std::getenv("GMMVB_PROJECT");
+        v = dev_env("GMMVB_PROJECT");
         ws->opt_project = (v && std::strcmp(v, "filter") == 0) ? 1 : ((v && std::strcmp(v, "only") == 0) ? 2 : 0);
-        v = std::getenv("GMMVB_REGROUP_MARGIN");     // "0": the rows are regrouped by best component only
+        v = dev_env("GMMVB_REGROUP_MARGIN");     // "0": the rows are regrouped by best component only
         ws->opt_regroup_margin = !(v && std::strcmp(v, "0") == 0);
-        v = std::getenv("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
+        v = dev_env("GMMVB_GATHER_EXIT");                      // "0": candidates are always evaluated in full
         ws->gather_exit = !(v && std::strcmp(v, "0") == 0);
-        v = std::getenv("GMMVB_MSTEP_CACHE");
+        v = dev_env("GMMVB_MSTEP_CACHE");
         ws->cache_on = !(v && std::strcmp(v, "0") == 0);
-        ws->opt_carry_off = std::getenv("GMMVB_ESTEP_CARRY_OFF") != nullptr;
-        ws->opt_hmm_mstep_dense = std::getenv("GMMVB_HMM_MSTEP_DENSE") != nullptr;
-        ws->opt_debug = std::getenv("GMMVB_DEBUG") != nullptr;
+        ws->opt_carry_off = dev_env("GMMVB_ESTEP_CARRY_OFF") != nullptr;
+        ws->opt_hmm_mstep_dense = dev_env("GMMVB_HMM_MSTEP_DENSE") != nullptr;
+        {
+            const char* dbg = std::getenv("GMMVB_DEBUG");
+            ws->opt_debug = dbg && dbg[0] == '2';
+        }
     }
     {
         const bool full = ws->estep_variant == kEstepI8, bound = ws->prune != 0;
@@ -349,6 +353,13 @@ static int create_workspace(int K, int D, int x_dtype, int64_t max_rows, gmmvb_w
     if (e == hipSuccess) e = hipMemset(ws->ctr, 0, 8 * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&ws->ctr_host, 8 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ctr_ev, hipEventDisableTiming);
+    // the policy table at this shape, and the events its calibration records around the workspace's own first bulk passes
+    ws->pt.init(ws->T, estep_bound_blocks(ws->T) ? (D + 31) / 32 : 0);
+    {
+        const char* v = dev_env("GMMVB_POLICY_CALIBRATE");
+        ws->opt_calibrate = !(v && std::strcmp(v, "0") == 0);
+    }
+    for (int i = 0; i < 6 && e == hipSuccess && ws->prune != 0; ++i) e = hipEventCreate(&ws->cal_ev[i]);
     if (e != hipSuccess) {
         gmmvb_workspace_destroy(ws);
         return fail(GMMVB_EHIP, "workspace initialisation", e);
@@ -401,6 +412,8 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     for (hipEvent_t e : ws->ev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ws->span_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ws->cal_ev)
         if (e) (void)hipEventDestroy(e);
     if (ws->hmm) hmm_state_destroy(ws->hmm);
     delete ws;
@@ -921,6 +934,28 @@ int gmmvb_last_work(gmmvb_workspace* ws, double* out) {
     return GMMVB_OK;
 }
 
+int gmmvb_policy_calibrate(gmmvb_workspace* ws, int on) {
+    if (!ws) return fail(GMMVB_EINVAL, "null argument");
+    ws->opt_calibrate = on != 0;
+    if (!on) {                        // back to the scaled literals
+        ws->pt.init(ws->T, estep_bound_blocks(ws->T) ? (ws->D + 31) / 32 : 0);
+        for (double& p : ws->cal_pairs) p = 0.0;
+    }
+    return GMMVB_OK;
+}
+
+int gmmvb_policy_table(gmmvb_workspace* ws, double* out /*[GMMVB_POLICY_TABLE_LEN], host*/) {
+    if (!ws || !out) return fail(GMMVB_EINVAL, "null argument");
+    cal_poll(ws);
+    const gmmvb::PolicyTable& t = ws->pt;
+    const double v[GMMVB_POLICY_TABLE_LEN] = {t.dense_e_ns, t.dense_m_ns, t.bound_ns, t.exact_ns, t.proof_ns, t.list_m_ns,
+                                              t.lit_dense_e, t.lit_dense_m, t.lit_bound, t.prune_below(), t.dense_again_above(),
+                                              t.list_m_below(), (double)(t.measured & 7), (double)((t.measured >> 3) & 7),
+                                              ws->opt_calibrate ? 1.0 : 0.0, 0.0};
+    for (int i = 0; i < GMMVB_POLICY_TABLE_LEN; ++i) out[i] = v[i];
+    return GMMVB_OK;
+}
+
 static int check_x(const gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_rows, bool* vec) {
     if (!ws || !x_dev) return fail(GMMVB_EINVAL, "null argument");
     if (n_rows < 1 || n_rows > ws->max_rows) return fail(GMMVB_EINVAL, "n_rows must be in [1, max_rows]");
@@ -1125,63 +1160,39 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     return e;
 }
 
-// ---- pass policy: unit costs and the thresholds that follow from them -------------------------------------------------
-// gmmvb_estep / gmmvb_mstep choose between kernels whose results agree to rounding; only the time depends on the choice.
-// Every number the choice uses is one of the unit costs below (measured on MI355X at the benchmark shape, they enter the
-// formulas multiplied by tile counts, so they scale with D) or a threshold derived from them; the few that are plain
-// observations cite the measurement.  Sources: bench.py's `dense` leg (profiles/r4_bench_line_w5s20.json), the kernel
-// trace profiles/r4_bench_kernel_summary.md, the spread sweep (`spread_sweep` leg of the same line), profiles/r*_experiments.md.
-namespace policy {
-// unit costs, in units of 1e-11 s
-constexpr double kI8BlockPair = 0.12;     // int8 bound pass, per 32 x 32 block pair of a (row, component) pair
-constexpr double kI8RowOfY = 0.039;       // ... per row of y its epilogue bounds (32 per output block)
-                                          //   all four blocks at D = 128: 0.12 * 10 + 0.039 * 128 = 6.2 -> 0.062 ns per pair = the
-                                          //   38-ms pass over 6.4e8 pairs of the kernel trace
-constexpr double kF64TilePair = 0.81;     // exact evaluation (estep_gather_dev_f64) per 16 x 16 f64 tile pair: 36 of them at D = 128
-                                          //   = 0.29 ns per pair; trace: 0.31-0.33 ns per pair in bulk
-constexpr double kProofPerExact = 0.33;   // an int8 proof pair (0.10 ns, tools/bench_proof.py) in exact pairs (0.31 ns)
-// dense kernels, ns per pair at D = 128: E 172.0 ms / 6.4e8 = 0.269, M 167.1 ms / 6.4e8 = 0.261 (`dense` leg)
-constexpr double kDenseEns = 0.269, kDenseMns = 0.261;
-constexpr double kBoundNs = 0.062 + 0.010;   // bound pass per pair + record building / selection around it (6 of 44 ms)
-constexpr double kExactNs = 0.31, kProofNs = 0.10;
-constexpr double kListMns = 0.355;        // list M-step per accumulated pair on long lists (22 of 64 active: 78 ms / 2.2e8,
-                                          //   profiles/r3_full_run.json pass 2; 0.29-0.30 on short lists since round 4)
-// The pruned E-step pays the bound pass for every pair and proof + exact evaluation for the active ones:
-//   kBoundNs K + act (kExactNs + kProofNs)  <  kDenseEns K   <=>   act / K < (0.269 - 0.072) / 0.41 = 0.48
-constexpr double kPruneBelow = (kDenseEns - kBoundNs) / (kExactNs + kProofNs);
-// ... and once a bound pass has left `eval` pairs per row for the exact kernels, the dense kernel is the cheaper next pass if
-//   kBoundNs K + eval kExactNs > kDenseEns K   <=>   eval / K > 0.64 (the proof round has run by then: its cost is sunk)
-constexpr double kDenseAgainAbove = (kDenseEns - kBoundNs) / kExactNs;
-// The list M-step wins while act kListMns < K kDenseMns  <=>  act / K < 0.73; a sixth off for building lists that long: 0.6.
-// (Round 3 used 0.35; the spread sweep's spread 0.75 - 31 to 40 of 64 components active for twenty passes - is where it matters.)
-constexpr double kListMBelow = kDenseMns / kListMns * (5.0 / 6.0);
-// An overflow row (no usable reference: all K pairs evaluated) costs K kExactNs against K kBoundNs for bounding it afresh, so
-// carrying stops paying at 0.072 / 0.31 = 0.23 overflow rows per row - and overflow rows multiply by 4-8 from one carried
-// pass to the next (profiles/r2_experiments.md): 0.23 / 8 = 0.029, rounded down
-constexpr double kOverflowRows = 0.02;
-static_assert(kOverflowRows <= kBoundNs / kExactNs / 8.0, "carrying must stop before overflow rows cost a bound pass");
-static_assert(kProofPerExact >= kProofNs / kExactNs && kProofPerExact < 1.1 * kProofNs / kExactNs, "proof pair cost in exact pairs");
-// Spare candidates (listed, then found inactive) of a carried pass grow by about 2.5x per pass (same source): carrying goes on
-// while evaluating next pass's spares costs less than a fresh bound pass
-constexpr double kSpareGrowth = 2.5;
-// A carried pass that evaluates more than this share of the pairs has lost its bounds (a fresh bound pass at the benchmark
-// shape leaves 0.05-0.10: profiles/r3_experiments.md, "bound level" rows)
-constexpr double kCarriedEvalAbove = 0.35;
-// The carry u' = c' - (gamma d - delta)^2 / 2 keeps gamma^2 of a pair's distance: below gamma = 0.5 a pair four thresholds
-// away becomes a candidate - nothing survives; straight from a dense pass (parameters still jumping) the measured limit is
-// higher: gamma < 0.85 left 118 of 256 candidates per row at config 4 (171 ms, profiles/r3_experiments.md)
-constexpr double kGammaNoCarry = 0.5, kGammaNoCarryAfterDense = 0.85;
-// A sweep straight after a dense pass carries K exact values per row: only worth it when few are active
-constexpr double kSweepAfterDenseBelow = 0.1;
-// Regrouping the rows by dominant component (8 ms at the benchmark shape) pays once the passes are list-driven: at most 2.5
-// active components per row to force the one regrouping bound pass, at most 4 to regroup at a bound pass that happens
-// anyway, again after 5 % of the rows have changed their component (profiles/r2_experiments.md: gather + select 7.3 -> 6.4 ms,
-// list M-step 4.8 -> 4.2 ms on grouped rows; profiles/r3_experiments.md r3a2: regrouping at up to 32 active was worse)
-constexpr double kRegroupForceBelow = 2.5, kRegroupBelow = 4.0, kRegroupMoved = 0.05;
-// The own-pair round before the sweep is skipped while no component moves: own_first() needs Gamma > 1.004 or delta > 0.04,
-// which min_k (gamma_k - delta_k / 30) >= 0.995 rules out for every k (1 / 1.004 = 0.996; 0.04 / 30 = 0.0013)
-constexpr double kOwnRoundBelow = 0.995;
-}  // namespace policy
+// ---- pass policy: unit costs, thresholds and their calibration live in policy.h (ws->pt) --------------------------------
+
+// Calibration of the policy table (policy.h) from the workspace's own passes: events around its first dense E-step, dense
+// M-step and full bound pass of at least 2^23 pairs, taken over - like the pass counters - once they have completed.
+static bool cal_wanted(gmmvb_workspace* ws, int what, double pairs) {
+    return ws->opt_calibrate && ws->cal_ev[0] != nullptr && !((ws->pt.measured >> what) & 1) && ws->cal_pairs[what] == 0.0 &&
+           pairs >= (double)(int64_t(1) << 23) && ws->hmm == nullptr;
+}
+static void cal_mark(gmmvb_workspace* ws, int what, double pairs, hipStream_t st) {
+    note_hip(ws, hipEventRecord(ws->cal_ev[2 * what + 1], st));
+    ws->cal_pairs[what] = pairs;
+}
+static void cal_poll(gmmvb_workspace* ws) {
+    for (int what = 0; what < 3; ++what) {
+        if (ws->cal_pairs[what] <= 0.0 || hipEventQuery(ws->cal_ev[2 * what + 1]) != hipSuccess) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ws->cal_ev[2 * what], ws->cal_ev[2 * what + 1]) == hipSuccess) {
+            double ns = (double)ms * 1e6 / ws->cal_pairs[what];
+            if (what == 2) ns += 0.010 * tri_pairs(ws->T) / 36.0;        // record building / selection around the bound kernel
+            const bool took = ws->pt.take(what, ns);
+            if (ws->opt_debug)
+                std::fprintf(stderr, "[gmmvb] policy table: %s %.4f ns per pair %s (prune below %.3f, dense again above %.3f, list M below %.3f)\n",
+                             what == 0 ? "dense E" : (what == 1 ? "dense M" : "bound pass"), ns, took ? "taken" : "out of range: literal kept",
+                             ws->pt.prune_below(), ws->pt.dense_again_above(), ws->pt.list_m_below());
+            if (!took) ws->pt.measured |= 8 << what;                     // (remembered as discarded: bits 3-5)
+            // a discarded measurement (the process's first launch of a kernel pays its code upload; a small pass has a tail)
+            // gets two more chances on later passes of the same kind
+            ws->cal_pairs[what] = (took || ++ws->cal_tries[what] >= 3) ? -1.0 : 0.0;
+        } else {
+            ws->cal_pairs[what] = -1.0;
+        }
+    }
+}
 
 // The proof round over the lists just filled from the selection blocks' bases `blk_base`: by row superblocks when the item
 // table fits the M-step's slabs (free during an E-step; estep_i8.h), else component after component.
@@ -1261,6 +1272,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (rc) return rc;
     }
     poll_counters(ws);
+    cal_poll(ws);
     enum { kDense = 0, kBound = 1, kSweep = 3 };      // (2 was the pass on per-row records, gone in round 3)
     int mode = kDense;
     const gmmvb_pass_counters& L = ws->sharded ? ws->pol : ws->lag;
@@ -1290,7 +1302,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
         bool sparse_ok = ws->prune == 2;
-        if (!sparse_ok && known && !ws->forget) sparse_ok = L.act <= policy::kPruneBelow * pairs_l;
+        if (!sparse_ok && known && !ws->forget) sparse_ok = L.act <= ws->pt.prune_below() * pairs_l;
         // a bound pass that left most pairs candidates (below) is not tried again until a quarter fewer pairs are active than
         // when it failed: at cluster spread 0.75 (31-40 of 64 active for twenty passes) every other pass was such an attempt
         if (sparse_ok && ws->prune != 2 && known && ws->bound_fail_act > 0.0 && L.act > 0.75 * ws->bound_fail_act * pairs_l)
@@ -1306,29 +1318,29 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // the first iterations at C3, 0.94 by the 13th, 0.97 by the 20th, 0.99 by the 26th): below 0.5 the bounds are
             // made afresh.
             const double tg = ws->typical_gamma;
-            bool sweep = hinted && (ws->dense_valid || (can_project && ws->opt_project == 2)) && !(tg > 0.0 && tg < policy::kGammaNoCarry);
+            bool sweep = hinted && (ws->dense_valid || (can_project && ws->opt_project == 2)) && !(tg > 0.0 && tg < ws->pt.gamma_no_carry);
             if (sweep && known && L.mode != kDense) {
                 // spare candidates (listed but inactive) of the last pruned pass: carry on only while evaluating them
                 // (they grow from pass to pass) costs less than a fresh bound pass, and while few rows overflow
                 // (a pair of the proof round costs about a third of an exact evaluation)
                 // (a bound pass's own proof stage works through the candidates its coarse bounds leave - not a sign of erosion)
-                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + (L.mode == kSweep ? policy::kProofPerExact * L.proof : 0.0)) / pairs_l;
+                const double spare = (std::max(0.0, L.eval - (L.act - L.settled)) + (L.mode == kSweep ? ws->pt.proof_per_exact * L.proof : 0.0)) / pairs_l;
                 ws->spare_last = spare;
                 const int tb = ws->bound_tb > 0 ? ws->bound_tb : 3;
-                const double bound_cost = policy::kI8BlockPair * tri_pairs(tb) + policy::kI8RowOfY * 32 * tb, gpp = policy::kF64TilePair * tri_pairs(ws->T);
-                if (gpp * spare * policy::kSpareGrowth >= bound_cost) sweep = false;
+                const double bound_cost = ws->pt.i8_block_pair * tri_pairs(tb) + ws->pt.i8_row_of_y * 32 * tb, gpp = ws->pt.f64_tile_pair * tri_pairs(ws->T);
+                if (gpp * spare * ws->pt.spare_growth >= bound_cost) sweep = false;
                 // rows whose record had to be rebuilt in full cost K evaluations each and multiply from pass to pass
                 // (x4 - x8 observed): stop carrying well before they dominate
-                if (L.over > policy::kOverflowRows * rows_l || L.eval > policy::kCarriedEvalAbove * pairs_l) sweep = false;
+                if (L.over > ws->pt.overflow_rows * rows_l || L.eval > ws->pt.carried_eval_above * pairs_l) sweep = false;
             }
-            if (sweep && known && L.mode == kDense && L.act > policy::kSweepAfterDenseBelow * pairs_l) sweep = false;
+            if (sweep && known && L.mode == kDense && L.act > ws->pt.sweep_after_dense_below * pairs_l) sweep = false;
             // straight from a dense pass the parameters usually still jump (second or third iteration of a restart): the
             // sweep's per-pair bounds are exact values then, but carried over such an update most of them end up
             // candidates (measured at C4: 118 of 256 per row, 171 ms) - a bound pass is the safe first pruned pass
-            if (sweep && known && L.mode == kDense && tg > 0.0 && tg < policy::kGammaNoCarryAfterDense) sweep = false;
+            if (sweep && known && L.mode == kDense && tg > 0.0 && tg < ws->pt.gamma_no_carry_after_dense) sweep = false;
             if (sweep) mode = kSweep;
             // a bound pass that left most pairs candidates (the parameters jumped): back to the dense kernel
-            if (mode == kBound && ws->prune != 2 && known && L.mode == kBound && L.eval > policy::kDenseAgainAbove * pairs_l) {
+            if (mode == kBound && ws->prune != 2 && known && L.mode == kBound && L.eval > ws->pt.dense_again_above() * pairs_l) {
                 mode = kDense;
                 ++ws->passes[3];
                 ws->bound_fail_act = L.act / pairs_l;
@@ -1347,13 +1359,13 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // to pay (at most 2.5 active components per row) a carried pass therefore gives way to a bound pass, once - list-driven
     // kernels over ungrouped rows are 15-40 % slower for the rest of the fit.
     if (mode == kSweep && ws->sort_rows && ws->xp && !ws->sorted && ws->sorts == 0 && same_rows &&
-        after_estep && known && L.act <= policy::kRegroupForceBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
+        after_estep && known && L.act <= ws->pt.regroup_force_below * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows &&
         ws->xc_ldx == ldx)
         mode = kBound;
     auto regroup_due = [&]() {
         return mode == kBound && ws->sort_rows && ws->xp && ws->hmm == nullptr && same_rows && after_estep && known &&
-               L.act <= policy::kRegroupBelow * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
-               (!ws->sorted || ws->moved_since_sort > policy::kRegroupMoved * rows_l);      // (again once that share of the rows has moved on)
+               L.act <= ws->pt.regroup_below * rows_l && ws->xc_src == x_dev && ws->xc_rows == n_rows && ws->xc_ldx == ldx &&
+               (!ws->sorted || ws->moved_since_sort > ws->pt.regroup_moved * rows_l);      // (again once that share of the rows has moved on)
     };
     bool settle = false;
     if (ws->lock) {
@@ -1412,12 +1424,12 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (l != cur && (++ws->tb_seen[l] > 32 || ws->tb_act[l] > 1.5 * ws->tb_act[cur] ||
                                  ws->tb_act[l] < ws->tb_act[cur] / 1.5))
                     ws->tb_cand[l] = -1.0;
-            const double gpp = policy::kF64TilePair * tri_pairs(ws->T);
+            const double gpp = ws->pt.f64_tile_pair * tri_pairs(ws->T);
             // carried passes follow a bound pass and inherit its spare candidates: a tighter bound pays for part of itself
             const double heirs = gmmvb_wants_drift(ws, n_rows) ? 3.0 : 0.0;
             auto cost = [&](int l) {
                 const double spare_l = ws->tb_cand[l] > ws->tb_act[l] ? ws->tb_cand[l] - ws->tb_act[l] : 0.0;
-                return policy::kI8BlockPair * tri_pairs(l) + policy::kI8RowOfY * 32 * l + gpp * (ws->tb_cand[l] + heirs * spare_l);
+                return ws->pt.i8_block_pair * tri_pairs(l) + ws->pt.i8_row_of_y * 32 * l + gpp * (ws->tb_cand[l] + heirs * spare_l);
             };
             int best = cur;
             for (int l = 1; l <= t32; ++l)
@@ -1427,7 +1439,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (cur > 1 && ws->tb_cand[cur - 1] < 0.0 && spare * ws->K < (heirs > 0.0 ? 0.02 : 0.25))
                     best = cur - 1;
                 else if (cur < t32 && ws->tb_cand[cur + 1] < 0.0 &&
-                         spare * gpp > policy::kI8BlockPair * (tri_pairs(cur + 1) - tri_pairs(cur)) + policy::kI8RowOfY * 32)
+                         spare * gpp > ws->pt.i8_block_pair * (tri_pairs(cur + 1) - tri_pairs(cur)) + ws->pt.i8_row_of_y * 32)
                     best = cur + 1;
             }
             ws->bound_tb = best;
@@ -1473,11 +1485,14 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         grid = (n_rows + rpw - 1) / rpw;
         if (grid > (1 << 20)) grid = 1 << 20;
         span_begin(ws, kSpanEstepMain, st);
+        const bool cal_e = !ws->wide && !i8 && !emission_to_hmm && !valu16 && cal_wanted(ws, 0, pairs);
+        if (cal_e) note_hip(ws, hipEventRecord(ws->cal_ev[0], st));
         e = ws->wide ? launch_estep_rows(ws->T, is64, (int)grid, st, a, &name)
                      : (i8 ? launch_estep_i8(is64, vec, (int)grid, st, a8, &name)
                            : (emission_to_hmm ? hmm_launch_emission16(ws->hmm, is64, vec, st, a, &name)
                               : (valu16 ? launch_estep_rows16(is64, vec, (int)grid, st, a, ws->tri, &name)
                                      : launch_estep(ws->estep_variant, ws->T, is64, vec, (int)grid, st, a, &name))));
+        if (cal_e) cal_mark(ws, 0, pairs, st);
         span_end(ws, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "estep launch", e);
         ++ws->passes[0];
@@ -1526,7 +1541,11 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         if (rc) return rc;
         if (mode == kBound) {
             span_begin(ws, kSpanEstepMain, st);
+            // (only a pass over all output blocks measures what the table's bound_ns stands for)
+            const bool cal_b = ws->bound_tb == (ws->D + 31) / 32 && cal_wanted(ws, 2, pairs);
+            if (cal_b) note_hip(ws, hipEventRecord(ws->cal_ev[4], st));
             e = launch_bound_pass(ws, a8, is64, vec, st, &name, &rpw, &grid);
+            if (cal_b) cal_mark(ws, 2, pairs, st);
             span_end(ws, st);
             if (e != hipSuccess) return fail(GMMVB_EHIP, "estep_bound launch", e);
             ++ws->passes[1];
@@ -1591,7 +1610,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 // digits), so that the sweep compares the other components' bounds with a tight reference instead of one
                 // carried through Gamma and delta (records.h, own_first).  While the summary of the drift says that no
                 // component moves that much the round is skipped altogether.
-                const bool own_round = proof && ws->skip_used && !(ws->typical_gamma >= policy::kOwnRoundBelow);
+                const bool own_round = proof && ws->skip_used && !(ws->typical_gamma >= ws->pt.own_round_below);
                 if (own_round) {
                     span_begin(ws, kSpanSelect, st);
                     hipLaunchKernelGGL(settled_mask_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->lock, ws->masks, ws->lcomp,
@@ -1884,7 +1903,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     const char* name = "";
     hipError_t e;
     bool sparse = ws->sparse && ws->masks && pre && ws->e_state == 1 && ws->act_rows == n_rows;
-    if (sparse) {      // the lists pay off while act kListMns < K kDenseMns (policy::kListMBelow)
+    if (sparse) {      // the lists pay off while act kListMns < K kDenseMns (ws->pt.list_m_below())
         const double pairs = (double)n_rows * ws->K;
         if (ws->rec_live) {
             // a pruned E-step leaves exact values for the listed pairs only (the others are bounded in the f32 array, not in
@@ -1893,7 +1912,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // after a dense E-step the host has been waiting for that kernel anyway: read this pass's own count
             rc = fetch_counters(ws);
             if (rc) return rc;
-            sparse = ws->lag.valid && ws->lag.act <= policy::kListMBelow * pairs;
+            sparse = ws->lag.valid && ws->lag.act <= ws->pt.list_m_below() * pairs;
         }
     }
     if (sparse && ws->K > 256) sparse = false;
@@ -1914,7 +1933,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
         MstepListArgs la0{ws->xc, ws->lnrho, ws->lse, ws->lists, ws->npad, ws->counts, ws->plan_m, cap_chunks0, r_min0,
                           ws->npad, ws->K, ws->slabs};
         // f32 rows with whole 16-feature tiles: read them instead of the twice as wide centred copy
-        static const bool list_xc = std::getenv("GMMVB_MLIST_XC") && std::getenv("GMMVB_MLIST_XC")[0] == '1';      // developer switch: the centred f64 copy
+        static const bool list_xc = dev_env("GMMVB_MLIST_XC") && dev_env("GMMVB_MLIST_XC")[0] == '1';      // developer switch: the centred f64 copy
         if (!list_xc && ws->x_dtype == GMMVB_F32 && ws->D == 16 * ws->T && (ws->T == 2 || ws->T == 4 || ws->T == 8)) {
             if (ws->sorted) {
                 la0.x32 = (const float*)ws->xp;
@@ -2020,7 +2039,10 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             else
                 e = launch_mstep_small((int)grid, st, a, KGW, kSmallCw, &name);
         } else {
+            const bool cal = a.direct_r == 0 && cal_wanted(ws, 1, (double)n_rows * ws->K);
+            if (cal) note_hip(ws, hipEventRecord(ws->cal_ev[2], st));
             e = launch_mstep(ws->T, ws->x_dtype == GMMVB_F64, vec, pre, (int)grid, st, a, &name);
+            if (cal) cal_mark(ws, 1, (double)n_rows * ws->K, st);
         }
         span_end(ws, st);
     }

@@ -405,7 +405,14 @@ __device__ __forceinline__ void i8_blocks_from(unsigned frag_addr, unsigned cons
         i8_rows_bound<JT, 0>(const_addr, acc, sb, sj * lc.c2f, y2);
         // sum |y| over the lane's 16 rows <= sqrt(16 sum y^2); 2e-6 covers the f32 sum (16 x 2^-24) and v_sqrt_f32's ulp
         // (a NaN y2 stays NaN: the bound says nothing, as before)
-        const float ya = 4.000008f * __builtin_amdgcn_sqrtf(y2);
+        // (the raw v_sqrt_f32 may flush a subnormal y2 to zero while sum |y| is still ~4e-19: below FLT_MIN the bound of the
+        // sum is taken from FLT_MIN itself, so that the error term never vanishes.  The factor 4 = sqrt(16) belongs to the
+        // 16 rows a lane holds per output block - kBoundDigits' epilogue; a change of rows per lane changes it)
+        // (one v_max_f32: a compare-and-select in this epilogue cost the proof round 0.3 ns per pair - 6.02 -> 6.36 ms per
+        // benchmark step; a NaN y2 still reaches q through the fma below)
+        float ysafe;
+        asm("v_max_f32 %0, %1, %2" : "=v"(ysafe) : "v"(y2), "v"(1.17549435e-38f));
+        const float ya = 4.000008f * __builtin_amdgcn_sqrtf(ysafe);
         const float eb = __builtin_fmaf(sj, lc.cef, beta);
         q = __builtin_fmaf(-2.0f * ya, eb, __builtin_fmaf(y2, 0.9999980926513671875f, q));
         if constexpr (TWO)

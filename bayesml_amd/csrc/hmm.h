@@ -95,7 +95,7 @@ __device__ const double kExp2Table64[64] = {
     0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
     0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
 __device__ __forceinline__ double exp_nonpos_fast(double x, const double* __restrict__ tab /*[64], LDS*/) {
-    x = fmax(x, -800.0);
+    x = x < -800.0 ? -800.0 : x;            // (not fmax: a NaN ln rho must stay NaN, as with exp())
     const double n = __builtin_rint(x * 0x1.71547652b82fep+6);
     double r = fma(-n, 0x1.62e42fef00000p-7, x);
     r = fma(-n, 0x1.473de6af278edp-40, r);

@@ -509,7 +509,7 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     h->Kp = 16 * h->KT;
     h->npad = ws->npad;
     h->generic = ws->K > 64;                    // (the chunk-parallel kernels hold K x K products in registers)
-    h->wide = ws->K > 64 && ws->K <= 128 && std::getenv("GMMVB_HMM_WIDE_OFF") == nullptr;      // hmm_wide.h (developer switch: off)
+    h->wide = ws->K > 64 && ws->K <= 128 && dev_env("GMMVB_HMM_WIDE_OFF") == nullptr;      // hmm_wide.h (developer switch: off)
     // (65 .. 128 states: chunks of 256 steps, or of 128 while those do not fill the CUs - run_wide)
     h->max_chunks = h->wide ? std::min<int64_t>(std::max<int64_t>(64 * (int64_t)ws->num_cu, ws->npad / kHmmWideChunk), ws->npad / 128) + 2
                             : (h->generic ? 1 : ws->npad / 16 + 2);          // chunk_len >= 16
@@ -519,7 +519,7 @@ int hmmvb_enable(gmmvb_workspace* ws) {
     // room for one xi slab per replay wave (hmm.h H5 XI): sequences past 2^15 steps have chunks of kHmmLongChunk steps, 16 to a
     // wave; shorter ones at most ~850 chunks (chunk_len)
     h->xi_slab_cap = std::max<int64_t>(h->xi_waves + 4, h->generic ? 0 : h->npad / (16 * (kHmmLongChunk / 2)) + 72);
-    h->xi_separate = std::getenv("GMMVB_HMM_XI_SEPARATE") != nullptr;
+    h->xi_separate = dev_env("GMMVB_HMM_XI_SEPARATE") != nullptr;
     const int64_t tk = h->npad * h->Kp;
     // chunk boundary vectors: more than 128 states walk chunks of kHmmGenericChunk steps in the forgetting pass (run_generic)
     const int64_t vec_chunks = (h->generic && !h->wide) ? h->npad / kHmmGenericChunk + 2 : h->max_chunks;
@@ -556,8 +556,8 @@ int hmmvb_enable(gmmvb_workspace* ws) {
             if (e2 == hipSuccess) e2 = hipMemset(p, 0, (size_t)(vec_chunks * h->Kp) * sizeof(double));
     }
     if (e2 == hipSuccess) {      // the forgetting pass's gate (run<KT>, run_wide, run_generic): device flag, pinned copy, event
-        h->spec_on = std::getenv("GMMVB_HMM_FORGETTING_OFF") == nullptr;
-        if (const char* v = std::getenv("GMMVB_HMM_SWEEP_LEN")) h->sweep_len = std::max<int64_t>(1, std::atoll(v));      // developer switch
+        h->spec_on = dev_env("GMMVB_HMM_FORGETTING_OFF") == nullptr;
+        if (const char* v = dev_env("GMMVB_HMM_SWEEP_LEN")) h->sweep_len = std::max<int64_t>(1, std::atoll(v));      // developer switch
         e2 = hipMalloc((void**)&h->gate_dev, 4 * sizeof(int));      // [0] forward-backward (chunk products), [1] Viterbi, [2] forward-backward (whole-chunk stage)
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->gate_host, 2 * sizeof(int));
         if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&h->gate_ev, hipEventDisableTiming);
@@ -803,7 +803,7 @@ int hmmvb_skip_h(gmmvb_workspace* ws, int skip) {
 int hmmvb_emission_target(gmmvb_workspace* ws, int fused, int* in_effect) {
     if (!ws) return fail(GMMVB_EINVAL, "null argument");
     if (!ws->hmm) return fail(GMMVB_ESTATE, "hmmvb_enable has not been called");
-    ws->hmm->fuse_emission = fused != 0 && ws->T == 1 && !ws->wide && std::getenv("GMMVB_HMM_FUSED_EMISSION_OFF") == nullptr;
+    ws->hmm->fuse_emission = fused != 0 && ws->T == 1 && !ws->wide && dev_env("GMMVB_HMM_FUSED_EMISSION_OFF") == nullptr;
     if (in_effect) *in_effect = hmm_fused_emission(ws->hmm) ? 1 : 0;
     return GMMVB_OK;
 }

@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
+#include "policy.h"
+
 struct gmmvb_hmm_state;      // HMM forward-backward buffers (hmm_capi.hip), allocated by hmmvb_enable
 struct gmmvb_workspace;
 
@@ -108,6 +112,13 @@ struct gmmvb_workspace {
     // (gmmvb_policy_export / all-reduce / gmmvb_policy_import): once gmmvb_set_shard has been called the policy reads
     // nothing else that differs between ranks, so every rank takes the same decisions.
     gmmvb_pass_counters lag, pol;
+    // unit costs and thresholds of the pass policy at this workspace's shape (policy.h); calibration from its own first
+    // dense E-step / dense M-step / bound pass: HIP events around those launches, taken over when they have completed
+    gmmvb::PolicyTable pt;
+    bool opt_calibrate = true;         // gmmvb_policy_calibrate(ws, 0) / env GMMVB_POLICY_CALIBRATE=0: the scaled literals only
+    hipEvent_t cal_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // begin / end for dense E, dense M, bound pass
+    double cal_pairs[3] = {0.0, 0.0, 0.0};       // pairs behind a pending measurement (0: none pending, -1: done)
+    int cal_tries[3] = {0, 0, 0};                // measurements discarded so far
     bool sharded = false;              // gmmvb_set_shard: this workspace holds one shard of shard_rows rows over shard_ranks ranks
     int64_t shard_rows = 0;
     int shard_ranks = 1;
@@ -174,7 +185,7 @@ struct gmmvb_workspace {
     bool gather_exit = true;           // env GMMVB_GATHER_EXIT=0: no early way out in the candidate gather
     // further switches, all read ONCE when the workspace is created (no getenv on the per-iteration path)
     bool opt_carry_off = false;        // GMMVB_ESTEP_CARRY_OFF: ignore gmmvb_set_drift
-    bool opt_debug = false;            // GMMVB_DEBUG: one line per E-step on stderr
+    bool opt_debug = false;            // GMMVB_DEBUG=2: one line per E-step on stderr
     // Proof round (estep_i8.h, records.h): the three int8 digit planes of every row, in the internal row order, made with
     // the centred copy (gmmvb_prepare_rows) and again when the rows are regrouped.  Valid for the matrix xq_src while the
     // pivot they are centred on is the one the component images were packed for (xq_gen == img_gen).
@@ -253,6 +264,14 @@ struct gmmvb_workspace {
 };
 
 namespace gmmvb {
+// Environment switches.  Two are part of the interface: GMMVB_ESTEP_PRUNE and GMMVB_MSTEP_SPARSE, read with
+// std::getenv.  Every other GMMVB_* switch is a test / developer seam - it selects between kernels whose results agree, so
+// that a parity test can run each of them - and is only looked at when GMMVB_DEBUG is set ("1"; "2" also prints one line
+// per E-step on stderr).  All of them are read once, when a workspace / HMM state is created.
+inline const char* dev_env(const char* name) {
+    const char* on = std::getenv("GMMVB_DEBUG");
+    return (on && on[0] != '\0' && on[0] != '0') ? std::getenv(name) : nullptr;
+}
 int fail(int code, const char* what, hipError_t e = hipSuccess);     // sets the thread-local message
 void hmm_state_destroy(gmmvb_hmm_state* h);
 const double* hmm_gamma_cm(const gmmvb_hmm_state* h);                 // [K][npad] responsibilities of the last pass (after hmm_ensure_gamma_cm)

@@ -235,7 +235,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._x_dev = None
         self._r_cache = None
         self._small_r = None                # device responsibilities of a small-problem fit (_small.py), fetched lazily
-        self._small_x = None                # that fit's rows (<= 16384 x 8): _ln_rho re-runs the final E-step on them when asked
+        self._small_x = None                # that fit's rows (<= 16384 x 8, a copy): _ln_rho re-runs the final E-step on them when asked
+        self._small_ln_rho = None           # ... once
         self._small_fit_impl = None         # test seam of the small-problem launch (tests/fake_engine.py); None = gmmvb_small_fit
 
         self.vl = 0.0
@@ -539,6 +540,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
         self._r_cache = None
         self._small_r = None
         self._small_x = None
+        self._small_ln_rho = None
 
     @property
     def r_vecs(self):
@@ -560,6 +562,8 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             # fit's own r_vecs in place
             if self._small_x is None:
                 return None
+            if getattr(self, "_small_ln_rho", None) is not None:      # (made once per fit, like _r_cache)
+                return self._small_ln_rho
             keep = (self._small_r, self._small_x, self._r_cache)
             eng, xd = self._open(self._small_x)
             self._give_params(eng, self._post_tensors(xd.device))
@@ -568,6 +572,7 @@ class LearnModel(DeviceModel, base.Posterior, base.PredictiveMixin):
             eng.close()
             self._engine = self._x_dev = None
             self._small_r, self._small_x, self._r_cache = keep
+            self._small_ln_rho = out
             return out
         return None if self._engine is None else _np(self._engine.ln_rho())
 

@@ -124,7 +124,10 @@ def fit(model, x, max_itr, num_init, tolerance, init_type):
     if model._engine is not None and model._data_pass_factory is None:
         model._engine.close()
     model._engine = model._x_dev = None
-    model._small_x = x
+    # (a copy: the lazily made _ln_rho must describe the rows of THIS fit even if the caller changes its array afterwards;
+    # at most 16384 x 8 values)
+    model._small_x = np.array(x, copy=True) if isinstance(x, np.ndarray) else x.clone()
+    model._small_ln_rho = None
     t0 = 2 + len(TERM_KEYS)
     best_vl, winner, never_converged = 0.0, 0, True
     for i in range(num_init):

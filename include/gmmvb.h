@@ -405,6 +405,20 @@ int gmmvb_last_sparsity(gmmvb_workspace* ws, void* stream, double* active_pairs,
  * table replaces the carried bounds, the pairs it did not clear (-1: the pass used no table). */
 int gmmvb_last_work(gmmvb_workspace* ws, double* out /*[8], host*/);
 
+/* The pass policy's unit costs (ABI v8; csrc/policy.h).  gmmvb_estep / gmmvb_mstep choose between kernels whose results agree;
+ * the thresholds of that choice follow from per-pair costs.  A workspace starts from literals measured on MI355X at the
+ * benchmark shape, scaled to its own tile counts, and - unless gmmvb_policy_calibrate(ws, 0) - replaces the three bulk costs
+ * by what its OWN first dense E-step, dense M-step and full bound pass (of at least 2^23 pairs) take on its device: HIP
+ * events around those launches, taken over without a synchronisation once they have completed; a measurement outside
+ * [1/2, 2] x the scaled literal is discarded.  Results never depend on the table.
+ * gmmvb_policy_table: out[0..5] = ns per (row, component) pair in force: dense E, dense M, bound pass, exact pair, proof pair,
+ * list M-step; out[6..8] the scaled literals of the first three; out[9..11] the thresholds that follow (pruned E-step while
+ * active / K is below [9], dense again above [10] evaluated / K, list M-step below [11]); out[12] bit mask of the costs
+ * measured (1 dense E, 2 dense M, 4 bound pass), out[13] of measurements discarded, out[14] calibration on, out[15] 0. */
+#define GMMVB_POLICY_TABLE_LEN 16
+int gmmvb_policy_calibrate(gmmvb_workspace* ws, int on);
+int gmmvb_policy_table(gmmvb_workspace* ws, double* out /*[GMMVB_POLICY_TABLE_LEN], host*/);
+
 /* ---- device-side data generation (ABI v8) -------------------------------------------------------------
  * GenModel.gen_sample of the mixture (bayesml/gaussianmixture/_gaussianmixture.py:241-264: a `choice` and a
  * `multivariate_normal` per row in a Python loop) and of the HMM (bayesml/hiddenmarkovnormal/_hiddenmarkovnormal.py:344-358,

@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The library honours its test / developer switches (every GMMVB_* but GMMVB_ESTEP_PRUNE and GMMVB_MSTEP_SPARSE) only under
+# GMMVB_DEBUG (csrc/workspace.h: dev_env): the suite's variants are such switches.
+os.environ.setdefault("GMMVB_DEBUG", "1")
 
 
 def pytest_configure(config):

@@ -560,3 +560,51 @@ def test_fused_k_side_against_the_torch_specification(K, D, monkeypatch):
             assert float((x - y).abs().max()) <= 1e-11 * max(1.0, float(y.abs().max())), (it, name)
         for ks in steppers:
             ks.advance()
+
+
+@pytest.mark.parametrize("T", [4096, 20000, 32768, 70001])
+def test_forgetting_pass_equals_chunk_products_with_sparse_transitions(T, monkeypatch):
+    """The forgetting pass's start vectors are only proven within chunks x tolerance in the Hilbert metric (relative per
+    entry): with near-absorbing rows of a~ (exp(psi) of a sparse h0_zeta prior), two DUPLICATE states
+    (same emission: the recursion cannot tell them apart, only a~ does) and lengths on both sides of the 2^15-step switch
+    between its chunk plans, gamma, the xi sum and sum ln c must still equal the chunk-product path's
+    (GMMVB_HMM_FORGETTING_OFF) far inside the 1e-5 contract: 1e-10 relative."""
+    from bayesml_amd import _kside
+    from bayesml_amd._engine import DataPass
+    dev = torch.device("cuda", 0)
+    K, D = 6, 3
+    rng = np.random.default_rng(11)
+    mu = 2.5 * rng.standard_normal((K, D))
+    mu[5] = mu[2]                                         # duplicate states
+    a_np = rng.dirichlet(np.full(K, 0.05), K) + 1e-30
+    a_np[np.arange(K), np.arange(K)] += 3.0               # sticky, rows far from normalised: a~ need not be
+    z = np.zeros(T, dtype=np.int64)
+    for i in range(1, T):
+        z[i] = z[i - 1] if rng.random() < 0.97 else rng.integers(0, K)
+    x = (mu[z] + rng.standard_normal((T, D))).astype(np.float32)
+    t = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+    f = _kside.features(_kside.PostT(torch.ones(K, dtype=torch.float64, device=dev), t(mu), t(np.full(K, 2.0)),
+                                     t(np.full(K, D + 3.0)), t(np.tile(np.eye(D) * (D + 3.0), (K, 1, 1)))))
+    c = (f.e_ln_lambda_det - D * _kside.LN_2PI - D / f.kappa) / 2.0
+    a, pi = t(a_np), t(np.full(K, 1.0 / K))
+    xd = torch.from_numpy(x).to(dev)
+    res = []
+    for off in (True, False):
+        if off:
+            monkeypatch.setenv("GMMVB_HMM_FORGETTING_OFF", "1")
+        else:
+            monkeypatch.delenv("GMMVB_HMM_FORGETTING_OFF", raising=False)
+        eng = DataPass(K, D, xd.dtype, T, dev)
+        eng.set_pivot(xd[:4096].to(torch.float64).mean(dim=0))
+        eng.prepare_rows(xd)
+        eng.enable_hmm()
+        eng.set_params(c, f.m, f.u)
+        eng.estep(xd)
+        ms, g0, gl, lnc = eng.forward_backward(pi, a)
+        res.append((eng.last_boundary_pass(), ms.clone(), eng.responsibilities().clone(), float(lnc)))
+        eng.close()
+    (how0, ms0, gam0, lnc0), (_how1, ms1, gam1, lnc1) = res
+    assert how0 == -1
+    assert float((ms0 - ms1).abs().max()) <= 1e-10 * float(ms0.abs().max())
+    assert float((gam0 - gam1).abs().max()) <= 1e-10
+    assert abs(lnc0 - lnc1) <= 1e-10 * abs(lnc0)

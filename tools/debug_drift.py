@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostics of the carried E-step: per VB iteration the drift hint's spread over the components and what the
-records made of it (needs a GPU; GMMVB_DEBUG=1 adds the library's own mode line on stderr)."""
+records made of it (needs a GPU; GMMVB_DEBUG=2 adds the library's own mode line on stderr)."""
 import os
 import sys
 
