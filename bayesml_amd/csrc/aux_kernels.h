@@ -1,4 +1,5 @@
 // K-sized packing, row log-normaliser, slab reduction and read-out kernels (all f64, bandwidth-trivial).
+// (The non-template kernels here have internal linkage: several translation units of the C ABI - capi*.hip - include this file.)
 #pragma once
 #include "common.h"
 #include "rec_common.h"
@@ -9,7 +10,7 @@ namespace gmmvb {
 //   [P][half][lane][2] tiles of u (zero padded to 16T) | [T][g][r] bias = -(u m) | zero pad to 1 KB
 // (also copies c -> cvec and, if asked, the pivot the int8 images are packed about: two device-to-device copies less per
 // parameter hand-over, each of which was a dispatch on the iteration's critical path)
-__global__ void pack_params_kernel(const double* __restrict__ u, const double* __restrict__ m, int K, int D,
+static __global__ void pack_params_kernel(const double* __restrict__ u, const double* __restrict__ m, int K, int D,
                                    int T, int img_len, double* __restrict__ img, const double* __restrict__ c_src = nullptr,
                                    double* __restrict__ c_dst = nullptr, const double* __restrict__ pivot_src = nullptr,
                                    double* __restrict__ pivot_dst = nullptr) {
@@ -60,7 +61,7 @@ constexpr int kLseRows = 1024;      // rows per block (256 threads x 4)
 // E-step prunes only when that fraction is small).
 // `stride` > 1: only every stride-th block of rows is visited (a sample of the rows: its maxima are lower bounds of the
 // true ones, which is all a skip threshold needs; see lse_mask_kernel).
-__global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
+static __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
                                                       int K, double* __restrict__ lse, double* __restrict__ dpart,
                                                       double* __restrict__ apart, int stride) {
     __shared__ double wmax[4];
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const double* __restrict__
 
 // thr[k] = max over blocks of dpart[.][k] - 80 ln 2 (mstep.h, sparse responsibilities); act_total = sum of apart.
 // One 256-thread workgroup per component (workgroup K sums apart).
-__global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpart, const double* __restrict__ apart,
+static __global__ __launch_bounds__(256) void thr_kernel(const double* __restrict__ dpart, const double* __restrict__ apart,
                                                   int blocks, int K, double* __restrict__ thr,
                                                   double* __restrict__ act_total) {
     __shared__ double part[256];
@@ -221,7 +222,7 @@ constexpr int kScanParts = 1024;
 constexpr int kScanChunk = 32;            // parts per thread of the middle kernel (kScanParts / kScanChunk chunks per component)
 
 // sums of the parts: part p = blocks [p per, (p + 1) per), all components
-__global__ __launch_bounds__(256) void scan_parts_kernel(const int* __restrict__ blk, int blocks, int K, int* __restrict__ parts) {
+static __global__ __launch_bounds__(256) void scan_parts_kernel(const int* __restrict__ blk, int blocks, int K, int* __restrict__ parts) {
     __shared__ int sh[256];
     const int p = blockIdx.x;
     const int R = K <= 256 ? 256 / K : 1;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void scan_parts_kernel(const int* __restrict__
 
 // parts[p][k] <- sum over p' < p (in place), counts[k] = the total.  One workgroup per eight components: thread
 // (component t % 8, chunk t / 8) takes kScanChunk consecutive parts.
-__global__ __launch_bounds__(256) void scan_mid_kernel(int* __restrict__ parts, int K, int* __restrict__ counts) {
+static __global__ __launch_bounds__(256) void scan_mid_kernel(int* __restrict__ parts, int K, int* __restrict__ counts) {
     static_assert(kScanParts == 32 * kScanChunk, "256 threads = 8 components x 32 chunks");
     __shared__ int sh[32][8];
     const int t = threadIdx.x, kk = t & 7, c = t >> 3;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void scan_mid_kernel(int* __restrict__ parts, 
 }
 
 // every part scans its blocks from its base; rows b0 + i R + r, r = 0 .. R - 1, go through the workgroup together
-__global__ __launch_bounds__(256) void scan_apply_kernel(int* __restrict__ blk, int blocks, int K, const int* __restrict__ parts) {
+static __global__ __launch_bounds__(256) void scan_apply_kernel(int* __restrict__ blk, int blocks, int K, const int* __restrict__ parts) {
     __shared__ int sh[256];
     const int p = blockIdx.x;
     const int R = K <= 256 ? 256 / K : 1;
@@ -321,7 +322,7 @@ inline void launch_scan_counts(hipStream_t st, int* blk, int blocks, int K, int*
 // lock (delta lists of the cache of single-component rows, records.h rec_finish_kernel): a row that leaves its
 // component's cache (state 2, or 4 in the list of a component that is not its best any more) is listed with the sign
 // bit set; one that enters (state 3, or 4 in the list of its new component lcomp) without.  State afterwards: 0 / 1.
-__global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned long long* __restrict__ masks, int64_t npad,
+static __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned long long* __restrict__ masks, int64_t npad,
                                                               int64_t n_rows, int K, const int* __restrict__ blk_base,
                                                               int* __restrict__ lists, int64_t cap,
                                                               unsigned char* __restrict__ lock = nullptr,
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsigned lon
 // its block counts, and the number of pairs with ln r >= -80 ln 2 per block (apart).  thr comes from a sample of
 // the rows (row_lse_kernel with a stride): a maximum over fewer rows is smaller, the threshold lower, the lists at
 // worst a little longer - never a relevant sample dropped.  One thread per row, 256 rows per block.
-__global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
+static __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
                                                             int K, const double* __restrict__ thr, double* __restrict__ lse,
                                                             unsigned long long* __restrict__ masks,
                                                             int* __restrict__ blk_cnt, double* __restrict__ apart,
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(kSelRows) void lse_mask_kernel(const double* __rest
 
 // r row-major [n][K] -> workspace [K][npad] (direct mode), lse = 0
 // (iperm: the caller's row -> internal row, null = identity; see "rows grouped by their dominant component")
-__global__ void load_r_kernel(const double* __restrict__ r, int64_t n_rows, int K, double* __restrict__ buf,
+static __global__ void load_r_kernel(const double* __restrict__ r, int64_t n_rows, int K, double* __restrict__ buf,
                               int64_t npad, double* __restrict__ lse, const int* __restrict__ iperm) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_rows) return;
@@ -465,7 +466,7 @@ __global__ void load_r_kernel(const double* __restrict__ r, int64_t n_rows, int 
 }
 
 // mode 0: ln rho; mode 1: r = exp(ln rho - lse) (or the stored r in direct mode)
-__global__ void readout_kernel(const double* __restrict__ buf, const double* __restrict__ lse, int64_t npad,
+static __global__ void readout_kernel(const double* __restrict__ buf, const double* __restrict__ lse, int64_t npad,
                                int64_t row0, int64_t n_rows, int K, int mode, int direct_r,
                                double* __restrict__ out, const int* __restrict__ iperm) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,14 +479,14 @@ __global__ void readout_kernel(const double* __restrict__ buf, const double* __r
 }
 
 // z[i] = src[iperm[row0 + i]] (the best components rec_finish_kernel left, in the caller's row order)
-__global__ void gather_int_kernel(const int* __restrict__ src, int64_t row0, int64_t n_rows, const int* __restrict__ iperm,
+static __global__ void gather_int_kernel(const int* __restrict__ src, int64_t row0, int64_t n_rows, const int* __restrict__ iperm,
                                   int32_t* __restrict__ z) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n < n_rows) z[n] = src[iperm ? iperm[row0 + n] : row0 + n];
 }
 
 // first maximiser over k, like numpy.argmax on the reference's r_vecs (_gaussianmixture.py:1191)
-__global__ void argmax_kernel(const double* __restrict__ buf, int64_t npad, int64_t row0, int64_t n_rows, int K,
+static __global__ void argmax_kernel(const double* __restrict__ buf, int64_t npad, int64_t row0, int64_t n_rows, int K,
                               int32_t* __restrict__ z, const int* __restrict__ iperm) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_rows) return;
@@ -504,7 +505,7 @@ __global__ void argmax_kernel(const double* __restrict__ buf, int64_t npad, int6
 
 // Sum slabs over row splits (fixed order => run-to-run identical) and scatter to
 // stats = [ ns[K] | h[K] | a[K][D] | B[K][D][D] ].
-__global__ void reduce_stats_kernel(const double* __restrict__ slabs, int S, int K, int D, int T,
+static __global__ void reduce_stats_kernel(const double* __restrict__ slabs, int S, int K, int D, int T,
                                     double* __restrict__ stats) {
     const int k = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,7 +550,7 @@ __global__ void reduce_stats_kernel(const double* __restrict__ slabs, int S, int
 // The same for the list M-step's chunk slabs (mstep.h): component k owns slabs plan[k] .. plan[k + 1] - 1.
 // accumulate: stats += the sum (the settled-row cache taking in a pass's delta lists); add: stats = the sum + add (the
 // statistics of a pass = its lists + the cache), add in the layout of stats.
-__global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int* __restrict__ plan, int K, int D, int T,
+static __global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int* __restrict__ plan, int K, int D, int T,
                                      double* __restrict__ stats, int accumulate = 0, const double* __restrict__ add = nullptr) {
     const int k = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,7 +609,7 @@ __global__ void reduce_chunks_kernel(const double* __restrict__ slabs, const int
 //
 // perm_new[start_k + j] = perm_old[lists[k][j]] (perm_old null: identity); lists[k] = ascending internal rows whose
 // best component is k (select_mask_kernel<3> + scan_counts + fill_lists).  gridDim = (blocks over j, K).
-__global__ __launch_bounds__(256) void perm_compose_kernel(const int* __restrict__ lists, int64_t cap,
+static __global__ __launch_bounds__(256) void perm_compose_kernel(const int* __restrict__ lists, int64_t cap,
                                                            const int* __restrict__ counts, const int* __restrict__ perm_old,
                                                            int* __restrict__ perm_new) {
     const int k = blockIdx.y;
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void perm_compose_kernel(const int* __restrict
 // component's group the settled rows - which the selection kernels skip by whole waves and tiles - stay contiguous, and so
 // do the rows the list-driven kernels still have to read.  (A NaN row lands in bucket 0.)
 constexpr int kMarginBuckets = 8;
-__global__ __launch_bounds__(256) void margin_bucket_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
+static __global__ __launch_bounds__(256) void margin_bucket_kernel(const double* __restrict__ lnrho, int64_t npad, int64_t n_rows,
                                                             const double* __restrict__ lse, const int* __restrict__ khat,
                                                             const unsigned char* __restrict__ lock /*null: no settled rows*/,
                                                             int* __restrict__ bucket) {
@@ -647,14 +648,14 @@ __global__ __launch_bounds__(256) void margin_bucket_kernel(const double* __rest
     bucket[n] = b;
 }
 
-__global__ void perm_invert_kernel(const int* __restrict__ perm, int64_t n_rows, int* __restrict__ iperm) {
+static __global__ void perm_invert_kernel(const int* __restrict__ perm, int64_t n_rows, int* __restrict__ iperm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rows) iperm[perm[i]] = (int)i;
 }
 
 // The per-row state of the cache of single-component rows follows the rows into their new order: new internal row i holds
 // the caller's row perm_new[i], which sat at internal row iperm_old[perm_new[i]] before (iperm_old null: the caller's order).
-__global__ void regroup_state_kernel(const int* __restrict__ perm_new, const int* __restrict__ iperm_old, int64_t n_rows,
+static __global__ void regroup_state_kernel(const int* __restrict__ perm_new, const int* __restrict__ iperm_old, int64_t n_rows,
                                      const unsigned char* __restrict__ lock, const unsigned char* __restrict__ lcomp,
                                      const float* __restrict__ dlock, unsigned char* __restrict__ lock_new,
                                      unsigned char* __restrict__ lcomp_new, float* __restrict__ dlock_new) {
@@ -680,7 +681,7 @@ __global__ void permute_rows_kernel(const XT* __restrict__ x, int64_t ldx, int64
 
 // the same in 16-byte pieces (rows and row strides are multiples of 16 bytes, both bases 16-byte aligned): a quarter of the
 // index arithmetic per byte moved
-__global__ void permute_rows16_kernel(const uint4* __restrict__ x, int64_t ld16, int64_t n_rows, int p16,
+static __global__ void permute_rows16_kernel(const uint4* __restrict__ x, int64_t ld16, int64_t n_rows, int p16,
                                       const int* __restrict__ perm, uint4* __restrict__ xp) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rows * p16) return;

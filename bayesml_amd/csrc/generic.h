@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void mstep_generic_second_kernel(const XT* __r
 }
 
 // sums over the splits in split order and scatters to stats = [ns | h | a | B] (B mirrored exactly)
-__global__ void reduce_generic_kernel(const double* __restrict__ first, const double* __restrict__ second, int S, int K, int D,
+static __global__ void reduce_generic_kernel(const double* __restrict__ first, const double* __restrict__ second, int S, int K, int D,
                                       int TD, double* __restrict__ stats) {
     const int k = blockIdx.y;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void rec_build_kernel(const double* __restrict
 // the components not listed; more than 24 such components, or no exact slot: all K pairs are evaluated, "overflow row").
 // Outputs: masks (candidate components per row), per-block counts for scan_counts / fill_lists, epart[block] = listed
 // pairs, opart[block] = overflow rows.
-__global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int64_t n_rows, int K,
+static __global__ __launch_bounds__(kSelRows) void rec_select_kernel(RecArrays rec, int64_t n_rows, int K,
                                                               const double* __restrict__ cvec,
                                                               unsigned long long* __restrict__ masks, int64_t npad,
                                                               int* __restrict__ blk_cnt, double* __restrict__ epart,
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kSelRows, (LAZY && WC >= 3 ? 5 : 1)) void rec_sweep
 // one of them are marked selected (rec_finish_kernel finds the evaluated pairs through the slots and the mask), and the
 // row is evaluated in full (threshold -inf).  The kernel visits every row: it also recounts the pass's candidate masks
 // per block (blk_cnt, epart) now that rows have joined, and counts the proof round's pairs (ppart).
-__global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays rec, const unsigned long long* __restrict__ pmask,
+static __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays rec, const unsigned long long* __restrict__ pmask,
                                                                     unsigned long long* __restrict__ masks, int64_t npad,
                                                                     int64_t n_rows, int K, const double* __restrict__ cvec,
                                                                     const float* __restrict__ ub32, const double* __restrict__ lb,
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecArrays re
 // output blocks only; estep_i8_proof has given each of them a bound from ALL blocks (ub32).  Those that now clear the row's
 // threshold (its best component's exact value - 80 ln 2) are done with: taken off the pass's lists; a slot keeps the fresh
 // bound, a component without a slot rejoins the rest bound B.  Overflow rows are left alone.  Recounts the lists per block.
-__global__ __launch_bounds__(kSelRows) void rec_prune_kernel(RecArrays rec, unsigned long long* __restrict__ masks, int64_t npad,
+static __global__ __launch_bounds__(kSelRows) void rec_prune_kernel(RecArrays rec, unsigned long long* __restrict__ masks, int64_t npad,
                                                              int64_t n_rows, int K, const double* __restrict__ cvec,
                                                              const float* __restrict__ ub32, const float* __restrict__ rthr,
                                                              int* __restrict__ blk_cnt, double* __restrict__ epart,
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(kSelRows) void rec_prune_kernel(RecArrays rec, unsi
 // first[k] = index of component k's first gather chunk (chunk = per_wg list entries), first[K] = number of chunks
 // (one workgroup: the counts come in with parallel loads - a single thread's K dependent loads were 24 us at K = 256 - and
 // the prefix over them is taken from LDS)
-__global__ void gather_plan_kernel(const int* __restrict__ counts, int K, int per_wg, int* __restrict__ first) {
+static __global__ void gather_plan_kernel(const int* __restrict__ counts, int K, int per_wg, int* __restrict__ first) {
     __shared__ int sc[1025];
     if (blockIdx.x != 0) return;
     if (K > 1024) {
@@ -1086,7 +1086,7 @@ __global__ void gather_plan_kernel(const int* __restrict__ counts, int K, int pe
 // After the exact evaluation of the listed pairs: refresh the records from the exact values (distances, exact
 // flags; overflow rows are rebuilt from all K values), and produce what the rest of the pass needs per row:
 // lse_n, the best component, the M-step's active mask (r_nk >= 2^-80) with its block counts, apart[block] = active pairs.
-__global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, const double* __restrict__ lnrho, int64_t npad,
+static __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, const double* __restrict__ lnrho, int64_t npad,
                                                               int64_t n_rows, int K, const double* __restrict__ cvec,
                                                               double* __restrict__ lse, int* __restrict__ khat,
                                                               unsigned long long* __restrict__ masks,
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(kSelRows) void rec_finish_kernel(RecArrays rec, con
 // in the E-step's lists), ctr[6] = sum qpart (pairs the M-step accumulates), ctr[7] = sum ppart (pairs of the proof round);
 // a null part leaves its counter as it is.
 // One workgroup per counter.
-__global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
+static __global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restrict__ apart, const double* __restrict__ epart,
                                                          const double* __restrict__ opart, const double* __restrict__ mpart,
                                                          const double* __restrict__ spart, const double* __restrict__ gpart,
                                                          const double* __restrict__ qpart, const double* __restrict__ ppart,
@@ -1460,7 +1460,7 @@ __device__ __forceinline__ bool row_settled(const unsigned char* __restrict__ lo
     return any == 0ull;                   // in the cache and in none of the E-step's lists
 }
 
-__global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned char* __restrict__ lock,
+static __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned char* __restrict__ lock,
                                                                 const unsigned long long* __restrict__ emask,
                                                                 const unsigned char* __restrict__ lcomp, int64_t npad, int64_t n_rows,
                                                                 int K, unsigned long long* __restrict__ masks,
@@ -1504,7 +1504,7 @@ __global__ __launch_bounds__(kSelRows) void settled_mask_kernel(const unsigned c
     }
 }
 
-__global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const unsigned long long* __restrict__ emask,
+static __global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const unsigned long long* __restrict__ emask,
                                    const unsigned char* __restrict__ lcomp, const double* __restrict__ lnrho, int64_t npad,
                                    int64_t n_rows, int K, double* __restrict__ lse) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1514,7 +1514,7 @@ __global__ void settled_lse_kernel(const unsigned char* __restrict__ lock, const
 // Read-outs of a pass that lived on records.  The active mask rec_finish_kernel left (r_nk >= 2^-80) marks the pairs
 // whose exact value is in the dense array.  mode 0: ln rho - exact for active pairs and for exact slots, otherwise the
 // record's upper bound (at least 80 ln 2 below the row's log-normaliser); mode 1: responsibilities, exactly 0 for inactive pairs.
-__global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __restrict__ masks,
+static __global__ void rec_readout_kernel(RecArrays rec, const unsigned long long* __restrict__ masks,
                                    const double* __restrict__ lnrho, const double* __restrict__ lse,
                                    const double* __restrict__ cvec, int64_t npad, int64_t row0, int64_t n_rows, int K,
                                    int mode, double* __restrict__ out, const int* __restrict__ iperm,
