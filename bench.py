@@ -190,6 +190,13 @@ def launch_ranks(n):
                        MASTER_PORT=str(port))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             env.setdefault("NCCL_DEBUG", "WARN")
+            env.setdefault("GLOO_SOCKET_IFNAME", "lo")          # (one node: the container's hostname may not resolve)
+            # host BLAS threads per rank (the K-sized NumPy linear algebra of the model's constructor): n ranks with one pool of
+            # os.cpu_count() spinning threads each stall one another - measured: eight ranks on a 256-core host sat in
+            # numpy.linalg.inv for minutes (profiles/r6_experiments.md); torch.distributed.run sets OMP_NUM_THREADS=1 itself
+            per_rank = str(max(1, (os.cpu_count() or n) // n))
+            env.setdefault("OMP_NUM_THREADS", per_rank)
+            env.setdefault("OPENBLAS_NUM_THREADS", per_rank)
             # fresh child processes, each in its own session (never a re-exec of a process that has touched a GPU)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           start_new_session=True))
@@ -420,11 +427,14 @@ def main():
     n_ranks, backend = 1, None
     use_dist = world > 1 or args.force_dist
     if use_dist:
+        # a rank that the parent stops (SIGTERM: another rank died, or the job's own timeout) says where it was
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGTERM, all_threads=True, chain=True, file=sys.stderr)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("NCCL_DEBUG", "WARN")          # (RCCL's own account of a failed init goes to stderr)
         # per-rank watchdog: if joining the group or the first collective stalls, dump every thread's stack and exit 1
-        import faulthandler
         print(f"bench.py: rank {rank}/{world} joining the process group (watchdog {args.init_timeout:.0f} s)", file=sys.stderr, flush=True)
         faulthandler.dump_traceback_later(args.init_timeout, exit=True, file=sys.stderr)
         if share_gpu:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: tests, bench legs, rocprofv3 kernel trace and PMC passes.  usage: tools/gpu_round.sh <tag> <stage>...
 # (bench.py prints its compact line on stdout; every stage keeps the full record next to it as *_detail.json)
-# stages: smoke tests newtests c4trace c4strong1 bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist wide share8
+# stages: smoke tests newtests c2trace c4trace c4strong1 bench bench20 dense c2 c4 c4w5 c4strong trace steps tracedel pmc hmm hmmtrace hmmpmc hmmbig full small dist proofbench spread1 hist wide share8
 # (pmc / hmmpmc first: the bench stages quote the traffic files they write)
 # Outputs under gpurun_out/<tag>_*; copy the summaries worth keeping into profiles/.
 set -u
@@ -26,7 +26,7 @@ d = json.load(open(sys.argv[1])); g = d["roofline"]["kernel_groups"]
 print("D =", sys.argv[2], "ms/step", round(d["ms_per_step"], 2), {k: (round(v["ms"], 2), round(v.get("executed_f64_tflops", 0), 1)) for k, v in g.items() if v["ms"] > 0.05}, d["launch"][:60])
 PY
           done ;;
-    share8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --rows 200000 --strong-total-rows 1600000 --steps 12 --warmup 5 --no-cpu --legs c4strong --detail $OUT/${TAG}_bench_detail_eight_ranks_one_gpu.json 2> $OUT/${TAG}_share8.err | grep -a "^{" > $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_share8.err; head -c 700 $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; echo ;;
+    share8) BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 8 --rows 200000 --strong-total-rows 1600000 --steps 12 --warmup 5 --no-cpu --legs c4strong --detail $OUT/${TAG}_bench_detail_eight_ranks_one_gpu.json 2> $OUT/${TAG}_share8.err | grep -a "^{" > $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_share8.err; head -c 700 $OUT/${TAG}_bench_line_eight_ranks_one_gpu.json; echo ;;
     legsall) timeout 1500 python bench.py --steps 20 --warmup 5 --legs all --detail $OUT/${TAG}_bench_detail_all_legs.json > $OUT/${TAG}_bench_line_all_legs.json 2> $OUT/${TAG}_legsall.err; tail -c 300 $OUT/${TAG}_legsall.err; cat $OUT/${TAG}_bench_line_all_legs.json; echo ;;
     strong8) BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --config c4 --scaling strong --total-rows 1600000 --steps 12 --warmup 5 --no-cpu --no-legs --detail $OUT/${TAG}_bench_detail_c4_strong_eight_ranks_one_gpu.json 2> $OUT/${TAG}_strong8.err | grep -a "^{" > $OUT/${TAG}_bench_line_c4_strong_eight_ranks_one_gpu.json; tail -c 300 $OUT/${TAG}_strong8.err; cat $OUT/${TAG}_bench_line_c4_strong_eight_ranks_one_gpu.json; echo ;;
     hmmsmall) for t in 10000 100000; do for g in 1 0; do BAYESML_AMD_KSIDE_GRAPH=$g timeout 300 python tools/bench_hmm.py --rows $t --no-cpu --steps 20 --warmup 5 2>/dev/null | grep -a "^{" > $OUT/${TAG}_hmm_t${t}_graph$g.json; python -c "
@@ -39,6 +39,10 @@ import json,sys; d=json.load(open('$OUT/${TAG}_hmm_t${t}_graph$g.json')); print(
            python tools/summarize_rocprof.py $OUT/${TAG}_c4trace > $OUT/${TAG}_c4_kernel_summary.md 2>> $OUT/${TAG}_c4trace.err; head -40 $OUT/${TAG}_c4_kernel_summary.md
            f=$(find $OUT/${TAG}_c4trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_steps.py $f 7 12 24 > $OUT/${TAG}_c4_steps.txt 2>&1
            find $OUT/${TAG}_c4trace -name "*kernel_trace.csv" -size +20M -delete ;;
+    c2trace) rm -rf $OUT/${TAG}_c2trace; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/${TAG}_c2trace -- python3 $GRAFT_REPO_ROOT/bench.py --config c2 --no-cpu --no-legs --steps 20 --warmup 5 --detail $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_c2_profiled_detail.json > $GRAFT_REPO_ROOT/$OUT/${TAG}_bench_line_c2_profiled.json 2> $GRAFT_REPO_ROOT/$OUT/${TAG}_c2trace.err)
+           python tools/summarize_rocprof.py $OUT/${TAG}_c2trace > $OUT/${TAG}_c2_kernel_summary.md 2>> $OUT/${TAG}_c2trace.err; head -24 $OUT/${TAG}_c2_kernel_summary.md
+           f=$(find $OUT/${TAG}_c2trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_steps.py $f 7 12 24 > $OUT/${TAG}_c2_steps.txt 2>&1; head -30 $OUT/${TAG}_c2_steps.txt
+           find $OUT/${TAG}_c2trace -name "*kernel_trace.csv" -size +20M -delete ;;
     c4strong1) timeout 1200 python bench.py --config c4 --scaling strong --gpus 1 --no-cpu --no-legs --steps 20 --warmup 5 --detail $OUT/${TAG}_bench_line_c4_strong1_detail.json > $OUT/${TAG}_bench_line_c4_strong1.json 2> $OUT/${TAG}_c4strong1.err; tail -c 300 $OUT/${TAG}_c4strong1.err; head -c 500 $OUT/${TAG}_bench_line_c4_strong1.json; echo ;;
     tracedel) find $OUT/${TAG}_trace -name "*kernel_trace.csv" -size +20M -delete ;;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/${TAG}_pmc_$c
