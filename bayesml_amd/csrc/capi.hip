@@ -300,7 +300,7 @@ int gmmvb_workspace_destroy(gmmvb_workspace* ws) {
     if (ws->xp) (void)hipFree(ws->xp);
     void* rbufs[] = {ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel, ws->rec_flags, ws->ub32,
                      ws->lock, ws->lcomp, ws->dlock, ws->rthr, ws->exit_ctr, ws->dmask, ws->dblk, ws->mmask, ws->mblk, ws->cache, ws->spart, ws->gpart, ws->qpart,
-                     ws->rmask, ws->rblk, ws->xq, ws->xqe, ws->ppart, ws->tmeta, ws->gimg, ws->gconst, ws->hk, ws->tile_ref, ws->xqn};
+                     ws->rmask, ws->rblk, ws->xq, ws->xqe, ws->ppart, ws->tmeta, ws->gimg, ws->gconst, ws->tile_ref};
     for (void* p : rbufs)
         if (p) (void)hipFree(p);
     if (ws->ctr_host) (void)hipHostFree(ws->ctr_host);
@@ -573,7 +573,7 @@ int gmmvb_set_params(gmmvb_workspace* ws, const double* c_dev, const double* m_d
     ws->proj_table = false;
     if (ws->gimg && ws->opt_project != 0 && ws->sorted && ws->tile_ref_valid && ws->have_drift && ws->xq_gen == ws->pivot_gen &&
         !ws->opt_carry_off) {
-        e = launch_proj_table(u_dev, m_dev, c_dev, ws->pivot, ws->K, ws->D, ws->hk, ws->gimg, ws->gconst, st);
+        e = launch_proj_table(u_dev, m_dev, c_dev, ws->pivot, ws->K, ws->D, ws->gimg, ws->gconst, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "proj_table_kernel", e);
         ws->proj_table = true;
     }
@@ -637,10 +637,8 @@ int ensure_lists(gmmvb_workspace* ws) {
             if (e == hipSuccess) e = hipMalloc((void**)&ws->gimg, (size_t)ib);
             if (e == hipSuccess) e = hipMemset(ws->gimg, 0, (size_t)ib);
             if (e == hipSuccess) e = hipMalloc(&ws->gconst, (size_t)cl * 16);
-            if (e == hipSuccess) e = hipMalloc((void**)&ws->hk, (size_t)ws->K * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void**)&ws->tile_ref, (size_t)sel_blocks * sizeof(int));
-            if (e == hipSuccess) e = hipMalloc((void**)&ws->xqn, (size_t)np * sizeof(float));
-            if (e == hipSuccess) ws->bytes += ib + cl * 16 + ws->K * 4 + sel_blocks * 4 + np * 4;
+            if (e == hipSuccess) ws->bytes += ib + cl * 16 + sel_blocks * 4;
         }
     }
     if (e == hipSuccess) e = hipMalloc((void**)&ws->rec_k, (size_t)kRecSlots * np * sizeof(unsigned short));
@@ -908,7 +906,7 @@ int gmmvb_prepare_rows(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int6
     ws->xc_ldx = ldx;
     ws->xc_stale = false;
     if (ws->xq) {              // the int8 digit planes of the proof round, about the same pivot
-        e = launch_x_digits(x_dev, ws->x_dtype == GMMVB_F64, ldx, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st, ws->xqn);
+        e = launch_x_digits(x_dev, ws->x_dtype == GMMVB_F64, ldx, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "x_digits launch", e);
         ws->xq_src = x_dev;
         ws->xq_rows = n_rows;

@@ -86,7 +86,7 @@ static hipError_t regroup_rows(gmmvb_workspace* ws, const void* x_dev, int64_t l
     // M-step of f64 / ragged-D inputs): rebuilt there when needed (recenter_rows), not here - 4 ms and 10 GB at C3
     ws->xc_stale = ws->xc != nullptr;
     if (ws->xq && ws->xq_src == x_dev) {       // the digit planes follow the internal order (3 ms at C3, once or twice per fit)
-        hipError_t eq = launch_x_digits(ws->xp, ws->x_dtype == GMMVB_F64, ws->D, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st, ws->xqn);
+        hipError_t eq = launch_x_digits(ws->xp, ws->x_dtype == GMMVB_F64, ws->D, n_rows, ws->D, ws->pivot, ws->xq, ws->xqe, st);
         if (eq != hipSuccess) return eq;
         ws->xq_gen = ws->pivot_gen;
     }
@@ -271,7 +271,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
     // The stateless sweep (project.h) needs no carried per-pair bounds: the table gmmvb_set_params made for these parameters,
     // the digit planes of this matrix about the pivot in force, regrouped rows and the previous pass's lists.
     const bool can_project = ws->proj_table && ws->gimg != nullptr && ws->sorted && ws->tile_ref_valid && prev_lists &&
-                             ws->xq != nullptr && ws->xqn != nullptr && ws->xq_src == x_dev && ws->xq_rows == n_rows &&
+                             ws->xq != nullptr && ws->xq_src == x_dev && ws->xq_rows == n_rows &&
                              ws->xq_ldx == ldx && ws->xq_gen == ws->pivot_gen && ws->lock != nullptr;
     if (can_prune && big) {
         // sparse enough?  (never for an HMM workspace: forward-backward consumes every emission ln rho)
@@ -603,7 +603,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     // bounds from the table of the parameters in force and the rows' digit planes: nothing carried, nothing
                     // written back (the per-pair array is void afterwards: ws->dense_valid below)
                     note_hip(ws, hipMemsetAsync(ws->exit_ctr + 2, 0, sizeof(unsigned long long), st));
-                    ProjectArgs pa{ws->xq, ws->xqe, ws->xqn, ws->gimg, ws->gconst, ws->tile_ref, ws->lnrho, ws->npad, n_rows, ws->K,
+                    ProjectArgs pa{ws->xq, ws->xqe, ws->gimg, ws->gconst, ws->tile_ref, ws->lnrho, ws->npad, n_rows, ws->K,
                                    ws->D, ws->drift, ws->cvec, ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel,
                                    ws->rec_flags, ws->masks, ws->blk, ws->epart, ws->opart, settle ? ws->lock : nullptr, ws->dlock,
                                    ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr, ws->rblk, ws->opt_proof_all ? 1 : 0,
@@ -639,7 +639,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 if (proof && can_project && !projected) {
                     // the table of the parameters in force first (project.h): a listed pair it clears needs no proof - most of
                     // them are far pairs whose carried bound has eroded to the relevance line
-                    ProjectArgs pa{ws->xq, ws->xqe, ws->xqn, ws->gimg, ws->gconst, ws->tile_ref, ws->lnrho, ws->npad, n_rows, ws->K,
+                    ProjectArgs pa{ws->xq, ws->xqe, ws->gimg, ws->gconst, ws->tile_ref, ws->lnrho, ws->npad, n_rows, ws->K,
                                    ws->D, ws->drift, ws->cvec, ws->rec_k, ws->rec_d, ws->rec_B, ws->rec_exact, ws->rec_sel,
                                    ws->rec_flags, ws->masks, ws->blk, ws->epart, ws->opart, ws->lock, ws->dlock, ws->rthr, ws->lcomp,
                                    ws->rmask, ws->rblk, 0, 0, ws->exit_ctr + 2};

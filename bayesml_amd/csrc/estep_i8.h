@@ -565,16 +565,14 @@ __host__ __device__ constexpr int64_t i8_digit_row_bytes(int t32) { return (int6
 template <typename XT>
 __global__ __launch_bounds__(256) void x_digits_kernel(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int D, int T32,
                                                        const double* __restrict__ pivot, unsigned char* __restrict__ xq,
-                                                       signed char* __restrict__ xqe,
-                                                       float* __restrict__ xqn /*[n_rows] || x - pivot ||^2 rounded down
-                                                                                 (project.h), or null*/) {
+                                                       signed char* __restrict__ xqe) {
     constexpr int ND = kBoundDigits;
     const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     const int g = threadIdx.x & 7;
     const bool in_row = row < n_rows;
     const bool has = in_row && g < 2 * T32;
     double v[16];
-    double mx = 0.0, sq = 0.0;
+    double mx = 0.0;
     bool bad = false;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -583,12 +581,10 @@ __global__ __launch_bounds__(256) void x_digits_kernel(const XT* __restrict__ x,
         const double a = fabs(v[e]);
         bad |= !(a <= 1.7976931348623157e308);
         mx = fmax(mx, a);
-        sq = fma(v[e], v[e], sq);
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
         mx = fmax(mx, __shfl_xor(mx, o));
-        sq += __shfl_xor(sq, o);
         bad |= (bool)__shfl_xor((int)bad, o);
     }
     int en = 0;
@@ -613,10 +609,7 @@ __global__ __launch_bounds__(256) void x_digits_kernel(const XT* __restrict__ x,
         for (int a = 0; a < ND; ++a)
             *reinterpret_cast<i4v*>(dst + a * 32 * T32) = i4v{(int)w[a][0], (int)w[a][1], (int)w[a][2], (int)w[a][3]};
     }
-    if (in_row && g == 0) {
-        xqe[row] = ok ? (signed char)en : kNoDigits;
-        if (xqn) xqn[row] = (ok && sq < 3.0e38) ? __double2float_rd(sq * (1.0 - 1e-12)) : 0.0f;
-    }
+    if (in_row && g == 0) xqe[row] = ok ? (signed char)en : kNoDigits;
 }
 
 // ---- two-sided bounds for listed (sample, component) pairs: the proof round of the pruned E-step ---------------------------

@@ -72,16 +72,16 @@ hipError_t launch_estep_i8_bound(int x_is_f64, bool vec, int tb, int grid, hipSt
 int64_t estep_i8_digit_row_bytes(int D) { return i8_digit_row_bytes(i8_blocks(D)); }
 
 hipError_t launch_x_digits(const void* x, int x_is_f64, int64_t ldx, int64_t n_rows, int D, const double* pivot,
-                           unsigned char* xq, signed char* xqe, hipStream_t st, float* xqn) {
+                           unsigned char* xq, signed char* xqe, hipStream_t st) {
     const int t32 = i8_blocks(D);
     if (t32 < 1 || t32 > 4) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((n_rows + 31) / 32);
     if (x_is_f64)
         hipLaunchKernelGGL(x_digits_kernel<double>, dim3(grid), dim3(256), 0, st, static_cast<const double*>(x), ldx, n_rows, D,
-                           t32, pivot, xq, xqe, xqn);
+                           t32, pivot, xq, xqe);
     else
         hipLaunchKernelGGL(x_digits_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x), ldx, n_rows, D,
-                           t32, pivot, xq, xqe, xqn);
+                           t32, pivot, xq, xqe);
     return hipGetLastError();
 }
 

@@ -46,16 +46,16 @@ hipError_t launch_estep_gather_dev(int T, int x_is_f64, bool vec, int grid, hipS
 // sample digits kept in HBM and the proof round over them (estep_i8.h: x_digits_kernel, estep_i8_proof)
 int64_t estep_i8_digit_row_bytes(int D);
 hipError_t launch_x_digits(const void* x, int x_is_f64, int64_t ldx, int64_t n_rows, int D, const double* pivot,
-                           unsigned char* xq, signed char* xqe, hipStream_t st, float* xqn = nullptr /*|| x - pivot ||^2, rounded down*/);
+                           unsigned char* xq, signed char* xqe, hipStream_t st);
 // the stateless sweep (project.h): table of the K x K reference frames from the parameters in force, the reference of every
 // tile of 256 regrouped rows, and the sweep itself (outputs of rec_sweep_kernel<PREV>)
 int64_t proj_image_len(int K, int D);         // bytes of gimg
 int64_t proj_const_len(int K);                // float4 entries of gconst
-hipError_t launch_proj_table(const double* u, const double* m, const double* cvec, const double* pivot, int K, int D, float* hk,
+hipError_t launch_proj_table(const double* u, const double* m, const double* cvec, const double* pivot, int K, int D,
                              unsigned char* gimg, void* gconst, hipStream_t st);
 hipError_t launch_proj_tile_ref(const int* counts, int K, int64_t n_tiles, int* tile_ref, hipStream_t st);
 struct ProjectArgs {
-    const unsigned char* xq; const signed char* xqe; const float* xqn;
+    const unsigned char* xq; const signed char* xqe;
     const unsigned char* gimg; const void* gconst; const int* tile_ref;
     const double* lnrho; int64_t npad; int64_t n_rows; int K; int D; const double* drift; const double* cvec;
     unsigned short* rec_k; float* rec_d; float* rec_B; unsigned char* rec_exact; unsigned char* rec_sel; unsigned char* rec_flags;

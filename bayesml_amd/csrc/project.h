@@ -4,25 +4,28 @@
 // A tile of 256 rows (= a selection block) of the regrouped row order belongs - apart from the few tiles on a group border -
 // to one dominant component j, the tile's reference.  For ANY reference j and every component k, with dx = x_n - m_j:
 //
-//   || U_k (x_n - m_k) ||^2  =  || U_k dx ||^2  +  2 g_jk . dx  +  s_jk^2,      g_jk = U_k^T U_k (m_j - m_k),  s_jk = || U_k (m_j - m_k) ||
-//                            >=  lmin_k || dx ||^2  +  2 g_jk . dx  +  s_jk^2,   lmin_k <= lambda_min(U_k^T U_k)
+//   || U_k (x_n - m_k) ||^2  =  || U_k dx ||^2  +  2 g_jk . dx  +  s_jk^2   >=   2 g_jk . dx  +  s_jk^2,
+//                                g_jk = U_k^T U_k (m_j - m_k),  s_jk = || U_k (m_j - m_k) ||
 //
-// (an identity, then one inequality: no triangle inequality, the cross term keeps the pair's direction - which is what a
+// (an identity, then the square dropped: no triangle inequality, the cross term keeps the pair's direction - which is what a
 // bound has to know at K = 256, D = 64, where the centre-to-centre distance s_jk - sigma d_j alone leaves a hundred components
-// per row undecided; tools/probe_projection.py).  The K x K table (g_jk as two base-128 int8 digits, s_jk, the constants) is
-// made from the parameters in force by proj_table_kernel - nothing is carried, nothing erodes -, and the row-dependent part
-// is ONE int8 GEMM per tile on the digit planes that the proof round keeps in HBM (estep_i8.h: xq):
+// per row undecided; tools/probe_projection.py).  A first form kept lmin_k || dx ||^2 with a Gershgorin bound of
+// lambda_min(U_k^T U_k): on the fits it is 0 for most components (and 0.01 where it is not) - it bought nothing and cost a
+// kernel and a GEMM column, so it went.  The K x K table (g_jk as two base-128 int8 digits, s_jk, the constants) is made from
+// the parameters in force by proj_table_kernel - nothing is carried, nothing erodes -, and the row-dependent part is ONE int8
+// GEMM per tile on the digit planes that the proof round keeps in HBM (estep_i8.h: xq):
 //
-//   p_nk = g_jk . (x_n - pivot)      [256 rows] x [D] x [K + 1 columns]        v_mfma_i32_32x32x32_i8, three MFMAs per block
-//   column K:  q_n = (m_j - pivot) . (x_n - pivot)   ->   || dx ||^2 = || x_n - pivot ||^2 - 2 q_n + || m_j - pivot ||^2
-//
-//   ln rho_nk  <=  A_jk - p_nk + err_nk - (lmin_k / 2) || dx ||^2,     A_jk = c_k - s_jk^2 / 2 + g_jk . (m_j - pivot)
+//   p_nk = g_jk . (x_n - pivot)      [256 rows] x [D] x [K columns]        v_mfma_i32_32x32x32_i8, three MFMAs per block
+//   ln rho_nk  <=  A_jk - p_nk + err_nk,     A_jk = c_k - s_jk^2 / 2 + g_jk . (m_j - pivot)
 //
 // with every rounding on the safe side (digit truncation, dropped digit class, f32 epilogue; a row or column without digits
-// gives no bound: it never lies).  A pair whose bound lies below the row's relevance threshold is done with; what is left
-// goes the way the carried sweep's candidates went (proof round for settled rows, exact gather for the others).  The kernel
-// has the outputs of rec_sweep_kernel<PREV> (masks, block counts, records, rthr, dlock, proof masks), so the rest of the pass
-// does not change.  The settled rows' own distance bound (dlock) is still carried through (Gamma, delta): one float per row.
+// gives no bound: it never lies).  Two uses (GMMVB_PROJECT, capi_estep.hip):
+//   filter   proj_filter_kernel: the carried sweep (records.h) stays; the pairs it lists for the int8 proof round - most of
+//            them far pairs whose carried bound has eroded - are taken off the lists where the table clears them;
+//   only     rec_project_kernel: the sweep itself is stateless (outputs of rec_sweep_kernel<PREV>); what the table leaves goes
+//            the way the carried sweep's candidates went.  The settled rows' own distance bound (dlock) is still carried
+//            through (Gamma, delta): one float per row.
+// Measured in profiles/r6_experiments.md.
 #pragma once
 #include "rec_common.h"
 
@@ -38,8 +41,8 @@ __host__ __device__ constexpr int proj_blocks(int D) { return (D + 31) / 32; }
 __host__ __device__ constexpr int64_t proj_digit_row_bytes(int t32) { return (int64_t)kProjPlaneDigits * 32 * t32; }
 
 constexpr int kProjDigits = 2;
-// column blocks of 32: the K components and, in column K, the reference's own offset (m_j - pivot)
-__host__ __device__ constexpr int proj_kblocks(int K) { return K / 32 + 1; }
+// column blocks of 32 components
+__host__ __device__ constexpr int proj_kblocks(int K) { return (K + 31) / 32; }
 __host__ __device__ constexpr int64_t proj_image_bytes(int K, int t32) { return (int64_t)proj_kblocks(K) * t32 * kProjDigits * 1024; }
 __host__ __device__ constexpr int proj_tri_len(int D) { return D * (D + 1) / 2; }
 
@@ -69,100 +72,49 @@ __device__ __forceinline__ void proj_reduce(double& a, double& b, double& c, dou
     for (int w = 1; w < 4; ++w) d = (scr[w][3] > d || scr[w][3] != scr[w][3]) ? scr[w][3] : d;
 }
 
-// hk[k] = (1/2) x a lower bound of lambda_min(U_k^T U_k) >= 0, by Gershgorin's circles on the rows of U_k^T U_k (rigorous
-// whatever the matrix; for the sample-covariance-like factors of a fit - identity plus noise of order 1 / sqrt(N_k) per entry -
-// it keeps 0.6 - 0.9 of the true value; 0 = "no help from this term").  One workgroup per component.
-__global__ __launch_bounds__(256) void proj_hk_kernel(const double* __restrict__ u, int K, int D, float* __restrict__ hk) {
-    extern __shared__ double s_tri[];                 // packed lower triangle of U_k: row r at r (r + 1) / 2
-    __shared__ double scr[4][4];
-    const int k = blockIdx.x, tid = threadIdx.x;
-    const double* uk = u + (int64_t)k * D * D;
-    for (int e = tid; e < D * D; e += 256) {
-        const int r = e / D, i = e - r * D;
-        if (i <= r) s_tri[r * (r + 1) / 2 + i] = uk[e];
-    }
-    __syncthreads();
-    // row i of U_k^T U_k, its columns dealt out over 256 / D threads (D <= 128: at least two)
-    __shared__ double s_off[256], s_diag[128];
-    const int parts = 256 / D, i = tid % D, part = tid / D;
-    double offp = 0.0;
-    if (part < parts) {
-        for (int j = part; j < D; j += parts) {
-            const int r0 = i > j ? i : j;
-            double s = 0.0;
-            for (int r = r0; r < D; ++r) s = fma(s_tri[r * (r + 1) / 2 + i], s_tri[r * (r + 1) / 2 + j], s);
-            if (j == i) s_diag[i] = s; else offp += fabs(s);
-        }
-    }
-    s_off[tid] = offp;
-    __syncthreads();
-    double low = __builtin_huge_val(), bad = 0.0, z0 = 0.0, z1 = 0.0;
-    if (tid < D) {
-        double off = 0.0;
-        for (int q = 0; q < parts; ++q) off += s_off[q * D + tid];
-        const double diag = s_diag[tid];
-        const double g = diag - off * (1.0 + 1e-12) - 1e-12 * diag;
-        low = g;
-        if (!(fabs(g) <= 1.7976931348623157e308)) bad = 1.0;
-    }
-    double neg = -low;                                  // (the reduction takes maxima)
-    proj_reduce(bad, z0, z1, neg, scr);
-    if (tid == 0) {
-        const double l = -neg;
-        hk[k] = (bad == 0.0 && l > 0.0) ? __double2float_rd(0.5 * l * (1.0 - 1e-9)) : 0.0f;
-    }
-}
-
-// The table.  Workgroup (k, y): component k (k = K: the offset column) against the references j = y, y + gridDim.y, ...
+// The table.  Workgroup (k, y): component k against the references j = y, y + gridDim.y, ...
 //   gimg   [K][proj_kblocks][T32][2][64 lanes][16]   B operands of v_mfma_i32_32x32x32_i8: lane (c, h) of block (kb, it) holds digit b
 //                                                     of features 32 it + 16 h + (0..15) of column 32 kb + c, for reference j
 //   gconst [K][32 proj_kblocks] float4               x = C = 2^(eg - 19): p^ = 2^en C t for the integer digit sum t = 128 acc0 + acc1
 //                                                     y = E: |p - p^| <= 2^en E   (both truncations, the dropped digit class, f64 rounding of g)
-//                                                     z = hk[k] (column K: || m_j - pivot ||^2 rounded down)
-//                                                     w = A_jk rounded up (+inf: no bound for this column)
+//                                                     z = 0;  w = A_jk rounded up (+inf: no bound for this column)
 __global__ __launch_bounds__(256) void proj_table_kernel(const double* __restrict__ u, const double* __restrict__ m,
                                                          const double* __restrict__ cvec, const double* __restrict__ pivot,
-                                                         const float* __restrict__ hk, int K, int D, int T32,
-                                                         unsigned char* __restrict__ gimg, float4* __restrict__ gconst) {
-    extern __shared__ double s_tri[];
+                                                         int K, int D, int T32, unsigned char* __restrict__ gimg,
+                                                         float4* __restrict__ gconst) {
+    extern __shared__ double s_tri[];                 // packed lower triangle of U_k: row r at r (r + 1) / 2
     __shared__ double s_dm[128], s_v[128], scr[4][4];
     const int k = blockIdx.x, tid = threadIdx.x;
     const int KB = proj_kblocks(K), Dp = 32 * T32;
-    if (k < K) {
+    {
         const double* uk = u + (int64_t)k * D * D;
         for (int e = tid; e < D * D; e += 256) {
             const int r = e / D, i = e - r * D;
             if (i <= r) s_tri[r * (r + 1) / 2 + i] = uk[e];
         }
     }
-    const double ck = k < K ? cvec[k] : 0.0;
-    const float hkk = k < K ? hk[k] : 0.0f;
+    const double ck = cvec[k];
     for (int j = blockIdx.y; j < K; j += gridDim.y) {
         __syncthreads();
         double off_j = 0.0;                               // (m_j - pivot)_i
         if (tid < D) {
             off_j = m[(int64_t)j * D + tid] - pivot[tid];
-            s_dm[tid] = k < K ? m[(int64_t)j * D + tid] - m[(int64_t)k * D + tid] : off_j;
+            s_dm[tid] = m[(int64_t)j * D + tid] - m[(int64_t)k * D + tid];
         }
         __syncthreads();
         double g = 0.0, s2 = 0.0, b = 0.0, babs = 0.0;
-        if (k < K) {
-            if (tid < D) {
-                double v = 0.0;
-                const double* row = s_tri + tid * (tid + 1) / 2;
-                for (int i = 0; i <= tid; ++i) v = fma(row[i], s_dm[i], v);
-                s_v[tid] = v;
-                s2 = v * v;
-            }
-            __syncthreads();
-            if (tid < D) {
-                for (int r = tid; r < D; ++r) g = fma(s_tri[r * (r + 1) / 2 + tid], s_v[r], g);
-                b = g * off_j;
-                babs = fabs(b);
-            }
-        } else if (tid < D) {
-            g = s_dm[tid];
-            s2 = g * g;                                   // || m_j - pivot ||^2
+        if (tid < D) {
+            double v = 0.0;
+            const double* row = s_tri + tid * (tid + 1) / 2;
+            for (int i = 0; i <= tid; ++i) v = fma(row[i], s_dm[i], v);
+            s_v[tid] = v;
+            s2 = v * v;
+        }
+        __syncthreads();
+        if (tid < D) {
+            for (int r = tid; r < D; ++r) g = fma(s_tri[r * (r + 1) / 2 + tid], s_v[r], g);
+            b = g * off_j;
+            babs = fabs(b);
         }
         double gmax = tid < D ? fabs(g) : 0.0;
         proj_reduce(s2, b, babs, gmax, scr);
@@ -191,23 +143,18 @@ __global__ __launch_bounds__(256) void proj_table_kernel(const double* __restric
             // dropped class (|X^| <= 64.5, |dX1| <= 64), 1e-9 x 64.5 D for the f64 rounding of g itself
             const double units = 0.00390625 * (64.5 * Dp + s1) + Dp * 1.52587890625e-05 + 64.0 * s11 * 6.103515625e-05 +
                                  1e-9 * 64.5 * Dp;
+            const double a = ck - 0.5 * s2 + b;
             float4 o;
             o.x = wide ? 0.0f : (float)ldexp(1.0, eg - 19);
             o.y = wide ? 0.0f : __double2float_ru(ldexp(1.0, eg - 12) * units * 1.0001);
-            if (k < K) {
-                const double a = ck - 0.5 * s2 + b;
-                o.z = hkk;
-                o.w = wide ? __builtin_huge_valf() : __double2float_ru(a + 1e-9 * (fabs(ck) + s2 + babs) + 1e-30);
-            } else {
-                o.z = wide ? 0.0f : __double2float_rd(s2 * (1.0 - 1e-9));
-                o.w = wide ? __builtin_huge_valf() : 0.0f;
-            }
+            o.z = 0.0f;
+            o.w = wide ? __builtin_huge_valf() : __double2float_ru(a + 1e-9 * (fabs(ck) + s2 + babs) + 1e-30);
             gconst[(int64_t)j * KB * 32 + k] = o;
         }
     }
-    // columns K + 1 .. 32 KB - 1 of the last block: no component (their image bytes are never written: the buffer is zeroed
-    // once at allocation; their constants say "no bound" and the sweep masks their bits anyway)
-    if (k == K && tid > 0 && K + tid < 32 * KB)
+    // columns K .. 32 KB - 1 of the last block: no component (their image bytes are never written: the buffer is zeroed once at
+    // allocation; their constants say "no bound" and the sweep masks their bits anyway)
+    if (k == 0 && K + tid < 32 * KB)
         for (int j = blockIdx.y; j < K; j += gridDim.y)
             gconst[(int64_t)j * KB * 32 + K + tid] = make_float4(0.0f, 0.0f, 0.0f, __builtin_huge_valf());
 }
@@ -247,13 +194,56 @@ __global__ __launch_bounds__(256) void proj_tile_ref_kernel(const int* __restric
     }
 }
 
+// ---- the GEMM's block and its comparison, shared by the two kernels below ------------------------------------------------------
+// Rows on the MFMA's M axis (A operand: a row's digits, lane (r, h) holds features 32 it + 16 h + (0..15) of row r), components on
+// its N axis (B operand: straight from the reference's image in global memory - 1 KB per wave and load, L2 resident: the
+// tiles of a component follow one another).  Accumulator register g of lane (c, h) is row (g & 3) + 8 (g >> 2) + 4 h of the
+// block, column c: a ballot per register is the word of two rows (low half: h = 0, high half: h = 1) for the block's 32 components.
+template <int T32>
+__device__ __forceinline__ void proj_load_rows(const unsigned char* __restrict__ xq, int64_t row, int h, pj_i4v (&xd)[kProjDigits][T32]) {
+    const unsigned char* xr = xq + row * proj_digit_row_bytes(T32) + 16 * h;
+#pragma unroll
+    for (int a = 0; a < kProjDigits; ++a)
+#pragma unroll
+        for (int it = 0; it < T32; ++it) xd[a][it] = *reinterpret_cast<const pj_i4v*>(xr + a * 32 * T32 + 32 * it);
+}
+template <int T32>
+__device__ __forceinline__ void proj_block(const unsigned char* __restrict__ gimg_j, int kb, int lane,
+                                           const pj_i4v (&xd)[kProjDigits][T32], pj_i16v& acc0, pj_i16v& acc1) {
+    pj_i4v g0[T32], g1[T32];
+    const unsigned char* gp = gimg_j + (int64_t)kb * T32 * kProjDigits * 1024 + lane * 16;
+#pragma unroll
+    for (int it = 0; it < T32; ++it) {
+        g0[it] = *reinterpret_cast<const pj_i4v*>(gp + (it * kProjDigits) * 1024);
+        g1[it] = *reinterpret_cast<const pj_i4v*>(gp + (it * kProjDigits + 1) * 1024);
+    }
+    acc0 = pj_i16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc1 = acc0;
+#pragma unroll
+    for (int it = 0; it < T32; ++it) {
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[0][it], g0[it], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[0][it], g1[it], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[1][it], g0[it], acc1, 0, 0, 0);
+    }
+}
+// |t| = |128 acc0 + acc1| stays below this (digits in [-64.5, 64.5], 32 T32 features, two kept classes)
+template <int T32>
+__device__ __forceinline__ constexpr float proj_tmax() { return 64.5f * 64.5f * 128.0f * (float)(32 * T32) * 1.01f; }
+// not cleared: ln rho_nk <= A - R (C t - E) is not below the row's threshold w, i.e. NOT  R (C t - E) + w > A'  where A' carries
+// 2^-20 of every magnitude that goes into the comparison (two fmas and the conversion of t; NaN: not cleared)
+__device__ __forceinline__ bool proj_left(int a0, int a1, float4 cc, float R, float w, float A) {
+    const float tf = (float)((a0 << 7) + a1);
+    const float v1 = fmaf(cc.x, tf, -cc.y);
+    return !(fmaf(R, v1, w) > A);
+}
+
 // The sweep.  Thread = row before and after the GEMM (like rec_sweep_kernel: reference value, threshold, record, masks);
 // in between wave w takes rows 64 w .. 64 w + 63 of the tile as two blocks of 32 MFMA rows against the tile's image in LDS.
 // Accumulator register g of lane (c, h) is row (g & 3) + 8 (g >> 2) + 4 h of the block, column c: a ballot per register is
 // the candidate word of two rows (low half: h = 0, high half: h = 1) for the block's 32 components.
 template <int T32>
 __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
-    const unsigned char* __restrict__ xq, const signed char* __restrict__ xqe, const float* __restrict__ xqn,
+    const unsigned char* __restrict__ xq, const signed char* __restrict__ xqe,
     const unsigned char* __restrict__ gimg, const float4* __restrict__ gconst, const int* __restrict__ tile_ref,
     const double* __restrict__ u /*ln rho: exact values of the pairs evaluated before the sweep, lower bounds of own pairs*/,
     int64_t npad, int64_t n_rows, int K, const double* __restrict__ drift, const double* __restrict__ c_new, RecArrays rec,
@@ -261,7 +251,6 @@ __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
     unsigned char* __restrict__ lock, float* __restrict__ dlock, float* __restrict__ rthr, const unsigned char* __restrict__ lcomp,
     unsigned long long* __restrict__ pmask, int* __restrict__ pblk, int proof_all, int own_fresh,
     unsigned long long* __restrict__ cand_ctr /*+= pairs the table did not clear (diagnostics), or null*/) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_img[];       // [KB][T32][2][1024]
     __shared__ int wcnt[4][256];
     __shared__ int pcnt[4][256];
     __shared__ float2 sq[256];          // Gamma (1 + 1e-6) up, c' down (settled rows)
@@ -269,7 +258,7 @@ __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
     __shared__ unsigned char sfirst[256];
     __shared__ float s_delta[256];
     __shared__ int wsum[3][4];
-    __shared__ __attribute__((aligned(16))) float s_R[256], s_w[256], s_xn[256], s_e[256];
+    __shared__ __attribute__((aligned(16))) float s_R[256], s_w[256];
     __shared__ unsigned s_m32[256][9];                   // candidate words per row and column block (K <= 256: 8 blocks)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int W = (K + 63) / 64, KB = proj_kblocks(K);
@@ -277,14 +266,6 @@ __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
     const int64_t n = tile0 + tid;
     const bool valid = n < n_rows;
     const int jref = tile_ref[blockIdx.x];
-    // ---- the reference's image -> LDS (LDS-DMA, 1 KB per wave and step) ------------------------------------------------
-    {
-        const int pieces = KB * T32 * kProjDigits;
-        const unsigned char* src = gimg + (int64_t)jref * pieces * 1024 + lane * 16;
-        for (int piece = wave; piece < pieces; piece += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void*)(&s_img[piece * 1024]), 16, 0, 0);
-    }
     // ---- per row: what rec_sweep_kernel<PREV> reads before its first barrier ----------------------------------------------
     unsigned long long fresh[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned lk_pre = 0u;
@@ -302,7 +283,6 @@ __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
         }
     }
     const int en_row = xqe[nn];
-    const float xn_row = xqn[nn];
     for (int k = lane; k < K; k += 64) wcnt[wave][k] = pcnt[wave][k] = 0;
     for (int k = tid; k < K; k += kSelRows) {
         sfirst[k] = (own_fresh && own_first(drift[3 * K + k], drift[K + k])) ? 1 : 0;
@@ -364,32 +344,23 @@ __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
         const float wv = thr_f == thr_f ? thr_f : -__builtin_huge_valf();
         s_R[tid] = valid ? R : 0.0f;
         s_w[tid] = valid ? wv : __builtin_huge_valf();                            // (rows past the end: never a candidate)
-        s_xn[tid] = xn_row;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- the GEMM ----------------------------------------------------------------------------------------------------------
     {
         const int c = lane & 31, h = lane >> 5;
-        const int64_t rbytes = proj_digit_row_bytes(T32);
-        const float tmaxf = 64.5f * 64.5f * 128.0f * (float)(32 * T32) * 1.01f;          // |t| = |128 acc0 + acc1| stays below this
         const float4* gc = gconst + (int64_t)jref * KB * 32;
-        const unsigned img_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)s_img) + lane * 16;
+        const unsigned char* gimg_j = gimg + (int64_t)jref * KB * T32 * kProjDigits * 1024;
         for (int rb = 0; rb < 2; ++rb) {
             const int r0 = 64 * wave + 32 * rb;
             if (tile0 + r0 >= n_rows) break;                                            // (wave uniform)
             int64_t row_a = tile0 + r0 + c;
             if (row_a >= n_rows) row_a = n_rows - 1;
             pj_i4v xd[kProjDigits][T32];
-            {
-                const unsigned char* xr = xq + row_a * rbytes + 16 * h;
-#pragma unroll
-                for (int a = 0; a < kProjDigits; ++a)
-#pragma unroll
-                    for (int it = 0; it < T32; ++it) xd[a][it] = *reinterpret_cast<const pj_i4v*>(xr + a * 32 * T32 + 32 * it);
-            }
+            proj_load_rows<T32>(xq, row_a, h, xd);
             // this lane's sixteen rows: rows r0 + 4 h + 8 q + (0..3), q = 0..3
-            float Rg[16], wg[16], eg[16];
+            float Rg[16], wg[16];
+            float Rm = 0.0f, wm = 0.0f;               // their largest magnitudes, for the f32 slack (NaN / inf rows are candidates anyway)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f4 a = *reinterpret_cast<const f4*>(&s_R[r0 + 4 * h + 8 * q]);
@@ -398,72 +369,18 @@ __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
                 for (int e = 0; e < 4; ++e) {
                     Rg[4 * q + e] = a[e];
                     wg[4 * q + e] = b[e];
+                    Rm = fmaxf(Rm, a[e]);
+                    wm = fmaxf(wm, fabsf(b[e]) < 3.0e38f ? fabsf(b[e]) : 0.0f);
                 }
             }
-            auto block = [&](int kb, pj_i16v& acc0, pj_i16v& acc1) {
-                acc0 = pj_i16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                acc1 = acc0;
-#pragma unroll
-                for (int it = 0; it < T32; ++it) {
-                    pj_i4v g0, g1;
-                    const unsigned at = img_lds + (unsigned)((kb * T32 + it) * kProjDigits) * 1024u;
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(g0) : "v"(at));
-                    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(g1) : "v"(at));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1));
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[0][it], g0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[0][it], g1, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[1][it], g0, acc1, 0, 0, 0);
-                }
-            };
-            // the offset column first: || x - m_j ||^2 of the block's rows (lower bounds) -> s_e
-            {
-                pj_i16v acc0, acc1;
-                block(KB - 1, acc0, acc1);
-                const float4 ce = gc[32 * (KB - 1) + c];
-                if (c == (K & 31)) {
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const int row = r0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                        const float tf = (float)((acc0[g] << 7) + acc1[g]);
-                        const float qhi = Rg[g] * fmaf(ce.x, tf, ce.y);                     // q <= qhi (NaN: no digits)
-                        const float sum = s_xn[row] + ce.z;
-                        const float e = fmaf(-2.0f, qhi, sum);
-                        const float slack = 3.9e-6f * (sum + 2.0f * fabsf(qhi));
-                        const float el = e - slack;
-                        s_e[row] = (ce.w == 0.0f && el > 0.0f) ? el : 0.0f;                   // (NaN -> 0: no help from this term)
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f4 a = *reinterpret_cast<const f4*>(&s_e[r0 + 4 * h + 8 * q]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) eg[4 * q + e] = a[e];
-                }
-            }
-            // the largest magnitudes among this lane's rows, for the f32 slack of the comparison (NaN / inf rows are
-            // candidates whatever the slack)
-            float Rm = 0.0f, wm = 0.0f, em = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                Rm = fmaxf(Rm, Rg[g]);
-                wm = fmaxf(wm, fabsf(wg[g]) < 3.0e38f ? fabsf(wg[g]) : 0.0f);
-                em = fmaxf(em, eg[g]);
-            }
-            for (int kb = 0; kb < KB - 1 || (kb == KB - 1 && (K & 31) != 0); ++kb) {
+            for (int kb = 0; kb < KB; ++kb) {
                 const float4 cc = gc[32 * kb + c];
                 pj_i16v acc0, acc1;
-                block(kb, acc0, acc1);
-                // f32 slack of the comparison: 2^-20 of every magnitude that goes into it (three fmas and the conversion of t)
-                const float mag = Rm * fmaf(cc.x, tmaxf, cc.y) + cc.z * em + wm + fabsf(cc.w);
-                const float A = cc.w + 9.6e-7f * mag;
+                proj_block<T32>(gimg_j, kb, lane, xd, acc0, acc1);
+                const float A = cc.w + 9.6e-7f * (Rm * fmaf(cc.x, proj_tmax<T32>(), cc.y) + wm + fabsf(cc.w));
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const float tf = (float)((acc0[g] << 7) + acc1[g]);
-                    const float v1 = fmaf(cc.x, tf, -cc.y);
-                    const float v2 = fmaf(cc.z, eg[g], wg[g]);
-                    const float v3 = fmaf(Rg[g], v1, v2);
-                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(!(v3 > A));
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(proj_left(acc0[g], acc1[g], cc, Rg[g], wg[g], A));
                     if (bal != 0ull && lane == 0) {
                         const int row = r0 + (g & 3) + 8 * (g >> 2);
                         s_m32[row][kb] = (unsigned)bal;
@@ -599,23 +516,24 @@ __global__ __launch_bounds__(kSelRows) void rec_project_kernel(
     }
 }
 
-// The table as a FILTER in front of the proof round (the default use).  The carried sweep (records.h) has just listed, for the
+// The table as a FILTER in front of the proof round.  The carried sweep (records.h) has just listed, for the
 // int8 proof round, the pairs whose carried bound no longer clears the row's threshold - most of them far pairs whose bound
 // has eroded over the parameter updates.  A pair that the table of the parameters in force clears needs no proof: it is
 // taken off the proof lists (a settled row that loses all its candidates stays settled as it is).  Work only where the
-// sweep left proof pairs: a block of 32 rows x 32 components runs its MFMAs only if it holds one.
+// sweep left proof pairs: a block of 32 rows x 32 components runs its MFMAs only if it holds one.  (Measured and lost,
+// profiles/r6_experiments.md: the image staged in LDS per tile; waves owning column blocks with the tile's digit planes in
+// LDS; a thread per row walking its listed pairs with v_dot4_i32_i8 - scattered 16-byte loads of the g_jk digits per pair.)
 // Reads rthr / flags / pmask as the sweep wrote them (the sweep stores the settled rows' new distance bound in dlock for
 // proof rows too); rewrites pmask, pblk and the flags of rows whose candidates are all gone.
 template <int T32>
 __global__ __launch_bounds__(kSelRows) void proj_filter_kernel(
-    const unsigned char* __restrict__ xq, const signed char* __restrict__ xqe, const float* __restrict__ xqn,
+    const unsigned char* __restrict__ xq, const signed char* __restrict__ xqe,
     const unsigned char* __restrict__ gimg, const float4* __restrict__ gconst, const int* __restrict__ tile_ref, int64_t npad,
     int64_t n_rows, int K, const float* __restrict__ rthr, RecArrays rec, const unsigned long long* __restrict__ masks,
     unsigned long long* __restrict__ pmask, int* __restrict__ pblk, const unsigned char* __restrict__ lcomp,
     unsigned long long* __restrict__ removed_ctr /*+= proof pairs the table made unnecessary, or null*/) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_img[];       // [KB][T32][2][1024]
     __shared__ int pcnt[4][256];
-    __shared__ __attribute__((aligned(16))) float s_R[256], s_w[256], s_xn[256], s_e[256];
+    __shared__ __attribute__((aligned(16))) float s_R[256], s_w[256];
     __shared__ unsigned s_c32[256][9];                   // the sweep's candidates per row and column block
     __shared__ unsigned s_m32[256][9];                   // ... of which the table does not clear
     __shared__ int s_any[4], s_rem[4];
@@ -645,7 +563,6 @@ __global__ __launch_bounds__(kSelRows) void proj_filter_kernel(
         const bool digits = en_row != (int)kProjNoDigits;
         s_R[tid] = (has && digits) ? ldexpf(1.0f, en_row) : (has ? __builtin_nanf("") : 0.0f);
         s_w[tid] = has ? rthr[n] : __builtin_huge_valf();                 // (rows without candidates: cleared whatever comes)
-        s_xn[tid] = xqn[nn];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             s_c32[tid][2 * q] = (unsigned)cand[q];
@@ -662,41 +579,25 @@ __global__ __launch_bounds__(kSelRows) void proj_filter_kernel(
     const bool tile_any = (s_any[0] | s_any[1] | s_any[2] | s_any[3]) != 0;
     if (!tile_any) return;                                   // nothing listed in this tile: pmask / pblk stay as the sweep wrote them
     const int jref = tile_ref[blockIdx.x];
-    {
-        const int pieces = KB * T32 * kProjDigits;
-        const unsigned char* src = gimg + (int64_t)jref * pieces * 1024 + lane * 16;
-        for (int piece = wave; piece < pieces; piece += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void*)(&s_img[piece * 1024]), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     // ---- the GEMM, block by block where the sweep left candidates ----------------------------------------------------------
     {
         const int c = lane & 31, h = lane >> 5;
-        const int64_t rbytes = proj_digit_row_bytes(T32);
-        const float tmaxf = 64.5f * 64.5f * 128.0f * (float)(32 * T32) * 1.01f;
         const float4* gc = gconst + (int64_t)jref * KB * 32;
-        const unsigned img_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)s_img) + lane * 16;
+        const unsigned char* gimg_j = gimg + (int64_t)jref * KB * T32 * kProjDigits * 1024;
         for (int rb = 0; rb < 2; ++rb) {
             const int r0 = 64 * wave + 32 * rb;
             if (tile0 + r0 >= n_rows) break;
             // column blocks in which one of the block's 32 rows has a candidate (lanes c and c + 32 look at row r0 + c)
             unsigned need = 0u;
-            for (int kb = 0; kb < 8; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
                 if (__builtin_amdgcn_ballot_w64(s_c32[r0 + c][kb] != 0u) != 0ull) need |= 1u << kb;
             if (need == 0u) continue;
             int64_t row_a = tile0 + r0 + c;
             if (row_a >= n_rows) row_a = n_rows - 1;
             pj_i4v xd[kProjDigits][T32];
-            {
-                const unsigned char* xr = xq + row_a * rbytes + 16 * h;
-#pragma unroll
-                for (int a = 0; a < kProjDigits; ++a)
-#pragma unroll
-                    for (int it = 0; it < T32; ++it) xd[a][it] = *reinterpret_cast<const pj_i4v*>(xr + a * 32 * T32 + 32 * it);
-            }
-            float Rg[16], wg[16], eg[16];
+            proj_load_rows<T32>(xq, row_a, h, xd);
+            float Rg[16], wg[16];
+            float Rm = 0.0f, wm = 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f4 a = *reinterpret_cast<const f4*>(&s_R[r0 + 4 * h + 8 * q]);
@@ -705,68 +606,19 @@ __global__ __launch_bounds__(kSelRows) void proj_filter_kernel(
                 for (int e = 0; e < 4; ++e) {
                     Rg[4 * q + e] = a[e];
                     wg[4 * q + e] = b[e];
+                    Rm = fmaxf(Rm, a[e]);
+                    wm = fmaxf(wm, fabsf(b[e]) < 3.0e38f ? fabsf(b[e]) : 0.0f);
                 }
             }
-            auto block = [&](int kb, pj_i16v& acc0, pj_i16v& acc1) {
-                acc0 = pj_i16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                acc1 = acc0;
-#pragma unroll
-                for (int it = 0; it < T32; ++it) {
-                    pj_i4v g0, g1;
-                    const unsigned at = img_lds + (unsigned)((kb * T32 + it) * kProjDigits) * 1024u;
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(g0) : "v"(at));
-                    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(g1) : "v"(at));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1));
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[0][it], g0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[0][it], g1, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xd[1][it], g0, acc1, 0, 0, 0);
-                }
-            };
-            {
-                pj_i16v acc0, acc1;
-                block(KB - 1, acc0, acc1);
-                const float4 ce = gc[32 * (KB - 1) + c];
-                if (c == (K & 31)) {
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const int row = r0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                        const float tf = (float)((acc0[g] << 7) + acc1[g]);
-                        const float qhi = Rg[g] * fmaf(ce.x, tf, ce.y);
-                        const float sum = s_xn[row] + ce.z;
-                        const float e = fmaf(-2.0f, qhi, sum);
-                        const float el = e - 3.9e-6f * (sum + 2.0f * fabsf(qhi));
-                        s_e[row] = (ce.w == 0.0f && el > 0.0f) ? el : 0.0f;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f4 a = *reinterpret_cast<const f4*>(&s_e[r0 + 4 * h + 8 * q]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) eg[4 * q + e] = a[e];
-                }
-            }
-            float Rm = 0.0f, wm = 0.0f, em = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                Rm = fmaxf(Rm, Rg[g]);
-                wm = fmaxf(wm, fabsf(wg[g]) < 3.0e38f ? fabsf(wg[g]) : 0.0f);
-                em = fmaxf(em, eg[g]);
-            }
-            for (int kb = 0; kb < 8; ++kb) {
+            for (int kb = 0; kb < KB; ++kb) {
                 if (!((need >> kb) & 1u)) continue;                                       // (wave uniform)
                 const float4 cc = gc[32 * kb + c];
                 pj_i16v acc0, acc1;
-                block(kb, acc0, acc1);
-                const float mag = Rm * fmaf(cc.x, tmaxf, cc.y) + cc.z * em + wm + fabsf(cc.w);
-                const float A = cc.w + 9.6e-7f * mag;
+                proj_block<T32>(gimg_j, kb, lane, xd, acc0, acc1);
+                const float A = cc.w + 9.6e-7f * (Rm * fmaf(cc.x, proj_tmax<T32>(), cc.y) + wm + fabsf(cc.w));
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const float tf = (float)((acc0[g] << 7) + acc1[g]);
-                    const float v1 = fmaf(cc.x, tf, -cc.y);
-                    const float v2 = fmaf(cc.z, eg[g], wg[g]);
-                    const float v3 = fmaf(Rg[g], v1, v2);
-                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(!(v3 > A));
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(proj_left(acc0[g], acc1[g], cc, Rg[g], wg[g], A));
                     if (lane == 0) {
                         const int row = r0 + (g & 3) + 8 * (g >> 2);
                         s_m32[row][kb] = (unsigned)bal;

@@ -206,9 +206,7 @@ struct gmmvb_workspace {
     // planes about the pivot in force, a drift hint for the settled rows' own bound), tile_ref by the regrouping.
     unsigned char* gimg = nullptr;     // [K][proj_image_bytes] int8 digit images of g_jk, per reference component j
     void* gconst = nullptr;            // [K][32 proj_kblocks] float4 constants per (reference, column)
-    float* hk = nullptr;               // [K] half a lower bound of lambda_min(U_k^T U_k)
     int* tile_ref = nullptr;           // [blocks] reference component of every tile of kSelRows rows (regrouped order)
-    float* xqn = nullptr;              // [npad] || x - pivot ||^2 rounded down, made with the digit planes
     int opt_project = 0;               // env GMMVB_PROJECT: "filter" (1) the table filters the carried sweep's proof lists, "only" (2)
                                        // the sweep itself is stateless (rec_project_kernel); default 0: no table (it does not
                                        // pay on the benchmark's fits, profiles/r6_experiments.md)
