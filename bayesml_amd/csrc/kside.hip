@@ -283,6 +283,10 @@ struct PostView {
 };
 constexpr int kPartials = 12;      // per component: p_x, p_z, (a0-1)E[ln pi], p_mu_lambda, h, lgamma(a), (a-1)psi(a), a, q_mu_lambda
 
+// (lgamma out of line: inlined into kside_step_kernel<1024> - 128 registers per lane at sixteen waves - the library routine's
+// temporaries pushed 67 registers of the factorisation's loops into scratch)
+__device__ __attribute__((noinline)) double lgamma_call(double x) { return lgamma(x); }
+
 // psi(x), x > 0: recurrence up to x >= 10, then the asymptotic series to x^-14 (remainder < 2e-16 there)
 __device__ inline double digamma_pos(double x) {
     double r = 0.0;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView 
         pt[3] = 0.5 * (D * (log(kap0) - LN_2PI - kap0 / kapq) - kap0 * acc[2] + 2.0 * pr.ln_b_w_nu[k] +
                        (nu0 - D) * eldq - acc[3]);                                                             // p_mu_lambda
         pt[4] = h;                                                                                             // -> q_z
-        pt[5] = lgamma(alq);
+        pt[5] = lgamma_call(alq);
         pt[6] = (alq - 1.0) * digamma_pos(alq);
         pt[7] = alq;
         pt[8] = 0.5 * (D * (1.0 + LN_2PI - log(kapq)) - 2.0 * q.ln_b_w_nu[k] - (nuq - D) * eldq + nuq * D);    // q_mu_lambda
@@ -423,14 +427,20 @@ __global__ __launch_bounds__(NT) void kside_step_kernel(int K, int D, PriorView 
     for (int d = tid; d < D; d += NT) {
         f[0] += log(mat[d * ld + d]);
         f[1] += digamma_pos(0.5 * (nun - d));
-        f[2] += lgamma(0.5 * (nun - d));
+        f[2] += lgamma_call(0.5 * (nun - d));
     }
-    block_sum_n<3, NT>(f, red);
+    // (sum of the new alphas over ALL components with the block, K / NT terms per thread: one thread walking K dependent
+    // global loads was 40 us of this kernel at K = 64 and most of it at K = 256 - round 6)
+    double f4[4] = {f[0], f[1], f[2], 0.0};
+    for (int c = tid; c < K; c += NT) f4[3] += pr.alpha[c] + stats[c];
+    block_sum_n<4, NT>(f4, red);
+    f[0] = f4[0];
+    f[1] = f4[1];
+    f[2] = f4[2];
     const double logdet = 2.0 * f[0];
     const double eld = f[1] + D * LN_2 - logdet;
     if (tid == 0) {
-        double asum = 0.0;
-        for (int c = 0; c < K; ++c) asum += pr.alpha[c] + stats[c];
+        const double asum = f4[3];
         const double elp = digamma_pos(aln) - digamma_pos(asum);
         qn.e_ln_pi[k] = elp;
         qn.e_ln_lambda_det[k] = eld;
