@@ -326,7 +326,12 @@ static __global__ __launch_bounds__(kSelRows) void fill_lists_kernel(const unsig
                                                               int64_t n_rows, int K, const int* __restrict__ blk_base,
                                                               int* __restrict__ lists, int64_t cap,
                                                               unsigned char* __restrict__ lock = nullptr,
-                                                              const unsigned char* __restrict__ lcomp = nullptr) {
+                                                              const unsigned char* __restrict__ lcomp = nullptr,
+                                                              const double* __restrict__ block_total = nullptr
+                                                              /*[blocks] bits set in this block's masks, if the producer counted
+                                                                them: a block without any has nothing to fill (round 6: most
+                                                                blocks of a converged pass - settled rows - are such)*/) {
+    if (block_total != nullptr && block_total[blockIdx.x] == 0.0) return;
     __shared__ int wcnt[4][256];
     const int64_t n = (int64_t)blockIdx.x * kSelRows + threadIdx.x;
     const bool valid = n < n_rows;

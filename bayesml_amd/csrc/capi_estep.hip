@@ -112,7 +112,7 @@ static hipError_t launch_bound_pass(gmmvb_workspace* ws, const EstepI8Args& a8, 
 
 // masks -> per-component lists -> chunk plan -> exact f64 evaluation of the listed pairs (all sized on the device)
 static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int is64, bool vec, int sel_grid, hipStream_t st,
-                                   const float* thr = nullptr) {
+                                   const float* thr = nullptr, const double* block_total = nullptr /*listed pairs per block, if counted*/) {
     if (thr) {
         hipError_t em = hipMemsetAsync(ws->exit_ctr, 0, sizeof(unsigned long long), st);
         if (em != hipSuccess) return em;
@@ -120,7 +120,7 @@ static hipError_t lists_and_gather(gmmvb_workspace* ws, const EstepArgs& a, int 
     span_begin(ws, kSpanSelect, st);
     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, a.n_rows, ws->K, ws->blk,
-                       ws->lists, ws->npad);
+                       ws->lists, ws->npad, nullptr, nullptr, block_total);
     hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
                        estep_gather_rows_per_wg(ws->T, is64), ws->plan);
     hipError_t e = hipGetLastError();
@@ -542,7 +542,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 // goes to the exact gather
                 launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
                 hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
-                                   ws->blk, ws->lists, ws->npad);
+                                   ws->blk, ws->lists, ws->npad, nullptr, nullptr, ws->epart);
                 span_end(ws, st);
                 span_begin(ws, kSpanProof, st);
                 e = proof_round(ws, st, ws->blk, sel_grid, n_rows, ws->ub32);
@@ -568,8 +568,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanSelect, st);
                 if (!ws->active_lists) {        // (the M-step's lists left out the rows in its cache)
                     launch_scan_counts(st, ws->blk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+                    // (gpart: the listed pairs rec_finish_kernel counted per block when it wrote these masks)
                     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->masks, ws->npad, n_rows, ws->K,
-                                       ws->blk, ws->lists, ws->npad);
+                                       ws->blk, ws->lists, ws->npad, nullptr, nullptr, ws->prev_pass != 0 ? ws->gpart : nullptr);
                 }
                 hipLaunchKernelGGL(gather_plan_kernel, dim3(1), dim3(64), 0, st, ws->counts, ws->K,
                                    estep_gather_rows_per_wg(ws->T, is64), ws->plan);
@@ -591,7 +592,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                                        ws->npad, n_rows, ws->K, ws->rmask, ws->rblk, ws->drift, ws->spart);
                     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
                     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
-                                       ws->K, ws->rblk, ws->lists, ws->npad);
+                                       ws->K, ws->rblk, ws->lists, ws->npad, nullptr, nullptr, ws->spart);
                     span_end(ws, st);
                     span_begin(ws, kSpanProof, st);
                     e = proof_round(ws, st, ws->rblk, sel_grid, n_rows, nullptr);
@@ -621,7 +622,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                        ws->npad, n_rows, ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart,            \
                        ws->opart, settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp,                                 \
                        proof ? ws->rmask : nullptr, ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0, ws->tmeta,         \
-                       tmeta_was_valid ? 0 : 1, ws->exit_ctr + 1)
+                       tmeta_was_valid ? 0 : 1, ws->exit_ctr + 1, ws->ppart)
                     switch ((ws->K + 63) / 64) {        // (mask words as a compile-time constant)
                         case 1: GMMVB_LAZY_SWEEP(1); break;
                         case 2: GMMVB_LAZY_SWEEP(2); break;
@@ -634,7 +635,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     hipLaunchKernelGGL(rec_sweep_kernel<true>, dim3(sel_grid), dim3(kSelRows), 0, st, ws->ub32, ws->lnrho, ws->npad,
                                        n_rows, ws->K, ws->drift, ws->cvec, ws->khat, rec, ws->masks, ws->blk, ws->epart, ws->opart,
                                        settle ? ws->lock : nullptr, ws->dlock, ws->rthr, ws->lcomp, proof ? ws->rmask : nullptr,
-                                       ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0, nullptr, 0);
+                                       ws->rblk, ws->opt_proof_all ? 1 : 0, own_round ? 1 : 0, nullptr, 0, nullptr, ws->ppart);
                 }
                 if (proof && can_project && !projected) {
                     // the table of the parameters in force first (project.h): a listed pair it clears needs no proof - most of
@@ -653,8 +654,9 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                     // get two-sided bounds from three int8 digits; rows that are proven stay settled, the others join
                     // the pass's lists (records.h)
                     launch_scan_counts(st, ws->rblk, sel_grid, ws->K, ws->counts, ws->scan_parts);
+                    // (ppart: the proof pairs the sweep listed per block; rec_proof_decide_kernel overwrites it afterwards)
                     hipLaunchKernelGGL(fill_lists_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, ws->rmask, ws->npad, n_rows,
-                                       ws->K, ws->rblk, ws->lists, ws->npad);
+                                       ws->K, ws->rblk, ws->lists, ws->npad, nullptr, nullptr, projected ? nullptr : ws->ppart);
                     span_end(ws, st);
                     span_begin(ws, kSpanProof, st);
                     e = proof_round(ws, st, ws->rblk, sel_grid, n_rows, ws->ub32);
@@ -683,7 +685,7 @@ int gmmvb_estep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             ws->sweep_prev = prev_lists;
         }
         // candidates: a pair whose first output blocks already put it below the row's threshold is not evaluated further
-        e = lists_and_gather(ws, a, is64, vec, sel_grid, st, ws->gather_exit ? ws->rthr : nullptr);
+        e = lists_and_gather(ws, a, is64, vec, sel_grid, st, ws->gather_exit ? ws->rthr : nullptr, ws->epart);
         if (e != hipSuccess) return fail(GMMVB_EHIP, "E-step candidate evaluation", e);
         span_begin(ws, kSpanLse, st);
         hipLaunchKernelGGL(rec_finish_kernel, dim3(sel_grid), dim3(kSelRows), 0, st, rec, ws->lnrho, ws->npad, n_rows, ws->K,

@@ -177,8 +177,9 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
             // cache of settled rows - before the pass's own lists are built in the same buffers
             span_begin(ws, kSpanLists, st);
             launch_scan_counts(st, ws->dblk, nblk, ws->K, ws->counts, ws->scan_parts);
+            // (qpart: the delta and M-step pairs rec_finish_kernel counted per block - none of either: nothing to fill)
             hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->dmask, ws->npad, n_rows, ws->K,
-                               ws->dblk, ws->lists, ws->npad, ws->lock, ws->lcomp);
+                               ws->dblk, ws->lists, ws->npad, ws->lock, ws->lcomp, ws->e_state == 1 ? ws->qpart : nullptr);
             span_end(ws, st);
             MstepListArgs ld = la0;
             ld.direct_r = 3;
@@ -208,7 +209,7 @@ int gmmvb_mstep(gmmvb_workspace* ws, const void* x_dev, int64_t ldx, int64_t n_r
                 span_begin(ws, kSpanLists, st);
                 launch_scan_counts(st, ws->mblk, nblk, ws->K, ws->counts, ws->scan_parts);
                 hipLaunchKernelGGL(fill_lists_kernel, dim3(nblk), dim3(kSelRows), 0, st, ws->mmask, ws->npad, n_rows, ws->K,
-                                   ws->mblk, ws->lists, ws->npad);
+                                   ws->mblk, ws->lists, ws->npad, nullptr, nullptr, ws->e_state == 1 ? ws->qpart : nullptr);
                 e = hipGetLastError();
                 span_end(ws, st);
                 if (e != hipSuccess) return fail(GMMVB_EHIP, "active-sample lists", e);

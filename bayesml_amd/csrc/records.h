@@ -354,7 +354,9 @@ __global__ __launch_bounds__(kSelRows, (LAZY && WC >= 3 ? 5 : 1)) void rec_sweep
                                                                              settled rows' own pairs (own_first components)*/,
                                                              float4* __restrict__ tmeta = nullptr /*LAZY: [tiles][K]*/,
                                                              int tmeta_reset = 0 /*LAZY: the stored tile state is void*/,
-                                                             unsigned long long* __restrict__ col_ctr = nullptr /*LAZY: += columns opened*/) {
+                                                             unsigned long long* __restrict__ col_ctr = nullptr /*LAZY: += columns opened*/,
+                                                             double* __restrict__ ppre = nullptr /*[blocks] pairs listed for the proof
+                                                                 round (fill_lists_kernel skips the blocks without any)*/) {
     static_assert(!LAZY || PREV, "the lazy sweep is a form of the PREV sweep");
     __shared__ int wcnt[4][256];
     __shared__ int pcnt[4][256];
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(kSelRows, (LAZY && WC >= 3 ? 5 : 1)) void rec_sweep
     __shared__ double sc[256];
     __shared__ unsigned char sfirst[256];
     __shared__ float s_delta[256];      // this pass's delta, rounded up
-    __shared__ int wsum[2][4];
+    __shared__ int wsum[3][4];
     __shared__ unsigned char s_force[LAZY ? 256 : 1];      // a row of the tile holds an exact value in this column
     __shared__ float s_thr[LAZY ? 4 : 1];                  // per wave: lowest threshold of its rows
     __shared__ unsigned long long s_open[LAZY ? 4 : 1];    // columns the tile's rows go through
@@ -748,18 +750,22 @@ __global__ __launch_bounds__(kSelRows, (LAZY && WC >= 3 ? 5 : 1)) void rec_sweep
         }
         }
     }
+    int plisted = 0;
     for (int w = 0; w < W; ++w) {
         count_word(mk[w], w, wave, wcnt);
         if (pmask) count_word(pm[w], w, wave, pcnt);
+        plisted += __builtin_popcountll(pm[w]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         listed += __shfl_xor(listed, o);
         over_i += __shfl_xor(over_i, o);
+        plisted += __shfl_xor(plisted, o);
     }
     if (lane == 0) {
         wsum[0][wave] = listed;
         wsum[1][wave] = over_i;
+        wsum[2][wave] = plisted;
     }
     if constexpr (LAZY) {
         if (lane == 0)
@@ -802,6 +808,7 @@ __global__ __launch_bounds__(kSelRows, (LAZY && WC >= 3 ? 5 : 1)) void rec_sweep
     if (tid == 0) {
         epart[blockIdx.x] = (double)(wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
         opart[blockIdx.x] = (double)(wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3]);
+        if (ppre) ppre[blockIdx.x] = (double)(wsum[2][0] + wsum[2][1] + wsum[2][2] + wsum[2][3]);
     }
 }
 
