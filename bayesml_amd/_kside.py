@@ -18,6 +18,8 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 
+import numpy as np
+
 import torch
 
 LN_2PI = math.log(2.0 * math.pi)
@@ -91,6 +93,8 @@ def niw_features(q):
         from ._engine import kside_factor
         g, g_inv, logdet = kside_factor(q.w_inv)
     else:
+        # (CPU tensors, and the GPU past 128 features - orders at which tools/probe_torch_linalg.py found the framework's
+        # batched routines sound; see spd_inverse for the one at which they are not)
         g, _info = torch.linalg.cholesky_ex(q.w_inv)          # NaNs propagate instead of raising, like inv()
         eye = torch.eye(D, dtype=q.w_inv.dtype, device=q.w_inv.device).expand(K, D, D)
         g_inv = torch.linalg.solve_triangular(g, eye, upper=False)
@@ -105,14 +109,36 @@ def niw_features(q):
     return q
 
 
+def spd_inverse(w, device):
+    """(W^-1 symmetrised, ln det W^-1) of a batch of symmetric positive definite matrices ``w`` (array-like ``[K, D, D]``)
+    as float64 tensors on ``device``.
+
+    On the GPU up to D = 128 this is the library's own LDS-resident factorisation (W = G G^T, W^-1 = G^-T G^-1,
+    csrc/kside.hip), elsewhere numpy on the host - never the framework's batched GPU inverse: on this image
+    ``torch.linalg.inv`` and ``torch.linalg.solve_triangular`` return wrong entries (an O(1) error in the last diagonal
+    element of some matrices, different from run to run) for batches of 24 or more 65 x 65 float64 matrices
+    (tools/probe_torch_linalg.py maps the orders 2..260; found by tools/fuzz_sparse.py in round 6, where it made fits
+    with c_degree = 65 irreproducible)."""
+    dev = torch.device(device)
+    D = int(np.shape(w)[-1])
+    if dev.type == "cuda" and D <= 128:
+        from ._engine import kside_factor
+        _g, g_inv, logdet_w = kside_factor(torch.as_tensor(w, dtype=torch.float64, device=dev).clone())
+        w_inv = g_inv.transpose(1, 2) @ g_inv
+        return 0.5 * (w_inv + w_inv.transpose(1, 2)), -logdet_w
+    host = np.asarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else w, dtype=np.float64)
+    w_inv = np.linalg.inv(host)
+    w_inv = 0.5 * (w_inv + np.swapaxes(w_inv, 1, 2))
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)             # noqa: E731
+    return t(w_inv), t(-np.linalg.slogdet(host)[1])
+
+
 def prior_from_numpy(alpha, m, kappa, nu, w, device) -> PriorT:
     t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=device).clone()   # noqa: E731
-    alpha, m, kappa, nu, w = t(alpha), t(m), t(kappa), t(nu), t(w)
+    alpha, m, kappa, nu = t(alpha), t(m), t(kappa), t(nu)
     D = m.shape[1]
-    w_inv = torch.linalg.inv(w)
-    w_inv = 0.5 * (w_inv + w_inv.transpose(1, 2))
+    w_inv, logdet_w_inv = spd_inverse(w, device)
     ln_c = float(torch.lgamma(alpha.sum()) - torch.lgamma(alpha).sum())
-    logdet_w_inv = -torch.linalg.slogdet(w)[1]
     return PriorT(alpha, m, kappa, nu, w_inv, ln_c, ln_wishart_b(logdet_w_inv, nu, D))
 
 
@@ -295,12 +321,11 @@ def hmm_features(q: HmmPostT) -> HmmPostT:
 
 def hmm_prior_from_numpy(eta, zeta, m, kappa, nu, w, device) -> HmmPriorT:
     t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=device).clone()   # noqa: E731
-    eta, zeta, m, kappa, nu, w = t(eta), t(zeta), t(m), t(kappa), t(nu), t(w)
+    eta, zeta, m, kappa, nu = t(eta), t(zeta), t(m), t(kappa), t(nu)
     D = m.shape[1]
-    w_inv = torch.linalg.inv(w)
-    w_inv = 0.5 * (w_inv + w_inv.transpose(1, 2))
+    w_inv, logdet_w_inv = spd_inverse(w, device)
     return HmmPriorT(eta, zeta, m, kappa, nu, w_inv, float(torch.lgamma(eta.sum()) - torch.lgamma(eta).sum()),
-                     float(_ln_c_rows(zeta)), ln_wishart_b(-torch.linalg.slogdet(w)[1], nu, D))
+                     float(_ln_c_rows(zeta)), ln_wishart_b(logdet_w_inv, nu, D))
 
 
 def hmm_post_from_prior(p: HmmPriorT) -> HmmPostT:

@@ -872,6 +872,8 @@ static __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecAr
                         if (b[q] >= 0 && !((double)uf[q] < thr)) kept[w] |= 1ull << b[q];      // also NaN
                 }
             }
+            unsigned long long done[4] = {0ull, 0ull, 0ull, 0ull};          // done with, and without a slot
+            for (int w = 0; w < W; ++w) done[w] = pmask[(int64_t)w * npad + n] & ~kept[w];
 #pragma unroll
             for (int j = 0; j < kRecSlots; ++j) {
                 const unsigned short k = rec.k[(int64_t)j * rec.npad + n];
@@ -879,11 +881,24 @@ static __global__ __launch_bounds__(kSelRows) void rec_proof_decide_kernel(RecAr
                 if (((kept[k >> 6] >> (k & 63)) & 1ull) && !((sel >> j) & 1u)) {
                     sel |= 1u << j;
                     ++in_slots;
-                } else if ((pmask[(int64_t)(k >> 6) * npad + n] >> (k & 63)) & 1ull) {
+                } else if ((done[k >> 6] >> (k & 63)) & 1ull) {
                     // done with by its fresh bound: the slot takes it over (tighter than the carried one)
                     rec.d[(int64_t)j * rec.npad + n] = dist_lower_f32(cvec[k], (double)ub32[(int64_t)k * npad + n]);
+                    done[k >> 6] &= ~(1ull << (k & 63));
                 }
             }
+            // ... without one it belongs to the rest, whose bound need not cover it yet: when the ninth largest key of the
+            // sweep was an exact pair, B is the largest bound among the pairs that were NOT candidates (restmax)
+            float done_max = -__builtin_huge_valf();
+            for (int w = 0; w < W; ++w) {
+                unsigned long long m = done[w];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    done_max = fmaxf(done_max, ub32[(int64_t)(64 * w + b) * npad + n]);
+                }
+            }
+            if (done_max > rec.B[n]) rec.B[n] = done_max;
             for (int w = 0; w < W; ++w) {
                 mk[w] |= kept[w];
                 total += __builtin_popcountll(mk[w]);

@@ -165,3 +165,31 @@ def test_component_below_the_relevance_line_is_pinned():
     orc.update_q_mu_lambda(p, q_zero, st0)
     for a, b in ((q_ref.m, q_zero.m), (q_ref.w_inv, q_zero.w_inv), (q_ref.kappa, q_zero.kappa), (q_ref.nu, q_zero.nu)):
         assert np.max(np.abs(a - b)) <= 1e-15 * np.max(np.abs(a))
+
+
+@pytest.mark.parametrize("K,D,N,dtype", [(24, 65, 513, np.float32), (64, 65, 2049, np.float64)])
+def test_degree_65_fit_is_reproducible_and_follows_the_oracle(K, D, N, dtype):
+    """A fit at c_degree = 65 (one feature in the fifth tile) with enough components to reach the batch sizes at which
+    this image's batched GPU inverse is unsound: two runs agree bit for bit and the posterior follows the oracle's.
+    Found by tools/fuzz_sparse.py (round 6): the prior's W^-1 had come from torch.linalg.inv."""
+    from bayesml_amd import gaussianmixture as gm
+    x = orc.synth_gmm(K, D, N, dtype, seed=826, spread=0.6)
+    runs = []
+    for _ in range(2):
+        m = gm.LearnModel(K, D, seed=826, device="cuda:0", verbose=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.update_posterior(x, max_itr=4, num_init=1, tolerance=0.0)
+        runs.append((m.get_hn_params(), np.array(m.hn_w_mats_inv)))
+        m._engine.close()
+    for key in runs[0][0]:
+        assert np.array_equal(runs[0][0][key], runs[1][0][key]), key
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.update_posterior(x.astype(np.float64), orc.Prior.default(K, D), orc.Posterior.from_prior(orc.Prior.default(K, D)),
+                                   np.random.default_rng(826), max_itr=4, num_init=1, tolerance=0.0)
+    hn = runs[0][0]
+    for key, val in (("hn_alpha_vec", ref.posterior.alpha), ("hn_m_vecs", ref.posterior.m), ("hn_kappas", ref.posterior.kappa),
+                     ("hn_nus", ref.posterior.nu), ("hn_w_mats", ref.posterior.w)):
+        assert rel_err(hn[key], val) < 1e-8, key
+    assert rel_err(runs[0][1], ref.posterior.w_inv) < 1e-9

@@ -104,3 +104,23 @@ def test_factor_and_drift_kernels_against_linalg():
     assert bool(torch.all(big >= sv[:, 0])) and bool(torch.all(big <= 1.05 * sv[:, 0]))
     dd = torch.linalg.vector_norm((q[1].u @ (q[1].m - q[0].m)[:, :, None])[:, :, 0], dim=1)
     assert bool(torch.all(d >= dd)) and bool(torch.all(d <= dd * (1 + 1e-6) + 1e-12))
+
+
+@pytest.mark.parametrize("K,D", [(24, 65), (64, 65), (64, 128), (5, 129), (3, 200)])
+def test_prior_inverse_never_uses_the_frameworks_batched_inverse(K, D):
+    """_kside.spd_inverse against numpy, repeatedly.  Order 65 with 24 or more matrices is where this image's
+    torch.linalg.inv / solve_triangular return an O(1) error in a last diagonal element, differently from run to run
+    (tools/probe_torch_linalg.py): with it the prior's W^-1 - and every posterior built on it - was wrong for c_degree = 65."""
+    from bayesml_amd import _kside
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(K * 1000 + D)
+    a = rng.standard_normal((K, D, D)) * 0.05
+    for w in (np.broadcast_to(np.eye(D), (K, D, D)).copy(), np.eye(D)[None] + a @ a.transpose(0, 2, 1)):
+        want, want_ld = np.linalg.inv(w), -np.linalg.slogdet(w)[1]
+        for _ in range(6):
+            got, ld = _kside.spd_inverse(w, dev)
+            assert float(np.abs(got.cpu().numpy() - want).max()) < 1e-12
+            assert float(np.abs(ld.cpu().numpy() - want_ld).max()) < 1e-10
+            assert torch.equal(got, got.transpose(1, 2))
+        p = _kside.prior_from_numpy(np.ones(K), np.zeros((K, D)), np.ones(K), np.full(K, float(D)), w, dev)
+        assert float(np.abs(p.w_inv.cpu().numpy() - want).max()) < 1e-12
