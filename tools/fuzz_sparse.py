@@ -26,16 +26,26 @@ VARIANTS = (("dense", dict(GMMVB_ESTEP_PRUNE="0", GMMVB_MSTEP_SPARSE="0")), ("fo
             ("default", {}))
 
 
-def fit(x, K, iters, env, seed):
+def random_prior(K, D, seed):
+    """Non-default hyper-parameters (h0_alpha_vec, h0_m_vecs, h0_kappas, h0_nus, h0_w_mats) for a case."""
+    rng = np.random.default_rng(seed + 77)
+    a = rng.standard_normal((K, D, D)) * (0.3 / np.sqrt(D))
+    w = np.eye(D)[None] * rng.uniform(0.5, 2.0, (K, 1, 1)) + a @ a.transpose(0, 2, 1)
+    return dict(h0_alpha_vec=rng.uniform(0.2, 3.0, K), h0_m_vecs=rng.standard_normal((K, D)) * 0.5, h0_kappas=rng.uniform(0.2, 3.0, K),
+                h0_nus=D - 1 + rng.uniform(0.1, 4.0, K), h0_w_mats=0.5 * (w + w.transpose(0, 2, 1)))
+
+
+def fit(x, K, iters, env, seed, num_init=1, prior=False):
     import torch
     from bayesml_amd import gaussianmixture as gm
     old = {k: os.environ.pop(k, None) for k in KEYS}
     os.environ.update(env)
     try:
-        m = gm.LearnModel(K, x.shape[1], seed=seed, device=torch.device("cuda", 0), verbose=False)
+        m = gm.LearnModel(K, x.shape[1], seed=seed, device=torch.device("cuda", 0), verbose=False,
+                          **(random_prior(K, x.shape[1], seed) if prior else {}))
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            m.update_posterior(x, max_itr=iters, num_init=1, tolerance=0.0)
+            m.update_posterior(x, max_itr=iters, num_init=num_init, tolerance=0.0)
     finally:
         for k in KEYS:
             os.environ.pop(k, None)
@@ -61,6 +71,10 @@ def draw_case(rng):
         case["weights_alpha"] = 0.3
     if rng.random() < 0.25:
         case["scale_range"] = (0.3, 3.0)
+    if rng.random() < 0.3:
+        case["num_init"] = 2
+    if rng.random() < 0.3:
+        case["prior"] = True
     return case
 
 
@@ -68,26 +82,24 @@ def rel(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)) / max(1e-300, float(np.max(np.abs(b)))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=60)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
-    a = ap.parse_args()
+def run(cases, seed, seconds=1e9, emit=print, max_pairs=6e6):
+    """`cases` random cases from `seed`; returns (cases run, the flagged lines).  tests/test_gpu_fuzz.py runs a few."""
     from oracle import gmm_vb_oracle as orc
-    rng = np.random.default_rng(a.seed)
-    t0, flagged = time.time(), 0
-    for i in range(a.cases):
-        if time.time() - t0 > a.seconds:
+    rng = np.random.default_rng(seed)
+    t0, flagged, i = time.time(), [], -1
+    for i in range(cases):
+        if time.time() - t0 > seconds:
             break
         c = draw_case(rng)
+        if c["K"] * c["N"] > max_pairs:
+            c["N"] = int(max_pairs // c["K"])
         x = orc.synth_gmm(c["K_data"], c["D"], c["N"], np.dtype(c["dtype"]), seed=c["seed"], spread=c["spread"],
                           weights_alpha=c.get("weights_alpha"), scale_range=c.get("scale_range"))
         try:
-            res = {tag: fit(x, c["K"], c["iters"], env, c["seed"]) for tag, env in VARIANTS}
+            res = {tag: fit(x, c["K"], c["iters"], env, c["seed"], c.get("num_init", 1), c.get("prior", False)) for tag, env in VARIANTS}
         except Exception as e:                                         # noqa: BLE001  (the case is the finding)
-            flagged += 1
-            print(json.dumps(dict(case=c, error=repr(e)[:400])), flush=True)
+            flagged.append(dict(case=c, error=repr(e)[:400]))
+            emit(json.dumps(flagged[-1]))
             continue
         d = res["dense"]
         line = dict(case=c)
@@ -107,10 +119,21 @@ def main():
                              pruned=float(f"{1.0 - same.mean():.3f}"), vl=float(f"{abs(s['vl'] - d['vl']) / abs(d['vl']):.1e}"),
                              info=s["info"][:90])
             bad |= hn > 1e-8 or dr > 1e-7 or not bound_ok or not np.isfinite(hn)
-        line["flag"] = bad
-        flagged += bad
-        print(json.dumps(line), flush=True)
-    print(json.dumps(dict(cases=i + 1, flagged=flagged, seconds=round(time.time() - t0, 1))), flush=True)
+        line["flag"] = bool(bad)
+        if bad:
+            flagged.append(line)
+        emit(json.dumps(line))
+    emit(json.dumps(dict(cases=i + 1, flagged=len(flagged), seconds=round(time.time() - t0, 1))))
+    return i + 1, flagged
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
+    a = ap.parse_args()
+    run(a.cases, a.seed, a.seconds, emit=lambda t: print(t, flush=True))
     return 0
 
 
