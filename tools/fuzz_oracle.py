@@ -80,6 +80,24 @@ def gmm_case(rng, dev):
              nu=rel(hn["hn_nus"], q.nu), w=rel(hn["hn_w_mats"], q.w), vl=rel(m.vl, ref.vl),
              r=float(np.nanmax(np.abs(m.r_vecs - ref.stats.r))), ns=rel(m.ns, ref.stats.ns))
     info = getattr(m._engine, "launch_info", "small_fit") if m._engine is not None else "small_fit"
+    # read-outs under the posterior the MODEL holds (no trajectory in between): latent variables of fresh rows, both
+    # losses (ref:1178-1193), and the predictive parameters (ref:1064-1070)
+    if not any(np.isnan(v).any() for v in hn.values()):
+        own = orc.Posterior(alpha=hn["hn_alpha_vec"].copy(), m=hn["hn_m_vecs"].copy(), kappa=hn["hn_kappas"].copy(),
+                            nu=hn["hn_nus"].copy(), w=hn["hn_w_mats"].copy(), w_inv=np.array(m.hn_w_mats_inv))
+        own.refresh_pi()
+        own.refresh_lambda()
+        xs = orc.synth_gmm(c["K_data"], D, int(rng.choice([1, 7, 64, 300])), np.dtype(c["dtype"]), seed=c["seed"] + 1, spread=c["spread"])
+        want = orc.estimate_latent_vars(xs.astype(np.float64), own, "squared")
+        got = m.estimate_latent_vars(xs, loss="squared")
+        d["latent_sq"] = float(np.max(np.abs(got - want)))
+        top2 = np.sort(want, axis=1)[:, -2:] if K > 1 else np.stack([np.zeros(len(want)), np.ones(len(want))], 1)
+        clear = top2[:, 1] - top2[:, 0] > 1e-6                # (a tie within rounding may go either way)
+        z = m.estimate_latent_vars(xs, loss="0-1")
+        d["latent_01"] = float(np.mean(z.argmax(axis=1)[clear] != want.argmax(axis=1)[clear])) if clear.any() else 0.0
+        m.calc_pred_dist()
+        pp, wp = m.get_p_params(), orc.predictive_params(own)
+        d["pred"] = max(rel(pp[k], wp[k]) for k in pp)
     if m._engine is not None:
         m._engine.close()
     return c, d, str(info)[:70]
@@ -110,6 +128,18 @@ def hmm_case(rng, dev):
     d = dict(eta=rel(hn["hn_eta_vec"], q.eta), zeta=rel(hn["hn_zeta_vecs"], q.zeta), m=rel(hn["hn_m_vecs"], q.m),
              kappa=rel(hn["hn_kappas"], q.kappa), nu=rel(hn["hn_nus"], q.nu), w=rel(hn["hn_w_mats"], q.w), vl=rel(m.vl, ref.vl))
     info = str(getattr(m._engine, "launch_info", ""))[:70]
+    # read-outs under the posterior the MODEL holds: Viterbi path and marginals of a fresh sequence (ref:1425-1499)
+    if not any(np.isnan(v).any() for v in hn.values()):
+        own = orc.HmmPosterior(hn["hn_eta_vec"].copy(), hn["hn_zeta_vecs"].copy(), hn["hn_m_vecs"].copy(), hn["hn_kappas"].copy(),
+                               hn["hn_nus"].copy(), hn["hn_w_mats"].copy(), np.array(m.hn_w_mats_inv)).refresh()
+        xs = orc.synth_hmm(max(1, min(K, 8)), D, int(rng.choice([2, 65, 300, 1500])), np.dtype(c["dtype"]), seed=c["seed"] + 1, stay=c["stay"])[0]
+        with np.errstate(all="ignore"):
+            st = orc.data_pass(xs.astype(np.float64), own)
+            path = orc.viterbi(xs.astype(np.float64), own)
+        if not np.isnan(st.gamma).any():
+            d["gamma"] = float(np.max(np.abs(m.estimate_latent_vars(xs, loss="squared", viterbi=False) - st.gamma)))
+        got = m.estimate_latent_vars(xs, loss="0-1", viterbi=True)
+        d["viterbi"] = float(np.mean(got.argmax(axis=1) != path.argmax(axis=1)))
     if m._engine is not None:
         m._engine.close()
     return c, d, info
@@ -154,14 +184,20 @@ def run(cases, seed, seconds=1e9, models=("gmm", "hmm", "mvn"), emit=print):
             flagged.append(dict(model=name, draw=i, error=repr(e)[:500]))
             emit(json.dumps(flagged[-1]))
             continue
-        worst = max(v for k, v in d.items() if k != "r")
+        soft = ("r", "latent_sq", "latent_01", "gamma", "viterbi")
+        worst = max(v for k, v in d.items() if k not in soft)
         # an oracle NaN is the reference's own behaviour on that input (e.g. exp(ln rho) underflowing for every state of a
         # step, _hiddenmarkovnormal.py:993): reported, not flagged; a device NaN where the oracle has numbers is
         # (fewer rows than a few times c_degree: rank-deficient scatter matrices, |ln rho| of 1e4 and more - rounding
         # differences of the two formulations reach the responsibilities)
         thin = c["N"] < 4 * c["D"]
         tol, tol_r = (1e-4, 1e-2) if thin else (1e-6, 1e-5)
+        if c["N"] < 16:       # a handful of rows: the subsampling initialisation inverts a rank-one scatter plus 1e-5 I
+            tol = tol_r = 10.0   # (ref:792-794; condition 1e10 and more) - the trajectory is rounding noise on both sides
         bad = (not NAN["ref"]) and (not np.isfinite(worst) or worst > tol or d.get("r", 0.0) > tol_r or NAN["dev"])
+        # the read-outs start from the same posterior on both sides: tight whatever the sample was like (a Viterbi path may
+        # part at an exact tie of two states; more than one step in a hundred is not that)
+        bad = bad or d.get("latent_sq", 0.0) > 1e-7 or d.get("latent_01", 0.0) > 0.0 or d.get("gamma", 0.0) > 1e-7 or d.get("viterbi", 0.0) > 0.01
         oracle_nan += NAN["ref"]
         line = dict(case=c, diff={k: float(f"{v:.1e}") for k, v in d.items()}, info=info, oracle_nan=NAN["ref"],
                     device_nan=NAN["dev"], flag=bool(bad))
