@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """[developer tool, GPU box] Random small fits through the public classes against the CPU oracle:
-python tools/fuzz_oracle.py [--cases 60] [--seed 1] [--models gmm,hmm,mvn]
+python tools/fuzz_oracle.py [--cases 60] [--seed 1] [--models gmm,hmm,mvn[,hmm_long]]
 
 Every case draws a model (Gaussian mixture, hidden Markov normal, single Gaussian), a shape (any c_degree up to 260, any
 K the engine takes, row counts around the kernels' granules), a storage dtype, a prior (the defaults or random
@@ -103,15 +103,23 @@ def gmm_case(rng, dev):
     return c, d, str(info)[:70]
 
 
-def hmm_case(rng, dev):
+def hmm_case(rng, dev, long=False):
     from oracle import hmm_vb_oracle as orc
     from bayesml_amd import hiddenmarkovnormal as hm
     K, D, N = draw_shape(rng, True)
     N = max(N, 2)
+    if long:          # sequences past 2^15 / 2^16 steps: the chunked forward-backward, forgetting and Viterbi-coalescence paths
+        K = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 32, 33, 64]))
+        D = int(rng.choice([1, 2, 3, 8, 15, 16, 17, 32]))
+        N = int(rng.choice([32_768, 40_000, 65_536, 70_001, 131_077]))
+        if K > 32:
+            N = min(N, 40_000)
     default = bool(rng.random() < 0.5)
     c = dict(model="hmm", K=K, D=D, N=N, dtype=str(rng.choice(["float32", "float64"])), default_prior=default,
              init=str(rng.choice(["subsampling", "subsampling", "random_responsibility"])), num_init=int(rng.integers(1, 3)),
              iters=int(rng.integers(1, 6)), seed=int(rng.integers(0, 1000)), stay=float(rng.choice([0.9, 0.5, 0.99])))
+    if long:                                            # (the host oracle walks every step in Python)
+        c["num_init"], c["iters"] = 1, min(c["iters"], 3)
     x = orc.synth_hmm(max(1, min(K, 8)), D, N, np.dtype(c["dtype"]), seed=c["seed"], stay=c["stay"])[0]
     pr = random_niw(rng, K, D, default)
     eta = np.full(K, 0.5) if default else rng.uniform(0.2, 3.0, K)
@@ -132,7 +140,8 @@ def hmm_case(rng, dev):
     if not any(np.isnan(v).any() for v in hn.values()):
         own = orc.HmmPosterior(hn["hn_eta_vec"].copy(), hn["hn_zeta_vecs"].copy(), hn["hn_m_vecs"].copy(), hn["hn_kappas"].copy(),
                                hn["hn_nus"].copy(), hn["hn_w_mats"].copy(), np.array(m.hn_w_mats_inv)).refresh()
-        xs = orc.synth_hmm(max(1, min(K, 8)), D, int(rng.choice([2, 65, 300, 1500])), np.dtype(c["dtype"]), seed=c["seed"] + 1, stay=c["stay"])[0]
+        xs = orc.synth_hmm(max(1, min(K, 8)), D, int(rng.choice([2, 65, 300, 1500] if not long else [66_000, 70_001])), np.dtype(c["dtype"]),
+                           seed=c["seed"] + 1, stay=c["stay"])[0]
         with np.errstate(all="ignore"):
             st = orc.data_pass(xs.astype(np.float64), own)
             path = orc.viterbi(xs.astype(np.float64), own)
@@ -168,7 +177,7 @@ def run(cases, seed, seconds=1e9, models=("gmm", "hmm", "mvn"), emit=print):
     import torch
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(seed)
-    fns = {"gmm": gmm_case, "hmm": hmm_case, "mvn": mvn_case}
+    fns = {"gmm": gmm_case, "hmm": hmm_case, "mvn": mvn_case, "hmm_long": lambda r, d: hmm_case(r, d, long=True)}
     t0, flagged, n, oracle_nan = time.time(), [], 0, 0
     for i in range(cases):
         if time.time() - t0 > seconds:

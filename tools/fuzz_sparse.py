@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GMMVB_DEBUG", "1")
 
-KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE")
+KEYS = ("GMMVB_ESTEP_PRUNE", "GMMVB_MSTEP_SPARSE", "BAYESML_AMD_TILE_ROWS", "BAYESML_AMD_TILE_RESIDENT")
 VARIANTS = (("dense", dict(GMMVB_ESTEP_PRUNE="0", GMMVB_MSTEP_SPARSE="0")), ("forced", dict(GMMVB_ESTEP_PRUNE="force")),
             ("default", {}))
 
@@ -75,6 +75,9 @@ def draw_case(rng):
         case["num_init"] = 2
     if rng.random() < 0.3:
         case["prior"] = True
+    if rng.random() < 0.35 and case["N"] > 600:
+        case["tile_rows"] = int(rng.choice([256, 320, 1000, 4096, 10_000, case["N"] // 2 + 1, case["N"] - 1]))
+        case["tile_resident"] = int(rng.integers(0, 2))
     return case
 
 
@@ -95,8 +98,11 @@ def run(cases, seed, seconds=1e9, emit=print, max_pairs=6e6):
             c["N"] = int(max_pairs // c["K"])
         x = orc.synth_gmm(c["K_data"], c["D"], c["N"], np.dtype(c["dtype"]), seed=c["seed"], spread=c["spread"],
                           weights_alpha=c.get("weights_alpha"), scale_range=c.get("scale_range"))
+        variants = list(VARIANTS)
+        if "tile_rows" in c:      # the same fit through row tiles (resident workspaces per tile, or one workspace for all)
+            variants.append(("tiled", dict(BAYESML_AMD_TILE_ROWS=str(c["tile_rows"]), BAYESML_AMD_TILE_RESIDENT=str(c["tile_resident"]))))
         try:
-            res = {tag: fit(x, c["K"], c["iters"], env, c["seed"], c.get("num_init", 1), c.get("prior", False)) for tag, env in VARIANTS}
+            res = {tag: fit(x, c["K"], c["iters"], env, c["seed"], c.get("num_init", 1), c.get("prior", False)) for tag, env in variants}
         except Exception as e:                                         # noqa: BLE001  (the case is the finding)
             flagged.append(dict(case=c, error=repr(e)[:400]))
             emit(json.dumps(flagged[-1]))
@@ -104,7 +110,7 @@ def run(cases, seed, seconds=1e9, emit=print, max_pairs=6e6):
         d = res["dense"]
         line = dict(case=c)
         bad = False
-        for tag in ("forced", "default"):
+        for tag in [t for t in ("forced", "default", "tiled") if t in res]:
             s = res[tag]
             hn = max(rel(s["hn"][k], d["hn"][k]) for k in d["hn"])
             dr = float(np.max(np.abs(s["r"] - d["r"])))
