@@ -402,6 +402,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
 
+    hide_stdout()
     import torch
     import torch.distributed as dist
     from bayesml_amd import RowShard
@@ -888,6 +889,25 @@ def build_roofline(eng, K, D, dt, n_local, steps, warmup, step_ms, ker, spans, l
     return roof, groups, fl_pair, timed_counts
 
 
+_STDOUT_FD = None
+
+
+def hide_stdout():
+    """The JSON line must be the only thing on stdout, and libraries print there from C (RCCL's version banner, gloo's
+    "connected to peer ranks" lines): file descriptor 1 points at stderr until emit() writes the line."""
+    global _STDOUT_FD
+    if _STDOUT_FD is None:
+        sys.stdout.flush()
+        _STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def show_stdout(on):
+    if _STDOUT_FD is not None:
+        flush_c_stdio()
+        os.dup2(_STDOUT_FD if on else 2, 1)
+
+
 def flush_c_stdio():
     try:
         import ctypes
@@ -959,7 +979,9 @@ def emit(out, args):
     """Full record to the detail file, the compact line - and nothing else - on stdout."""
     line = compact_line(out)
     if args.detail == "-":
+        show_stdout(True)
         print(json.dumps(out), flush=True)
+        show_stdout(False)
     elif args.detail:
         try:
             os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
@@ -975,8 +997,9 @@ def emit(out, args):
         text = json.dumps(line)
         if len(text) < 6000:
             break
-    flush_c_stdio()
+    show_stdout(True)
     print(text, flush=True)
+    show_stdout(False)
 
 
 def dense_leg_run(w, K, D, n_local, fl_pair):
