@@ -85,7 +85,7 @@ def rel(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)) / max(1e-300, float(np.max(np.abs(b)))))
 
 
-def run(cases, seed, seconds=1e9, emit=print, max_pairs=6e6):
+def run(cases, seed, seconds=1e9, emit=print, max_pairs=6e6, scale=1):
     """`cases` random cases from `seed`; returns (cases run, the flagged lines).  tests/test_gpu_fuzz.py runs a few."""
     from oracle import gmm_vb_oracle as orc
     rng = np.random.default_rng(seed)
@@ -94,6 +94,7 @@ def run(cases, seed, seconds=1e9, emit=print, max_pairs=6e6):
         if time.time() - t0 > seconds:
             break
         c = draw_case(rng)
+        c["N"] *= scale                     # (--scale: the same draws with more rows, for the many-tile machinery)
         if c["K"] * c["N"] > max_pairs:
             c["N"] = int(max_pairs // c["K"])
         x = orc.synth_gmm(c["K_data"], c["D"], c["N"], np.dtype(c["dtype"]), seed=c["seed"], spread=c["spread"],
@@ -138,8 +139,10 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
+    ap.add_argument("--scale", type=int, default=1, help="multiply every case's row count")
+    ap.add_argument("--max-pairs", type=float, default=6e6, help="cap on rows x components of a case")
     a = ap.parse_args()
-    run(a.cases, a.seed, a.seconds, emit=lambda t: print(t, flush=True))
+    run(a.cases, a.seed, a.seconds, emit=lambda t: print(t, flush=True), max_pairs=a.max_pairs, scale=a.scale)
     return 0
 
 
