@@ -14,11 +14,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [12])
 def test_pruned_pass_equals_dense_on_random_shapes(seed):
     import fuzz_sparse
     lines = []
-    n, flagged = fuzz_sparse.run(10, seed, seconds=120, emit=lines.append, max_pairs=2e6)
+    n, flagged = fuzz_sparse.run(10, seed, seconds=90, emit=lines.append, max_pairs=2e6)
     assert n >= 6, lines[-1]
     assert not flagged, flagged
 

@@ -39,7 +39,7 @@ def _random_stats(K, D, n, rng, dev, dead=()):
     ns = r.sum(0)
     h = np.where(r > 0, r * np.log(np.where(r > 0, r, 1.0)), 0.0).sum(0)
     a = r.T @ x
-    B = np.einsum("nk,ni,nj->kij", r, x, x)
+    B = np.stack([(x * r[:, k, None]).T @ x for k in range(K)])       # (einsum "nk,ni,nj->kij" takes a minute at K = 256)
     B = 0.5 * (B + B.transpose(0, 2, 1))
     return torch.from_numpy(np.concatenate([ns, h, a.ravel(), B.ravel()])).to(dev)
 
