@@ -117,7 +117,7 @@ def spd_inverse(w, device):
     csrc/kside.hip), elsewhere numpy on the host - never the framework's batched GPU inverse: on this image
     ``torch.linalg.inv`` and ``torch.linalg.solve_triangular`` return wrong entries (an O(1) error in the last diagonal
     element of some matrices, different from run to run) for batches of 24 or more 65 x 65 float64 matrices
-    (tools/probe_torch_linalg.py maps the orders 2..260; found by tools/fuzz_sparse.py in round 6, where it made fits
+    (tools/probe_torch_linalg.py maps the orders 2..260; found by tests/fuzz_sparse.py in round 6, where it made fits
     with c_degree = 65 irreproducible)."""
     dev = torch.device(device)
     D = int(np.shape(w)[-1])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""[developer tool, GPU box] One case of tools/fuzz_sparse.py again, iteration by iteration: python tools/fuzz_case.py '<case json>'
+"""[test utility, run by hand on a GPU box] One case of tests/fuzz_sparse.py again, iteration by iteration: python tests/fuzz_case.py '<case json>'
 prints, for max_itr = 1..iters (or, with a second argument <iters>, for that max_itr under each developer switch), the pruned pairs whose reported bound is not an upper bound of the dense ln rho or is not
 below the relevance line."""
 import json
@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np                                   # noqa: E402
 import fuzz_sparse as fz                             # noqa: E402
 from oracle import gmm_vb_oracle as orc              # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""[developer tool, GPU box] Random small fits through the public classes against the CPU oracle:
-python tools/fuzz_oracle.py [--cases 60] [--seed 1] [--models gmm,hmm,mvn[,hmm_long]]
+"""[test utility, run by hand on a GPU box] Random small fits through the public classes against the CPU oracle:
+python tests/fuzz_oracle.py [--cases 60] [--seed 1] [--models gmm,hmm,mvn[,hmm_long]]
 
 Every case draws a model (Gaussian mixture, hidden Markov normal, single Gaussian), a shape (any c_degree up to 260, any
 K the engine takes, row counts around the kernels' granules), a storage dtype, a prior (the defaults or random

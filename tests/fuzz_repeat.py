@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""[developer tool, GPU box] Run one fuzz case's variant several times and compare the runs with each other (determinism):
-python tools/fuzz_repeat.py '<case json>' <variant> <iters> [repeats]"""
+"""[test utility, run by hand on a GPU box] Run one fuzz case's variant several times and compare the runs with each other (determinism):
+python tests/fuzz_repeat.py '<case json>' <variant> <iters> [repeats]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np                                   # noqa: E402
 import fuzz_sparse as fz                             # noqa: E402
 from oracle import gmm_vb_oracle as orc              # noqa: E402

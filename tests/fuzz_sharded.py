@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""[developer tool, GPU box] Random row-sharded fits: python tools/fuzz_sharded.py [--cases 16] [--seed 1] [--world 3]
+"""[test utility, run by hand on a GPU box] Random row-sharded fits: python tests/fuzz_sharded.py [--cases 16] [--seed 1] [--world 3]
 
 `world` processes share cuda:0 and exchange the statistics block over gloo (RCCL wants a device per rank; the collective
 is the same torch.distributed.all_reduce call bench.py issues over "nccl").  Every case draws a shape, a data recipe,

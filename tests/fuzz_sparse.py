@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""[developer tool, GPU box] Random-shape stress of the pruned data pass: python tools/fuzz_sparse.py [--cases 60] [--seed 1]
+"""[test utility, run by hand on a GPU box] Random-shape stress of the pruned data pass: python tests/fuzz_sparse.py [--cases 60] [--seed 1]
 
 Every case draws a shape (K, D, N, dtype), a data recipe (cluster spread, unequal weights, anisotropic scales, fewer true
 clusters than components) and an iteration count, fits it three times through the public driver - dense kernels only,

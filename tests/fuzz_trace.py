@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""[developer tool, GPU box] Where do two runs of the same fit part?  python tools/fuzz_trace.py '<case json>' <variant> <iters>
+"""[test utility, run by hand on a GPU box] Where do two runs of the same fit part?  python tests/fuzz_trace.py '<case json>' <variant> <iters>
 Records, after every K-side step of two identical fits, the statistics block the data pass produced and the next
 posterior's fields, and prints the first quantities that differ between the runs."""
 import json
@@ -9,7 +9,7 @@ import warnings
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np                                   # noqa: E402
 import torch                                         # noqa: E402
 import fuzz_sparse as fz                             # noqa: E402

@@ -171,7 +171,7 @@ def test_component_below_the_relevance_line_is_pinned():
 def test_degree_65_fit_is_reproducible_and_follows_the_oracle(K, D, N, dtype):
     """A fit at c_degree = 65 (one feature in the fifth tile) with enough components to reach the batch sizes at which
     this image's batched GPU inverse is unsound: two runs agree bit for bit and the posterior follows the oracle's.
-    Found by tools/fuzz_sparse.py (round 6): the prior's W^-1 had come from torch.linalg.inv."""
+    Found by tests/fuzz_sparse.py (round 6): the prior's W^-1 had come from torch.linalg.inv."""
     from bayesml_amd import gaussianmixture as gm
     x = orc.synth_gmm(K, D, N, dtype, seed=826, spread=0.6)
     runs = []

@@ -1,15 +1,15 @@
-"""A slice of the random-shape stress tools (tools/fuzz_sparse.py, tools/fuzz_oracle.py) with fixed seeds, so that every
+"""A slice of the random-shape stress tools (tests/fuzz_sparse.py, tests/fuzz_oracle.py) with fixed seeds, so that every
 GPU run of the suite repeats it: the pruned data pass against the dense kernels through the public driver (ragged shapes,
 overlapping / unequal / anisotropic clusters, restarts, random priors), and the three public classes against the CPU
 oracle (any c_degree up to 260, row counts around the kernels' granules, both initialisations).  Round 6: the tools found
 a rest bound that did not cover proof-cleared candidates without a slot, and this image's batched GPU inverse returning
-wrong entries at order 65 (bayesml_amd/_kside.py spd_inverse).  Run by hand for more: python tools/fuzz_sparse.py --seed N."""
+wrong entries at order 65 (bayesml_amd/_kside.py spd_inverse).  Run by hand for more: python tests/fuzz_sparse.py --seed N."""
 import os
 import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
