@@ -485,3 +485,40 @@ def test_wire_block_packs_the_upper_triangles():
     _kside.stats_triangle(True, K, D, lop, wire)
     _kside.stats_triangle(False, K, D, wire, back)
     assert torch.equal(back, full)
+
+
+def test_factorisation_outside_the_library_kernel_is_verified(monkeypatch):
+    """_kside._factor_checked (CPU tensors, GPU past 128 features): a wrong entry from the framework's batched triangular
+    solve - what this image's GPU routines return at order 65 - is caught by the residual check and redone on the host;
+    NaN inputs still propagate.  Also _kside.spd_inverse on the host path."""
+    import torch
+    from bayesml_amd import _kside
+    rng = np.random.default_rng(5)
+    K, D = 5, 37
+    a = rng.standard_normal((K, D, D))
+    w_inv = a @ a.transpose(0, 2, 1) + D * np.eye(D)
+    t = torch.as_tensor(w_inv)
+    want_g = np.linalg.cholesky(w_inv)
+    g, g_inv, logdet = _kside._factor_checked(t)
+    assert np.abs(g.numpy() - want_g).max() < 1e-12 and np.abs(g_inv.numpy() - np.linalg.inv(want_g)).max() < 1e-12
+    assert np.abs(logdet.numpy() - np.linalg.slogdet(w_inv)[1]).max() < 1e-11
+    real = torch.linalg.solve_triangular
+
+    def broken(*args, **kw):
+        out = real(*args, **kw).clone()
+        out[2, D - 1, D - 1] = 0.0           # "an O(1) error in a last diagonal element"
+        return out
+
+    monkeypatch.setattr(torch.linalg, "solve_triangular", broken)
+    g2, g_inv2, _ = _kside._factor_checked(t)
+    assert np.abs(g_inv2.numpy() - np.linalg.inv(want_g)).max() < 1e-12
+    bad = t.clone()
+    bad[1, 3, 3] = float("nan")
+    g3, g_inv3, _ = _kside._factor_checked(bad)
+    assert torch.isnan(g3[1]).any() and not torch.isnan(g3[0]).any()
+    monkeypatch.undo()
+    w = np.linalg.inv(w_inv)
+    got, ld = _kside.spd_inverse(w, "cpu")
+    assert np.abs(got.numpy() - w_inv).max() < 1e-9 * np.abs(w_inv).max() and np.abs(ld.numpy() + np.linalg.slogdet(w)[1]).max() < 1e-10
+    p = _kside.prior_from_numpy(np.ones(K), np.zeros((K, D)), np.ones(K), np.full(K, float(D)), w, "cpu")
+    assert torch.equal(p.w_inv, got)
