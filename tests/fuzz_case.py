@@ -22,7 +22,7 @@ runs = [(i, {}) for i in range(1, c["iters"] + 1)] if len(sys.argv) < 3 else [(i
 for iters, sw in runs:
     os.environ.update(sw)
     other = os.environ.get("FUZZ_VARIANT", "forced")            # or "default"
-    res = {tag: fz.fit(x, c["K"], iters, env, c["seed"], c.get("num_init", 1), c.get("prior", False)) for tag, env in fz.VARIANTS if tag in ("dense", other)}
+    res = {tag: fz.fit(x, c["K"], iters, env, c["seed"], c.get("num_init", 1), c.get("prior", False), c.get("init", "subsampling")) for tag, env in fz.VARIANTS if tag in ("dense", other)}
     res["forced"] = res[other]
     for k in sw:
         os.environ.pop(k)

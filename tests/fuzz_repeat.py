@@ -18,7 +18,7 @@ iters = int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 x = orc.synth_gmm(c["K_data"], c["D"], c["N"], np.dtype(c["dtype"]), seed=c["seed"], spread=c["spread"],
                   weights_alpha=c.get("weights_alpha"), scale_range=c.get("scale_range"))
-runs = [fz.fit(x, c["K"], iters, env, c["seed"], c.get("num_init", 1), c.get("prior", False)) for _ in range(reps)]
+runs = [fz.fit(x, c["K"], iters, env, c["seed"], c.get("num_init", 1), c.get("prior", False), c.get("init", "subsampling")) for _ in range(reps)]
 a = runs[0]
 for i, b in enumerate(runs[1:], 1):
     print("run", i, "vs 0:", {k: float(f"{fz.rel(b['hn'][k], a['hn'][k]):.1e}") for k in a["hn"]},

@@ -35,7 +35,7 @@ def random_prior(K, D, seed):
                 h0_nus=D - 1 + rng.uniform(0.1, 4.0, K), h0_w_mats=0.5 * (w + w.transpose(0, 2, 1)))
 
 
-def fit(x, K, iters, env, seed, num_init=1, prior=False):
+def fit(x, K, iters, env, seed, num_init=1, prior=False, init="subsampling"):
     import torch
     from bayesml_amd import gaussianmixture as gm
     old = {k: os.environ.pop(k, None) for k in KEYS}
@@ -45,7 +45,7 @@ def fit(x, K, iters, env, seed, num_init=1, prior=False):
                           **(random_prior(K, x.shape[1], seed) if prior else {}))
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            m.update_posterior(x, max_itr=iters, num_init=num_init, tolerance=0.0)
+            m.update_posterior(x, max_itr=iters, num_init=num_init, tolerance=0.0, init_type=init)
     finally:
         for k in KEYS:
             os.environ.pop(k, None)
@@ -75,6 +75,8 @@ def draw_case(rng):
         case["num_init"] = 2
     if rng.random() < 0.3:
         case["prior"] = True
+    if rng.random() < 0.2:
+        case["init"] = "random_responsibility"
     if rng.random() < 0.35 and case["N"] > 600:
         case["tile_rows"] = int(rng.choice([256, 320, 1000, 4096, 10_000, case["N"] // 2 + 1, case["N"] - 1]))
         case["tile_resident"] = int(rng.integers(0, 2))
@@ -103,7 +105,8 @@ def run(cases, seed, seconds=1e9, emit=print, max_pairs=6e6, scale=1):
         if "tile_rows" in c:      # the same fit through row tiles (resident workspaces per tile, or one workspace for all)
             variants.append(("tiled", dict(BAYESML_AMD_TILE_ROWS=str(c["tile_rows"]), BAYESML_AMD_TILE_RESIDENT=str(c["tile_resident"]))))
         try:
-            res = {tag: fit(x, c["K"], c["iters"], env, c["seed"], c.get("num_init", 1), c.get("prior", False)) for tag, env in variants}
+            res = {tag: fit(x, c["K"], c["iters"], env, c["seed"], c.get("num_init", 1), c.get("prior", False), c.get("init", "subsampling"))
+                   for tag, env in variants}
         except Exception as e:                                         # noqa: BLE001  (the case is the finding)
             flagged.append(dict(case=c, error=repr(e)[:400]))
             emit(json.dumps(flagged[-1]))
