@@ -77,3 +77,16 @@ def test_a_dying_rank_takes_the_others_down(tmp_path):
     while time.time() < end and any(_alive(p) for p in pids):
         time.sleep(0.1)
     assert not any(_alive(p) for p in pids)
+
+
+def test_stdout_carries_nothing_but_the_line():
+    """bench.hide_stdout / show_stdout: what libraries write to file descriptor 1 from C (RCCL's banner, gloo's connection
+    lines) goes to stderr; only what is printed between show_stdout(True) and show_stdout(False) reaches stdout."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "bench.hide_stdout(); os.write(1, b'library noise\\n')\n"
+            "bench.show_stdout(True); print('{\"metric\": 1}', flush=True); bench.show_stdout(False)\n"
+            "os.write(1, b'more noise\\n')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": 1}\n'
+    assert "library noise" in r.stderr and "more noise" in r.stderr
