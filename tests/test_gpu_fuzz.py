@@ -8,6 +8,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  (the first import of a fresh box takes a minute: outside the cases' time limits)
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
